@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by importing the upstream reference (read-only) on CPU.
+
+Run in the build container only (needs /root/reference):
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Everything written under tests/golden/ is DATA (inputs + expected outputs as .npz);
+no reference source text is stored.  Weights of whole networks are NOT stored: they are
+re-created on the test machine by recipe (torch.manual_seed(s) + the construction order
+documented in SURVEY.md §8a3, bit-identical to the reference's default init).
+
+Reference call sites exercised (file:line in /root/reference):
+  models/unet.py:5-17   BasicConv2d   (conv3x3+BN+ReLU, train and eval)
+  models/unet.py:19-32  UpSample2d    (bilinear x2 align_corners + BasicConv2d)
+  models/unet.py:92     MaxPool2d(2,2)
+  models/unet.py:120-124 F.pad + torch.cat
+  models/unet.py:94-156 UNet.forward
+  models/segnet.py:79-80,82-119 SegNet pool-with-indices / unpool / forward
+  train.py:105,130-131  CrossEntropyLoss + backward
+  train.py:100-134      AdamW + OneCycleLR trajectory
+  utils.py:162-190      intersect_and_union
+"""
+import os, sys, json
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+REF = "/root/reference"
+sys.path.insert(0, REF)
+from models.unet import UNet, BasicConv2d, UpSample2d   # noqa: E402
+from models.segnet import SegNet, BasicConv              # noqa: E402
+import utils as ref_utils                                # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(8)
+torch.backends.mkldnn.enabled = True
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()   # copy: state_dict buffers alias live tensors
+
+
+def rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def save(name, **kw):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+# ---------------------------------------------------------------- per-op: BasicConv2d
+def gold_basicconv():
+    cases = [  # (cin, cout, N, H, W, seed)
+        (5, 7, 2, 9, 11, 11),
+        (3, 64, 2, 8, 10, 12),
+        (64, 12, 1, 6, 10, 13),
+        (8, 8, 2, 4, 4, 14),
+        (128, 64, 1, 5, 7, 15),
+        (16, 32, 3, 13, 3, 16),
+    ]
+    for (ci, co, n, h, w, seed) in cases:
+        torch.manual_seed(seed)
+        m = BasicConv2d(ci, co)
+        # non-trivial BN affine so dgamma/dbeta paths are exercised
+        with torch.no_grad():
+            m.conv[1].weight.copy_(rand((co,), seed + 100) * 0.5 + 1.0)
+            m.conv[1].bias.copy_(rand((co,), seed + 200) * 0.3)
+        x = rand((n, ci, h, w), seed + 1).requires_grad_(True)
+        r = rand((n, co, h, w), seed + 2)
+        d = {"x": npy(x), "r": npy(r)}
+        for k, v in m.state_dict().items():
+            d["p." + k] = npy(v)
+        m.train()
+        y = m(x)
+        (y * r).sum().backward()
+        d["y_train"] = npy(y)
+        d["dx"] = npy(x.grad)
+        for k, p in m.named_parameters():
+            d["g." + k] = npy(p.grad)
+        for k, v in m.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                d["after." + k] = npy(v)
+        m.eval()
+        with torch.no_grad():
+            d["y_eval"] = npy(m(x))
+        save(f"basicconv_{ci}_{co}_{n}x{h}x{w}", **d)
+
+
+# ---------------------------------------------------------------- per-op: UpSample2d
+def gold_upsample():
+    for (ci, co, n, h, w, seed) in [(8, 4, 2, 5, 7, 21), (16, 8, 1, 3, 2, 22)]:
+        torch.manual_seed(seed)
+        m = UpSample2d(ci, co)
+        x = rand((n, ci, h, w), seed + 1).requires_grad_(True)
+        r = rand((n, co, 2 * h, 2 * w), seed + 2)
+        d = {"x": npy(x), "r": npy(r)}
+        for k, v in m.state_dict().items():
+            d["p." + k] = npy(v)
+        m.train()
+        up = m.up(x)
+        d["up_only"] = npy(up)
+        y = m(x)
+        (y * r).sum().backward()
+        d["y_train"] = npy(y)
+        d["dx"] = npy(x.grad)
+        for k, p in m.named_parameters():
+            d["g." + k] = npy(p.grad)
+        # pure bilinear backward
+        x2 = x.detach().clone().requires_grad_(True)
+        r2 = rand((n, ci, 2 * h, 2 * w), seed + 3)
+        (m.up(x2) * r2).sum().backward()
+        d["r_up"] = npy(r2)
+        d["dx_up_only"] = npy(x2.grad)
+        save(f"upsample2d_{ci}_{co}_{n}x{h}x{w}", **d)
+
+
+# ---------------------------------------------------------------- per-op: maxpool, pad+cat, CE
+def gold_pool_cat_ce():
+    d = {}
+    pool = nn.MaxPool2d(2, 2)
+    for tag, shape, seed in [("a", (2, 4, 7, 9), 31), ("b", (1, 8, 6, 4), 32), ("c", (2, 3, 45 // 5, 5), 33)]:
+        x = rand(shape, seed)
+        # plant exact ties (post-ReLU zeros are the realistic tie case)
+        x = torch.where(x < 0, torch.zeros_like(x), x).requires_grad_(True)
+        y = pool(x)
+        r = rand(tuple(y.shape), seed + 1)
+        (y * r).sum().backward()
+        d[f"pool_{tag}_x"] = npy(x); d[f"pool_{tag}_y"] = npy(y)
+        d[f"pool_{tag}_r"] = npy(r); d[f"pool_{tag}_dx"] = npy(x.grad)
+    # pad + cat exactly as models/unet.py:117-124
+    for tag, us, ss, seed in [("a", (2, 4, 4, 6), (2, 4, 5, 6), 41), ("b", (1, 2, 6, 4), (1, 2, 7, 7), 42), ("c", (2, 3, 8, 8), (2, 3, 8, 8), 43)]:
+        xup = rand(us, seed).requires_grad_(True)
+        skip = rand(ss, seed + 1).requires_grad_(True)
+        dh = skip.size(2) - xup.size(2); dw = skip.size(3) - xup.size(3)
+        p = F.pad(xup, [dw // 2, dw - dw // 2, dh // 2, dh - dh // 2])
+        c = torch.cat([p, skip], dim=1)
+        r = rand(tuple(c.shape), seed + 2)
+        (c * r).sum().backward()
+        d[f"cat_{tag}_up"] = npy(xup); d[f"cat_{tag}_skip"] = npy(skip); d[f"cat_{tag}_out"] = npy(c)
+        d[f"cat_{tag}_r"] = npy(r); d[f"cat_{tag}_dup"] = npy(xup.grad); d[f"cat_{tag}_dskip"] = npy(skip.grad)
+    # cross entropy, train.py:105,130-131
+    lossf = nn.CrossEntropyLoss()
+    for tag, shape, seed in [("a", (2, 12, 5, 7), 51), ("b", (1, 12, 9, 3), 52), ("c", (3, 5, 4, 4), 53)]:
+        lg = (rand(shape, seed).abs() * 2).requires_grad_(True)   # logits are post-ReLU (>=0) in the reference
+        g = torch.Generator().manual_seed(seed + 1)
+        t = torch.randint(0, shape[1], (shape[0], shape[2], shape[3]), generator=g)
+        loss = lossf(lg, t)
+        loss.backward()
+        d[f"ce_{tag}_logits"] = npy(lg); d[f"ce_{tag}_target"] = npy(t)
+        d[f"ce_{tag}_loss"] = npy(loss); d[f"ce_{tag}_dlogits"] = npy(lg.grad)
+    # SegNet pool-with-indices / unpool, models/segnet.py:79-80
+    mp = nn.MaxPool2d(2, return_indices=True); up = nn.MaxUnpool2d(2)
+    for tag, shape, seed in [("a", (2, 4, 7, 9), 61), ("b", (1, 3, 6, 6), 62)]:
+        x = rand(shape, seed)
+        x = torch.where(x < 0, torch.zeros_like(x), x).requires_grad_(True)
+        y, idx = mp(x)
+        z = up(y, idx, output_size=x.shape)
+        r = rand(tuple(z.shape), seed + 1)
+        (z * r).sum().backward()
+        d[f"unpool_{tag}_x"] = npy(x); d[f"unpool_{tag}_y"] = npy(y); d[f"unpool_{tag}_idx"] = npy(idx)
+        d[f"unpool_{tag}_z"] = npy(z); d[f"unpool_{tag}_r"] = npy(r); d[f"unpool_{tag}_dx"] = npy(x.grad)
+    save("ops_pool_cat_ce", **d)
+
+
+# ---------------------------------------------------------------- whole nets
+def net_case(kind, seed, shape, data_seed, tag, steps=0, lr=5e-4, total_steps=None):
+    torch.manual_seed(seed)
+    net = UNet(3, 12) if kind == "unet" else SegNet(3, 12)
+    n, _, h, w = shape
+    g = torch.Generator().manual_seed(data_seed)
+    x = torch.randn(n, 3, h, w, generator=g)
+    t = torch.randint(0, 12, (n, h, w), generator=g)
+    lossf = nn.CrossEntropyLoss()
+    d = {"meta": json.dumps({"kind": kind, "seed": seed, "shape": list(shape), "data_seed": data_seed, "lr": lr,
+                              "steps": steps, "total_steps": total_steps, "torch": torch.__version__})}
+    net.train()
+    out = net(x)
+    loss = lossf(out, t)
+    loss.backward()
+    d["logits"] = npy(out).astype(np.float32)
+    d["loss"] = npy(loss)
+    names = [k for k, _ in net.named_parameters()]
+    d["param_names"] = np.array(names)
+    d["grad_l2"] = np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()])
+    d["grad_absmax"] = np.array([float(p.grad.abs().max()) for _, p in net.named_parameters()])
+    d["param_l2"] = np.array([float(p.detach().double().norm()) for _, p in net.named_parameters()])
+    for k, p in net.named_parameters():  # a few grad slices (first 64 flat elements) for every tensor
+        d["gs." + k] = npy(p.grad.flatten()[:64])
+    sd = net.state_dict()
+    for k in sd:
+        if "running_mean" in k or "running_var" in k:
+            d["bn." + k] = npy(sd[k])
+    # eval-mode forward with the (once-updated) running stats
+    net.eval()
+    with torch.no_grad():
+        oe = net(x)
+    d["logits_eval_sum"] = np.float64(oe.double().sum().item())
+    d["logits_eval_slice"] = npy(oe[0, :, ::7, ::5])
+    d["argmax_eval"] = npy(oe.argmax(dim=1)).astype(np.uint8)
+    net.train()
+    if steps:
+        # trajectory: fresh net, train.py:100-134 semantics
+        torch.manual_seed(seed)
+        net = UNet(3, 12) if kind == "unet" else SegNet(3, 12)
+        net.train()
+        opt = torch.optim.AdamW(net.parameters(), lr=lr, weight_decay=0)
+        sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=lr, total_steps=total_steps)
+        losses = []
+        for _ in range(steps):
+            opt.zero_grad()
+            l = lossf(net(x), t)
+            l.backward()
+            opt.step(); sched.step()
+            losses.append(float(l))
+        d["traj_losses"] = np.array(losses)
+        print(tag, "traj", losses)
+    save(tag, **d)
+
+
+def gold_nets():
+    net_case("unet", 0, (2, 3, 48, 64), 1234, "unet_s0_2x48x64", steps=4, total_steps=40)
+    net_case("unet", 1, (1, 3, 45, 60), 77, "unet_s1_1x45x60")          # odd sizes: 45->22->44->pad 45
+    net_case("unet", 2, (2, 3, 36, 52), 78, "unet_s2_2x36x52")          # pads at several levels
+    net_case("segnet", 0, (2, 3, 64, 96), 1234, "segnet_s0_2x64x96", steps=3, total_steps=30)
+    net_case("segnet", 3, (1, 3, 45, 60), 79, "segnet_s3_1x45x60")
+
+
+def gold_fullsize():
+    """360x480 batch-2 (BASELINE.json configs[0]): loss, checksum, loss trajectory."""
+    torch.manual_seed(0)
+    net = UNet(3, 12); net.train()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(2, 3, 360, 480, generator=g)
+    t = torch.randint(0, 12, (2, 360, 480), generator=g)
+    lossf = nn.CrossEntropyLoss()
+    opt = torch.optim.AdamW(net.parameters(), lr=5e-4, weight_decay=0)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=5e-4, steps_per_epoch=300, epochs=1)
+    d = {}
+    losses = []
+    for it in range(3):
+        opt.zero_grad()
+        out = net(x)
+        l = lossf(out, t)
+        l.backward()
+        if it == 0:
+            d["logits_sum"] = np.float64(out.double().sum().item())
+            d["logits_abs_sum"] = np.float64(out.double().abs().sum().item())
+            d["logits_slice"] = npy(out[:, :, ::40, ::48])
+            names = [k for k, _ in net.named_parameters()]
+            d["param_names"] = np.array(names)
+            d["grad_l2"] = np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()])
+        opt.step(); sched.step()
+        losses.append(float(l)); print("full", it, float(l), flush=True)
+    d["traj_losses"] = np.array(losses)
+    save("unet_s0_2x360x480", **d)
+
+
+def gold_miou():
+    g = np.random.RandomState(5)
+    d = {}
+    for tag in ("a", "b"):
+        pred = g.randint(0, 12, size=(3, 40, 50)).astype(np.int64)
+        lab = g.randint(0, 12, size=(3, 40, 50)).astype(np.int64)
+        agree = g.rand(*lab.shape) < 0.4
+        pred = np.where(agree, lab, pred)
+        ai = np.zeros(12); au = np.zeros(12); ap = np.zeros(12); al = np.zeros(12)
+        for i in range(pred.shape[0]):
+            a, b, c, e = ref_utils.intersect_and_union(pred[i], lab[i], 12, 11)
+            ai += a; au += b; ap += c; al += e
+        d[f"{tag}_pred"] = pred.astype(np.uint8); d[f"{tag}_label"] = lab.astype(np.uint8)
+        d[f"{tag}_inter"] = ai; d[f"{tag}_union"] = au; d[f"{tag}_pred_area"] = ap; d[f"{tag}_label_area"] = al
+    save("miou_intersect_union", **d)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["ops", "nets", "full", "miou"]
+    if "ops" in which:
+        gold_basicconv(); gold_upsample(); gold_pool_cat_ce()
+    if "nets" in which:
+        gold_nets()
+    if "miou" in which:
+        gold_miou()
+    if "full" in which:
+        gold_fullsize()
