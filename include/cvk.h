@@ -1,0 +1,145 @@
+/*
+ * cvk.h — C ABI of libcvk.so: the MI355X (gfx950) kernels behind the CamVid UNet/SegNet training hot path.
+ *
+ * The upstream reference (weiaicunzai/pytorch-camvid) has NO native code and NO FFI on this path: its hot path
+ * is torch.nn modules calling ATen.  The boundary a maintainer binds is therefore the set of torch operators the
+ * reference invokes; each entry point below names the reference call site (file:line under the reference root)
+ * whose ATen operator it replaces.  INTEGRATION.md shows the ctypes stub and the nn.Module that sits on top.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers owned by the caller (torch tensors); the library allocates nothing
+ *     persistent and keeps no pointer past return.  Workspaces are caller-provided.
+ *   - Every call only enqueues work on `stream` (a hipStream_t passed as void*) and never synchronises.
+ *   - Re-entrant, no mutable globals except a thread-local last-error string.
+ *   - Return value: 0 on success, CVK_E* (<0) on argument errors, or a positive hipError_t from the launch.
+ *   - Activations are fp32 NHWC ("channels_last"): element (n,y,x,c) of a dense tensor lives at
+ *     ((n*H + y)*W + x)*ld + c with pixel stride ld >= C.  A *view* (cvk_view) addresses a channel slice and/or a
+ *     spatial window of a larger NHWC buffer: element (n,y,x,c) at  ptr + n*sN + y*sY + x*sX + c.
+ *   - Conv weights are [Cout][3][3][Cin] (= torch OIHW with channels_last strides, i.e. KRSC).
+ *   - Vectorised paths need 16-byte aligned base pointers and ld % 4 == 0; the conv kernels REQUIRE it
+ *     (the host pads channel counts to a multiple of 4 with zero channels).
+ */
+#ifndef CVK_H
+#define CVK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVK_VERSION 100          /* 0.1.0 */
+#define CVK_OK 0
+#define CVK_EINVAL (-1)          /* bad argument (shape, alignment, null pointer) */
+#define CVK_EWORKSPACE (-2)      /* workspace too small */
+#define CVK_STAT_ROWS 64         /* rows (pixels) summarised by one BN-statistics partial of the conv epilogue */
+
+typedef struct cvk_view {        /* strided NHWC view, strides in floats */
+    float*  ptr;                 /* address of element (0,0,0,0) of the view */
+    int64_t sN, sY, sX;          /* image, row, pixel strides */
+} cvk_view;
+
+int         cvk_version(void);
+const char* cvk_last_error_string(void);
+
+/* ---- layout at the module boundary: logical NCHW tensors of any strides <-> dense NHWC (ld >= C) --------------
+ * replaces nothing in the reference (torch tensors are layout-polymorphic); it is the import/export step of
+ * models/unet.py:94 `forward(x)` input and :156 return value. Pad channels [C,ld) of dst are written as 0. */
+int cvk_import_nchw(const float* src, int64_t sN, int64_t sC, int64_t sH, int64_t sW,
+                    float* dst, int ld, int N, int C, int H, int W, void* stream);
+int cvk_export_nchw(const float* src, int ld, float* dst, int64_t dN, int64_t dC, int64_t dH, int64_t dW,
+                    int N, int C, int H, int W, void* stream);
+/* zero channels [0,C) of every pixel of an NHWC frame [N,H,W] that lies OUTSIDE the window
+ * [y0,y0+h) x [x0,x0+w): the F.pad of models/unet.py:120-123 written in place into the concat buffer. */
+int cvk_zero_frame(cvk_view buf, int N, int H, int W, int C, int y0, int x0, int h, int w, void* stream);
+
+/* ---- conv 3x3, stride 1, zero pad 1 (nn.Conv2d(cin,cout,3,padding=1): models/unet.py:11, models/segnet.py:8) --
+ * forward: y[m][co] = bias[co] + sum_{tap,ci} x[m+tap][ci] * w[co][tap][ci]      (implicit GEMM on fp32 MFMA)
+ *   x: dense NHWC, ld = Cin (Cin % 4 == 0).  w: [Cout][9][Cin].  y: dense, pixel stride ldy >= Cout, columns
+ *   [Cout,ldy) are written as 0.  bias may be NULL.
+ *   stats (nullable): fused BatchNorm statistics partials, float[2][P][Cout], P = ceil(N*H*W / CVK_STAT_ROWS):
+ *   stats[0][p][c] = sum of y over rows [64p,64p+64) ; stats[1][p][c] = sum of (y - partial mean)^2.
+ * data-grad = the same kernel on dy with the packed weights of cvk_pack_weight_dgrad. */
+int cvk_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, float* stats,
+                    int N, int H, int W, int Cin, int Cout, int ldy, void* stream);
+/* w_src: [Cout][9][Cin] -> dst [Cout][9][Cin_pad] (zero padded). */
+int cvk_pack_weight_fwd(const float* w_src, float* dst, int Cout, int Cin, int Cin_pad, void* stream);
+/* w_src: [Cout][9][Cin] -> dst [Cin_pad][9][Cout_pad], dst[ci][t][co] = w_src[co][8-t][ci] (flipped taps). */
+int cvk_pack_weight_dgrad(const float* w_src, float* dst, int Cout, int Cin, int Cin_pad, int Cout_pad, void* stream);
+/* weight-grad (ConvolutionBackward of train.py:131): dw[co][tap][ci] = sum_m dy[m][co] * x[m+tap][ci].
+ *   x: dense, ld = Cin_pad; dy: dense, ld = ld_dy; dw: [Cout][9][Cin] (Cin <= Cin_pad real channels).
+ *   Split over pixels into fp32 slabs in `workspace`, then a deterministic slab reduction. */
+size_t cvk_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout);
+int cvk_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,
+                      int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- BatchNorm2d (+ReLU) (models/unet.py:12-13, models/segnet.py:9-10) -------------------------------------------
+ * finalize (training): combines the conv-epilogue partials (Chan's parallel variance, fp64) into per-channel
+ *   mean / rstd = 1/sqrt(biased var + eps), scale = gamma*rstd, shift = beta - mean*scale, and updates
+ *   running_mean/var (unbiased var, momentum) and num_batches_tracked in place when those pointers are non-NULL. */
+size_t cvk_bn_finalize_workspace_bytes(int P, int C);
+int cvk_bn_finalize(const float* stats, int P, int M, int C, const float* gamma, const float* beta,
+                    float* mean, float* rstd, float* scale, float* shift,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream);
+/* eval mode: scale/shift from running statistics (train.py:169 net.eval()); also fills mean/rstd. */
+int cvk_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float* mean, float* rstd, float* scale, float* shift, int C, float eps, void* stream);
+/* out = max(0, y*scale + shift), y dense (ldy), out a view. */
+int cvk_bn_relu_apply(const float* y, int ldy, const float* scale, const float* shift, cvk_view out,
+                      int N, int H, int W, int C, void* stream);
+/* backward, pass 1: g = dout * [y*scale+shift > 0]; partial sums of g and g*xhat per row block:
+ *   part float[2][PB][C], PB = cvk_bn_bwd_blocks(M). */
+int cvk_bn_bwd_blocks(int M);
+int cvk_bn_bwd_reduce(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift,
+                      const float* mean, const float* rstd, float* part, int N, int H, int W, int C, void* stream);
+/* sums PB partial rows in fp64: out0[c] = sum part[0][:,c], out1[c] = sum part[1][:,c] (out1/part1 nullable) */
+int cvk_colsum_finalize(const float* part, int PB, int C, float* out0, float* out1, void* stream);
+/* backward, pass 2: dy = scale*(g - dbeta/M - xhat*dgamma/M) (training) or dy = scale*g (eval: use_batch_stats=0);
+ *   also emits column-sum partials of dy (conv bias gradient) into dbias_part float[PB][C] when non-NULL. */
+int cvk_bn_bwd_dx(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift,
+                  const float* mean, const float* rstd, const float* dgamma, const float* dbeta,
+                  float* dy, int ld_dy, float* dbias_part, int N, int H, int W, int C, int use_batch_stats, void* stream);
+
+/* ---- MaxPool2d(2,2) (models/unet.py:92; with indices models/segnet.py:79) and MaxUnpool2d (segnet.py:80) ------
+ * floor output size; first maximum wins ties.  code (nullable): uint8 window position 0..3 (= 2*dy+dx) of the
+ * arg-max, the compact form of torch's int64 flat indices. */
+int cvk_maxpool2x2_fwd(cvk_view x, float* out, uint8_t* code, int N, int H, int W, int C, void* stream);
+/* dx(view) (+)= route(dout) ; arg-max recomputed from x when code == NULL.  accumulate=0 overwrites (and zeroes
+ * the odd trailing row/column), accumulate=1 adds. */
+int cvk_maxpool2x2_bwd(const float* dout, cvk_view x, const uint8_t* code, cvk_view dx, int accumulate,
+                       int N, int H, int W, int C, void* stream);
+int cvk_maxunpool2x2_fwd(const float* v, const uint8_t* code, float* out, int N, int H, int W, int C, void* stream);
+int cvk_maxunpool2x2_bwd(const float* dout, const uint8_t* code, float* dv, int N, int H, int W, int C, void* stream);
+/* uint8 codes -> torch-style int64 flat H*W indices in NCHW order (API parity with return_indices=True) */
+int cvk_pool_code_to_index(const uint8_t* code, int64_t* idx, int N, int H, int W, int C, void* stream);
+
+/* ---- bilinear x2, align_corners=True (nn.Upsample: models/unet.py:25) -----------------------------------------
+ * x: dense [N,H,W,C] (ld=C) -> out dense [N,2H,2W,C];  bwd: dx = transpose(dout). */
+int cvk_bilinear_up2_fwd(const float* x, float* out, int N, int H, int W, int C, void* stream);
+int cvk_bilinear_up2_bwd(const float* dout, float* dx, int N, int H, int W, int C, void* stream);
+
+/* ---- softmax cross-entropy, mean over pixels (nn.CrossEntropyLoss(): train.py:105,130-131) --------------------
+ * logits: dense NHWC rows [M][ld], target int64 [M].  fwd writes the scalar mean loss to *loss (device) using
+ * `part` (float[cvk_ce_blocks(M)]) as scratch.  bwd: dlogits = (softmax - onehot) * (*grad_out) * scale / M. */
+int cvk_ce_blocks(int M);
+int cvk_softmax_ce_fwd(const float* logits, int ld, const int64_t* target, float* part, float* loss,
+                       int M, int C, void* stream);
+int cvk_softmax_ce_bwd(const float* logits, int ld, const int64_t* target, const float* grad_out, float scale,
+                       float* dlogits, int ld_d, int M, int C, void* stream);
+
+/* ---- evaluation (train.py:191 argmax; utils.py:162-190 histograms) -------------------------------------------- */
+int cvk_argmax_channels(const float* logits, int ld, int64_t* out, int M, int C, void* stream);
+/* hist int64[3][num_classes] += (intersection, prediction area, label area), pixels with label==ignore skipped */
+int cvk_confusion_accumulate(const int64_t* pred, const int64_t* label, int64_t* hist, int M, int num_classes,
+                             int ignore_index, void* stream);
+
+/* ---- fused AdamW over a flat fp32 buffer (torch.optim.AdamW: train.py:100,133) -------------------------------- */
+int cvk_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVK_H */

@@ -1,0 +1,12 @@
+"""pytorch_camvid_amd — MI355X-native (gfx950) execution of the pytorch-camvid UNet/SegNet training hot path.
+
+Import name: `pytorch_camvid_amd` (the directory is `pytorch-camvid_amd/`; `pytorch_camvid_amd.py` at the repository
+root aliases it).  Public surface mirrors the reference (models/unet.py, models/segnet.py, utils.get_model,
+train.py's loss): UNet, SegNet, BasicConv2d, BasicConv, UpSample2d, get_model, CrossEntropyLoss.
+"""
+from ._lib import CvkError, build as build_library, load as load_library          # noqa: F401
+from .modules import BasicConv, BasicConv2d, SegNet, UNet, UpSample2d, get_model   # noqa: F401
+from .functional import ConfusionMeter, CrossEntropyLoss, argmax_channels, cross_entropy  # noqa: F401
+
+__all__ = ["UNet", "SegNet", "BasicConv2d", "BasicConv", "UpSample2d", "get_model", "CrossEntropyLoss",
+           "cross_entropy", "argmax_channels", "ConfusionMeter", "build_library", "load_library", "CvkError"]

@@ -1,0 +1,109 @@
+"""ctypes binding of libcvk.so (include/cvk.h).  There is NO fallback: if the HIP library is missing or cannot be
+loaded the product path raises — a silent eager/CPU path would void every parity claim."""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcvk.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+CVK_STAT_ROWS = 64
+
+c_f32p = ctypes.c_void_p      # device pointers are passed as integers
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_size = ctypes.c_size_t
+c_float = ctypes.c_float
+c_vp = ctypes.c_void_p
+
+
+class View(ctypes.Structure):
+    """cvk_view: strided NHWC view, strides in floats."""
+    _fields_ = [("ptr", ctypes.c_void_p), ("sN", ctypes.c_int64), ("sY", ctypes.c_int64), ("sX", ctypes.c_int64)]
+
+
+# name -> (restype, argtypes); the list is checked against include/cvk.h by tests/test_abi.py
+SIGNATURES = {
+    "cvk_version": (c_int, []),
+    "cvk_last_error_string": (ctypes.c_char_p, []),
+    "cvk_import_nchw": (c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_export_nchw": (c_int, [c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_zero_frame": (c_int, [View, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_conv3x3_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_pack_weight_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "cvk_pack_weight_dgrad": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_conv3x3_wgrad_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
+    "cvk_conv3x3_wgrad": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
+    "cvk_bn_finalize_workspace_bytes": (c_size, [c_int, c_int]),
+    "cvk_bn_finalize": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                c_float, c_float, c_vp, c_size, c_vp]),
+    "cvk_bn_eval_params": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_float, c_vp]),
+    "cvk_bn_relu_apply": (c_int, [c_vp, c_int, c_vp, c_vp, View, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_bn_bwd_blocks": (c_int, [c_int]),
+    "cvk_bn_bwd_reduce": (c_int, [View, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_colsum_finalize": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "cvk_bn_bwd_dx": (c_int, [View, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp,
+                              c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_maxpool2x2_fwd": (c_int, [View, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_maxpool2x2_bwd": (c_int, [c_vp, View, c_vp, View, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_maxunpool2x2_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_maxunpool2x2_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_pool_code_to_index": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_bilinear_up2_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_bilinear_up2_bwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_ce_blocks": (c_int, [c_int]),
+    "cvk_softmax_ce_fwd": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    "cvk_softmax_ce_bwd": (c_int, [c_vp, c_int, c_vp, c_vp, c_float, c_vp, c_int, c_int, c_int, c_vp]),
+    "cvk_argmax_channels": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp]),
+    "cvk_confusion_accumulate": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "cvk_adamw_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_float, c_float, c_float, c_float, c_float, c_int, c_vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class CvkError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 into lib/libcvk.so (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:])
+        print(r.stderr[-4000:])
+    if r.returncode != 0:
+        raise CvkError("building libcvk.so failed (hipcc --offload-arch=gfx950); see output above")
+    return LIB_PATH
+
+
+def load():
+    """Load libcvk.so once.  Raises CvkError when it is missing — there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        import torch  # noqa: F401  torch's bundled libamdhip64 (SONAME libamdhip64.so.7) must be the one HIP runtime in-process
+        if not os.path.exists(LIB_PATH):
+            raise CvkError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950).  pytorch_camvid_amd has no CPU/eager fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here = ABI drift between header and library
+            fn.restype = res
+            fn.argtypes = args
+        if lib.cvk_version() != 100:
+            raise CvkError(f"libcvk.so version {lib.cvk_version()} != 100 expected by the Python host side")
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().cvk_last_error_string()
+        raise CvkError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")

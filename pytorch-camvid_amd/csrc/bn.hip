@@ -1,0 +1,365 @@
+// bn.hip — BatchNorm2d (+ fused ReLU) forward/backward for NHWC fp32, gfx950.
+//
+// Replaces ATen native_batch_norm / native_batch_norm_backward / relu_ / threshold_backward behind
+// nn.BatchNorm2d + nn.ReLU(inplace=True) of the reference (models/unet.py:12-13, models/segnet.py:9-10).
+// All kernels are HBM-bound streams: 16-byte vector access along the channel (innermost) dimension, every tensor
+// read at most once per pass.  Per-channel reductions: each thread owns a fixed 4-channel vector and walks pixels,
+// the block combines through LDS, and the few hundred block partials are summed in fp64 in a fixed order
+// (bitwise reproducible; no float atomics).
+//   forward statistics arrive already reduced to 64-row partials from the conv epilogue (conv3x3.hip), so the
+//   activation tensor is NOT re-read for the mean/variance: training forward = 1 read + 1 write.
+#include "cvk_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- forward statistics
+// level 1: [2][P][C] float partials (sum, M2 about the partial mean, n_p = min(64, M-64p) rows) ->
+//          [G][C][3] double: (sum s_p, sum q_p, sum s_p^2/n_p)
+__global__ __launch_bounds__(256) void k_bn_stats_l1(const float* __restrict__ stats, double* __restrict__ ws, int P, int M,
+                                                    int C, int rows_per_g) {
+    __shared__ double red[3][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int g = threadIdx.x >> 6;
+    const int pbeg = blockIdx.y * rows_per_g, pend = min(P, pbeg + rows_per_g);
+    double a = 0.0, b = 0.0, q = 0.0;
+    if (c < C) {
+        for (int p = pbeg + g; p < pend; p += 4) {
+            const double s = stats[(size_t)p * C + c];
+            const double m2 = stats[(size_t)(P + p) * C + c];
+            const int n = min(CVK_STAT_ROWS, M - p * CVK_STAT_ROWS);
+            a += s;
+            b += m2;
+            q += s * s / (double)n;
+        }
+    }
+    red[0][g][threadIdx.x & 63] = a;
+    red[1][g][threadIdx.x & 63] = b;
+    red[2][g][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        const int l = threadIdx.x;
+        double* o = ws + ((size_t)blockIdx.y * C + c) * 3;
+        o[0] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+        o[1] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+        o[2] = (red[2][0][l] + red[2][1][l]) + (red[2][2][l] + red[2][3][l]);
+    }
+}
+
+// level 2: one thread per channel; M2 = sum q_p + sum s_p^2/n_p - S^2/M (Chan, evaluated in fp64)
+__global__ void k_bn_stats_l2(const double* __restrict__ ws, int G, int M, int C, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, float* mean, float* rstd, float* scale, float* shift,
+                              float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt != nullptr) *nbt += 1;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0, q = 0.0;
+    for (int g = 0; g < G; ++g) {
+        const double* o = ws + ((size_t)g * C + c) * 3;
+        a += o[0];
+        b += o[1];
+        q += o[2];
+    }
+    const double mu = a / (double)M;
+    double m2 = b + q - a * a / (double)M;
+    if (m2 < 0.0) m2 = 0.0;
+    const double var = m2 / (double)M;  // biased, used for normalisation
+    const double rs = 1.0 / sqrt(var + (double)eps);
+    const float fmu = (float)mu, frs = (float)rs;
+    mean[c] = fmu;
+    rstd[c] = frs;
+    const float sc = gamma[c] * frs;
+    scale[c] = sc;
+    shift[c] = beta[c] - fmu * sc;
+    if (running_mean != nullptr) {
+        const double unb = M > 1 ? m2 / (double)(M - 1) : var;  // running_var tracks the unbiased estimate
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fmu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+__global__ void k_bn_eval_params(const float* gamma, const float* beta, const float* rm, const float* rv, float* mean,
+                                 float* rstd, float* scale, float* shift, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float rs = 1.f / sqrtf(rv[c] + eps);
+    mean[c] = rm[c];
+    rstd[c] = rs;
+    const float sc = gamma[c] * rs;
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+// ---------------------------------------------------------------------------------------------- view addressing
+struct PixMap {  // pixel m (row-major over N,H,W) -> float offset inside a strided view
+    int64_t sN, sY, sX;
+    int H, W, linear;
+    __device__ __forceinline__ int64_t off(int m) const {
+        if (linear) return (int64_t)m * sX;
+        const int hw = H * W;
+        const int n = m / hw, rem = m - n * hw;
+        const int y = rem / W, x = rem - y * W;
+        return n * sN + y * sY + x * sX;
+    }
+};
+
+PixMap make_map(const cvk_view& v, int H, int W) {
+    PixMap p;
+    p.sN = v.sN; p.sY = v.sY; p.sX = v.sX; p.H = H; p.W = W;
+    p.linear = (v.sY == (int64_t)W * v.sX && v.sN == (int64_t)H * v.sY) ? 1 : 0;
+    return p;
+}
+
+template <int V> struct Vec;
+template <> struct Vec<4> { typedef f32x4 T; };
+template <> struct Vec<1> { typedef float T; };
+template <int V> __device__ __forceinline__ float vget(const typename Vec<V>::T& v, int j);
+template <> __device__ __forceinline__ float vget<4>(const f32x4& v, int j) { return v[j]; }
+template <> __device__ __forceinline__ float vget<1>(const float& v, int) { return v; }
+template <int V> __device__ __forceinline__ void vset(typename Vec<V>::T& v, int j, float x);
+template <> __device__ __forceinline__ void vset<4>(f32x4& v, int j, float x) { v[j] = x; }
+template <> __device__ __forceinline__ void vset<1>(float& v, int, float x) { v = x; }
+
+// ---------------------------------------------------------------------------------------------- apply + ReLU
+template <int V>
+__global__ __launch_bounds__(256) void k_bn_relu_apply(const float* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, float* __restrict__ out, PixMap om,
+                                                      int M, int C) {
+    typedef typename Vec<V>::T VT;
+    const int cvn = C / V;  // vectors per pixel
+    const long total = (long)M * cvn;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / cvn);
+        const int c = (int)(i - (long)m * cvn) * V;
+        const VT v = *reinterpret_cast<const VT*>(y + (size_t)m * ldy + c);
+        const VT sc = *reinterpret_cast<const VT*>(scale + c);
+        const VT sh = *reinterpret_cast<const VT*>(shift + c);
+        VT o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) vset<V>(o, j, fmaxf(vget<V>(v, j) * vget<V>(sc, j) + vget<V>(sh, j), 0.f));
+        *reinterpret_cast<VT*>(out + om.off(m) + c) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- backward
+// Shared walker: block b owns pixel rows [b*rows, (b+1)*rows); thread t owns channel vector (t % cvn) and walks
+// pixels t/cvn, t/cvn + 256/cvn, ...  MODE 0: partial sums of g and g*xhat.  MODE 1: write dy, partial sums of dy.
+template <int V, int MODE>
+__global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dout, PixMap dm, const float* __restrict__ y, int ldy,
+                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                               const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                               float* __restrict__ dy, int ld_dy, float* __restrict__ part, int M, int C,
+                                               int rows, int PB, int cchunk, int use_batch_stats) {
+    typedef typename Vec<V>::T VT;
+    __shared__ float red[2][256 * V];
+    const int c0 = blockIdx.y * cchunk;
+    const int cw = min(cchunk, C - c0);  // channels handled by this block column
+    const int cvn = cw / V;               // vectors per pixel in this chunk (cw % V == 0 by construction)
+    const int ppp = 256 / cvn;            // pixels per pass
+    const int t = threadIdx.x;
+    const bool active = t < cvn * ppp;
+    const int cv = t % cvn, pr = t / cvn;
+    const int c = c0 + cv * V;
+    const int mbeg = blockIdx.x * rows, mend = min(M, mbeg + rows);
+
+    float s0[V], s1[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+    if (active) {
+        const VT sc = *reinterpret_cast<const VT*>(scale + c);
+        const VT sh = *reinterpret_cast<const VT*>(shift + c);
+        const VT mu = *reinterpret_cast<const VT*>(mean + c);
+        const VT rs = *reinterpret_cast<const VT*>(rstd + c);
+        float k1[V], k2[V];
+        if (MODE == 1) {
+            const float invM = 1.f / (float)M;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                k1[j] = use_batch_stats ? dbeta[c + j] * invM : 0.f;
+                k2[j] = use_batch_stats ? dgamma[c + j] * invM : 0.f;
+            }
+        }
+        for (int m = mbeg + pr; m < mend; m += ppp) {
+            const VT d = *reinterpret_cast<const VT*>(dout + dm.off(m) + c);
+            const VT yy = *reinterpret_cast<const VT*>(y + (size_t)m * ldy + c);
+            VT o;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float yv = vget<V>(yy, j);
+                const float g = (yv * vget<V>(sc, j) + vget<V>(sh, j) > 0.f) ? vget<V>(d, j) : 0.f;
+                const float xh = (yv - vget<V>(mu, j)) * vget<V>(rs, j);
+                if (MODE == 0) {
+                    s0[j] += g;
+                    s1[j] += g * xh;
+                } else {
+                    const float r = vget<V>(sc, j) * (g - k1[j] - xh * k2[j]);
+                    vset<V>(o, j, r);
+                    s0[j] += r;
+                }
+            }
+            if (MODE == 1) *reinterpret_cast<VT*>(dy + (size_t)m * ld_dy + c) = o;
+        }
+    }
+    if (part == nullptr) return;
+    // block combine: threads with equal cv, fixed order over pr
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        red[0][t * V + j] = s0[j];
+        if (MODE == 0) red[1][t * V + j] = s1[j];
+    }
+    __syncthreads();
+    if (t < cvn) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float a = 0.f, b = 0.f;
+            for (int p = 0; p < ppp; ++p) {
+                a += red[0][(p * cvn + t) * V + j];
+                if (MODE == 0) b += red[1][(p * cvn + t) * V + j];
+            }
+            part[(size_t)blockIdx.x * C + c0 + t * V + j] = a;
+            if (MODE == 0) part[(size_t)(PB + blockIdx.x) * C + c0 + t * V + j] = b;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_colsum_finalize(const float* __restrict__ part, int PB, int C, float* out0,
+                                                         float* out1) {
+    __shared__ double red[16][64];
+    const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l;
+    const int which = blockIdx.y;
+    const float* src = part + (size_t)which * PB * C;
+    double a = 0.0;
+    if (c < C)
+        for (int p = g; p < PB; p += 16) a += (double)src[(size_t)p * C + c];
+    red[g][l] = a;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += red[i][l];
+        (which == 0 ? out0 : out1)[c] = (float)s;
+    }
+}
+
+int bwd_rows(int M) {
+    const int pb = cvk_bn_bwd_blocks(M);
+    return cvk_cdiv(M, pb);
+}
+
+bool vec_ok(const void* a, const void* b, const void* c, int ld0, int ld1, int C, const PixMap* pm) {
+    if (C % 4 || ld0 % 4 || ld1 % 4) return false;
+    if (!cvk_aligned16(a) || !cvk_aligned16(b) || (c && !cvk_aligned16(c))) return false;
+    if (pm && ((pm->sN | pm->sY | pm->sX) & 3)) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" size_t cvk_bn_finalize_workspace_bytes(int P, int C) {
+    if (P <= 0 || C <= 0) return 0;
+    const int G = P < 32 ? 1 : (P / 32 < 64 ? P / 32 : 64);
+    return (size_t)G * C * 3 * sizeof(double);
+}
+
+extern "C" int cvk_bn_finalize(const float* stats, int P, int M, int C, const float* gamma, const float* beta, float* mean,
+                               float* rstd, float* scale, float* shift, float* running_mean, float* running_var,
+                               int64_t* num_batches_tracked, float momentum, float eps, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    CVK_CHECK_ARG(stats && gamma && beta && mean && rstd && scale && shift && workspace, "cvk_bn_finalize: null pointer");
+    CVK_CHECK_ARG(P == cvk_cdiv(M, CVK_STAT_ROWS) && C > 0 && M > 0, "cvk_bn_finalize: P=%d inconsistent with M=%d", P, M);
+    CVK_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "cvk_bn_finalize: running_mean/var must come together");
+    CVK_CHECK_ARG((((uintptr_t)workspace) & 7u) == 0, "cvk_bn_finalize: workspace must be 8-byte aligned");
+    if (workspace_bytes < cvk_bn_finalize_workspace_bytes(P, C)) {
+        cvk_set_error("cvk_bn_finalize: workspace too small");
+        return CVK_EWORKSPACE;
+    }
+    const int G = P < 32 ? 1 : (P / 32 < 64 ? P / 32 : 64);
+    const int rows_per_g = cvk_cdiv(P, G);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bn_stats_l1, dim3(cvk_cdiv(C, 64), G), dim3(256), 0, s, stats, (double*)workspace, P, M, C, rows_per_g);
+    hipLaunchKernelGGL(k_bn_stats_l2, dim3(cvk_cdiv(C, 64)), dim3(64), 0, s, (const double*)workspace, G, M, C, gamma, beta, mean,
+                       rstd, scale, shift, running_mean, running_var, num_batches_tracked, momentum, eps);
+    CVK_LAUNCH_RETURN("cvk_bn_finalize");
+}
+
+extern "C" int cvk_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                  float* mean, float* rstd, float* scale, float* shift, int C, float eps, void* stream) {
+    CVK_CHECK_ARG(gamma && beta && running_mean && running_var && mean && rstd && scale && shift && C > 0, "cvk_bn_eval_params: bad arguments");
+    hipLaunchKernelGGL(k_bn_eval_params, dim3(cvk_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                       running_var, mean, rstd, scale, shift, C, eps);
+    CVK_LAUNCH_RETURN("cvk_bn_eval_params");
+}
+
+extern "C" int cvk_bn_relu_apply(const float* y, int ldy, const float* scale, const float* shift, cvk_view out, int N, int H,
+                                 int W, int C, void* stream) {
+    CVK_CHECK_ARG(y && scale && shift && out.ptr, "cvk_bn_relu_apply: null pointer");
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && ldy >= C && (long)N * H * W < (1L << 31), "cvk_bn_relu_apply: bad shape");
+    const int M = N * H * W;
+    const PixMap om = make_map(out, H, W);
+    const bool v4 = vec_ok(y, out.ptr, scale, ldy, 0, C, &om) && cvk_aligned16(shift);
+    const long total = (long)M * (v4 ? C / 4 : C);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (v4)
+        hipLaunchKernelGGL(k_bn_relu_apply<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, ldy, scale, shift, out.ptr, om, M, C);
+    else
+        hipLaunchKernelGGL(k_bn_relu_apply<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, ldy, scale, shift, out.ptr, om, M, C);
+    CVK_LAUNCH_RETURN("cvk_bn_relu_apply");
+}
+
+extern "C" int cvk_bn_bwd_blocks(int M) {
+    if (M <= 0) return 0;
+    const int pb = cvk_cdiv(M, 16);
+    return pb < 1024 ? pb : 1024;
+}
+
+static int bn_bwd_launch(int mode, cvk_view dout, const float* y, int ldy, const float* scale, const float* shift,
+                         const float* mean, const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy,
+                         float* part, int N, int H, int W, int C, int use_batch_stats, void* stream, const char* name) {
+    CVK_CHECK_ARG(dout.ptr && y && scale && shift && mean && rstd, "%s: null pointer", name);
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && ldy >= C && (long)N * H * W < (1L << 31), "%s: bad shape", name);
+    const int M = N * H * W;
+    const PixMap dm = make_map(dout, H, W);
+    bool v4 = vec_ok(y, dout.ptr, scale, ldy, mode == 1 ? ld_dy : 0, C, &dm) && cvk_aligned16(shift) && cvk_aligned16(mean) && cvk_aligned16(rstd);
+    if (mode == 1) v4 = v4 && cvk_aligned16(dy);
+    const int PB = cvk_bn_bwd_blocks(M), rows = bwd_rows(M);
+    const int nb = cvk_cdiv(M, rows);  // blocks actually needed (<= PB); unused partial rows are zero-filled below
+    const int cchunk = v4 ? 1024 : 256;
+    dim3 grid(nb, cvk_cdiv(C, cchunk));
+    hipStream_t s = (hipStream_t)stream;
+    if (part != nullptr && nb < PB) {
+        // keep the [PB][C] contract: rows [nb, PB) must read as zero
+        const int planes = mode == 0 ? 2 : 1;
+        for (int pl = 0; pl < planes; ++pl)
+            (void)hipMemsetAsync(part + ((size_t)pl * PB + nb) * C, 0, (size_t)(PB - nb) * C * sizeof(float), s);
+    }
+#define CVK_BWD(V_, MODE_)                                                                                              \
+    hipLaunchKernelGGL((k_bn_bwd<V_, MODE_>), grid, dim3(256), 0, s, dout.ptr, dm, y, ldy, scale, shift, mean, rstd, dgamma, \
+                       dbeta, dy, ld_dy, part, M, C, rows, PB, cchunk, use_batch_stats)
+    if (mode == 0) { if (v4) CVK_BWD(4, 0); else CVK_BWD(1, 0); }
+    else { if (v4) CVK_BWD(4, 1); else CVK_BWD(1, 1); }
+#undef CVK_BWD
+    CVK_LAUNCH_RETURN(name);
+}
+
+extern "C" int cvk_bn_bwd_reduce(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift,
+                                 const float* mean, const float* rstd, float* part, int N, int H, int W, int C, void* stream) {
+    CVK_CHECK_ARG(part, "cvk_bn_bwd_reduce: null partial buffer");
+    return bn_bwd_launch(0, dout, y, ldy, scale, shift, mean, rstd, nullptr, nullptr, nullptr, 0, part, N, H, W, C, 1, stream,
+                         "cvk_bn_bwd_reduce");
+}
+
+extern "C" int cvk_bn_bwd_dx(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
+                             const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* dbias_part,
+                             int N, int H, int W, int C, int use_batch_stats, void* stream) {
+    CVK_CHECK_ARG(dy && ld_dy >= C, "cvk_bn_bwd_dx: bad dy");
+    CVK_CHECK_ARG(!use_batch_stats || (dgamma && dbeta), "cvk_bn_bwd_dx: dgamma/dbeta required in training mode");
+    return bn_bwd_launch(1, dout, y, ldy, scale, shift, mean, rstd, dgamma, dbeta, dy, ld_dy, dbias_part, N, H, W, C,
+                         use_batch_stats, stream, "cvk_bn_bwd_dx");
+}
+
+extern "C" int cvk_colsum_finalize(const float* part, int PB, int C, float* out0, float* out1, void* stream) {
+    CVK_CHECK_ARG(part && out0 && PB > 0 && C > 0, "cvk_colsum_finalize: bad arguments");
+    hipLaunchKernelGGL(k_colsum_finalize, dim3(cvk_cdiv(C, 64), out1 ? 2 : 1), dim3(1024), 0, (hipStream_t)stream, part, PB, C, out0, out1);
+    CVK_LAUNCH_RETURN("cvk_colsum_finalize");
+}

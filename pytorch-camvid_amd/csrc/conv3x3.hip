@@ -1,0 +1,463 @@
+// conv3x3.hip — 3x3 / stride 1 / pad 1 convolution on the gfx950 fp32 matrix cores.
+//
+// Replaces ATen's convolution forward / ConvolutionBackward behind nn.Conv2d(cin, cout, 3, padding=1)
+// (reference models/unet.py:11, models/segnet.py:8; backward driven by train.py:131).
+//
+// Formulation: implicit GEMM, never materialising im2col.
+//   forward / data-grad : C[M = N*H*W pixels][N = Cout] += A[M][K = 9*Cin] * B[K][N]
+//       A row m, column k=(tap,ci) is the NHWC input pixel m shifted by `tap` (zero outside the frame): K-contiguous.
+//       B is the weight matrix [Cout][9*Cin] (torch OIHW in channels_last strides): K-contiguous per output channel.
+//   weight-grad         : C[M = Cout][N = 9*Cin] += A^T[K = pixels][M] * B[K][N], split over pixel ranges.
+// Matrix instruction: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains, 64 cycles / 4096 FLOP per SIMD), 64-wide waves,
+// each wave owns 32x32 accumulator tiles.  Because this MFMA is 16x slower than bf16 the kernel is MFMA-issue bound
+// with huge slack on LDS/L2, so staging is simple: 16-byte coalesced global loads -> registers (prefetched one
+// K-slice ahead, in flight under the previous slice's 64 MFMAs per wave) -> padded LDS rows -> ds_read_b128 fragments.
+// K order inside a slice is permuted identically for A and B (lane half h takes k = 8*kk + 4*h + j for MFMA j), which
+// lets one ds_read_b128 feed four MFMAs.
+#include "cvk_common.h"
+
+namespace {
+
+constexpr int BK = 32;        // K slice per LDS stage (floats)
+constexpr int LDT = BK + 4;   // padded LDS row: 144 B -> the 16 rows of a ds_read_b128 lane group hit 16 distinct slots
+
+// ------------------------------------------------------------------------------------------------ forward / dgrad
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool STATS>
+__global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm(
+    const float* __restrict__ X, const float* __restrict__ Wt, const float* __restrict__ bias, float* __restrict__ Y,
+    float* __restrict__ stats, int M, int H, int W, int Cin, int Cout, int ldy, int Ktot, int P, int tilesN) {
+    constexpr int NT = WARPS_M * WARPS_N * 64;
+    constexpr int TM = BM / WARPS_M / 32, TN = BN / WARPS_N / 32;
+    constexpr int RP = NT / 8;  // tile rows staged per pass (8 lanes x 16 B cover one 32-float row)
+    constexpr int NA = BM / RP, NB = BN / RP;
+    static_assert(NA >= 1 && NB >= 1 && BM % RP == 0 && BN % RP == 0, "tile/threads mismatch");
+    static_assert(!STATS || TM == 2, "BN statistics granule is 64 rows per wave");
+
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDT];
+    float* As = smem;
+    float* Bs = smem + BM * LDT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+
+    const int tile = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tilesN) * BM;
+    const int n0 = (tile % tilesN) * BN;
+
+    // ---- per-thread staging coordinates (fixed for the whole K loop)
+    const int kv = tid & 7, r0 = tid >> 3;
+    int ay[NA], ax[NA];
+    const float* ap[NA];
+    const int HW = H * W;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + r0 + i * RP;
+        if (m < M) {
+            const int n = m / HW, rem = m - n * HW;
+            ay[i] = rem / W;
+            ax[i] = rem - ay[i] * W;
+        } else {
+            ay[i] = -8;  // every tap fails the bounds test -> zero rows
+            ax[i] = 0;
+        }
+        ap[i] = X + (size_t)(m < M ? m : 0) * Cin;
+    }
+    const float* bp[NB];
+    bool bok[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int co = n0 + r0 + i * RP;
+        bok[i] = co < Cout;
+        bp[i] = Wt + (size_t)(bok[i] ? co : 0) * Ktot;
+    }
+
+    f32x4 ra[NA], rb[NB];
+    int k_cur = kv * 4, tap = 0, ci = kv * 4;  // this thread's K column in the current slice, split as (tap, ci)
+    while (ci >= Cin) { ci -= Cin; ++tap; }
+
+    auto load_stage = [&]() {
+        const bool kok = k_cur < Ktot;
+        const int t3 = tap / 3;
+        const int dy = t3 - 1, dx = tap - t3 * 3 - 1;
+        const int shift = (dy * W + dx) * Cin + ci;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const bool ok = kok && (unsigned)(ay[i] + dy) < (unsigned)H && (unsigned)(ax[i] + dx) < (unsigned)W;
+            ra[i] = ok ? *reinterpret_cast<const f32x4*>(ap[i] + shift) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            rb[i] = (kok && bok[i]) ? *reinterpret_cast<const f32x4*>(bp[i] + k_cur) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        k_cur += BK;
+        ci += BK;
+        while (ci >= Cin) { ci -= Cin; ++tap; }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nK = (Ktot + BK - 1) / BK;
+    load_stage();
+    for (int ks = 0; ks < nK; ++ks) {
+        __syncthreads();  // all waves finished reading the previous slice
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&As[(r0 + i * RP) * LDT + kv * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&Bs[(r0 + i * RP) * LDT + kv * 4]) = rb[i];
+        __syncthreads();
+        if (ks + 1 < nK) load_stage();  // next slice's global loads fly under this slice's MFMAs
+
+        const float* arow = &As[(wm * TM * 32 + li) * LDT + lh * 4];
+        const float* brow = &Bs[(wn * TN * 32 + li) * LDT + lh * 4];
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const f32x4*>(arow + t * 32 * LDT + kk * 8);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const f32x4*>(brow + t * 32 * LDT + kk * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: + bias, store NHWC, fused BatchNorm statistics partials
+    // C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
+    const int rowbase = m0 + wm * TM * 32;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = n0 + wn * TN * 32 + tn * 32 + li;
+        const float bv = (bias != nullptr && col < Cout) ? bias[col] : 0.f;
+        float s = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rowbase + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float v = acc[tm][tn][r] + bv;
+                acc[tm][tn][r] = v;
+                if (row < M) {
+                    s += v;
+                    if (col < ldy) Y[(size_t)row * ldy + col] = v;
+                }
+            }
+        if (STATS) {
+            const int cnt = min(64, M - rowbase);  // rows of this wave inside the tensor (wave-uniform)
+            if (cnt > 0) {
+                s += __shfl_xor(s, 32, 64);
+                const float mean = s / (float)cnt;
+                float q = 0.f;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rowbase + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float d = acc[tm][tn][r] - mean;
+                        if (row < M) q += d * d;
+                    }
+                q += __shfl_xor(q, 32, 64);
+                const int prow = rowbase / CVK_STAT_ROWS;
+                if (col < Cout) {
+                    if (lh == 0) stats[(size_t)prow * Cout + col] = s;
+                    else stats[(size_t)(P + prow) * Cout + col] = q;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight-grad
+// slab[split][co][k] = sum over the split's pixels of dy[m][co] * x[m + tap(k)][ci(k)]
+template <int BM, int BN, int WARPS_M, int WARPS_N>
+__global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
+    const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ slab, int M, int H, int W, int Cin,
+    int Cout, int ld_dy, int Ktot, int chunk, int tilesN) {
+    constexpr int NT = WARPS_M * WARPS_N * 64;
+    constexpr int TM = BM / WARPS_M / 32, TN = BN / WARPS_N / 32;
+    constexpr int VA = BM / 4, VB = BN / 4;      // 16-byte vectors per staged pixel row
+    constexpr int RPA = NT / VA, RPB = NT / VB;  // pixel rows staged per pass
+    constexpr int NA = BK / RPA, NB = BK / RPB;
+    static_assert(NA >= 1 && NB >= 1 && BK % RPA == 0 && BK % RPB == 0, "tile/threads mismatch");
+
+    __shared__ __attribute__((aligned(16))) float smem[BK * (BM + BN)];
+    float* As = smem;             // [BK pixels][BM output channels]
+    float* Bs = smem + BK * BM;   // [BK pixels][BN (tap,ci) columns]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+
+    const int tile = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int c0 = (tile / tilesN) * BM;  // first output channel of the tile
+    const int n0 = (tile % tilesN) * BN;  // first (tap,ci) column of the tile
+    const int mbeg = blockIdx.y * chunk;
+    const int mend = min(M, mbeg + chunk);
+
+    const int cva = tid % VA, pra = tid / VA;
+    const int cvb = tid % VB, prb = tid / VB;
+    const int coA = c0 + cva * 4;
+    const bool aok = coA < Cout;          // Cout is padded to a multiple of 4 by the host (ld_dy % 4 == 0 covers it)
+    const int colB = n0 + cvb * 4;
+    const bool bok = colB < Ktot;
+    const int tapB = bok ? colB / Cin : 0;
+    const int ciB = colB - tapB * Cin;
+    const int dyB = tapB / 3 - 1, dxB = tapB % 3 - 1;
+    const int shiftB = (dyB * W + dxB) * Cin + ciB;
+    const int HW = H * W;
+
+    f32x4 ra[NA], rb[NB];
+    auto load_stage = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = mb + pra + i * RPA;
+            ra[i] = (aok && m < mend) ? *reinterpret_cast<const f32x4*>(DY + (size_t)m * ld_dy + coA)
+                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int m = mb + prb + i * RPB;
+            const int n = m / HW, rem = m - n * HW;
+            const int y = rem / W, x = rem - y * W;
+            const bool ok = bok && m < mend && (unsigned)(y + dyB) < (unsigned)H && (unsigned)(x + dxB) < (unsigned)W;
+            rb[i] = ok ? *reinterpret_cast<const f32x4*>(X + (size_t)m * Cin + shiftB) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nK = (mend - mbeg + BK - 1) / BK;
+    if (nK > 0) load_stage(mbeg);
+    for (int ks = 0; ks < nK; ++ks) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&As[(pra + i * RPA) * BM + cva * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&Bs[(prb + i * RPB) * BN + cvb * 4]) = rb[i];
+        __syncthreads();
+        if (ks + 1 < nK) load_stage(mbeg + (ks + 1) * BK);
+
+        const float* acol = &As[lh * BM + wm * TM * 32 + li];
+        const float* bcol = &Bs[lh * BN + wn * TN * 32 + li];
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) a[t] = acol[2 * s * BM + t * 32];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b[t] = bcol[2 * s * BN + t * 32];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+    }
+
+    float* out = slab + (size_t)blockIdx.y * Cout * Ktot;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = n0 + wn * TN * 32 + tn * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < Cout && col < Ktot) out[(size_t)row * Ktot + col] = acc[tm][tn][r];
+            }
+        }
+}
+
+// dw[co][tap][ci] = sum_s slab[s][co][tap*Cin_pad + ci], fixed order (bitwise reproducible)
+__global__ void k_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dw, int splits, int Cout, int Cin,
+                               int Cin_pad, size_t slab_stride) {
+    const size_t total = (size_t)Cout * 9 * Cin;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        const size_t ct = i / Cin;  // co*9 + tap
+        const float* p = slab + ct * Cin_pad + ci;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int s = 0;
+        for (; s + 4 <= splits; s += 4) {
+            s0 += p[(size_t)(s + 0) * slab_stride];
+            s1 += p[(size_t)(s + 1) * slab_stride];
+            s2 += p[(size_t)(s + 2) * slab_stride];
+            s3 += p[(size_t)(s + 3) * slab_stride];
+        }
+        for (; s < splits; ++s) s0 += p[(size_t)s * slab_stride];
+        dw[i] = (s0 + s1) + (s2 + s3);
+    }
+}
+
+__global__ void k_pack_weight_fwd(const float* __restrict__ src, float* __restrict__ dst, int rows, int Cin, int Cin_pad) {
+    const size_t total = (size_t)rows * Cin_pad;  // rows = Cout*9
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin_pad);
+        const size_t r = i / Cin_pad;
+        dst[i] = ci < Cin ? src[r * Cin + ci] : 0.f;
+    }
+}
+
+// dst[ci][t][co] = src[co][8-t][ci]; 32x32 LDS transpose per tap so both sides stay coalesced
+__global__ void k_pack_weight_dgrad(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int Cin_pad,
+                                    int Cout_pad) {
+    __shared__ float t[32][33];
+    const int tap = blockIdx.z;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int co = co0 + j, ci = ci0 + tx;
+        t[j][tx] = (co < Cout && ci < Cin) ? src[((size_t)co * 9 + (8 - tap)) * Cin + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int ci = ci0 + j, co = co0 + tx;
+        if (ci < Cin_pad && co < Cout_pad) dst[((size_t)ci * 9 + tap) * Cout_pad + co] = t[tx][j];
+    }
+}
+
+// ---- launch-shape heuristics --------------------------------------------------------------------------------------
+// Split the pixel dimension of the weight-grad so that the grid is close to a whole number of rounds over the
+// 256 CUs (equal blocks => efficiency = blocks / (256 * ceil(blocks/256))), keeping >= 16 K-slices per block.
+int choose_splits(int tiles, int M) {
+    const int max_splits = M / (BK * 16) > 0 ? M / (BK * 16) : 1;
+    int best = 1;
+    double best_eff = -1.0;
+    for (int s = 1; s <= max_splits && s <= 2048; ++s) {
+        const long blocks = (long)tiles * s;
+        if (blocks > 4096 && s > 1) break;
+        if (blocks < 512 && s < max_splits) continue;  // want >= 2 co-resident blocks per CU to cover barrier bubbles
+        const long rounds = (blocks + 255) / 256;
+        const double eff = (double)blocks / (256.0 * rounds);
+        if (eff > best_eff + 0.02) {
+            best_eff = eff;
+            best = s;
+        }
+    }
+    return best;
+}
+
+struct WgradPlan {
+    int bm, bn, tilesM, tilesN, splits, chunk;
+};
+
+WgradPlan plan_wgrad(int M, int Cin_pad, int Cout) {
+    WgradPlan p;
+    const int Ktot = 9 * Cin_pad;
+    if (Cout > 64) { p.bm = 128; p.bn = 128; }
+    else if (Cout > 32) { p.bm = 64; p.bn = 128; }
+    else { p.bm = 32; p.bn = 256; }
+    p.tilesM = cvk_cdiv(Cout, p.bm);
+    p.tilesN = cvk_cdiv(Ktot, p.bn);
+    p.splits = choose_splits(p.tilesM * p.tilesN, M);
+    p.chunk = cvk_cdiv(cvk_cdiv(M, p.splits), BK) * BK;
+    p.splits = cvk_cdiv(M, p.chunk);
+    return p;
+}
+
+}  // namespace
+
+// =================================================================================================== C ABI
+extern "C" int cvk_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, float* stats, int N, int H,
+                               int W, int Cin, int Cout, int ldy, void* stream) {
+    CVK_CHECK_ARG(x && w && y, "cvk_conv3x3_fwd: null pointer");
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "cvk_conv3x3_fwd: bad shape N=%d H=%d W=%d Cin=%d Cout=%d", N, H, W, Cin, Cout);
+    CVK_CHECK_ARG(Cin % 4 == 0, "cvk_conv3x3_fwd: Cin=%d must be a multiple of 4 (pad on the host)", Cin);
+    CVK_CHECK_ARG(ldy >= Cout, "cvk_conv3x3_fwd: ldy=%d < Cout=%d", ldy, Cout);
+    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(w), "cvk_conv3x3_fwd: x and w must be 16-byte aligned");
+    CVK_CHECK_ARG((long)N * H * W < (1L << 31) - 512 && (long)H * W * Cin < (1L << 31), "cvk_conv3x3_fwd: tensor too large for 32-bit pixel indices");
+    const int M = N * H * W, Ktot = 9 * Cin, P = cvk_cdiv(M, CVK_STAT_ROWS);
+    hipStream_t s = (hipStream_t)stream;
+#define CVK_CONV_LAUNCH(BM_, BN_, WM_, WN_)                                                                         \
+    do {                                                                                                           \
+        const int tilesN = cvk_cdiv(ldy, BN_), tilesM = cvk_cdiv(M, BM_);                                          \
+        dim3 grid(tilesM* tilesN), block(WM_* WN_ * 64);                                                           \
+        if (stats)                                                                                                 \
+            hipLaunchKernelGGL((k_conv3x3_igemm<BM_, BN_, WM_, WN_, true>), grid, block, 0, s, x, w, bias, y, stats, M, H, \
+                               W, Cin, Cout, ldy, Ktot, P, tilesN);                                                \
+        else                                                                                                       \
+            hipLaunchKernelGGL((k_conv3x3_igemm<BM_, BN_, WM_, WN_, false>), grid, block, 0, s, x, w, bias, y, stats, M, H, \
+                               W, Cin, Cout, ldy, Ktot, P, tilesN);                                                \
+    } while (0)
+    if (ldy > 64) CVK_CONV_LAUNCH(128, 128, 2, 2);
+    else if (ldy > 32) CVK_CONV_LAUNCH(128, 64, 2, 2);
+    else CVK_CONV_LAUNCH(256, 32, 4, 1);
+#undef CVK_CONV_LAUNCH
+    CVK_LAUNCH_RETURN("cvk_conv3x3_fwd");
+}
+
+extern "C" int cvk_pack_weight_fwd(const float* w_src, float* dst, int Cout, int Cin, int Cin_pad, void* stream) {
+    CVK_CHECK_ARG(w_src && dst && Cout > 0 && Cin > 0 && Cin_pad >= Cin, "cvk_pack_weight_fwd: bad arguments");
+    const size_t total = (size_t)Cout * 9 * Cin_pad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_pack_weight_fwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_src, dst, Cout * 9, Cin, Cin_pad);
+    CVK_LAUNCH_RETURN("cvk_pack_weight_fwd");
+}
+
+extern "C" int cvk_pack_weight_dgrad(const float* w_src, float* dst, int Cout, int Cin, int Cin_pad, int Cout_pad,
+                                     void* stream) {
+    CVK_CHECK_ARG(w_src && dst && Cout > 0 && Cin > 0 && Cin_pad >= Cin && Cout_pad >= Cout, "cvk_pack_weight_dgrad: bad arguments");
+    dim3 grid(cvk_cdiv(Cin_pad, 32), cvk_cdiv(Cout_pad, 32), 9);
+    hipLaunchKernelGGL(k_pack_weight_dgrad, grid, dim3(256), 0, (hipStream_t)stream, w_src, dst, Cout, Cin, Cin_pad, Cout_pad);
+    CVK_LAUNCH_RETURN("cvk_pack_weight_dgrad");
+}
+
+extern "C" size_t cvk_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin_pad <= 0 || Cout <= 0) return 0;
+    const WgradPlan p = plan_wgrad(N * H * W, Cin_pad, Cout);
+    return (size_t)p.splits * Cout * 9 * Cin_pad * sizeof(float);
+}
+
+extern "C" int cvk_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,
+                                 int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream) {
+    CVK_CHECK_ARG(x && dy && dw && workspace, "cvk_conv3x3_wgrad: null pointer");
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin_pad >= Cin, "cvk_conv3x3_wgrad: bad shape");
+    CVK_CHECK_ARG(Cin_pad % 4 == 0 && ld_dy % 4 == 0 && ld_dy >= Cout, "cvk_conv3x3_wgrad: Cin_pad=%d and ld_dy=%d must be multiples of 4, ld_dy >= Cout", Cin_pad, ld_dy);
+    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(dy) && cvk_aligned16(workspace), "cvk_conv3x3_wgrad: pointers must be 16-byte aligned");
+    CVK_CHECK_ARG((long)N * H * W < (1L << 31) - 512, "cvk_conv3x3_wgrad: tensor too large");
+    const int M = N * H * W, Ktot = 9 * Cin_pad;
+    const WgradPlan p = plan_wgrad(M, Cin_pad, Cout);
+    const size_t need = (size_t)p.splits * Cout * Ktot * sizeof(float);
+    if (workspace_bytes < need) {
+        cvk_set_error("cvk_conv3x3_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
+        return CVK_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float* slab = (float*)workspace;
+    dim3 grid(p.tilesM * p.tilesN, p.splits);
+    // dy columns [Cout, ld_dy) are zero by contract, so the last 16-byte vector of a row may straddle Cout
+    if (p.bm == 128)
+        hipLaunchKernelGGL((k_conv3x3_wgrad<128, 128, 2, 2>), grid, dim3(256), 0, s, x, dy, slab, M, H, W, Cin_pad, Cout, ld_dy, Ktot, p.chunk, p.tilesN);
+    else if (p.bm == 64)
+        hipLaunchKernelGGL((k_conv3x3_wgrad<64, 128, 2, 2>), grid, dim3(256), 0, s, x, dy, slab, M, H, W, Cin_pad, Cout, ld_dy, Ktot, p.chunk, p.tilesN);
+    else
+        hipLaunchKernelGGL((k_conv3x3_wgrad<32, 256, 1, 4>), grid, dim3(256), 0, s, x, dy, slab, M, H, W, Cin_pad, Cout, ld_dy, Ktot, p.chunk, p.tilesN);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        cvk_set_error("cvk_conv3x3_wgrad: launch failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    const size_t total = (size_t)Cout * 9 * Cin;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, s, slab, dw, p.splits, Cout, Cin, Cin_pad, (size_t)Cout * Ktot);
+    CVK_LAUNCH_RETURN("cvk_conv3x3_wgrad");
+}

@@ -1,0 +1,486 @@
+"""Static-plan executor for the conv/BN/ReLU/pool/upsample/concat hot path.
+
+A network's `forward` (reference models/unet.py:94-156, models/segnet.py:82-119) is recorded ONCE per input shape as
+a list of ops over NHWC fp32 activation buffers, then replayed: forward launches the libcvk kernels in order on the
+current HIP stream, backward replays the list in reverse with explicit gradient buffers.  The whole network is ONE
+autograd node (`_PlanFunction`), so PyTorch autograd sees `(input, *parameters) -> logits` and nothing in between:
+no per-layer Python autograd overhead, no tensor version counters on the in-place concat writes, and the executor
+knows exactly when each parameter gradient is final (the hook data-parallel bucketing uses, see ddp.py).
+
+Buffers are torch tensors (caching allocator); concat is zero-copy: the upsample branch and the encoder stage write
+into the two channel halves of one pre-sized buffer through strided views (cvk_view).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import View, check
+
+_F32 = torch.float32
+
+
+def pad4(c):
+    return (c + 3) // 4 * 4
+
+
+class ActBuf:
+    """Logical NHWC activation buffer [N,H,W,C] stored with pixel stride ld = pad4(C)."""
+    __slots__ = ("id", "N", "H", "W", "C", "ld", "name")
+
+    def __init__(self, id_, N, H, W, C, name=""):
+        self.id, self.N, self.H, self.W, self.C, self.ld, self.name = id_, N, H, W, C, pad4(C), name
+
+    @property
+    def M(self):
+        return self.N * self.H * self.W
+
+    def full_view(self):
+        return BufView(self, 0, self.C, 0, 0, self.H, self.W)
+
+    def __repr__(self):
+        return f"ActBuf({self.name}#{self.id} {self.N}x{self.H}x{self.W}x{self.C}/{self.ld})"
+
+
+class BufView:
+    """Channel slice [c0, c0+C) and spatial window [y0,y0+H) x [x0,x0+W) of an ActBuf."""
+    __slots__ = ("buf", "c0", "C", "y0", "x0", "H", "W")
+
+    def __init__(self, buf, c0, C, y0, x0, H, W):
+        assert 0 <= c0 and c0 + C <= buf.ld and 0 <= y0 and y0 + H <= buf.H and 0 <= x0 and x0 + W <= buf.W
+        self.buf, self.c0, self.C, self.y0, self.x0, self.H, self.W = buf, c0, C, y0, x0, H, W
+
+    def cview(self, tensor):
+        b = self.buf
+        ptr = tensor.data_ptr() + 4 * ((self.y0 * b.W + self.x0) * b.ld + self.c0)
+        return View(ptr, b.H * b.W * b.ld, b.W * b.ld, b.ld)
+
+    @property
+    def is_full(self):
+        b = self.buf
+        return self.c0 == 0 and self.C == b.C and self.y0 == 0 and self.x0 == 0 and self.H == b.H and self.W == b.W
+
+
+class RunState:
+    """Per-forward-call tensors: activations, saved-for-backward, gradient buffers."""
+
+    def __init__(self, params, training, need_grad):
+        self.params = params
+        self.training = training
+        self.need_grad = need_grad
+        self.act = {}      # buf.id -> tensor [N,H,W,ld]
+        self.saved = {}    # op index -> tuple
+        self.grad = {}     # buf.id -> grad tensor
+        self.gflat = None
+        self.stream = None
+        self.sync = None   # optional gradient synchroniser (ddp.GradSync)
+
+
+def _empty(n, dev, dtype=_F32):
+    return torch.empty(n, device=dev, dtype=dtype)
+
+
+# ===================================================================================================== ops
+class Op:
+    idx = -1
+
+    def fwd(self, R, st):
+        raise NotImplementedError
+
+    def bwd(self, R, st):
+        pass
+
+
+class ConvBnRelu(Op):
+    """ReLU(BN(conv3x3(x)+b)) — reference BasicConv2d (models/unet.py:5-17) / BasicConv (models/segnet.py:5-17)."""
+
+    def __init__(self, src, dst, pslot, holder, cin, cout, src_needs_grad):
+        self.src, self.dst, self.pslot, self.holder = src, dst, pslot, holder
+        self.cin, self.cout, self.src_needs_grad = cin, cout, src_needs_grad
+        assert src.C == cin and dst.C == cout and dst.H == src.H and dst.W == src.W
+
+    def _weight_fwd(self, R, st, w):
+        """[Cout][9][ld_in]: the parameter itself when it is channels_last and needs no channel padding."""
+        ldx = self.src.ld
+        if ldx == self.cin and w.is_contiguous(memory_format=torch.channels_last):
+            return w
+        wc = w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last)
+        out = _empty(self.cout * 9 * ldx, w.device)
+        check(R.lib.cvk_pack_weight_fwd(wc.data_ptr(), out.data_ptr(), self.cout, self.cin, ldx, st.stream), "cvk_pack_weight_fwd")
+        return out
+
+    def fwd(self, R, st):
+        lib, s = R.lib, st.stream
+        src, dst = self.src, self.dst
+        X = st.act[src.id]
+        w, b, gamma, beta = st.params[4 * self.pslot:4 * self.pslot + 4]
+        dev = X.device
+        N, H, W = src.N, src.H, src.W
+        M, C, ldy = src.M, self.cout, pad4(self.cout)
+        wk = self._weight_fwd(R, st, w)
+        y = _empty(M * ldy, dev)
+        bnp = _empty(4 * ldy, dev)                      # mean | rstd | scale | shift
+        pm, pr, psc, psh = (bnp.data_ptr() + 4 * ldy * i for i in range(4))
+        conv, bn = self.holder.conv_bn()
+        if st.training:
+            P = (M + _lib.CVK_STAT_ROWS - 1) // _lib.CVK_STAT_ROWS
+            stats = _empty(2 * P * C, dev)
+            check(lib.cvk_conv3x3_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(),
+                                      N, H, W, src.ld, C, ldy, s), "cvk_conv3x3_fwd")
+            if M <= 1:
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size {[N, C, H, W]}")
+            wsb = lib.cvk_bn_finalize_workspace_bytes(P, C)
+            ws = R.workspace(wsb, dev)
+            track = bn.track_running_stats and bn.running_mean is not None
+            mom = 0.1 if bn.momentum is None else float(bn.momentum)
+            check(lib.cvk_bn_finalize(stats.data_ptr(), P, M, C, gamma.data_ptr(), beta.data_ptr(), pm, pr, psc, psh,
+                                      bn.running_mean.data_ptr() if track else None,
+                                      bn.running_var.data_ptr() if track else None,
+                                      bn.num_batches_tracked.data_ptr() if track else None,
+                                      mom, float(bn.eps), ws.data_ptr(), wsb, s), "cvk_bn_finalize")
+        else:
+            check(lib.cvk_conv3x3_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), None,
+                                      N, H, W, src.ld, C, ldy, s), "cvk_conv3x3_fwd")
+            check(lib.cvk_bn_eval_params(gamma.data_ptr(), beta.data_ptr(), bn.running_mean.data_ptr(),
+                                         bn.running_var.data_ptr(), pm, pr, psc, psh, C, float(bn.eps), s), "cvk_bn_eval_params")
+        out = R.alloc_act(st, dst.buf, dev)
+        check(lib.cvk_bn_relu_apply(y.data_ptr(), ldy, psc, psh, dst.cview(out), N, H, W, C, s), "cvk_bn_relu_apply")
+        if st.need_grad:
+            st.saved[self.idx] = (y, bnp)
+
+    def bwd(self, R, st):
+        lib, s = R.lib, st.stream
+        src, dst = self.src, self.dst
+        y, bnp = st.saved.pop(self.idx)
+        X = st.act[src.id]
+        dev = X.device
+        N, H, W = src.N, src.H, src.W
+        M, C, ldy = src.M, self.cout, pad4(self.cout)
+        pm, pr, psc, psh = (bnp.data_ptr() + 4 * ldy * i for i in range(4))
+        w = st.params[4 * self.pslot]
+        gw, gb, gg, gbe = R.grad_ptrs(st, self.pslot)
+        dO = dst.cview(st.grad[dst.buf.id])
+        PB = lib.cvk_bn_bwd_blocks(M)
+        part = _empty(2 * PB * C, dev)
+        check(lib.cvk_bn_bwd_reduce(dO, y.data_ptr(), ldy, psc, psh, pm, pr, part.data_ptr(), N, H, W, C, s), "cvk_bn_bwd_reduce")
+        check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, gbe, gg, s), "cvk_colsum_finalize")   # dbeta, dgamma
+        dy = torch.zeros(M * ldy, device=dev, dtype=_F32) if ldy != C else _empty(M * ldy, dev)
+        check(lib.cvk_bn_bwd_dx(dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, part.data_ptr(),
+                                N, H, W, C, 1 if st.training else 0, s), "cvk_bn_bwd_dx")
+        check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, gb, None, s), "cvk_colsum_finalize")  # conv bias grad
+        del y
+        if self.src_needs_grad:
+            if src.id in st.grad:
+                raise NotImplementedError("conv data-grad must be the first writer of its input's gradient buffer")
+            wc = w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last)
+            wd = _empty(src.ld * 9 * ldy, dev)
+            check(lib.cvk_pack_weight_dgrad(wc.data_ptr(), wd.data_ptr(), C, self.cin, src.ld, ldy, s), "cvk_pack_weight_dgrad")
+            dX = _empty(M * src.ld, dev).view(N, H, W, src.ld)
+            check(lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
+                  "cvk_conv3x3_fwd(dgrad)")
+            st.grad[src.id] = dX
+        wsb = lib.cvk_conv3x3_wgrad_workspace_bytes(N, H, W, src.ld, C)
+        ws = R.workspace(wsb, dev)
+        check(lib.cvk_conv3x3_wgrad(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
+              "cvk_conv3x3_wgrad")
+        R.grads_ready(st, self.pslot)
+
+
+class MaxPool(Op):
+    """nn.MaxPool2d(2,2) (models/unet.py:92) / with indices (models/segnet.py:79)."""
+
+    def __init__(self, src_view, dst_buf, keep_code):
+        self.src, self.dst, self.keep_code = src_view, dst_buf, keep_code
+        if src_view.H < 2 or src_view.W < 2:
+            raise RuntimeError(f"max_pool2d: input {src_view.H}x{src_view.W} is too small for a 2x2 window")
+
+    def fwd(self, R, st):
+        v, d = self.src, self.dst
+        X = st.act[v.buf.id]
+        out = R.alloc_act(st, d, X.device)
+        code = None
+        if self.keep_code:
+            code = torch.empty(d.M * d.ld, device=X.device, dtype=torch.uint8)
+            st.saved[self.idx] = code
+        check(R.lib.cvk_maxpool2x2_fwd(v.cview(X), out.data_ptr(), code.data_ptr() if code is not None else None,
+                                       v.buf.N, v.H, v.W, v.C, st.stream), "cvk_maxpool2x2_fwd")
+
+    def bwd(self, R, st):
+        v, d = self.src, self.dst
+        if d.id not in st.grad:
+            return
+        X = st.act[v.buf.id]
+        acc = v.buf.id in st.grad
+        if not acc:
+            if not v.is_full:
+                st.grad[v.buf.id] = torch.zeros_like(X)
+            else:
+                st.grad[v.buf.id] = torch.empty_like(X)
+        code = st.saved.get(self.idx)
+        check(R.lib.cvk_maxpool2x2_bwd(st.grad[d.id].data_ptr(), v.cview(X), code.data_ptr() if code is not None else None,
+                                       v.cview(st.grad[v.buf.id]), 1 if acc else 0, v.buf.N, v.H, v.W, v.C, st.stream),
+              "cvk_maxpool2x2_bwd")
+        st.grad.pop(d.id)
+
+
+class Unpool(Op):
+    """nn.MaxUnpool2d(2)(x, idx, output_size) (models/segnet.py:80,104-116)."""
+
+    def __init__(self, src_buf, pool_op, dst_buf):
+        self.src, self.pool, self.dst = src_buf, pool_op, dst_buf
+
+    def fwd(self, R, st):
+        V = st.act[self.src.id]
+        code = st.saved[self.pool.idx]
+        d = self.dst
+        out = R.alloc_act(st, d, V.device)
+        check(R.lib.cvk_maxunpool2x2_fwd(V.data_ptr(), code.data_ptr(), out.data_ptr(), d.N, d.H, d.W, d.ld, st.stream),
+              "cvk_maxunpool2x2_fwd")
+
+    def bwd(self, R, st):
+        d = self.dst
+        g = st.grad.pop(d.id)
+        code = st.saved[self.pool.idx]
+        dv = torch.empty_like(st.act[self.src.id])
+        check(R.lib.cvk_maxunpool2x2_bwd(g.data_ptr(), code.data_ptr(), dv.data_ptr(), d.N, d.H, d.W, d.ld, st.stream),
+              "cvk_maxunpool2x2_bwd")
+        assert self.src.id not in st.grad
+        st.grad[self.src.id] = dv
+
+
+class Upsample(Op):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (models/unet.py:25)."""
+
+    def __init__(self, src_buf, dst_buf):
+        self.src, self.dst = src_buf, dst_buf
+
+    def fwd(self, R, st):
+        X = st.act[self.src.id]
+        out = R.alloc_act(st, self.dst, X.device)
+        b = self.src
+        check(R.lib.cvk_bilinear_up2_fwd(X.data_ptr(), out.data_ptr(), b.N, b.H, b.W, b.ld, st.stream), "cvk_bilinear_up2_fwd")
+
+    def bwd(self, R, st):
+        g = st.grad.pop(self.dst.id)
+        b = self.src
+        dx = torch.empty_like(st.act[b.id])
+        check(R.lib.cvk_bilinear_up2_bwd(g.data_ptr(), dx.data_ptr(), b.N, b.H, b.W, b.ld, st.stream), "cvk_bilinear_up2_bwd")
+        assert b.id not in st.grad
+        st.grad[b.id] = dx
+
+
+class ZeroFrame(Op):
+    """The F.pad border of models/unet.py:120-123, written in place into the concat buffer (forward only)."""
+
+    def __init__(self, view):
+        self.view = view
+
+    def fwd(self, R, st):
+        v = self.view
+        b = v.buf
+        t = R.alloc_act(st, b, st.device)
+        chan = BufView(b, v.c0, v.C, 0, 0, b.H, b.W)
+        check(R.lib.cvk_zero_frame(chan.cview(t), b.N, b.H, b.W, v.C, v.y0, v.x0, v.H, v.W, st.stream), "cvk_zero_frame")
+
+
+# ===================================================================================================== plan
+class Plan:
+    """Recorded op list for one (N, H, W) input geometry."""
+
+    def __init__(self, N, cin, H, W):
+        self.N, self.cin, self.H, self.W = N, cin, H, W
+        self.bufs, self.ops, self.holders = [], [], []
+        self.input = self.new_buf(cin, H, W, "input")
+        self.output = None
+        self.input_needs_grad = False
+
+    def new_buf(self, C, H, W, name=""):
+        b = ActBuf(len(self.bufs), self.N, H, W, C, name)
+        self.bufs.append(b)
+        return b
+
+    def add(self, op):
+        op.idx = len(self.ops)
+        self.ops.append(op)
+        return op
+
+    # ---- builders used by the modules -----------------------------------------------------------------------
+    def conv_bn_relu(self, src_buf, holder, dst_view=None):
+        cin, cout = holder.in_channels, holder.out_channels
+        if src_buf.C != cin:
+            raise RuntimeError(f"Given groups=1, weight of size [{cout}, {cin}, 3, 3], expected input[{src_buf.N}, {src_buf.C}, "
+                               f"{src_buf.H}, {src_buf.W}] to have {cin} channels, but got {src_buf.C} channels instead")
+        if dst_view is None:
+            dst_view = self.new_buf(cout, src_buf.H, src_buf.W, holder.tag).full_view()
+        pslot = len(self.holders)
+        self.holders.append(holder)
+        needs = src_buf is not self.input or self.input_needs_grad
+        self.add(ConvBnRelu(src_buf, dst_view, pslot, holder, cin, cout, needs))
+        return dst_view
+
+    def maxpool(self, src_view, keep_code=False):
+        dst = self.new_buf(src_view.C, src_view.H // 2, src_view.W // 2, "pool")
+        return self.add(MaxPool(src_view, dst, keep_code))
+
+    def unpool(self, src_buf, pool_op):
+        v = pool_op.src
+        dst = self.new_buf(v.C, v.H, v.W, "unpool")
+        self.add(Unpool(src_buf, pool_op, dst))
+        return dst
+
+    def upsample(self, src_buf):
+        dst = self.new_buf(src_buf.C, 2 * src_buf.H, 2 * src_buf.W, "up")
+        self.add(Upsample(src_buf, dst))
+        return dst
+
+    def zero_frame(self, view):
+        self.add(ZeroFrame(view))
+
+
+class Runner:
+    """Executes a Plan.  One Runner per module instance; plans are cached per input geometry."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self._ws = None
+        self.grad_sync = None       # set by ddp.DataParallel
+        self._flat = [None, None]   # alternating flat gradient buffers (see grad_flat)
+
+    def workspace(self, nbytes, dev):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            self._ws = torch.empty(max(nbytes, 1 << 20), device=dev, dtype=torch.uint8)
+        return self._ws
+
+    def alloc_act(self, st, buf, dev):
+        t = st.act.get(buf.id)
+        if t is None:
+            shape = (buf.N, buf.H, buf.W, buf.ld)
+            t = torch.zeros(shape, device=dev, dtype=_F32) if buf.ld != buf.C else torch.empty(shape, device=dev, dtype=_F32)
+            st.act[buf.id] = t
+        return t
+
+    # ---- flat gradient buffer: parameter grads are views, laid out in REVERSE execution order --------------------
+    def layout_grads(self, plan, params):
+        """offsets (in floats) of every parameter inside the flat buffer; last-executed layer first."""
+        offs = [0] * len(params)
+        o = 0
+        for slot in range(len(plan.holders) - 1, -1, -1):
+            for j in range(4):
+                i = 4 * slot + j
+                offs[i] = o
+                o += (params[i].numel() + 3) // 4 * 4     # keep every view 16-byte aligned
+        return offs, o
+
+    def grad_ptrs(self, st, slot):
+        base = st.gflat.data_ptr()
+        return tuple(base + 4 * st.goffs[4 * slot + j] for j in range(4))
+
+    def grads_ready(self, st, slot):
+        if st.sync is not None:
+            st.sync.layer_done(st, slot)
+
+    # ---- forward / backward -------------------------------------------------------------------------------------
+    def forward(self, plan, x, params, training, need_grad):
+        dev = x.device
+        st = RunState(params, training, need_grad)
+        st.device = dev
+        st.plan = plan
+        st.stream = torch.cuda.current_stream(dev).cuda_stream
+        inb = plan.input
+        xp = x.permute(0, 2, 3, 1)
+        if inb.ld == inb.C and xp.is_contiguous():
+            st.act[inb.id] = xp                               # already dense NHWC: zero-copy
+        else:
+            t = torch.empty((inb.N, inb.H, inb.W, inb.ld), device=dev, dtype=_F32)
+            sN, sC, sH, sW = x.stride()
+            check(self.lib.cvk_import_nchw(x.data_ptr(), sN, sC, sH, sW, t.data_ptr(), inb.ld, inb.N, inb.C, inb.H, inb.W,
+                                           st.stream), "cvk_import_nchw")
+            st.act[inb.id] = t
+        for op in plan.ops:
+            op.fwd(self, st)
+        ov = plan.output
+        out = st.act[ov.buf.id][..., :ov.buf.C].permute(0, 3, 1, 2)    # logical NCHW, channels_last strides
+        if not need_grad:
+            st.act.clear()
+            st.saved.clear()
+        return out, st
+
+    def backward(self, plan, st, gout):
+        dev = gout.device
+        st.stream = torch.cuda.current_stream(dev).cuda_stream
+        params = st.params
+        st.goffs, total = self.layout_grads(plan, params)
+        st.gflat = self.grad_flat(total, dev, params, st.goffs)
+        st.sync = self.grad_sync
+        if st.sync is not None:
+            st.sync.begin(st, plan)
+        ob = plan.output.buf
+        gp = gout.permute(0, 2, 3, 1)
+        if ob.ld == ob.C and gp.is_contiguous():
+            st.grad[ob.id] = gp
+        else:
+            g = torch.zeros((ob.N, ob.H, ob.W, ob.ld), device=dev, dtype=_F32) if ob.ld != ob.C else \
+                torch.empty((ob.N, ob.H, ob.W, ob.ld), device=dev, dtype=_F32)
+            sN, sC, sH, sW = gout.stride()
+            check(self.lib.cvk_import_nchw(gout.data_ptr(), sN, sC, sH, sW, g.data_ptr(), ob.ld, ob.N, ob.C, ob.H, ob.W,
+                                           st.stream), "cvk_import_nchw")
+            st.grad[ob.id] = g
+        for op in reversed(plan.ops):
+            op.bwd(self, st)
+        dx = None
+        if plan.input_needs_grad:
+            gi = st.grad[plan.input.id]
+            dx = gi[..., :plan.input.C].permute(0, 3, 1, 2)
+        grads = []
+        for i, p in enumerate(params):
+            n = p.numel()
+            seg = st.gflat[st.goffs[i]:st.goffs[i] + n]
+            if p.dim() == 4:   # [Cout][3][3][Cin] storage -> logical OIHW with channels_last strides
+                co, ci, kh, kw = p.shape
+                seg = seg.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+            else:
+                seg = seg.view(p.shape)
+            grads.append(seg)
+        if st.sync is not None:
+            st.sync.finish(st)
+        st.act.clear(); st.saved.clear(); st.grad.clear()
+        return dx, grads
+
+    def grad_flat(self, total, dev, params, offs):
+        """Pick a flat buffer that no live `.grad` aliases (autograd accumulates INTO an existing .grad; writing our
+        fresh gradients over it first would double them).  With zero_grad(set_to_none=True) slot 0 is always free."""
+        for k in range(2):
+            f = self._flat[k]
+            if f is None or f.numel() != total or f.device != dev:
+                f = self._flat[k] = torch.empty(total, device=dev, dtype=_F32)
+            lo, hi = f.data_ptr(), f.data_ptr() + 4 * total
+            if not any(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in params):
+                return f
+        return torch.empty(total, device=dev, dtype=_F32)
+
+
+class _PlanFunction(torch.autograd.Function):
+    """The whole recorded network as one autograd node: (x, *parameters) -> logits."""
+
+    @staticmethod
+    def forward(ctx, runner, plan, training, x, *params):
+        out, st = runner.forward(plan, x, params, training, True)
+        ctx.runner, ctx.plan, ctx.st = runner, plan, st
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        st = ctx.st
+        if st is None:
+            raise RuntimeError("Trying to backward through the plan a second time (activations were already freed)")
+        ctx.st = None
+        dx, grads = ctx.runner.backward(ctx.plan, st, gout)
+        return (None, None, None, dx, *grads)
+
+
+def run_plan(runner, plan, training, x, params):
+    need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+    if not need:
+        out, _ = runner.forward(plan, x, params, training, False)
+        return out
+    return _PlanFunction.apply(runner, plan, training, x, *params)

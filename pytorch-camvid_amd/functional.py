@@ -1,0 +1,123 @@
+"""Loss / evaluation operators of the hot path as autograd-aware callables on HIP tensors.
+
+  CrossEntropyLoss  <- nn.CrossEntropyLoss() of reference train.py:105 (mean over N*H*W, no ignored class)
+  argmax_channels   <- preds.argmax(dim=1) of train.py:191
+  ConfusionMeter    <- utils.intersect_and_union / mean_iou (utils.py:162-228) accumulated on device, with the
+                       np.float crash (utils.py:210) and the per-batch-sum bug of train.py:192-206 not reproduced
+                       (SURVEY.md §0.5): IoU = sum(intersection)/sum(union) per class over the whole set.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _as_nhwc(logits):
+    """[N,C,H,W] logical -> (tensor whose memory is dense NHWC rows, ld).  Zero-copy for channels_last producers
+    (our networks return channels_last strides), one copy otherwise."""
+    if logits.dim() != 4:
+        raise ValueError("expected logits of shape [N, C, H, W]")
+    p = logits.permute(0, 2, 3, 1)
+    if p.is_contiguous():
+        return p, logits.shape[1]
+    st = p.stride()
+    N, H, W, C = p.shape
+    if st[3] == 1 and st[2] >= C and st[1] == st[2] * W and st[0] == st[1] * H:
+        return p, st[2]                                   # padded pixel stride (ld > C)
+    return p.contiguous(), C
+
+
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, grad_scale):
+        lib = _lib.load()
+        if not logits.is_cuda:
+            raise RuntimeError("pytorch_camvid_amd.CrossEntropyLoss needs HIP tensors (no CPU fallback)")
+        if logits.dtype != torch.float32 or target.dtype != torch.int64:
+            raise RuntimeError(f"expected float32 logits and int64 target, got {logits.dtype} / {target.dtype}")
+        N, C, H, W = logits.shape
+        if tuple(target.shape) != (N, H, W):
+            raise ValueError(f"Expected target size {[N, H, W]}, got {list(target.shape)}")
+        lg, ld = _as_nhwc(logits)
+        tg = target.contiguous()
+        M = N * H * W
+        part = torch.empty(lib.cvk_ce_blocks(M), device=logits.device, dtype=torch.float32)
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        check(lib.cvk_softmax_ce_fwd(lg.data_ptr(), ld, tg.data_ptr(), part.data_ptr(), loss.data_ptr(), M, C, _stream(logits)),
+              "cvk_softmax_ce_fwd")
+        ctx.save_for_backward(lg, tg)
+        ctx.meta = (N, C, H, W, ld, grad_scale)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        lg, tg = ctx.saved_tensors
+        N, C, H, W, ld, grad_scale = ctx.meta
+        M = N * H * W
+        d = torch.empty((N, H, W, C), device=lg.device, dtype=torch.float32)
+        g = gout.contiguous()
+        check(lib.cvk_softmax_ce_bwd(lg.data_ptr(), ld, tg.data_ptr(), g.data_ptr(), float(grad_scale), d.data_ptr(), C, M, C,
+                                     _stream(lg)), "cvk_softmax_ce_bwd")
+        return d.permute(0, 3, 1, 2), None, None
+
+
+class CrossEntropyLoss(nn.Module):
+    """Drop-in for the reference's `nn.CrossEntropyLoss()` (train.py:105): defaults only — reduction='mean', no class
+    weights, no label smoothing; targets are int64 class indices in [0, C).  `grad_scale` multiplies the backward only
+    (data-parallel training folds 1/world_size in here so the gradient all-reduce is a plain sum)."""
+
+    def __init__(self, grad_scale=1.0):
+        super().__init__()
+        self.grad_scale = grad_scale
+
+    def forward(self, logits, target):
+        return _CrossEntropy.apply(logits, target, self.grad_scale)
+
+
+def cross_entropy(logits, target):
+    return _CrossEntropy.apply(logits, target, 1.0)
+
+
+def argmax_channels(logits):
+    """preds.argmax(dim=1) (train.py:191): int64 [N,H,W]; first maximum wins."""
+    lib = _lib.load()
+    N, C, H, W = logits.shape
+    lg, ld = _as_nhwc(logits.detach())
+    out = torch.empty((N, H, W), device=logits.device, dtype=torch.int64)
+    check(lib.cvk_argmax_channels(lg.data_ptr(), ld, out.data_ptr(), N * H * W, C, _stream(logits)), "cvk_argmax_channels")
+    return out
+
+
+class ConfusionMeter:
+    """Device-side accumulation of per-class intersection / prediction / label pixel counts (utils.py:162-190)."""
+
+    def __init__(self, num_classes=12, ignore_index=11, device="cuda"):
+        self.num_classes, self.ignore_index = num_classes, ignore_index
+        self.hist = torch.zeros((3, num_classes), device=device, dtype=torch.int64)
+
+    def reset(self):
+        self.hist.zero_()
+
+    def update(self, pred, label):
+        lib = _lib.load()
+        p = pred.contiguous(); l = label.contiguous()
+        if p.dtype != torch.int64 or l.dtype != torch.int64 or p.shape != l.shape:
+            raise ValueError("pred and label must be int64 tensors of the same shape")
+        check(lib.cvk_confusion_accumulate(p.data_ptr(), l.data_ptr(), self.hist.data_ptr(), p.numel(), self.num_classes,
+                                           self.ignore_index, _stream(p)), "cvk_confusion_accumulate")
+
+    def compute(self):
+        """(overall accuracy, per-class IoU tensor, mIoU over the non-ignored classes) — one device->host copy."""
+        h = self.hist.cpu().double()
+        inter, pred, lab = h[0], h[1], h[2]
+        union = pred + lab - inter
+        iou = inter / union
+        valid = [c for c in range(self.num_classes) if c != self.ignore_index]
+        acc = float(inter.sum() / lab.sum().clamp(min=1))
+        return acc, iou, float(torch.nanmean(iou[valid]))

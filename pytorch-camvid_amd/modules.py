@@ -1,0 +1,248 @@
+"""Drop-in nn.Module surface of the reference's model zoo, executed by libcvk on MI355X.
+
+Same constructor signatures, attribute tree, parameter registration order (= RNG consumption order, so
+`torch.manual_seed(s); UNet(3, 12)` initialises bit-identically to the reference) and state_dict keys as
+  models/unet.py:5-17  BasicConv2d      models/unet.py:19-32  UpSample2d      models/unet.py:35-156 UNet
+  models/segnet.py:5-17 BasicConv       models/segnet.py:19-119 SegNet        utils.py:147-160      get_model
+The torch.nn.Conv2d / BatchNorm2d children are kept ONLY as parameter/buffer containers (state_dict, .cuda(),
+optimizers, checkpoints all work unchanged); their forward is never called.  forward() records a static plan for the
+input geometry (engine.Plan) and replays it with hand-written HIP kernels; there is no eager/CPU fallback.
+"""
+import weakref
+
+import torch
+import torch.nn as nn
+
+from . import engine
+from .engine import BufView
+
+
+def _channels_last_(conv):
+    """Store OIHW weights physically as [Cout][3][3][Cin] (KRSC): the layout the implicit-GEMM kernels read, so
+    no per-step re-layout of 138 MB of weights.  Logical shape and values are unchanged (state_dict compatible)."""
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+
+
+class _Block(nn.Module):
+    """Shared machinery of the two conv+BN+ReLU block flavours."""
+    tag = "cbr"
+
+    def conv_bn(self):
+        raise NotImplementedError
+
+    @property
+    def in_channels(self):
+        return self.conv_bn()[0].in_channels
+
+    @property
+    def out_channels(self):
+        return self.conv_bn()[0].out_channels
+
+    def block_params(self):
+        c, b = self.conv_bn()
+        return [c.weight, c.bias, b.weight, b.bias]
+
+    def _emit(self, plan, src_buf, dst_view=None):
+        return plan.conv_bn_relu(src_buf, self, dst_view)
+
+    def forward(self, x):
+        return _run(self, x)
+
+
+class BasicConv2d(_Block):
+    """Conv2d(3x3, pad 1, bias) + BatchNorm2d + ReLU; keys conv.0.*, conv.1.* (reference models/unet.py:5-17)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(in_channels, out_channels, 3, padding=1), nn.BatchNorm2d(out_channels),
+                                  nn.ReLU(inplace=True))
+        _channels_last_(self.conv[0])
+
+    def conv_bn(self):
+        return self.conv[0], self.conv[1]
+
+
+class BasicConv(_Block):
+    """Same block with SegNet's attribute names conv / bn / relu (reference models/segnet.py:5-17)."""
+
+    def __init__(self, input_channels, out_channels):
+        super().__init__()
+        self.conv = nn.Conv2d(input_channels, out_channels, 3, padding=1)
+        self.bn = nn.BatchNorm2d(out_channels)
+        self.relu = nn.ReLU()
+        _channels_last_(self.conv)
+
+    def conv_bn(self):
+        return self.conv, self.bn
+
+
+class UpSample2d(nn.Module):
+    """Bilinear x2 (align_corners=True) followed by BasicConv2d (reference models/unet.py:19-32; the scale_factor
+    argument is accepted and ignored exactly as there)."""
+
+    def __init__(self, in_channels, out_channels, scale_factor=2.0):
+        super().__init__()
+        self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+        self.conv = BasicConv2d(in_channels, out_channels)
+
+    def _emit(self, plan, src_buf, dst_view=None):
+        return self.conv._emit(plan, plan.upsample(src_buf), dst_view)
+
+    def forward(self, x):
+        return _run(self, x)
+
+
+class _Stage(nn.Sequential):
+    """nn.Sequential of blocks that can also emit itself into a plan."""
+
+    def _emit(self, plan, src_buf, dst_view=None):
+        n = len(self)
+        v = None
+        for i, blk in enumerate(self):
+            v = blk._emit(plan, src_buf, dst_view if i == n - 1 else None)
+            src_buf = v.buf
+        return v
+
+    def forward(self, x):
+        return _run(self, x)
+
+
+_UNET_WIDTHS = (64, 128, 256, 512, 1024)
+
+
+class UNet(nn.Module):
+    """reference models/unet.py:35-156.  Registration order: down1..down5, then per level upsample_k, up_k, then
+    output, maxpool — the reference's order, so default init consumes the RNG identically."""
+
+    def __init__(self, input_channels, class_num):
+        super().__init__()
+        cin = input_channels
+        for k, w in enumerate(_UNET_WIDTHS, 1):
+            self.add_module(f"down{k}", _Stage(BasicConv2d(cin, w), BasicConv2d(w, w)))
+            cin = w
+        for k in range(1, 5):
+            wide, narrow = _UNET_WIDTHS[5 - k], _UNET_WIDTHS[4 - k]
+            self.add_module(f"upsample{k}", UpSample2d(wide, narrow))
+            self.add_module(f"up{k}", _Stage(BasicConv2d(wide, narrow), BasicConv2d(narrow, narrow)))
+        self.output = BasicConv2d(_UNET_WIDTHS[0], class_num)
+        self.maxpool = nn.MaxPool2d(2, 2)
+
+    def _emit(self, plan, src_buf, dst_view=None):
+        cats = []
+        t = src_buf
+        for k in range(1, 5):
+            stage = getattr(self, f"down{k}")
+            w = stage[-1].out_channels
+            # the skip tensor is produced directly inside channels [w, 2w) of the level's concat buffer
+            cat = plan.new_buf(2 * w, t.H, t.W, f"cat{k}")
+            skip = stage._emit(plan, t, BufView(cat, w, w, 0, 0, t.H, t.W))
+            cats.append((cat, skip))
+            t = plan.maxpool(skip).dst
+        t = self.down5._emit(plan, t).buf
+        for k in range(1, 5):
+            cat, skip = cats[4 - k]
+            w = skip.C
+            uh, uw = 2 * t.H, 2 * t.W
+            dh, dw = cat.H - uh, cat.W - uw            # models/unet.py:117-123: pad [dw//2, dw-dw//2, dh//2, dh-dh//2]
+            if dh < 0 or dw < 0:
+                raise RuntimeError("upsampled branch larger than the skip tensor (negative padding is not supported)")
+            win = BufView(cat, 0, w, dh // 2, dw // 2, uh, uw)
+            if dh or dw:
+                plan.zero_frame(win)
+            getattr(self, f"upsample{k}")._emit(plan, t, win)
+            t = getattr(self, f"up{k}")._emit(plan, cat).buf
+        return self.output._emit(plan, t, dst_view)
+
+    def forward(self, x):
+        return _run(self, x)
+
+
+_SEGNET = (("encoder1", (None, 64, 64)), ("encoder2", (64, 128, 128)), ("encoder3", (128, 256, 256, 256)),
+           ("encoder4", (256, 512, 512, 512)), ("encoder5", (512, 512, 512, 512)),
+           ("decoder5", (512, 512, 512, 512)), ("decoder4", (512, 512, 512, 256)), ("decoder3", (256, 256, 256, 128)),
+           ("decoder2", (128, 128, 64)), ("decoder1", (64, 64, None)))
+
+
+class SegNet(nn.Module):
+    """reference models/segnet.py:19-119: 13-conv encoder with pooling indices, mirrored 13-conv decoder with unpooling."""
+
+    def __init__(self, input_channels, class_num):
+        super().__init__()
+        for name, chain in _SEGNET:
+            chain = [input_channels if c is None and i == 0 else (class_num if c is None else c) for i, c in enumerate(chain)]
+            self.add_module(name, _Stage(*[BasicConv(a, b) for a, b in zip(chain[:-1], chain[1:])]))
+        self.maxpool = nn.MaxPool2d(2, return_indices=True)
+        self.unpool = nn.MaxUnpool2d(2)
+
+    def _emit(self, plan, src_buf, dst_view=None):
+        pools = []
+        t = src_buf
+        for k in range(1, 6):
+            v = getattr(self, f"encoder{k}")._emit(plan, t)
+            op = plan.maxpool(v, keep_code=True)
+            pools.append(op)
+            t = op.dst
+        v = None
+        for k in range(5, 0, -1):
+            t = plan.unpool(t, pools[k - 1])
+            v = getattr(self, f"decoder{k}")._emit(plan, t, dst_view if k == 1 else None)
+            t = v.buf
+        return v
+
+    def forward(self, x):
+        return _run(self, x)
+
+
+def get_model(model_name, input_channels, class_num):
+    """reference utils.py:147-160."""
+    if model_name == "unet":
+        return UNet(input_channels, class_num)
+    if model_name == "segnet":
+        return SegNet(input_channels, class_num)
+    raise ValueError("network type does not supported")
+
+
+# ------------------------------------------------------------------------------------------------- execution glue
+def _holders_of(root):
+    return [m for m in root.modules() if isinstance(m, _Block)]
+
+
+_STATE = weakref.WeakKeyDictionary()   # module -> {"runner", "plans"}; kept out of the module so deepcopy/pickle stay plain
+
+
+def _state_of(module):
+    st = _STATE.get(module)
+    if st is None:
+        st = _STATE[module] = {"runner": engine.Runner(), "plans": {}}
+    return st
+
+
+def _run(root, x):
+    if not isinstance(x, torch.Tensor) or x.dim() != 4:
+        raise ValueError(f"expected a 4-D NCHW tensor, got {tuple(x.shape) if isinstance(x, torch.Tensor) else type(x)}")
+    if not x.is_cuda:
+        raise RuntimeError("pytorch_camvid_amd runs on MI355X (HIP) tensors only; there is no CPU fallback. "
+                           "Move the module and the input to 'cuda'.")
+    if x.dtype != torch.float32:
+        raise RuntimeError(f"expected float32 input (reference dtype), got {x.dtype}")
+    state = _state_of(root)
+    N, C, H, W = x.shape
+    key = (N, C, H, W, bool(x.requires_grad and torch.is_grad_enabled()))
+    plan = state["plans"].get(key)
+    if plan is None:
+        plan = engine.Plan(N, C, H, W)
+        plan.input_needs_grad = key[-1]
+        plan.output = root._emit(plan, plan.input)
+        state["plans"][key] = plan
+    params = []
+    for h in plan.holders:
+        params.extend(h.block_params())
+    p0 = params[0]
+    if p0.device != x.device or p0.dtype != torch.float32:
+        raise RuntimeError(f"Input type ({x.dtype}, {x.device}) and weight type ({p0.dtype}, {p0.device}) should be the same")
+    return engine.run_plan(state["runner"], plan, root.training, x, params)
+
+
+def runner_of(module):
+    """The engine.Runner of a module (created on first use); ddp.DataParallel hooks gradient sync into it."""
+    return _state_of(module)["runner"]

@@ -1,0 +1,66 @@
+"""CPU-side checks of the C-ABI boundary: libcvk.so loads, exports exactly what include/cvk.h declares, and the
+Python binding table matches.  No compute calls (no GPU here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "cvk.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(cvk_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_declares_expected_surface():
+    syms = header_symbols()
+    assert "cvk_conv3x3_fwd" in syms and "cvk_conv3x3_wgrad" in syms and "cvk_softmax_ce_fwd" in syms
+    assert len(syms) >= 30
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    import ctypes
+    from pytorch_camvid_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    lib = _lib.load()
+    assert lib.cvk_version() == 100
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in header_symbols():
+        assert hasattr(raw, s), f"{s} declared in include/cvk.h but not exported by libcvk.so"
+    assert sorted(_lib.SIGNATURES) == header_symbols(), "Python binding table out of sync with include/cvk.h"
+
+
+def test_argument_validation_without_gpu():
+    """Argument errors are detected before any launch, return CVK_EINVAL and set the error string."""
+    from pytorch_camvid_amd import _lib
+    lib = _lib.load()
+    rc = lib.cvk_conv3x3_fwd(None, None, None, None, None, 1, 8, 8, 4, 8, 8, None)
+    assert rc == -1 and b"null" in lib.cvk_last_error_string()
+    rc = lib.cvk_conv3x3_fwd(16, 16, None, 16, None, 1, 8, 8, 3, 8, 8, None)
+    assert rc == -1 and b"multiple of 4" in lib.cvk_last_error_string()
+    assert lib.cvk_conv3x3_wgrad_workspace_bytes(8, 360, 480, 64, 64) > 0
+    assert lib.cvk_bn_bwd_blocks(1382400) == 1024 and lib.cvk_ce_blocks(1025) == 2
+
+
+def test_module_surface_matches_reference_and_fails_loudly_on_cpu():
+    import torch
+    import pytorch_camvid_amd as A
+    net = A.get_model("unet", 3, 12)
+    assert len(net.state_dict()) == 161 and sum(p.numel() for p in net.parameters()) == 34533924
+    seg = A.get_model("segnet", 3, 12)
+    assert len(seg.state_dict()) == 182 and sum(p.numel() for p in seg.parameters()) == 29449956
+    with pytest.raises(ValueError):
+        A.get_model("nope", 3, 12)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 3, 32, 32))
+    # checkpoints interchange with the reference layout: plain OIHW tensors load into channels_last storage
+    from oracle import torch_ref as R
+    torch.manual_seed(3)
+    ref = R.build("unet", 3, 12)
+    net.load_state_dict(ref.state_dict())
+    for (k, a), (_, b) in zip(net.state_dict().items(), ref.state_dict().items()):
+        assert torch.equal(a, b), k
+    ref.load_state_dict(net.state_dict())

@@ -1,0 +1,216 @@
+"""GPU parity of the HIP path (through the C ABI) against golden vectors produced by the reference, and against
+the oracle on seeded inputs.  Tolerances are stated per check: fp32 accumulation order differs from oneDNN, so
+parity is floating-point closeness, not bit equality (integer outputs — pool indices, argmax — are bit-exact)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def close(a, b, rtol, atol, what=""):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float64)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
+
+
+def _load_block(mod, d):
+    sd = {k[2:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("p.")}
+    mod.load_state_dict(sd)
+    return mod.to(dev())
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "basicconv_*.npz"))))
+def test_basicconv2d_golden(path):
+    import pytorch_camvid_amd as A
+    d = dict(np.load(path))
+    ci, co = d["p.conv.0.weight"].shape[1], d["p.conv.0.weight"].shape[0]
+    m = _load_block(A.BasicConv2d(ci, co), d)
+    x = torch.from_numpy(d["x"]).to(dev()).requires_grad_(True)
+    r = torch.from_numpy(d["r"]).to(dev())
+    m.train()
+    y = m(x)
+    assert tuple(y.shape) == d["y_train"].shape
+    close(y, d["y_train"], 2e-4, 2e-5, "train forward")
+    (y * r).sum().backward()
+    close(x.grad, d["dx"], 1e-3, 3e-4, "dx")
+    close(m.conv[0].weight.grad, d["g.conv.0.weight"], 1e-3, 3e-4, "dW")
+    close(m.conv[1].weight.grad, d["g.conv.1.weight"], 1e-3, 3e-4, "dgamma")
+    close(m.conv[1].bias.grad, d["g.conv.1.bias"], 1e-3, 3e-4, "dbeta")
+    # conv bias gradient is mathematically zero under train-mode BN; both sides are rounding noise
+    assert m.conv[0].bias.grad.abs().max().item() < 1e-3
+    close(m.conv[1].running_mean, d["after.conv.1.running_mean"], 1e-4, 1e-6, "running_mean")
+    close(m.conv[1].running_var, d["after.conv.1.running_var"], 1e-4, 1e-6, "running_var")
+    assert int(m.conv[1].num_batches_tracked) == int(d["after.conv.1.num_batches_tracked"])
+    m.eval()
+    with torch.no_grad():
+        close(m(x), d["y_eval"], 2e-4, 2e-5, "eval forward")
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "upsample2d_*.npz"))))
+def test_upsample2d_golden(path):
+    import pytorch_camvid_amd as A
+    d = dict(np.load(path))
+    co, ci = d["p.conv.conv.0.weight"].shape[:2]
+    m = _load_block(A.UpSample2d(ci, co), d)
+    x = torch.from_numpy(d["x"]).to(dev()).requires_grad_(True)
+    r = torch.from_numpy(d["r"]).to(dev())
+    m.train()
+    y = m(x)
+    close(y, d["y_train"], 2e-4, 2e-5, "forward")
+    (y * r).sum().backward()
+    close(x.grad, d["dx"], 1e-3, 3e-4, "dx")
+    close(m.conv.conv[0].weight.grad, d["g.conv.conv.0.weight"], 1e-3, 3e-4, "dW")
+
+
+# ------------------------------------------------------------------------------------------------ raw C-ABI ops
+def nhwc(a):
+    return torch.from_numpy(np.ascontiguousarray(np.transpose(a, (0, 2, 3, 1)))).to(dev())
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).cpu().numpy()
+
+
+def full_view(t):
+    from pytorch_camvid_amd._lib import View
+    N, H, W, C = t.shape
+    return View(t.data_ptr(), H * W * C, W * C, C)
+
+
+def test_pool_unpool_bilinear_ce_raw_abi():
+    from pytorch_camvid_amd import _lib
+    from pytorch_camvid_amd._lib import check
+    from oracle import np_ops as O
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    d = dict(np.load(os.path.join(G, "ops_pool_cat_ce.npz")))
+    for t in "abc":
+        x = nhwc(d[f"pool_{t}_x"]); N, H, W, C = x.shape
+        out = torch.empty((N, H // 2, W // 2, C), device=dev())
+        code = torch.empty((N, H // 2, W // 2, C), device=dev(), dtype=torch.uint8)
+        check(lib.cvk_maxpool2x2_fwd(full_view(x), out.data_ptr(), code.data_ptr(), N, H, W, C, s))
+        assert np.array_equal(nchw(out), d[f"pool_{t}_y"])
+        r = nhwc(d[f"pool_{t}_r"])
+        for use_code in (False, True):
+            dx = torch.full_like(x, 7.0)
+            check(lib.cvk_maxpool2x2_bwd(r.data_ptr(), full_view(x), code.data_ptr() if use_code else None, full_view(dx), 0, N, H, W, C, s))
+            assert np.array_equal(nchw(dx), d[f"pool_{t}_dx"])
+            check(lib.cvk_maxpool2x2_bwd(r.data_ptr(), full_view(x), code.data_ptr() if use_code else None, full_view(dx), 1, N, H, W, C, s))
+            assert np.allclose(nchw(dx), 2 * d[f"pool_{t}_dx"])
+    for t in "ab":
+        x = nhwc(d[f"unpool_{t}_x"]); N, H, W, C = x.shape
+        out = torch.empty((N, H // 2, W // 2, C), device=dev())
+        code = torch.empty((N, H // 2, W // 2, C), device=dev(), dtype=torch.uint8)
+        check(lib.cvk_maxpool2x2_fwd(full_view(x), out.data_ptr(), code.data_ptr(), N, H, W, C, s))
+        idx = torch.empty((N, C, H // 2, W // 2), device=dev(), dtype=torch.int64)
+        check(lib.cvk_pool_code_to_index(code.data_ptr(), idx.data_ptr(), N, H, W, C, s))
+        assert np.array_equal(idx.cpu().numpy(), d[f"unpool_{t}_idx"])          # bit-exact torch indices
+        z = torch.full((N, H, W, C), 5.0, device=dev())
+        check(lib.cvk_maxunpool2x2_fwd(out.data_ptr(), code.data_ptr(), z.data_ptr(), N, H, W, C, s))
+        assert np.array_equal(nchw(z), d[f"unpool_{t}_z"])
+        r = nhwc(d[f"unpool_{t}_r"])
+        dv = torch.empty_like(out)
+        check(lib.cvk_maxunpool2x2_bwd(r.data_ptr(), code.data_ptr(), dv.data_ptr(), N, H, W, C, s))
+        dx = torch.empty_like(x)
+        check(lib.cvk_maxpool2x2_bwd(dv.data_ptr(), full_view(x), code.data_ptr(), full_view(dx), 0, N, H, W, C, s))
+        assert np.array_equal(nchw(dx), d[f"unpool_{t}_dx"])
+    for t in "abc":
+        lg = nhwc(d[f"ce_{t}_logits"]); N, H, W, C = lg.shape
+        tg = torch.from_numpy(d[f"ce_{t}_target"]).to(dev())
+        M = N * H * W
+        part = torch.empty(lib.cvk_ce_blocks(M), device=dev()); loss = torch.empty((), device=dev())
+        check(lib.cvk_softmax_ce_fwd(lg.data_ptr(), C, tg.data_ptr(), part.data_ptr(), loss.data_ptr(), M, C, s))
+        close(loss, d[f"ce_{t}_loss"], 1e-6, 1e-6)
+        dl = torch.empty_like(lg); one = torch.ones((), device=dev())
+        check(lib.cvk_softmax_ce_bwd(lg.data_ptr(), C, tg.data_ptr(), one.data_ptr(), 1.0, dl.data_ptr(), C, M, C, s))
+        close(nchw(dl), d[f"ce_{t}_dlogits"], 1e-5, 1e-8)
+    for path in sorted(glob.glob(os.path.join(G, "upsample2d_*.npz"))):
+        u = dict(np.load(path))
+        x = nhwc(u["x"]); N, H, W, C = x.shape
+        out = torch.empty((N, 2 * H, 2 * W, C), device=dev())
+        check(lib.cvk_bilinear_up2_fwd(x.data_ptr(), out.data_ptr(), N, H, W, C, s))
+        close(nchw(out), u["up_only"], 1e-6, 1e-6)
+        r = nhwc(u["r_up"]); dx = torch.empty_like(x)
+        check(lib.cvk_bilinear_up2_bwd(r.data_ptr(), dx.data_ptr(), N, H, W, C, s))
+        close(nchw(dx), u["dx_up_only"], 1e-5, 1e-5)
+
+
+def test_ce_module_and_eval_ops():
+    import pytorch_camvid_amd as A
+    from oracle import np_ops as O
+    g = torch.Generator().manual_seed(3)
+    lg = (torch.randn(2, 12, 9, 11, generator=g).abs() * 3)
+    tg = torch.randint(0, 12, (2, 9, 11), generator=g)
+    loss_o, sm = O.cross_entropy_fwd(lg.numpy(), tg.numpy())
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        l = lg.to(dev()).contiguous(memory_format=fmt).requires_grad_(True)
+        loss = A.CrossEntropyLoss()(l, tg.to(dev()))
+        loss.backward()
+        close(loss, loss_o, 1e-6, 1e-6)
+        close(l.grad, O.cross_entropy_bwd(sm, tg.numpy()), 1e-5, 1e-8)
+    am = A.argmax_channels(lg.to(dev()))
+    assert torch.equal(am.cpu(), lg.argmax(dim=1))
+    md = np.load(os.path.join(G, "miou_intersect_union.npz"))
+    for t in "ab":
+        meter = A.ConfusionMeter(12, 11, dev())
+        pred = torch.from_numpy(md[f"{t}_pred"].astype(np.int64)).to(dev()); lab = torch.from_numpy(md[f"{t}_label"].astype(np.int64)).to(dev())
+        for i in range(pred.shape[0]):
+            meter.update(pred[i], lab[i])
+        h = meter.hist.cpu().numpy().astype(np.float64)
+        assert np.array_equal(h[0], md[f"{t}_inter"]) and np.array_equal(h[1] + h[2] - h[0], md[f"{t}_union"])
+        _, _, miou_o = O.mean_iou(list(md[f"{t}_pred"].astype(np.int64)), list(md[f"{t}_label"].astype(np.int64)))
+        assert abs(meter.compute()[2] - miou_o) < 1e-12
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 12, 20, 24), (1, 4, 5, 7, 12), (3, 12, 9, 4, 8), (1, 64, 33, 47, 64), (2, 128, 6, 10, 256)])
+def test_conv_block_vs_oracle_seeded(shape):
+    """Seeded random blocks incl. ragged tiles (M not a multiple of 64/128) against the numpy oracle in fp64."""
+    import pytorch_camvid_amd as A
+    from oracle import np_ops as O
+    n, ci, h, w, co = shape
+    torch.manual_seed(sum(shape))
+    m = A.BasicConv2d(ci, co)
+    with torch.no_grad():
+        m.conv[1].weight.uniform_(0.5, 1.5); m.conv[1].bias.uniform_(-0.3, 0.3)
+    p = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    x = torch.randn(n, ci, h, w); r = torch.randn(n, co, h, w)
+    out_o, cache = O.basic_conv_fwd(x.numpy(), p, "", train=True)
+    dx_o, g_o = O.basic_conv_bwd(r.numpy(), cache, p)
+    m = m.to(dev()); m.train()
+    xg = x.to(dev()).requires_grad_(True)
+    y = m(xg)
+    (y * r.to(dev())).sum().backward()
+    scale = max(1.0, float(np.abs(out_o).max()))
+    close(y, out_o, 1e-4, 2e-5 * scale, "fwd")
+    close(xg.grad, dx_o, 1e-3, 1e-4 * float(np.abs(dx_o).max()), "dx")
+    close(m.conv[0].weight.grad, g_o["conv.0.weight"], 1e-3, 1e-4 * float(np.abs(g_o["conv.0.weight"]).max()), "dW")
+    close(m.conv[1].weight.grad, g_o["conv.1.weight"], 1e-3, 1e-4 * float(np.abs(g_o["conv.1.weight"]).max()), "dgamma")
+    close(m.conv[1].bias.grad, g_o["conv.1.bias"], 1e-3, 1e-4 * float(np.abs(g_o["conv.1.bias"]).max()), "dbeta")
+
+
+def test_errors_match_reference_classes():
+    import pytorch_camvid_amd as A
+    with pytest.raises(ValueError):
+        A.get_model("fcn", 3, 12)
+    net = A.BasicConv2d(3, 8).to(dev())
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 5, 8, 8, device=dev()))          # channel mismatch, like F.conv2d
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 8, 8))                        # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        net.train(); net(torch.zeros(1, 3, 1, 1, device=dev()))   # BN needs > 1 value per channel in training
+    u = A.UNet(3, 12).to(dev()).eval()
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            u(torch.zeros(1, 3, 15, 15, device=dev()))      # too small for four 2x2 pools
