@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py — forward+backward images/s of UNet(3,12) on synthetic 3x360x480 batches (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]            (N=1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W                   (N>1: one rank per GPU, RCCL)
+
+One "step" = zero_grad(set_to_none) -> net(x) -> CrossEntropy -> backward (-> gradient all-reduce complete for N>1)
+on a per-GPU batch of 8 (SURVEY.md §8d timed region; the optimizer step is excluded and reported separately).
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+Extra objects on the line:
+  roofline     — the dominant kernel (fp32-MFMA implicit-GEMM conv, largest share of step time): algorithmic
+                 FLOPs per launch / average launch duration, measured live with HIP events on the launch stream
+                 during extra instrumented steps after the timed region; peak = 157.3 TFLOP/s (fp32 MFMA, dense).
+  cpu_baseline — the same loop on the host cores with the stock-torch rebuild of the reference network
+                 (oracle/torch_ref.py; the reference itself is stock torch.nn and its source cannot travel to the GPU
+                 box), batch 2, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PER_GPU_BATCH = 8
+H, W = 360, 480
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="unet", choices=["unet", "segnet"])
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH)
+    ap.add_argument("--height", type=int, default=H)
+    ap.add_argument("--width", type=int, default=W)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--with-optimizer", action="store_true", help="also time AdamW steps (reported separately)")
+    return ap.parse_args()
+
+
+def cpu_baseline(model, h, w):
+    """Stock-torch rebuild of the reference on the host cores: batch 2, 1 warm-up + 3 timed fwd+bwd steps."""
+    from oracle import torch_ref as R
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    net = R.build(model, 3, 12).train()
+    x, t = R.synthetic_batch(2, h, w, 1234)
+    R.fwd_bwd_step(net, x, t)
+    t0 = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        R.fwd_bwd_step(net, x, t)
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(2 / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"stock-torch.nn rebuild of the reference {model} (oracle/torch_ref.py), batch 2 x 3x{h}x{w}, "
+                      f"1 warm-up + {n} timed fwd+bwd steps, {dt:.2f} s/step"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import pytorch_camvid_amd as A
+    from pytorch_camvid_amd import ddp
+    from pytorch_camvid_amd.modules import runner_of
+
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)     # RCCL
+
+    torch.manual_seed(0)                                    # identical init on every rank (also broadcast below)
+    net = A.get_model(a.model, 3, 12).to(dev).train()
+    model = ddp.DataParallel(net) if world > 1 else net
+    lossf = A.CrossEntropyLoss()
+    g = torch.Generator().manual_seed(1234 + rank)          # per-rank shard of the global batch
+    x = torch.randn(a.batch, 3, a.height, a.width, generator=g).to(dev)
+    t = torch.randint(0, 12, (a.batch, a.height, a.width), generator=g).to(dev)
+    params = list(net.parameters())
+
+    def step():
+        for p in params:
+            p.grad = None
+        loss = lossf(model(x), t)
+        loss.backward()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / a.steps * 1e3
+    value = world * a.batch * a.steps / dt
+
+    opt_ms = None
+    if a.with_optimizer and rank == 0:
+        opt = torch.optim.AdamW(params, lr=5e-4, weight_decay=0)
+        step(); opt.step(); torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            opt.step()
+        torch.cuda.synchronize(dev)
+        opt_ms = (time.perf_counter() - t1) / 5 * 1e3
+
+    roof = None
+    kernels = None
+    if not a.no_kernel_profile:
+        R = runner_of(net)
+        R.prof = []
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(dev)
+        agg = {}
+        for name, flops, e0, e1 in R.prof:
+            d = agg.setdefault(name, [0, 0.0, 0.0])
+            d[0] += 1; d[1] += flops; d[2] += e0.elapsed_time(e1) * 1e-3
+        R.prof = None
+        kernels = {k: {"launches_per_step": v[0] // 3, "avg_us": round(v[2] / v[0] * 1e6, 1),
+                       "tflops": round(v[1] / v[2] / 1e12, 2), "ms_per_step": round(v[2] / 3 * 1e3, 3)} for k, v in agg.items()}
+        dom = max(agg.items(), key=lambda kv: kv[1][2])
+        cnt, fl, sec = dom[1]
+        ach = fl / sec / 1e12
+        allf = sum(v[1] for v in agg.values()); alls = sum(v[2] for v in agg.values())
+        roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "flops_per_launch": fl / cnt, "avg_launch_us": round(sec / cnt * 1e6, 1), "launches_per_step": cnt // 3,
+                "all_conv_kernels": {"achieved": round(allf / alls / 1e12, 2), "frac": round(allf / alls / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                     "ms_per_step": round(alls / 3 * 1e3, 2)}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.model, a.height, a.width)
+
+    if rank == 0:
+        line = {
+            "metric": "images/sec fwd+bwd UNet 3x360x480 bs=8" if a.model == "unet" and (a.height, a.width, a.batch) == (H, W, 8)
+                      else f"images/sec fwd+bwd {a.model} 3x{a.height}x{a.width} bs={a.batch}",
+            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.model.upper() if a.model=='unet' else 'SegNet'}(3,12) train fwd+bwd+CE, per-GPU batch {a.batch} x 3x{a.height}x{a.width} fp32 "
+                                   f"(BASELINE.json configs[1]{' x N ranks, RCCL grad all-reduce (configs[2])' if world > 1 else ''})",
+                       "global_batch": world * a.batch, "parallelism": f"dp{world}", "timed_region": "zero_grad+forward+CE+backward"
+                                   + ("+allreduce" if world > 1 else ""), "loss": round(float(loss.item()), 6)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if kernels:
+            line["conv_kernels"] = kernels
+        if opt_ms is not None:
+            line["adamw_ms"] = round(opt_ms, 3)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

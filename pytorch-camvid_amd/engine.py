@@ -80,6 +80,27 @@ def _empty(n, dev, dtype=_F32):
     return torch.empty(n, device=dev, dtype=dtype)
 
 
+def conv_kernel_name(kind, n_cols):
+    """Mirror of the tile dispatch in csrc/conv3x3.hip (cvk_conv3x3_fwd / plan_wgrad): the kernel-trace name."""
+    if kind == "wgrad":
+        t = "128, 128, 2, 2" if n_cols > 64 else ("64, 128, 2, 2" if n_cols > 32 else "32, 256, 1, 4")
+        return f"k_conv3x3_wgrad<{t}>"
+    t = "128, 128, 2, 2" if n_cols > 64 else ("128, 64, 2, 2" if n_cols > 32 else "256, 32, 4, 1")
+    return f"k_conv3x3_igemm<{t}, {'true' if kind == 'fwd' else 'false'}>"
+
+
+def _timed(R, name, flops, fn):
+    """Run fn(); when a profile list is attached (bench.py), bracket it with HIP events on the launch stream."""
+    if R.prof is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    R.prof.append((name, flops, e0, e1))
+    return r
+
+
 # ===================================================================================================== ops
 class Op:
     idx = -1
@@ -125,10 +146,11 @@ class ConvBnRelu(Op):
         if st.training:
             P = (M + _lib.CVK_STAT_ROWS - 1) // _lib.CVK_STAT_ROWS
             stats = _empty(2 * P * C, dev)
-            check(lib.cvk_conv3x3_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(),
-                                      N, H, W, src.ld, C, ldy, s), "cvk_conv3x3_fwd")
             if M <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {[N, C, H, W]}")
+            _timed(R, conv_kernel_name("fwd", ldy), 18.0 * M * C * self.cin, lambda: check(
+                lib.cvk_conv3x3_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(),
+                                    N, H, W, src.ld, C, ldy, s), "cvk_conv3x3_fwd"))
             wsb = lib.cvk_bn_finalize_workspace_bytes(P, C)
             ws = R.workspace(wsb, dev)
             track = bn.track_running_stats and bn.running_mean is not None
@@ -176,13 +198,15 @@ class ConvBnRelu(Op):
             wd = _empty(src.ld * 9 * ldy, dev)
             check(lib.cvk_pack_weight_dgrad(wc.data_ptr(), wd.data_ptr(), C, self.cin, src.ld, ldy, s), "cvk_pack_weight_dgrad")
             dX = _empty(M * src.ld, dev).view(N, H, W, src.ld)
-            check(lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
-                  "cvk_conv3x3_fwd(dgrad)")
+            _timed(R, conv_kernel_name("dgrad", src.ld), 18.0 * M * C * self.cin, lambda: check(
+                lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
+                "cvk_conv3x3_fwd(dgrad)"))
             st.grad[src.id] = dX
         wsb = lib.cvk_conv3x3_wgrad_workspace_bytes(N, H, W, src.ld, C)
         ws = R.workspace(wsb, dev)
-        check(lib.cvk_conv3x3_wgrad(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
-              "cvk_conv3x3_wgrad")
+        _timed(R, conv_kernel_name("wgrad", C), 18.0 * M * C * self.cin, lambda: check(
+            lib.cvk_conv3x3_wgrad(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
+            "cvk_conv3x3_wgrad"))
         R.grads_ready(st, self.pslot)
 
 
@@ -344,6 +368,7 @@ class Runner:
         self.lib = _lib.load()
         self._ws = None
         self.grad_sync = None       # set by ddp.DataParallel
+        self.prof = None            # list collecting (kernel name, flops, start event, end event) when bench.py profiles
         self._flat = [None, None]   # alternating flat gradient buffers (see grad_flat)
 
     def workspace(self, nbytes, dev):
