@@ -20,9 +20,22 @@ namespace {
 
 constexpr int BK = 32;        // K slice per LDS stage (floats)
 constexpr int LDT = BK + 4;   // padded LDS row: 144 B -> the 16 rows of a ds_read_b128 lane group hit 16 distinct slots
+constexpr unsigned OOB = 0x80000000u;  // buffer offset beyond num_records (< 2 GiB by contract): the load returns 0
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool STATS>
+// Pipeline per K slice (one barrier per slice, two LDS stages, one register stage):
+//   MFMAs of kk=0  ->  registers (slice ks+1, loaded a whole slice ago) -> LDS[next]  ->  issue global loads of
+//   slice ks+2 (range-checked buffer loads: out-of-frame taps / rows / columns return 0, no branches)  ->  MFMAs of
+//   kk=1..3  ->  barrier.  Everything between two barriers is ONE basic block, so the compiler interleaves the ~60
+//   staging instructions into the 64-cycle shadows of the 64 MFMAs instead of serialising them.
+// CIN32: Cin % 32 == 0, so a K slice never straddles a filter tap and tap / shift are wave-uniform (SGPR math).
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool STATS, bool CIN32>
 __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm(
     const float* __restrict__ X, const float* __restrict__ Wt, const float* __restrict__ bias, float* __restrict__ Y,
     float* __restrict__ stats, int M, int H, int W, int Cin, int Cout, int ldy, int Ktot, int P, int tilesN) {
@@ -30,12 +43,11 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm(
     constexpr int TM = BM / WARPS_M / 32, TN = BN / WARPS_N / 32;
     constexpr int RP = NT / 8;  // tile rows staged per pass (8 lanes x 16 B cover one 32-float row)
     constexpr int NA = BM / RP, NB = BN / RP;
+    constexpr int STAGE = (BM + BN) * LDT;
     static_assert(NA >= 1 && NB >= 1 && BM % RP == 0 && BN % RP == 0, "tile/threads mismatch");
     static_assert(!STATS || TM == 2, "BN statistics granule is 64 rows per wave");
 
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDT];
-    float* As = smem;
-    float* Bs = smem + BM * LDT;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -46,54 +58,75 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm(
     const int m0 = (tile / tilesN) * BM;
     const int n0 = (tile % tilesN) * BN;
 
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, M * Cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, Cout * Ktot * 4, 0x00020000);
+
     // ---- per-thread staging coordinates (fixed for the whole K loop)
     const int kv = tid & 7, r0 = tid >> 3;
-    int ay[NA], ax[NA];
-    const float* ap[NA];
+    unsigned aoff[NA], amask[NA], boff[NB];
     const int HW = H * W;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int m = m0 + r0 + i * RP;
+        unsigned mask = 0;
         if (m < M) {
             const int n = m / HW, rem = m - n * HW;
-            ay[i] = rem / W;
-            ax[i] = rem - ay[i] * W;
-        } else {
-            ay[i] = -8;  // every tap fails the bounds test -> zero rows
-            ax[i] = 0;
+            const int y = rem / W, x = rem - y * W;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) mask |= 1u << t;
+            }
         }
-        ap[i] = X + (size_t)(m < M ? m : 0) * Cin;
+        amask[i] = mask;
+        aoff[i] = (unsigned)(m < M ? m : 0) * (unsigned)Cin * 4u + (CIN32 ? kv * 16u : 0u);
     }
-    const float* bp[NB];
-    bool bok[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int co = n0 + r0 + i * RP;
-        bok[i] = co < Cout;
-        bp[i] = Wt + (size_t)(bok[i] ? co : 0) * Ktot;
+        boff[i] = co < Cout ? (unsigned)co * (unsigned)Ktot * 4u + kv * 16u : OOB;
     }
 
     f32x4 ra[NA], rb[NB];
-    int k_cur = kv * 4, tap = 0, ci = kv * 4;  // this thread's K column in the current slice, split as (tap, ci)
-    while (ci >= Cin) { ci -= Cin; ++tap; }
+    int lk = 0;                              // K base of the next slice to load (uniform)
+    int ltap = 0, lcib = 0;                  // CIN32: its tap and channel base (uniform)
+    int vtap = 0, vci = kv * 4;              // generic: this thread's (tap, ci)
+    if (!CIN32) while (vci >= Cin) { vci -= Cin; ++vtap; }
 
-    auto load_stage = [&]() {
-        const bool kok = k_cur < Ktot;
-        const int t3 = tap / 3;
-        const int dy = t3 - 1, dx = tap - t3 * 3 - 1;
-        const int shift = (dy * W + dx) * Cin + ci;
+    auto issue_loads = [&]() {
+        if (CIN32) {
+            const int t3 = (ltap * 11) >> 5;             // ltap / 3 for ltap < 32
+            const int dy = t3 - 1, dx = ltap - 3 * t3 - 1;
+            const unsigned sh = (unsigned)(((dy * W + dx) * Cin + lcib) * 4);
+            const unsigned bit = 1u << ltap;             // tap >= 9 (past the end of K) matches no row
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const bool ok = kok && (unsigned)(ay[i] + dy) < (unsigned)H && (unsigned)(ax[i] + dx) < (unsigned)W;
-            ra[i] = ok ? *reinterpret_cast<const f32x4*>(ap[i] + shift) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+            for (int i = 0; i < NA; ++i) ra[i] = buf_load16(xr, (amask[i] & bit) ? aoff[i] + sh : OOB);
+            const unsigned kb = lk < Ktot ? (unsigned)lk * 4u : OOB;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            rb[i] = (kok && bok[i]) ? *reinterpret_cast<const f32x4*>(bp[i] + k_cur) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < NB; ++i) rb[i] = buf_load16(wr, (boff[i] | kb) & OOB ? OOB : boff[i] + kb);
+            lcib += BK;
+            if (lcib >= Cin) { lcib = 0; ++ltap; }
+        } else {
+            const int k = lk + kv * 4;
+            const bool kok = k < Ktot;
+            const int t3 = (vtap * 11) >> 5;
+            const int dy = t3 - 1, dx = vtap - 3 * t3 - 1;
+            const unsigned sh = (unsigned)(((dy * W + dx) * Cin + vci) * 4);
+            const unsigned bit = (kok && vtap < 9) ? 1u << vtap : 0u;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] = buf_load16(xr, (amask[i] & bit) ? aoff[i] + sh : OOB);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb[i] = buf_load16(wr, (kok && boff[i] != OOB) ? boff[i] + (unsigned)lk * 4u : OOB);
+            vci += BK;
+            while (vci >= Cin) { vci -= Cin; ++vtap; }
         }
-        k_cur += BK;
-        ci += BK;
-        while (ci >= Cin) { ci -= Cin; ++tap; }
+        lk += BK;
+    };
+    auto store_stage = [&](float* dst) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&dst[(r0 + i * RP) * LDT + kv * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&dst[BM * LDT + (r0 + i * RP) * LDT + kv * 4]) = rb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -104,56 +137,74 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nK = (Ktot + BK - 1) / BK;
-    load_stage();
-    for (int ks = 0; ks < nK; ++ks) {
-        __syncthreads();  // all waves finished reading the previous slice
+    auto mma_kk = [&](const float* arow, const float* brow, int kk) {
+        f32x4 a[TM], b[TN];
 #pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&As[(r0 + i * RP) * LDT + kv * 4]) = ra[i];
+        for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const f32x4*>(arow + t * 32 * LDT + kk * 8);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&Bs[(r0 + i * RP) * LDT + kv * 4]) = rb[i];
-        __syncthreads();
-        if (ks + 1 < nK) load_stage();  // next slice's global loads fly under this slice's MFMAs
+        for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const f32x4*>(brow + t * 32 * LDT + kk * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
+    };
 
-        const float* arow = &As[(wm * TM * 32 + li) * LDT + lh * 4];
-        const float* brow = &Bs[(wn * TN * 32 + li) * LDT + lh * 4];
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 a[TM], b[TN];
-#pragma unroll
-            for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const f32x4*>(arow + t * 32 * LDT + kk * 8);
-#pragma unroll
-            for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const f32x4*>(brow + t * 32 * LDT + kk * 8);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
-        }
+    const int nK = (Ktot + BK - 1) / BK;
+    issue_loads();            // slice 0
+    store_stage(smem);
+    issue_loads();            // slice 1 (zeros when nK == 1)
+    __syncthreads();
+    const int aro = (wm * TM * 32 + li) * LDT + lh * 4;
+    const int bro = BM * LDT + (wn * TN * 32 + li) * LDT + lh * 4;
+    for (int ks = 0; ks < nK; ++ks) {
+        const float* cur = smem + (ks & 1) * STAGE;
+        float* nxt = smem + ((ks & 1) ^ 1) * STAGE;
+        mma_kk(cur + aro, cur + bro, 0);
+        store_stage(nxt);     // slice ks+1 (all-zero past the end)
+        issue_loads();        // slice ks+2 (range-checked to zero past the end; no memory traffic)
+        mma_kk(cur + aro, cur + bro, 1);
+        mma_kk(cur + aro, cur + bro, 2);
+        mma_kk(cur + aro, cur + bro, 3);
+        __syncthreads();
     }
 
     // ---- epilogue: + bias, store NHWC, fused BatchNorm statistics partials
     // C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
     const int rowbase = m0 + wm * TM * 32;
+    const bool full = (m0 + BM <= M) && (n0 + BN <= ldy) && (n0 + BN <= Cout);   // block-uniform fast path
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int col = n0 + wn * TN * 32 + tn * 32 + li;
         const float bv = (bias != nullptr && col < Cout) ? bias[col] : 0.f;
         float s = 0.f;
+        if (full) {
+            float* yp = Y + (size_t)(rowbase + 4 * lh) * ldy + col;
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+            for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rowbase + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float v = acc[tm][tn][r] + bv;
-                acc[tm][tn][r] = v;
-                if (row < M) {
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[tm][tn][r] + bv;
+                    acc[tm][tn][r] = v;
                     s += v;
-                    if (col < ldy) Y[(size_t)row * ldy + col] = v;
+                    yp[(size_t)(tm * 32 + (r & 3) + 8 * (r >> 2)) * ldy] = v;
                 }
-            }
+        } else {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rowbase + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float v = acc[tm][tn][r] + bv;
+                    acc[tm][tn][r] = v;
+                    if (row < M) {
+                        s += v;
+                        if (col < ldy) Y[(size_t)row * ldy + col] = v;
+                    }
+                }
+        }
         if (STATS) {
             const int cnt = min(64, M - rowbase);  // rows of this wave inside the tensor (wave-uniform)
             if (cnt > 0) {
@@ -166,7 +217,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm(
                     for (int r = 0; r < 16; ++r) {
                         const int row = rowbase + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                         const float d = acc[tm][tn][r] - mean;
-                        if (row < M) q += d * d;
+                        if (full || row < M) q += d * d;
                     }
                 q += __shfl_xor(q, 32, 64);
                 const int prow = rowbase / CVK_STAT_ROWS;
@@ -180,7 +231,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm(
 }
 
 // ------------------------------------------------------------------------------------------------ weight-grad
-// slab[split][co][k] = sum over the split's pixels of dy[m][co] * x[m + tap(k)][ci(k)]
+// slab[split][co][k] = sum over the split's pixels of dy[m][co] * x[m + tap(k)][ci(k)]; same pipeline as above.
 template <int BM, int BN, int WARPS_M, int WARPS_N>
 __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
     const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ slab, int M, int H, int W, int Cin,
@@ -190,11 +241,10 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
     constexpr int VA = BM / 4, VB = BN / 4;      // 16-byte vectors per staged pixel row
     constexpr int RPA = NT / VA, RPB = NT / VB;  // pixel rows staged per pass
     constexpr int NA = BK / RPA, NB = BK / RPB;
+    constexpr int STAGE = BK * (BM + BN);
     static_assert(NA >= 1 && NB >= 1 && BK % RPA == 0 && BK % RPB == 0, "tile/threads mismatch");
 
-    __shared__ __attribute__((aligned(16))) float smem[BK * (BM + BN)];
-    float* As = smem;             // [BK pixels][BM output channels]
-    float* Bs = smem + BK * BM;   // [BK pixels][BN (tap,ci) columns]
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];   // stage: [BK px][BM co] | [BK px][BN (tap,ci)]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -207,34 +257,54 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
     const int mbeg = blockIdx.y * chunk;
     const int mend = min(M, mbeg + chunk);
 
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, M * Cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)DY, 0, M * ld_dy * 4, 0x00020000);
+
     const int cva = tid % VA, pra = tid / VA;
     const int cvb = tid % VB, prb = tid / VB;
     const int coA = c0 + cva * 4;
-    const bool aok = coA < Cout;          // Cout is padded to a multiple of 4 by the host (ld_dy % 4 == 0 covers it)
+    const bool aok = coA < Cout;          // dy columns [Cout, ld_dy) are zero by contract (ld_dy % 4 == 0)
     const int colB = n0 + cvb * 4;
     const bool bok = colB < Ktot;
     const int tapB = bok ? colB / Cin : 0;
     const int ciB = colB - tapB * Cin;
     const int dyB = tapB / 3 - 1, dxB = tapB % 3 - 1;
-    const int shiftB = (dyB * W + dxB) * Cin + ciB;
+    const unsigned shiftB = (unsigned)(((dyB * W + dxB) * Cin + ciB) * 4);
     const int HW = H * W;
 
+    int by[NB], bx[NB];                   // frame coordinates of this thread's B rows in the current slice
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int m = mbeg + prb + i * RPB;
+        const int n = m / HW, rem = m - n * HW;
+        by[i] = rem / W;
+        bx[i] = rem - by[i] * W;
+    }
+    int lm = mbeg;                        // first pixel of the next slice to load
+
     f32x4 ra[NA], rb[NB];
-    auto load_stage = [&](int mb) {
+    auto issue_loads = [&]() {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int m = mb + pra + i * RPA;
-            ra[i] = (aok && m < mend) ? *reinterpret_cast<const f32x4*>(DY + (size_t)m * ld_dy + coA)
-                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int m = lm + pra + i * RPA;
+            ra[i] = buf_load16(dr, (aok && m < mend) ? ((unsigned)m * (unsigned)ld_dy + (unsigned)coA) * 4u : OOB);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int m = mb + prb + i * RPB;
-            const int n = m / HW, rem = m - n * HW;
-            const int y = rem / W, x = rem - y * W;
-            const bool ok = bok && m < mend && (unsigned)(y + dyB) < (unsigned)H && (unsigned)(x + dxB) < (unsigned)W;
-            rb[i] = ok ? *reinterpret_cast<const f32x4*>(X + (size_t)m * Cin + shiftB) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int m = lm + prb + i * RPB;
+            const bool ok = bok && m < mend && (unsigned)(by[i] + dyB) < (unsigned)H && (unsigned)(bx[i] + dxB) < (unsigned)W;
+            rb[i] = buf_load16(xr, ok ? (unsigned)m * (unsigned)Cin * 4u + shiftB : OOB);
+            bx[i] += BK;                  // advance 32 pixels in raster order
+            while (bx[i] >= W) { bx[i] -= W; ++by[i]; }
+            while (by[i] >= H) by[i] -= H;
         }
+        lm += BK;
+    };
+    auto store_stage = [&](float* dst) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&dst[(pra + i * RPA) * BM + cva * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&dst[BK * BM + (prb + i * RPB) * BN + cvb * 4]) = rb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -245,21 +315,9 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nK = (mend - mbeg + BK - 1) / BK;
-    if (nK > 0) load_stage(mbeg);
-    for (int ks = 0; ks < nK; ++ks) {
-        __syncthreads();
+    auto mma_part = [&](const float* acol, const float* bcol, int s0, int s1) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&As[(pra + i * RPA) * BM + cva * 4]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&Bs[(prb + i * RPB) * BN + cvb * 4]) = rb[i];
-        __syncthreads();
-        if (ks + 1 < nK) load_stage(mbeg + (ks + 1) * BK);
-
-        const float* acol = &As[lh * BM + wm * TM * 32 + li];
-        const float* bcol = &Bs[lh * BN + wn * TN * 32 + li];
-#pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
+        for (int s = s0; s < s1; ++s) {
             float a[TM], b[TN];
 #pragma unroll
             for (int t = 0; t < TM; ++t) a[t] = acol[2 * s * BM + t * 32];
@@ -271,6 +329,23 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
                 for (int tn = 0; tn < TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
         }
+    };
+
+    const int nK = (mend - mbeg + BK - 1) / BK;
+    issue_loads();
+    store_stage(smem);
+    issue_loads();
+    __syncthreads();
+    const int aco = lh * BM + wm * TM * 32 + li;
+    const int bco = BK * BM + lh * BN + wn * TN * 32 + li;
+    for (int ks = 0; ks < nK; ++ks) {
+        const float* cur = smem + (ks & 1) * STAGE;
+        float* nxt = smem + ((ks & 1) ^ 1) * STAGE;
+        mma_part(cur + aco, cur + bco, 0, 4);
+        store_stage(nxt);
+        issue_loads();
+        mma_part(cur + aco, cur + bco, 4, 16);
+        __syncthreads();
     }
 
     float* out = slab + (size_t)blockIdx.y * Cout * Ktot;
@@ -385,18 +460,26 @@ extern "C" int cvk_conv3x3_fwd(const float* x, const float* w, const float* bias
     CVK_CHECK_ARG(ldy >= Cout, "cvk_conv3x3_fwd: ldy=%d < Cout=%d", ldy, Cout);
     CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(w), "cvk_conv3x3_fwd: x and w must be 16-byte aligned");
     CVK_CHECK_ARG((long)N * H * W < (1L << 31) - 512 && (long)H * W * Cin < (1L << 31), "cvk_conv3x3_fwd: tensor too large for 32-bit pixel indices");
+    CVK_CHECK_ARG((long)N * H * W * Cin * 4 < (1L << 31) && (long)Cout * 9 * Cin * 4 < (1L << 31), "cvk_conv3x3_fwd: input or weight tensor exceeds the 2 GiB buffer-addressing limit; split the batch");
     const int M = N * H * W, Ktot = 9 * Cin, P = cvk_cdiv(M, CVK_STAT_ROWS);
+    const bool c32 = Cin % 32 == 0;
     hipStream_t s = (hipStream_t)stream;
 #define CVK_CONV_LAUNCH(BM_, BN_, WM_, WN_)                                                                         \
     do {                                                                                                           \
         const int tilesN = cvk_cdiv(ldy, BN_), tilesM = cvk_cdiv(M, BM_);                                          \
         dim3 grid(tilesM* tilesN), block(WM_* WN_ * 64);                                                           \
-        if (stats)                                                                                                 \
-            hipLaunchKernelGGL((k_conv3x3_igemm<BM_, BN_, WM_, WN_, true>), grid, block, 0, s, x, w, bias, y, stats, M, H, \
-                               W, Cin, Cout, ldy, Ktot, P, tilesN);                                                \
+        if (stats && c32)                                                                                          \
+            hipLaunchKernelGGL((k_conv3x3_igemm<BM_, BN_, WM_, WN_, true, true>), grid, block, 0, s, x, w, bias, y, stats, \
+                               M, H, W, Cin, Cout, ldy, Ktot, P, tilesN);                                          \
+        else if (stats)                                                                                            \
+            hipLaunchKernelGGL((k_conv3x3_igemm<BM_, BN_, WM_, WN_, true, false>), grid, block, 0, s, x, w, bias, y, stats, \
+                               M, H, W, Cin, Cout, ldy, Ktot, P, tilesN);                                          \
+        else if (c32)                                                                                              \
+            hipLaunchKernelGGL((k_conv3x3_igemm<BM_, BN_, WM_, WN_, false, true>), grid, block, 0, s, x, w, bias, y, stats, \
+                               M, H, W, Cin, Cout, ldy, Ktot, P, tilesN);                                          \
         else                                                                                                       \
-            hipLaunchKernelGGL((k_conv3x3_igemm<BM_, BN_, WM_, WN_, false>), grid, block, 0, s, x, w, bias, y, stats, M, H, \
-                               W, Cin, Cout, ldy, Ktot, P, tilesN);                                                \
+            hipLaunchKernelGGL((k_conv3x3_igemm<BM_, BN_, WM_, WN_, false, false>), grid, block, 0, s, x, w, bias, y, stats, \
+                               M, H, W, Cin, Cout, ldy, Ktot, P, tilesN);                                          \
     } while (0)
     if (ldy > 64) CVK_CONV_LAUNCH(128, 128, 2, 2);
     else if (ldy > 32) CVK_CONV_LAUNCH(128, 64, 2, 2);
@@ -433,7 +516,7 @@ extern "C" int cvk_conv3x3_wgrad(const float* x, const float* dy, float* dw, int
     CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin_pad >= Cin, "cvk_conv3x3_wgrad: bad shape");
     CVK_CHECK_ARG(Cin_pad % 4 == 0 && ld_dy % 4 == 0 && ld_dy >= Cout, "cvk_conv3x3_wgrad: Cin_pad=%d and ld_dy=%d must be multiples of 4, ld_dy >= Cout", Cin_pad, ld_dy);
     CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(dy) && cvk_aligned16(workspace), "cvk_conv3x3_wgrad: pointers must be 16-byte aligned");
-    CVK_CHECK_ARG((long)N * H * W < (1L << 31) - 512, "cvk_conv3x3_wgrad: tensor too large");
+    CVK_CHECK_ARG((long)N * H * W * Cin_pad * 4 < (1L << 31) && (long)N * H * W * ld_dy * 4 < (1L << 31), "cvk_conv3x3_wgrad: x or dy exceeds the 2 GiB buffer-addressing limit; split the batch");
     const int M = N * H * W, Ktot = 9 * Cin_pad;
     const WgradPlan p = plan_wgrad(M, Cin_pad, Cout);
     const size_t need = (size_t)p.splits * Cout * Ktot * sizeof(float);

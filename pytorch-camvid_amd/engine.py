@@ -80,13 +80,13 @@ def _empty(n, dev, dtype=_F32):
     return torch.empty(n, device=dev, dtype=dtype)
 
 
-def conv_kernel_name(kind, n_cols):
+def conv_kernel_name(kind, n_cols, k_ch=32):
     """Mirror of the tile dispatch in csrc/conv3x3.hip (cvk_conv3x3_fwd / plan_wgrad): the kernel-trace name."""
     if kind == "wgrad":
         t = "128, 128, 2, 2" if n_cols > 64 else ("64, 128, 2, 2" if n_cols > 32 else "32, 256, 1, 4")
         return f"k_conv3x3_wgrad<{t}>"
     t = "128, 128, 2, 2" if n_cols > 64 else ("128, 64, 2, 2" if n_cols > 32 else "256, 32, 4, 1")
-    return f"k_conv3x3_igemm<{t}, {'true' if kind == 'fwd' else 'false'}>"
+    return f"k_conv3x3_igemm<{t}, {'true' if kind == 'fwd' else 'false'}, {'true' if k_ch % 32 == 0 else 'false'}>"
 
 
 def _timed(R, name, flops, fn):
@@ -148,7 +148,7 @@ class ConvBnRelu(Op):
             stats = _empty(2 * P * C, dev)
             if M <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {[N, C, H, W]}")
-            _timed(R, conv_kernel_name("fwd", ldy), 18.0 * M * C * self.cin, lambda: check(
+            _timed(R, conv_kernel_name("fwd", ldy, src.ld), 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(),
                                     N, H, W, src.ld, C, ldy, s), "cvk_conv3x3_fwd"))
             wsb = lib.cvk_bn_finalize_workspace_bytes(P, C)
@@ -198,7 +198,7 @@ class ConvBnRelu(Op):
             wd = _empty(src.ld * 9 * ldy, dev)
             check(lib.cvk_pack_weight_dgrad(wc.data_ptr(), wd.data_ptr(), C, self.cin, src.ld, ldy, s), "cvk_pack_weight_dgrad")
             dX = _empty(M * src.ld, dev).view(N, H, W, src.ld)
-            _timed(R, conv_kernel_name("dgrad", src.ld), 18.0 * M * C * self.cin, lambda: check(
+            _timed(R, conv_kernel_name("dgrad", src.ld, ldy), 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
                 "cvk_conv3x3_fwd(dgrad)"))
             st.grad[src.id] = dX

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Per-layer timing of the conv kernels at the UNet batch-8 shapes: fwd (with BN stats), dgrad, wgrad -> TFLOP/s."""
+import sys, os, json
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pytorch_camvid_amd import _lib
+from pytorch_camvid_amd._lib import check
+
+LAYERS = [  # name, Cin, Cout, H, W
+    ("down1.0", 4, 64, 360, 480), ("down1.1", 64, 64, 360, 480), ("down2.0", 64, 128, 180, 240), ("down2.1", 128, 128, 180, 240),
+    ("down3.0", 128, 256, 90, 120), ("down3.1", 256, 256, 90, 120), ("down4.0", 256, 512, 45, 60), ("down4.1", 512, 512, 45, 60),
+    ("down5.0", 512, 1024, 22, 30), ("down5.1", 1024, 1024, 22, 30), ("ups1.conv", 1024, 512, 44, 60), ("up1.0", 1024, 512, 45, 60),
+    ("ups2.conv", 512, 256, 90, 120), ("up2.0", 512, 256, 90, 120), ("ups3.conv", 256, 128, 180, 240), ("up3.0", 256, 128, 180, 240),
+    ("ups4.conv", 128, 64, 360, 480), ("up4.0", 128, 64, 360, 480), ("output", 64, 12, 360, 480),
+]
+
+COLD = "--cold" in sys.argv
+if COLD:
+    sys.argv.remove("--cold")
+_flush = None
+
+def timeit(fn, n=5):
+    global _flush
+    fn(); torch.cuda.synchronize()
+    if not COLD:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n): fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e-3
+    if _flush is None:
+        _flush = torch.empty(1 << 28, device="cuda")      # 1 GiB: evicts L2 (32 MiB) and the 256 MiB Infinity Cache
+    tot = 0.0
+    for _ in range(n):
+        _flush.add_(1.0)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1)
+    return tot / n * 1e-3
+
+def main():
+    lib = _lib.load(); N = 8
+    which = sys.argv[1:] or ["fwd", "dgrad", "wgrad"]
+    s = torch.cuda.current_stream().cuda_stream
+    dev = "cuda"
+    tot = {k: [0.0, 0.0] for k in which}
+    for name, ci, co, H, W in LAYERS:
+        M = N * H * W
+        flops = 18.0 * M * ci * co
+        x = torch.randn(M, ci, device=dev); w = torch.randn(co, 9 * ci, device=dev) * 0.05; b = torch.randn(co, device=dev)
+        ldy = (co + 3) // 4 * 4
+        y = torch.empty(M, ldy, device=dev); P = (M + 63) // 64
+        stats = torch.empty(2 * P * co, device=dev)
+        row = f"{name:10s} {ci:5d}->{co:5d} {H:3d}x{W:3d} "
+        if "fwd" in which:
+            t = timeit(lambda: check(lib.cvk_conv3x3_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, ci, co, ldy, s)))
+            row += f" fwd {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["fwd"][0] += flops; tot["fwd"][1] += t
+        if "dgrad" in which and name != "down1.0":
+            dy = torch.randn(M, ldy, device=dev); wd = torch.randn(ci, 9 * ldy, device=dev) * 0.05; dx = torch.empty(M, ci, device=dev)
+            t = timeit(lambda: check(lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), None, N, H, W, ldy, ci, ci, s)))
+            row += f" dgrad {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["dgrad"][0] += flops; tot["dgrad"][1] += t
+        if "wgrad" in which:
+            dy = torch.randn(M, ldy, device=dev); dw = torch.empty(co, 9 * ci, device=dev)
+            wsb = lib.cvk_conv3x3_wgrad_workspace_bytes(N, H, W, ci, co); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            t = timeit(lambda: check(lib.cvk_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, H, W, ci, ci, co, ldy, ws.data_ptr(), wsb, s)))
+            row += f" wgrad {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["wgrad"][0] += flops; tot["wgrad"][1] += t
+        print(row, flush=True)
+    for k, (f, t) in tot.items():
+        print(f"TOTAL {k}: {t*1e3:.2f} ms  {f/t/1e12:.1f} TF")
+
+main()
