@@ -6,7 +6,7 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcvk.so")
+LIB_PATH = os.environ.get("CVK_LIB_PATH") or os.path.join(_HERE, "lib", "libcvk.so")   # override: kernel experiments only
 CSRC = os.path.join(_HERE, "csrc")
 
 CVK_STAT_ROWS = 64

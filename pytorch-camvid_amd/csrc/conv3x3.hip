@@ -87,13 +87,13 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm(
         boff[i] = co < Cout ? (unsigned)co * (unsigned)Ktot * 4u + kv * 16u : OOB;
     }
 
-    f32x4 ra[NA], rb[NB];
+    f32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];   // two register stages: every slice is in flight for two K steps
     int lk = 0;                              // K base of the next slice to load (uniform)
     int ltap = 0, lcib = 0;                  // CIN32: its tap and channel base (uniform)
     int vtap = 0, vci = kv * 4;              // generic: this thread's (tap, ci)
     if (!CIN32) while (vci >= Cin) { vci -= Cin; ++vtap; }
 
-    auto issue_loads = [&]() {
+    auto issue_loads = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
         if (CIN32) {
             const int t3 = (ltap * 11) >> 5;             // ltap / 3 for ltap < 32
             const int dy = t3 - 1, dx = ltap - 3 * t3 - 1;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm(
         }
         lk += BK;
     };
-    auto store_stage = [&](float* dst) {
+    auto store_stage = [&](float* dst, const f32x4 (&ra)[NA], const f32x4 (&rb)[NB]) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&dst[(r0 + i * RP) * LDT + kv * 4]) = ra[i];
 #pragma unroll
@@ -153,23 +153,50 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm(
     };
 
     const int nK = (Ktot + BK - 1) / BK;
-    issue_loads();            // slice 0
-    store_stage(smem);
-    issue_loads();            // slice 1 (zeros when nK == 1)
+    issue_loads(ra0, rb0);            // slice 0
+    store_stage(smem, ra0, rb0);
+    issue_loads(ra0, rb0);            // slice 1 (zeros past the end of K: range-checked, no memory traffic)
+    issue_loads(ra1, rb1);            // slice 2
     __syncthreads();
     const int aro = (wm * TM * 32 + li) * LDT + lh * 4;
     const int bro = BM * LDT + (wn * TN * 32 + li) * LDT + lh * 4;
-    for (int ks = 0; ks < nK; ++ks) {
-        const float* cur = smem + (ks & 1) * STAGE;
-        float* nxt = smem + ((ks & 1) ^ 1) * STAGE;
-        mma_kk(cur + aro, cur + bro, 0);
-        store_stage(nxt);     // slice ks+1 (all-zero past the end)
-        issue_loads();        // slice ks+2 (range-checked to zero past the end; no memory traffic)
-        mma_kk(cur + aro, cur + bro, 1);
-        mma_kk(cur + aro, cur + bro, 2);
-        mma_kk(cur + aro, cur + bro, 3);
-        __syncthreads();
+    float* const buf0 = smem;
+    float* const buf1 = smem + STAGE;
+    // one K step: MFMAs of `cur`; meanwhile the register stage loaded two steps ago goes to `nxt` and is re-issued
+    // for the slice three steps ahead.  All of it is one basic block between two barriers.
+#define CVK_KSTEP(cur, nxt, RA, RB)            \
+    do {                                       \
+        mma_kk(cur + aro, cur + bro, 0);       \
+        CVK_STORE(nxt, RA, RB);                \
+        CVK_LOAD(RA, RB);                      \
+        mma_kk(cur + aro, cur + bro, 1);       \
+        mma_kk(cur + aro, cur + bro, 2);       \
+        mma_kk(cur + aro, cur + bro, 3);       \
+        CVK_SYNC();                            \
+    } while (0)
+#if defined(CVK_ABLATE) && (CVK_ABLATE == 3 || CVK_ABLATE == 4)
+#define CVK_STORE(n, a, b)
+#else
+#define CVK_STORE(n, a, b) store_stage(n, a, b)
+#endif
+#if defined(CVK_ABLATE) && (CVK_ABLATE == 2 || CVK_ABLATE == 4)
+#define CVK_LOAD(a, b)
+#else
+#define CVK_LOAD(a, b) issue_loads(a, b)
+#endif
+#if defined(CVK_ABLATE) && (CVK_ABLATE == 1 || CVK_ABLATE == 4)
+#define CVK_SYNC()
+#else
+#define CVK_SYNC() __syncthreads()
+#endif
+    // straight-line double step (no branch inside: the compiler's vmcnt bookkeeping then leaves the newer register
+    // stage in flight, `s_waitcnt vmcnt(8..15)`), odd tail peeled
+    int ks = 0;
+    for (; ks + 2 <= nK; ks += 2) {
+        CVK_KSTEP(buf0, buf1, ra0, rb0);
+        CVK_KSTEP(buf1, buf0, ra1, rb1);
     }
+    if (ks < nK) CVK_KSTEP(buf0, buf1, ra0, rb0);
 
     // ---- epilogue: + bias, store NHWC, fused BatchNorm statistics partials
     // C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
@@ -272,18 +299,16 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
     const unsigned shiftB = (unsigned)(((dyB * W + dxB) * Cin + ciB) * 4);
     const int HW = H * W;
 
-    int by[NB], bx[NB];                   // frame coordinates of this thread's B rows in the current slice
+    // Raster position (index inside its image) of this thread's B rows in the next slice to load; advanced by BK per
+    // slice with one conditional wrap; row/column come from an exact multiply-high division (rem * W < 2^32).
+    unsigned brem[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int m = mbeg + prb + i * RPB;
-        const int n = m / HW, rem = m - n * HW;
-        by[i] = rem / W;
-        bx[i] = rem - by[i] * W;
-    }
+    for (int i = 0; i < NB; ++i) brem[i] = (unsigned)((mbeg + prb + i * RPB) % HW);
+    const unsigned magicW = (unsigned)(0x100000000ULL / (unsigned)W) + 1u;
     int lm = mbeg;                        // first pixel of the next slice to load
 
-    f32x4 ra[NA], rb[NB];
-    auto issue_loads = [&]() {
+    f32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+    auto issue_loads = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int m = lm + pra + i * RPA;
@@ -292,15 +317,17 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int m = lm + prb + i * RPB;
-            const bool ok = bok && m < mend && (unsigned)(by[i] + dyB) < (unsigned)H && (unsigned)(bx[i] + dxB) < (unsigned)W;
+            const int y = (int)__umulhi(brem[i], magicW);
+            const int x = (int)brem[i] - y * W;
+            const bool ok = bok && m < mend && (unsigned)(y + dyB) < (unsigned)H && (unsigned)(x + dxB) < (unsigned)W;
             rb[i] = buf_load16(xr, ok ? (unsigned)m * (unsigned)Cin * 4u + shiftB : OOB);
-            bx[i] += BK;                  // advance 32 pixels in raster order
-            while (bx[i] >= W) { bx[i] -= W; ++by[i]; }
-            while (by[i] >= H) by[i] -= H;
+            brem[i] += BK;
+            if (HW >= BK) { if (brem[i] >= (unsigned)HW) brem[i] -= (unsigned)HW; }
+            else brem[i] %= (unsigned)HW;
         }
         lm += BK;
     };
-    auto store_stage = [&](float* dst) {
+    auto store_stage = [&](float* dst, const f32x4 (&ra)[NA], const f32x4 (&rb)[NB]) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&dst[(pra + i * RPA) * BM + cva * 4]) = ra[i];
 #pragma unroll
@@ -332,21 +359,29 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
     };
 
     const int nK = (mend - mbeg + BK - 1) / BK;
-    issue_loads();
-    store_stage(smem);
-    issue_loads();
+    issue_loads(ra0, rb0);
+    store_stage(smem, ra0, rb0);
+    issue_loads(ra0, rb0);
+    issue_loads(ra1, rb1);
     __syncthreads();
     const int aco = lh * BM + wm * TM * 32 + li;
     const int bco = BK * BM + lh * BN + wn * TN * 32 + li;
-    for (int ks = 0; ks < nK; ++ks) {
-        const float* cur = smem + (ks & 1) * STAGE;
-        float* nxt = smem + ((ks & 1) ^ 1) * STAGE;
-        mma_part(cur + aco, cur + bco, 0, 4);
-        store_stage(nxt);
-        issue_loads();
-        mma_part(cur + aco, cur + bco, 4, 16);
-        __syncthreads();
+    float* const buf0 = smem;
+    float* const buf1 = smem + STAGE;
+#define CVK_WSTEP(cur, nxt, RA, RB)                 \
+    do {                                            \
+        mma_part(cur + aco, cur + bco, 0, 4);       \
+        store_stage(nxt, RA, RB);                   \
+        issue_loads(RA, RB);                        \
+        mma_part(cur + aco, cur + bco, 4, 16);      \
+        __syncthreads();                            \
+    } while (0)
+    int ks = 0;
+    for (; ks + 2 <= nK; ks += 2) {
+        CVK_WSTEP(buf0, buf1, ra0, rb0);
+        CVK_WSTEP(buf1, buf0, ra1, rb1);
     }
+    if (ks < nK) CVK_WSTEP(buf0, buf1, ra0, rb0);
 
     float* out = slab + (size_t)blockIdx.y * Cout * Ktot;
 #pragma unroll
@@ -517,6 +552,7 @@ extern "C" int cvk_conv3x3_wgrad(const float* x, const float* dy, float* dw, int
     CVK_CHECK_ARG(Cin_pad % 4 == 0 && ld_dy % 4 == 0 && ld_dy >= Cout, "cvk_conv3x3_wgrad: Cin_pad=%d and ld_dy=%d must be multiples of 4, ld_dy >= Cout", Cin_pad, ld_dy);
     CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(dy) && cvk_aligned16(workspace), "cvk_conv3x3_wgrad: pointers must be 16-byte aligned");
     CVK_CHECK_ARG((long)N * H * W * Cin_pad * 4 < (1L << 31) && (long)N * H * W * ld_dy * 4 < (1L << 31), "cvk_conv3x3_wgrad: x or dy exceeds the 2 GiB buffer-addressing limit; split the batch");
+    CVK_CHECK_ARG((long)H * W * W < (1L << 32), "cvk_conv3x3_wgrad: frame too large for the multiply-high row/column split");
     const int M = N * H * W, Ktot = 9 * Cin_pad;
     const WgradPlan p = plan_wgrad(M, Cin_pad, Cout);
     const size_t need = (size_t)p.splits * Cout * Ktot * sizeof(float);
