@@ -386,15 +386,7 @@ class Runner:
 
     # ---- flat gradient buffer: parameter grads are views, laid out in REVERSE execution order --------------------
     def layout_grads(self, plan, params):
-        """offsets (in floats) of every parameter inside the flat buffer; last-executed layer first."""
-        offs = [0] * len(params)
-        o = 0
-        for slot in range(len(plan.holders) - 1, -1, -1):
-            for j in range(4):
-                i = 4 * slot + j
-                offs[i] = o
-                o += (params[i].numel() + 3) // 4 * 4     # keep every view 16-byte aligned
-        return offs, o
+        return layout_grads(params)
 
     def grad_ptrs(self, st, slot):
         base = st.gflat.data_ptr()
@@ -482,6 +474,20 @@ class Runner:
             if not any(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in params):
                 return f
         return torch.empty(total, device=dev, dtype=_F32)
+
+
+def layout_grads(params):
+    """Offsets (in floats) of every parameter inside the flat gradient buffer.  `params` is the executor's flat list
+    [w, b, gamma, beta] per conv block in execution order; the LAST-executed block comes first in the buffer, so the
+    buffer fills front to back during backward and contiguous prefixes can be all-reduced early (ddp.GradSync)."""
+    offs = [0] * len(params)
+    o = 0
+    for slot in range(len(params) // 4 - 1, -1, -1):
+        for j in range(4):
+            i = 4 * slot + j
+            offs[i] = o
+            o += (params[i].numel() + 3) // 4 * 4     # keep every view 16-byte aligned
+    return offs, o
 
 
 class _PlanFunction(torch.autograd.Function):
