@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_BPS = 8.0e12             # MI355X_MICROARCH.md: HBM3E spec (6.29e12 measured copy)
 PER_GPU_BATCH = 8
 H, W = 360, 480
 
@@ -138,19 +139,23 @@ def main():
 
     roof = None
     kernels = None
+    hbm_kernels = None
     if not a.no_kernel_profile:
         R = runner_of(net)
         R.prof = []
         for _ in range(3):
             step()
         torch.cuda.synchronize(dev)
-        agg = {}
-        for name, flops, e0, e1 in R.prof:
-            d = agg.setdefault(name, [0, 0.0, 0.0])
-            d[0] += 1; d[1] += flops; d[2] += e0.elapsed_time(e1) * 1e-3
+        agg, mem = {}, {}
+        for name, work, e0, e1, unit in R.prof:
+            d = (agg if unit == "flop" else mem).setdefault(name, [0, 0.0, 0.0])
+            d[0] += 1; d[1] += work; d[2] += e0.elapsed_time(e1) * 1e-3
         R.prof = None
         kernels = {k: {"launches_per_step": v[0] // 3, "avg_us": round(v[2] / v[0] * 1e6, 1),
                        "tflops": round(v[1] / v[2] / 1e12, 2), "ms_per_step": round(v[2] / 3 * 1e3, 3)} for k, v in agg.items()}
+        hbm_kernels = {k: {"launches_per_step": v[0] // 3, "ms_per_step": round(v[2] / 3 * 1e3, 3),
+                           "algorithmic_GBps": round(v[1] / v[2] / 1e9, 1), "frac_of_8TBps": round(v[1] / v[2] / PEAK_HBM_BPS, 3)}
+                       for k, v in mem.items()}
         dom = max(agg.items(), key=lambda kv: kv[1][2])
         cnt, fl, sec = dom[1]
         ach = fl / sec / 1e12
@@ -180,6 +185,8 @@ def main():
         }
         if kernels:
             line["conv_kernels"] = kernels
+        if hbm_kernels:
+            line["hbm_kernels"] = hbm_kernels
         if opt_ms is not None:
             line["adamw_ms"] = round(opt_ms, 3)
         print(json.dumps(line), flush=True)

@@ -40,8 +40,9 @@ def make_buckets(layer_ranges, bucket_floats):
 class GradSync:
     """Called by engine.Runner.backward: begin() -> layer_done(slot) for each conv block in reverse order -> finish()."""
 
-    def __init__(self, process_group=None, bucket_mb=32.0):
+    def __init__(self, process_group=None, bucket_mb=32.0, always_issue=False):
         self.pg = process_group
+        self.always_issue = always_issue     # issue the collectives even for world_size 1 (plumbing tests)
         self.bucket_floats = int(bucket_mb * (1 << 20) / 4)
         self.world = dist.get_world_size(process_group)
         self._native_avg = dist.get_backend(process_group) == "nccl"
@@ -71,7 +72,7 @@ class GradSync:
             self._next_bucket += 1
 
     def _issue(self, t):
-        if self.world == 1:
+        if self.world == 1 and not self.always_issue:
             return
         if self._native_avg:
             self._work.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.pg, async_op=True), None))
@@ -94,11 +95,11 @@ class DataParallel(nn.Module):
     >>> net = DataParallel(UNet(3, 12).cuda())
     Each rank feeds its own minibatch shard; after loss.backward() every rank holds the gradient mean."""
 
-    def __init__(self, module, process_group=None, bucket_mb=32.0, broadcast=True):
+    def __init__(self, module, process_group=None, bucket_mb=32.0, broadcast=True, always_issue=False):
         super().__init__()
         from .modules import runner_of
         self.module = module
-        self.sync = GradSync(process_group, bucket_mb)
+        self.sync = GradSync(process_group, bucket_mb, always_issue)
         if broadcast and self.sync.world > 1:
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):

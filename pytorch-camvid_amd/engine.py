@@ -89,15 +89,17 @@ def conv_kernel_name(kind, n_cols, k_ch=32):
     return f"k_conv3x3_igemm<{t}, {'true' if kind == 'fwd' else 'false'}, {'true' if k_ch % 32 == 0 else 'false'}>"
 
 
-def _timed(R, name, flops, fn):
-    """Run fn(); when a profile list is attached (bench.py), bracket it with HIP events on the launch stream."""
+def _timed(R, name, work, fn, unit="flop"):
+    """Run fn(); when a profile list is attached (bench.py), bracket it with HIP events on the launch stream.
+    `work` is the ALGORITHMIC work of the call: FLOPs for the conv kernels, HBM bytes (each input read once, each
+    output written once, fp32) for the memory-bound kernels."""
     if R.prof is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = fn()
     e1.record()
-    R.prof.append((name, flops, e0, e1))
+    R.prof.append((name, work, e0, e1, unit))
     return r
 
 
@@ -166,7 +168,8 @@ class ConvBnRelu(Op):
             check(lib.cvk_bn_eval_params(gamma.data_ptr(), beta.data_ptr(), bn.running_mean.data_ptr(),
                                          bn.running_var.data_ptr(), pm, pr, psc, psh, C, float(bn.eps), s), "cvk_bn_eval_params")
         out = R.alloc_act(st, dst.buf, dev)
-        check(lib.cvk_bn_relu_apply(y.data_ptr(), ldy, psc, psh, dst.cview(out), N, H, W, C, s), "cvk_bn_relu_apply")
+        _timed(R, "k_bn_relu_apply", 8.0 * M * C, lambda: check(
+            lib.cvk_bn_relu_apply(y.data_ptr(), ldy, psc, psh, dst.cview(out), N, H, W, C, s), "cvk_bn_relu_apply"), "byte")
         if st.need_grad:
             st.saved[self.idx] = (y, bnp)
 
@@ -184,11 +187,13 @@ class ConvBnRelu(Op):
         dO = dst.cview(st.grad[dst.buf.id])
         PB = lib.cvk_bn_bwd_blocks(M)
         part = _empty(2 * PB * C, dev)
-        check(lib.cvk_bn_bwd_reduce(dO, y.data_ptr(), ldy, psc, psh, pm, pr, part.data_ptr(), N, H, W, C, s), "cvk_bn_bwd_reduce")
+        _timed(R, "k_bn_bwd<reduce>", 8.0 * M * C, lambda: check(
+            lib.cvk_bn_bwd_reduce(dO, y.data_ptr(), ldy, psc, psh, pm, pr, part.data_ptr(), N, H, W, C, s), "cvk_bn_bwd_reduce"), "byte")
         check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, gbe, gg, s), "cvk_colsum_finalize")   # dbeta, dgamma
         dy = torch.zeros(M * ldy, device=dev, dtype=_F32) if ldy != C else _empty(M * ldy, dev)
-        check(lib.cvk_bn_bwd_dx(dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, part.data_ptr(),
-                                N, H, W, C, 1 if st.training else 0, s), "cvk_bn_bwd_dx")
+        _timed(R, "k_bn_bwd<dx>", 12.0 * M * C, lambda: check(
+            lib.cvk_bn_bwd_dx(dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, part.data_ptr(),
+                              N, H, W, C, 1 if st.training else 0, s), "cvk_bn_bwd_dx"), "byte")
         check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, gb, None, s), "cvk_colsum_finalize")  # conv bias grad
         del y
         if self.src_needs_grad:
@@ -226,8 +231,9 @@ class MaxPool(Op):
         if self.keep_code:
             code = torch.empty(d.M * d.ld, device=X.device, dtype=torch.uint8)
             st.saved[self.idx] = code
-        check(R.lib.cvk_maxpool2x2_fwd(v.cview(X), out.data_ptr(), code.data_ptr() if code is not None else None,
-                                       v.buf.N, v.H, v.W, v.C, st.stream), "cvk_maxpool2x2_fwd")
+        _timed(R, "k_maxpool_fwd", 5.0 * v.buf.N * v.H * v.W * v.C, lambda: check(
+            R.lib.cvk_maxpool2x2_fwd(v.cview(X), out.data_ptr(), code.data_ptr() if code is not None else None,
+                                     v.buf.N, v.H, v.W, v.C, st.stream), "cvk_maxpool2x2_fwd"), "byte")
 
     def bwd(self, R, st):
         v, d = self.src, self.dst
@@ -241,9 +247,10 @@ class MaxPool(Op):
             else:
                 st.grad[v.buf.id] = torch.empty_like(X)
         code = st.saved.get(self.idx)
-        check(R.lib.cvk_maxpool2x2_bwd(st.grad[d.id].data_ptr(), v.cview(X), code.data_ptr() if code is not None else None,
-                                       v.cview(st.grad[v.buf.id]), 1 if acc else 0, v.buf.N, v.H, v.W, v.C, st.stream),
-              "cvk_maxpool2x2_bwd")
+        _timed(R, "k_pool_scatter(bwd)", (13.0 if acc else 9.0) * v.buf.N * v.H * v.W * v.C, lambda: check(
+            R.lib.cvk_maxpool2x2_bwd(st.grad[d.id].data_ptr(), v.cview(X), code.data_ptr() if code is not None else None,
+                                     v.cview(st.grad[v.buf.id]), 1 if acc else 0, v.buf.N, v.H, v.W, v.C, st.stream),
+            "cvk_maxpool2x2_bwd"), "byte")
         st.grad.pop(d.id)
 
 
@@ -282,13 +289,15 @@ class Upsample(Op):
         X = st.act[self.src.id]
         out = R.alloc_act(st, self.dst, X.device)
         b = self.src
-        check(R.lib.cvk_bilinear_up2_fwd(X.data_ptr(), out.data_ptr(), b.N, b.H, b.W, b.ld, st.stream), "cvk_bilinear_up2_fwd")
+        _timed(R, "k_bilinear_fwd", 20.0 * b.M * b.ld, lambda: check(
+            R.lib.cvk_bilinear_up2_fwd(X.data_ptr(), out.data_ptr(), b.N, b.H, b.W, b.ld, st.stream), "cvk_bilinear_up2_fwd"), "byte")
 
     def bwd(self, R, st):
         g = st.grad.pop(self.dst.id)
         b = self.src
         dx = torch.empty_like(st.act[b.id])
-        check(R.lib.cvk_bilinear_up2_bwd(g.data_ptr(), dx.data_ptr(), b.N, b.H, b.W, b.ld, st.stream), "cvk_bilinear_up2_bwd")
+        _timed(R, "k_bilinear_bwd", 20.0 * b.M * b.ld, lambda: check(
+            R.lib.cvk_bilinear_up2_bwd(g.data_ptr(), dx.data_ptr(), b.N, b.H, b.W, b.ld, st.stream), "cvk_bilinear_up2_bwd"), "byte")
         assert b.id not in st.grad
         st.grad[b.id] = dx
 

@@ -138,3 +138,37 @@ def test_unet_batch8_properties():
         for i in (0, 5):
             one = net(x[i:i + 1])
             assert torch.allclose(full[i:i + 1], one, rtol=1e-4, atol=1e-5)
+
+
+def test_data_parallel_rccl_plumbing_single_rank():
+    """RCCL path on one GPU: world_size-1 'nccl' process group with the collectives forced on.  Gradients must be
+    bitwise those of the plain run (AVG over one rank), buckets must tile the flat buffer, and the all-reduces must
+    be issued while backward is still running (before finish)."""
+    import torch.distributed as dist
+    import pytorch_camvid_amd as A
+    from pytorch_camvid_amd import ddp
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1, device_id=dev())
+    try:
+        torch.manual_seed(0)
+        net = A.UNet(3, 12).to(dev()).train()
+        x, t = batch(2, 96, 128, 5)
+        lossf = A.CrossEntropyLoss()
+        lossf(net(x), t).backward()
+        ref = [p.grad.clone() for p in net.parameters()]
+        for p in net.parameters():
+            p.grad = None
+        # undo the running-stat update of the first pass so both passes see identical state
+        dp = ddp.DataParallel(net, bucket_mb=8.0, always_issue=True)
+        lossf(dp(x), t).backward()
+        torch.cuda.synchronize()
+        for a, p in zip(ref, net.parameters()):
+            assert torch.equal(a, p.grad)
+        launched = dp.sync.launched
+        assert len(launched) >= 4 and launched[0][0] == 0
+        for (a0, a1), (b0, b1) in zip(launched[:-1], launched[1:]):
+            assert a1 == b0
+        total = sum((p.numel() + 3) // 4 * 4 for p in net.parameters())
+        assert launched[-1][1] == total
+    finally:
+        dist.destroy_process_group()
