@@ -74,6 +74,15 @@ size_t cvk_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin_pad, int C
 int cvk_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,
                       int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same operator through 1-D Winograd F(2,3) along the width (1.5x fewer MFMA FLOPs; csrc/wino.hip), for Cin % 64 == 0.
+ *   U = cvk_wino_weight_transform(w): [4][Cout][3][Cin] from w [Cout][3][3][Cin].  cvk_conv3x3_wino has the contract of
+ *   cvk_conv3x3_fwd (bias, fused BN statistics partials, ldy % 4 == 0) plus a workspace holding the four transformed
+ *   products M_xi[N*H*ceil(W/2)][ldy].  Data-grad: apply it to dy with U of the cvk_pack_weight_dgrad weights. */
+int cvk_wino_weight_transform(const float* w, float* U, int Cout, int Cin, void* stream);
+size_t cvk_conv3x3_wino_workspace_bytes(int N, int H, int W, int Cout_ld);
+int cvk_conv3x3_wino(const float* x, const float* U, const float* bias, float* y, float* stats,
+                     int N, int H, int W, int Cin, int Cout, int ldy, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- BatchNorm2d (+ReLU) (models/unet.py:12-13, models/segnet.py:9-10) -------------------------------------------
  * finalize (training): combines the conv-epilogue partials (Chan's parallel variance, fp64) into per-channel
  *   mean / rstd = 1/sqrt(biased var + eps), scale = gamma*rstd, shift = beta - mean*scale, and updates

@@ -14,19 +14,9 @@
 // K-slice ahead, in flight under the previous slice's 64 MFMAs per wave) -> padded LDS rows -> ds_read_b128 fragments.
 // K order inside a slice is permuted identically for A and B (lane half h takes k = 8*kk + 4*h + j for MFMA j), which
 // lets one ds_read_b128 feed four MFMAs.
-#include "cvk_common.h"
+#include "conv_tile.h"
 
 namespace {
-
-constexpr int BK = 32;        // K slice per LDS stage (floats)
-constexpr int LDT = BK + 4;   // padded LDS row: 144 B -> the 16 rows of a ds_read_b128 lane group hit 16 distinct slots
-constexpr unsigned OOB = 0x80000000u;  // buffer offset beyond num_records (< 2 GiB by contract): the load returns 0
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
-}
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad
 // Pipeline per K slice (one barrier per slice, two LDS stages, one register stage):

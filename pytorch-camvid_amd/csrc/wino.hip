@@ -1,0 +1,354 @@
+// wino.hip — 3x3 convolution as 1-D Winograd F(2,3) along the image width on the fp32 matrix cores.
+//
+// Same operator as conv3x3.hip (nn.Conv2d(cin,cout,3,padding=1): reference models/unet.py:11, models/segnet.py:8) with
+// 1.5x fewer multiplies: per kernel row r and output-column pair (2t, 2t+1)
+//     y[2t]   = m0 + m1 + m2,   y[2t+1] = m1 - m2 - m3,      m_xi = sum_{r,ci} V_xi[r][ci] * U_xi[r][ci]
+//     V = (d0-d2, d1+d2, d2-d1, d1-d3)  with d_o = x[y+r-1][2t-1+o],   U = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2).
+// Each xi is an implicit GEMM  M_xi[tiles][Cout] = V_xi[tiles][3*Cin] * U_xi[3*Cin][Cout]  (K = 3*Cin instead of 9*Cin, and
+// half as many rows).  The input transform costs nothing in memory: the staging path loads the two pixels a V element
+// needs (range-checked buffer loads -> zero padding for free) and combines them with one FMA on the way to LDS.  One
+// workgroup walks all four xi of its (tile block, channel block) back to back so the load pipeline never drains and
+// the four accumulator flushes overlap the next xi's MFMAs.  The output transform (+bias, +BatchNorm statistics) is a
+// separate HBM-bound pass (k_wino_output).  Arithmetic is exact-fp32 MFMA; only the summation order differs from
+// the direct kernel (error ~1e-7 relative, same order as the direct kernel's).
+#include "conv_tile.h"
+
+namespace {
+
+// U[xi][co][r][ci] from w[co][r][s][ci]
+__global__ void k_wino_weight(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin) {
+    const size_t total = (size_t)Cout * 3 * Cin;
+    const size_t plane = total;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        const size_t cr = i / Cin;   // co*3 + r
+        const float* g = w + (cr * 3) * Cin + ci;
+        const float g0 = g[0], g1 = g[Cin], g2 = g[2 * (size_t)Cin];
+        U[i] = g0;
+        U[plane + i] = 0.5f * (g0 + g1 + g2);
+        U[2 * plane + i] = 0.5f * (g0 - g1 + g2);
+        U[3 * plane + i] = g2;
+    }
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N>
+__global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino(
+    const float* __restrict__ X, const float* __restrict__ U, float* __restrict__ Mo, int Mt, int H, int W, int Wt,
+    int Cin, int Cout, int ldm, int tilesN, int Mpix, int nxi) {
+    constexpr int NT = WARPS_M * WARPS_N * 64;
+    constexpr int TM = BM / WARPS_M / 32, TN = BN / WARPS_N / 32;
+    constexpr int RP = NT / 8;
+    constexpr int NA = BM / RP, NB = BN / RP;
+    constexpr int STAGE = (BM + BN) * LDT;
+    static_assert(NA >= 1 && NB >= 1 && BM % RP == 0 && BN % RP == 0, "tile/threads mismatch");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+
+    const int tile = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tilesN) * BM;
+    const int n0 = (tile % tilesN) * BN;
+    const int K3 = 3 * Cin;
+    const int nK = K3 / BK;   // even by contract (Cin % 64 == 0)
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, Mpix * Cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, 4 * Cout * K3 * 4, 0x00020000);
+
+    const int kv = tid & 7, r0 = tid >> 3;
+    // per staged row: byte offset of pixel (n, y, 2*xt) (a multiple of 256 because Cin % 64 == 0) with the 7 validity
+    // bits in its low byte: bit r (r<3): image row y+r-1 exists; bit 3+o (o<4): column 2*xt-1+o exists
+    unsigned arow[NA], boff[NB];
+    const int HWt = H * Wt;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int t = m0 + r0 + i * RP;
+        unsigned v = 0;
+        if (t < Mt) {
+            const int n = t / HWt, rem = t - n * HWt;
+            const int y = rem / Wt, xt = rem - y * Wt;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                if ((unsigned)(y + r - 1) < (unsigned)H) v |= 1u << r;
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if ((unsigned)(2 * xt + o - 1) < (unsigned)W) v |= 8u << o;
+            v |= (unsigned)((n * H + y) * W + 2 * xt) * (unsigned)Cin * 4u;
+        }
+        arow[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int co = n0 + r0 + i * RP;
+        boff[i] = co < Cout ? (unsigned)co * (unsigned)K3 * 4u + kv * 16u : OOB;
+    }
+    const unsigned kvb = kv * 16u;
+
+    // Register stages: the "p" pixel of every V element is loaded two-and-a-half slices ahead (two stages), the "q"
+    // pixel and the weights one slice ahead (their lines are L2-warm: q of tile xt is p of tile xt+1 / of the previous
+    // xi phase, weights are re-read by every row block) -> 64 staging VGPRs, which keeps two workgroups per CU.
+    f32x4 rp0[NA], rp1[NA], rq[NA], rb[NB];
+    // blockIdx.y selects which of the 4 transform indices this workgroup walks (all 4 when gridDim.y == 1; one each
+    // when the layer has too few tile blocks to fill the chip otherwise)
+    const int xi_begin = blockIdx.y * nxi, xi_end = xi_begin + nxi;
+    int pxi = xi_begin, pr = 0, pcib = 0;   // next slice for the p loads   (transform index, kernel row, channel base; uniform)
+    int qxi = xi_begin, qr = 0, qcib = 0;   // next slice for the q / weight loads
+
+    // xi: 0 -> d0-d2   1 -> d1+d2   2 -> d2-d1   3 -> d1-d3        (d_o sits at column 2*xt-1+o)
+    auto issue_p = [&](f32x4 (&rp)[NA]) {
+        const int po = pxi == 0 ? -1 : (pxi == 2 ? 1 : 0);
+        const unsigned sh = (unsigned)((((pr - 1) * W + po) * Cin + pcib) * 4) + kvb;
+        const unsigned need = (pxi < xi_end ? (1u << pr) : 0x80u) | (8u << (po + 1));   // 0x80 is never set: past-the-end -> zeros
+#pragma unroll
+        for (int i = 0; i < NA; ++i) rp[i] = buf_load16(xr, (arow[i] & need) == need ? (arow[i] & ~0xFFu) + sh : OOB);
+        pcib += BK;
+        if (pcib >= Cin) {
+            pcib = 0;
+            if (++pr == 3) { pr = 0; ++pxi; }
+        }
+    };
+    float sg = 1.f;                    // V = p + sg*q for the slice whose q is in rq
+    auto issue_qb = [&]() {
+        const int qo = qxi == 2 ? 0 : (qxi == 3 ? 2 : 1);
+        sg = qxi == 1 ? 1.f : -1.f;
+        const unsigned sh = (unsigned)((((qr - 1) * W + qo) * Cin + qcib) * 4) + kvb;
+        const unsigned need = (qxi < xi_end ? (1u << qr) : 0x80u) | (8u << (qo + 1));
+#pragma unroll
+        for (int i = 0; i < NA; ++i) rq[i] = buf_load16(xr, (arow[i] & need) == need ? (arow[i] & ~0xFFu) + sh : OOB);
+        const unsigned ub = qxi < xi_end ? (unsigned)((qxi * Cout * K3 + qr * Cin + qcib) * 4) : OOB;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = buf_load16(ur, (boff[i] | ub) & OOB ? OOB : boff[i] + ub);
+        qcib += BK;
+        if (qcib >= Cin) {
+            qcib = 0;
+            if (++qr == 3) { qr = 0; ++qxi; }
+        }
+    };
+    auto store_stage = [&](float* dst, const f32x4 (&rp)[NA]) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaf(sg, rq[i][j], rp[i][j]);
+            *reinterpret_cast<f32x4*>(&dst[(r0 + i * RP) * LDT + kv * 4]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&dst[BM * LDT + (r0 + i * RP) * LDT + kv * 4]) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    auto mma_kk = [&](const float* arow_, const float* brow_, int kk) {
+        f32x4 a[TM], b[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const f32x4*>(arow_ + t * 32 * LDT + kk * 8);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const f32x4*>(brow_ + t * 32 * LDT + kk * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
+    };
+
+    // prologue: slice 0 into LDS stage 0; p of slices 1 and 2 in flight
+    issue_p(rp0);
+    issue_qb();
+    store_stage(smem, rp0);
+    issue_p(rp0);
+    issue_p(rp1);
+    __syncthreads();
+    const int aro = (wm * TM * 32 + li) * LDT + lh * 4;
+    const int bro = BM * LDT + (wn * TN * 32 + li) * LDT + lh * 4;
+    float* const buf0 = smem;
+    float* const buf1 = smem + STAGE;
+    const int rowbase = m0 + wm * TM * 32;
+    const bool full = (m0 + BM <= Mt) && (n0 + BN <= ldm);
+
+#define CVK_WINO_STEP(cur, nxt, RP_)                  \
+    do {                                              \
+        issue_qb();                  /* slice ks+1 */ \
+        mma_kk(cur + aro, cur + bro, 0);              \
+        mma_kk(cur + aro, cur + bro, 1);              \
+        store_stage(nxt, RP_);       /* slice ks+1 */ \
+        issue_p(RP_);                /* slice ks+3 */ \
+        mma_kk(cur + aro, cur + bro, 2);              \
+        mma_kk(cur + aro, cur + bro, 3);              \
+        __syncthreads();                              \
+    } while (0)
+
+    for (int xi = xi_begin; xi < xi_end; ++xi) {
+        for (int ks = 0; ks < nK; ks += 2) {
+            CVK_WINO_STEP(buf0, buf1, rp0);
+            CVK_WINO_STEP(buf1, buf0, rp1);
+        }
+        // flush M_xi (the next xi's slices are already in flight / in LDS) and restart the accumulators
+        float* out = Mo + (size_t)xi * Mt * ldm;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = n0 + wn * TN * 32 + tn * 32 + li;
+            if (full) {
+                float* yp = out + (size_t)(rowbase + 4 * lh) * ldm + col;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        yp[(size_t)(tm * 32 + (r & 3) + 8 * (r >> 2)) * ldm] = acc[tm][tn][r];
+                        acc[tm][tn][r] = 0.f;
+                    }
+            } else {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rowbase + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (row < Mt && col < ldm) out[(size_t)row * ldm + col] = acc[tm][tn][r];
+                        acc[tm][tn][r] = 0.f;
+                    }
+            }
+        }
+    }
+#undef CVK_WINO_STEP
+}
+
+// y[pixel][c] = A^T-combination of M_0..3 + bias; BatchNorm statistics partials per 64-pixel granule
+// (sum and M2 about the granule mean, from bias-shifted sums).  One block = one granule x up to 1024 channels.
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_wino_output(const float* __restrict__ Mo, int ldm, int Mt,
+                                                    const float* __restrict__ bias, float* __restrict__ Y, int ldy,
+                                                    float* __restrict__ stats, int P, int Mpix, int H, int W, int Wt,
+                                                    int C, int Cout) {
+    __shared__ float red[2][1024];
+    const int c0 = blockIdx.y * 1024;
+    const int cw = min(1024, C - c0);
+    const int cvn = cw / 4, ppp = 256 / cvn;
+    const int t = threadIdx.x;
+    const bool active = t < cvn * ppp;
+    const int cv = t % cvn, pr = t / cvn;
+    const int c = c0 + cv * 4;
+    const int mbeg = blockIdx.x * CVK_STAT_ROWS, mend = min(Mpix, mbeg + CVK_STAT_ROWS);
+    f32x4 sh = {0.f, 0.f, 0.f, 0.f};
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        if (bias != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sh[j] = (c + j < Cout) ? bias[c + j] : 0.f;
+        }
+        const int HW = H * W;
+        const size_t plane = (size_t)Mt * ldm;
+        for (int m = mbeg + pr; m < mend; m += ppp) {
+            const int n = m / HW, rem = m - n * HW;
+            const int y = rem / W, x = rem - y * W;
+            const float* p = Mo + ((size_t)(n * H + y) * Wt + (x >> 1)) * ldm + c;
+            const f32x4 m1 = *reinterpret_cast<const f32x4*>(p + plane);
+            const f32x4 m2 = *reinterpret_cast<const f32x4*>(p + 2 * plane);
+            f32x4 v;
+            if (x & 1) {
+                const f32x4 m3 = *reinterpret_cast<const f32x4*>(p + 3 * plane);
+                v = m1 - m2 - m3;
+            } else {
+                const f32x4 m0v = *reinterpret_cast<const f32x4*>(p);
+                v = m0v + m1 + m2;
+            }
+            v += sh;
+            *reinterpret_cast<f32x4*>(Y + (size_t)m * ldy + c) = v;
+            if (STATS) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = v[j] - sh[j];
+                    s1[j] += d;
+                    s2[j] += d * d;
+                }
+            }
+        }
+    }
+    if (!STATS) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[0][t * 4 + j] = s1[j];
+        red[1][t * 4 + j] = s2[j];
+    }
+    __syncthreads();
+    if (t < cvn) {
+        const float cnt = (float)(mend - mbeg);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.f, b = 0.f;
+            for (int p = 0; p < ppp; ++p) {
+                a += red[0][(p * cvn + t) * 4 + j];
+                b += red[1][(p * cvn + t) * 4 + j];
+            }
+            const int ch = c0 + t * 4 + j;
+            if (ch < Cout) {
+                float m2 = b - a * a / cnt;
+                stats[(size_t)blockIdx.x * Cout + ch] = a + cnt * sh[j];   // sh is per-thread: thread t owns channels c0+4t..
+                stats[(size_t)(P + blockIdx.x) * Cout + ch] = m2 > 0.f ? m2 : 0.f;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cvk_wino_weight_transform(const float* w, float* U, int Cout, int Cin, void* stream) {
+    CVK_CHECK_ARG(w && U && Cout > 0 && Cin > 0, "cvk_wino_weight_transform: bad arguments");
+    const size_t total = (size_t)Cout * 3 * Cin;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_wino_weight, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
+    CVK_LAUNCH_RETURN("cvk_wino_weight_transform");
+}
+
+extern "C" size_t cvk_conv3x3_wino_workspace_bytes(int N, int H, int W, int Cout_ld) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cout_ld <= 0) return 0;
+    return (size_t)4 * N * H * ((W + 1) / 2) * Cout_ld * sizeof(float);
+}
+
+extern "C" int cvk_conv3x3_wino(const float* x, const float* U, const float* bias, float* y, float* stats, int N, int H,
+                                int W, int Cin, int Cout, int ldy, void* workspace, size_t workspace_bytes, void* stream) {
+    CVK_CHECK_ARG(x && U && y && workspace, "cvk_conv3x3_wino: null pointer");
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout && ldy % 4 == 0, "cvk_conv3x3_wino: bad shape");
+    CVK_CHECK_ARG(Cin > 0 && Cin % 64 == 0, "cvk_conv3x3_wino: Cin=%d must be a multiple of 64 (use cvk_conv3x3_fwd otherwise)", Cin);
+    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(U) && cvk_aligned16(y) && cvk_aligned16(workspace), "cvk_conv3x3_wino: pointers must be 16-byte aligned");
+    CVK_CHECK_ARG((long)N * H * W * Cin * 4 < (1L << 31) && (long)4 * Cout * 3 * Cin * 4 < (1L << 31), "cvk_conv3x3_wino: tensor exceeds the 2 GiB buffer-addressing limit; split the batch");
+    const int Wt = (W + 1) / 2, Mt = N * H * Wt, Mpix = N * H * W;
+    if (workspace_bytes < cvk_conv3x3_wino_workspace_bytes(N, H, W, ldy)) {
+        cvk_set_error("cvk_conv3x3_wino: workspace too small");
+        return CVK_EWORKSPACE;
+    }
+    float* Mo = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    // few tile blocks (deep, small-spatial layers): give every transform index its own workgroup so the grid still
+    // covers the 256 CUs twice; K per index (3*Cin/32 slices) is long there, so the extra prologues are cheap
+    if (ldy > 64) {
+        const int tilesN = cvk_cdiv(ldy, 128), tilesM = cvk_cdiv(Mt, 128);
+        const int split = (tilesM * tilesN < 1024 && Cin >= 256) ? 4 : 1;
+        hipLaunchKernelGGL((k_conv3x3_wino<128, 128, 2, 2>), dim3(tilesM * tilesN, split), dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, Mpix, 4 / split);
+    } else {
+        const int tilesN = cvk_cdiv(ldy, 64), tilesM = cvk_cdiv(Mt, 128);
+        const int split = (tilesM * tilesN < 1024 && Cin >= 256) ? 4 : 1;
+        hipLaunchKernelGGL((k_conv3x3_wino<128, 64, 2, 2>), dim3(tilesM * tilesN, split), dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, Mpix, 4 / split);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        cvk_set_error("cvk_conv3x3_wino: launch failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    const int P = cvk_cdiv(Mpix, CVK_STAT_ROWS);
+    dim3 grid(P, cvk_cdiv(ldy, 1024));
+    if (stats)
+        hipLaunchKernelGGL(k_wino_output<true>, grid, dim3(256), 0, s, Mo, ldy, Mt, bias, y, ldy, stats, P, Mpix, H, W, Wt, ldy, Cout);
+    else
+        hipLaunchKernelGGL(k_wino_output<false>, grid, dim3(256), 0, s, Mo, ldy, Mt, bias, y, ldy, stats, P, Mpix, H, W, Wt, ldy, Cout);
+    CVK_LAUNCH_RETURN("cvk_conv3x3_wino");
+}

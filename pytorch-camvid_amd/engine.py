@@ -80,8 +80,19 @@ def _empty(n, dev, dtype=_F32):
     return torch.empty(n, device=dev, dtype=dtype)
 
 
+import os
+
+WINO_DEFAULT = os.environ.get("CVK_WINO", "1") != "0"   # 1-D Winograd F(2,3) for eligible layers (Cin % 64 == 0, > 32 columns)
+
+
+def wino_ok(R, k_ch, n_cols):
+    return R.wino and k_ch % 64 == 0 and n_cols > 32
+
+
 def conv_kernel_name(kind, n_cols, k_ch=32):
-    """Mirror of the tile dispatch in csrc/conv3x3.hip (cvk_conv3x3_fwd / plan_wgrad): the kernel-trace name."""
+    """Mirror of the tile dispatch in csrc/conv3x3.hip / wino.hip: the kernel-trace name."""
+    if kind == "wino":
+        return "k_conv3x3_wino<128, 128, 2, 2>" if n_cols > 64 else "k_conv3x3_wino<128, 64, 2, 2>"
     if kind == "wgrad":
         t = "128, 128, 2, 2" if n_cols > 64 else ("64, 128, 2, 2" if n_cols > 32 else "32, 256, 1, 4")
         return f"k_conv3x3_wgrad<{t}>"
@@ -132,6 +143,24 @@ class ConvBnRelu(Op):
         check(R.lib.cvk_pack_weight_fwd(wc.data_ptr(), out.data_ptr(), self.cout, self.cin, ldx, st.stream), "cvk_pack_weight_fwd")
         return out
 
+    def _conv(self, R, st, X, wk, b, y, stats, kind):
+        """y = conv3x3(X, wk) + b (+ BN statistics partials): Winograd F(2,3) kernel when eligible, else direct."""
+        lib, s, src = R.lib, st.stream, self.src
+        N, H, W, M, C, ldy = src.N, src.H, src.W, src.M, self.cout, pad4(self.cout)
+        sp = stats.data_ptr() if stats is not None else None
+        if wino_ok(R, src.ld, ldy):
+            U = _empty(4 * C * 3 * src.ld, X.device)
+            check(lib.cvk_wino_weight_transform(wk.data_ptr(), U.data_ptr(), C, src.ld, s), "cvk_wino_weight_transform")
+            wsb = lib.cvk_conv3x3_wino_workspace_bytes(N, H, W, ldy)
+            ws = R.workspace(wsb, X.device)
+            _timed(R, conv_kernel_name("wino", ldy), 18.0 * M * C * self.cin, lambda: check(
+                lib.cvk_conv3x3_wino(X.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy,
+                                     ws.data_ptr(), wsb, s), "cvk_conv3x3_wino"))
+        else:
+            _timed(R, conv_kernel_name("fwd", ldy, src.ld), 18.0 * M * C * self.cin, lambda: check(
+                lib.cvk_conv3x3_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy, s),
+                "cvk_conv3x3_fwd"))
+
     def fwd(self, R, st):
         lib, s = R.lib, st.stream
         src, dst = self.src, self.dst
@@ -150,9 +179,7 @@ class ConvBnRelu(Op):
             stats = _empty(2 * P * C, dev)
             if M <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {[N, C, H, W]}")
-            _timed(R, conv_kernel_name("fwd", ldy, src.ld), 18.0 * M * C * self.cin, lambda: check(
-                lib.cvk_conv3x3_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(),
-                                    N, H, W, src.ld, C, ldy, s), "cvk_conv3x3_fwd"))
+            self._conv(R, st, X, wk, b, y, stats, "fwd")
             wsb = lib.cvk_bn_finalize_workspace_bytes(P, C)
             ws = R.workspace(wsb, dev)
             track = bn.track_running_stats and bn.running_mean is not None
@@ -163,8 +190,7 @@ class ConvBnRelu(Op):
                                       bn.num_batches_tracked.data_ptr() if track else None,
                                       mom, float(bn.eps), ws.data_ptr(), wsb, s), "cvk_bn_finalize")
         else:
-            check(lib.cvk_conv3x3_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), None,
-                                      N, H, W, src.ld, C, ldy, s), "cvk_conv3x3_fwd")
+            self._conv(R, st, X, wk, b, y, None, "fwd")
             check(lib.cvk_bn_eval_params(gamma.data_ptr(), beta.data_ptr(), bn.running_mean.data_ptr(),
                                          bn.running_var.data_ptr(), pm, pr, psc, psh, C, float(bn.eps), s), "cvk_bn_eval_params")
         out = R.alloc_act(st, dst.buf, dev)
@@ -203,9 +229,18 @@ class ConvBnRelu(Op):
             wd = _empty(src.ld * 9 * ldy, dev)
             check(lib.cvk_pack_weight_dgrad(wc.data_ptr(), wd.data_ptr(), C, self.cin, src.ld, ldy, s), "cvk_pack_weight_dgrad")
             dX = _empty(M * src.ld, dev).view(N, H, W, src.ld)
-            _timed(R, conv_kernel_name("dgrad", src.ld, ldy), 18.0 * M * C * self.cin, lambda: check(
-                lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
-                "cvk_conv3x3_fwd(dgrad)"))
+            if wino_ok(R, ldy, src.ld):
+                U = _empty(4 * src.ld * 3 * ldy, dev)
+                check(lib.cvk_wino_weight_transform(wd.data_ptr(), U.data_ptr(), src.ld, ldy, s), "cvk_wino_weight_transform")
+                wsb2 = lib.cvk_conv3x3_wino_workspace_bytes(N, H, W, src.ld)
+                ws2 = R.workspace(wsb2, dev)
+                _timed(R, conv_kernel_name("wino", src.ld), 18.0 * M * C * self.cin, lambda: check(
+                    lib.cvk_conv3x3_wino(dy.data_ptr(), U.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld,
+                                         ws2.data_ptr(), wsb2, s), "cvk_conv3x3_wino(dgrad)"))
+            else:
+                _timed(R, conv_kernel_name("dgrad", src.ld, ldy), 18.0 * M * C * self.cin, lambda: check(
+                    lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
+                    "cvk_conv3x3_fwd(dgrad)"))
             st.grad[src.id] = dX
         wsb = lib.cvk_conv3x3_wgrad_workspace_bytes(N, H, W, src.ld, C)
         ws = R.workspace(wsb, dev)
@@ -377,6 +412,7 @@ class Runner:
         self.lib = _lib.load()
         self._ws = None
         self.grad_sync = None       # set by ddp.DataParallel
+        self.wino = WINO_DEFAULT
         self.prof = None            # list collecting (kernel name, flops, start event, end event) when bench.py profiles
         self._flat = [None, None]   # alternating flat gradient buffers (see grad_flat)
 

@@ -228,7 +228,10 @@ def gold_nets():
     net_case("unet", 1, (1, 3, 45, 60), 77, "unet_s1_1x45x60")          # odd sizes: 45->22->44->pad 45
     net_case("unet", 2, (2, 3, 36, 52), 78, "unet_s2_2x36x52")          # pads at several levels
     net_case("segnet", 0, (2, 3, 64, 96), 1234, "segnet_s0_2x64x96", steps=3, total_steps=30)
-    net_case("segnet", 3, (1, 3, 45, 60), 79, "segnet_s3_1x45x60")
+    # odd sizes through five pools (45->22->11->5->2->1).  Batch 2: with batch 1 the 2x3 maps give BatchNorm only six
+    # samples and the REFERENCE ITSELF is chaotic there (its fp32 and fp64 runs differ by 1.08 on the logits, as does a
+    # 1e-6 input perturbation) — such a case cannot pin parity, so it is not used as a golden.
+    net_case("segnet", 3, (2, 3, 45, 60), 79, "segnet_s3_2x45x60")
 
 
 def gold_fullsize():

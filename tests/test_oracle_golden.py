@@ -90,7 +90,7 @@ def test_miou_histograms():
         assert np.array_equal(ti, d[f"{t}_inter"]) and np.array_equal(tu, d[f"{t}_union"])
 
 
-NETS = ["unet_s0_2x48x64", "unet_s1_1x45x60", "unet_s2_2x36x52", "segnet_s0_2x64x96", "segnet_s3_1x45x60"]
+NETS = ["unet_s0_2x48x64", "unet_s1_1x45x60", "unet_s2_2x36x52", "segnet_s0_2x64x96", "segnet_s3_2x45x60"]
 
 
 @pytest.mark.parametrize("tag", NETS)

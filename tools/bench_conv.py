@@ -40,7 +40,7 @@ def timeit(fn, n=5):
 
 def main():
     lib = _lib.load(); N = 8
-    which = sys.argv[1:] or ["fwd", "dgrad", "wgrad"]
+    which = sys.argv[1:] or ["fwd", "wino", "dgrad", "wgrad"]
     s = torch.cuda.current_stream().cuda_stream
     dev = "cuda"
     tot = {k: [0.0, 0.0] for k in which}
@@ -55,6 +55,12 @@ def main():
         if "fwd" in which:
             t = timeit(lambda: check(lib.cvk_conv3x3_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, ci, co, ldy, s)))
             row += f" fwd {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["fwd"][0] += flops; tot["fwd"][1] += t
+        if "wino" in which and ci % 64 == 0 and ldy > 32:
+            U = torch.empty(4 * co * 3 * ci, device=dev)
+            check(lib.cvk_wino_weight_transform(w.data_ptr(), U.data_ptr(), co, ci, s))
+            wsb = lib.cvk_conv3x3_wino_workspace_bytes(N, H, W, ldy); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            t = timeit(lambda: check(lib.cvk_conv3x3_wino(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, ci, co, ldy, ws.data_ptr(), wsb, s)))
+            row += f" wino {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["wino"][0] += flops; tot["wino"][1] += t
         if "dgrad" in which and name != "down1.0":
             dy = torch.randn(M, ldy, device=dev); wd = torch.randn(ci, 9 * ldy, device=dev) * 0.05; dx = torch.empty(M, ci, device=dev)
             t = timeit(lambda: check(lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), None, N, H, W, ldy, ci, ci, s)))

@@ -1,0 +1,20 @@
+import sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pytorch_camvid_amd import _lib
+from pytorch_camvid_amd._lib import check
+lib=_lib.load(); s=torch.cuda.current_stream().cuda_stream
+def one(N,H,W,ci,co):
+    M=N*H*W; torch.manual_seed(1)
+    x=torch.randn(M,ci,device='cuda'); w=torch.randn(co,9*ci,device='cuda')*0.05; b=torch.randn(co,device='cuda')
+    ldy=(co+3)//4*4; P=(M+63)//64
+    y1=torch.zeros(M,ldy,device='cuda'); y2=torch.zeros(M,ldy,device='cuda'); s1=torch.zeros(2*P*co,device='cuda'); s2=torch.zeros(2*P*co,device='cuda')
+    check(lib.cvk_conv3x3_fwd(x.data_ptr(),w.data_ptr(),b.data_ptr(),y1.data_ptr(),s1.data_ptr(),N,H,W,ci,co,ldy,s))
+    U=torch.empty(4*co*3*ci,device='cuda'); check(lib.cvk_wino_weight_transform(w.data_ptr(),U.data_ptr(),co,ci,s))
+    wsb=lib.cvk_conv3x3_wino_workspace_bytes(N,H,W,ldy); ws=torch.zeros(wsb,dtype=torch.uint8,device='cuda')
+    check(lib.cvk_conv3x3_wino(x.data_ptr(),U.data_ptr(),b.data_ptr(),y2.data_ptr(),s2.data_ptr(),N,H,W,ci,co,ldy,ws.data_ptr(),wsb,s))
+    torch.cuda.synchronize()
+    e=(y1-y2).abs().max().item(); es=(s1-s2).abs().max().item()
+    bad=((y1-y2).abs()>1e-3).nonzero()
+    print(f"N{N} {H}x{W} {ci}->{co}: max|dy|={e:.3e} (|y|max {y1.abs().max().item():.2f}) stats diff {es:.3e} (|s|max {s1.abs().max().item():.1f}) nbad={len(bad)}", bad[:6].tolist() if len(bad) else "")
+for shp in [(1,2,3,512,512),(1,5,7,512,512),(1,11,15,256,256),(1,22,30,128,128),(1,45,60,64,64),(1,1,1,512,512),(1,2,3,64,64),(2,9,4,64,128),(1,1,3,64,64),(1,3,1,64,64),(1,1,2,64,64)]:
+    one(*shp)
