@@ -83,6 +83,11 @@ size_t cvk_conv3x3_wino_workspace_bytes(int N, int H, int W, int Cout_ld);
 int cvk_conv3x3_wino(const float* x, const float* U, const float* bias, float* y, float* stats,
                      int N, int H, int W, int Cin, int Cout, int ldy, void* workspace, size_t workspace_bytes, void* stream);
 
+/* weight-grad through the transposed F(2,3) (same contract as cvk_conv3x3_wgrad; any Cin_pad % 4 == 0) */
+size_t cvk_conv3x3_wgrad_wino_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout);
+int cvk_conv3x3_wgrad_wino(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,
+                           int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- BatchNorm2d (+ReLU) (models/unet.py:12-13, models/segnet.py:9-10) -------------------------------------------
  * finalize (training): combines the conv-epilogue partials (Chan's parallel variance, fp64) into per-channel
  *   mean / rstd = 1/sqrt(biased var + eps), scale = gamma*rstd, shift = beta - mean*scale, and updates

@@ -39,6 +39,8 @@ SIGNATURES = {
     "cvk_wino_weight_transform": (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
     "cvk_conv3x3_wino_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int]),
     "cvk_conv3x3_wino": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
+    "cvk_conv3x3_wgrad_wino_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
+    "cvk_conv3x3_wgrad_wino": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
     "cvk_bn_finalize_workspace_bytes": (c_size, [c_int, c_int]),
     "cvk_bn_finalize": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                 c_float, c_float, c_vp, c_size, c_vp]),

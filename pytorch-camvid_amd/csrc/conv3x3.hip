@@ -327,7 +327,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int m = lm + prb + i * RPB;
-            const int y = (int)__umulhi(brem[i], magicW);
+            const int y = W == 1 ? (int)brem[i] : (int)__umulhi(brem[i], magicW);   // 2^32/1 + 1 overflows the magic
             const int x = (int)brem[i] - y * W;
             const bool ok = bok && m < mend && (unsigned)(y + dyB) < (unsigned)H && (unsigned)(x + dxB) < (unsigned)W;
             rb[i] = buf_load16(xr, ok ? (unsigned)m * (unsigned)Cin * 4u + shiftB : OOB);

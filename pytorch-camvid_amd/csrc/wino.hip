@@ -299,6 +299,238 @@ __global__ __launch_bounds__(256) void k_wino_output(const float* __restrict__ M
     }
 }
 
+// ------------------------------------------------------------------------------------------------ weight-grad
+// Transposed F(2,3):  dW[co][r][0..2][ci] = G^T [ (A dy) (.) (B^T d) ]  summed over column pairs, with
+//   A dy = (dy0, dy0+dy1, dy0-dy1, -dy1)  (dy0/dy1 = output-gradient at columns 2t / 2t+1; we store +dy1 and flip the sign
+//   in the final combination),  B^T d = the same input transform as the forward pass.  Per xi one implicit GEMM
+//   P_xi[Cout][3*Cin] = E_xi^T[tiles][Cout] * V_xi[tiles][3*Cin]   (reduction over N*H*ceil(W/2) tiles: half the pixels,
+//   3 instead of 9 column blocks per pixel -> 12*M*Cin*Cout FLOPs instead of 18).  Both operands are transformed on the
+//   way to LDS; the 4 P_xi only meet in the (tiny, weight-sized) slab reduction, so there is no extra activation pass.
+template <int BM, int BN, int WARPS_M, int WARPS_N>
+__global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
+    const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ slab, int Mt, int H, int W, int Wt,
+    int Cin, int Cout, int ld_dy, int K3, int chunk, int tilesN, int Mpix) {
+    constexpr int NT = WARPS_M * WARPS_N * 64;
+    constexpr int TM = BM / WARPS_M / 32, TN = BN / WARPS_N / 32;
+    constexpr int VA = BM / 4, VB = BN / 4;
+    constexpr int RPA = NT / VA, RPB = NT / VB;
+    constexpr int NA = BK / RPA, NB = BK / RPB;
+    constexpr int STAGE = BK * (BM + BN);
+    static_assert(NA >= 1 && NB >= 1 && BK % RPA == 0 && BK % RPB == 0, "tile/threads mismatch");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+
+    const int tile = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int c0 = (tile / tilesN) * BM;
+    const int n0 = (tile % tilesN) * BN;
+    const int xi = blockIdx.z;
+    const int tbeg = blockIdx.y * chunk;
+    const int tend = min(Mt, tbeg + chunk);
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, Mpix * Cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)DY, 0, Mpix * ld_dy * 4, 0x00020000);
+
+    const int cva = tid % VA, pra = tid / VA;
+    const int cvb = tid % VB, prb = tid / VB;
+    const int coA = c0 + cva * 4;
+    const bool aok = coA < Cout;
+    const int colB = n0 + cvb * 4;
+    const bool bok = colB < K3;
+    const int rB = bok ? colB / Cin : 0;              // kernel row of this thread's column
+    const int ciB = colB - rB * Cin;
+    // input-transform taps for this xi (column offsets relative to 2*xt) and signs
+    const int po = xi == 0 ? -1 : (xi == 2 ? 1 : 0);
+    const int qo = xi == 2 ? 0 : (xi == 3 ? 2 : 1);
+    const float sgB = xi == 1 ? 1.f : -1.f;
+    const float sgA = xi == 2 ? -1.f : 1.f;           // E = a0 + sgA*a1 with a0 = dy0 (off for xi 3), a1 = dy1 (off for xi 0)
+    const bool useA0 = xi != 3, useA1 = xi != 0;
+    const unsigned magicWt = (unsigned)(0x100000000ULL / (unsigned)Wt) + 1u;
+    const unsigned magicH = (unsigned)(0x100000000ULL / (unsigned)H) + 1u;
+
+    f32x4 ap0[NA], ap1[NA], bp0[NB], bp1[NB], aq[NA], bq[NB];
+    int lp = tbeg, lq = tbeg;                          // first tile of the next slice for the p / q loads
+
+    // tile t -> (global image-row index rowidx = n*H + y, column pair xt)
+    auto coords = [&](int t, int& rowidx, int& xt) {
+        rowidx = Wt == 1 ? t : (int)__umulhi((unsigned)t, magicWt);   // 2^32/1 + 1 does not fit the 32-bit magic
+        xt = t - rowidx * Wt;
+    };
+    auto issue_p = [&](f32x4 (&ap)[NA], f32x4 (&bp)[NB]) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int t = lp + pra + i * RPA;
+            int rowidx, xt;
+            coords(t, rowidx, xt);
+            const unsigned pix = (unsigned)(rowidx * W + 2 * xt);
+            ap[i] = buf_load16(dr, (aok && useA0 && t < tend) ? (pix * (unsigned)ld_dy + (unsigned)coA) * 4u : OOB);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int t = lp + prb + i * RPB;
+            int rowidx, xt;
+            coords(t, rowidx, xt);
+            const int n = H == 1 ? rowidx : (int)__umulhi((unsigned)rowidx, magicH);
+            const int y = rowidx - n * H;
+            const bool ok = bok && t < tend && (unsigned)(y + rB - 1) < (unsigned)H && (unsigned)(2 * xt + po) < (unsigned)W;
+            bp[i] = buf_load16(xr, ok ? ((unsigned)((rowidx + rB - 1) * W + 2 * xt + po) * (unsigned)Cin + (unsigned)ciB) * 4u : OOB);
+        }
+        lp += BK;
+    };
+    auto issue_q = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int t = lq + pra + i * RPA;
+            int rowidx, xt;
+            coords(t, rowidx, xt);
+            const unsigned pix = (unsigned)(rowidx * W + 2 * xt + 1);
+            aq[i] = buf_load16(dr, (aok && useA1 && t < tend && 2 * xt + 1 < W) ? (pix * (unsigned)ld_dy + (unsigned)coA) * 4u : OOB);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int t = lq + prb + i * RPB;
+            int rowidx, xt;
+            coords(t, rowidx, xt);
+            const int n = H == 1 ? rowidx : (int)__umulhi((unsigned)rowidx, magicH);
+            const int y = rowidx - n * H;
+            const bool ok = bok && t < tend && (unsigned)(y + rB - 1) < (unsigned)H && (unsigned)(2 * xt + qo) < (unsigned)W;
+            bq[i] = buf_load16(xr, ok ? ((unsigned)((rowidx + rB - 1) * W + 2 * xt + qo) * (unsigned)Cin + (unsigned)ciB) * 4u : OOB);
+        }
+        lq += BK;
+    };
+    auto store_stage = [&](float* dst, const f32x4 (&ap)[NA], const f32x4 (&bp)[NB]) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaf(sgA, aq[i][j], ap[i][j]);
+            *reinterpret_cast<f32x4*>(&dst[(pra + i * RPA) * BM + cva * 4]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaf(sgB, bq[i][j], bp[i][j]);
+            *reinterpret_cast<f32x4*>(&dst[BK * BM + (prb + i * RPB) * BN + cvb * 4]) = v;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    auto mma_part = [&](const float* acol, const float* bcol, int s0, int s1) {
+#pragma unroll
+        for (int s = s0; s < s1; ++s) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) a[t] = acol[2 * s * BM + t * 32];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b[t] = bcol[2 * s * BN + t * 32];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+    };
+
+    const int nK = (tend - tbeg + BK - 1) / BK;
+    issue_p(ap0, bp0);
+    issue_q();
+    store_stage(smem, ap0, bp0);
+    issue_p(ap0, bp0);
+    issue_p(ap1, bp1);
+    __syncthreads();
+    const int aco = lh * BM + wm * TM * 32 + li;
+    const int bco = BK * BM + lh * BN + wn * TN * 32 + li;
+    float* const buf0 = smem;
+    float* const buf1 = smem + STAGE;
+#define CVK_WW_STEP(cur, nxt, AP_, BP_)             \
+    do {                                            \
+        issue_q();                                  \
+        mma_part(cur + aco, cur + bco, 0, 8);       \
+        store_stage(nxt, AP_, BP_);                 \
+        issue_p(AP_, BP_);                          \
+        mma_part(cur + aco, cur + bco, 8, 16);      \
+        __syncthreads();                            \
+    } while (0)
+    int ks = 0;
+    for (; ks + 2 <= nK; ks += 2) {
+        CVK_WW_STEP(buf0, buf1, ap0, bp0);
+        CVK_WW_STEP(buf1, buf0, ap1, bp1);
+    }
+    if (ks < nK) CVK_WW_STEP(buf0, buf1, ap0, bp0);
+#undef CVK_WW_STEP
+
+    float* out = slab + ((size_t)blockIdx.y * 4 + xi) * Cout * K3;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = n0 + wn * TN * 32 + tn * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < Cout && col < K3) out[(size_t)row * K3 + col] = acc[tm][tn][r];
+            }
+        }
+}
+
+// dw[co][r][s][ci] from the slabs: P_xi = sum over splits (fixed order), then G^T: (P0 + (P1+P2)/2, (P1-P2)/2, (P1+P2)/2 - P3)
+__global__ void k_wgrad_wino_reduce(const float* __restrict__ slab, float* __restrict__ dw, int splits, int Cout, int Cin,
+                                    int Cin_pad) {
+    const size_t total = (size_t)Cout * 3 * Cin;
+    const size_t plane = (size_t)Cout * 3 * Cin_pad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        const size_t cr = i / Cin;  // co*3 + r
+        const float* p = slab + cr * Cin_pad + ci;
+        float P[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < splits; ++s) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) P[x] += p[((size_t)s * 4 + x) * plane];
+        }
+        const float h = 0.5f * (P[1] + P[2]);
+        float* o = dw + (cr * 3) * Cin + ci;
+        o[0] = P[0] + h;
+        o[Cin] = 0.5f * (P[1] - P[2]);
+        o[2 * (size_t)Cin] = h - P[3];
+    }
+}
+
+struct WWPlan { int bm, tilesM, tilesN, splits, chunk; };
+WWPlan plan_wgrad_wino(int Mt, int Cin_pad, int Cout) {
+    WWPlan p;
+    p.bm = Cout > 64 ? 128 : 64;
+    p.tilesM = cvk_cdiv(Cout, p.bm);
+    p.tilesN = cvk_cdiv(3 * Cin_pad, 128);
+    const int units = p.tilesM * p.tilesN * 4;
+    const int max_splits = Mt / (BK * 16) > 0 ? Mt / (BK * 16) : 1;
+    int best = 1;
+    double best_eff = -1.0;
+    for (int s = 1; s <= max_splits && s <= 2048; ++s) {
+        const long blocks = (long)units * s;
+        if (blocks > 4096 && s > 1) break;
+        if (blocks < 512 && s < max_splits) continue;
+        const long rounds = (blocks + 255) / 256;
+        const double eff = (double)blocks / (256.0 * rounds);
+        if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
+    }
+    p.splits = best;
+    p.chunk = cvk_cdiv(cvk_cdiv(Mt, p.splits), BK) * BK;
+    p.splits = cvk_cdiv(Mt, p.chunk);
+    return p;
+}
+
 }  // namespace
 
 extern "C" int cvk_wino_weight_transform(const float* w, float* U, int Cout, int Cin, void* stream) {
@@ -351,4 +583,43 @@ extern "C" int cvk_conv3x3_wino(const float* x, const float* U, const float* bia
     else
         hipLaunchKernelGGL(k_wino_output<false>, grid, dim3(256), 0, s, Mo, ldy, Mt, bias, y, ldy, stats, P, Mpix, H, W, Wt, ldy, Cout);
     CVK_LAUNCH_RETURN("cvk_conv3x3_wino");
+}
+
+extern "C" size_t cvk_conv3x3_wgrad_wino_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin_pad <= 0 || Cout <= 0) return 0;
+    const WWPlan p = plan_wgrad_wino(N * H * ((W + 1) / 2), Cin_pad, Cout);
+    return (size_t)p.splits * 4 * Cout * 3 * Cin_pad * sizeof(float);
+}
+
+extern "C" int cvk_conv3x3_wgrad_wino(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,
+                                      int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream) {
+    CVK_CHECK_ARG(x && dy && dw && workspace, "cvk_conv3x3_wgrad_wino: null pointer");
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin_pad >= Cin, "cvk_conv3x3_wgrad_wino: bad shape");
+    CVK_CHECK_ARG(Cin_pad % 4 == 0 && ld_dy % 4 == 0 && ld_dy >= Cout, "cvk_conv3x3_wgrad_wino: Cin_pad and ld_dy must be multiples of 4, ld_dy >= Cout");
+    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(dy) && cvk_aligned16(workspace), "cvk_conv3x3_wgrad_wino: pointers must be 16-byte aligned");
+    CVK_CHECK_ARG((long)N * H * W * Cin_pad * 4 < (1L << 31) && (long)N * H * W * ld_dy * 4 < (1L << 31), "cvk_conv3x3_wgrad_wino: x or dy exceeds the 2 GiB buffer-addressing limit; split the batch");
+    const int Wt = (W + 1) / 2, Mt = N * H * Wt, Mpix = N * H * W, K3 = 3 * Cin_pad;
+    CVK_CHECK_ARG((long)Mt * Wt < (1L << 32) && (long)N * H * H < (1L << 32), "cvk_conv3x3_wgrad_wino: frame too large for the multiply-high coordinate split");
+    const WWPlan p = plan_wgrad_wino(Mt, Cin_pad, Cout);
+    const size_t need = (size_t)p.splits * 4 * Cout * K3 * sizeof(float);
+    if (workspace_bytes < need) {
+        cvk_set_error("cvk_conv3x3_wgrad_wino: workspace %zu < %zu bytes", workspace_bytes, need);
+        return CVK_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float* slab = (float*)workspace;
+    dim3 grid(p.tilesM * p.tilesN, p.splits, 4);
+    if (p.bm == 128)
+        hipLaunchKernelGGL((k_wgrad_wino<128, 128, 2, 2>), grid, dim3(256), 0, s, x, dy, slab, Mt, H, W, Wt, Cin_pad, Cout, ld_dy, K3, p.chunk, p.tilesN, Mpix);
+    else
+        hipLaunchKernelGGL((k_wgrad_wino<64, 128, 2, 2>), grid, dim3(256), 0, s, x, dy, slab, Mt, H, W, Wt, Cin_pad, Cout, ld_dy, K3, p.chunk, p.tilesN, Mpix);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        cvk_set_error("cvk_conv3x3_wgrad_wino: launch failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    const size_t total = (size_t)Cout * 3 * Cin;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_wgrad_wino_reduce, dim3(blocks), dim3(256), 0, s, slab, dw, p.splits, Cout, Cin, Cin_pad);
+    CVK_LAUNCH_RETURN("cvk_conv3x3_wgrad_wino");
 }

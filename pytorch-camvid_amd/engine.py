@@ -242,11 +242,18 @@ class ConvBnRelu(Op):
                     lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
                     "cvk_conv3x3_fwd(dgrad)"))
             st.grad[src.id] = dX
-        wsb = lib.cvk_conv3x3_wgrad_workspace_bytes(N, H, W, src.ld, C)
-        ws = R.workspace(wsb, dev)
-        _timed(R, conv_kernel_name("wgrad", C), 18.0 * M * C * self.cin, lambda: check(
-            lib.cvk_conv3x3_wgrad(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
-            "cvk_conv3x3_wgrad"))
+        if R.wino and src.ld >= 32 and C > 32 and (src.ld > 64 or C > 64):   # 64->64 layers: the direct kernel is faster
+            wsb = lib.cvk_conv3x3_wgrad_wino_workspace_bytes(N, H, W, src.ld, C)
+            ws = R.workspace(wsb, dev)
+            _timed(R, "k_wgrad_wino<128, 128, 2, 2>" if C > 64 else "k_wgrad_wino<64, 128, 2, 2>", 18.0 * M * C * self.cin, lambda: check(
+                lib.cvk_conv3x3_wgrad_wino(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
+                "cvk_conv3x3_wgrad_wino"))
+        else:
+            wsb = lib.cvk_conv3x3_wgrad_workspace_bytes(N, H, W, src.ld, C)
+            ws = R.workspace(wsb, dev)
+            _timed(R, conv_kernel_name("wgrad", C), 18.0 * M * C * self.cin, lambda: check(
+                lib.cvk_conv3x3_wgrad(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
+                "cvk_conv3x3_wgrad"))
         R.grads_ready(st, self.pslot)
 
 

@@ -214,3 +214,30 @@ def test_errors_match_reference_classes():
     with pytest.raises(RuntimeError):
         with torch.no_grad():
             u(torch.zeros(1, 3, 15, 15, device=dev()))      # too small for four 2x2 pools
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 3, 1, 64), (1, 64, 1, 3, 128), (2, 128, 7, 5, 64), (1, 64, 6, 9, 96), (3, 96, 5, 4, 40)])
+def test_winograd_and_direct_kernels_agree(shape):
+    """Both conv implementations (direct implicit GEMM, 1-D Winograd F(2,3)) against the fp64 oracle on degenerate
+    widths (W=1, odd W) — forward, data-grad and weight-grad."""
+    import pytorch_camvid_amd as A
+    from pytorch_camvid_amd.modules import runner_of
+    from oracle import np_ops as O
+    n, ci, h, w, co = shape
+    torch.manual_seed(7)
+    m = A.BasicConv2d(ci, co)
+    p = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    x = torch.randn(n, ci, h, w); r = torch.randn(n, co, h, w)
+    out_o, cache = O.basic_conv_fwd(x.numpy(), p, "", train=True)
+    dx_o, g_o = O.basic_conv_bwd(r.numpy(), cache, p)
+    m = m.to(dev()).train()
+    for wino in (False, True):
+        runner_of(m).wino = wino
+        for q in m.parameters():
+            q.grad = None
+        xg = x.to(dev()).requires_grad_(True)
+        y = m(xg)
+        (y * r.to(dev())).sum().backward()
+        close(y, out_o, 1e-4, 3e-5 * max(1.0, float(np.abs(out_o).max())), f"fwd wino={wino}")
+        close(xg.grad, dx_o, 1e-3, 2e-4 * float(np.abs(dx_o).max()), f"dx wino={wino}")
+        close(m.conv[0].weight.grad, g_o["conv.0.weight"], 1e-3, 2e-4 * float(np.abs(g_o["conv.0.weight"]).max()), f"dW wino={wino}")

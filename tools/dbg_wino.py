@@ -18,3 +18,16 @@ def one(N,H,W,ci,co):
     print(f"N{N} {H}x{W} {ci}->{co}: max|dy|={e:.3e} (|y|max {y1.abs().max().item():.2f}) stats diff {es:.3e} (|s|max {s1.abs().max().item():.1f}) nbad={len(bad)}", bad[:6].tolist() if len(bad) else "")
 for shp in [(1,2,3,512,512),(1,5,7,512,512),(1,11,15,256,256),(1,22,30,128,128),(1,45,60,64,64),(1,1,1,512,512),(1,2,3,64,64),(2,9,4,64,128),(1,1,3,64,64),(1,3,1,64,64),(1,1,2,64,64)]:
     one(*shp)
+
+def wg(N,H,W,ci,co):
+    M=N*H*W; torch.manual_seed(2)
+    x=torch.randn(M,ci,device='cuda'); ldy=(co+3)//4*4; dy=torch.zeros(M,ldy,device='cuda'); dy[:,:co]=torch.randn(M,co,device='cuda')
+    d1=torch.zeros(co,9*ci,device='cuda'); d2=torch.zeros(co,9*ci,device='cuda')
+    wsb=lib.cvk_conv3x3_wgrad_workspace_bytes(N,H,W,ci,co); ws=torch.zeros(wsb,dtype=torch.uint8,device='cuda')
+    check(lib.cvk_conv3x3_wgrad(x.data_ptr(),dy.data_ptr(),d1.data_ptr(),N,H,W,ci,ci,co,ldy,ws.data_ptr(),wsb,s))
+    wsb=lib.cvk_conv3x3_wgrad_wino_workspace_bytes(N,H,W,ci,co); ws=torch.zeros(wsb,dtype=torch.uint8,device='cuda')
+    check(lib.cvk_conv3x3_wgrad_wino(x.data_ptr(),dy.data_ptr(),d2.data_ptr(),N,H,W,ci,ci,co,ldy,ws.data_ptr(),wsb,s))
+    torch.cuda.synchronize()
+    print(f"WGRAD N{N} {H}x{W} {ci}->{co}: max|d|={(d1-d2).abs().max().item():.3e} (|dw|max {d1.abs().max().item():.2f})")
+for shp in [(2,3,1,64,64),(2,1,3,64,64),(1,2,3,64,64),(1,5,7,128,128),(2,11,15,32,96),(1,22,30,128,64),(2,45,60,64,128),(1,1,1,64,64),(1,1,2,64,64),(1,3,1,64,64),(8,90,120,256,256)]:
+    wg(*shp)
