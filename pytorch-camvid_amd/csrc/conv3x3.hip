@@ -272,7 +272,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm(
 template <int BM, int BN, int WARPS_M, int WARPS_N>
 __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
     const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ slab, int M, int H, int W, int Cin,
-    int Cout, int ld_dy, int Ktot, int chunk, int tilesN) {
+    int Cout, int ld_dy, int Ktot, int chunk, int tilesN, int ntiles) {
     constexpr int NT = WARPS_M * WARPS_N * 64;
     constexpr int TM = BM / WARPS_M / 32, TN = BN / WARPS_N / 32;
     constexpr int VA = BM / 4, VB = BN / 4;      // 16-byte vectors per staged pixel row
@@ -288,10 +288,13 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WARPS_N, wn = wave % WARPS_N;
 
-    const int tile = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    // 1-D grid, XCD-remapped, pixel-range (split) major: the tiles of one pixel range are neighbours and share its
+    // dy / x lines in one L2
+    const int gid = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int split = gid / ntiles, tile = gid - split * ntiles;
     const int c0 = (tile / tilesN) * BM;  // first output channel of the tile
     const int n0 = (tile % tilesN) * BN;  // first (tap,ci) column of the tile
-    const int mbeg = blockIdx.y * chunk;
+    const int mbeg = split * chunk;
     const int mend = min(M, mbeg + chunk);
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, M * Cin * 4, 0x00020000);
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
     }
     if (ks < nK) CVK_WSTEP(buf0, buf1, ra0, rb0);
 
-    float* out = slab + (size_t)blockIdx.y * Cout * Ktot;
+    float* out = slab + (size_t)split * Cout * Ktot;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -572,14 +575,14 @@ extern "C" int cvk_conv3x3_wgrad(const float* x, const float* dy, float* dw, int
     }
     hipStream_t s = (hipStream_t)stream;
     float* slab = (float*)workspace;
-    dim3 grid(p.tilesM * p.tilesN, p.splits);
+    dim3 grid(p.tilesM * p.tilesN * p.splits);
     // dy columns [Cout, ld_dy) are zero by contract, so the last 16-byte vector of a row may straddle Cout
     if (p.bm == 128)
-        hipLaunchKernelGGL((k_conv3x3_wgrad<128, 128, 2, 2>), grid, dim3(256), 0, s, x, dy, slab, M, H, W, Cin_pad, Cout, ld_dy, Ktot, p.chunk, p.tilesN);
+        hipLaunchKernelGGL((k_conv3x3_wgrad<128, 128, 2, 2>), grid, dim3(256), 0, s, x, dy, slab, M, H, W, Cin_pad, Cout, ld_dy, Ktot, p.chunk, p.tilesN, p.tilesM * p.tilesN);
     else if (p.bm == 64)
-        hipLaunchKernelGGL((k_conv3x3_wgrad<64, 128, 2, 2>), grid, dim3(256), 0, s, x, dy, slab, M, H, W, Cin_pad, Cout, ld_dy, Ktot, p.chunk, p.tilesN);
+        hipLaunchKernelGGL((k_conv3x3_wgrad<64, 128, 2, 2>), grid, dim3(256), 0, s, x, dy, slab, M, H, W, Cin_pad, Cout, ld_dy, Ktot, p.chunk, p.tilesN, p.tilesM * p.tilesN);
     else
-        hipLaunchKernelGGL((k_conv3x3_wgrad<32, 256, 1, 4>), grid, dim3(256), 0, s, x, dy, slab, M, H, W, Cin_pad, Cout, ld_dy, Ktot, p.chunk, p.tilesN);
+        hipLaunchKernelGGL((k_conv3x3_wgrad<32, 256, 1, 4>), grid, dim3(256), 0, s, x, dy, slab, M, H, W, Cin_pad, Cout, ld_dy, Ktot, p.chunk, p.tilesN, p.tilesM * p.tilesN);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         cvk_set_error("cvk_conv3x3_wgrad: launch failed: %s", hipGetErrorString(e));

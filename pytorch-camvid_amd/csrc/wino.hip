@@ -49,7 +49,10 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino(
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WARPS_N, wn = wave % WARPS_N;
 
-    const int tile = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    // 1-D grid, XCD-remapped; the transform-index groups of one tile are neighbours (they read the same pixels -> one L2)
+    const int gid = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int ngroups = 4 / nxi;
+    const int tile = gid / ngroups, xgroup = gid - tile * ngroups;
     const int m0 = (tile / tilesN) * BM;
     const int n0 = (tile % tilesN) * BN;
     const int K3 = 3 * Cin;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino(
     f32x4 rp0[NA], rp1[NA], rq[NA], rb[NB];
     // blockIdx.y selects which of the 4 transform indices this workgroup walks (all 4 when gridDim.y == 1; one each
     // when the layer has too few tile blocks to fill the chip otherwise)
-    const int xi_begin = blockIdx.y * nxi, xi_end = xi_begin + nxi;
+    const int xi_begin = xgroup * nxi, xi_end = xi_begin + nxi;
     int pxi = xi_begin, pr = 0, pcib = 0;   // next slice for the p loads   (transform index, kernel row, channel base; uniform)
     int qxi = xi_begin, qr = 0, qcib = 0;   // next slice for the q / weight loads
 
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256) void k_wino_output(const float* __restrict__ M
 template <int BM, int BN, int WARPS_M, int WARPS_N>
 __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
     const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ slab, int Mt, int H, int W, int Wt,
-    int Cin, int Cout, int ld_dy, int K3, int chunk, int tilesN, int Mpix) {
+    int Cin, int Cout, int ld_dy, int K3, int chunk, int tilesN, int Mpix, int ntiles) {
     constexpr int NT = WARPS_M * WARPS_N * 64;
     constexpr int TM = BM / WARPS_M / 32, TN = BN / WARPS_N / 32;
     constexpr int VA = BM / 4, VB = BN / 4;
@@ -325,11 +328,15 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WARPS_N, wn = wave % WARPS_N;
 
-    const int tile = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    // 1-D grid, XCD-remapped, pixel-range (split) major: all (tile, xi) workgroups of one pixel range are neighbours and
+    // share its dy / x lines in one L2 instead of re-fetching them from HBM
+    const int gid = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int inner = ntiles * 4;
+    const int split = gid / inner, rem_ = gid - split * inner;
+    const int tile = rem_ >> 2, xi = rem_ & 3;
     const int c0 = (tile / tilesN) * BM;
     const int n0 = (tile % tilesN) * BN;
-    const int xi = blockIdx.z;
-    const int tbeg = blockIdx.y * chunk;
+    const int tbeg = split * chunk;
     const int tend = min(Mt, tbeg + chunk);
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, Mpix * Cin * 4, 0x00020000);
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
     if (ks < nK) CVK_WW_STEP(buf0, buf1, ap0, bp0);
 #undef CVK_WW_STEP
 
-    float* out = slab + ((size_t)blockIdx.y * 4 + xi) * Cout * K3;
+    float* out = slab + ((size_t)split * 4 + xi) * Cout * K3;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -565,11 +572,11 @@ extern "C" int cvk_conv3x3_wino(const float* x, const float* U, const float* bia
     if (ldy > 64) {
         const int tilesN = cvk_cdiv(ldy, 128), tilesM = cvk_cdiv(Mt, 128);
         const int split = (tilesM * tilesN < 1024 && Cin >= 256) ? 4 : 1;
-        hipLaunchKernelGGL((k_conv3x3_wino<128, 128, 2, 2>), dim3(tilesM * tilesN, split), dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, Mpix, 4 / split);
+        hipLaunchKernelGGL((k_conv3x3_wino<128, 128, 2, 2>), dim3(tilesM * tilesN * split), dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, Mpix, 4 / split);
     } else {
         const int tilesN = cvk_cdiv(ldy, 64), tilesM = cvk_cdiv(Mt, 128);
         const int split = (tilesM * tilesN < 1024 && Cin >= 256) ? 4 : 1;
-        hipLaunchKernelGGL((k_conv3x3_wino<128, 64, 2, 2>), dim3(tilesM * tilesN, split), dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, Mpix, 4 / split);
+        hipLaunchKernelGGL((k_conv3x3_wino<128, 64, 2, 2>), dim3(tilesM * tilesN * split), dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, Mpix, 4 / split);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -608,11 +615,11 @@ extern "C" int cvk_conv3x3_wgrad_wino(const float* x, const float* dy, float* dw
     }
     hipStream_t s = (hipStream_t)stream;
     float* slab = (float*)workspace;
-    dim3 grid(p.tilesM * p.tilesN, p.splits, 4);
+    dim3 grid(p.tilesM * p.tilesN * p.splits * 4);
     if (p.bm == 128)
-        hipLaunchKernelGGL((k_wgrad_wino<128, 128, 2, 2>), grid, dim3(256), 0, s, x, dy, slab, Mt, H, W, Wt, Cin_pad, Cout, ld_dy, K3, p.chunk, p.tilesN, Mpix);
+        hipLaunchKernelGGL((k_wgrad_wino<128, 128, 2, 2>), grid, dim3(256), 0, s, x, dy, slab, Mt, H, W, Wt, Cin_pad, Cout, ld_dy, K3, p.chunk, p.tilesN, Mpix, p.tilesM * p.tilesN);
     else
-        hipLaunchKernelGGL((k_wgrad_wino<64, 128, 2, 2>), grid, dim3(256), 0, s, x, dy, slab, Mt, H, W, Wt, Cin_pad, Cout, ld_dy, K3, p.chunk, p.tilesN, Mpix);
+        hipLaunchKernelGGL((k_wgrad_wino<64, 128, 2, 2>), grid, dim3(256), 0, s, x, dy, slab, Mt, H, W, Wt, Cin_pad, Cout, ld_dy, K3, p.chunk, p.tilesN, Mpix, p.tilesM * p.tilesN);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         cvk_set_error("cvk_conv3x3_wgrad_wino: launch failed: %s", hipGetErrorString(e));
