@@ -310,7 +310,7 @@ extern "C" int cvk_bn_relu_apply(const float* y, int ldy, const float* scale, co
 extern "C" int cvk_bn_bwd_blocks(int M) {
     if (M <= 0) return 0;
     const int pb = cvk_cdiv(M, 16);
-    return pb < 1024 ? pb : 1024;
+    return pb < 512 ? pb : 512;     // 2 blocks per CU keep the stream bandwidth-bound; fewer partial rows keep the fp64 finalize short
 }
 
 static int bn_bwd_launch(int mode, cvk_view dout, const float* y, int ldy, const float* scale, const float* shift,

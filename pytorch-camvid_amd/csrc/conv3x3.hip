@@ -487,7 +487,7 @@ WgradPlan plan_wgrad(int M, int Cin_pad, int Cout) {
     WgradPlan p;
     const int Ktot = 9 * Cin_pad;
     if (Cout > 64) { p.bm = 128; p.bn = 128; }
-    else if (Cout > 32) { p.bm = 64; p.bn = 128; }
+    else if (Cout > 32) { p.bm = 64; p.bn = Ktot <= 64 ? 64 : 128; }   // 64x64: the 3-channel stem (36 columns)
     else { p.bm = 32; p.bn = 256; }
     p.tilesM = cvk_cdiv(Cout, p.bm);
     p.tilesN = cvk_cdiv(Ktot, p.bn);
@@ -579,6 +579,8 @@ extern "C" int cvk_conv3x3_wgrad(const float* x, const float* dy, float* dw, int
     // dy columns [Cout, ld_dy) are zero by contract, so the last 16-byte vector of a row may straddle Cout
     if (p.bm == 128)
         hipLaunchKernelGGL((k_conv3x3_wgrad<128, 128, 2, 2>), grid, dim3(256), 0, s, x, dy, slab, M, H, W, Cin_pad, Cout, ld_dy, Ktot, p.chunk, p.tilesN, p.tilesM * p.tilesN);
+    else if (p.bm == 64 && p.bn == 64)
+        hipLaunchKernelGGL((k_conv3x3_wgrad<64, 64, 2, 2>), grid, dim3(256), 0, s, x, dy, slab, M, H, W, Cin_pad, Cout, ld_dy, Ktot, p.chunk, p.tilesN, p.tilesM * p.tilesN);
     else if (p.bm == 64)
         hipLaunchKernelGGL((k_conv3x3_wgrad<64, 128, 2, 2>), grid, dim3(256), 0, s, x, dy, slab, M, H, W, Cin_pad, Cout, ld_dy, Ktot, p.chunk, p.tilesN, p.tilesM * p.tilesN);
     else

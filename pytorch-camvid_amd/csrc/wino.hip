@@ -573,10 +573,13 @@ extern "C" int cvk_conv3x3_wino(const float* x, const float* U, const float* bia
         const int tilesN = cvk_cdiv(ldy, 128), tilesM = cvk_cdiv(Mt, 128);
         const int split = (tilesM * tilesN < 1024 && Cin >= 256) ? 4 : 1;
         hipLaunchKernelGGL((k_conv3x3_wino<128, 128, 2, 2>), dim3(tilesM * tilesN * split), dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, Mpix, 4 / split);
-    } else {
+    } else if (ldy > 32) {
         const int tilesN = cvk_cdiv(ldy, 64), tilesM = cvk_cdiv(Mt, 128);
         const int split = (tilesM * tilesN < 1024 && Cin >= 256) ? 4 : 1;
         hipLaunchKernelGGL((k_conv3x3_wino<128, 64, 2, 2>), dim3(tilesM * tilesN * split), dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, Mpix, 4 / split);
+    } else {   // narrow heads (e.g. the 12-class logits layer): 32-column tiles, four 32x32 wave tiles stacked in M
+        const int tilesM = cvk_cdiv(Mt, 128);
+        hipLaunchKernelGGL((k_conv3x3_wino<128, 32, 4, 1>), dim3(tilesM), dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, 1, Mpix, 4);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

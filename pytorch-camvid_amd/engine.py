@@ -86,15 +86,17 @@ WINO_DEFAULT = os.environ.get("CVK_WINO", "1") != "0"   # 1-D Winograd F(2,3) fo
 
 
 def wino_ok(R, k_ch, n_cols):
-    return R.wino and k_ch % 64 == 0 and n_cols > 32
+    return R.wino and k_ch % 64 == 0
 
 
 def conv_kernel_name(kind, n_cols, k_ch=32):
     """Mirror of the tile dispatch in csrc/conv3x3.hip / wino.hip: the kernel-trace name."""
     if kind == "wino":
-        return "k_conv3x3_wino<128, 128, 2, 2>" if n_cols > 64 else "k_conv3x3_wino<128, 64, 2, 2>"
+        return "k_conv3x3_wino<128, 128, 2, 2>" if n_cols > 64 else ("k_conv3x3_wino<128, 64, 2, 2>" if n_cols > 32 else "k_conv3x3_wino<128, 32, 4, 1>")
     if kind == "wgrad":
         t = "128, 128, 2, 2" if n_cols > 64 else ("64, 128, 2, 2" if n_cols > 32 else "32, 256, 1, 4")
+        if 32 < n_cols <= 64 and k_ch * 9 <= 64:
+            t = "64, 64, 2, 2"
         return f"k_conv3x3_wgrad<{t}>"
     t = "128, 128, 2, 2" if n_cols > 64 else ("128, 64, 2, 2" if n_cols > 32 else "256, 32, 4, 1")
     return f"k_conv3x3_igemm<{t}, {'true' if kind == 'fwd' else 'false'}, {'true' if k_ch % 32 == 0 else 'false'}>"
@@ -251,7 +253,7 @@ class ConvBnRelu(Op):
         else:
             wsb = lib.cvk_conv3x3_wgrad_workspace_bytes(N, H, W, src.ld, C)
             ws = R.workspace(wsb, dev)
-            _timed(R, conv_kernel_name("wgrad", C), 18.0 * M * C * self.cin, lambda: check(
+            _timed(R, conv_kernel_name("wgrad", C, src.ld), 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_wgrad(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
                 "cvk_conv3x3_wgrad"))
         R.grads_ready(st, self.pslot)

@@ -42,7 +42,7 @@ def test_argument_validation_without_gpu():
     rc = lib.cvk_conv3x3_fwd(16, 16, None, 16, None, 1, 8, 8, 3, 8, 8, None)
     assert rc == -1 and b"multiple of 4" in lib.cvk_last_error_string()
     assert lib.cvk_conv3x3_wgrad_workspace_bytes(8, 360, 480, 64, 64) > 0
-    assert lib.cvk_bn_bwd_blocks(1382400) == 1024 and lib.cvk_ce_blocks(1025) == 2
+    assert lib.cvk_bn_bwd_blocks(1382400) == 512 and lib.cvk_ce_blocks(1025) == 2
 
 
 def test_module_surface_matches_reference_and_fails_loudly_on_cpu():
