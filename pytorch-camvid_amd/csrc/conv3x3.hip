@@ -317,7 +317,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
     unsigned brem[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) brem[i] = (unsigned)((mbeg + prb + i * RPB) % HW);
-    const unsigned magicW = (unsigned)(0x100000000ULL / (unsigned)W) + 1u;
+    const FastDiv divW((unsigned)W);
     int lm = mbeg;                        // first pixel of the next slice to load
 
     f32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
@@ -325,15 +325,15 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int m = lm + pra + i * RPA;
-            ra[i] = buf_load16(dr, (aok && m < mend) ? ((unsigned)m * (unsigned)ld_dy + (unsigned)coA) * 4u : OOB);
+            ra[i] = buf_load16(dr, oob_unless(aok & (m < mend), ((unsigned)m * (unsigned)ld_dy + (unsigned)coA) * 4u));
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int m = lm + prb + i * RPB;
-            const int y = W == 1 ? (int)brem[i] : (int)__umulhi(brem[i], magicW);   // 2^32/1 + 1 overflows the magic
+            const int y = (int)divW.div(brem[i]);
             const int x = (int)brem[i] - y * W;
-            const bool ok = bok && m < mend && (unsigned)(y + dyB) < (unsigned)H && (unsigned)(x + dxB) < (unsigned)W;
-            rb[i] = buf_load16(xr, ok ? (unsigned)m * (unsigned)Cin * 4u + shiftB : OOB);
+            const bool ok = bok & (m < mend) & ((unsigned)(y + dyB) < (unsigned)H) & ((unsigned)(x + dxB) < (unsigned)W);   // '&': no short-circuit branches
+            rb[i] = buf_load16(xr, oob_unless(ok, (unsigned)m * (unsigned)Cin * 4u + shiftB));
             brem[i] += BK;
             if (HW >= BK) { if (brem[i] >= (unsigned)HW) brem[i] -= (unsigned)HW; }
             else brem[i] %= (unsigned)HW;

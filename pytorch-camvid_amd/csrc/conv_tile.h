@@ -14,4 +14,19 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned b
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
 
+// Exact unsigned division by a runtime constant d >= 1 without branches: q = floor(t / d) for t*d < 2^32.
+// magic = floor(2^32/d) + 1 needs 33 bits when d == 1, so it is kept as (hi ? 2^32 : 0) + lo with hi_mask = all-ones iff d == 1.
+struct FastDiv {
+    unsigned lo, hi_mask;
+    __host__ __device__ explicit FastDiv(unsigned d) {
+        const unsigned long long m = 0x100000000ULL / d + 1ULL;
+        lo = (unsigned)m;
+        hi_mask = (m >> 32) ? 0xFFFFFFFFu : 0u;
+    }
+    __device__ __forceinline__ unsigned div(unsigned t) const { return __umulhi(t, lo) + (t & hi_mask); }
+};
+
+// byte offset, forced out of range (-> the buffer load returns 0) when !ok; pure ALU so the staging code stays branch-free
+__device__ __forceinline__ unsigned oob_unless(bool ok, unsigned off) { return off | ((unsigned)(!ok) << 31); }
+
 }  // namespace

@@ -106,12 +106,14 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino(
         const unsigned sh = (unsigned)((((pr - 1) * W + po) * Cin + pcib) * 4) + kvb;
         const unsigned need = (pxi < xi_end ? (1u << pr) : 0x80u) | (8u << (po + 1));   // 0x80 is never set: past-the-end -> zeros
 #pragma unroll
-        for (int i = 0; i < NA; ++i) rp[i] = buf_load16(xr, (arow[i] & need) == need ? (arow[i] & ~0xFFu) + sh : OOB);
-        pcib += BK;
-        if (pcib >= Cin) {
-            pcib = 0;
-            if (++pr == 3) { pr = 0; ++pxi; }
-        }
+        for (int i = 0; i < NA; ++i) rp[i] = buf_load16(xr, oob_unless((arow[i] & need) == need, (arow[i] & ~0xFFu) + sh));
+        pcib += BK;                                  // branch-free advance (slice -> kernel row -> transform index)
+        const int w1 = pcib >= Cin;
+        pcib = w1 ? 0 : pcib;
+        pr += w1;
+        const int w2 = pr == 3;
+        pr = w2 ? 0 : pr;
+        pxi += w2;
     };
     float sg = 1.f;                    // V = p + sg*q for the slice whose q is in rq
     auto issue_qb = [&]() {
@@ -120,15 +122,17 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino(
         const unsigned sh = (unsigned)((((qr - 1) * W + qo) * Cin + qcib) * 4) + kvb;
         const unsigned need = (qxi < xi_end ? (1u << qr) : 0x80u) | (8u << (qo + 1));
 #pragma unroll
-        for (int i = 0; i < NA; ++i) rq[i] = buf_load16(xr, (arow[i] & need) == need ? (arow[i] & ~0xFFu) + sh : OOB);
+        for (int i = 0; i < NA; ++i) rq[i] = buf_load16(xr, oob_unless((arow[i] & need) == need, (arow[i] & ~0xFFu) + sh));
         const unsigned ub = qxi < xi_end ? (unsigned)((qxi * Cout * K3 + qr * Cin + qcib) * 4) : OOB;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = buf_load16(ur, (boff[i] | ub) & OOB ? OOB : boff[i] + ub);
+        for (int i = 0; i < NB; ++i) rb[i] = buf_load16(ur, (boff[i] + ub) | ((boff[i] | ub) & OOB));
         qcib += BK;
-        if (qcib >= Cin) {
-            qcib = 0;
-            if (++qr == 3) { qr = 0; ++qxi; }
-        }
+        const int w1 = qcib >= Cin;
+        qcib = w1 ? 0 : qcib;
+        qr += w1;
+        const int w2 = qr == 3;
+        qr = w2 ? 0 : qr;
+        qxi += w2;
     };
     auto store_stage = [&](float* dst, const f32x4 (&rp)[NA]) {
 #pragma unroll
@@ -356,15 +360,14 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
     const float sgB = xi == 1 ? 1.f : -1.f;
     const float sgA = xi == 2 ? -1.f : 1.f;           // E = a0 + sgA*a1 with a0 = dy0 (off for xi 3), a1 = dy1 (off for xi 0)
     const bool useA0 = xi != 3, useA1 = xi != 0;
-    const unsigned magicWt = (unsigned)(0x100000000ULL / (unsigned)Wt) + 1u;
-    const unsigned magicH = (unsigned)(0x100000000ULL / (unsigned)H) + 1u;
+    const FastDiv divWt((unsigned)Wt), divH((unsigned)H);
 
     f32x4 ap0[NA], ap1[NA], bp0[NB], bp1[NB], aq[NA], bq[NB];
     int lp = tbeg, lq = tbeg;                          // first tile of the next slice for the p / q loads
 
     // tile t -> (global image-row index rowidx = n*H + y, column pair xt)
     auto coords = [&](int t, int& rowidx, int& xt) {
-        rowidx = Wt == 1 ? t : (int)__umulhi((unsigned)t, magicWt);   // 2^32/1 + 1 does not fit the 32-bit magic
+        rowidx = (int)divWt.div((unsigned)t);
         xt = t - rowidx * Wt;
     };
     auto issue_p = [&](f32x4 (&ap)[NA], f32x4 (&bp)[NB]) {
@@ -374,17 +377,17 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
             int rowidx, xt;
             coords(t, rowidx, xt);
             const unsigned pix = (unsigned)(rowidx * W + 2 * xt);
-            ap[i] = buf_load16(dr, (aok && useA0 && t < tend) ? (pix * (unsigned)ld_dy + (unsigned)coA) * 4u : OOB);
+            ap[i] = buf_load16(dr, oob_unless(aok & useA0 & (t < tend), (pix * (unsigned)ld_dy + (unsigned)coA) * 4u));
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int t = lp + prb + i * RPB;
             int rowidx, xt;
             coords(t, rowidx, xt);
-            const int n = H == 1 ? rowidx : (int)__umulhi((unsigned)rowidx, magicH);
+            const int n = (int)divH.div((unsigned)rowidx);
             const int y = rowidx - n * H;
-            const bool ok = bok && t < tend && (unsigned)(y + rB - 1) < (unsigned)H && (unsigned)(2 * xt + po) < (unsigned)W;
-            bp[i] = buf_load16(xr, ok ? ((unsigned)((rowidx + rB - 1) * W + 2 * xt + po) * (unsigned)Cin + (unsigned)ciB) * 4u : OOB);
+            const bool ok = bok & (t < tend) & ((unsigned)(y + rB - 1) < (unsigned)H) & ((unsigned)(2 * xt + po) < (unsigned)W);   // '&': no short-circuit branches
+            bp[i] = buf_load16(xr, oob_unless(ok, ((unsigned)((rowidx + rB - 1) * W + 2 * xt + po) * (unsigned)Cin + (unsigned)ciB) * 4u));
         }
         lp += BK;
     };
@@ -395,17 +398,17 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
             int rowidx, xt;
             coords(t, rowidx, xt);
             const unsigned pix = (unsigned)(rowidx * W + 2 * xt + 1);
-            aq[i] = buf_load16(dr, (aok && useA1 && t < tend && 2 * xt + 1 < W) ? (pix * (unsigned)ld_dy + (unsigned)coA) * 4u : OOB);
+            aq[i] = buf_load16(dr, oob_unless(aok & useA1 & (t < tend) & (2 * xt + 1 < W), (pix * (unsigned)ld_dy + (unsigned)coA) * 4u));
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int t = lq + prb + i * RPB;
             int rowidx, xt;
             coords(t, rowidx, xt);
-            const int n = H == 1 ? rowidx : (int)__umulhi((unsigned)rowidx, magicH);
+            const int n = (int)divH.div((unsigned)rowidx);
             const int y = rowidx - n * H;
-            const bool ok = bok && t < tend && (unsigned)(y + rB - 1) < (unsigned)H && (unsigned)(2 * xt + qo) < (unsigned)W;
-            bq[i] = buf_load16(xr, ok ? ((unsigned)((rowidx + rB - 1) * W + 2 * xt + qo) * (unsigned)Cin + (unsigned)ciB) * 4u : OOB);
+            const bool ok = bok & (t < tend) & ((unsigned)(y + rB - 1) < (unsigned)H) & ((unsigned)(2 * xt + qo) < (unsigned)W);
+            bq[i] = buf_load16(xr, oob_unless(ok, ((unsigned)((rowidx + rB - 1) * W + 2 * xt + qo) * (unsigned)Cin + (unsigned)ciB) * 4u));
         }
         lq += BK;
     };
