@@ -74,14 +74,19 @@ size_t cvk_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin_pad, int C
 int cvk_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,
                       int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Same operator through 1-D Winograd F(2,3) along the width (1.5x fewer MFMA FLOPs; csrc/wino.hip), for Cin % 64 == 0.
- *   U = cvk_wino_weight_transform(w): [4][Cout][3][Cin] from w [Cout][3][3][Cin].  cvk_conv3x3_wino has the contract of
- *   cvk_conv3x3_fwd (bias, fused BN statistics partials, ldy % 4 == 0) plus a workspace holding the four transformed
- *   products M_xi[N*H*ceil(W/2)][ldy].  Data-grad: apply it to dy with U of the cvk_pack_weight_dgrad weights. */
+/* Same operator through 1-D Winograd F(2,3) along the width (1.5x fewer MFMA FLOPs; csrc/wino.hip), for Cin % 64 == 0:
+ *   U  = cvk_wino_weight_transform(w)                      [4][Cout][3][Cin] from w [Cout][3][3][Cin]
+ *   Mo = cvk_conv3x3_wino_gemm(x, U)                       four transformed products, float[4][N*H*ceil(W/2)][ldm]
+ *                                                          (cvk_conv3x3_wino_workspace_bytes(N,H,W,ldm) bytes)
+ *   y, stats = cvk_wino_output(Mo, bias)                   output transform + bias + fused BN statistics partials;
+ *                                                          y / stats / bias / ldy exactly as in cvk_conv3x3_fwd (ldy == ldm)
+ * Data-grad: the same three calls on dy with the cvk_pack_weight_dgrad weights, bias = stats = NULL. */
 int cvk_wino_weight_transform(const float* w, float* U, int Cout, int Cin, void* stream);
 size_t cvk_conv3x3_wino_workspace_bytes(int N, int H, int W, int Cout_ld);
-int cvk_conv3x3_wino(const float* x, const float* U, const float* bias, float* y, float* stats,
-                     int N, int H, int W, int Cin, int Cout, int ldy, void* workspace, size_t workspace_bytes, void* stream);
+int cvk_conv3x3_wino_gemm(const float* x, const float* U, float* Mo, int N, int H, int W, int Cin, int Cout, int ldm,
+                          void* stream);
+int cvk_wino_output(const float* Mo, const float* bias, float* y, float* stats, int N, int H, int W, int Cout, int ldy,
+                    void* stream);
 
 /* weight-grad through the transposed F(2,3) (same contract as cvk_conv3x3_wgrad; any Cin_pad % 4 == 0) */
 size_t cvk_conv3x3_wgrad_wino_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout);

@@ -556,19 +556,14 @@ extern "C" size_t cvk_conv3x3_wino_workspace_bytes(int N, int H, int W, int Cout
     return (size_t)4 * N * H * ((W + 1) / 2) * Cout_ld * sizeof(float);
 }
 
-extern "C" int cvk_conv3x3_wino(const float* x, const float* U, const float* bias, float* y, float* stats, int N, int H,
-                                int W, int Cin, int Cout, int ldy, void* workspace, size_t workspace_bytes, void* stream) {
-    CVK_CHECK_ARG(x && U && y && workspace, "cvk_conv3x3_wino: null pointer");
-    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout && ldy % 4 == 0, "cvk_conv3x3_wino: bad shape");
-    CVK_CHECK_ARG(Cin > 0 && Cin % 64 == 0, "cvk_conv3x3_wino: Cin=%d must be a multiple of 64 (use cvk_conv3x3_fwd otherwise)", Cin);
-    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(U) && cvk_aligned16(y) && cvk_aligned16(workspace), "cvk_conv3x3_wino: pointers must be 16-byte aligned");
-    CVK_CHECK_ARG((long)N * H * W * Cin * 4 < (1L << 31) && (long)4 * Cout * 3 * Cin * 4 < (1L << 31), "cvk_conv3x3_wino: tensor exceeds the 2 GiB buffer-addressing limit; split the batch");
-    const int Wt = (W + 1) / 2, Mt = N * H * Wt, Mpix = N * H * W;
-    if (workspace_bytes < cvk_conv3x3_wino_workspace_bytes(N, H, W, ldy)) {
-        cvk_set_error("cvk_conv3x3_wino: workspace too small");
-        return CVK_EWORKSPACE;
-    }
-    float* Mo = (float*)workspace;
+extern "C" int cvk_conv3x3_wino_gemm(const float* x, const float* U, float* Mo, int N, int H, int W, int Cin, int Cout,
+                                     int ldm, void* stream) {
+    CVK_CHECK_ARG(x && U && Mo, "cvk_conv3x3_wino_gemm: null pointer");
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldm >= Cout && ldm % 4 == 0, "cvk_conv3x3_wino_gemm: bad shape");
+    CVK_CHECK_ARG(Cin > 0 && Cin % 64 == 0, "cvk_conv3x3_wino_gemm: Cin=%d must be a multiple of 64 (use cvk_conv3x3_fwd otherwise)", Cin);
+    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(U) && cvk_aligned16(Mo), "cvk_conv3x3_wino_gemm: pointers must be 16-byte aligned");
+    CVK_CHECK_ARG((long)N * H * W * Cin * 4 < (1L << 31) && (long)4 * Cout * 3 * Cin * 4 < (1L << 31), "cvk_conv3x3_wino_gemm: tensor exceeds the 2 GiB buffer-addressing limit; split the batch");
+    const int Wt = (W + 1) / 2, Mt = N * H * Wt, Mpix = N * H * W, ldy = ldm;
     hipStream_t s = (hipStream_t)stream;
     // few tile blocks (deep, small-spatial layers): give every transform index its own workgroup so the grid still
     // covers the 256 CUs twice; K per index (3*Cin/32 slices) is long there, so the extra prologues are cheap
@@ -584,18 +579,23 @@ extern "C" int cvk_conv3x3_wino(const float* x, const float* U, const float* bia
         const int tilesM = cvk_cdiv(Mt, 128);
         hipLaunchKernelGGL((k_conv3x3_wino<128, 32, 4, 1>), dim3(tilesM), dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, 1, Mpix, 4);
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-        cvk_set_error("cvk_conv3x3_wino: launch failed: %s", hipGetErrorString(e));
-        return (int)e;
-    }
+    CVK_LAUNCH_RETURN("cvk_conv3x3_wino_gemm");
+}
+
+extern "C" int cvk_wino_output(const float* Mo, const float* bias, float* y, float* stats, int N, int H, int W, int Cout,
+                               int ldy, void* stream) {
+    CVK_CHECK_ARG(Mo && y, "cvk_wino_output: null pointer");
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout && ldy % 4 == 0, "cvk_wino_output: bad shape");
+    CVK_CHECK_ARG(cvk_aligned16(Mo) && cvk_aligned16(y), "cvk_wino_output: pointers must be 16-byte aligned");
+    const int Wt = (W + 1) / 2, Mt = N * H * Wt, Mpix = N * H * W;
     const int P = cvk_cdiv(Mpix, CVK_STAT_ROWS);
     dim3 grid(P, cvk_cdiv(ldy, 1024));
+    hipStream_t s = (hipStream_t)stream;
     if (stats)
         hipLaunchKernelGGL(k_wino_output<true>, grid, dim3(256), 0, s, Mo, ldy, Mt, bias, y, ldy, stats, P, Mpix, H, W, Wt, ldy, Cout);
     else
         hipLaunchKernelGGL(k_wino_output<false>, grid, dim3(256), 0, s, Mo, ldy, Mt, bias, y, ldy, stats, P, Mpix, H, W, Wt, ldy, Cout);
-    CVK_LAUNCH_RETURN("cvk_conv3x3_wino");
+    CVK_LAUNCH_RETURN("cvk_wino_output");
 }
 
 extern "C" size_t cvk_conv3x3_wgrad_wino_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout) {

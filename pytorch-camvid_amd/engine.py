@@ -156,8 +156,9 @@ class ConvBnRelu(Op):
             wsb = lib.cvk_conv3x3_wino_workspace_bytes(N, H, W, ldy)
             ws = R.workspace(wsb, X.device)
             _timed(R, conv_kernel_name("wino", ldy), 18.0 * M * C * self.cin, lambda: check(
-                lib.cvk_conv3x3_wino(X.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy,
-                                     ws.data_ptr(), wsb, s), "cvk_conv3x3_wino"))
+                lib.cvk_conv3x3_wino_gemm(X.data_ptr(), U.data_ptr(), ws.data_ptr(), N, H, W, src.ld, C, ldy, s), "cvk_conv3x3_wino_gemm"))
+            _timed(R, "k_wino_output", 12.0 * M * ldy, lambda: check(
+                lib.cvk_wino_output(ws.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, C, ldy, s), "cvk_wino_output"), "byte")
         else:
             _timed(R, conv_kernel_name("fwd", ldy, src.ld), 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy, s),
@@ -237,8 +238,10 @@ class ConvBnRelu(Op):
                 wsb2 = lib.cvk_conv3x3_wino_workspace_bytes(N, H, W, src.ld)
                 ws2 = R.workspace(wsb2, dev)
                 _timed(R, conv_kernel_name("wino", src.ld), 18.0 * M * C * self.cin, lambda: check(
-                    lib.cvk_conv3x3_wino(dy.data_ptr(), U.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld,
-                                         ws2.data_ptr(), wsb2, s), "cvk_conv3x3_wino(dgrad)"))
+                    lib.cvk_conv3x3_wino_gemm(dy.data_ptr(), U.data_ptr(), ws2.data_ptr(), N, H, W, ldy, src.ld, src.ld, s),
+                    "cvk_conv3x3_wino_gemm(dgrad)"))
+                _timed(R, "k_wino_output", 12.0 * M * src.ld, lambda: check(
+                    lib.cvk_wino_output(ws2.data_ptr(), None, dX.data_ptr(), None, N, H, W, src.ld, src.ld, s), "cvk_wino_output"), "byte")
             else:
                 _timed(R, conv_kernel_name("dgrad", src.ld, ldy), 18.0 * M * C * self.cin, lambda: check(
                     lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),

@@ -59,7 +59,7 @@ def main():
             U = torch.empty(4 * co * 3 * ci, device=dev)
             check(lib.cvk_wino_weight_transform(w.data_ptr(), U.data_ptr(), co, ci, s))
             wsb = lib.cvk_conv3x3_wino_workspace_bytes(N, H, W, ldy); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            t = timeit(lambda: check(lib.cvk_conv3x3_wino(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, ci, co, ldy, ws.data_ptr(), wsb, s)))
+            t = timeit(lambda: (check(lib.cvk_conv3x3_wino_gemm(x.data_ptr(), U.data_ptr(), ws.data_ptr(), N, H, W, ci, co, ldy, s)), check(lib.cvk_wino_output(ws.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, co, ldy, s))))
             row += f" wino {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["wino"][0] += flops; tot["wino"][1] += t
         if "dgrad" in which and name != "down1.0":
             dy = torch.randn(M, ldy, device=dev); wd = torch.randn(ci, 9 * ldy, device=dev) * 0.05; dx = torch.empty(M, ci, device=dev)

@@ -11,7 +11,7 @@ def one(N,H,W,ci,co):
     check(lib.cvk_conv3x3_fwd(x.data_ptr(),w.data_ptr(),b.data_ptr(),y1.data_ptr(),s1.data_ptr(),N,H,W,ci,co,ldy,s))
     U=torch.empty(4*co*3*ci,device='cuda'); check(lib.cvk_wino_weight_transform(w.data_ptr(),U.data_ptr(),co,ci,s))
     wsb=lib.cvk_conv3x3_wino_workspace_bytes(N,H,W,ldy); ws=torch.zeros(wsb,dtype=torch.uint8,device='cuda')
-    check(lib.cvk_conv3x3_wino(x.data_ptr(),U.data_ptr(),b.data_ptr(),y2.data_ptr(),s2.data_ptr(),N,H,W,ci,co,ldy,ws.data_ptr(),wsb,s))
+    check(lib.cvk_conv3x3_wino_gemm(x.data_ptr(),U.data_ptr(),ws.data_ptr(),N,H,W,ci,co,ldy,s)); check(lib.cvk_wino_output(ws.data_ptr(),b.data_ptr(),y2.data_ptr(),s2.data_ptr(),N,H,W,co,ldy,s))
     torch.cuda.synchronize()
     e=(y1-y2).abs().max().item(); es=(s1-s2).abs().max().item()
     bad=((y1-y2).abs()>1e-3).nonzero()
