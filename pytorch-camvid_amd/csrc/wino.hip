@@ -313,10 +313,15 @@ __global__ __launch_bounds__(256) void k_wino_output(const float* __restrict__ M
 //   P_xi[Cout][3*Cin] = E_xi^T[tiles][Cout] * V_xi[tiles][3*Cin]   (reduction over N*H*ceil(W/2) tiles: half the pixels,
 //   3 instead of 9 column blocks per pixel -> 12*M*Cin*Cout FLOPs instead of 18).  Both operands are transformed on the
 //   way to LDS; the 4 P_xi only meet in the (tiny, weight-sized) slab reduction, so there is no extra activation pass.
-template <int BM, int BN, int WARPS_M, int WARPS_N>
+// K slices are aligned to image rows so that every coordinate is either a per-thread constant or wave-uniform (SALU):
+//   W >= 64 (Wt >= 32): a slice is 32 consecutive column pairs of ONE image row (S = ceil(Wt/32) slices per row),
+//   W <  64            : a slice is R = floor(32/Wt) whole image rows.
+// A thread's tile inside a slice is (dr, xt) = constants; the slice contributes the uniform (row0, xbase).
+// L = tiles per K slice (32, or 30 so that frame widths that are multiples of 30/60 - every CamVid level - waste nothing).
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool MULTIROW, int L>
 __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
-    const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ slab, int Mt, int H, int W, int Wt,
-    int Cin, int Cout, int ld_dy, int K3, int chunk, int tilesN, int Mpix, int ntiles) {
+    const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ slab, int NH, int H, int W, int Wt,
+    int Cin, int Cout, int ld_dy, int K3, int chunk, int tilesN, int Mpix, int ntiles, int nslices, int S, int R) {
     constexpr int NT = WARPS_M * WARPS_N * 64;
     constexpr int TM = BM / WARPS_M / 32, TN = BN / WARPS_N / 32;
     constexpr int VA = BM / 4, VB = BN / 4;
@@ -340,11 +345,11 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
     const int tile = rem_ >> 2, xi = rem_ & 3;
     const int c0 = (tile / tilesN) * BM;
     const int n0 = (tile % tilesN) * BN;
-    const int tbeg = split * chunk;
-    const int tend = min(Mt, tbeg + chunk);
+    const int sbeg = split * chunk;
+    const int send = min(nslices, sbeg + chunk);
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, Mpix * Cin * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)DY, 0, Mpix * ld_dy * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dr_ = __builtin_amdgcn_make_buffer_rsrc((void*)DY, 0, Mpix * ld_dy * 4, 0x00020000);
 
     const int cva = tid % VA, pra = tid / VA;
     const int cvb = tid % VB, prb = tid / VB;
@@ -360,58 +365,73 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
     const float sgB = xi == 1 ? 1.f : -1.f;
     const float sgA = xi == 2 ? -1.f : 1.f;           // E = a0 + sgA*a1 with a0 = dy0 (off for xi 3), a1 = dy1 (off for xi 0)
     const bool useA0 = xi != 3, useA1 = xi != 0;
-    const FastDiv divWt((unsigned)Wt), divH((unsigned)H);
+    const FastDiv divS((unsigned)S), divH((unsigned)H), divWt((unsigned)Wt);
+
+    // per-thread tile constants inside a slice: row delta, column pair, and the constant part of the byte offsets; the
+    // slice adds wave-uniform terms only, so a load costs ~5 VALU (offset add, two range compares, predicate, OOB select)
+    int adr[NA], axt[NA], bdr[NB], bxt[NB];
+    unsigned aconst[NA], bconst[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int pr = pra + i * RPA;
+        adr[i] = (S > 1 || R == 1) ? 0 : (int)divWt.div((unsigned)pr);
+        axt[i] = pr - adr[i] * Wt;
+        if ((S == 1 && adr[i] >= R) || pr >= L) axt[i] = Wt;   // beyond the slice: never valid
+        aconst[i] = ((unsigned)(adr[i] * W + 2 * axt[i]) * (unsigned)ld_dy + (unsigned)coA) * 4u;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int pr = prb + i * RPB;
+        bdr[i] = (S > 1 || R == 1) ? 0 : (int)divWt.div((unsigned)pr);
+        bxt[i] = pr - bdr[i] * Wt;
+        if ((S == 1 && bdr[i] >= R) || pr >= L) bxt[i] = Wt;
+        bconst[i] = ((unsigned)((bdr[i] + rB - 1) * W + 2 * bxt[i]) * (unsigned)Cin + (unsigned)ciB) * 4u;
+    }
 
     f32x4 ap0[NA], ap1[NA], bp0[NB], bp1[NB], aq[NA], bq[NB];
-    int lp = tbeg, lq = tbeg;                          // first tile of the next slice for the p / q loads
+    int lp = sbeg, lq = sbeg;                          // next slice for the p / q loads (uniform)
 
-    // tile t -> (global image-row index rowidx = n*H + y, column pair xt)
-    auto coords = [&](int t, int& rowidx, int& xt) {
-        rowidx = (int)divWt.div((unsigned)t);
-        xt = t - rowidx * Wt;
+    // slice -> uniform (first image row index row0 = n*H + y0, first column pair xbase)
+    auto slice_origin = [&](int sl, int& row0, int& xbase, int& y0) {
+        const int q = (int)divS.div((unsigned)sl);     // S == 1: q = sl
+        row0 = q * R;                                  // S > 1  => R == 1
+        xbase = (sl - q * S) * L;
+        y0 = row0 - (int)divH.div((unsigned)row0) * H;
     };
-    auto issue_p = [&](f32x4 (&ap)[NA], f32x4 (&bp)[NB]) {
+    // which: 0 = "p" taps (dy0 / x column 2xt+po), 1 = "q" taps (dy1 / x column 2xt+qo)
+    auto issue = [&](int sl, int which, f32x4 (&ar)[NA], f32x4 (&br)[NB]) {
+        int row0, xbase, y0;
+        slice_origin(sl, row0, xbase, y0);
+        const bool live = sl < send;
+        const int xlim = Wt - xbase, rlim = NH - row0;                       // uniform validity limits
+        const int acol = which;                                               // dy column 2xt + which
+        const unsigned sA = (unsigned)((row0 * W + 2 * xbase + acol) * ld_dy) * 4u;
+        const bool aon = aok & live & (which ? useA1 : useA0);
+        const int wlimA = W - 2 * xbase - acol;                               // need 2*axt < wlimA
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int t = lp + pra + i * RPA;
-            int rowidx, xt;
-            coords(t, rowidx, xt);
-            const unsigned pix = (unsigned)(rowidx * W + 2 * xt);
-            ap[i] = buf_load16(dr, oob_unless(aok & useA0 & (t < tend), (pix * (unsigned)ld_dy + (unsigned)coA) * 4u));
+            const bool ok = aon & (axt[i] < xlim) & (adr[i] < rlim) & (2 * axt[i] < wlimA);
+            ar[i] = buf_load16(dr_, oob_unless(ok, aconst[i] + sA));
         }
+        const int o = which ? qo : po;
+        const unsigned sB = (unsigned)((row0 * W + 2 * xbase + o) * Cin) * 4u;
+        const int xoff = 2 * xbase + o;
+        const bool bon = bok & live;
+        const bool rowok_uniform = (unsigned)(y0 + rB - 1) < (unsigned)H;    // exact when the slice is one image row
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int t = lp + prb + i * RPB;
-            int rowidx, xt;
-            coords(t, rowidx, xt);
-            const int n = (int)divH.div((unsigned)rowidx);
-            const int y = rowidx - n * H;
-            const bool ok = bok & (t < tend) & ((unsigned)(y + rB - 1) < (unsigned)H) & ((unsigned)(2 * xt + po) < (unsigned)W);   // '&': no short-circuit branches
-            bp[i] = buf_load16(xr, oob_unless(ok, ((unsigned)((rowidx + rB - 1) * W + 2 * xt + po) * (unsigned)Cin + (unsigned)ciB) * 4u));
+            bool rowok = rowok_uniform;
+            if (MULTIROW) {                                                   // narrow frames only (compile-time)
+                const int yy = y0 + bdr[i];
+                const int y = yy - (int)divH.div((unsigned)yy) * H;
+                rowok = (unsigned)(y + rB - 1) < (unsigned)H;
+            }
+            const bool ok = bon & rowok & (bxt[i] < xlim) & (bdr[i] < rlim) & ((unsigned)(2 * bxt[i] + xoff) < (unsigned)W);
+            br[i] = buf_load16(xr, oob_unless(ok, bconst[i] + sB));
         }
-        lp += BK;
     };
-    auto issue_q = [&]() {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int t = lq + pra + i * RPA;
-            int rowidx, xt;
-            coords(t, rowidx, xt);
-            const unsigned pix = (unsigned)(rowidx * W + 2 * xt + 1);
-            aq[i] = buf_load16(dr, oob_unless(aok & useA1 & (t < tend) & (2 * xt + 1 < W), (pix * (unsigned)ld_dy + (unsigned)coA) * 4u));
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int t = lq + prb + i * RPB;
-            int rowidx, xt;
-            coords(t, rowidx, xt);
-            const int n = (int)divH.div((unsigned)rowidx);
-            const int y = rowidx - n * H;
-            const bool ok = bok & (t < tend) & ((unsigned)(y + rB - 1) < (unsigned)H) & ((unsigned)(2 * xt + qo) < (unsigned)W);
-            bq[i] = buf_load16(xr, oob_unless(ok, ((unsigned)((rowidx + rB - 1) * W + 2 * xt + qo) * (unsigned)Cin + (unsigned)ciB) * 4u));
-        }
-        lq += BK;
-    };
+    auto issue_p = [&](f32x4 (&ap)[NA], f32x4 (&bp)[NB]) { issue(lp, 0, ap, bp); ++lp; };
+    auto issue_q = [&]() { issue(lq, 1, aq, bq); ++lq; };
     auto store_stage = [&](float* dst, const f32x4 (&ap)[NA], const f32x4 (&bp)[NB]) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -453,7 +473,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
         }
     };
 
-    const int nK = (tend - tbeg + BK - 1) / BK;
+    const int nK = send - sbeg;
     issue_p(ap0, bp0);
     issue_q();
     store_stage(smem, ap0, bp0);
@@ -470,7 +490,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
         mma_part(cur + aco, cur + bco, 0, 8);       \
         store_stage(nxt, AP_, BP_);                 \
         issue_p(AP_, BP_);                          \
-        mma_part(cur + aco, cur + bco, 8, 16);      \
+        mma_part(cur + aco, cur + bco, 8, L / 2);   \
         __syncthreads();                            \
     } while (0)
     int ks = 0;
@@ -517,14 +537,20 @@ __global__ void k_wgrad_wino_reduce(const float* __restrict__ slab, float* __res
     }
 }
 
-struct WWPlan { int bm, tilesM, tilesN, splits, chunk; };
-WWPlan plan_wgrad_wino(int Mt, int Cin_pad, int Cout) {
+struct WWPlan { int bm, tilesM, tilesN, splits, chunk, nslices, S, R, L; };
+WWPlan plan_wgrad_wino(int NH, int Wt, int Cin_pad, int Cout) {
     WWPlan p;
     p.bm = Cout > 64 ? 128 : 64;
     p.tilesM = cvk_cdiv(Cout, p.bm);
     p.tilesN = cvk_cdiv(3 * Cin_pad, 128);
+    // slice length: 32 tiles, or 30 when that wastes fewer MFMA K steps (useful fraction = Wt / (slices_per_row * L))
+    auto useful = [&](int L) { return Wt >= L ? (double)Wt / ((double)cvk_cdiv(Wt, L) * L) : (double)((L / Wt) * Wt) / L; };
+    p.L = useful(30) > useful(32) + 1e-9 ? 30 : 32;
+    p.S = Wt >= p.L ? cvk_cdiv(Wt, p.L) : 1;               // slices per image row (wide frames)
+    p.R = Wt >= p.L ? 1 : p.L / Wt;                        // whole image rows per slice (narrow frames)
+    p.nslices = Wt >= p.L ? NH * p.S : cvk_cdiv(NH, p.R);
     const int units = p.tilesM * p.tilesN * 4;
-    const int max_splits = Mt / (BK * 16) > 0 ? Mt / (BK * 16) : 1;
+    const int max_splits = p.nslices / 16 > 0 ? p.nslices / 16 : 1;
     int best = 1;
     double best_eff = -1.0;
     for (int s = 1; s <= max_splits && s <= 2048; ++s) {
@@ -536,8 +562,8 @@ WWPlan plan_wgrad_wino(int Mt, int Cin_pad, int Cout) {
         if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
     }
     p.splits = best;
-    p.chunk = cvk_cdiv(cvk_cdiv(Mt, p.splits), BK) * BK;
-    p.splits = cvk_cdiv(Mt, p.chunk);
+    p.chunk = cvk_cdiv(p.nslices, p.splits);               // slices per split
+    p.splits = cvk_cdiv(p.nslices, p.chunk);
     return p;
 }
 
@@ -600,7 +626,7 @@ extern "C" int cvk_wino_output(const float* Mo, const float* bias, float* y, flo
 
 extern "C" size_t cvk_conv3x3_wgrad_wino_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin_pad <= 0 || Cout <= 0) return 0;
-    const WWPlan p = plan_wgrad_wino(N * H * ((W + 1) / 2), Cin_pad, Cout);
+    const WWPlan p = plan_wgrad_wino(N * H, (W + 1) / 2, Cin_pad, Cout);
     return (size_t)p.splits * 4 * Cout * 3 * Cin_pad * sizeof(float);
 }
 
@@ -612,8 +638,9 @@ extern "C" int cvk_conv3x3_wgrad_wino(const float* x, const float* dy, float* dw
     CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(dy) && cvk_aligned16(workspace), "cvk_conv3x3_wgrad_wino: pointers must be 16-byte aligned");
     CVK_CHECK_ARG((long)N * H * W * Cin_pad * 4 < (1L << 31) && (long)N * H * W * ld_dy * 4 < (1L << 31), "cvk_conv3x3_wgrad_wino: x or dy exceeds the 2 GiB buffer-addressing limit; split the batch");
     const int Wt = (W + 1) / 2, Mt = N * H * Wt, Mpix = N * H * W, K3 = 3 * Cin_pad;
-    CVK_CHECK_ARG((long)Mt * Wt < (1L << 32) && (long)N * H * H < (1L << 32), "cvk_conv3x3_wgrad_wino: frame too large for the multiply-high coordinate split");
-    const WWPlan p = plan_wgrad_wino(Mt, Cin_pad, Cout);
+    CVK_CHECK_ARG((long)N * H * H < (1L << 32) && (long)N * H * Wt < (1L << 31), "cvk_conv3x3_wgrad_wino: frame too large for the multiply-high coordinate split");
+    const WWPlan p = plan_wgrad_wino(N * H, Wt, Cin_pad, Cout);
+    (void)Mt;
     const size_t need = (size_t)p.splits * 4 * Cout * K3 * sizeof(float);
     if (workspace_bytes < need) {
         cvk_set_error("cvk_conv3x3_wgrad_wino: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -622,10 +649,17 @@ extern "C" int cvk_conv3x3_wgrad_wino(const float* x, const float* dy, float* dw
     hipStream_t s = (hipStream_t)stream;
     float* slab = (float*)workspace;
     dim3 grid(p.tilesM * p.tilesN * p.splits * 4);
-    if (p.bm == 128)
-        hipLaunchKernelGGL((k_wgrad_wino<128, 128, 2, 2>), grid, dim3(256), 0, s, x, dy, slab, Mt, H, W, Wt, Cin_pad, Cout, ld_dy, K3, p.chunk, p.tilesN, Mpix, p.tilesM * p.tilesN);
-    else
-        hipLaunchKernelGGL((k_wgrad_wino<64, 128, 2, 2>), grid, dim3(256), 0, s, x, dy, slab, Mt, H, W, Wt, Cin_pad, Cout, ld_dy, K3, p.chunk, p.tilesN, Mpix, p.tilesM * p.tilesN);
+#define CVK_WW_LAUNCH(BM_, MR_, L_)                                                                                                   \
+    hipLaunchKernelGGL((k_wgrad_wino<BM_, 128, 2, 2, MR_, L_>), grid, dim3(256), 0, s, x, dy, slab, N * H, H, W, Wt, Cin_pad, Cout, ld_dy, \
+                       K3, p.chunk, p.tilesN, Mpix, p.tilesM * p.tilesN, p.nslices, p.S, p.R)
+#define CVK_WW_PICK(BM_)                                                                        \
+    do {                                                                                        \
+        if (p.L == 30) { if (p.R > 1) CVK_WW_LAUNCH(BM_, true, 30); else CVK_WW_LAUNCH(BM_, false, 30); } \
+        else { if (p.R > 1) CVK_WW_LAUNCH(BM_, true, 32); else CVK_WW_LAUNCH(BM_, false, 32); }           \
+    } while (0)
+    if (p.bm == 128) CVK_WW_PICK(128); else CVK_WW_PICK(64);
+#undef CVK_WW_PICK
+#undef CVK_WW_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         cvk_set_error("cvk_conv3x3_wgrad_wino: launch failed: %s", hipGetErrorString(e));

@@ -250,7 +250,7 @@ class ConvBnRelu(Op):
         if R.wino and src.ld >= 32 and C > 32 and (src.ld > 64 or C > 64):   # 64->64 layers: the direct kernel is faster
             wsb = lib.cvk_conv3x3_wgrad_wino_workspace_bytes(N, H, W, src.ld, C)
             ws = R.workspace(wsb, dev)
-            _timed(R, "k_wgrad_wino<128, 128, 2, 2>" if C > 64 else "k_wgrad_wino<64, 128, 2, 2>", 18.0 * M * C * self.cin, lambda: check(
+            _timed(R, f"k_wgrad_wino<{'128' if C > 64 else '64'}, 128, 2, 2>", 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_wgrad_wino(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
                 "cvk_conv3x3_wgrad_wino"))
         else:

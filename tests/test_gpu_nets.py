@@ -88,10 +88,12 @@ def test_adamw_trajectory_golden(tag):
         opt.step(); sched.step()
         losses.append(l.item())
     # Adam divides by sqrt(v): rounding-level gradient differences become lr-sized parameter differences, so the
-    # trajectory is only as reproducible as the reference itself is.  Measured on the reference graph (oracle/torch_ref,
-    # UNet 2x48x64): fp32 vs fp64 runs differ by 7e-6 / 1.2e-5 / 3.5e-3 / 7.1e-3 at steps 2..5, and a 1e-6 relative input
-    # perturbation moves step 4 by 7.2e-3.  Tolerances: step 1 2e-5 (pure forward), steps 2-3 2e-3, later steps 1.5e-2.
-    tol = [2e-5, 2e-3, 2e-3] + [1.5e-2] * 8
+    # trajectory is only as reproducible as the reference itself is.  Measured on the reference graph (oracle/torch_ref):
+    #   UNet 2x48x64:   fp32 vs fp64 runs differ by 7e-6 / 1.2e-5 / 3.5e-3 at steps 2..4; a 1e-6 relative input
+    #                   perturbation moves steps 3/4 by 1.0e-3 / 7.2e-3
+    #   SegNet 2x64x96: fp32 vs fp64 6.9e-4 / 2.5e-3 / 9.1e-3 at steps 2..4; perturbation 2.8e-3 / 3.6e-3 at steps 3/4
+    # Tolerances (about 3x that noise): step 1 2e-5 (pure forward), step 2 3e-3, step 3 1e-2, later steps 3e-2.
+    tol = [2e-5, 3e-3, 1e-2] + [3e-2] * 8
     for i, (a, b) in enumerate(zip(losses, d["traj_losses"])):
         assert abs(a - b) < tol[i], (i, a, b)
 
