@@ -154,6 +154,11 @@ int cvk_argmax_channels(const float* logits, int ld, int64_t* out, int M, int C,
 int cvk_confusion_accumulate(const int64_t* pred, const int64_t* label, int64_t* hist, int M, int num_classes,
                              int ignore_index, void* stream);
 
+/* ---- input pipeline on device (transforms.ToTensor + Normalize: transforms.py:485-538, MEAN/STD conf/settings.py:8-9) ----
+ * src uint8 [N,H,W,3] (channel order as decoded, i.e. cv2 BGR) -> dst float32 NHWC with ld = 4 (pad channel 0):
+ * dst[c] = (src[c]/255 - mean3[c]) / std3[c].  mean3 / std3 are HOST pointers to 3 floats. */
+int cvk_preprocess_u8(const uint8_t* src, float* dst, int N, int H, int W, const float* mean3, const float* std3, void* stream);
+
 /* ---- fused AdamW over a flat fp32 buffer (torch.optim.AdamW: train.py:100,133) -------------------------------- */
 int cvk_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);

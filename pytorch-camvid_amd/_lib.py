@@ -64,6 +64,7 @@ SIGNATURES = {
     "cvk_softmax_ce_bwd": (c_int, [c_vp, c_int, c_vp, c_vp, c_float, c_vp, c_int, c_int, c_int, c_vp]),
     "cvk_argmax_channels": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp]),
     "cvk_confusion_accumulate": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "cvk_preprocess_u8": (c_int, [c_vp, c_vp, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_vp]),
     "cvk_adamw_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_float, c_float, c_float, c_float, c_float, c_int, c_vp]),
 }
 

@@ -114,7 +114,33 @@ __global__ void k_adamw(float* __restrict__ p, const float* __restrict__ g, floa
     }
 }
 
+// uint8 HWC (cv2 BGR order kept) -> float32 NHWC, 4 channels per pixel (3 valid + zero pad): (v/255 - mean[c]) / std[c]
+// = reference transforms.ToTensor + Normalize (transforms.py:485-538) with conf/settings.py:8-9 MEAN/STD passed in.
+__global__ void k_preprocess_u8(const uint8_t* __restrict__ src, float* __restrict__ dst, long npix, float m0, float m1,
+                                float m2, float r0, float r1, float r2) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+        const uint8_t* p = src + i * 3;
+        f32x4 v;
+        v[0] = ((float)p[0] * (1.f / 255.f) - m0) * r0;
+        v[1] = ((float)p[1] * (1.f / 255.f) - m1) * r1;
+        v[2] = ((float)p[2] * (1.f / 255.f) - m2) * r2;
+        v[3] = 0.f;
+        *reinterpret_cast<f32x4*>(dst + i * 4) = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int cvk_preprocess_u8(const uint8_t* src, float* dst, int N, int H, int W, const float* mean3, const float* std3,
+                                 void* stream) {
+    CVK_CHECK_ARG(src && dst && mean3 && std3 && N > 0 && H > 0 && W > 0 && cvk_aligned16(dst), "cvk_preprocess_u8: bad arguments");
+    CVK_CHECK_ARG(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "cvk_preprocess_u8: zero std");
+    const long npix = (long)N * H * W;
+    const long b = (npix + 255) / 256;
+    hipLaunchKernelGGL(k_preprocess_u8, dim3((int)(b < 8192 ? b : 8192)), dim3(256), 0, (hipStream_t)stream, src, dst, npix, mean3[0],
+                       mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
+    CVK_LAUNCH_RETURN("cvk_preprocess_u8");
+}
 
 extern "C" int cvk_ce_blocks(int M) { return M > 0 ? cvk_cdiv(M, CE_ROWS_PER_BLOCK) : 0; }
 

@@ -121,3 +121,43 @@ class ConfusionMeter:
         valid = [c for c in range(self.num_classes) if c != self.ignore_index]
         acc = float(inter.sum() / lab.sum().clamp(min=1))
         return acc, iou, float(torch.nanmean(iou[valid]))
+
+
+# reference conf/settings.py:8-9 (BGR order, as cv2 decodes)
+CAMVID_MEAN = (0.42019099703461577, 0.41323568513979647, 0.4010048431259079)
+CAMVID_STD = (0.30598050258519743, 0.3089986932156864, 0.3054061869915674)
+
+
+def preprocess_uint8(images_u8, mean=CAMVID_MEAN, std=CAMVID_STD):
+    """Device-side ToTensor + Normalize (reference transforms.py:485-538): uint8 [N,H,W,3] on the GPU -> float32
+    logical [N,3,H,W] (a channels_last view of an NHWC-4 buffer).  Replaces the per-sample CPU float conversion and the
+    pageable `images.cuda()` copy of 4 bytes/value (train.py:126) by a 1 byte/value upload + one kernel."""
+    import ctypes
+    lib = _lib.load()
+    if images_u8.dtype != torch.uint8 or images_u8.dim() != 4 or images_u8.shape[-1] != 3 or not images_u8.is_cuda:
+        raise ValueError("expected a uint8 HIP tensor of shape [N, H, W, 3]")
+    src = images_u8.contiguous()
+    N, H, W, _ = src.shape
+    dst = torch.empty((N, H, W, 4), device=src.device, dtype=torch.float32)
+    m = (ctypes.c_float * 3)(*mean); sd = (ctypes.c_float * 3)(*std)
+    check(lib.cvk_preprocess_u8(src.data_ptr(), dst.data_ptr(), N, H, W, m, sd, _stream(src)), "cvk_preprocess_u8")
+    return dst[..., :3].permute(0, 3, 1, 2)
+
+
+@torch.no_grad()
+def evaluate(net, batches, num_classes=12, ignore_index=11):
+    """Validation pass of reference train.py:169-206 / eval.py:44-80 without their bugs: eval-mode forward, device-side
+    argmax and histogram accumulation over the WHOLE set, one host copy at the end.
+    `batches` yields (images [N,3,H,W] float32, masks [N,H,W] int64) on the GPU.  Returns (accuracy, per-class IoU, mIoU)."""
+    was_training = net.training
+    net.eval()
+    meter = None
+    for images, masks in batches:
+        logits = net(images)
+        if meter is None:
+            meter = ConfusionMeter(num_classes, ignore_index, logits.device)
+        meter.update(argmax_channels(logits), masks)
+    net.train(was_training)
+    if meter is None:
+        raise ValueError("evaluate(): no batches")
+    return meter.compute()
