@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak (spec), opt-in --precision bf16 only
 PEAK_HBM_BPS = 8.0e12             # MI355X_MICROARCH.md: HBM3E spec (6.29e12 measured copy)
 PER_GPU_BATCH = 8
 H, W = 360, 480
@@ -44,6 +45,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH)
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16 = opt-in bf16-MFMA forward/data-grad convolutions (configs[3] path); the headline is fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--with-optimizer", action="store_true", help="also time AdamW steps (reported separately)")
@@ -92,6 +95,7 @@ def main():
 
     torch.manual_seed(0)                                    # identical init on every rank (also broadcast below)
     net = A.get_model(a.model, 3, 12).to(dev).train()
+    A.set_conv_precision(net, a.precision)
     model = ddp.DataParallel(net) if world > 1 else net
     lossf = A.CrossEntropyLoss()
     g = torch.Generator().manual_seed(1234 + rank)          # per-rank shard of the global batch
@@ -163,6 +167,7 @@ def main():
         # Winograd kernels execute 2/3 of the algorithmic (direct-convolution) FLOPs; the roofline numerator stays
         # algorithmic, the executed-MFMA utilisation is reported beside it
         executed = (2.0 / 3.0) if "wino" in dom[0] else 1.0
+        peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom[0] else PEAK_F32_MFMA_TFLOPS
         traffic = None
         tp = os.path.join(ROOT, "profiles", "r01_d_pmc_hbm_traffic.json")
         if os.path.exists(tp):
@@ -171,9 +176,9 @@ def main():
                     traffic = {"bytes_per_launch": (v["read_MB_per_launch"] + v["write_MB_per_launch"]) * 1e6,
                                "source": "profiles/r01_d_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                                          "FETCH doubled per MI355X_MICROARCH.md; recorded run, not this run)"}
-        roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "executed_mfma_tflops": round(ach * executed, 2), "executed_mfma_frac": round(ach * executed / PEAK_F32_MFMA_TFLOPS, 4),
+        roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": traffic,
+                "executed_mfma_tflops": round(ach * executed, 2), "executed_mfma_frac": round(ach * executed / peak, 4),
                 "flops_per_launch": fl / cnt, "avg_launch_us": round(sec / cnt * 1e6, 1), "launches_per_step": cnt // 3,
                 "all_conv_kernels": {"achieved": round(allf / alls / 1e12, 2), "frac": round(allf / alls / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                                      "ms_per_step": round(alls / 3 * 1e3, 2)}}
@@ -184,11 +189,11 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "images/sec fwd+bwd UNet 3x360x480 bs=8" if a.model == "unet" and (a.height, a.width, a.batch) == (H, W, 8)
-                      else f"images/sec fwd+bwd {a.model} 3x{a.height}x{a.width} bs={a.batch}",
+            "metric": "images/sec fwd+bwd UNet 3x360x480 bs=8" if a.model == "unet" and (a.height, a.width, a.batch) == (H, W, 8) and a.precision == "fp32"
+                      else f"images/sec fwd+bwd {a.model} 3x{a.height}x{a.width} bs={a.batch} ({a.precision})",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if a.precision == "fp32" else "bf16-mfma fwd/dgrad convs, f32 storage/accumulate/wgrad", "data": "synthetic",
             "config": {"workload": f"{a.model.upper() if a.model=='unet' else 'SegNet'}(3,12) train fwd+bwd+CE, per-GPU batch {a.batch} x 3x{a.height}x{a.width} fp32 "
                                    f"(BASELINE.json configs[1]{' x N ranks, RCCL grad all-reduce (configs[2])' if world > 1 else ''})",
                        "global_batch": world * a.batch, "parallelism": f"dp{world}", "timed_region": "zero_grad+forward+CE+backward"

@@ -74,6 +74,11 @@ size_t cvk_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin_pad, int C
 int cvk_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,
                       int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Opt-in reduced precision (BASELINE.json configs[3]): same contract as cvk_conv3x3_fwd with Cin % 32 == 0; operands are
+ * rounded to bf16 on the way to LDS and multiplied on the bf16 matrix cores with fp32 accumulation; HBM stays fp32. */
+int cvk_conv3x3_fwd_bf16(const float* x, const float* w, const float* bias, float* y, float* stats,
+                         int N, int H, int W, int Cin, int Cout, int ldy, void* stream);
+
 /* Same operator through 1-D Winograd F(2,3) along the width (1.5x fewer MFMA FLOPs; csrc/wino.hip), for Cin % 64 == 0:
  *   U  = cvk_wino_weight_transform(w)                      [4][Cout][3][Cin] from w [Cout][3][3][Cin]
  *   Mo = cvk_conv3x3_wino_gemm(x, U)                       four transformed products, float[4][N*H*ceil(W/2)][ldm]

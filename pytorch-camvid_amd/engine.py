@@ -89,8 +89,15 @@ def wino_ok(R, k_ch, n_cols):
     return R.wino and k_ch % 64 == 0
 
 
+def bf16_ok(R, k_ch):
+    return R.bf16 and k_ch % 32 == 0
+
+
 def conv_kernel_name(kind, n_cols, k_ch=32):
     """Mirror of the tile dispatch in csrc/conv3x3.hip / wino.hip: the kernel-trace name."""
+    if kind in ("bf16_fwd", "bf16_dgrad"):
+        t = "128, 128, 2, 2" if n_cols > 64 else ("128, 64, 2, 2" if n_cols > 32 else "256, 32, 4, 1")
+        return f"k_conv3x3_igemm_bf16<{t}, {'true' if kind == 'bf16_fwd' else 'false'}>"
     if kind == "wino":
         return "k_conv3x3_wino<128, 128, 2, 2>" if n_cols > 64 else ("k_conv3x3_wino<128, 64, 2, 2>" if n_cols > 32 else "k_conv3x3_wino<128, 32, 4, 1>")
     if kind == "wgrad":
@@ -150,7 +157,11 @@ class ConvBnRelu(Op):
         lib, s, src = R.lib, st.stream, self.src
         N, H, W, M, C, ldy = src.N, src.H, src.W, src.M, self.cout, pad4(self.cout)
         sp = stats.data_ptr() if stats is not None else None
-        if wino_ok(R, src.ld, ldy):
+        if bf16_ok(R, src.ld):
+            _timed(R, conv_kernel_name("bf16_fwd", ldy), 18.0 * M * C * self.cin, lambda: check(
+                lib.cvk_conv3x3_fwd_bf16(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy, s),
+                "cvk_conv3x3_fwd_bf16"))
+        elif wino_ok(R, src.ld, ldy):
             U = _empty(4 * C * 3 * src.ld, X.device)
             check(lib.cvk_wino_weight_transform(wk.data_ptr(), U.data_ptr(), C, src.ld, s), "cvk_wino_weight_transform")
             wsb = lib.cvk_conv3x3_wino_workspace_bytes(N, H, W, ldy)
@@ -232,7 +243,11 @@ class ConvBnRelu(Op):
             wd = _empty(src.ld * 9 * ldy, dev)
             check(lib.cvk_pack_weight_dgrad(wc.data_ptr(), wd.data_ptr(), C, self.cin, src.ld, ldy, s), "cvk_pack_weight_dgrad")
             dX = _empty(M * src.ld, dev).view(N, H, W, src.ld)
-            if wino_ok(R, ldy, src.ld):
+            if bf16_ok(R, ldy):
+                _timed(R, conv_kernel_name("bf16_dgrad", src.ld), 18.0 * M * C * self.cin, lambda: check(
+                    lib.cvk_conv3x3_fwd_bf16(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
+                    "cvk_conv3x3_fwd_bf16(dgrad)"))
+            elif wino_ok(R, ldy, src.ld):
                 U = _empty(4 * src.ld * 3 * ldy, dev)
                 check(lib.cvk_wino_weight_transform(wd.data_ptr(), U.data_ptr(), src.ld, ldy, s), "cvk_wino_weight_transform")
                 wsb2 = lib.cvk_conv3x3_wino_workspace_bytes(N, H, W, src.ld)
@@ -425,6 +440,7 @@ class Runner:
         self._ws = None
         self.grad_sync = None       # set by ddp.DataParallel
         self.wino = WINO_DEFAULT
+        self.bf16 = False           # opt-in: bf16-MFMA forward / data-grad convolutions (modules.set_conv_precision)
         self.prof = None            # list collecting (kernel name, flops, start event, end event) when bench.py profiles
         self._flat = [None, None]   # alternating flat gradient buffers (see grad_flat)
 

@@ -243,6 +243,16 @@ def _run(root, x):
     return engine.run_plan(state["runner"], plan, root.training, x, params)
 
 
+def set_conv_precision(module, precision):
+    """"fp32" (default; exact-fp32 MFMA, Winograd where eligible) or "bf16": forward and data-grad convolutions round
+    their operands to bf16 in LDS and run on the bf16 matrix cores with fp32 accumulation (BASELINE.json configs[3]);
+    tensors in HBM, BatchNorm, the weight-grad and the optimizer state stay fp32.  Expect ~1e-2 relative differences."""
+    if precision not in ("fp32", "bf16"):
+        raise ValueError("precision must be 'fp32' or 'bf16'")
+    _state_of(module)["runner"].bf16 = precision == "bf16"
+    return module
+
+
 def runner_of(module):
     """The engine.Runner of a module (created on first use); ddp.DataParallel hooks gradient sync into it."""
     return _state_of(module)["runner"]

@@ -241,3 +241,32 @@ def test_winograd_and_direct_kernels_agree(shape):
         close(y, out_o, 1e-4, 3e-5 * max(1.0, float(np.abs(out_o).max())), f"fwd wino={wino}")
         close(xg.grad, dx_o, 1e-3, 2e-4 * float(np.abs(dx_o).max()), f"dx wino={wino}")
         close(m.conv[0].weight.grad, g_o["conv.0.weight"], 1e-3, 2e-4 * float(np.abs(g_o["conv.0.weight"]).max()), f"dW wino={wino}")
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 12, 20, 64), (1, 128, 7, 5, 96), (1, 32, 9, 4, 12)])
+def test_bf16_mfma_conv_mode(shape):
+    """Opt-in bf16-MFMA forward/data-grad (BASELINE.json configs[3]): bf16 operand rounding gives ~2^-8 relative error per
+    product; stated tolerance: relative L2 error <= 3e-2 against the fp64 oracle (max-norm is not meaningful for the
+    gradients: a 1e-2 forward perturbation flips a few ReLU masks, which moves single gradient elements by O(|r*w|));
+    the fp32 mode must be unaffected."""
+    import pytorch_camvid_amd as A
+    from oracle import np_ops as O
+    n, ci, h, w, co = shape
+    torch.manual_seed(3)
+    m = A.BasicConv2d(ci, co)
+    p = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    x = torch.randn(n, ci, h, w); r = torch.randn(n, co, h, w)
+    out_o, cache = O.basic_conv_fwd(x.numpy(), p, "", train=True)
+    dx_o, g_o = O.basic_conv_bwd(r.numpy(), cache, p)
+    m = A.set_conv_precision(m.to(dev()).train(), "bf16")
+    xg = x.to(dev()).requires_grad_(True)
+    y = m(xg)
+    (y * r.to(dev())).sum().backward()
+    for got, want, what in ((y, out_o, "fwd"), (xg.grad, dx_o, "dx"), (m.conv[0].weight.grad, g_o["conv.0.weight"], "dW")):
+        g = got.detach().cpu().double().numpy()
+        err = np.sqrt(((g - want) ** 2).sum()) / np.sqrt((want ** 2).sum())
+        assert err <= (3e-2 if what == "fwd" else 8e-2), (what, err)     # gradients also carry the ReLU-mask flips
+    assert np.abs(y.detach().cpu().double().numpy() - out_o).max() > 1e-5     # it really ran the reduced-precision kernel
+    A.set_conv_precision(m, "fp32")
+    with torch.no_grad():
+        close(m(x.to(dev())), out_o, 1e-4, 3e-5 * max(1.0, float(np.abs(out_o).max())), "fp32 restored")

@@ -55,6 +55,9 @@ def main():
         if "fwd" in which:
             t = timeit(lambda: check(lib.cvk_conv3x3_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, ci, co, ldy, s)))
             row += f" fwd {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["fwd"][0] += flops; tot["fwd"][1] += t
+        if "bf16" in which and ci % 32 == 0:
+            t = timeit(lambda: check(lib.cvk_conv3x3_fwd_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, ci, co, ldy, s)))
+            row += f" bf16 {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["bf16"][0] += flops; tot["bf16"][1] += t
         if "wino" in which and ci % 64 == 0 and ldy > 32:
             U = torch.empty(4 * co * 3 * ci, device=dev)
             check(lib.cvk_wino_weight_transform(w.data_ptr(), U.data_ptr(), co, ci, s))
