@@ -79,6 +79,12 @@ int cvk_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
 int cvk_conv3x3_fwd_bf16(const float* x, const float* w, const float* bias, float* y, float* stats,
                          int N, int H, int W, int Cin, int Cout, int ldy, void* stream);
 
+/* bf16-MFMA weight-grad (opt-in, Cout > 32): contract and workspace size of cvk_conv3x3_wgrad
+ * (a workspace of cvk_conv3x3_wgrad_bf16_workspace_bytes bytes). */
+size_t cvk_conv3x3_wgrad_bf16_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout);
+int cvk_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,
+                           int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Same operator through 1-D Winograd F(2,3) along the width (1.5x fewer MFMA FLOPs; csrc/wino.hip), for Cin % 64 == 0:
  *   U  = cvk_wino_weight_transform(w)                      [4][Cout][3][Cin] from w [Cout][3][3][Cin]
  *   Mo = cvk_conv3x3_wino_gemm(x, U)                       four transformed products, float[4][N*H*ceil(W/2)][ldm]

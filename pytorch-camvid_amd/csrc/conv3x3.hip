@@ -410,27 +410,6 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
         }
 }
 
-// dw[co][tap][ci] = sum_s slab[s][co][tap*Cin_pad + ci], fixed order (bitwise reproducible)
-__global__ void k_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dw, int splits, int Cout, int Cin,
-                               int Cin_pad, size_t slab_stride) {
-    const size_t total = (size_t)Cout * 9 * Cin;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ci = (int)(i % Cin);
-        const size_t ct = i / Cin;  // co*9 + tap
-        const float* p = slab + ct * Cin_pad + ci;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int s = 0;
-        for (; s + 4 <= splits; s += 4) {
-            s0 += p[(size_t)(s + 0) * slab_stride];
-            s1 += p[(size_t)(s + 1) * slab_stride];
-            s2 += p[(size_t)(s + 2) * slab_stride];
-            s3 += p[(size_t)(s + 3) * slab_stride];
-        }
-        for (; s < splits; ++s) s0 += p[(size_t)s * slab_stride];
-        dw[i] = (s0 + s1) + (s2 + s3);
-    }
-}
-
 __global__ void k_pack_weight_fwd(const float* __restrict__ src, float* __restrict__ dst, int rows, int Cin, int Cin_pad) {
     const size_t total = (size_t)rows * Cin_pad;  // rows = Cout*9
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -456,45 +435,6 @@ __global__ void k_pack_weight_dgrad(const float* __restrict__ src, float* __rest
         const int ci = ci0 + j, co = co0 + tx;
         if (ci < Cin_pad && co < Cout_pad) dst[((size_t)ci * 9 + tap) * Cout_pad + co] = t[tx][j];
     }
-}
-
-// ---- launch-shape heuristics --------------------------------------------------------------------------------------
-// Split the pixel dimension of the weight-grad so that the grid is close to a whole number of rounds over the
-// 256 CUs (equal blocks => efficiency = blocks / (256 * ceil(blocks/256))), keeping >= 16 K-slices per block.
-int choose_splits(int tiles, int M) {
-    const int max_splits = M / (BK * 16) > 0 ? M / (BK * 16) : 1;
-    int best = 1;
-    double best_eff = -1.0;
-    for (int s = 1; s <= max_splits && s <= 2048; ++s) {
-        const long blocks = (long)tiles * s;
-        if (blocks > 4096 && s > 1) break;
-        if (blocks < 512 && s < max_splits) continue;  // want >= 2 co-resident blocks per CU to cover barrier bubbles
-        const long rounds = (blocks + 255) / 256;
-        const double eff = (double)blocks / (256.0 * rounds);
-        if (eff > best_eff + 0.02) {
-            best_eff = eff;
-            best = s;
-        }
-    }
-    return best;
-}
-
-struct WgradPlan {
-    int bm, bn, tilesM, tilesN, splits, chunk;
-};
-
-WgradPlan plan_wgrad(int M, int Cin_pad, int Cout) {
-    WgradPlan p;
-    const int Ktot = 9 * Cin_pad;
-    if (Cout > 64) { p.bm = 128; p.bn = 128; }
-    else if (Cout > 32) { p.bm = 64; p.bn = Ktot <= 64 ? 64 : 128; }   // 64x64: the 3-channel stem (36 columns)
-    else { p.bm = 32; p.bn = 256; }
-    p.tilesM = cvk_cdiv(Cout, p.bm);
-    p.tilesN = cvk_cdiv(Ktot, p.bn);
-    p.splits = choose_splits(p.tilesM * p.tilesN, M);
-    p.chunk = cvk_cdiv(cvk_cdiv(M, p.splits), BK) * BK;
-    p.splits = cvk_cdiv(M, p.chunk);
-    return p;
 }
 
 }  // namespace

@@ -262,7 +262,13 @@ class ConvBnRelu(Op):
                     lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
                     "cvk_conv3x3_fwd(dgrad)"))
             st.grad[src.id] = dX
-        if R.wino and src.ld >= 32 and C > 32 and (src.ld > 64 or C > 64):   # 64->64 layers: the direct kernel is faster
+        if R.bf16 and C > 32:
+            wsb = lib.cvk_conv3x3_wgrad_bf16_workspace_bytes(N, H, W, src.ld, C)
+            ws = R.workspace(wsb, dev)
+            _timed(R, f"k_conv3x3_wgrad_bf16<{'128' if C > 64 else '64'}, 128, 2, 2>", 18.0 * M * C * self.cin, lambda: check(
+                lib.cvk_conv3x3_wgrad_bf16(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
+                "cvk_conv3x3_wgrad_bf16"))
+        elif R.wino and src.ld >= 32 and C > 32 and (src.ld > 64 or C > 64):   # 64->64 layers: the direct kernel is faster
             wsb = lib.cvk_conv3x3_wgrad_wino_workspace_bytes(N, H, W, src.ld, C)
             ws = R.workspace(wsb, dev)
             _timed(R, f"k_wgrad_wino<{'128' if C > 64 else '64'}, 128, 2, 2>", 18.0 * M * C * self.cin, lambda: check(

@@ -244,9 +244,10 @@ def _run(root, x):
 
 
 def set_conv_precision(module, precision):
-    """"fp32" (default; exact-fp32 MFMA, Winograd where eligible) or "bf16": forward and data-grad convolutions round
-    their operands to bf16 in LDS and run on the bf16 matrix cores with fp32 accumulation (BASELINE.json configs[3]);
-    tensors in HBM, BatchNorm, the weight-grad and the optimizer state stay fp32.  Expect ~1e-2 relative differences."""
+    """"fp32" (default; exact-fp32 MFMA, Winograd where eligible) or "bf16": the convolutions (forward, data-grad,
+    weight-grad; all layers except the 3-channel stem and the 12-channel head's data/weight-grad) round their operands
+    to bf16 on the way to LDS and run on the bf16 matrix cores with fp32 accumulation (BASELINE.json configs[3]).
+    Tensors in HBM, BatchNorm, loss, gradients and optimizer state stay fp32.  Expect ~1e-2 relative differences."""
     if precision not in ("fp32", "bf16"):
         raise ValueError("precision must be 'fp32' or 'bf16'")
     _state_of(module)["runner"].bf16 = precision == "bf16"

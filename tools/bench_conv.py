@@ -73,6 +73,11 @@ def main():
             wsb = lib.cvk_conv3x3_wgrad_wino_workspace_bytes(N, H, W, ci, co); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             t = timeit(lambda: check(lib.cvk_conv3x3_wgrad_wino(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, H, W, ci, ci, co, ldy, ws.data_ptr(), wsb, s)))
             row += f" wwino {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["wwino"][0] += flops; tot["wwino"][1] += t
+        if "wbf16" in which and co > 32:
+            dy = torch.randn(M, ldy, device=dev); dw = torch.empty(co, 9 * ci, device=dev)
+            wsb = lib.cvk_conv3x3_wgrad_bf16_workspace_bytes(N, H, W, ci, co); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            t = timeit(lambda: check(lib.cvk_conv3x3_wgrad_bf16(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, H, W, ci, ci, co, ldy, ws.data_ptr(), wsb, s)))
+            row += f" wbf16 {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["wbf16"][0] += flops; tot["wbf16"][1] += t
         if "wgrad" in which:
             dy = torch.randn(M, ldy, device=dev); dw = torch.empty(co, 9 * ci, device=dev)
             wsb = lib.cvk_conv3x3_wgrad_workspace_bytes(N, H, W, ci, co); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
