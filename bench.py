@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH)
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp32_split"],
                     help="bf16 = opt-in bf16-MFMA forward/data-grad convolutions (configs[3] path); the headline is fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
@@ -167,7 +167,7 @@ def main():
         # Winograd kernels execute 2/3 of the algorithmic (direct-convolution) FLOPs; the roofline numerator stays
         # algorithmic, the executed-MFMA utilisation is reported beside it
         executed = (2.0 / 3.0) if "wino" in dom[0] else 1.0
-        peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom[0] else PEAK_F32_MFMA_TFLOPS
+        peak = PEAK_BF16_MFMA_TFLOPS if ("bf16" in dom[0] and "split" not in dom[0]) else PEAK_F32_MFMA_TFLOPS
         traffic = None
         tp = os.path.join(ROOT, "profiles", "r01_d_pmc_hbm_traffic.json")
         if os.path.exists(tp):
@@ -193,7 +193,8 @@ def main():
                       else f"images/sec fwd+bwd {a.model} 3x{a.height}x{a.width} bs={a.batch} ({a.precision})",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.precision == "fp32" else "bf16-mfma convs (f32 accumulate, f32 tensors in HBM)", "data": "synthetic",
+            "dtype": {"fp32": "f32", "bf16": "bf16-mfma convs (f32 accumulate, f32 tensors in HBM)",
+                      "fp32_split": "f32-accurate 3-way bf16 split on bf16 MFMA (fwd/dgrad), f32 elsewhere"}[a.precision], "data": "synthetic",
             "config": {"workload": f"{a.model.upper() if a.model=='unet' else 'SegNet'}(3,12) train fwd+bwd+CE, per-GPU batch {a.batch} x 3x{a.height}x{a.width} fp32 "
                                    f"(BASELINE.json configs[1]{' x N ranks, RCCL grad all-reduce (configs[2])' if world > 1 else ''})",
                        "global_batch": world * a.batch, "parallelism": f"dp{world}", "timed_region": "zero_grad+forward+CE+backward"

@@ -79,6 +79,12 @@ int cvk_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
 int cvk_conv3x3_fwd_bf16(const float* x, const float* w, const float* bias, float* y, float* stats,
                          int N, int H, int W, int Cin, int Cout, int ldy, void* stream);
 
+/* EXPERIMENTAL fp32-accurate convolution on the bf16 matrix cores: exact 3-way bf16 split of every fp32 operand, six
+ * cross-term MFMAs with fp32 accumulation (csrc/conv_split.hip).  Contract of cvk_conv3x3_fwd, Cin % 32 == 0, Cout > 32.
+ * variant: 0 = 16-wide K slices, 1 = 32-wide. */
+int cvk_conv3x3_fwd_split(const float* x, const float* w, const float* bias, float* y, float* stats,
+                          int N, int H, int W, int Cin, int Cout, int ldy, int variant, void* stream);
+
 /* bf16-MFMA weight-grad (opt-in, Cout > 32): contract and workspace size of cvk_conv3x3_wgrad
  * (a workspace of cvk_conv3x3_wgrad_bf16_workspace_bytes bytes). */
 size_t cvk_conv3x3_wgrad_bf16_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout);

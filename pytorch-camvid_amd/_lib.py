@@ -35,6 +35,7 @@ SIGNATURES = {
     "cvk_conv3x3_fwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_wgrad_bf16_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
     "cvk_conv3x3_wgrad_bf16": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
+    "cvk_conv3x3_fwd_split": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_pack_weight_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "cvk_pack_weight_dgrad": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_wgrad_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),

@@ -93,6 +93,10 @@ def bf16_ok(R, k_ch):
     return R.bf16 and k_ch % 32 == 0
 
 
+def split_ok(R, k_ch, n_cols):
+    return R.split and k_ch % 32 == 0 and n_cols > 32
+
+
 def conv_kernel_name(kind, n_cols, k_ch=32):
     """Mirror of the tile dispatch in csrc/conv3x3.hip / wino.hip: the kernel-trace name."""
     if kind in ("bf16_fwd", "bf16_dgrad"):
@@ -157,7 +161,11 @@ class ConvBnRelu(Op):
         lib, s, src = R.lib, st.stream, self.src
         N, H, W, M, C, ldy = src.N, src.H, src.W, src.M, self.cout, pad4(self.cout)
         sp = stats.data_ptr() if stats is not None else None
-        if bf16_ok(R, src.ld):
+        if split_ok(R, src.ld, ldy):
+            _timed(R, f"k_conv3x3_igemm_split<{'128, 128' if ldy > 64 else '128, 64'}, 2, 2, {'true' if stats is not None else 'false'}, 16>", 18.0 * M * C * self.cin, lambda: check(
+                lib.cvk_conv3x3_fwd_split(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy, 0, s),
+                "cvk_conv3x3_fwd_split"))
+        elif bf16_ok(R, src.ld):
             _timed(R, conv_kernel_name("bf16_fwd", ldy), 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_fwd_bf16(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy, s),
                 "cvk_conv3x3_fwd_bf16"))
@@ -243,7 +251,11 @@ class ConvBnRelu(Op):
             wd = _empty(src.ld * 9 * ldy, dev)
             check(lib.cvk_pack_weight_dgrad(wc.data_ptr(), wd.data_ptr(), C, self.cin, src.ld, ldy, s), "cvk_pack_weight_dgrad")
             dX = _empty(M * src.ld, dev).view(N, H, W, src.ld)
-            if bf16_ok(R, ldy):
+            if split_ok(R, ldy, src.ld):
+                _timed(R, f"k_conv3x3_igemm_split<{'128, 128' if src.ld > 64 else '128, 64'}, 2, 2, false, 16>", 18.0 * M * C * self.cin, lambda: check(
+                    lib.cvk_conv3x3_fwd_split(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, 0, s),
+                    "cvk_conv3x3_fwd_split(dgrad)"))
+            elif bf16_ok(R, ldy):
                 _timed(R, conv_kernel_name("bf16_dgrad", src.ld), 18.0 * M * C * self.cin, lambda: check(
                     lib.cvk_conv3x3_fwd_bf16(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
                     "cvk_conv3x3_fwd_bf16(dgrad)"))
@@ -446,7 +458,8 @@ class Runner:
         self._ws = None
         self.grad_sync = None       # set by ddp.DataParallel
         self.wino = WINO_DEFAULT
-        self.bf16 = False           # opt-in: bf16-MFMA forward / data-grad convolutions (modules.set_conv_precision)
+        self.bf16 = False           # opt-in: bf16-MFMA convolutions (modules.set_conv_precision)
+        self.split = False          # opt-in, experimental: fp32-accurate 3-way bf16 split forward / data-grad
         self.prof = None            # list collecting (kernel name, flops, start event, end event) when bench.py profiles
         self._flat = [None, None]   # alternating flat gradient buffers (see grad_flat)
 

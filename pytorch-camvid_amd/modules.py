@@ -247,10 +247,14 @@ def set_conv_precision(module, precision):
     """"fp32" (default; exact-fp32 MFMA, Winograd where eligible) or "bf16": the convolutions (forward, data-grad,
     weight-grad; all layers except the 3-channel stem and the 12-channel head's data/weight-grad) round their operands
     to bf16 on the way to LDS and run on the bf16 matrix cores with fp32 accumulation (BASELINE.json configs[3]).
-    Tensors in HBM, BatchNorm, loss, gradients and optimizer state stay fp32.  Expect ~1e-2 relative differences."""
-    if precision not in ("fp32", "bf16"):
-        raise ValueError("precision must be 'fp32' or 'bf16'")
-    _state_of(module)["runner"].bf16 = precision == "bf16"
+    Tensors in HBM, BatchNorm, loss, gradients and optimizer state stay fp32.  Expect ~1e-2 relative differences.
+    "fp32_split" (experimental): forward / data-grad through conv_split.hip — every fp32 operand split exactly into three
+    bf16 pieces, six cross-term bf16 MFMAs with fp32 accumulation; agrees with the exact-fp32 kernels to fp32 rounding."""
+    if precision not in ("fp32", "bf16", "fp32_split"):
+        raise ValueError("precision must be 'fp32', 'bf16' or 'fp32_split'")
+    r = _state_of(module)["runner"]
+    r.bf16 = precision == "bf16"
+    r.split = precision == "fp32_split"
     return module
 
 

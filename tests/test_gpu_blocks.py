@@ -270,3 +270,31 @@ def test_bf16_mfma_conv_mode(shape):
     A.set_conv_precision(m, "fp32")
     with torch.no_grad():
         close(m(x.to(dev())), out_o, 1e-4, 3e-5 * max(1.0, float(np.abs(out_o).max())), "fp32 restored")
+
+
+def test_fp32_split_mode_is_fp32_accurate():
+    """Experimental fp32_split mode (exact 3-way bf16 split, six cross-term MFMAs): same tolerances as the exact-fp32
+    kernels against the fp64 oracle, and its error is of the same size as theirs."""
+    import pytorch_camvid_amd as A
+    from oracle import np_ops as O
+    n, ci, h, w, co = 2, 64, 12, 20, 128
+    torch.manual_seed(5)
+    m = A.BasicConv2d(ci, co)
+    p = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    x = torch.randn(n, ci, h, w); r = torch.randn(n, co, h, w)
+    out_o, cache = O.basic_conv_fwd(x.numpy(), p, "", train=True)
+    dx_o, g_o = O.basic_conv_bwd(r.numpy(), cache, p)
+    m = m.to(dev()).train()
+    errs = {}
+    for mode in ("fp32", "fp32_split"):
+        A.set_conv_precision(m, mode)
+        for q in m.parameters():
+            q.grad = None
+        xg = x.to(dev()).requires_grad_(True)
+        y = m(xg)
+        (y * r.to(dev())).sum().backward()
+        close(y, out_o, 1e-4, 3e-5 * max(1.0, float(np.abs(out_o).max())), f"fwd {mode}")
+        close(xg.grad, dx_o, 1e-3, 2e-4 * float(np.abs(dx_o).max()), f"dx {mode}")
+        errs[mode] = float(np.abs(y.detach().cpu().double().numpy() - out_o).max())
+    assert errs["fp32_split"] < 4 * errs["fp32"] + 1e-6, errs
+    A.set_conv_precision(m, "fp32")

@@ -55,6 +55,10 @@ def main():
         if "fwd" in which:
             t = timeit(lambda: check(lib.cvk_conv3x3_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, ci, co, ldy, s)))
             row += f" fwd {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["fwd"][0] += flops; tot["fwd"][1] += t
+        for var in (0, 1):
+            if f"split{var}" in which and ci % 32 == 0 and co > 32:
+                t = timeit(lambda: check(lib.cvk_conv3x3_fwd_split(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, ci, co, ldy, var, s)))
+                row += f" split{var} {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot[f"split{var}"][0] += flops; tot[f"split{var}"][1] += t
         if "bf16" in which and ci % 32 == 0:
             t = timeit(lambda: check(lib.cvk_conv3x3_fwd_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, ci, co, ldy, s)))
             row += f" bf16 {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["bf16"][0] += flops; tot["bf16"][1] += t
