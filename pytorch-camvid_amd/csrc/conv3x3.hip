@@ -129,17 +129,10 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm(
 
     auto mma_kk = [&](const float* arow, const float* brow, int kk) {
         f32x4 a[TM], b[TN];
-#if defined(CVK_ABLATE) && CVK_ABLATE == 6
-#pragma unroll
-        for (int t = 0; t < TM; ++t) { a[t] = f32x4{1.f + lane, 2.f, 3.f + kk, 4.f}; asm volatile("" : "+v"(a[t])); }
-#pragma unroll
-        for (int t = 0; t < TN; ++t) { b[t] = f32x4{1.f, 2.f + lane, 3.f, 4.f + kk}; asm volatile("" : "+v"(b[t])); }
-#else
 #pragma unroll
         for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const f32x4*>(arow + t * 32 * LDT + kk * 8);
 #pragma unroll
         for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const f32x4*>(brow + t * 32 * LDT + kk * 8);
-#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -164,28 +157,13 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm(
 #define CVK_KSTEP(cur, nxt, RA, RB)            \
     do {                                       \
         mma_kk(cur + aro, cur + bro, 0);       \
-        CVK_STORE(nxt, RA, RB);                \
-        CVK_LOAD(RA, RB);                      \
+        store_stage(nxt, RA, RB);              \
+        issue_loads(RA, RB);                   \
         mma_kk(cur + aro, cur + bro, 1);       \
         mma_kk(cur + aro, cur + bro, 2);       \
         mma_kk(cur + aro, cur + bro, 3);       \
-        CVK_SYNC();                            \
+        __syncthreads();                       \
     } while (0)
-#if defined(CVK_ABLATE) && (CVK_ABLATE == 3 || CVK_ABLATE == 4 || CVK_ABLATE == 6)
-#define CVK_STORE(n, a, b)
-#else
-#define CVK_STORE(n, a, b) store_stage(n, a, b)
-#endif
-#if defined(CVK_ABLATE) && (CVK_ABLATE == 2 || CVK_ABLATE == 4 || CVK_ABLATE == 6)
-#define CVK_LOAD(a, b)
-#else
-#define CVK_LOAD(a, b) issue_loads(a, b)
-#endif
-#if defined(CVK_ABLATE) && (CVK_ABLATE == 1 || CVK_ABLATE == 4 || CVK_ABLATE == 6)
-#define CVK_SYNC()
-#else
-#define CVK_SYNC() __syncthreads()
-#endif
     // straight-line double step (no branch inside: the compiler's vmcnt bookkeeping then leaves the newer register
     // stage in flight, `s_waitcnt vmcnt(8..15)`), odd tail peeled
     int ks = 0;
@@ -195,19 +173,6 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm(
     }
     if (ks < nK) CVK_KSTEP(buf0, buf1, ra0, rb0);
 
-#if defined(CVK_ABLATE) && (CVK_ABLATE == 5 || CVK_ABLATE == 6)
-    {   // timing experiment: no epilogue; keep the accumulators alive with an impossible store
-        float t = 0.f;
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t += acc[a][b][r];
-        if (t == 12345.678f) Y[0] = t;
-        return;
-    }
-#endif
     // ---- epilogue: + bias, store NHWC, fused BatchNorm statistics partials
     // C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
     const int rowbase = m0 + wm * TM * 32;

@@ -184,30 +184,15 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino(
     const int rowbase = m0 + wm * TM * 32;
     const bool full = (m0 + BM <= Mt) && (n0 + BN <= ldm);
 
-#if defined(CVK_ABLATE) && (CVK_ABLATE == 12 || CVK_ABLATE == 15)
-#define WQB()
-#else
-#define WQB() issue_qb()
-#endif
-#if defined(CVK_ABLATE) && (CVK_ABLATE == 13 || CVK_ABLATE == 15)
-#define WP(r)
-#else
-#define WP(r) issue_p(r)
-#endif
-#if defined(CVK_ABLATE) && (CVK_ABLATE == 14 || CVK_ABLATE == 15)
-#define WST(n, r)
-#else
-#define WST(n, r) store_stage(n, r)
-#endif
     // q / weight registers are re-issued right after the LDS store that consumed them, so they too are in flight for a
     // whole K step (an earlier version issued them at the top of the step that stores them: +20 % time in vmcnt waits)
 #define CVK_WINO_STEP(cur, nxt, RP_)                  \
     do {                                              \
         mma_kk(cur + aro, cur + bro, 0);              \
         mma_kk(cur + aro, cur + bro, 1);              \
-        WST(nxt, RP_);               /* slice ks+1 */ \
-        WQB();                       /* slice ks+2 */ \
-        WP(RP_);                     /* slice ks+3 */ \
+        store_stage(nxt, RP_);       /* slice ks+1 */ \
+        issue_qb();                  /* slice ks+2 */ \
+        issue_p(RP_);                /* slice ks+3 */ \
         mma_kk(cur + aro, cur + bro, 2);              \
         mma_kk(cur + aro, cur + bro, 3);              \
         __syncthreads();                              \
@@ -219,19 +204,6 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino(
             CVK_WINO_STEP(buf1, buf0, rp1);
         }
         // flush M_xi (the next xi's slices are already in flight / in LDS) and restart the accumulators
-#if defined(CVK_ABLATE) && CVK_ABLATE == 11
-        if (xi >= 0) {   // timing experiment: no flush stores
-            float t_ = 0.f;
-#pragma unroll
-            for (int a_ = 0; a_ < TM; ++a_)
-#pragma unroll
-                for (int b_ = 0; b_ < TN; ++b_)
-#pragma unroll
-                    for (int r_ = 0; r_ < 16; ++r_) { t_ += acc[a_][b_][r_]; acc[a_][b_][r_] = 0.f; }
-            if (t_ == 12345.678f) Mo[0] = t_;
-            continue;
-        }
-#endif
         float* out = Mo + (size_t)xi * Mt * ldm;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
