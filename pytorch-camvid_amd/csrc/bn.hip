@@ -309,8 +309,10 @@ extern "C" int cvk_bn_relu_apply(const float* y, int ldy, const float* scale, co
 
 extern "C" int cvk_bn_bwd_blocks(int M) {
     if (M <= 0) return 0;
-    const int pb = cvk_cdiv(M, 16);
-    return pb < 512 ? pb : 512;     // 2 blocks per CU keep the stream bandwidth-bound; fewer partial rows keep the fp64 finalize short
+    int pb = cvk_cdiv(M, 16);
+    pb = pb < 512 ? pb : 512;       // 2 blocks per CU keep the stream bandwidth-bound; fewer partial rows keep the fp64 finalize short
+    const int rows = cvk_cdiv(M, pb);
+    return cvk_cdiv(M, rows);       // exactly the number of row blocks the kernels launch: every partial row gets written
 }
 
 static int bn_bwd_launch(int mode, cvk_view dout, const float* y, int ldy, const float* scale, const float* shift,
@@ -327,12 +329,6 @@ static int bn_bwd_launch(int mode, cvk_view dout, const float* y, int ldy, const
     const int cchunk = v4 ? 1024 : 256;
     dim3 grid(nb, cvk_cdiv(C, cchunk));
     hipStream_t s = (hipStream_t)stream;
-    if (part != nullptr && nb < PB) {
-        // keep the [PB][C] contract: rows [nb, PB) must read as zero
-        const int planes = mode == 0 ? 2 : 1;
-        for (int pl = 0; pl < planes; ++pl)
-            (void)hipMemsetAsync(part + ((size_t)pl * PB + nb) * C, 0, (size_t)(PB - nb) * C * sizeof(float), s);
-    }
 #define CVK_BWD(V_, MODE_)                                                                                              \
     hipLaunchKernelGGL((k_bn_bwd<V_, MODE_>), grid, dim3(256), 0, s, dout.ptr, dm, y, ldy, scale, shift, mean, rstd, dgamma, \
                        dbeta, dy, ld_dy, part, M, C, rows, PB, cchunk, use_batch_stats)
