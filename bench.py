@@ -84,6 +84,11 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # CVK_REHEARSAL=1: ranks share the visible GPUs and talk over gloo — a plumbing check of the N>1 path on a 1-GPU
+    # box (its number is meaningless and is labelled as such); the real thing is one rank per GPU over RCCL.
+    rehearsal = os.environ.get("CVK_REHEARSAL") == "1"
+    if rehearsal:
+        local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import pytorch_camvid_amd as A
@@ -91,7 +96,10 @@ def main():
     from pytorch_camvid_amd.modules import runner_of
 
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)     # RCCL
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)     # RCCL
 
     torch.manual_seed(0)                                    # identical init on every rank (also broadcast below)
     net = A.get_model(a.model, 3, 12).to(dev).train()
@@ -194,7 +202,7 @@ def main():
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16": "bf16-mfma convs (f32 accumulate, f32 tensors in HBM)",
-                      "fp32_split": "f32-accurate 3-way bf16 split on bf16 MFMA (fwd/dgrad), f32 elsewhere"}[a.precision], "data": "synthetic",
+                      "fp32_split": "f32-accurate 3-way bf16 split on bf16 MFMA (fwd/dgrad), f32 elsewhere"}[a.precision], "data": "synthetic" + (" (REHEARSAL: ranks share a GPU over gloo — not a measurement)" if rehearsal else ""),
             "config": {"workload": f"{a.model.upper() if a.model=='unet' else 'SegNet'}(3,12) train fwd+bwd+CE, per-GPU batch {a.batch} x 3x{a.height}x{a.width} fp32 "
                                    f"(BASELINE.json configs[1]{' x N ranks, RCCL grad all-reduce (configs[2])' if world > 1 else ''})",
                        "global_batch": world * a.batch, "parallelism": f"dp{world}", "timed_region": "zero_grad+forward+CE+backward"
