@@ -48,7 +48,8 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm(
     const int m0 = (tile / tilesN) * BM;
     const int n0 = (tile % tilesN) * BN;
 
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, M * Cin * 4, 0x00020000);
+    const int pb = max(m0 - W - 1, 0);    // first pixel any tap of this tile can touch: base of the input window
+    const __amdgpu_buffer_rsrc_t xr = window_rsrc(X, (size_t)pb * Cin, (size_t)M * Cin);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, Cout * Ktot * 4, 0x00020000);
 
     // ---- per-thread staging coordinates (fixed for the whole K loop)
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm(
             }
         }
         amask[i] = mask;
-        aoff[i] = (unsigned)(m < M ? m : 0) * (unsigned)Cin * 4u + (CIN32 ? kv * 16u : 0u);
+        aoff[i] = (unsigned)(m < M ? m - pb : 0) * (unsigned)Cin * 4u + (CIN32 ? kv * 16u : 0u);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -262,8 +263,9 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
     const int mbeg = split * chunk;
     const int mend = min(M, mbeg + chunk);
 
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, M * Cin * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)DY, 0, M * ld_dy * 4, 0x00020000);
+    const int pbx = max(mbeg - W - 1, 0);   // operand windows start at this pixel range (see window_rsrc)
+    const __amdgpu_buffer_rsrc_t xr = window_rsrc(X, (size_t)pbx * Cin, (size_t)M * Cin);
+    const __amdgpu_buffer_rsrc_t dr = window_rsrc(DY, (size_t)mbeg * ld_dy, (size_t)M * ld_dy);
 
     const int cva = tid % VA, pra = tid / VA;
     const int cvb = tid % VB, prb = tid / VB;
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int m = lm + pra + i * RPA;
-            ra[i] = buf_load16(dr, oob_unless(aok & (m < mend), ((unsigned)m * (unsigned)ld_dy + (unsigned)coA) * 4u));
+            ra[i] = buf_load16(dr, oob_unless(aok & (m < mend), ((unsigned)(m - mbeg) * (unsigned)ld_dy + (unsigned)coA) * 4u));
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad(
             const int y = (int)divW.div(brem[i]);
             const int x = (int)brem[i] - y * W;
             const bool ok = bok & (m < mend) & ((unsigned)(y + dyB) < (unsigned)H) & ((unsigned)(x + dxB) < (unsigned)W);   // '&': no short-circuit branches
-            rb[i] = buf_load16(xr, oob_unless(ok, (unsigned)m * (unsigned)Cin * 4u + shiftB));
+            rb[i] = buf_load16(xr, oob_unless(ok, (unsigned)(m - pbx) * (unsigned)Cin * 4u + shiftB));
             brem[i] += BK;
             if (HW >= BK) { if (brem[i] >= (unsigned)HW) brem[i] -= (unsigned)HW; }
             else brem[i] %= (unsigned)HW;
@@ -413,7 +415,8 @@ extern "C" int cvk_conv3x3_fwd(const float* x, const float* w, const float* bias
     CVK_CHECK_ARG(ldy >= Cout, "cvk_conv3x3_fwd: ldy=%d < Cout=%d", ldy, Cout);
     CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(w), "cvk_conv3x3_fwd: x and w must be 16-byte aligned");
     CVK_CHECK_ARG((long)N * H * W < (1L << 31) - 512 && (long)H * W * Cin < (1L << 31), "cvk_conv3x3_fwd: tensor too large for 32-bit pixel indices");
-    CVK_CHECK_ARG((long)N * H * W * Cin * 4 < (1L << 31) && (long)Cout * 9 * Cin * 4 < (1L << 31), "cvk_conv3x3_fwd: input or weight tensor exceeds the 2 GiB buffer-addressing limit; split the batch");
+    // the input may exceed 2 GiB: each workgroup addresses it through its own window (window_rsrc) of <= 256 + 2W + 2 pixels
+    CVK_CHECK_ARG((long)(2 * W + 260) * Cin * 4 < (1L << 31) && (long)Cout * 9 * Cin * 4 < (1L << 31), "cvk_conv3x3_fwd: a tile's input window or the weight tensor exceeds the 2 GiB buffer-addressing limit");
     const int M = N * H * W, Ktot = 9 * Cin, P = cvk_cdiv(M, CVK_STAT_ROWS);
     const bool c32 = Cin % 32 == 0;
     hipStream_t s = (hipStream_t)stream;
@@ -469,10 +472,12 @@ extern "C" int cvk_conv3x3_wgrad(const float* x, const float* dy, float* dw, int
     CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin_pad >= Cin, "cvk_conv3x3_wgrad: bad shape");
     CVK_CHECK_ARG(Cin_pad % 4 == 0 && ld_dy % 4 == 0 && ld_dy >= Cout, "cvk_conv3x3_wgrad: Cin_pad=%d and ld_dy=%d must be multiples of 4, ld_dy >= Cout", Cin_pad, ld_dy);
     CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(dy) && cvk_aligned16(workspace), "cvk_conv3x3_wgrad: pointers must be 16-byte aligned");
-    CVK_CHECK_ARG((long)N * H * W * Cin_pad * 4 < (1L << 31) && (long)N * H * W * ld_dy * 4 < (1L << 31), "cvk_conv3x3_wgrad: x or dy exceeds the 2 GiB buffer-addressing limit; split the batch");
+    CVK_CHECK_ARG((long)N * H * W < (1L << 31) - 512, "cvk_conv3x3_wgrad: tensor too large for 32-bit pixel indices");
     CVK_CHECK_ARG((long)H * W * W < (1L << 32), "cvk_conv3x3_wgrad: frame too large for the multiply-high row/column split");
     const int M = N * H * W, Ktot = 9 * Cin_pad;
     const WgradPlan p = plan_wgrad(M, Cin_pad, Cout);
+    // x and dy may exceed 2 GiB: a workgroup addresses only its own pixel range (window_rsrc)
+    CVK_CHECK_ARG((long)(p.chunk + 2 * W + 2 + 2 * BK) * (Cin_pad > ld_dy ? Cin_pad : ld_dy) * 4 < (1L << 31), "cvk_conv3x3_wgrad: one pixel range exceeds the 2 GiB buffer-addressing limit");
     const size_t need = (size_t)p.splits * Cout * Ktot * sizeof(float);
     if (workspace_bytes < need) {
         cvk_set_error("cvk_conv3x3_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm_bf16(
     const int m0 = (tile / tilesN) * BM;
     const int n0 = (tile % tilesN) * BN;
 
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, M * Cin * 4, 0x00020000);
+    const int pb = max(m0 - W - 1, 0);    // base of this tile's input window (window_rsrc)
+    const __amdgpu_buffer_rsrc_t xr = window_rsrc(X, (size_t)pb * Cin, (size_t)M * Cin);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, Cout * Ktot * 4, 0x00020000);
 
     const int kv = tid & 7, r0 = tid >> 3;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm_bf16(
             }
         }
         amask[i] = mask;
-        aoff[i] = (unsigned)(m < M ? m : 0) * (unsigned)Cin * 4u + kv * 16u;
+        aoff[i] = (unsigned)(m < M ? m - pb : 0) * (unsigned)Cin * 4u + kv * 16u;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -254,8 +255,9 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad_bf16(
     const int mbeg = split * chunk;
     const int mend = min(M, mbeg + chunk);
 
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, M * Cin * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)DY, 0, M * ld_dy * 4, 0x00020000);
+    const int pbx = max(mbeg - W - 1, 0);   // operand windows start at this pixel range (window_rsrc)
+    const __amdgpu_buffer_rsrc_t xr = window_rsrc(X, (size_t)pbx * Cin, (size_t)M * Cin);
+    const __amdgpu_buffer_rsrc_t dr = window_rsrc(DY, (size_t)mbeg * ld_dy, (size_t)M * ld_dy);
 
     const int cva = tid % VA, pra = tid / VA;
     const int cvb = tid % VB, prb = tid / VB;
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad_bf16(
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int m = lm + pra + i * RPA;
-            ra[i] = buf_load16(dr, oob_unless(aok & (m < mend), ((unsigned)m * (unsigned)ld_dy + (unsigned)coA) * 4u));
+            ra[i] = buf_load16(dr, oob_unless(aok & (m < mend), ((unsigned)(m - mbeg) * (unsigned)ld_dy + (unsigned)coA) * 4u));
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_wgrad_bf16(
             const int y = (int)divW.div(brem[i]);
             const int x = (int)brem[i] - y * W;
             const bool ok = bok & (m < mend) & ((unsigned)(y + dyB) < (unsigned)H) & ((unsigned)(x + dxB) < (unsigned)W);
-            rb[i] = buf_load16(xr, oob_unless(ok, (unsigned)m * (unsigned)Cin * 4u + shiftB));
+            rb[i] = buf_load16(xr, oob_unless(ok, (unsigned)(m - pbx) * (unsigned)Cin * 4u + shiftB));
             brem[i] += BK;
             if (HW >= BK) { if (brem[i] >= (unsigned)HW) brem[i] -= (unsigned)HW; }
             else brem[i] %= (unsigned)HW;
@@ -380,7 +382,7 @@ extern "C" int cvk_conv3x3_fwd_bf16(const float* x, const float* w, const float*
     CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout, "cvk_conv3x3_fwd_bf16: bad shape");
     CVK_CHECK_ARG(Cin > 0 && Cin % 32 == 0, "cvk_conv3x3_fwd_bf16: Cin=%d must be a multiple of 32 (use cvk_conv3x3_fwd otherwise)", Cin);
     CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(w), "cvk_conv3x3_fwd_bf16: x and w must be 16-byte aligned");
-    CVK_CHECK_ARG((long)N * H * W * Cin * 4 < (1L << 31) && (long)Cout * 9 * Cin * 4 < (1L << 31), "cvk_conv3x3_fwd_bf16: tensor exceeds the 2 GiB buffer-addressing limit; split the batch");
+    CVK_CHECK_ARG((long)(2 * W + 260) * Cin * 4 < (1L << 31) && (long)Cout * 9 * Cin * 4 < (1L << 31), "cvk_conv3x3_fwd_bf16: a tile's input window or the weight tensor exceeds the 2 GiB buffer-addressing limit");
     const int M = N * H * W, Ktot = 9 * Cin, P = cvk_cdiv(M, CVK_STAT_ROWS);
     hipStream_t s = (hipStream_t)stream;
 #define CVK_BF_LAUNCH(BM_, BN_, WM_, WN_)                                                                                  \
@@ -425,10 +427,11 @@ extern "C" int cvk_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw
     CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 32 && Cin_pad >= Cin, "cvk_conv3x3_wgrad_bf16: bad shape (needs Cout > 32; use cvk_conv3x3_wgrad otherwise)");
     CVK_CHECK_ARG(Cin_pad % 4 == 0 && ld_dy % 4 == 0 && ld_dy >= Cout, "cvk_conv3x3_wgrad_bf16: Cin_pad and ld_dy must be multiples of 4, ld_dy >= Cout");
     CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(dy) && cvk_aligned16(workspace), "cvk_conv3x3_wgrad_bf16: pointers must be 16-byte aligned");
-    CVK_CHECK_ARG((long)N * H * W * Cin_pad * 4 < (1L << 31) && (long)N * H * W * ld_dy * 4 < (1L << 31), "cvk_conv3x3_wgrad_bf16: x or dy exceeds the 2 GiB buffer-addressing limit; split the batch");
+    CVK_CHECK_ARG((long)N * H * W < (1L << 31) - 512, "cvk_conv3x3_wgrad_bf16: tensor too large for 32-bit pixel indices");
     CVK_CHECK_ARG((long)H * W * W < (1L << 32), "cvk_conv3x3_wgrad_bf16: frame too large for the multiply-high row/column split");
     const int M = N * H * W, Ktot = 9 * Cin_pad;
     const WgradPlan p = plan_wgrad_bf16(M, Cin_pad, Cout);
+    CVK_CHECK_ARG((long)(p.chunk + 2 * W + 2 + 2 * BK) * (Cin_pad > ld_dy ? Cin_pad : ld_dy) * 4 < (1L << 31), "cvk_conv3x3_wgrad_bf16: one pixel range exceeds the 2 GiB buffer-addressing limit");
     const size_t need = (size_t)p.splits * Cout * Ktot * sizeof(float);
     if (workspace_bytes < need) {
         cvk_set_error("cvk_conv3x3_wgrad_bf16: workspace %zu < %zu bytes", workspace_bytes, need);

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm_split(
     const int m0 = (tile / tilesN) * BM;
     const int n0 = (tile % tilesN) * BN;
 
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, M * Cin * 4, 0x00020000);
+    const int pb = max(m0 - W - 1, 0);    // base of this tile's input window (window_rsrc)
+    const __amdgpu_buffer_rsrc_t xr = window_rsrc(X, (size_t)pb * Cin, (size_t)M * Cin);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, Cout * Ktot * 4, 0x00020000);
 
     const int kv = tid % VPR, r0 = tid / VPR;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k_conv3x3_igemm_split(
             }
         }
         amask[i] = mask;
-        aoff[i] = (unsigned)(m < M ? m : 0) * (unsigned)Cin * 4u + kv * 16u;
+        aoff[i] = (unsigned)(m < M ? m - pb : 0) * (unsigned)Cin * 4u + kv * 16u;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -237,7 +238,7 @@ extern "C" int cvk_conv3x3_fwd_split(const float* x, const float* w, const float
     CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout, "cvk_conv3x3_fwd_split: bad shape");
     CVK_CHECK_ARG(Cin > 0 && Cin % 32 == 0, "cvk_conv3x3_fwd_split: Cin=%d must be a multiple of 32", Cin);
     CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(w), "cvk_conv3x3_fwd_split: x and w must be 16-byte aligned");
-    CVK_CHECK_ARG((long)N * H * W * Cin * 4 < (1L << 31) && (long)Cout * 9 * Cin * 4 < (1L << 31), "cvk_conv3x3_fwd_split: tensor exceeds the 2 GiB buffer-addressing limit");
+    CVK_CHECK_ARG((long)(2 * W + 260) * Cin * 4 < (1L << 31) && (long)Cout * 9 * Cin * 4 < (1L << 31), "cvk_conv3x3_fwd_split: a tile's input window or the weight tensor exceeds the 2 GiB buffer-addressing limit");
     const int M = N * H * W, Ktot = 9 * Cin, P = cvk_cdiv(M, CVK_STAT_ROWS);
     hipStream_t s = (hipStream_t)stream;
 #define CVK_SP_LAUNCH(BM_, BN_, WM_, WN_, BKS_)                                                                            \

@@ -6,12 +6,20 @@ namespace {
 
 constexpr int BK = 32;        // K slice per LDS stage (floats)
 constexpr int LDT = BK + 4;   // padded LDS row: 144 B -> the 16 rows of a ds_read_b128 lane group hit 16 distinct slots
-constexpr unsigned OOB = 0x80000000u;  // buffer offset beyond num_records (< 2 GiB by contract): the load returns 0
+constexpr unsigned OOB = 0x80000000u;  // buffer offset beyond num_records (< 2 GiB by construction): the load returns 0
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
+// Buffer resource over the tail [first, total) (in floats) of a tensor.  Every workgroup addresses its operand through a
+// window that starts just before the first pixel it can touch, so 32-bit byte offsets only have to span one workgroup's
+// working set and tensors may be arbitrarily larger than the 2 GiB a single resource can address.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t window_rsrc(const float* base, size_t first, size_t total) {
+    const size_t bytes = first < total ? (total - first) * 4 : 0;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + first), 0, (int)(bytes < 0x7FFFFFFFu ? bytes : 0x7FFFFFFFu), 0x00020000);
 }
 
 // Exact unsigned division by a runtime constant d >= 1 without branches: q = floor(t / d) for t*d < 2^32.

@@ -70,7 +70,9 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino(
     const int K3 = 3 * Cin;
     const int nK = K3 / BK;   // even by contract (Cin % 64 == 0)
 
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, Mpix * Cin * 4, 0x00020000);
+    // input window (window_rsrc): starts one image row + one pixel before the first column pair of this tile
+    const int pb = max((m0 / Wt) * W + 2 * (m0 % Wt) - W - 1, 0);
+    const __amdgpu_buffer_rsrc_t xr = window_rsrc(X, (size_t)pb * Cin, (size_t)Mpix * Cin);
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, 4 * Cout * K3 * 4, 0x00020000);
 
     const int kv = tid & 7, r0 = tid >> 3;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino(
 #pragma unroll
             for (int o = 0; o < 4; ++o)
                 if ((unsigned)(2 * xt + o - 1) < (unsigned)W) v |= 8u << o;
-            v |= (unsigned)((n * H + y) * W + 2 * xt) * (unsigned)Cin * 4u;
+            v |= (unsigned)((n * H + y) * W + 2 * xt - pb) * (unsigned)Cin * 4u;
         }
         arow[i] = v;
     }
@@ -360,8 +362,11 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
     const int sbeg = split * chunk;
     const int send = min(nslices, sbeg + chunk);
 
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, Mpix * Cin * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t dr_ = __builtin_amdgcn_make_buffer_rsrc((void*)DY, 0, Mpix * ld_dy * 4, 0x00020000);
+    const FastDiv divS((unsigned)S), divH((unsigned)H), divWt((unsigned)Wt);
+    // operand windows (window_rsrc) start two image rows before the first row of this workgroup's slice range
+    const int rowb = max((int)divS.div((unsigned)sbeg) * R - 2, 0);
+    const __amdgpu_buffer_rsrc_t xr = window_rsrc(X, (size_t)rowb * W * Cin, (size_t)Mpix * Cin);
+    const __amdgpu_buffer_rsrc_t dr_ = window_rsrc(DY, (size_t)rowb * W * ld_dy, (size_t)Mpix * ld_dy);
 
     const int cva = tid % VA, pra = tid / VA;
     const int cvb = tid % VB, prb = tid / VB;
@@ -377,7 +382,6 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
     const float sgB = xi == 1 ? 1.f : -1.f;
     const float sgA = xi == 2 ? -1.f : 1.f;           // E = a0 + sgA*a1 with a0 = dy0 (off for xi 3), a1 = dy1 (off for xi 0)
     const bool useA0 = xi != 3, useA1 = xi != 0;
-    const FastDiv divS((unsigned)S), divH((unsigned)H), divWt((unsigned)Wt);
 
     // per-thread tile constants inside a slice: row delta, column pair, and the constant part of the byte offsets; the
     // slice adds wave-uniform terms only, so a load costs ~5 VALU (offset add, two range compares, predicate, OOB select)
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
         const bool live = sl < send;
         const int xlim = Wt - xbase, rlim = NH - row0;                       // uniform validity limits
         const int acol = which;                                               // dy column 2xt + which
-        const unsigned sA = (unsigned)((row0 * W + 2 * xbase + acol) * ld_dy) * 4u;
+        const unsigned sA = (unsigned)(((row0 - rowb) * W + 2 * xbase + acol) * ld_dy) * 4u;
         const bool aon = aok & live & (which ? useA1 : useA0);
         const int wlimA = W - 2 * xbase - acol;                               // need 2*axt < wlimA
 #pragma unroll
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
             ar[i] = buf_load16(dr_, oob_unless(ok, aconst[i] + sA));
         }
         const int o = which ? qo : po;
-        const unsigned sB = (unsigned)((row0 * W + 2 * xbase + o) * Cin) * 4u;
+        const unsigned sB = (unsigned)(((row0 - rowb) * W + 2 * xbase + o) * Cin) * 4u;
         const int xoff = 2 * xbase + o;
         const bool bon = bok & live;
         const bool rowok_uniform = (unsigned)(y0 + rB - 1) < (unsigned)H;    // exact when the slice is one image row
@@ -601,7 +605,9 @@ extern "C" int cvk_conv3x3_wino_gemm(const float* x, const float* U, float* Mo, 
     CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldm >= Cout && ldm % 4 == 0, "cvk_conv3x3_wino_gemm: bad shape");
     CVK_CHECK_ARG(Cin > 0 && Cin % 64 == 0, "cvk_conv3x3_wino_gemm: Cin=%d must be a multiple of 64 (use cvk_conv3x3_fwd otherwise)", Cin);
     CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(U) && cvk_aligned16(Mo), "cvk_conv3x3_wino_gemm: pointers must be 16-byte aligned");
-    CVK_CHECK_ARG((long)N * H * W * Cin * 4 < (1L << 31) && (long)4 * Cout * 3 * Cin * 4 < (1L << 31), "cvk_conv3x3_wino_gemm: tensor exceeds the 2 GiB buffer-addressing limit; split the batch");
+    CVK_CHECK_ARG((long)N * H * W < (1L << 31) - 512, "cvk_conv3x3_wino_gemm: tensor too large for 32-bit pixel indices");
+    // the input may exceed 2 GiB: each workgroup addresses it through its own window (window_rsrc) of <= 256 + 2W + 4 pixels
+    CVK_CHECK_ARG((long)(2 * W + 264) * Cin * 4 < (1L << 31) && (long)4 * Cout * 3 * Cin * 4 < (1L << 31), "cvk_conv3x3_wino_gemm: a tile's input window or the weight tensor exceeds the 2 GiB buffer-addressing limit");
     const int Wt = (W + 1) / 2, Mt = N * H * Wt, Mpix = N * H * W, ldy = ldm;
     hipStream_t s = (hipStream_t)stream;
     // tiles are dealt to the 256 CUs in whole rounds as four-index blocks; the remainder (and, for deep layers with few
@@ -651,11 +657,15 @@ extern "C" int cvk_conv3x3_wgrad_wino(const float* x, const float* dy, float* dw
     CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin_pad >= Cin, "cvk_conv3x3_wgrad_wino: bad shape");
     CVK_CHECK_ARG(Cin_pad % 4 == 0 && ld_dy % 4 == 0 && ld_dy >= Cout, "cvk_conv3x3_wgrad_wino: Cin_pad and ld_dy must be multiples of 4, ld_dy >= Cout");
     CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(dy) && cvk_aligned16(workspace), "cvk_conv3x3_wgrad_wino: pointers must be 16-byte aligned");
-    CVK_CHECK_ARG((long)N * H * W * Cin_pad * 4 < (1L << 31) && (long)N * H * W * ld_dy * 4 < (1L << 31), "cvk_conv3x3_wgrad_wino: x or dy exceeds the 2 GiB buffer-addressing limit; split the batch");
+    CVK_CHECK_ARG((long)N * H * W < (1L << 31) - 512, "cvk_conv3x3_wgrad_wino: tensor too large for 32-bit pixel indices");
     const int Wt = (W + 1) / 2, Mt = N * H * Wt, Mpix = N * H * W, K3 = 3 * Cin_pad;
     CVK_CHECK_ARG((long)N * H * H < (1L << 32) && (long)N * H * Wt < (1L << 31), "cvk_conv3x3_wgrad_wino: frame too large for the multiply-high coordinate split");
     const WWPlan p = plan_wgrad_wino(N * H, Wt, Cin_pad, Cout);
     (void)Mt;
+    {   // x and dy may exceed 2 GiB: a workgroup addresses only the image rows of its own slice range (window_rsrc)
+        const long rows = (p.S > 1 ? p.chunk / p.S + 2 : (long)p.chunk * p.R) + 4;
+        CVK_CHECK_ARG(rows * W * (Cin_pad > ld_dy ? Cin_pad : ld_dy) * 4 < (1L << 31), "cvk_conv3x3_wgrad_wino: one slice range exceeds the 2 GiB buffer-addressing limit");
+    }
     const size_t need = (size_t)p.splits * 4 * Cout * K3 * sizeof(float);
     if (workspace_bytes < need) {
         cvk_set_error("cvk_conv3x3_wgrad_wino: workspace %zu < %zu bytes", workspace_bytes, need);

@@ -1,0 +1,154 @@
+"""Maximum sizes: tensors beyond the 2 GiB a single buffer resource can address (the 288 GB of an MI355X make batches
+of 50-100 full frames per GPU ordinary).  Every conv workgroup addresses its operands through a window that starts at
+its own pixel range (csrc/conv_tile.h window_rsrc), so the only size contract left is N*H*W < 2^31 pixels.
+The oracle cannot run at these sizes in seconds; the checks are the size-independent properties the domain offers:
+  * the rows of a convolution are independent  -> a call on the whole batch == calls on its image chunks, bit for bit;
+  * the weight gradient is a sum over pixels   -> whole batch == sum of the chunks (summation order differs: 2e-4);
+  * the two independent implementations (direct implicit GEMM, Winograd F(2,3)) agree on the whole batch.
+Small sizes of the same kernels are pinned to the reference goldens / the fp64 oracle in test_gpu_blocks.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TWO_GIB = 1 << 31
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _chunks(n, k):
+    return [(i, min(n, i + k)) for i in range(0, n, k)]
+
+
+@pytest.mark.parametrize("cfg", [dict(N=50, C=64, Co=64, wino=True), dict(N=100, C=32, Co=32, wino=False)])
+def test_conv_raw_abi_beyond_2gib(cfg):
+    from pytorch_camvid_amd import _lib
+    from pytorch_camvid_amd._lib import check
+    lib = _lib.load()
+    N, C, Co, wino = cfg["N"], cfg["C"], cfg["Co"], cfg["wino"]
+    H, W = 360, 480
+    assert N * H * W * C * 4 > TWO_GIB
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(N, H, W, C, device=dev(), generator=g)
+    dy = torch.randn(N, H, W, Co, device=dev(), generator=g)
+    w = torch.randn(Co, 3, 3, C, device=dev(), generator=g) * 0.05          # KRSC
+    bias = torch.randn(Co, device=dev(), generator=g)
+    P = (N * H * W + 63) // 64
+
+    def fwd(xs, n):
+        y = torch.empty(n, H, W, Co, device=dev())
+        p = (n * H * W + 63) // 64
+        st = torch.empty(2 * p * Co, device=dev())
+        if wino:
+            U = torch.empty(4 * Co * 3 * C, device=dev())
+            check(lib.cvk_wino_weight_transform(w.data_ptr(), U.data_ptr(), Co, C, s))
+            Mo = torch.empty(lib.cvk_conv3x3_wino_workspace_bytes(n, H, W, Co) // 4, device=dev())
+            check(lib.cvk_conv3x3_wino_gemm(xs.data_ptr(), U.data_ptr(), Mo.data_ptr(), n, H, W, C, Co, Co, s))
+            check(lib.cvk_wino_output(Mo.data_ptr(), bias.data_ptr(), y.data_ptr(), st.data_ptr(), n, H, W, Co, Co, s))
+        else:
+            check(lib.cvk_conv3x3_fwd(xs.data_ptr(), w.data_ptr(), bias.data_ptr(), y.data_ptr(), st.data_ptr(), n, H, W, C, Co, Co, s))
+        return y, st
+
+    def wgrad(xs, dys, n):
+        dw = torch.empty(Co, 3, 3, C, device=dev())
+        f_ws, f = (lib.cvk_conv3x3_wgrad_wino_workspace_bytes, lib.cvk_conv3x3_wgrad_wino) if wino else \
+                  (lib.cvk_conv3x3_wgrad_workspace_bytes, lib.cvk_conv3x3_wgrad)
+        wsb = f_ws(n, H, W, C, Co)
+        ws = torch.empty(wsb // 4, device=dev())
+        check(f(xs.data_ptr(), dys.data_ptr(), dw.data_ptr(), n, H, W, C, C, Co, Co, ws.data_ptr(), wsb, s))
+        return dw
+
+    y, st = fwd(x, N)
+    k = N // 5                                   # chunk pixel counts are multiples of 64: statistics granules line up
+    dw_sum = torch.zeros(Co, 3, 3, C, device=dev(), dtype=torch.float64)
+    for (a, b) in _chunks(N, k):
+        yc, stc = fwd(x[a:b], b - a)
+        assert torch.equal(yc, y[a:b]), f"forward rows of images {a}:{b} differ from the whole-batch call"
+        pc = (b - a) * H * W // 64
+        p0 = a * H * W // 64
+        assert torch.equal(stc[:pc * Co], st[p0 * Co:(p0 + pc) * Co])                       # per-granule sums
+        assert torch.equal(stc[pc * Co:], st[(P + p0) * Co:(P + p0 + pc) * Co])            # per-granule M2
+        dw_sum += wgrad(x[a:b], dy[a:b], b - a).double()
+        del yc, stc
+    del y, st
+    dw = wgrad(x, dy, N).double()
+    err = (dw - dw_sum).abs().max().item() / dw_sum.abs().max().item()
+    assert err < 2e-4, err
+    # last image against torch's own convolution of that image (MIOpen, fp32): the window of the last tiles is right
+    yl, _ = fwd(x[N - 1:], 1)
+    ref = torch.nn.functional.conv2d(x[N - 1:].permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1)
+    assert (yl - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+    torch.cuda.empty_cache()
+
+
+def test_block_direct_and_winograd_agree_beyond_2gib():
+    """BasicConv2d(64, 64), batch 50 x 360x480 (2.2 GB per activation): train-mode forward/backward through the engine
+    with the Winograd kernels and with the direct kernels; eval-mode rows are independent of the batch."""
+    import pytorch_camvid_amd as A
+    from pytorch_camvid_amd.modules import runner_of
+    N, C, H, W = 50, 64, 360, 480
+    assert N * C * H * W * 4 > TWO_GIB
+    torch.manual_seed(1)
+    m = A.BasicConv2d(C, C).to(dev()).train()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(N, C, H, W, device=dev(), generator=g)
+    r = torch.randn(N, C, H, W, device=dev(), generator=g)
+    res = {}
+    for wino in (True, False):
+        runner_of(m).wino = wino
+        for q in m.parameters():
+            q.grad = None
+        xg = x.detach().requires_grad_(True)
+        y = m(xg)
+        (y * r).sum().backward()
+        res[wino] = (y.detach(), xg.grad, m.conv[0].weight.grad.clone(), m.conv[1].weight.grad.clone())
+        del y, xg
+    # y: max-norm.  Gradients: relative L2 <= 2e-3 — of 5.5e8 pre-activations ~5e2 sit within rounding (1e-6) of zero; each
+    # flipped ReLU mask switches one dy element on/off, i.e. moves a 3x3xCin patch of dx by O(|r*w|): expected relative L2
+    # ~ sqrt(5e2 / 5.5e8) ~ 1e-3 (measured 5e-4).  An addressing fault garbles whole tiles (>= 1e-2).
+    ya, yb = res[True][0], res[False][0]
+    assert torch.isfinite(ya).all() and (ya - yb).abs().max().item() <= 1e-4 * yb.abs().max().item()
+    for a, b, what in zip(res[True][1:], res[False][1:], ("dx", "dW", "dgamma")):
+        rel = ((a - b).double().norm() / b.double().norm()).item()
+        assert torch.isfinite(a).all() and rel <= 2e-3, (what, rel)
+    del res
+    runner_of(m).wino = True
+    m.eval()
+    with torch.no_grad():
+        full = m(x)
+        for (a, b) in ((0, 10), (40, 50)):
+            assert torch.equal(m(x[a:b]), full[a:b])
+    del full, x, r
+    torch.cuda.empty_cache()
+
+
+def test_unet_batch24_concat_beyond_2gib():
+    """UNet at 24 x 3x360x480: the 128-channel full-resolution concat buffer is 2.1 GB.  Eval rows are independent of the
+    batch (bit-exact against batch-8 calls); a training step runs, is finite and reproducible."""
+    import pytorch_camvid_amd as A
+    torch.manual_seed(0)
+    net = A.get_model("unet", 3, 12).to(dev())
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.randn(24, 3, 360, 480, device=dev(), generator=g)
+    t = torch.randint(0, 12, (24, 360, 480), device=dev(), generator=g)
+    net.eval()
+    with torch.no_grad():
+        full = net(x)
+        for a in (0, 16):
+            assert torch.equal(net(x[a:a + 8]), full[a:a + 8])
+    del full
+    net.train()
+    lossf = A.CrossEntropyLoss()
+    l1 = lossf(net(x), t); l1.backward()
+    g1 = [p.grad.clone() for p in net.parameters()]
+    for p in net.parameters():
+        p.grad = None
+    l2 = lossf(net(x), t); l2.backward()
+    assert torch.isfinite(l1) and l1.item() == l2.item() and abs(l1.item() - np.log(12)) < 0.6
+    assert all(torch.equal(a, p.grad) and torch.isfinite(p.grad).all() for a, p in zip(g1, net.parameters()))
+    del net, x, t, g1
+    torch.cuda.empty_cache()
