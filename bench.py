@@ -172,9 +172,9 @@ def main():
         cnt, fl, sec = dom[1]
         ach = fl / sec / 1e12
         allf = sum(v[1] for v in agg.values()); alls = sum(v[2] for v in agg.values())
-        # Winograd kernels execute 2/3 of the algorithmic (direct-convolution) FLOPs; the roofline numerator stays
+        # Winograd kernels execute 1/2 (F(4,3)) or 2/3 (F(2,3)) of the algorithmic (direct-convolution) FLOPs; the roofline numerator stays
         # algorithmic, the executed-MFMA utilisation is reported beside it
-        executed = (2.0 / 3.0) if "wino" in dom[0] else 1.0
+        executed = 0.5 if "wino4" in dom[0] else ((2.0 / 3.0) if "wino" in dom[0] else 1.0)   # F(4,3): 9 of 18; F(2,3): 12 of 18
         peak = PEAK_BF16_MFMA_TFLOPS if ("bf16" in dom[0] and "split" not in dom[0]) else PEAK_F32_MFMA_TFLOPS
         traffic = None
         tp = os.path.join(ROOT, "profiles", "r01_d_pmc_hbm_traffic.json")

@@ -105,6 +105,15 @@ int cvk_conv3x3_wino_gemm(const float* x, const float* U, float* Mo, int N, int 
 int cvk_wino_output(const float* Mo, const float* bias, float* y, float* stats, int N, int H, int W, int Cout, int ldy,
                     void* stream);
 
+/* The same three steps through 1-D Winograd F(4,3) (2x fewer MFMA FLOPs than the direct form; csrc/wino4.hip):
+ *   U [6][Cout][3][Cin],  Mo float[6][N*H*ceil(W/4)][ldm],  otherwise the contract of the F(2,3) calls above. */
+int cvk_wino4_weight_transform(const float* w, float* U, int Cout, int Cin, void* stream);
+size_t cvk_conv3x3_wino4_workspace_bytes(int N, int H, int W, int Cout_ld);
+int cvk_conv3x3_wino4_gemm(const float* x, const float* U, float* Mo, int N, int H, int W, int Cin, int Cout, int ldm,
+                           void* stream);
+int cvk_wino4_output(const float* Mo, const float* bias, float* y, float* stats, int N, int H, int W, int Cout, int ldy,
+                     void* stream);
+
 /* weight-grad through the transposed F(2,3) (same contract as cvk_conv3x3_wgrad; any Cin_pad % 4 == 0) */
 size_t cvk_conv3x3_wgrad_wino_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout);
 int cvk_conv3x3_wgrad_wino(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,

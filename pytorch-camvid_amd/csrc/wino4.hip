@@ -1,0 +1,389 @@
+// wino4.hip — 3x3 convolution as 1-D Winograd F(4,3) along the image width on the fp32 matrix cores.
+//
+// Same operator as conv3x3.hip / wino.hip (nn.Conv2d(cin,cout,3,padding=1): reference models/unet.py:11,
+// models/segnet.py:8) with 2x fewer multiplies than the direct form (F(2,3) in wino.hip: 1.5x): per kernel row r and
+// group of four output columns 4t..4t+3, six products instead of twelve
+//     m_xi = sum_{r,ci} V_xi[r][ci] * U_xi[r][ci],   xi = 0..5,      d_j = x[y+r-1][4t-1+j], j = 0..5
+//     V = B^T d:  V0 = 4d0 - 5d2 + d4            U = G g:  U0 = g0/4
+//                 V1 = -4d1 - 4d2 + d3 + d4                U1 = -(g0 + g1 + g2)/6
+//                 V2 =  4d1 - 4d2 - d3 + d4                U2 = -(g0 - g1 + g2)/6
+//                 V3 = -2d1 -  d2 + 2d3 + d4               U3 = g0/24 + g1/12 + g2/6
+//                 V4 =  2d1 -  d2 - 2d3 + d4               U4 = g0/24 - g1/12 + g2/6
+//                 V5 =  4d1 - 5d3 + d5                     U5 = g2
+//     y[4t]   = m0 + m1 + m2 + m3 + m4          y[4t+1] = (m1 - m2) + 2(m3 - m4)
+//     y[4t+2] = (m1 + m2) + 4(m3 + m4)          y[4t+3] = (m1 - m2) + 8(m3 - m4) + m5
+// (interpolation points 0, +-1, +-2, inf).  Each xi is an implicit GEMM M_xi[N*H*ceil(W/4)][Cout] = V_xi[.][3*Cin] * U_xi:
+// 6 GEMM units per 4 output columns = 9*M*Cin*Cout executed FLOPs instead of 18.  As in wino.hip the input transform
+// never touches HBM: the staging path loads the (up to four) pixels a V element needs with range-checked buffer loads
+// (zero padding for free) and combines them with three FMAs on the way to LDS; one workgroup walks the six xi of its
+// tile back to back.  Arithmetic is exact-fp32 MFMA; the transform constants (4, 5, 8) cost ~2.5x the rounding error of
+// F(2,3) (measured 6e-7 relative rms against fp64 for K = 768, direct fp32 summation: 4e-7).
+#include "conv_tile.h"
+
+namespace {
+
+// U[xi][co][r][ci] from w[co][r][s][ci]; evaluated in double, rounded once
+__global__ void k_wino4_weight(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin) {
+    const size_t total = (size_t)Cout * 3 * Cin;
+    const size_t plane = total;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        const size_t cr = i / Cin;   // co*3 + r
+        const float* g = w + (cr * 3) * Cin + ci;
+        const double g0 = g[0], g1 = g[Cin], g2 = g[2 * (size_t)Cin];
+        U[i] = (float)(0.25 * g0);
+        U[plane + i] = (float)(-(g0 + g1 + g2) / 6.0);
+        U[2 * plane + i] = (float)(-(g0 - g1 + g2) / 6.0);
+        U[3 * plane + i] = (float)(g0 / 24.0 + g1 / 12.0 + g2 / 6.0);
+        U[4 * plane + i] = (float)(g0 / 24.0 - g1 / 12.0 + g2 / 6.0);
+        U[5 * plane + i] = (float)g2;
+    }
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N>
+__global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino4(
+    const float* __restrict__ X, const float* __restrict__ U, float* __restrict__ Mo, int Mt, int H, int W, int Wt,
+    int Cin, int Cout, int ldm, int tilesN, int Mpix, int nfull) {
+    constexpr int NT = WARPS_M * WARPS_N * 64;
+    constexpr int TM = BM / WARPS_M / 32, TN = BN / WARPS_N / 32;
+    constexpr int RP = NT / 8;
+    constexpr int NA = BM / RP, NB = BN / RP;
+    constexpr int STAGE = (BM + BN) * LDT;
+    static_assert(NA >= 1 && NB >= 1 && BM % RP == 0 && BN % RP == 0, "tile/threads mismatch");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+
+    // 1-D grid in two regions (as in wino.hip): blocks [0, nfull) own one tile each and walk all six transform indices;
+    // the remaining tiles are cut into six single-index blocks (finer last dispatch round).
+    int tile, xi_begin, xi_end;
+    if ((int)blockIdx.x < nfull) {
+        tile = cvk_xcd_remap(blockIdx.x, nfull);
+        xi_begin = 0;
+        xi_end = 6;
+    } else {
+        const int r = cvk_xcd_remap(blockIdx.x - nfull, gridDim.x - nfull);
+        tile = nfull + r / 6;
+        xi_begin = r - (r / 6) * 6;
+        xi_end = xi_begin + 1;
+    }
+    const int m0 = (tile / tilesN) * BM;
+    const int n0 = (tile % tilesN) * BN;
+    const int K3 = 3 * Cin;
+    const int nK = K3 / BK;   // even by contract (Cin % 64 == 0)
+
+    // input window (window_rsrc): starts one image row + one pixel before the first column group of this tile
+    const int pb = max((m0 / Wt) * W + 4 * (m0 % Wt) - W - 1, 0);
+    const __amdgpu_buffer_rsrc_t xr = window_rsrc(X, (size_t)pb * Cin, (size_t)Mpix * Cin);
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, 6 * Cout * K3 * 4, 0x00020000);
+
+    const int kv = tid & 7, r0 = tid >> 3;
+    // per staged row: byte offset of pixel (n, y, 4*xt) = d1 (a multiple of 256 because Cin % 64 == 0) with 8 validity bits
+    // in its low byte: bit r (r<3): image row y+r-1 exists; bits 3..7: columns d0, d2, d3, d4, d5 exist (d1 always does)
+    unsigned arow[NA], boff[NB];
+    const int HWt = H * Wt;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int t = m0 + r0 + i * RP;
+        unsigned v = 0;
+        if (t < Mt) {
+            const int n = t / HWt, rem = t - n * HWt;
+            const int y = rem / Wt, xt = rem - y * Wt;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                if ((unsigned)(y + r - 1) < (unsigned)H) v |= 1u << r;
+            if (xt > 0) v |= 8u;
+#pragma unroll
+            for (int j = 2; j < 6; ++j)
+                if (4 * xt + j - 1 < W) v |= 8u << (j - 1);
+            v |= (unsigned)((n * H + y) * W + 4 * xt - pb) * (unsigned)Cin * 4u;
+        } else {
+            v = OOB;   // no flags: every load of this row is out of range
+        }
+        arow[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int co = n0 + r0 + i * RP;
+        boff[i] = co < Cout ? (unsigned)co * (unsigned)K3 * 4u + kv * 16u : OOB;
+    }
+    const unsigned kvb = kv * 16u;
+
+    // One register stage: the (up to) four pixels of every V element and the weights are issued right after the LDS store
+    // that consumed the previous slice, i.e. they are in flight for one whole K step.
+    f32x4 ra0[NA], ra1[NA], ra2[NA], ra3[NA], rb[NB];
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;              // V = c0*a0 + c1*a1 + c2*a2 + a3 for the slice held in ra*
+    int lxi = xi_begin, lr = 0, lcib = 0;            // next slice to load (transform index, kernel row, channel base; uniform)
+
+    auto colbit = [](int j) -> unsigned { return j == 1 ? 0u : (8u << (j == 0 ? 0 : j - 1)); };
+    auto issue = [&]() {
+        const int x5 = lxi == 5, x0 = lxi == 0;
+        const int j0 = x0 ? 0 : 1;
+        const int j1 = x5 ? 3 : 2;
+        const int j2 = x0 ? 4 : (x5 ? 5 : 3);
+        const bool four = (unsigned)(lxi - 1) < 4u;  // xi 1..4: fourth tap d4 with coefficient 1
+        c0 = (x0 | x5 | (lxi == 2)) ? 4.f : (lxi == 1 ? -4.f : (lxi == 3 ? -2.f : 2.f));
+        c1 = (x0 | x5) ? -5.f : (lxi < 3 ? -4.f : -1.f);
+        c2 = (x0 | x5 | (lxi == 1)) ? 1.f : (lxi == 2 ? -1.f : (lxi == 3 ? 2.f : -2.f));
+        const unsigned dead = lxi < xi_end ? 0u : OOB;                 // past the last slice: zeros
+        const unsigned rowbit = 1u << lr;
+        const unsigned base = (unsigned)((((lr - 1) * W - 1) * Cin + lcib) * 4) + kvb + dead;   // column d0
+        const unsigned cs = (unsigned)Cin * 4u;
+        const unsigned s0 = base + j0 * cs, s1 = base + j1 * cs, s2 = base + j2 * cs, s3 = base + 4 * cs;
+        const unsigned n0_ = rowbit | colbit(j0), n1_ = rowbit | colbit(j1), n2_ = rowbit | colbit(j2);
+        const unsigned n3_ = four ? (rowbit | colbit(4)) : 0xFFFFFFFFu;   // never satisfied -> zero
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const unsigned a = arow[i], o = a & ~0xFFu;
+            ra0[i] = buf_load16(xr, oob_unless((a & n0_) == n0_, o + s0));
+            ra1[i] = buf_load16(xr, oob_unless((a & n1_) == n1_, o + s1));
+            ra2[i] = buf_load16(xr, oob_unless((a & n2_) == n2_, o + s2));
+            ra3[i] = buf_load16(xr, oob_unless((a & n3_) == n3_, o + s3));
+        }
+        const unsigned ub = (unsigned)((lxi * Cout * K3 + lr * Cin + lcib) * 4) | dead;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = buf_load16(ur, (boff[i] + ub) | ((boff[i] | ub) & OOB));
+        lcib += BK;                                  // branch-free advance (slice -> kernel row -> transform index)
+        const int w1 = lcib >= Cin;
+        lcib = w1 ? 0 : lcib;
+        lr += w1;
+        const int w2 = lr == 3;
+        lr = w2 ? 0 : lr;
+        lxi += w2;
+    };
+    auto store_stage = [&](float* dst) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaf(c0, ra0[i][j], fmaf(c1, ra1[i][j], fmaf(c2, ra2[i][j], ra3[i][j])));
+            *reinterpret_cast<f32x4*>(&dst[(r0 + i * RP) * LDT + kv * 4]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&dst[BM * LDT + (r0 + i * RP) * LDT + kv * 4]) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    auto mma_kk = [&](const float* arow_, const float* brow_, int kk) {
+        f32x4 a[TM], b[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const f32x4*>(arow_ + t * 32 * LDT + kk * 8);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const f32x4*>(brow_ + t * 32 * LDT + kk * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
+    };
+
+    // prologue: slice 0 into LDS stage 0; slice 1 in flight
+    issue();
+    store_stage(smem);
+    issue();
+    __syncthreads();
+    const int aro = (wm * TM * 32 + li) * LDT + lh * 4;
+    const int bro = BM * LDT + (wn * TN * 32 + li) * LDT + lh * 4;
+    float* const buf0 = smem;
+    float* const buf1 = smem + STAGE;
+    const int rowbase = m0 + wm * TM * 32;
+    const bool full = (m0 + BM <= Mt) && (n0 + BN <= ldm);
+
+#define CVK_WINO4_STEP(cur, nxt)                      \
+    do {                                              \
+        mma_kk(cur + aro, cur + bro, 0);              \
+        mma_kk(cur + aro, cur + bro, 1);              \
+        store_stage(nxt);            /* slice ks+1 */ \
+        issue();                     /* slice ks+2 */ \
+        mma_kk(cur + aro, cur + bro, 2);              \
+        mma_kk(cur + aro, cur + bro, 3);              \
+        __syncthreads();                              \
+    } while (0)
+
+    for (int xi = xi_begin; xi < xi_end; ++xi) {
+        for (int ks = 0; ks < nK; ks += 2) {
+            CVK_WINO4_STEP(buf0, buf1);
+            CVK_WINO4_STEP(buf1, buf0);
+        }
+        // flush M_xi (the next xi's first slice is already in LDS) and restart the accumulators
+        float* out = Mo + (size_t)xi * Mt * ldm;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = n0 + wn * TN * 32 + tn * 32 + li;
+            if (full) {
+                float* yp = out + (size_t)(rowbase + 4 * lh) * ldm + col;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        yp[(size_t)(tm * 32 + (r & 3) + 8 * (r >> 2)) * ldm] = acc[tm][tn][r];
+                        acc[tm][tn][r] = 0.f;
+                    }
+            } else {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rowbase + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (row < Mt && col < ldm) out[(size_t)row * ldm + col] = acc[tm][tn][r];
+                        acc[tm][tn][r] = 0.f;
+                    }
+            }
+        }
+    }
+#undef CVK_WINO4_STEP
+}
+
+// y[pixel][c] = A^T-combination of M_0..5 + bias; BatchNorm statistics partials per 64-pixel granule (as k_wino_output).
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_wino4_output(const float* __restrict__ Mo, int ldm, int Mt,
+                                                     const float* __restrict__ bias, float* __restrict__ Y, int ldy,
+                                                     float* __restrict__ stats, int P, int Mpix, int H, int W, int Wt,
+                                                     int C, int Cout) {
+    __shared__ float red[2][1024];
+    const int c0 = blockIdx.y * 1024;
+    const int cw = min(1024, C - c0);
+    const int cvn = cw / 4, ppp = 256 / cvn;
+    const int t = threadIdx.x;
+    const bool active = t < cvn * ppp;
+    const int cv = t % cvn, pr = t / cvn;
+    const int c = c0 + cv * 4;
+    const int mbeg = blockIdx.x * CVK_STAT_ROWS, mend = min(Mpix, mbeg + CVK_STAT_ROWS);
+    f32x4 sh = {0.f, 0.f, 0.f, 0.f};
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        if (bias != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sh[j] = (c + j < Cout) ? bias[c + j] : 0.f;
+        }
+        const int HW = H * W;
+        const size_t plane = (size_t)Mt * ldm;
+        for (int m = mbeg + pr; m < mend; m += ppp) {
+            const int n = m / HW, rem = m - n * HW;
+            const int y = rem / W, x = rem - y * W;
+            const float* p = Mo + ((size_t)(n * H + y) * Wt + (x >> 2)) * ldm + c;
+            const f32x4 m1 = *reinterpret_cast<const f32x4*>(p + plane);
+            const f32x4 m2 = *reinterpret_cast<const f32x4*>(p + 2 * plane);
+            const f32x4 m3 = *reinterpret_cast<const f32x4*>(p + 3 * plane);
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(p + 4 * plane);
+            const int i = x & 3;
+            f32x4 v;
+            if (i == 0) {
+                const f32x4 m0v = *reinterpret_cast<const f32x4*>(p);
+                v = m0v + (m1 + m2) + (m3 + m4);
+            } else if (i == 1) {
+                v = (m1 - m2) + 2.f * (m3 - m4);
+            } else if (i == 2) {
+                v = (m1 + m2) + 4.f * (m3 + m4);
+            } else {
+                const f32x4 m5 = *reinterpret_cast<const f32x4*>(p + 5 * plane);
+                v = (m1 - m2) + 8.f * (m3 - m4) + m5;
+            }
+            v += sh;
+            *reinterpret_cast<f32x4*>(Y + (size_t)m * ldy + c) = v;
+            if (STATS) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = v[j] - sh[j];
+                    s1[j] += d;
+                    s2[j] += d * d;
+                }
+            }
+        }
+    }
+    if (!STATS) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[0][t * 4 + j] = s1[j];
+        red[1][t * 4 + j] = s2[j];
+    }
+    __syncthreads();
+    if (t < cvn) {
+        const float cnt = (float)(mend - mbeg);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.f, b = 0.f;
+            for (int p = 0; p < ppp; ++p) {
+                a += red[0][(p * cvn + t) * 4 + j];
+                b += red[1][(p * cvn + t) * 4 + j];
+            }
+            const int ch = c0 + t * 4 + j;
+            if (ch < Cout) {
+                float m2 = b - a * a / cnt;
+                stats[(size_t)blockIdx.x * Cout + ch] = a + cnt * sh[j];
+                stats[(size_t)(P + blockIdx.x) * Cout + ch] = m2 > 0.f ? m2 : 0.f;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cvk_wino4_weight_transform(const float* w, float* U, int Cout, int Cin, void* stream) {
+    CVK_CHECK_ARG(w && U && Cout > 0 && Cin > 0, "cvk_wino4_weight_transform: bad arguments");
+    const size_t total = (size_t)Cout * 3 * Cin;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_wino4_weight, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
+    CVK_LAUNCH_RETURN("cvk_wino4_weight_transform");
+}
+
+extern "C" size_t cvk_conv3x3_wino4_workspace_bytes(int N, int H, int W, int Cout_ld) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cout_ld <= 0) return 0;
+    return (size_t)6 * N * H * ((W + 3) / 4) * Cout_ld * sizeof(float);
+}
+
+extern "C" int cvk_conv3x3_wino4_gemm(const float* x, const float* U, float* Mo, int N, int H, int W, int Cin, int Cout,
+                                      int ldm, void* stream) {
+    CVK_CHECK_ARG(x && U && Mo, "cvk_conv3x3_wino4_gemm: null pointer");
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldm >= Cout && ldm % 4 == 0, "cvk_conv3x3_wino4_gemm: bad shape");
+    CVK_CHECK_ARG(Cin > 0 && Cin % 64 == 0, "cvk_conv3x3_wino4_gemm: Cin=%d must be a multiple of 64 (use cvk_conv3x3_fwd otherwise)", Cin);
+    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(U) && cvk_aligned16(Mo), "cvk_conv3x3_wino4_gemm: pointers must be 16-byte aligned");
+    CVK_CHECK_ARG((long)N * H * W < (1L << 31) - 512, "cvk_conv3x3_wino4_gemm: tensor too large for 32-bit pixel indices");
+    CVK_CHECK_ARG((long)(2 * W + 520) * Cin * 4 < (1L << 31) && (long)6 * Cout * 3 * Cin * 4 < (1L << 31), "cvk_conv3x3_wino4_gemm: a tile's input window or the weight tensor exceeds the 2 GiB buffer-addressing limit");
+    const int Wt = (W + 3) / 4, Mt = N * H * Wt, Mpix = N * H * W, ldy = ldm;
+    hipStream_t s = (hipStream_t)stream;
+    auto full_tiles = [&](int tiles) {
+        if (tiles < 1024 && Cin >= 256) return 0;
+        return tiles / 256 * 256;
+    };
+    if (ldy > 64) {
+        const int tilesN = cvk_cdiv(ldy, 128), tiles = cvk_cdiv(Mt, 128) * tilesN, nf = full_tiles(tiles);
+        hipLaunchKernelGGL((k_conv3x3_wino4<128, 128, 2, 2>), dim3(nf + 6 * (tiles - nf)), dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, Mpix, nf);
+    } else if (ldy > 32) {
+        const int tilesN = cvk_cdiv(ldy, 64), tiles = cvk_cdiv(Mt, 128) * tilesN, nf = full_tiles(tiles);
+        hipLaunchKernelGGL((k_conv3x3_wino4<128, 64, 2, 2>), dim3(nf + 6 * (tiles - nf)), dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, Mpix, nf);
+    } else {
+        const int tiles = cvk_cdiv(Mt, 128), nf = full_tiles(tiles);
+        hipLaunchKernelGGL((k_conv3x3_wino4<128, 32, 4, 1>), dim3(nf + 6 * (tiles - nf)), dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, 1, Mpix, nf);
+    }
+    CVK_LAUNCH_RETURN("cvk_conv3x3_wino4_gemm");
+}
+
+extern "C" int cvk_wino4_output(const float* Mo, const float* bias, float* y, float* stats, int N, int H, int W, int Cout,
+                                int ldy, void* stream) {
+    CVK_CHECK_ARG(Mo && y, "cvk_wino4_output: null pointer");
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout && ldy % 4 == 0, "cvk_wino4_output: bad shape");
+    CVK_CHECK_ARG(cvk_aligned16(Mo) && cvk_aligned16(y), "cvk_wino4_output: pointers must be 16-byte aligned");
+    const int Wt = (W + 3) / 4, Mt = N * H * Wt, Mpix = N * H * W;
+    const int P = cvk_cdiv(Mpix, CVK_STAT_ROWS);
+    dim3 grid(P, cvk_cdiv(ldy, 1024));
+    hipStream_t s = (hipStream_t)stream;
+    if (stats)
+        hipLaunchKernelGGL(k_wino4_output<true>, grid, dim3(256), 0, s, Mo, ldy, Mt, bias, y, ldy, stats, P, Mpix, H, W, Wt, ldy, Cout);
+    else
+        hipLaunchKernelGGL(k_wino4_output<false>, grid, dim3(256), 0, s, Mo, ldy, Mt, bias, y, ldy, stats, P, Mpix, H, W, Wt, ldy, Cout);
+    CVK_LAUNCH_RETURN("cvk_wino4_output");
+}

@@ -85,8 +85,51 @@ import os
 WINO_DEFAULT = os.environ.get("CVK_WINO", "1") != "0"   # 1-D Winograd F(2,3) for eligible layers (Cin % 64 == 0, > 32 columns)
 
 
+# F(4,3) instead of F(2,3) for the forward / data-grad GEMMs of the layers where it pays (wino4_pays); Runner.wino4 may
+# also be set to "always" (tests: every eligible layer, whatever its size)
+WINO4_DEFAULT = {"0": False, "1": True, "always": "always"}[os.environ.get("CVK_WINO4", "1")]
+
+
 def wino_ok(R, k_ch, n_cols):
     return R.wino and k_ch % 64 == 0
+
+
+def wino4_pays(N, H, W, k_ch, n_cols):
+    """F(4,3) or F(2,3) for this layer?  Both kernels do the same work per workgroup (3*k_ch/32 K steps of a 128-row
+    tile); F(4,3) needs 6 workgroups per 4 columns, F(2,3) 8, so it wins whenever the grid is large.  It does not pay
+    (measured, tools/bench_conv.py wino wino4) for 64-column tiles with k_ch >= 128 (the four-tap staging of the 128-row
+    operand outweighs the halved MFMA work per slice) and when the 256-CU round count does not drop (few tiles)."""
+    if n_cols <= 32 or (n_cols <= 64 and k_ch >= 128):
+        return False
+    tn = -(-n_cols // 128) if n_cols > 64 else 1
+
+    def rounds(blocks):
+        return -(-blocks // 256) if blocks < 2048 else blocks / 256.0
+    r2 = rounds(-(-(N * H * ((W + 1) // 2)) // 128) * tn * 4)
+    r4 = rounds(-(-(N * H * ((W + 3) // 4)) // 128) * tn * 6)
+    return r4 < r2
+
+
+def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what=""):
+    """y[N,H,W,ldy] = conv3x3(x[N,H,W,k_ch], w[cout][3][3][k_ch]) (+bias, +BN statistics partials at sp) through the 1-D
+    Winograd kernels: weight transform -> implicit GEMMs M_xi -> output transform.  F(4,3) when R.wino4, else F(2,3)."""
+    M = N * H * W
+    if R.wino4 == "always" or (R.wino4 and wino4_pays(N, H, W, k_ch, ldy)):
+        U = _empty(6 * cout * 3 * k_ch, x.device)
+        check(lib.cvk_wino4_weight_transform(w.data_ptr(), U.data_ptr(), cout, k_ch, s), "cvk_wino4_weight_transform")
+        ws = R.workspace(lib.cvk_conv3x3_wino4_workspace_bytes(N, H, W, ldy), x.device)
+        _timed(R, conv_kernel_name("wino4", ldy), flops, lambda: check(
+            lib.cvk_conv3x3_wino4_gemm(x.data_ptr(), U.data_ptr(), ws.data_ptr(), N, H, W, k_ch, cout, ldy, s), "cvk_conv3x3_wino4_gemm" + what))
+        _timed(R, "k_wino4_output", 10.0 * M * ldy, lambda: check(
+            lib.cvk_wino4_output(ws.data_ptr(), bias, y.data_ptr(), sp, N, H, W, cout, ldy, s), "cvk_wino4_output"), "byte")
+    else:
+        U = _empty(4 * cout * 3 * k_ch, x.device)
+        check(lib.cvk_wino_weight_transform(w.data_ptr(), U.data_ptr(), cout, k_ch, s), "cvk_wino_weight_transform")
+        ws = R.workspace(lib.cvk_conv3x3_wino_workspace_bytes(N, H, W, ldy), x.device)
+        _timed(R, conv_kernel_name("wino", ldy), flops, lambda: check(
+            lib.cvk_conv3x3_wino_gemm(x.data_ptr(), U.data_ptr(), ws.data_ptr(), N, H, W, k_ch, cout, ldy, s), "cvk_conv3x3_wino_gemm" + what))
+        _timed(R, "k_wino_output", 12.0 * M * ldy, lambda: check(
+            lib.cvk_wino_output(ws.data_ptr(), bias, y.data_ptr(), sp, N, H, W, cout, ldy, s), "cvk_wino_output"), "byte")
 
 
 def bf16_ok(R, k_ch):
@@ -102,6 +145,8 @@ def conv_kernel_name(kind, n_cols, k_ch=32):
     if kind in ("bf16_fwd", "bf16_dgrad"):
         t = "128, 128, 2, 2" if n_cols > 64 else ("128, 64, 2, 2" if n_cols > 32 else "256, 32, 4, 1")
         return f"k_conv3x3_igemm_bf16<{t}, {'true' if kind == 'bf16_fwd' else 'false'}>"
+    if kind == "wino4":
+        return "k_conv3x3_wino4<128, 128, 2, 2>" if n_cols > 64 else ("k_conv3x3_wino4<128, 64, 2, 2>" if n_cols > 32 else "k_conv3x3_wino4<128, 32, 4, 1>")
     if kind == "wino":
         return "k_conv3x3_wino<128, 128, 2, 2>" if n_cols > 64 else ("k_conv3x3_wino<128, 64, 2, 2>" if n_cols > 32 else "k_conv3x3_wino<128, 32, 4, 1>")
     if kind == "wgrad":
@@ -170,14 +215,7 @@ class ConvBnRelu(Op):
                 lib.cvk_conv3x3_fwd_bf16(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy, s),
                 "cvk_conv3x3_fwd_bf16"))
         elif wino_ok(R, src.ld, ldy):
-            U = _empty(4 * C * 3 * src.ld, X.device)
-            check(lib.cvk_wino_weight_transform(wk.data_ptr(), U.data_ptr(), C, src.ld, s), "cvk_wino_weight_transform")
-            wsb = lib.cvk_conv3x3_wino_workspace_bytes(N, H, W, ldy)
-            ws = R.workspace(wsb, X.device)
-            _timed(R, conv_kernel_name("wino", ldy), 18.0 * M * C * self.cin, lambda: check(
-                lib.cvk_conv3x3_wino_gemm(X.data_ptr(), U.data_ptr(), ws.data_ptr(), N, H, W, src.ld, C, ldy, s), "cvk_conv3x3_wino_gemm"))
-            _timed(R, "k_wino_output", 12.0 * M * ldy, lambda: check(
-                lib.cvk_wino_output(ws.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, C, ldy, s), "cvk_wino_output"), "byte")
+            wino_conv(R, lib, s, X, wk, b.data_ptr(), y, sp, N, H, W, src.ld, C, ldy, 18.0 * M * C * self.cin)
         else:
             _timed(R, conv_kernel_name("fwd", ldy, src.ld), 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy, s),
@@ -260,15 +298,7 @@ class ConvBnRelu(Op):
                     lib.cvk_conv3x3_fwd_bf16(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
                     "cvk_conv3x3_fwd_bf16(dgrad)"))
             elif wino_ok(R, ldy, src.ld):
-                U = _empty(4 * src.ld * 3 * ldy, dev)
-                check(lib.cvk_wino_weight_transform(wd.data_ptr(), U.data_ptr(), src.ld, ldy, s), "cvk_wino_weight_transform")
-                wsb2 = lib.cvk_conv3x3_wino_workspace_bytes(N, H, W, src.ld)
-                ws2 = R.workspace(wsb2, dev)
-                _timed(R, conv_kernel_name("wino", src.ld), 18.0 * M * C * self.cin, lambda: check(
-                    lib.cvk_conv3x3_wino_gemm(dy.data_ptr(), U.data_ptr(), ws2.data_ptr(), N, H, W, ldy, src.ld, src.ld, s),
-                    "cvk_conv3x3_wino_gemm(dgrad)"))
-                _timed(R, "k_wino_output", 12.0 * M * src.ld, lambda: check(
-                    lib.cvk_wino_output(ws2.data_ptr(), None, dX.data_ptr(), None, N, H, W, src.ld, src.ld, s), "cvk_wino_output"), "byte")
+                wino_conv(R, lib, s, dy, wd, None, dX, None, N, H, W, ldy, src.ld, src.ld, 18.0 * M * C * self.cin, "(dgrad)")
             else:
                 _timed(R, conv_kernel_name("dgrad", src.ld, ldy), 18.0 * M * C * self.cin, lambda: check(
                     lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
@@ -458,6 +488,7 @@ class Runner:
         self._ws = None
         self.grad_sync = None       # set by ddp.DataParallel
         self.wino = WINO_DEFAULT
+        self.wino4 = WINO4_DEFAULT
         self.bf16 = False           # opt-in: bf16-MFMA convolutions (modules.set_conv_precision)
         self.split = False          # opt-in, experimental: fp32-accurate 3-way bf16 split forward / data-grad
         self.prof = None            # list collecting (kernel name, flops, start event, end event) when bench.py profiles

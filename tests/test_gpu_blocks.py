@@ -216,10 +216,12 @@ def test_errors_match_reference_classes():
             u(torch.zeros(1, 3, 15, 15, device=dev()))      # too small for four 2x2 pools
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 3, 1, 64), (1, 64, 1, 3, 128), (2, 128, 7, 5, 64), (1, 64, 6, 9, 96), (3, 96, 5, 4, 40)])
+@pytest.mark.parametrize("shape", [(2, 64, 3, 1, 64), (1, 64, 1, 3, 128), (2, 128, 7, 5, 64), (1, 64, 6, 9, 96), (3, 96, 5, 4, 40),
+                                   (2, 64, 5, 2, 64), (1, 128, 4, 6, 128), (2, 64, 3, 7, 192), (1, 64, 9, 30, 64), (3, 64, 2, 8, 64)])
 def test_winograd_and_direct_kernels_agree(shape):
-    """Both conv implementations (direct implicit GEMM, 1-D Winograd F(2,3)) against the fp64 oracle on degenerate
-    widths (W=1, odd W) — forward, data-grad and weight-grad."""
+    """The three conv implementations (direct implicit GEMM, 1-D Winograd F(2,3) and F(4,3)) against the fp64 oracle on
+    degenerate and ragged widths (W = 1..9 covers every W mod 4 and tiles cut by the right edge; W = 30 is the UNet
+    bottleneck width) — forward, data-grad and weight-grad."""
     import pytorch_camvid_amd as A
     from pytorch_camvid_amd.modules import runner_of
     from oracle import np_ops as O
@@ -231,16 +233,17 @@ def test_winograd_and_direct_kernels_agree(shape):
     out_o, cache = O.basic_conv_fwd(x.numpy(), p, "", train=True)
     dx_o, g_o = O.basic_conv_bwd(r.numpy(), cache, p)
     m = m.to(dev()).train()
-    for wino in (False, True):
-        runner_of(m).wino = wino
+    for wino, wino4 in ((False, False), (True, False), (True, "always")):     # direct, F(2,3), F(4,3) forward/data-grad
+        runner_of(m).wino, runner_of(m).wino4 = wino, wino4
         for q in m.parameters():
             q.grad = None
         xg = x.to(dev()).requires_grad_(True)
         y = m(xg)
         (y * r.to(dev())).sum().backward()
-        close(y, out_o, 1e-4, 3e-5 * max(1.0, float(np.abs(out_o).max())), f"fwd wino={wino}")
-        close(xg.grad, dx_o, 1e-3, 2e-4 * float(np.abs(dx_o).max()), f"dx wino={wino}")
-        close(m.conv[0].weight.grad, g_o["conv.0.weight"], 1e-3, 2e-4 * float(np.abs(g_o["conv.0.weight"]).max()), f"dW wino={wino}")
+        tag = f"wino={wino} wino4={wino4}"
+        close(y, out_o, 1e-4, 3e-5 * max(1.0, float(np.abs(out_o).max())), f"fwd {tag}")
+        close(xg.grad, dx_o, 1e-3, 2e-4 * float(np.abs(dx_o).max()), f"dx {tag}")
+        close(m.conv[0].weight.grad, g_o["conv.0.weight"], 1e-3, 2e-4 * float(np.abs(g_o["conv.0.weight"]).max()), f"dW {tag}")
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 12, 20, 64), (1, 128, 7, 5, 96), (1, 32, 9, 4, 12)])

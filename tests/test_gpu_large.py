@@ -128,7 +128,7 @@ def test_block_direct_and_winograd_agree_beyond_2gib():
 
 def test_unet_batch24_concat_beyond_2gib():
     """UNet at 24 x 3x360x480: the 128-channel full-resolution concat buffer is 2.1 GB.  Eval rows are independent of the
-    batch (bit-exact against batch-8 calls); a training step runs, is finite and reproducible."""
+    batch (against batch-8 calls); a training step runs, is finite and reproducible."""
     import pytorch_camvid_amd as A
     torch.manual_seed(0)
     net = A.get_model("unet", 3, 12).to(dev())
@@ -138,8 +138,8 @@ def test_unet_batch24_concat_beyond_2gib():
     net.eval()
     with torch.no_grad():
         full = net(x)
-        for a in (0, 16):
-            assert torch.equal(net(x[a:a + 8]), full[a:a + 8])
+        for a in (0, 16):      # not bit-exact: the engine picks F(4,3) or F(2,3) per layer from the grid size, which depends on N
+            assert torch.allclose(net(x[a:a + 8]), full[a:a + 8], rtol=1e-4, atol=2e-5)
     del full
     net.train()
     lossf = A.CrossEntropyLoss()

@@ -23,22 +23,36 @@ def batch(n, h, w, seed):
     return x.to(dev()), t.to(dev())
 
 
+@pytest.mark.parametrize("conv", ["default", "f43_always"])
 @pytest.mark.parametrize("tag", NETS)
-def test_net_forward_loss_grads_golden(tag):
+def test_net_forward_loss_grads_golden(tag, conv):
+    """conv = "default": the engine's per-layer choice (direct / F(2,3) / F(4,3) by grid size; at these small goldens
+    mostly F(2,3)).  "f43_always": every eligible layer through the F(4,3) kernels, logits tolerance 1e-3 instead of 5e-4:
+    F(4,3) rounds ~2.5x coarser than F(2,3) (6e-7 vs 2.5e-7 relative rms per layer, csrc/wino4.hip) and these tiny
+    geometries amplify a per-layer relative perturbation ~800x (BatchNorm over 6-12 samples at the bottleneck; measured
+    with oracle/torch_ref in fp64 + injected noise).  tests/chaos_probe.py over 8 data seeds: direct 3e-4, F(2,3) 2.5e-4,
+    F(4,3) 5e-4 max logits deviation.  segnet_s0 is left out of the forced mode: for that one seed the perturbation flips
+    a max-pool arg-max at the 2x3 bottleneck (28 % of the logits move, the signature of fp64 + 1e-6 noise in the
+    reference itself); the default mode never runs F(4,3) on layers that small."""
+    if conv == "f43_always" and tag == "segnet_s0_2x64x96":
+        pytest.skip("arg-max flip at the 2x3 bottleneck for this seed under F(4,3) rounding (see docstring)")
     import pytorch_camvid_amd as A
+    from pytorch_camvid_amd.modules import runner_of
     d = dict(np.load(os.path.join(G, tag + ".npz")))
     meta = json.loads(str(d["meta"]))
     torch.manual_seed(meta["seed"])
     net = A.get_model(meta["kind"], 3, 12)
     assert [k for k, _ in net.named_parameters()] == list(d["param_names"])
     net = net.to(dev()).train()
+    if conv == "f43_always":
+        runner_of(net).wino4 = "always"
     n, _, h, w = meta["shape"]
     x, t = batch(n, h, w, meta["data_seed"])
     out = net(x)
     assert tuple(out.shape) == (n, 12, h, w)
     # forward tolerance (fp32, 23-26 conv+BN layers, BN over as few as 6-12 samples at the bottleneck of these
     # small goldens): 5e-4 absolute on logits in [0, ~5]; the reference itself moves ~5e-5 between fp32 and fp64
-    np.testing.assert_allclose(out.detach().cpu().numpy(), d["logits"], rtol=1e-3, atol=5e-4)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), d["logits"], rtol=1e-3, atol=5e-4 if conv == "default" else 1e-3)
     loss = A.CrossEntropyLoss()(out, t)
     loss.backward()
     assert abs(loss.item() - float(d["loss"])) < 2e-5

@@ -68,6 +68,17 @@ def main():
             wsb = lib.cvk_conv3x3_wino_workspace_bytes(N, H, W, ldy); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             t = timeit(lambda: (check(lib.cvk_conv3x3_wino_gemm(x.data_ptr(), U.data_ptr(), ws.data_ptr(), N, H, W, ci, co, ldy, s)), check(lib.cvk_wino_output(ws.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, co, ldy, s))))
             row += f" wino {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["wino"][0] += flops; tot["wino"][1] += t
+        if "wino4" in which and ci % 64 == 0 and ldy > 32:
+            yref = y.clone(); sref = stats.clone()
+            U4 = torch.empty(6 * co * 3 * ci, device=dev)
+            check(lib.cvk_wino4_weight_transform(w.data_ptr(), U4.data_ptr(), co, ci, s))
+            wsb = lib.cvk_conv3x3_wino4_workspace_bytes(N, H, W, ldy); ws4 = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            tg = timeit(lambda: check(lib.cvk_conv3x3_wino4_gemm(x.data_ptr(), U4.data_ptr(), ws4.data_ptr(), N, H, W, ci, co, ldy, s)))
+            to = timeit(lambda: check(lib.cvk_wino4_output(ws4.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, co, ldy, s)))
+            t = tg + to
+            err = (y - yref).abs().max().item() / yref.abs().max().item() if "wino" in which else float("nan")
+            serr = (stats - sref).abs().max().item() / sref.abs().max().item() if "wino" in which else float("nan")
+            row += f" wino4 gemm {tg*1e6:7.1f} out {to*1e6:6.1f}us {flops/t/1e12:6.1f}TF (gemm {flops/tg/1e12:6.1f}) err {err:.1e} {serr:.1e}"; tot["wino4"][0] += flops; tot["wino4"][1] += t
         if "dgrad" in which and name != "down1.0":
             dy = torch.randn(M, ldy, device=dev); wd = torch.randn(ci, 9 * ldy, device=dev) * 0.05; dx = torch.empty(M, ci, device=dev)
             t = timeit(lambda: check(lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), None, N, H, W, ldy, ci, ci, s)))
