@@ -501,6 +501,20 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
     const int bco = BK * BM + lh * BN + wn * TN * 32 + li;
     float* const buf0 = smem;
     float* const buf1 = smem + STAGE;
+    // instruction order inside a K step imposed on the scheduler: 16 MFMAs; the LDS stores of the next slice under the next
+    // 16; the 2*(NA+NB) loads one per MFMA; the rest.   masks: 0x008 MFMA, 0x020 VMEM read, 0x200 DS write
+#define CVK_WW_PIPELINE()                                                     \
+    if (TM * TN == 4) {   /* 60-64 MFMAs per step; the 64-row tile (30-32 MFMAs) is left to the compiler */ \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < NA + NB; ++q_) {              \
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                \
+            __builtin_amdgcn_sched_group_barrier(0x008, 16 / (NA + NB), 0);   \
+        }                                                                     \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2 * (NA + NB); ++q_) {        \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
+        }                                                                     \
+    }
 #define CVK_WW_STEP(cur, nxt, AP_, BP_)             \
     do {                                            \
         mma_part(cur + aco, cur + bco, 0, 8);       \
@@ -508,6 +522,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
         issue_q();                   /* slice ks+2 */ \
         issue_p(AP_, BP_);           /* slice ks+3 */ \
         mma_part(cur + aco, cur + bco, 8, L / 2);   \
+        CVK_WW_PIPELINE();                          \
         __syncthreads();                            \
     } while (0)
     int ks = 0;
@@ -517,6 +532,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
     }
     if (ks < nK) CVK_WW_STEP(buf0, buf1, ap0, bp0);
 #undef CVK_WW_STEP
+#undef CVK_WW_PIPELINE
 
     float* out = slab + ((size_t)split * 4 + xi) * Cout * K3;
 #pragma unroll

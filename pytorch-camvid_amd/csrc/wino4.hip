@@ -119,23 +119,29 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino4(
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;              // V = c0*a0 + c1*a1 + c2*a2 + a3 for the slice held in ra*
     int lxi = xi_begin, lr = 0, lcib = 0;            // next slice to load (transform index, kernel row, channel base; uniform)
 
-    auto colbit = [](int j) -> unsigned { return j == 1 ? 0u : (8u << (j == 0 ? 0 : j - 1)); };
+    // Per-slice constants come from nibble tables indexed by the (uniform) transform index — pure SALU shifts, no
+    // branches: the whole K step must stay one basic block so that the loads interleave with the MFMAs.
+    //   nibble xi of: TJ0/TJ1/TJ2 = columns j of the first three taps (d_j), TC0/TC1/TC2 = their coefficients + 8;
+    //   bit xi of FOUR: a fourth tap d4 with coefficient 1 (xi 1..4); byte j of COLBIT: the validity flag of column d_j.
+    constexpr unsigned TJ0 = 0x00111110u, TJ1 = 0x00322222u, TJ2 = 0x00533334u;
+    constexpr unsigned TC0 = 0x00CA6C4Cu, TC1 = 0x00377443u, TC2 = 0x0096A799u, FOUR = 0x1Eu;
+    constexpr unsigned long long COLBIT = 0x0000804020100008ULL;
     auto issue = [&]() {
-        const int x5 = lxi == 5, x0 = lxi == 0;
-        const int j0 = x0 ? 0 : 1;
-        const int j1 = x5 ? 3 : 2;
-        const int j2 = x0 ? 4 : (x5 ? 5 : 3);
-        const bool four = (unsigned)(lxi - 1) < 4u;  // xi 1..4: fourth tap d4 with coefficient 1
-        c0 = (x0 | x5 | (lxi == 2)) ? 4.f : (lxi == 1 ? -4.f : (lxi == 3 ? -2.f : 2.f));
-        c1 = (x0 | x5) ? -5.f : (lxi < 3 ? -4.f : -1.f);
-        c2 = (x0 | x5 | (lxi == 1)) ? 1.f : (lxi == 2 ? -1.f : (lxi == 3 ? 2.f : -2.f));
-        const unsigned dead = lxi < xi_end ? 0u : OOB;                 // past the last slice: zeros
+        const unsigned sh4 = 4u * (unsigned)lxi;                      // lxi <= 7
+        const unsigned j0 = (TJ0 >> sh4) & 15u, j1 = (TJ1 >> sh4) & 15u, j2 = (TJ2 >> sh4) & 15u;
+        c0 = (float)((int)((TC0 >> sh4) & 15u) - 8);
+        c1 = (float)((int)((TC1 >> sh4) & 15u) - 8);
+        c2 = (float)((int)((TC2 >> sh4) & 15u) - 8);
+        const unsigned four = (FOUR >> lxi) & 1u;
+        const unsigned dead = (unsigned)(lxi >= xi_end) << 31;        // past the last slice: zeros
         const unsigned rowbit = 1u << lr;
         const unsigned base = (unsigned)((((lr - 1) * W - 1) * Cin + lcib) * 4) + kvb + dead;   // column d0
         const unsigned cs = (unsigned)Cin * 4u;
         const unsigned s0 = base + j0 * cs, s1 = base + j1 * cs, s2 = base + j2 * cs, s3 = base + 4 * cs;
-        const unsigned n0_ = rowbit | colbit(j0), n1_ = rowbit | colbit(j1), n2_ = rowbit | colbit(j2);
-        const unsigned n3_ = four ? (rowbit | colbit(4)) : 0xFFFFFFFFu;   // never satisfied -> zero
+        const unsigned n0_ = rowbit | (unsigned)((COLBIT >> (8u * j0)) & 0xFFu);
+        const unsigned n1_ = rowbit | (unsigned)((COLBIT >> (8u * j1)) & 0xFFu);
+        const unsigned n2_ = rowbit | (unsigned)((COLBIT >> (8u * j2)) & 0xFFu);
+        const unsigned n3_ = (rowbit | 0x40u) | (four - 1u);           // no fourth tap: never satisfied -> zero
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const unsigned a = arow[i], o = a & ~0xFFu;
@@ -202,6 +208,22 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino4(
     const int rowbase = m0 + wm * TM * 32;
     const bool full = (m0 + BM <= Mt) && (n0 + BN <= ldm);
 
+    // Instruction order inside a K step, imposed on the scheduler (left alone, hipcc sinks all loads of the step below its
+    // MFMAs and consumes them at the top of the next step: a quarter of a step in flight).  16 MFMAs; the 8 LDS stores of
+    // the next slice (each waits for its loads, issued a whole step earlier) under 16 MFMAs; the 4*NA+NB loads of the slice
+    // after that, one per MFMA; the remaining MFMAs.   masks: 0x008 MFMA, 0x020 VMEM read, 0x200 DS write
+#define CVK_WINO4_PIPELINE()                                                  \
+    do {                                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < NA + NB; ++q_) {              \
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                \
+            __builtin_amdgcn_sched_group_barrier(0x008, 16 / (NA + NB), 0);   \
+        }                                                                     \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4 * NA + NB; ++q_) {          \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
+        }                                                                     \
+    } while (0)
 #define CVK_WINO4_STEP(cur, nxt)                      \
     do {                                              \
         mma_kk(cur + aro, cur + bro, 0);              \
@@ -210,6 +232,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino4(
         issue();                     /* slice ks+2 */ \
         mma_kk(cur + aro, cur + bro, 2);              \
         mma_kk(cur + aro, cur + bro, 3);              \
+        CVK_WINO4_PIPELINE();                         \
         __syncthreads();                              \
     } while (0)
 
@@ -245,6 +268,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino4(
         }
     }
 #undef CVK_WINO4_STEP
+#undef CVK_WINO4_PIPELINE
 }
 
 // y[pixel][c] = A^T-combination of M_0..5 + bias; BatchNorm statistics partials per 64-pixel granule (as k_wino_output).
