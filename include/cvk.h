@@ -114,6 +114,12 @@ int cvk_conv3x3_wino4_gemm(const float* x, const float* U, float* Mo, int N, int
 int cvk_wino4_output(const float* Mo, const float* bias, float* y, float* stats, int N, int H, int W, int Cout, int ldy,
                      void* stream);
 
+/* weight-grad through the transposed F(4,3) (contract of cvk_conv3x3_wgrad; the workspace also holds the transformed
+ * output-gradient planes E1..E4, float[4][N*H*ceil(W/4)][ld_dy], hence the extra ld_dy argument of the size query) */
+size_t cvk_conv3x3_wgrad_wino4_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout, int ld_dy);
+int cvk_conv3x3_wgrad_wino4(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,
+                            int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream);
+
 /* weight-grad through the transposed F(2,3) (same contract as cvk_conv3x3_wgrad; any Cin_pad % 4 == 0) */
 size_t cvk_conv3x3_wgrad_wino_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout);
 int cvk_conv3x3_wgrad_wino(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,

@@ -354,6 +354,308 @@ __global__ __launch_bounds__(256) void k_wino4_output(const float* __restrict__ 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ weight-grad
+// Transposed F(4,3):  dW[co][r][0..2][ci] = G^T [ (A dy) (.) (B^T d) ]  summed over groups of four columns, with
+//   E = A dy:  E0 = dy0, E1 = dy0+dy1+dy2+dy3, E2 = dy0-dy1+dy2-dy3, E3 = dy0+2dy1+4dy2+8dy3, E4 = dy0-2dy1+4dy2-8dy3, E5 = dy3
+//   (dy_i = output gradient at column 4t+i, zero beyond the right edge),  V = B^T d as in the forward kernel, and per xi one
+//   implicit GEMM  P_xi[Cout][3*Cin] = E_xi^T[tiles][Cout] * V_xi[tiles][3*Cin]  over N*H*ceil(W/4) tiles: 6 GEMM units per
+//   4 columns = 9*M*Cin*Cout executed FLOPs instead of 18 (wino.hip's transposed F(2,3): 12).
+// Transforming both operands on the fly would need 8 taps per K element pair (128 staging VGPRs); instead E1..E4 are
+// written once by k_wino4_dy_transform (an HBM pass of 2x the dy bytes) and read back as plain rows, E0/E5 are columns of
+// dy itself, and only V is transformed in the staging path (four taps, three FMAs).  Slices, grid and slab reduction as
+// in wino.hip's k_wgrad_wino.
+__global__ void k_wino4_dy_transform(const float* __restrict__ DY, int ld, float* __restrict__ E, int NH, int W, int Wt) {
+    const int cvn = ld / 4;
+    const size_t total = (size_t)NH * Wt * cvn;
+    const size_t plane = (size_t)NH * Wt * ld;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cvn);
+        const size_t t = i / cvn;                       // row * Wt + xt
+        const int xt = (int)(t % Wt);
+        const size_t row = t / Wt;
+        const float* p = DY + (row * W + 4 * (size_t)xt) * ld + cv * 4;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(p);
+        const f32x4 d1 = 4 * xt + 1 < W ? *reinterpret_cast<const f32x4*>(p + ld) : z;
+        const f32x4 d2 = 4 * xt + 2 < W ? *reinterpret_cast<const f32x4*>(p + 2 * ld) : z;
+        const f32x4 d3 = 4 * xt + 3 < W ? *reinterpret_cast<const f32x4*>(p + 3 * ld) : z;
+        float* o = E + t * ld + cv * 4;
+        const f32x4 a = d0 + d2, b = d1 + d3, c = d0 + 4.f * d2, d = 2.f * d1 + 8.f * d3;
+        *reinterpret_cast<f32x4*>(o) = a + b;
+        *reinterpret_cast<f32x4*>(o + plane) = a - b;
+        *reinterpret_cast<f32x4*>(o + 2 * plane) = c + d;
+        *reinterpret_cast<f32x4*>(o + 3 * plane) = c - d;
+    }
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool MULTIROW, int L>
+__global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino4(
+    const float* __restrict__ X, const float* __restrict__ DY, const float* __restrict__ E, float* __restrict__ slab, int NH,
+    int H, int W, int Wt, int Cin, int Cout, int ld_dy, int K3, int chunk, int tilesN, int Mpix, int ntiles, int nslices,
+    int S, int R) {
+    constexpr int NT = WARPS_M * WARPS_N * 64;
+    constexpr int TM = BM / WARPS_M / 32, TN = BN / WARPS_N / 32;
+    constexpr int VA = BM / 4, VB = BN / 4;
+    constexpr int RPA = NT / VA, RPB = NT / VB;
+    constexpr int NA = BK / RPA, NB = BK / RPB;
+    constexpr int STAGE = BK * (BM + BN);
+    static_assert(NA >= 1 && NB >= 1 && BK % RPA == 0 && BK % RPB == 0, "tile/threads mismatch");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+
+    // 1-D grid, XCD-remapped, pixel-range (split) major: the (tile, xi) workgroups of one range share its lines in one L2
+    const int gid = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int inner = ntiles * 6;
+    const int split = gid / inner, rem_ = gid - split * inner;
+    const int tile = rem_ / 6, xi = rem_ - tile * 6;
+    const int c0 = (tile / tilesN) * BM;
+    const int n0 = (tile % tilesN) * BN;
+    const int sbeg = split * chunk;
+    const int send = min(nslices, sbeg + chunk);
+
+    const FastDiv divS((unsigned)S), divH((unsigned)H), divWt((unsigned)Wt);
+    // operand windows (window_rsrc) start two image rows before the first row of this workgroup's slice range
+    const int rowb = max((int)divS.div((unsigned)sbeg) * R - 2, 0);
+    // E operand: xi 0 / 5 are columns 0 / 3 of the dy groups; xi 1..4 are rows of the transformed planes E[xi-1]
+    const bool from_dy = (xi == 0) | (xi == 5);
+    const int acol = xi == 5 ? 3 : 0;
+    const int RS = from_dy ? W : Wt, XS = from_dy ? 4 : 1;          // row / tile strides of the A operand, in pixels
+    const size_t Mt = (size_t)NH * Wt;
+    const __amdgpu_buffer_rsrc_t xr = window_rsrc(X, (size_t)rowb * W * Cin, (size_t)Mpix * Cin);
+    const __amdgpu_buffer_rsrc_t ar = from_dy ? window_rsrc(DY, (size_t)rowb * W * ld_dy, (size_t)Mpix * ld_dy)
+                                              : window_rsrc(E + (size_t)(xi - 1) * Mt * ld_dy, (size_t)rowb * Wt * ld_dy, Mt * ld_dy);
+
+    const int cva = tid % VA, pra = tid / VA;
+    const int cvb = tid % VB, prb = tid / VB;
+    const int coA = c0 + cva * 4;
+    const bool aok = coA < Cout;
+    const int colB = n0 + cvb * 4;
+    const bool bok = colB < K3;
+    const int rB = bok ? colB / Cin : 0;              // kernel row of this thread's column
+    const int ciB = colB - rB * Cin;
+    // input-transform taps of this xi: columns d_j (x column 4*xt - 1 + j) and coefficients; fourth tap d4 (coefficient 1) for xi 1..4
+    const int j0 = xi == 0 ? 0 : 1;
+    const int j1 = xi == 5 ? 3 : 2;
+    const int j2 = xi == 0 ? 4 : (xi == 5 ? 5 : 3);
+    const bool four = (unsigned)(xi - 1) < 4u;
+    const float c0f = (float)((int)((0x00CA6C4Cu >> (4 * xi)) & 15u) - 8);
+    const float c1f = (float)((int)((0x00377443u >> (4 * xi)) & 15u) - 8);
+    const float c2f = (float)((int)((0x0096A799u >> (4 * xi)) & 15u) - 8);
+
+    // per-thread tile constants inside a slice: row delta, column group, and the constant part of the byte offsets
+    int adr[NA], axt[NA], bdr[NB], bxt[NB];
+    unsigned aconst[NA], bconst[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int pr = pra + i * RPA;
+        adr[i] = (S > 1 || R == 1) ? 0 : (int)divWt.div((unsigned)pr);
+        axt[i] = pr - adr[i] * Wt;
+        if ((S == 1 && adr[i] >= R) || pr >= L) axt[i] = Wt;   // beyond the slice: never valid
+        aconst[i] = ((unsigned)(adr[i] * RS + XS * axt[i]) * (unsigned)ld_dy + (unsigned)coA) * 4u;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int pr = prb + i * RPB;
+        bdr[i] = (S > 1 || R == 1) ? 0 : (int)divWt.div((unsigned)pr);
+        bxt[i] = pr - bdr[i] * Wt;
+        if ((S == 1 && bdr[i] >= R) || pr >= L) bxt[i] = Wt;
+        bconst[i] = ((unsigned)((bdr[i] + rB - 1) * W + 4 * bxt[i]) * (unsigned)Cin + (unsigned)ciB) * 4u;
+    }
+
+    f32x4 ra[NA], rb0[NB], rb1[NB], rb2[NB], rb3[NB];   // one register stage: in flight for one whole K step
+    int ls = sbeg;                                       // next slice to load (uniform)
+
+    // slice -> uniform (first image row index row0 = n*H + y0, first column group xbase)
+    auto slice_origin = [&](int sl, int& row0, int& xbase, int& y0) {
+        const int q = (int)divS.div((unsigned)sl);     // S == 1: q = sl
+        row0 = q * R;                                  // S > 1  => R == 1
+        xbase = (sl - q * S) * L;
+        y0 = row0 - (int)divH.div((unsigned)row0) * H;
+    };
+    auto issue = [&]() {
+        int row0, xbase, y0;
+        slice_origin(ls, row0, xbase, y0);
+        const bool live = ls < send;
+        const int xlim = Wt - xbase, rlim = NH - row0;                       // uniform validity limits
+        const unsigned sA = (unsigned)(((row0 - rowb) * RS + XS * xbase + (from_dy ? acol : 0)) * ld_dy) * 4u;
+        const bool aon = aok & live;
+        const int wlimA = from_dy ? W - 4 * xbase - acol : 0x7FFFFFFF;        // need XS*axt < wlimA
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const bool ok = aon & (axt[i] < xlim) & (adr[i] < rlim) & (XS * axt[i] < wlimA);
+            ra[i] = buf_load16(ar, oob_unless(ok, aconst[i] + sA));
+        }
+        const unsigned sB = (unsigned)((((row0 - rowb) * W + 4 * xbase - 1) * Cin) * 4);   // column d0 of the slice's first group
+        const unsigned cs = (unsigned)Cin * 4u;
+        const int xoff = 4 * xbase - 1;
+        const bool bon = bok & live;
+        const bool rowok_uniform = (unsigned)(y0 + rB - 1) < (unsigned)H;    // exact when the slice is one image row
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            bool rowok = rowok_uniform;
+            if (MULTIROW) {                                                   // narrow frames only (compile-time)
+                const int yy = y0 + bdr[i];
+                const int y = yy - (int)divH.div((unsigned)yy) * H;
+                rowok = (unsigned)(y + rB - 1) < (unsigned)H;
+            }
+            const bool ok = bon & rowok & (bxt[i] < xlim) & (bdr[i] < rlim);
+            const int xc = 4 * bxt[i] + xoff;                                 // x column of d0
+            const unsigned o = bconst[i] + sB;
+            rb0[i] = buf_load16(xr, oob_unless(ok & ((unsigned)(xc + j0) < (unsigned)W), o + j0 * cs));
+            rb1[i] = buf_load16(xr, oob_unless(ok & ((unsigned)(xc + j1) < (unsigned)W), o + j1 * cs));
+            rb2[i] = buf_load16(xr, oob_unless(ok & ((unsigned)(xc + j2) < (unsigned)W), o + j2 * cs));
+            rb3[i] = buf_load16(xr, oob_unless(ok & four & ((unsigned)(xc + 4) < (unsigned)W), o + 4 * cs));
+        }
+        ++ls;
+    };
+    auto store_stage = [&](float* dst) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&dst[(pra + i * RPA) * BM + cva * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaf(c0f, rb0[i][j], fmaf(c1f, rb1[i][j], fmaf(c2f, rb2[i][j], rb3[i][j])));
+            *reinterpret_cast<f32x4*>(&dst[BK * BM + (prb + i * RPB) * BN + cvb * 4]) = v;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    auto mma_part = [&](const float* acol_, const float* bcol_, int s0, int s1) {
+#pragma unroll
+        for (int s = s0; s < s1; ++s) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) a[t] = acol_[2 * s * BM + t * 32];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b[t] = bcol_[2 * s * BN + t * 32];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+    };
+
+    const int nK = send - sbeg;
+    issue();
+    store_stage(smem);
+    issue();
+    __syncthreads();
+    const int aco = lh * BM + wm * TM * 32 + li;
+    const int bco = BK * BM + lh * BN + wn * TN * 32 + li;
+    float* const buf0 = smem;
+    float* const buf1 = smem + STAGE;
+    // imposed instruction order (128-row tile: 60-64 MFMAs per step): 16 MFMAs; the LDS stores under the next 16; the
+    // NA + 4*NB loads one per MFMA; the rest.   masks: 0x008 MFMA, 0x020 VMEM read, 0x200 DS write
+#define CVK_WW4_PIPELINE()                                                    \
+    if (TM * TN == 4) {                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < NA + NB; ++q_) {              \
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                \
+            __builtin_amdgcn_sched_group_barrier(0x008, 16 / (NA + NB), 0);   \
+        }                                                                     \
+        _Pragma("unroll") for (int q_ = 0; q_ < NA + 4 * NB; ++q_) {          \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
+        }                                                                     \
+    }
+#define CVK_WW4_STEP(cur, nxt)                      \
+    do {                                            \
+        mma_part(cur + aco, cur + bco, 0, 8);       \
+        store_stage(nxt);            /* slice ks+1 */ \
+        issue();                     /* slice ks+2 */ \
+        mma_part(cur + aco, cur + bco, 8, L / 2);   \
+        CVK_WW4_PIPELINE();                         \
+        __syncthreads();                            \
+    } while (0)
+    int ks = 0;
+    for (; ks + 2 <= nK; ks += 2) {
+        CVK_WW4_STEP(buf0, buf1);
+        CVK_WW4_STEP(buf1, buf0);
+    }
+    if (ks < nK) CVK_WW4_STEP(buf0, buf1);
+#undef CVK_WW4_STEP
+#undef CVK_WW4_PIPELINE
+
+    float* out = slab + ((size_t)split * 6 + xi) * Cout * K3;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = n0 + wn * TN * 32 + tn * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < Cout && col < K3) out[(size_t)row * K3 + col] = acc[tm][tn][r];
+            }
+        }
+}
+
+// dw[co][r][s][ci] from the slabs: P_xi = sum over splits (fixed order), then G^T
+__global__ void k_wgrad_wino4_reduce(const float* __restrict__ slab, float* __restrict__ dw, int splits, int Cout, int Cin,
+                                     int Cin_pad) {
+    const size_t total = (size_t)Cout * 3 * Cin;
+    const size_t plane = (size_t)Cout * 3 * Cin_pad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        const size_t cr = i / Cin;  // co*3 + r
+        const float* p = slab + cr * Cin_pad + ci;
+        float P[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < splits; ++s) {
+#pragma unroll
+            for (int x = 0; x < 6; ++x) P[x] += p[((size_t)s * 6 + x) * plane];
+        }
+        const float s12 = P[1] + P[2], d12 = P[2] - P[1], s34 = P[3] + P[4], d34 = P[3] - P[4];
+        float* o = dw + (cr * 3) * Cin + ci;
+        o[0] = 0.25f * P[0] - s12 * (1.f / 6.f) + s34 * (1.f / 24.f);
+        o[Cin] = d12 * (1.f / 6.f) + d34 * (1.f / 12.f);
+        o[2 * (size_t)Cin] = (s34 - s12) * (1.f / 6.f) + P[5];
+    }
+}
+
+struct WW4Plan { int bm, tilesM, tilesN, splits, chunk, nslices, S, R, L; };
+WW4Plan plan_wgrad_wino4(int NH, int Wt, int Cin_pad, int Cout) {
+    WW4Plan p;
+    p.bm = Cout > 64 ? 128 : 64;
+    p.tilesM = cvk_cdiv(Cout, p.bm);
+    p.tilesN = cvk_cdiv(3 * Cin_pad, 128);
+    auto useful = [&](int L) { return Wt >= L ? (double)Wt / ((double)cvk_cdiv(Wt, L) * L) : (double)((L / Wt) * Wt) / L; };
+    p.L = useful(30) > useful(32) + 1e-9 ? 30 : 32;
+    p.S = Wt >= p.L ? cvk_cdiv(Wt, p.L) : 1;               // slices per image row (wide frames)
+    p.R = Wt >= p.L ? 1 : p.L / Wt;                        // whole image rows per slice (narrow frames)
+    p.nslices = Wt >= p.L ? NH * p.S : cvk_cdiv(NH, p.R);
+    const int units = p.tilesM * p.tilesN * 6;
+    const int max_splits = p.nslices / 16 > 0 ? p.nslices / 16 : 1;
+    int best = 1;
+    double best_eff = -1.0;
+    for (int s = 1; s <= max_splits && s <= 2048; ++s) {
+        const long blocks = (long)units * s;
+        if (blocks > 4096 && s > 1) break;
+        if (blocks < 512 && s < max_splits) continue;
+        const long rounds = (blocks + 255) / 256;
+        const double eff = (double)blocks / (256.0 * rounds);
+        if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
+    }
+    p.splits = best;
+    p.chunk = cvk_cdiv(p.nslices, p.splits);               // slices per split
+    p.splits = cvk_cdiv(p.nslices, p.chunk);
+    return p;
+}
+
 }  // namespace
 
 extern "C" int cvk_wino4_weight_transform(const float* w, float* U, int Cout, int Cin, void* stream) {
@@ -410,4 +712,62 @@ extern "C" int cvk_wino4_output(const float* Mo, const float* bias, float* y, fl
     else
         hipLaunchKernelGGL(k_wino4_output<false>, grid, dim3(256), 0, s, Mo, ldy, Mt, bias, y, ldy, stats, P, Mpix, H, W, Wt, ldy, Cout);
     CVK_LAUNCH_RETURN("cvk_wino4_output");
+}
+
+extern "C" size_t cvk_conv3x3_wgrad_wino4_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout, int ld_dy) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin_pad <= 0 || Cout <= 0 || ld_dy < Cout) return 0;
+    const int Wt = (W + 3) / 4;
+    const WW4Plan p = plan_wgrad_wino4(N * H, Wt, Cin_pad, Cout);
+    return ((size_t)4 * N * H * Wt * ld_dy + (size_t)p.splits * 6 * Cout * 3 * Cin_pad) * sizeof(float);
+}
+
+extern "C" int cvk_conv3x3_wgrad_wino4(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,
+                                       int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream) {
+    CVK_CHECK_ARG(x && dy && dw && workspace, "cvk_conv3x3_wgrad_wino4: null pointer");
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin_pad >= Cin, "cvk_conv3x3_wgrad_wino4: bad shape");
+    CVK_CHECK_ARG(Cin_pad % 4 == 0 && ld_dy % 4 == 0 && ld_dy >= Cout, "cvk_conv3x3_wgrad_wino4: Cin_pad and ld_dy must be multiples of 4, ld_dy >= Cout");
+    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(dy) && cvk_aligned16(workspace), "cvk_conv3x3_wgrad_wino4: pointers must be 16-byte aligned");
+    CVK_CHECK_ARG((long)N * H * W < (1L << 31) - 512, "cvk_conv3x3_wgrad_wino4: tensor too large for 32-bit pixel indices");
+    const int Wt = (W + 3) / 4, Mpix = N * H * W, K3 = 3 * Cin_pad;
+    CVK_CHECK_ARG((long)N * H * H < (1L << 32) && (long)N * H * Wt < (1L << 31), "cvk_conv3x3_wgrad_wino4: frame too large for the multiply-high coordinate split");
+    const WW4Plan p = plan_wgrad_wino4(N * H, Wt, Cin_pad, Cout);
+    {   // x, dy and E may exceed 2 GiB: a workgroup addresses only the image rows of its own slice range (window_rsrc)
+        const long rows = (p.S > 1 ? p.chunk / p.S + 2 : (long)p.chunk * p.R) + 4;
+        CVK_CHECK_ARG(rows * W * (Cin_pad > ld_dy ? Cin_pad : ld_dy) * 4 < (1L << 31), "cvk_conv3x3_wgrad_wino4: one slice range exceeds the 2 GiB buffer-addressing limit");
+    }
+    const size_t e_floats = (size_t)4 * N * H * Wt * ld_dy;
+    const size_t need = (e_floats + (size_t)p.splits * 6 * Cout * K3) * sizeof(float);
+    if (workspace_bytes < need) {
+        cvk_set_error("cvk_conv3x3_wgrad_wino4: workspace %zu < %zu bytes", workspace_bytes, need);
+        return CVK_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float* E = (float*)workspace;
+    float* slab = E + e_floats;
+    {
+        const size_t total = (size_t)N * H * Wt * (ld_dy / 4);
+        const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+        hipLaunchKernelGGL(k_wino4_dy_transform, dim3(blocks), dim3(256), 0, s, dy, ld_dy, E, N * H, W, Wt);
+    }
+    dim3 grid(p.tilesM * p.tilesN * p.splits * 6);
+#define CVK_WW4_LAUNCH(BM_, MR_, L_)                                                                                                       \
+    hipLaunchKernelGGL((k_wgrad_wino4<BM_, 128, 2, 2, MR_, L_>), grid, dim3(256), 0, s, x, dy, E, slab, N * H, H, W, Wt, Cin_pad, Cout, ld_dy, \
+                       K3, p.chunk, p.tilesN, Mpix, p.tilesM * p.tilesN, p.nslices, p.S, p.R)
+#define CVK_WW4_PICK(BM_)                                                                         \
+    do {                                                                                          \
+        if (p.L == 30) { if (p.R > 1) CVK_WW4_LAUNCH(BM_, true, 30); else CVK_WW4_LAUNCH(BM_, false, 30); } \
+        else { if (p.R > 1) CVK_WW4_LAUNCH(BM_, true, 32); else CVK_WW4_LAUNCH(BM_, false, 32); }           \
+    } while (0)
+    if (p.bm == 128) CVK_WW4_PICK(128); else CVK_WW4_PICK(64);
+#undef CVK_WW4_PICK
+#undef CVK_WW4_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        cvk_set_error("cvk_conv3x3_wgrad_wino4: launch failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    const size_t total = (size_t)Cout * 3 * Cin;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_wgrad_wino4_reduce, dim3(blocks), dim3(256), 0, s, slab, dw, p.splits, Cout, Cin, Cin_pad);
+    CVK_LAUNCH_RETURN("cvk_conv3x3_wgrad_wino4");
 }

@@ -88,6 +88,15 @@ def main():
             wsb = lib.cvk_conv3x3_wgrad_wino_workspace_bytes(N, H, W, ci, co); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             t = timeit(lambda: check(lib.cvk_conv3x3_wgrad_wino(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, H, W, ci, ci, co, ldy, ws.data_ptr(), wsb, s)))
             row += f" wwino {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["wwino"][0] += flops; tot["wwino"][1] += t
+        if "wwino4" in which and ci >= 32 and co > 32:
+            dy = torch.randn(M, ldy, device=dev); dw4 = torch.empty(co, 9 * ci, device=dev)
+            wsb = lib.cvk_conv3x3_wgrad_wino4_workspace_bytes(N, H, W, ci, co, ldy); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            t = timeit(lambda: check(lib.cvk_conv3x3_wgrad_wino4(x.data_ptr(), dy.data_ptr(), dw4.data_ptr(), N, H, W, ci, ci, co, ldy, ws.data_ptr(), wsb, s)))
+            dwr = torch.empty(co, 9 * ci, device=dev)
+            wsb2 = lib.cvk_conv3x3_wgrad_wino_workspace_bytes(N, H, W, ci, co); ws2 = torch.empty(wsb2, dtype=torch.uint8, device=dev)
+            check(lib.cvk_conv3x3_wgrad_wino(x.data_ptr(), dy.data_ptr(), dwr.data_ptr(), N, H, W, ci, ci, co, ldy, ws2.data_ptr(), wsb2, s))
+            err = (dw4 - dwr).abs().max().item() / dwr.abs().max().item()
+            row += f" wwino4 {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF err {err:.1e}"; tot["wwino4"][0] += flops; tot["wwino4"][1] += t
         if "wbf16" in which and co > 32:
             dy = torch.randn(M, ldy, device=dev); dw = torch.empty(co, 9 * ci, device=dev)
             wsb = lib.cvk_conv3x3_wgrad_bf16_workspace_bytes(N, H, W, ci, co); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
