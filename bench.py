@@ -18,6 +18,7 @@ Extra objects on the line:
                  box), batch 2, rank 0 at N=1 only.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -177,12 +178,13 @@ def main():
         executed = 0.5 if "wino4" in dom[0] else ((2.0 / 3.0) if "wino" in dom[0] else 1.0)   # F(4,3): 9 of 18; F(2,3): 12 of 18
         peak = PEAK_BF16_MFMA_TFLOPS if ("bf16" in dom[0] and "split" not in dom[0]) else PEAK_F32_MFMA_TFLOPS
         traffic = None
-        tp = os.path.join(ROOT, "profiles", "r01_d_pmc_hbm_traffic.json")
+        tp = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))[-1:]
+        tp = tp[0] if tp else ""
         if os.path.exists(tp):
             for k, v in json.load(open(tp)).items():
                 if k.replace(" ", "") == dom[0].replace(" ", ""):
                     traffic = {"bytes_per_launch": (v["read_MB_per_launch"] + v["write_MB_per_launch"]) * 1e6,
-                               "source": "profiles/r01_d_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                               "source": "profiles/" + os.path.basename(tp) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                                          "FETCH doubled per MI355X_MICROARCH.md; recorded run, not this run)"}
         roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic,

@@ -681,8 +681,14 @@ extern "C" int cvk_conv3x3_wino4_gemm(const float* x, const float* U, float* Mo,
     CVK_CHECK_ARG((long)(2 * W + 520) * Cin * 4 < (1L << 31) && (long)6 * Cout * 3 * Cin * 4 < (1L << 31), "cvk_conv3x3_wino4_gemm: a tile's input window or the weight tensor exceeds the 2 GiB buffer-addressing limit");
     const int Wt = (W + 3) / 4, Mt = N * H * Wt, Mpix = N * H * W, ldy = ldm;
     hipStream_t s = (hipStream_t)stream;
+    // Tiles are dealt to the 256 CUs in whole rounds as six-index blocks; the remainder is cut into single-index blocks.
+    // Everything is cut that way for deep layers with few tiles but long K, and for <= 64 output columns with Cin >= 128:
+    // there a block's input footprint per index (3 rows x 512 pixels x Cin) is re-read six times and the 64 blocks of an XCD
+    // overflow its 4 MB L2 (PMC: 3.6 GB fetched per launch for a 0.7 GB input) — the six single-index blocks of a tile are
+    // neighbours on one XCD and run at the same time, so five of the six reads hit L2 (-17 % time on the 128->64 layers).
     auto full_tiles = [&](int tiles) {
         if (tiles < 1024 && Cin >= 256) return 0;
+        if (ldy <= 64 && Cin >= 128) return 0;
         return tiles / 256 * 256;
     };
     if (ldy > 64) {

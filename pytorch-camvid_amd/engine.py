@@ -97,9 +97,9 @@ def wino_ok(R, k_ch, n_cols):
 def wino4_pays(N, H, W, k_ch, n_cols):
     """F(4,3) or F(2,3) for this layer?  Both kernels do the same work per workgroup (3*k_ch/32 K steps of a 128-row
     tile); F(4,3) needs 6 workgroups per 4 columns, F(2,3) 8, so it wins whenever the grid is large.  It does not pay
-    (measured, tools/bench_conv.py wino wino4) for 64-column tiles with k_ch >= 128 (the four-tap staging of the 128-row
-    operand outweighs the halved MFMA work per slice) and when the 256-CU round count does not drop (few tiles)."""
-    if n_cols <= 32 or (n_cols <= 64 and k_ch >= 128):
+    (measured, tools/bench_conv.py wino wino4) for <= 32 columns (the logits layer) and when the 256-CU round count does
+    not drop (few tiles)."""
+    if n_cols <= 32:
         return False
     tn = -(-n_cols // 128) if n_cols > 64 else 1
 

@@ -23,7 +23,8 @@ def _chunks(n, k):
     return [(i, min(n, i + k)) for i in range(0, n, k)]
 
 
-@pytest.mark.parametrize("cfg", [dict(N=50, C=64, Co=64, wino=True), dict(N=100, C=32, Co=32, wino=False)])
+@pytest.mark.parametrize("cfg", [dict(N=50, C=64, Co=64, wino=True), dict(N=100, C=32, Co=32, wino=False),
+                                 dict(N=50, C=64, Co=128, wino=4)])
 def test_conv_raw_abi_beyond_2gib(cfg):
     from pytorch_camvid_amd import _lib
     from pytorch_camvid_amd._lib import check
@@ -43,7 +44,13 @@ def test_conv_raw_abi_beyond_2gib(cfg):
         y = torch.empty(n, H, W, Co, device=dev())
         p = (n * H * W + 63) // 64
         st = torch.empty(2 * p * Co, device=dev())
-        if wino:
+        if wino == 4:
+            U = torch.empty(6 * Co * 3 * C, device=dev())
+            check(lib.cvk_wino4_weight_transform(w.data_ptr(), U.data_ptr(), Co, C, s))
+            Mo = torch.empty(lib.cvk_conv3x3_wino4_workspace_bytes(n, H, W, Co) // 4, device=dev())
+            check(lib.cvk_conv3x3_wino4_gemm(xs.data_ptr(), U.data_ptr(), Mo.data_ptr(), n, H, W, C, Co, Co, s))
+            check(lib.cvk_wino4_output(Mo.data_ptr(), bias.data_ptr(), y.data_ptr(), st.data_ptr(), n, H, W, Co, Co, s))
+        elif wino:
             U = torch.empty(4 * Co * 3 * C, device=dev())
             check(lib.cvk_wino_weight_transform(w.data_ptr(), U.data_ptr(), Co, C, s))
             Mo = torch.empty(lib.cvk_conv3x3_wino_workspace_bytes(n, H, W, Co) // 4, device=dev())
@@ -55,9 +62,13 @@ def test_conv_raw_abi_beyond_2gib(cfg):
 
     def wgrad(xs, dys, n):
         dw = torch.empty(Co, 3, 3, C, device=dev())
-        f_ws, f = (lib.cvk_conv3x3_wgrad_wino_workspace_bytes, lib.cvk_conv3x3_wgrad_wino) if wino else \
-                  (lib.cvk_conv3x3_wgrad_workspace_bytes, lib.cvk_conv3x3_wgrad)
-        wsb = f_ws(n, H, W, C, Co)
+        if wino == 4:
+            wsb = lib.cvk_conv3x3_wgrad_wino4_workspace_bytes(n, H, W, C, Co, Co)
+            f = lib.cvk_conv3x3_wgrad_wino4
+        else:
+            f_ws, f = (lib.cvk_conv3x3_wgrad_wino_workspace_bytes, lib.cvk_conv3x3_wgrad_wino) if wino else \
+                      (lib.cvk_conv3x3_wgrad_workspace_bytes, lib.cvk_conv3x3_wgrad)
+            wsb = f_ws(n, H, W, C, Co)
         ws = torch.empty(wsb // 4, device=dev())
         check(f(xs.data_ptr(), dys.data_ptr(), dw.data_ptr(), n, H, W, C, C, Co, Co, ws.data_ptr(), wsb, s))
         return dw
