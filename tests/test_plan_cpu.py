@@ -76,3 +76,17 @@ def test_kernel_name_mirror():
     assert engine.conv_kernel_name("dgrad", 64, 12) == "k_conv3x3_igemm<128, 64, 2, 2, false, false>"
     assert engine.conv_kernel_name("wgrad", 64, 4) == "k_conv3x3_wgrad<64, 64, 2, 2>"
     assert engine.conv_kernel_name("wgrad", 12, 64) == "k_conv3x3_wgrad<32, 256, 1, 4>"
+    assert engine.conv_kernel_name("wino4", 128) == "k_conv3x3_wino4<128, 128, 2, 2>"
+    assert engine.conv_kernel_name("wino4", 64) == "k_conv3x3_wino4<128, 64, 2, 2>"
+
+
+def test_winograd_variant_choice_per_layer():
+    """engine.wino4_pays: F(4,3) wherever the 256-CU round count drops, F(2,3) for the 22x30 bottleneck of the batch-8
+    workload and for the 12-column head; tiny geometries (the goldens) stay on F(2,3) unless a test forces "always"."""
+    pays = engine.wino4_pays
+    assert pays(8, 360, 480, 64, 64) and pays(8, 360, 480, 128, 64) and pays(8, 180, 240, 128, 128)
+    assert pays(8, 90, 120, 256, 256) and pays(8, 45, 60, 512, 512) and pays(8, 44, 60, 1024, 512)
+    assert not pays(8, 22, 30, 512, 1024) and not pays(8, 22, 30, 1024, 1024)      # 528 vs 672 workgroups: both 3 rounds
+    assert not pays(8, 360, 480, 64, 12)                                           # the logits layer
+    assert not pays(2, 6, 8, 512, 512) and not pays(1, 45, 60, 64, 64)             # golden-sized layers
+    assert pays(50, 360, 480, 64, 64)                                              # large batches
