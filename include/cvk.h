@@ -106,13 +106,17 @@ int cvk_wino_output(const float* Mo, const float* bias, float* y, float* stats, 
                     void* stream);
 
 /* The same three steps through 1-D Winograd F(4,3) (2x fewer MFMA FLOPs than the direct form; csrc/wino4.hip):
- *   U [6][Cout][3][Cin],  Mo float[6][N*H*ceil(W/4)][ldm],  otherwise the contract of the F(2,3) calls above. */
+ *   U [6][Cout][3][Cin],  Mo float[ksplit][6][N*H*ceil(W/4)][ldm],  otherwise the contract of the F(2,3) calls above.
+ * Layers with few tiles split the K = 3*Cin reduction over ksplit = cvk_conv3x3_wino4_ksplit(...) in {1,2,3} workgroups per
+ * transform index (a fixed function of the shape); the partial planes are summed by cvk_wino4_output, which takes that
+ * ksplit, and the workspace size query accounts for them. */
 int cvk_wino4_weight_transform(const float* w, float* U, int Cout, int Cin, void* stream);
-size_t cvk_conv3x3_wino4_workspace_bytes(int N, int H, int W, int Cout_ld);
+int cvk_conv3x3_wino4_ksplit(int N, int H, int W, int Cin, int Cout_ld);
+size_t cvk_conv3x3_wino4_workspace_bytes(int N, int H, int W, int Cin, int Cout_ld);
 int cvk_conv3x3_wino4_gemm(const float* x, const float* U, float* Mo, int N, int H, int W, int Cin, int Cout, int ldm,
                            void* stream);
 int cvk_wino4_output(const float* Mo, const float* bias, float* y, float* stats, int N, int H, int W, int Cout, int ldy,
-                     void* stream);
+                     int ksplit, void* stream);
 
 /* weight-grad through the transposed F(4,3) (contract of cvk_conv3x3_wgrad; the workspace also holds the transformed
  * output-gradient planes E1..E4, float[4][N*H*ceil(W/4)][ld_dy], hence the extra ld_dy argument of the size query) */

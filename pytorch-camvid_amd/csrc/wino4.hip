@@ -43,7 +43,7 @@ __global__ void k_wino4_weight(const float* __restrict__ w, float* __restrict__ 
 template <int BM, int BN, int WARPS_M, int WARPS_N>
 __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino4(
     const float* __restrict__ X, const float* __restrict__ U, float* __restrict__ Mo, int Mt, int H, int W, int Wt,
-    int Cin, int Cout, int ldm, int tilesN, int Mpix, int nfull) {
+    int Cin, int Cout, int ldm, int tilesN, int Mpix, int nfull, int ksplit) {
     constexpr int NT = WARPS_M * WARPS_N * 64;
     constexpr int TM = BM / WARPS_M / 32, TN = BN / WARPS_N / 32;
     constexpr int RP = NT / 8;
@@ -59,22 +59,27 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino4(
     const int wm = wave / WARPS_N, wn = wave % WARPS_N;
 
     // 1-D grid in two regions (as in wino.hip): blocks [0, nfull) own one tile each and walk all six transform indices;
-    // the remaining tiles are cut into six single-index blocks (finer last dispatch round).
-    int tile, xi_begin, xi_end;
+    // the remaining tiles are cut into six single-index blocks (finer last dispatch round), and each of those into
+    // `ksplit` blocks over equal parts of the K = 3*Cin reduction (layers with few tiles: the partial planes M[kp][xi]
+    // are summed by k_wino4_output).  The 6*ksplit blocks of a tile are neighbours (same pixels -> one L2).
+    int tile, xi_begin, xi_end, kp = 0;
     if ((int)blockIdx.x < nfull) {
         tile = cvk_xcd_remap(blockIdx.x, nfull);
         xi_begin = 0;
         xi_end = 6;
     } else {
         const int r = cvk_xcd_remap(blockIdx.x - nfull, gridDim.x - nfull);
-        tile = nfull + r / 6;
-        xi_begin = r - (r / 6) * 6;
+        const int per = 6 * ksplit;
+        const int q = r / per, rem = r - q * per;
+        tile = nfull + q;
+        xi_begin = rem / ksplit;
+        kp = rem - xi_begin * ksplit;
         xi_end = xi_begin + 1;
     }
     const int m0 = (tile / tilesN) * BM;
     const int n0 = (tile % tilesN) * BN;
     const int K3 = 3 * Cin;
-    const int nK = K3 / BK;   // even by contract (Cin % 64 == 0)
+    const int nK = K3 / BK / ksplit;   // K steps of this block per transform index; even by contract
 
     // input window (window_rsrc): starts one image row + one pixel before the first column group of this tile
     const int pb = max((m0 / Wt) * W + 4 * (m0 % Wt) - W - 1, 0);
@@ -117,7 +122,10 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino4(
     // that consumed the previous slice, i.e. they are in flight for one whole K step.
     f32x4 ra0[NA], ra1[NA], ra2[NA], ra3[NA], rb[NB];
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;              // V = c0*a0 + c1*a1 + c2*a2 + a3 for the slice held in ra*
-    int lxi = xi_begin, lr = 0, lcib = 0;            // next slice to load (transform index, kernel row, channel base; uniform)
+    // next slice to load (transform index, kernel row, channel base; uniform) and the number of live slices left
+    const int k0 = kp * nK * BK;                     // first K element of this block's part
+    int lxi = xi_begin, lr = k0 / Cin, lcib = k0 - (k0 / Cin) * Cin;
+    int lleft = (xi_end - xi_begin) * nK;
 
     // Per-slice constants come from nibble tables indexed by the (uniform) transform index — pure SALU shifts, no
     // branches: the whole K step must stay one basic block so that the loads interleave with the MFMAs.
@@ -133,7 +141,8 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino4(
         c1 = (float)((int)((TC1 >> sh4) & 15u) - 8);
         c2 = (float)((int)((TC2 >> sh4) & 15u) - 8);
         const unsigned four = (FOUR >> lxi) & 1u;
-        const unsigned dead = (unsigned)(lxi >= xi_end) << 31;        // past the last slice: zeros
+        const unsigned dead = (unsigned)(lleft <= 0) << 31;           // past the last slice: zeros
+        --lleft;
         const unsigned rowbit = 1u << lr;
         const unsigned base = (unsigned)((((lr - 1) * W - 1) * Cin + lcib) * 4) + kvb + dead;   // column d0
         const unsigned cs = (unsigned)Cin * 4u;
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino4(
             CVK_WINO4_STEP(buf1, buf0);
         }
         // flush M_xi (the next xi's first slice is already in LDS) and restart the accumulators
-        float* out = Mo + (size_t)xi * Mt * ldm;
+        float* out = Mo + (size_t)(kp * 6 + xi) * Mt * ldm;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int col = n0 + wn * TN * 32 + tn * 32 + li;
@@ -276,10 +285,10 @@ template <bool STATS>
 __global__ __launch_bounds__(256) void k_wino4_output(const float* __restrict__ Mo, int ldm, int Mt,
                                                      const float* __restrict__ bias, float* __restrict__ Y, int ldy,
                                                      float* __restrict__ stats, int P, int Mpix, int H, int W, int Wt,
-                                                     int C, int Cout) {
+                                                     int C, int Cout, int ksplit, int chunk) {
     __shared__ float red[2][1024];
-    const int c0 = blockIdx.y * 1024;
-    const int cw = min(1024, C - c0);
+    const int c0 = blockIdx.y * chunk;              // chunk <= 1024 channels per block (256 for small layers: more blocks)
+    const int cw = min(chunk, C - c0);
     const int cvn = cw / 4, ppp = 256 / cvn;
     const int t = threadIdx.x;
     const bool active = t < cvn * ppp;
@@ -299,22 +308,23 @@ __global__ __launch_bounds__(256) void k_wino4_output(const float* __restrict__ 
             const int n = m / HW, rem = m - n * HW;
             const int y = rem / W, x = rem - y * W;
             const float* p = Mo + ((size_t)(n * H + y) * Wt + (x >> 2)) * ldm + c;
-            const f32x4 m1 = *reinterpret_cast<const f32x4*>(p + plane);
-            const f32x4 m2 = *reinterpret_cast<const f32x4*>(p + 2 * plane);
-            const f32x4 m3 = *reinterpret_cast<const f32x4*>(p + 3 * plane);
-            const f32x4 m4 = *reinterpret_cast<const f32x4*>(p + 4 * plane);
             const int i = x & 3;
+            // plane xi of this pixel's column group, summed over the K parts (fixed order)
+            auto mplane = [&](int xi) {
+                f32x4 a = *reinterpret_cast<const f32x4*>(p + (size_t)xi * plane);
+                for (int k = 1; k < ksplit; ++k) a += *reinterpret_cast<const f32x4*>(p + (size_t)(k * 6 + xi) * plane);
+                return a;
+            };
+            const f32x4 m1 = mplane(1), m2 = mplane(2), m3 = mplane(3), m4 = mplane(4);
             f32x4 v;
             if (i == 0) {
-                const f32x4 m0v = *reinterpret_cast<const f32x4*>(p);
-                v = m0v + (m1 + m2) + (m3 + m4);
+                v = mplane(0) + (m1 + m2) + (m3 + m4);
             } else if (i == 1) {
                 v = (m1 - m2) + 2.f * (m3 - m4);
             } else if (i == 2) {
                 v = (m1 + m2) + 4.f * (m3 + m4);
             } else {
-                const f32x4 m5 = *reinterpret_cast<const f32x4*>(p + 5 * plane);
-                v = (m1 - m2) + 8.f * (m3 - m4) + m5;
+                v = (m1 - m2) + 8.f * (m3 - m4) + mplane(5);
             }
             v += sh;
             *reinterpret_cast<f32x4*>(Y + (size_t)m * ldy + c) = v;
@@ -666,9 +676,44 @@ extern "C" int cvk_wino4_weight_transform(const float* w, float* U, int Cout, in
     CVK_LAUNCH_RETURN("cvk_wino4_weight_transform");
 }
 
-extern "C" size_t cvk_conv3x3_wino4_workspace_bytes(int N, int H, int W, int Cout_ld) {
-    if (N <= 0 || H <= 0 || W <= 0 || Cout_ld <= 0) return 0;
-    return (size_t)6 * N * H * ((W + 3) / 4) * Cout_ld * sizeof(float);
+// How a layer is cut into workgroups: number of six-index blocks (the rest are single-index) and the K split of those.
+struct W4Plan { int tilesN, tiles, nfull, ksplit; };
+static W4Plan plan_wino4(int N, int H, int W, int Cin, int ldy) {
+    W4Plan p;
+    const int Mt = N * H * ((W + 3) / 4);
+    p.tilesN = ldy > 64 ? cvk_cdiv(ldy, 128) : 1;
+    p.tiles = cvk_cdiv(Mt, 128) * p.tilesN;
+    // Tiles are dealt to the 256 CUs in whole rounds as six-index blocks; the remainder is cut into single-index blocks.
+    // Everything is cut that way for deep layers with few tiles but long K, and for <= 64 output columns with Cin >= 128:
+    // there a block's input footprint per index (3 rows x 512 pixels x Cin) is re-read six times and the 64 blocks of an XCD
+    // overflow its 4 MB L2 (PMC: 3.6 GB fetched per launch for a 0.7 GB input) — the six single-index blocks of a tile are
+    // neighbours on one XCD and run at the same time, so five of the six reads hit L2 (-17 % time on the 128->64 layers).
+    p.nfull = p.tiles / 256 * 256;
+    if ((p.tiles < 1024 && Cin >= 256) || (ldy <= 64 && Cin >= 128)) p.nfull = 0;
+    // Few single-index blocks (< 4 waves of the 512 resident workgroups): also split the K loop 2 or 3 ways when that
+    // fills the last wave better (the partial planes are small for such layers).  nK / ksplit must stay even.
+    p.ksplit = 1;
+    const long blocks = (long)p.tiles * 6;
+    if (p.nfull == 0 && blocks < 2048 && Cin >= 256) {
+        const int nK = 3 * Cin / BK;
+        double best = (double)blocks / (512.0 * cvk_cdiv(blocks, 512));
+        for (int f = 2; f <= 3; ++f) {
+            if (nK % (2 * f)) continue;
+            const double fill = (double)(blocks * f) / (512.0 * cvk_cdiv(blocks * f, 512));
+            if (fill > best + 0.08) { best = fill; p.ksplit = f; }
+        }
+    }
+    return p;
+}
+
+extern "C" int cvk_conv3x3_wino4_ksplit(int N, int H, int W, int Cin, int Cout_ld) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout_ld <= 0) return 0;
+    return plan_wino4(N, H, W, Cin, Cout_ld).ksplit;
+}
+
+extern "C" size_t cvk_conv3x3_wino4_workspace_bytes(int N, int H, int W, int Cin, int Cout_ld) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout_ld <= 0) return 0;
+    return (size_t)6 * plan_wino4(N, H, W, Cin, Cout_ld).ksplit * N * H * ((W + 3) / 4) * Cout_ld * sizeof(float);
 }
 
 extern "C" int cvk_conv3x3_wino4_gemm(const float* x, const float* U, float* Mo, int N, int H, int W, int Cin, int Cout,
@@ -681,42 +726,34 @@ extern "C" int cvk_conv3x3_wino4_gemm(const float* x, const float* U, float* Mo,
     CVK_CHECK_ARG((long)(2 * W + 520) * Cin * 4 < (1L << 31) && (long)6 * Cout * 3 * Cin * 4 < (1L << 31), "cvk_conv3x3_wino4_gemm: a tile's input window or the weight tensor exceeds the 2 GiB buffer-addressing limit");
     const int Wt = (W + 3) / 4, Mt = N * H * Wt, Mpix = N * H * W, ldy = ldm;
     hipStream_t s = (hipStream_t)stream;
-    // Tiles are dealt to the 256 CUs in whole rounds as six-index blocks; the remainder is cut into single-index blocks.
-    // Everything is cut that way for deep layers with few tiles but long K, and for <= 64 output columns with Cin >= 128:
-    // there a block's input footprint per index (3 rows x 512 pixels x Cin) is re-read six times and the 64 blocks of an XCD
-    // overflow its 4 MB L2 (PMC: 3.6 GB fetched per launch for a 0.7 GB input) — the six single-index blocks of a tile are
-    // neighbours on one XCD and run at the same time, so five of the six reads hit L2 (-17 % time on the 128->64 layers).
-    auto full_tiles = [&](int tiles) {
-        if (tiles < 1024 && Cin >= 256) return 0;
-        if (ldy <= 64 && Cin >= 128) return 0;
-        return tiles / 256 * 256;
-    };
-    if (ldy > 64) {
-        const int tilesN = cvk_cdiv(ldy, 128), tiles = cvk_cdiv(Mt, 128) * tilesN, nf = full_tiles(tiles);
-        hipLaunchKernelGGL((k_conv3x3_wino4<128, 128, 2, 2>), dim3(nf + 6 * (tiles - nf)), dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, Mpix, nf);
-    } else if (ldy > 32) {
-        const int tilesN = cvk_cdiv(ldy, 64), tiles = cvk_cdiv(Mt, 128) * tilesN, nf = full_tiles(tiles);
-        hipLaunchKernelGGL((k_conv3x3_wino4<128, 64, 2, 2>), dim3(nf + 6 * (tiles - nf)), dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, Mpix, nf);
-    } else {
-        const int tiles = cvk_cdiv(Mt, 128), nf = full_tiles(tiles);
-        hipLaunchKernelGGL((k_conv3x3_wino4<128, 32, 4, 1>), dim3(nf + 6 * (tiles - nf)), dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, 1, Mpix, nf);
-    }
+    const W4Plan p = plan_wino4(N, H, W, Cin, ldy);
+    const dim3 grid(p.nfull + 6 * p.ksplit * (p.tiles - p.nfull));
+    if (ldy > 64)
+        hipLaunchKernelGGL((k_conv3x3_wino4<128, 128, 2, 2>), grid, dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, p.tilesN, Mpix, p.nfull, p.ksplit);
+    else if (ldy > 32)
+        hipLaunchKernelGGL((k_conv3x3_wino4<128, 64, 2, 2>), grid, dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, p.tilesN, Mpix, p.nfull, p.ksplit);
+    else   // narrow heads: 32-column tiles, four 32x32 wave tiles stacked in M
+        hipLaunchKernelGGL((k_conv3x3_wino4<128, 32, 4, 1>), grid, dim3(256), 0, s, x, U, Mo, Mt, H, W, Wt, Cin, Cout, ldy, p.tilesN, Mpix, p.nfull, p.ksplit);
     CVK_LAUNCH_RETURN("cvk_conv3x3_wino4_gemm");
 }
 
 extern "C" int cvk_wino4_output(const float* Mo, const float* bias, float* y, float* stats, int N, int H, int W, int Cout,
-                                int ldy, void* stream) {
+                                int ldy, int ksplit, void* stream) {
     CVK_CHECK_ARG(Mo && y, "cvk_wino4_output: null pointer");
-    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout && ldy % 4 == 0, "cvk_wino4_output: bad shape");
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout && ldy % 4 == 0 && ksplit >= 1 && ksplit <= 3, "cvk_wino4_output: bad shape");
     CVK_CHECK_ARG(cvk_aligned16(Mo) && cvk_aligned16(y), "cvk_wino4_output: pointers must be 16-byte aligned");
     const int Wt = (W + 3) / 4, Mt = N * H * Wt, Mpix = N * H * W;
     const int P = cvk_cdiv(Mpix, CVK_STAT_ROWS);
-    dim3 grid(P, cvk_cdiv(ldy, 1024));
+    // one block = one 64-pixel granule x `chunk` channels; small layers (few granules) get 256- or 64-channel blocks so
+    // that the grid still covers the chip (the 22x30 level has only 83 granules)
+    int chunk = 1024;
+    while (chunk > 64 && (long)P * cvk_cdiv(ldy, chunk) < 1024) chunk /= 4;
+    dim3 grid(P, cvk_cdiv(ldy, chunk));
     hipStream_t s = (hipStream_t)stream;
     if (stats)
-        hipLaunchKernelGGL(k_wino4_output<true>, grid, dim3(256), 0, s, Mo, ldy, Mt, bias, y, ldy, stats, P, Mpix, H, W, Wt, ldy, Cout);
+        hipLaunchKernelGGL(k_wino4_output<true>, grid, dim3(256), 0, s, Mo, ldy, Mt, bias, y, ldy, stats, P, Mpix, H, W, Wt, ldy, Cout, ksplit, chunk);
     else
-        hipLaunchKernelGGL(k_wino4_output<false>, grid, dim3(256), 0, s, Mo, ldy, Mt, bias, y, ldy, stats, P, Mpix, H, W, Wt, ldy, Cout);
+        hipLaunchKernelGGL(k_wino4_output<false>, grid, dim3(256), 0, s, Mo, ldy, Mt, bias, y, ldy, stats, P, Mpix, H, W, Wt, ldy, Cout, ksplit, chunk);
     CVK_LAUNCH_RETURN("cvk_wino4_output");
 }
 

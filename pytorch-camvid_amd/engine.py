@@ -96,18 +96,14 @@ def wino_ok(R, k_ch, n_cols):
 
 def wino4_pays(N, H, W, k_ch, n_cols):
     """F(4,3) or F(2,3) for this layer?  Both kernels do the same work per workgroup (3*k_ch/32 K steps of a 128-row
-    tile); F(4,3) needs 6 workgroups per 4 columns, F(2,3) 8, so it wins whenever the grid is large.  It does not pay
-    (measured, tools/bench_conv.py wino wino4) for <= 32 columns (the logits layer) and when the 256-CU round count does
-    not drop (few tiles)."""
+    tile); F(4,3) needs 6 workgroups per 4 columns, F(2,3) 8, and splits its K loop when the grid is small
+    (csrc/wino4.hip plan_wino4), so it wins (measured, tools/bench_conv.py wino wino4) whenever there is more than one
+    wave of work.  F(2,3) — the more accurate of the two — keeps the <= 32-column head and layers whose whole F(2,3)
+    grid is at most one workgroup per CU anyway (the small golden geometries)."""
     if n_cols <= 32:
         return False
     tn = -(-n_cols // 128) if n_cols > 64 else 1
-
-    def rounds(blocks):
-        return -(-blocks // 256) if blocks < 2048 else blocks / 256.0
-    r2 = rounds(-(-(N * H * ((W + 1) // 2)) // 128) * tn * 4)
-    r4 = rounds(-(-(N * H * ((W + 3) // 4)) // 128) * tn * 6)
-    return r4 < r2
+    return -(-(N * H * ((W + 1) // 2)) // 128) * tn * 4 > 256
 
 
 def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what=""):
@@ -117,11 +113,12 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
     if R.wino4 == "always" or (R.wino4 and wino4_pays(N, H, W, k_ch, ldy)):
         U = _empty(6 * cout * 3 * k_ch, x.device)
         check(lib.cvk_wino4_weight_transform(w.data_ptr(), U.data_ptr(), cout, k_ch, s), "cvk_wino4_weight_transform")
-        ws = R.workspace(lib.cvk_conv3x3_wino4_workspace_bytes(N, H, W, ldy), x.device)
+        ws = R.workspace(lib.cvk_conv3x3_wino4_workspace_bytes(N, H, W, k_ch, ldy), x.device)
+        ksplit = lib.cvk_conv3x3_wino4_ksplit(N, H, W, k_ch, ldy)
         _timed(R, conv_kernel_name("wino4", ldy), flops, lambda: check(
             lib.cvk_conv3x3_wino4_gemm(x.data_ptr(), U.data_ptr(), ws.data_ptr(), N, H, W, k_ch, cout, ldy, s), "cvk_conv3x3_wino4_gemm" + what))
-        _timed(R, "k_wino4_output", 10.0 * M * ldy, lambda: check(
-            lib.cvk_wino4_output(ws.data_ptr(), bias, y.data_ptr(), sp, N, H, W, cout, ldy, s), "cvk_wino4_output"), "byte")
+        _timed(R, "k_wino4_output", (4.0 + 6.0 * ksplit) * M * ldy, lambda: check(
+            lib.cvk_wino4_output(ws.data_ptr(), bias, y.data_ptr(), sp, N, H, W, cout, ldy, ksplit, s), "cvk_wino4_output"), "byte")
     else:
         U = _empty(4 * cout * 3 * k_ch, x.device)
         check(lib.cvk_wino_weight_transform(w.data_ptr(), U.data_ptr(), cout, k_ch, s), "cvk_wino_weight_transform")

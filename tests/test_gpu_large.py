@@ -47,9 +47,9 @@ def test_conv_raw_abi_beyond_2gib(cfg):
         if wino == 4:
             U = torch.empty(6 * Co * 3 * C, device=dev())
             check(lib.cvk_wino4_weight_transform(w.data_ptr(), U.data_ptr(), Co, C, s))
-            Mo = torch.empty(lib.cvk_conv3x3_wino4_workspace_bytes(n, H, W, Co) // 4, device=dev())
+            Mo = torch.empty(lib.cvk_conv3x3_wino4_workspace_bytes(n, H, W, C, Co) // 4, device=dev())
             check(lib.cvk_conv3x3_wino4_gemm(xs.data_ptr(), U.data_ptr(), Mo.data_ptr(), n, H, W, C, Co, Co, s))
-            check(lib.cvk_wino4_output(Mo.data_ptr(), bias.data_ptr(), y.data_ptr(), st.data_ptr(), n, H, W, Co, Co, s))
+            check(lib.cvk_wino4_output(Mo.data_ptr(), bias.data_ptr(), y.data_ptr(), st.data_ptr(), n, H, W, Co, Co, lib.cvk_conv3x3_wino4_ksplit(n, H, W, C, Co), s))
         elif wino:
             U = torch.empty(4 * Co * 3 * C, device=dev())
             check(lib.cvk_wino_weight_transform(w.data_ptr(), U.data_ptr(), Co, C, s))

@@ -81,12 +81,12 @@ def test_kernel_name_mirror():
 
 
 def test_winograd_variant_choice_per_layer():
-    """engine.wino4_pays: F(4,3) wherever the 256-CU round count drops, F(2,3) for the 22x30 bottleneck of the batch-8
-    workload and for the 12-column head; tiny geometries (the goldens) stay on F(2,3) unless a test forces "always"."""
+    """engine.wino4_pays: F(4,3) wherever the layer is more than one wave of 512 resident workgroups, F(2,3) for the
+    12-column head and for tiny geometries (the goldens) unless a test forces "always"."""
     pays = engine.wino4_pays
     assert pays(8, 360, 480, 64, 64) and pays(8, 360, 480, 128, 64) and pays(8, 180, 240, 128, 128)
     assert pays(8, 90, 120, 256, 256) and pays(8, 45, 60, 512, 512) and pays(8, 44, 60, 1024, 512)
-    assert not pays(8, 22, 30, 512, 1024) and not pays(8, 22, 30, 1024, 1024)      # 528 vs 672 workgroups: both 3 rounds
+    assert pays(8, 22, 30, 512, 1024) and pays(8, 22, 30, 1024, 1024)              # bottleneck: F(4,3) with a 3-way K split
     assert not pays(8, 360, 480, 64, 12)                                           # the logits layer
     assert not pays(2, 6, 8, 512, 512) and not pays(1, 45, 60, 64, 64)             # golden-sized layers
     assert pays(50, 360, 480, 64, 64)                                              # large batches

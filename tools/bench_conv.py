@@ -72,9 +72,9 @@ def main():
             yref = y.clone(); sref = stats.clone()
             U4 = torch.empty(6 * co * 3 * ci, device=dev)
             check(lib.cvk_wino4_weight_transform(w.data_ptr(), U4.data_ptr(), co, ci, s))
-            wsb = lib.cvk_conv3x3_wino4_workspace_bytes(N, H, W, ldy); ws4 = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            wsb = lib.cvk_conv3x3_wino4_workspace_bytes(N, H, W, ci, ldy); ws4 = torch.empty(wsb, dtype=torch.uint8, device=dev)
             tg = timeit(lambda: check(lib.cvk_conv3x3_wino4_gemm(x.data_ptr(), U4.data_ptr(), ws4.data_ptr(), N, H, W, ci, co, ldy, s)))
-            to = timeit(lambda: check(lib.cvk_wino4_output(ws4.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, co, ldy, s)))
+            to = timeit(lambda: check(lib.cvk_wino4_output(ws4.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, co, ldy, lib.cvk_conv3x3_wino4_ksplit(N, H, W, ci, ldy), s)))
             t = tg + to
             err = (y - yref).abs().max().item() / yref.abs().max().item() if "wino" in which else float("nan")
             serr = (stats - sref).abs().max().item() / sref.abs().max().item() if "wino" in which else float("nan")
