@@ -122,6 +122,16 @@ class ConfusionMeter:
         acc = float(inter.sum() / lab.sum().clamp(min=1))
         return acc, iou, float(torch.nanmean(iou[valid]))
 
+    def precision_recall(self):
+        """Mean precision and recall over the non-ignored classes (the two extra numbers reference eval.py:70-79 prints;
+        legacy/metrics.py:33-57: diag / column sums and diag / row sums of the confusion matrix).  Pixels whose label is
+        ignore_index are left out of every count, as in utils.intersect_and_union (utils.py:170-172)."""
+        h = self.hist.cpu().double()
+        valid = [c for c in range(self.num_classes) if c != self.ignore_index]
+        prec = (h[0] / (h[1] + 1e-15))[valid].mean()
+        rec = (h[0] / (h[2] + 1e-15))[valid].mean()
+        return float(prec), float(rec)
+
 
 # reference conf/settings.py:8-9 (BGR order, as cv2 decodes)
 CAMVID_MEAN = (0.42019099703461577, 0.41323568513979647, 0.4010048431259079)
@@ -161,3 +171,53 @@ def evaluate(net, batches, num_classes=12, ignore_index=11):
     if meter is None:
         raise ValueError("evaluate(): no batches")
     return meter.compute()
+
+
+def evaluate_report(net, batches, num_classes=12, ignore_index=11, loss_fn=None):
+    """The report of reference eval.py:44-80: {"miou", "precision", "recall", "loss" (mean over batches), "accuracy",
+    "iou" (per class)} for a set of (images, masks) batches on the GPU; eval-mode forward under no_grad, argmax and
+    histograms on the device, one host copy at the end (the reference copies N*H*W int64 per batch, eval.py:60-62)."""
+    loss_fn = loss_fn or CrossEntropyLoss()
+    was_training = net.training
+    net.eval()
+    meter, loss_sum, n = None, None, 0
+    with torch.no_grad():
+        for images, masks in batches:
+            logits = net(images)
+            if meter is None:
+                meter = ConfusionMeter(num_classes, ignore_index, logits.device)
+            l = loss_fn(logits, masks).detach()
+            loss_sum = l if loss_sum is None else loss_sum + l
+            n += 1
+            meter.update(argmax_channels(logits), masks)
+    net.train(was_training)
+    if meter is None:
+        raise ValueError("evaluate_report(): no batches")
+    acc, iou, miou = meter.compute()
+    prec, rec = meter.precision_recall()
+    return {"miou": miou, "precision": prec, "recall": rec, "loss": float(loss_sum) / n, "accuracy": acc, "iou": iou}
+
+
+def predict(net, image_u8, out_size=None, mean=CAMVID_MEAN, std=CAMVID_STD):
+    """reference predict.py:35-57 from the decoded image onward: `image_u8` is one uint8 [H, W, 3] frame (BGR, as cv2
+    decodes; a CPU or GPU tensor or a numpy array) already at the network's input size; normalisation, eval-mode forward
+    and channel argmax run on the device.  Returns the int64 class map [H, W]; with out_size=(h, w) it is resized by
+    nearest neighbour the way `cv2.resize(..., INTER_NEAREST)` does (predict.py:55; source index floor(dst * in / out)).
+    Image decoding / PIL resizing to IMAGE_SIZE stay on the host side (cv2 / PIL are not part of this package)."""
+    dev = next(net.parameters()).device
+    img = torch.as_tensor(image_u8)
+    if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[-1] != 3:
+        raise ValueError("expected one uint8 image of shape [H, W, 3]")
+    x = preprocess_uint8(img.to(dev).unsqueeze(0), mean, std)
+    was_training = net.training
+    net.eval()
+    with torch.no_grad():
+        cls = argmax_channels(net(x))[0]
+    net.train(was_training)
+    if out_size is not None:
+        h, w = out_size
+        H, W = cls.shape
+        yi = torch.clamp((torch.arange(h, device=dev, dtype=torch.float64) * (H / h)).floor().long(), max=H - 1)
+        xi = torch.clamp((torch.arange(w, device=dev, dtype=torch.float64) * (W / w)).floor().long(), max=W - 1)
+        cls = cls[yi][:, xi]
+    return cls

@@ -276,3 +276,42 @@ def test_large_geometries():
         assert torch.allclose(full[1:2], one, rtol=1e-4, atol=2e-5)
         del net, x, t, g1
         torch.cuda.empty_cache()
+
+
+def test_eval_report_and_predict_equivalents():
+    """reference eval.py:44-80 (mIoU, precision, recall, mean loss) and predict.py:35-57 (normalise -> eval forward ->
+    argmax -> nearest resize) restated on the device, against numpy restatements of legacy/metrics.py:20-71 and of
+    cv2's INTER_NEAREST index rule."""
+    import pytorch_camvid_amd as A
+    torch.manual_seed(0)
+    net = A.get_model("unet", 3, 12).to(dev()).eval()
+    batches = [batch(2, 48, 64, 40 + i) for i in range(3)]
+    rep = A.evaluate_report(net, batches, num_classes=12, ignore_index=11)
+    cm = np.zeros((12, 12)); losses = []
+    with torch.no_grad():
+        for x, t in batches:
+            lg = net(x)
+            losses.append(torch.nn.functional.cross_entropy(lg.float(), t).item())
+            p = lg.argmax(1).cpu().numpy().ravel(); g = t.cpu().numpy().ravel()
+            keep = g != 11                                         # utils.intersect_and_union masks ignore_index pixels
+            np.add.at(cm, (g[keep], p[keep]), 1)
+    valid = [c for c in range(12) if c != 11]
+    diag = np.diag(cm)
+    iou = diag / (cm.sum(1) + cm.sum(0) - diag + 1e-15)
+    assert abs(rep["miou"] - iou[valid].mean()) < 1e-9
+    assert abs(rep["precision"] - (diag / (cm.sum(0) + 1e-15))[valid].mean()) < 1e-9
+    assert abs(rep["recall"] - (diag / (cm.sum(1) + 1e-15))[valid].mean()) < 1e-9
+    assert abs(rep["loss"] - np.mean(losses)) < 1e-5
+    # predict: uint8 BGR frame -> class map; equals argmax of the eval forward on the normalised frame
+    g = torch.Generator().manual_seed(3)
+    frame = torch.randint(0, 256, (48, 64, 3), generator=g, dtype=torch.uint8)
+    cls = A.predict(net, frame.numpy())
+    with torch.no_grad():
+        want = net(A.preprocess_uint8(frame.to(dev()).unsqueeze(0))).argmax(1)[0]
+    assert cls.dtype == torch.int64 and torch.equal(cls, want)
+    big = A.predict(net, frame, out_size=(100, 130))
+    yi = np.minimum(np.floor(np.arange(100) * (48 / 100)).astype(int), 47)
+    xi = np.minimum(np.floor(np.arange(130) * (64 / 130)).astype(int), 63)
+    assert np.array_equal(big.cpu().numpy(), want.cpu().numpy()[yi][:, xi])
+    with pytest.raises(ValueError):
+        A.predict(net, torch.zeros(48, 64, 3))                     # not uint8
