@@ -23,14 +23,24 @@ __global__ __launch_bounds__(256) void k_bn_stats_l1(const float* __restrict__ s
     const int pbeg = blockIdx.y * rows_per_g, pend = min(P, pbeg + rows_per_g);
     double a = 0.0, b = 0.0, q = 0.0;
     if (c < C) {
-        for (int p = pbeg + g; p < pend; p += 4) {
-            const double s = stats[(size_t)p * C + c];
-            const double m2 = stats[(size_t)(P + p) * C + c];
-            const int n = min(CVK_STAT_ROWS, M - p * CVK_STAT_ROWS);
-            a += s;
-            b += m2;
-            q += s * s / (double)n;
+        // every granule holds CVK_STAT_ROWS rows except the last one of the tensor: 1/n is a constant (exact power of two)
+        // for all but that one — no fp64 division in the loop; two independent chains hide the load latency
+        const double inv_full = 1.0 / (double)CVK_STAT_ROWS;
+        const int last = P - 1;
+        const double inv_last = 1.0 / (double)(M - last * CVK_STAT_ROWS);
+        double a1 = 0.0, b1 = 0.0, q1 = 0.0;
+        int p = pbeg + g;
+        for (; p + 4 < pend; p += 8) {
+            const double s0 = stats[(size_t)p * C + c], s1 = stats[(size_t)(p + 4) * C + c];
+            const double m0 = stats[(size_t)(P + p) * C + c], m1 = stats[(size_t)(P + p + 4) * C + c];
+            a += s0; b += m0; q += s0 * s0 * (p == last ? inv_last : inv_full);
+            a1 += s1; b1 += m1; q1 += s1 * s1 * (p + 4 == last ? inv_last : inv_full);
         }
+        for (; p < pend; p += 4) {
+            const double s0 = stats[(size_t)p * C + c];
+            a += s0; b += stats[(size_t)(P + p) * C + c]; q += s0 * s0 * (p == last ? inv_last : inv_full);
+        }
+        a += a1; b += b1; q += q1;
     }
     red[0][g][threadIdx.x & 63] = a;
     red[1][g][threadIdx.x & 63] = b;
@@ -46,19 +56,29 @@ __global__ __launch_bounds__(256) void k_bn_stats_l1(const float* __restrict__ s
 }
 
 // level 2: one thread per channel; M2 = sum q_p + sum s_p^2/n_p - S^2/M (Chan, evaluated in fp64)
-__global__ void k_bn_stats_l2(const double* __restrict__ ws, int G, int M, int C, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void k_bn_stats_l2(const double* __restrict__ ws, int G, int M, int C, const float* __restrict__ gamma,
                               const float* __restrict__ beta, float* mean, float* rstd, float* scale, float* shift,
                               float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt != nullptr) *nbt += 1;
-    if (c >= C) return;
+    __shared__ double red[3][4][64];
+    const int l = threadIdx.x & 63, lane = threadIdx.x >> 6;      // 64 channels x 4 lanes over the G partial rows
+    const int c = blockIdx.x * 64 + l;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt != nullptr) *nbt += 1;
     double a = 0.0, b = 0.0, q = 0.0;
-    for (int g = 0; g < G; ++g) {
-        const double* o = ws + ((size_t)g * C + c) * 3;
-        a += o[0];
-        b += o[1];
-        q += o[2];
-    }
+    if (c < C)
+        for (int g = lane; g < G; g += 4) {
+            const double* o = ws + ((size_t)g * C + c) * 3;
+            a += o[0];
+            b += o[1];
+            q += o[2];
+        }
+    red[0][lane][l] = a;
+    red[1][lane][l] = b;
+    red[2][lane][l] = q;
+    __syncthreads();
+    if (lane != 0 || c >= C) return;
+    a = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+    b = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+    q = (red[2][0][l] + red[2][1][l]) + (red[2][2][l] + red[2][3][l]);
     const double mu = a / (double)M;
     double m2 = b + q - a * a / (double)M;
     if (m2 < 0.0) m2 = 0.0;
@@ -230,8 +250,18 @@ __global__ __launch_bounds__(1024) void k_colsum_finalize(const float* __restric
     const int which = blockIdx.y;
     const float* src = part + (size_t)which * PB * C;
     double a = 0.0;
-    if (c < C)
-        for (int p = g; p < PB; p += 16) a += (double)src[(size_t)p * C + c];
+    if (c < C) {
+        double a1 = 0.0, a2 = 0.0, a3 = 0.0;       // four independent chains: the loads overlap (fixed order, deterministic)
+        int p = g;
+        for (; p + 48 < PB; p += 64) {
+            a += (double)src[(size_t)p * C + c];
+            a1 += (double)src[(size_t)(p + 16) * C + c];
+            a2 += (double)src[(size_t)(p + 32) * C + c];
+            a3 += (double)src[(size_t)(p + 48) * C + c];
+        }
+        for (; p < PB; p += 16) a += (double)src[(size_t)p * C + c];
+        a = (a + a1) + (a2 + a3);
+    }
     red[g][l] = a;
     __syncthreads();
     if (g == 0 && c < C) {
@@ -278,7 +308,7 @@ extern "C" int cvk_bn_finalize(const float* stats, int P, int M, int C, const fl
     const int rows_per_g = cvk_cdiv(P, G);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_bn_stats_l1, dim3(cvk_cdiv(C, 64), G), dim3(256), 0, s, stats, (double*)workspace, P, M, C, rows_per_g);
-    hipLaunchKernelGGL(k_bn_stats_l2, dim3(cvk_cdiv(C, 64)), dim3(64), 0, s, (const double*)workspace, G, M, C, gamma, beta, mean,
+    hipLaunchKernelGGL(k_bn_stats_l2, dim3(cvk_cdiv(C, 64)), dim3(256), 0, s, (const double*)workspace, G, M, C, gamma, beta, mean,
                        rstd, scale, shift, running_mean, running_var, num_batches_tracked, momentum, eps);
     CVK_LAUNCH_RETURN("cvk_bn_finalize");
 }
