@@ -111,6 +111,9 @@ int cvk_wino_output(const float* Mo, const float* bias, float* y, float* stats, 
  * transform index (a fixed function of the shape); the partial planes are summed by cvk_wino4_output, which takes that
  * ksplit, and the workspace size query accounts for them. */
 int cvk_wino4_weight_transform(const float* w, float* U, int Cout, int Cin, void* stream);
+/* data-grad weights in one step: U[6][Cin][3][Cout] of the rotated, channel-transposed filter, straight from
+ * w [Cout][3][3][Cin] (== cvk_pack_weight_dgrad without padding followed by cvk_wino4_weight_transform) */
+int cvk_wino4_weight_transform_dgrad(const float* w, float* U, int Cout, int Cin, void* stream);
 int cvk_conv3x3_wino4_ksplit(int N, int H, int W, int Cin, int Cout_ld);
 size_t cvk_conv3x3_wino4_workspace_bytes(int N, int H, int W, int Cin, int Cout_ld);
 int cvk_conv3x3_wino4_gemm(const float* x, const float* U, float* Mo, int N, int H, int W, int Cin, int Cout, int ldm,

@@ -45,6 +45,7 @@ SIGNATURES = {
     "cvk_conv3x3_wino_gemm": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_wino_output": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_wino4_weight_transform": (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
+    "cvk_wino4_weight_transform_dgrad": (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
     "cvk_conv3x3_wino4_ksplit": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "cvk_conv3x3_wino4_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
     "cvk_conv3x3_wino4_gemm": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),

@@ -40,6 +40,36 @@ __global__ void k_wino4_weight(const float* __restrict__ w, float* __restrict__ 
     }
 }
 
+// Data-grad weights in one step: U_d[xi][ci][r][co] = (G g)_xi with g_s = w[co][2-r][2-s][ci] (the 180-degree-rotated,
+// channel-transposed filter cvk_pack_weight_dgrad builds), straight from w — 32x32 LDS transposes keep both sides coalesced.
+__global__ __launch_bounds__(256) void k_wino4_weight_dgrad(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin) {
+    __shared__ float t[3][32][33];
+    const int r = blockIdx.z;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int co = co0 + j, ci = ci0 + tx;
+        const bool ok = co < Cout && ci < Cin;
+        const float* g = w + (((size_t)co * 3 + (2 - r)) * 3) * Cin + ci;
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) t[s_][j][tx] = ok ? g[(size_t)s_ * Cin] : 0.f;
+    }
+    __syncthreads();
+    const size_t plane = (size_t)Cin * 3 * Cout;
+    for (int j = ty; j < 32; j += 8) {
+        const int ci = ci0 + j, co = co0 + tx;
+        if (ci >= Cin || co >= Cout) continue;
+        const double g0 = t[2][tx][j], g1 = t[1][tx][j], g2 = t[0][tx][j];
+        float* o = U + ((size_t)ci * 3 + r) * Cout + co;
+        o[0] = (float)(0.25 * g0);
+        o[plane] = (float)(-(g0 + g1 + g2) / 6.0);
+        o[2 * plane] = (float)(-(g0 - g1 + g2) / 6.0);
+        o[3 * plane] = (float)(g0 / 24.0 + g1 / 12.0 + g2 / 6.0);
+        o[4 * plane] = (float)(g0 / 24.0 - g1 / 12.0 + g2 / 6.0);
+        o[5 * plane] = (float)g2;
+    }
+}
+
 template <int BM, int BN, int WARPS_M, int WARPS_N>
 __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino4(
     const float* __restrict__ X, const float* __restrict__ U, float* __restrict__ Mo, int Mt, int H, int W, int Wt,
@@ -674,6 +704,13 @@ extern "C" int cvk_wino4_weight_transform(const float* w, float* U, int Cout, in
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(k_wino4_weight, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
     CVK_LAUNCH_RETURN("cvk_wino4_weight_transform");
+}
+
+extern "C" int cvk_wino4_weight_transform_dgrad(const float* w, float* U, int Cout, int Cin, void* stream) {
+    CVK_CHECK_ARG(w && U && Cout > 0 && Cin > 0, "cvk_wino4_weight_transform_dgrad: bad arguments");
+    dim3 grid(cvk_cdiv(Cin, 32), cvk_cdiv(Cout, 32), 3);
+    hipLaunchKernelGGL(k_wino4_weight_dgrad, grid, dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
+    CVK_LAUNCH_RETURN("cvk_wino4_weight_transform_dgrad");
 }
 
 // How a layer is cut into workgroups: number of six-index blocks (the rest are single-index) and the K split of those.

@@ -106,13 +106,20 @@ def wino4_pays(N, H, W, k_ch, n_cols):
     return -(-(N * H * ((W + 1) // 2)) // 128) * tn * 4 > 256
 
 
-def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what=""):
+def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what="", dgrad_of=None):
     """y[N,H,W,ldy] = conv3x3(x[N,H,W,k_ch], w[cout][3][3][k_ch]) (+bias, +BN statistics partials at sp) through the 1-D
-    Winograd kernels: weight transform -> implicit GEMMs M_xi -> output transform.  F(4,3) when R.wino4, else F(2,3)."""
+    Winograd kernels: weight transform -> implicit GEMMs M_xi -> output transform.  F(4,3) when R.wino4, else F(2,3).
+    Data-grad: `w` is a callable returning the rotated/transposed pack (built only if a kernel needs it) and
+    dgrad_of = (forward weights [Cout_f][3][3][Cin_f], Cout_f, Cin_f) lets F(4,3) transform straight from them."""
     M = N * H * W
     if R.wino4 == "always" or (R.wino4 and wino4_pays(N, H, W, k_ch, ldy)):
         U = _empty(6 * cout * 3 * k_ch, x.device)
-        check(lib.cvk_wino4_weight_transform(w.data_ptr(), U.data_ptr(), cout, k_ch, s), "cvk_wino4_weight_transform")
+        if dgrad_of is not None and dgrad_of[1] == k_ch and dgrad_of[2] == cout:       # no channel padding on either side
+            check(lib.cvk_wino4_weight_transform_dgrad(dgrad_of[0].data_ptr(), U.data_ptr(), dgrad_of[1], dgrad_of[2], s),
+                  "cvk_wino4_weight_transform_dgrad")
+        else:
+            w = w() if callable(w) else w
+            check(lib.cvk_wino4_weight_transform(w.data_ptr(), U.data_ptr(), cout, k_ch, s), "cvk_wino4_weight_transform")
         ws = R.workspace(lib.cvk_conv3x3_wino4_workspace_bytes(N, H, W, k_ch, ldy), x.device)
         ksplit = lib.cvk_conv3x3_wino4_ksplit(N, H, W, k_ch, ldy)
         _timed(R, conv_kernel_name("wino4", ldy), flops, lambda: check(
@@ -120,6 +127,7 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
         _timed(R, "k_wino4_output", (4.0 + 6.0 * ksplit) * M * ldy, lambda: check(
             lib.cvk_wino4_output(ws.data_ptr(), bias, y.data_ptr(), sp, N, H, W, cout, ldy, ksplit, s), "cvk_wino4_output"), "byte")
     else:
+        w = w() if callable(w) else w
         U = _empty(4 * cout * 3 * k_ch, x.device)
         check(lib.cvk_wino_weight_transform(w.data_ptr(), U.data_ptr(), cout, k_ch, s), "cvk_wino_weight_transform")
         ws = R.workspace(lib.cvk_conv3x3_wino_workspace_bytes(N, H, W, ldy), x.device)
@@ -283,9 +291,14 @@ class ConvBnRelu(Op):
             if src.id in st.grad:
                 raise NotImplementedError("conv data-grad must be the first writer of its input's gradient buffer")
             wc = w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last)
-            wd = _empty(src.ld * 9 * ldy, dev)
-            check(lib.cvk_pack_weight_dgrad(wc.data_ptr(), wd.data_ptr(), C, self.cin, src.ld, ldy, s), "cvk_pack_weight_dgrad")
+
+            def packed():       # [Cin_pad][9][Cout_pad] rotated + transposed filter for the data-grad-as-forward kernels
+                wd_ = _empty(src.ld * 9 * ldy, dev)
+                check(lib.cvk_pack_weight_dgrad(wc.data_ptr(), wd_.data_ptr(), C, self.cin, src.ld, ldy, s), "cvk_pack_weight_dgrad")
+                return wd_
             dX = _empty(M * src.ld, dev).view(N, H, W, src.ld)
+            if not wino_ok(R, ldy, src.ld) or split_ok(R, ldy, src.ld) or bf16_ok(R, ldy):
+                wd = packed()
             if split_ok(R, ldy, src.ld):
                 _timed(R, f"k_conv3x3_igemm_split<{'128, 128' if src.ld > 64 else '128, 64'}, 2, 2, false, 16>", 18.0 * M * C * self.cin, lambda: check(
                     lib.cvk_conv3x3_fwd_split(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, 0, s),
@@ -295,7 +308,8 @@ class ConvBnRelu(Op):
                     lib.cvk_conv3x3_fwd_bf16(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
                     "cvk_conv3x3_fwd_bf16(dgrad)"))
             elif wino_ok(R, ldy, src.ld):
-                wino_conv(R, lib, s, dy, wd, None, dX, None, N, H, W, ldy, src.ld, src.ld, 18.0 * M * C * self.cin, "(dgrad)")
+                wino_conv(R, lib, s, dy, packed, None, dX, None, N, H, W, ldy, src.ld, src.ld, 18.0 * M * C * self.cin, "(dgrad)",
+                          dgrad_of=(wc, C, self.cin))
             else:
                 _timed(R, conv_kernel_name("dgrad", src.ld, ldy), 18.0 * M * C * self.cin, lambda: check(
                     lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
