@@ -157,24 +157,29 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino4(
     int lxi = xi_begin, lr = k0 / Cin, lcib = k0 - (k0 / Cin) * Cin;
     int lleft = (xi_end - xi_begin) * nK;
 
-    // Per-slice constants come from nibble tables indexed by the (uniform) transform index — pure SALU shifts, no
-    // branches: the whole K step must stay one basic block so that the loads interleave with the MFMAs.
-    //   nibble xi of: TJ0/TJ1/TJ2 = columns j of the first three taps (d_j), TC0/TC1/TC2 = their coefficients + 8;
+    // On this part the fp32 MFMAs and the vector ALU share issue/execute bandwidth: every VALU instruction in the K loop
+    // costs ~3.5 cycles of matrix time (tools/micro/mfma_peak.hip: a bare MFMA loop reaches 98 % of peak, +128 VALU per 64
+    // MFMAs 73 %).  So the per-load address/validity arithmetic is hoisted out of the slice loop: all Cin/32 slices of one
+    // (transform index, kernel row) group read the same pixels and differ only in the channel base, which travels in the
+    // SGPR offset of the buffer load.  aoff[tap][row] (byte offset, bit 31 set = out of frame -> the load returns 0) is
+    // recomputed once per group; per-slice constants come from nibble tables indexed by the uniform transform index:
+    //   nibble xi of TJ0/TJ1/TJ2 = columns j of the first three taps (d_j), TC0/TC1/TC2 = their coefficients + 8;
     //   bit xi of FOUR: a fourth tap d4 with coefficient 1 (xi 1..4); byte j of COLBIT: the validity flag of column d_j.
     constexpr unsigned TJ0 = 0x00111110u, TJ1 = 0x00322222u, TJ2 = 0x00533334u;
     constexpr unsigned TC0 = 0x00CA6C4Cu, TC1 = 0x00377443u, TC2 = 0x0096A799u, FOUR = 0x1Eu;
     constexpr unsigned long long COLBIT = 0x0000804020100008ULL;
-    auto issue = [&]() {
+    const __amdgpu_buffer_rsrc_t null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, 0, 0x00020000);   // every load -> 0
+    unsigned aoff0[NA], aoff1[NA], aoff2[NA], aoff3[NA];
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;              // coefficients of the group being issued (c0..c2: of the slice in flight)
+    auto regroup = [&]() {                                            // (lxi, lr) changed: taps, coefficients, offsets
         const unsigned sh4 = 4u * (unsigned)lxi;                      // lxi <= 7
         const unsigned j0 = (TJ0 >> sh4) & 15u, j1 = (TJ1 >> sh4) & 15u, j2 = (TJ2 >> sh4) & 15u;
-        c0 = (float)((int)((TC0 >> sh4) & 15u) - 8);
-        c1 = (float)((int)((TC1 >> sh4) & 15u) - 8);
-        c2 = (float)((int)((TC2 >> sh4) & 15u) - 8);
+        g0 = (float)((int)((TC0 >> sh4) & 15u) - 8);
+        g1 = (float)((int)((TC1 >> sh4) & 15u) - 8);
+        g2 = (float)((int)((TC2 >> sh4) & 15u) - 8);
         const unsigned four = (FOUR >> lxi) & 1u;
-        const unsigned dead = (unsigned)(lleft <= 0) << 31;           // past the last slice: zeros
-        --lleft;
         const unsigned rowbit = 1u << lr;
-        const unsigned base = (unsigned)((((lr - 1) * W - 1) * Cin + lcib) * 4) + kvb + dead;   // column d0
+        const unsigned base = (unsigned)((((lr - 1) * W - 1) * Cin) * 4) + kvb;   // column d0, channel 0
         const unsigned cs = (unsigned)Cin * 4u;
         const unsigned s0 = base + j0 * cs, s1 = base + j1 * cs, s2 = base + j2 * cs, s3 = base + 4 * cs;
         const unsigned n0_ = rowbit | (unsigned)((COLBIT >> (8u * j0)) & 0xFFu);
@@ -184,15 +189,30 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino4(
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const unsigned a = arow[i], o = a & ~0xFFu;
-            ra0[i] = buf_load16(xr, oob_unless((a & n0_) == n0_, o + s0));
-            ra1[i] = buf_load16(xr, oob_unless((a & n1_) == n1_, o + s1));
-            ra2[i] = buf_load16(xr, oob_unless((a & n2_) == n2_, o + s2));
-            ra3[i] = buf_load16(xr, oob_unless((a & n3_) == n3_, o + s3));
+            aoff0[i] = oob_unless((a & n0_) == n0_, o + s0);
+            aoff1[i] = oob_unless((a & n1_) == n1_, o + s1);
+            aoff2[i] = oob_unless((a & n2_) == n2_, o + s2);
+            aoff3[i] = oob_unless((a & n3_) == n3_, o + s3);
         }
-        const unsigned ub = (unsigned)((lxi * Cout * K3 + lr * Cin + lcib) * 4) | dead;
+    };
+    auto issue = [&]() {
+        const bool live = lleft > 0;                                   // past the last slice: zeros, no memory access
+        --lleft;
+        c0 = g0; c1 = g1; c2 = g2;                                     // used by the LDS store of this slice, one step later
+        const __amdgpu_buffer_rsrc_t xs = live ? xr : null_rsrc;
+        const __amdgpu_buffer_rsrc_t us = live ? ur : null_rsrc;
+        const unsigned sa = (unsigned)lcib * 4u;                       // SGPR offsets: the only per-slice address terms
+        const unsigned sb = (unsigned)((lxi * Cout * K3 + lr * Cin + lcib) * 4);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = buf_load16(ur, (boff[i] + ub) | ((boff[i] | ub) & OOB));
-        lcib += BK;                                  // branch-free advance (slice -> kernel row -> transform index)
+        for (int i = 0; i < NA; ++i) {
+            ra0[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, aoff0[i], sa, 0));
+            ra1[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, aoff1[i], sa, 0));
+            ra2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, aoff2[i], sa, 0));
+            ra3[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, aoff3[i], sa, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(us, boff[i], sb, 0));
+        lcib += BK;                                  // uniform advance (slice -> kernel row -> transform index)
         const int w1 = lcib >= Cin;
         lcib = w1 ? 0 : lcib;
         lr += w1;
@@ -235,7 +255,8 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino4(
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
     };
 
-    // prologue: slice 0 into LDS stage 0; slice 1 in flight
+    // prologue: slice 0 into LDS stage 0; slice 1 in flight (both in the first group: groups hold an even number of slices)
+    regroup();
     issue();
     store_stage(smem);
     issue();
@@ -277,6 +298,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino4(
 
     for (int xi = xi_begin; xi < xi_end; ++xi) {
         for (int ks = 0; ks < nK; ks += 2) {
+            if (lcib == 0) regroup();        // the two slices this pair issues open a new (transform index, kernel row) group
             CVK_WINO4_STEP(buf0, buf1);
             CVK_WINO4_STEP(buf1, buf0);
         }
