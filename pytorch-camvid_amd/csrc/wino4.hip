@@ -294,6 +294,8 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino4(
         mma_kk(cur + aro, cur + bro, 3);              \
         CVK_WINO4_PIPELINE();                         \
         __syncthreads();                              \
+        __builtin_amdgcn_sched_barrier(0);   /* nothing crosses the step boundary: hipcc otherwise hoists the next step's \
+                                                transform FMAs up here, i.e. consumes the loads right after issuing them */ \
     } while (0)
 
     for (int xi = xi_begin; xi < xi_end; ++xi) {
