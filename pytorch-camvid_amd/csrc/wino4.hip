@@ -623,28 +623,41 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino4(
     const int bco = BK * BM + lh * BN + wn * TN * 32 + li;
     float* const buf0 = smem;
     float* const buf1 = smem + STAGE;
-    // imposed instruction order (128-row tile: 60-64 MFMAs per step): 16 MFMAs; the LDS stores under the next 16; the
-    // NA + 4*NB loads one per MFMA; the rest.   masks: 0x008 MFMA, 0x020 VMEM read, 0x200 DS write
-#define CVK_WW4_PIPELINE()                                                    \
-    if (TM * TN == 4) {                                                       \
-        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                   \
-        _Pragma("unroll") for (int q_ = 0; q_ < NA + NB; ++q_) {              \
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                \
-            __builtin_amdgcn_sched_group_barrier(0x008, 16 / (NA + NB), 0);   \
-        }                                                                     \
-        _Pragma("unroll") for (int q_ = 0; q_ < NA + 4 * NB; ++q_) {          \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
-        }                                                                     \
-    }
-#define CVK_WW4_STEP(cur, nxt)                      \
-    do {                                            \
-        mma_part(cur + aco, cur + bco, 0, 8);       \
-        store_stage(nxt);            /* slice ks+1 */ \
-        issue();                     /* slice ks+2 */ \
-        mma_part(cur + aco, cur + bco, 8, L / 2);   \
-        CVK_WW4_PIPELINE();                         \
-        __syncthreads();                            \
+    // Imposed instruction order of a K step (128-row tile: 60-64 MFMAs): four phases separated by scheduling fences, each
+    // with its own interleave — 16 MFMAs | the 8 LDS stores of the next slice (their transform FMAs and vmcnt waits) under
+    // 16 MFMAs | the NA + 4*NB loads of the slice after that, one per MFMA | the rest.  Left alone (or with one
+    // sched_group_barrier list for the whole step) hipcc stores at the top and issues every load at the bottom of the
+    // step, so a slice is in flight for a barrier's length instead of a whole step.
+    //   masks: 0x008 MFMA, 0x020 VMEM read, 0x200 DS write
+#define CVK_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define CVK_WW4_STEP(cur, nxt)                                                    \
+    do {                                                                          \
+        if (TM * TN == 4) {                                                       \
+            mma_part(cur + aco, cur + bco, 0, 4);                                 \
+            CVK_FENCE();                                                          \
+            store_stage(nxt);            /* slice ks+1 */                         \
+            mma_part(cur + aco, cur + bco, 4, 8);                                 \
+            _Pragma("unroll") for (int q_ = 0; q_ < NA + NB; ++q_) {              \
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                \
+                __builtin_amdgcn_sched_group_barrier(0x008, 16 / (NA + NB), 0);   \
+            }                                                                     \
+            CVK_FENCE();                                                          \
+            issue();                     /* slice ks+2 */                         \
+            mma_part(cur + aco, cur + bco, 8, 13);                                \
+            _Pragma("unroll") for (int q_ = 0; q_ < NA + 4 * NB; ++q_) {          \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
+            }                                                                     \
+            CVK_FENCE();                                                          \
+            mma_part(cur + aco, cur + bco, 13, L / 2);                            \
+        } else {                                                                  \
+            mma_part(cur + aco, cur + bco, 0, 8);                                 \
+            store_stage(nxt);                                                     \
+            issue();                                                              \
+            mma_part(cur + aco, cur + bco, 8, L / 2);                             \
+        }                                                                         \
+        __syncthreads();                                                          \
+        CVK_FENCE();                                                              \
     } while (0)
     int ks = 0;
     for (; ks + 2 <= nK; ks += 2) {
@@ -653,7 +666,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino4(
     }
     if (ks < nK) CVK_WW4_STEP(buf0, buf1);
 #undef CVK_WW4_STEP
-#undef CVK_WW4_PIPELINE
+#undef CVK_FENCE
 
     float* out = slab + ((size_t)split * 6 + xi) * Cout * K3;
 #pragma unroll
