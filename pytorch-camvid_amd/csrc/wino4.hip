@@ -273,7 +273,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino4(
     // the next slice (each waits for its loads, issued a whole step earlier) under 16 MFMAs; the 4*NA+NB loads of the slice
     // after that, one per MFMA; the remaining MFMAs.   masks: 0x008 MFMA, 0x020 VMEM read, 0x200 DS write
 #define CVK_WINO4_PIPELINE()                                                  \
-    do {                                                                      \
+    if (TM * TN == 4) {              /* 64 MFMAs per step */                  \
         __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                   \
         _Pragma("unroll") for (int q_ = 0; q_ < NA + NB; ++q_) {              \
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                \
@@ -283,7 +283,17 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_conv3x3_wino4(
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
         }                                                                     \
-    } while (0)
+    } else if (TM * TN == 2) {       /* 32 MFMAs per step (64-column tile): 4 | 6 stores | 18 loads | 4 */ \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                    \
+        _Pragma("unroll") for (int q_ = 0; q_ < NA + NB; ++q_) {              \
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
+        }                                                                     \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4 * NA + NB; ++q_) {          \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
+        }                                                                     \
+    }
 #define CVK_WINO4_STEP(cur, nxt)                      \
     do {                                              \
         mma_kk(cur + aro, cur + bro, 0);              \
