@@ -501,29 +501,37 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
     const int bco = BK * BM + lh * BN + wn * TN * 32 + li;
     float* const buf0 = smem;
     float* const buf1 = smem + STAGE;
-    // instruction order inside a K step imposed on the scheduler: 16 MFMAs; the LDS stores of the next slice under the next
-    // 16; the 2*(NA+NB) loads one per MFMA; the rest.   masks: 0x008 MFMA, 0x020 VMEM read, 0x200 DS write
-#define CVK_WW_PIPELINE()                                                     \
-    if (TM * TN == 4) {   /* 60-64 MFMAs per step; the 64-row tile (30-32 MFMAs) is left to the compiler */ \
-        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                   \
-        _Pragma("unroll") for (int q_ = 0; q_ < NA + NB; ++q_) {              \
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                \
-            __builtin_amdgcn_sched_group_barrier(0x008, 16 / (NA + NB), 0);   \
-        }                                                                     \
-        _Pragma("unroll") for (int q_ = 0; q_ < 2 * (NA + NB); ++q_) {        \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
-        }                                                                     \
-    }
-#define CVK_WW_STEP(cur, nxt, AP_, BP_)             \
-    do {                                            \
-        mma_part(cur + aco, cur + bco, 0, 8);       \
-        store_stage(nxt, AP_, BP_);  /* slice ks+1 */ \
-        issue_q();                   /* slice ks+2 */ \
-        issue_p(AP_, BP_);           /* slice ks+3 */ \
-        mma_part(cur + aco, cur + bco, 8, L / 2);   \
-        CVK_WW_PIPELINE();                          \
-        __syncthreads();                            \
+    // Imposed instruction order of a K step: four phases separated by scheduling fences, each with its own interleave —
+    // MFMAs | the LDS stores of the next slice (transform FMAs, vmcnt waits) under MFMAs | the 2*(NA+NB) loads one per MFMA |
+    // the rest; and a fence at the step boundary (hipcc otherwise stores at the top and loads at the bottom of the step, or
+    // hoists the next step's FMAs across the barrier).  H/S/Q = phase boundaries in units of TM*TN MFMAs.
+    //   masks: 0x008 MFMA, 0x020 VMEM read, 0x200 DS write
+    constexpr int PH = TM * TN == 4 ? 4 : 2;                         // 16 / 4 MFMAs ahead of the stores
+    constexpr int PS = TM * TN == 4 ? 8 : 5;                         // stores under 16 / 6 MFMAs
+    constexpr int PQ = TM * TN == 4 ? 12 : 11;                       // loads under 16 / 12 MFMAs
+#define CVK_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define CVK_WW_STEP(cur, nxt, AP_, BP_)                                           \
+    do {                                                                          \
+        mma_part(cur + aco, cur + bco, 0, PH);                                    \
+        CVK_FENCE();                                                              \
+        store_stage(nxt, AP_, BP_);  /* slice ks+1 */                             \
+        mma_part(cur + aco, cur + bco, PH, PS);                                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < NA + NB; ++q_) {                  \
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                    \
+            __builtin_amdgcn_sched_group_barrier(0x008, (PS - PH) * TM * TN / (NA + NB), 0); \
+        }                                                                         \
+        CVK_FENCE();                                                              \
+        issue_q();                   /* slice ks+2 */                             \
+        issue_p(AP_, BP_);           /* slice ks+3 */                             \
+        mma_part(cur + aco, cur + bco, PS, PQ);                                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2 * (NA + NB); ++q_) {            \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                    \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    \
+        }                                                                         \
+        CVK_FENCE();                                                              \
+        mma_part(cur + aco, cur + bco, PQ, L / 2);                                \
+        __syncthreads();                                                          \
+        CVK_FENCE();                                                              \
     } while (0)
     int ks = 0;
     for (; ks + 2 <= nK; ks += 2) {
@@ -532,7 +540,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino(
     }
     if (ks < nK) CVK_WW_STEP(buf0, buf1, ap0, bp0);
 #undef CVK_WW_STEP
-#undef CVK_WW_PIPELINE
+#undef CVK_FENCE
 
     float* out = slab + ((size_t)split * 4 + xi) * Cout * K3;
 #pragma unroll
