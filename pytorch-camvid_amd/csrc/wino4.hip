@@ -660,11 +660,24 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino4(
             }                                                                     \
             CVK_FENCE();                                                          \
             mma_part(cur + aco, cur + bco, 13, L / 2);                            \
-        } else {                                                                  \
-            mma_part(cur + aco, cur + bco, 0, 8);                                 \
+        } else {                         /* 64-row tile, 30-32 MFMAs: 2 | 6 stores under 6 | 18 loads under 18 | rest */ \
+            mma_part(cur + aco, cur + bco, 0, 1);                                 \
+            CVK_FENCE();                                                          \
             store_stage(nxt);                                                     \
+            mma_part(cur + aco, cur + bco, 1, 4);                                 \
+            _Pragma("unroll") for (int q_ = 0; q_ < NA + NB; ++q_) {              \
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
+            }                                                                     \
+            CVK_FENCE();                                                          \
             issue();                                                              \
-            mma_part(cur + aco, cur + bco, 8, L / 2);                             \
+            mma_part(cur + aco, cur + bco, 4, 13);                                \
+            _Pragma("unroll") for (int q_ = 0; q_ < NA + 4 * NB; ++q_) {          \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
+            }                                                                     \
+            CVK_FENCE();                                                          \
+            mma_part(cur + aco, cur + bco, 13, L / 2);                            \
         }                                                                         \
         __syncthreads();                                                          \
         CVK_FENCE();                                                              \

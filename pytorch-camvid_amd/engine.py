@@ -321,8 +321,8 @@ class ConvBnRelu(Op):
             _timed(R, f"k_conv3x3_wgrad_bf16<{'128' if C > 64 else '64'}, 128, 2, 2>", 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_wgrad_bf16(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
                 "cvk_conv3x3_wgrad_bf16"))
-        elif R.wino and src.ld >= 32 and C > 32 and (R.wino4 == "always" or (R.wino4 and C > 64 and src.ld >= 64)):
-            # transposed F(4,3); for <= 64 output channels it only ties with F(2,3) (tools/bench_conv.py wwino wwino4)
+        elif R.wino and src.ld >= 32 and C > 32 and (R.wino4 == "always" or (R.wino4 and src.ld >= 64)):
+            # transposed F(4,3): fastest weight-grad on every layer with >= 64 input channels (tools/bench_conv.py wgrad wwino wwino4)
             wsb = lib.cvk_conv3x3_wgrad_wino4_workspace_bytes(N, H, W, src.ld, C, ldy)
             ws = R.workspace(wsb, dev)
             _timed(R, f"k_wgrad_wino4<{'128' if C > 64 else '64'}, 128, 2, 2>", 18.0 * M * C * self.cin, lambda: check(
