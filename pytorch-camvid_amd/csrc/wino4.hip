@@ -501,7 +501,13 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino4(
     const int acol = xi == 5 ? 3 : 0;
     const int RS = from_dy ? W : Wt, XS = from_dy ? 4 : 1;          // row / tile strides of the A operand, in pixels
     const size_t Mt = (size_t)NH * Wt;
-    const __amdgpu_buffer_rsrc_t xr = window_rsrc(X, (size_t)rowb * W * Cin, (size_t)Mpix * Cin);
+    // X window: its base sits one image row + one pixel BEFORE row `rowb` (possibly before the tensor: only valid taps are
+    // ever dereferenced), so that a tap's offset splits into two non-negative parts — a per-thread VGPR part
+    // ((bdr + rB)*W + 4*bxt) and a slice-uniform SGPR part ((row0 - rowb)*W + 4*xbase + j); the buffer range check sees
+    // the VGPR part only.
+    const long xfirst = ((long)rowb * W - (W + 1)) * Cin;
+    const size_t xbytes = ((size_t)((long)Mpix * Cin - xfirst)) * 4;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(X + xfirst), 0, (int)(xbytes < 0x7FFFFFFFu ? xbytes : 0x7FFFFFFFu), 0x00020000);
     const __amdgpu_buffer_rsrc_t ar = from_dy ? window_rsrc(DY, (size_t)rowb * W * ld_dy, (size_t)Mpix * ld_dy)
                                               : window_rsrc(E + (size_t)(xi - 1) * Mt * ld_dy, (size_t)rowb * Wt * ld_dy, Mt * ld_dy);
 
@@ -539,7 +545,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino4(
         bdr[i] = (S > 1 || R == 1) ? 0 : (int)divWt.div((unsigned)pr);
         bxt[i] = pr - bdr[i] * Wt;
         if ((S == 1 && bdr[i] >= R) || pr >= L) bxt[i] = Wt;
-        bconst[i] = ((unsigned)((bdr[i] + rB - 1) * W + 4 * bxt[i]) * (unsigned)Cin + (unsigned)ciB) * 4u;
+        bconst[i] = ((unsigned)((bdr[i] + rB) * W + 4 * bxt[i]) * (unsigned)Cin + (unsigned)ciB) * 4u;
     }
 
     f32x4 ra[NA], rb0[NB], rb1[NB], rb2[NB], rb3[NB];   // one register stage: in flight for one whole K step
@@ -552,39 +558,61 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino4(
         xbase = (sl - q * S) * L;
         y0 = row0 - (int)divH.div((unsigned)row0) * H;
     };
+    // The fp32 MFMAs share issue bandwidth with the vector ALU (tools/micro/mfma_peak.hip), so the per-load arithmetic is
+    // kept minimal: every slice-uniform address term travels in the SGPR offset of the buffer load, dead slices and the
+    // absent fourth tap read through a null resource, and a load costs a compare + a select (A operand) or an add, a
+    // compare and a select (V taps: the column of the tap must lie inside the frame).
+    const __amdgpu_buffer_rsrc_t null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, 0, 0x00020000);   // every load -> 0
+    int bx4[NB];
+    unsigned aconstv[NA], bconstv[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) aconstv[i] = aok ? aconst[i] : OOB;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        bx4[i] = 4 * bxt[i];
+        bconstv[i] = bok ? bconst[i] : OOB;
+    }
+    const unsigned cs = (unsigned)Cin * 4u;
     auto issue = [&]() {
         int row0, xbase, y0;
         slice_origin(ls, row0, xbase, y0);
         const bool live = ls < send;
         const int xlim = Wt - xbase, rlim = NH - row0;                       // uniform validity limits
+        const __amdgpu_buffer_rsrc_t ars = live ? ar : null_rsrc;
+        const __amdgpu_buffer_rsrc_t xrs = live ? xr : null_rsrc;
+        const __amdgpu_buffer_rsrc_t xr4 = (live & four) ? xr : null_rsrc;
+        // A operand: tile exists (and, for the dy columns, column 4*xt + acol lies inside the frame)
         const unsigned sA = (unsigned)(((row0 - rowb) * RS + XS * xbase + (from_dy ? acol : 0)) * ld_dy) * 4u;
-        const bool aon = aok & live;
-        const int wlimA = from_dy ? W - 4 * xbase - acol : 0x7FFFFFFF;        // need XS*axt < wlimA
+        const int xlimA = from_dy ? min(xlim, (W - 4 * xbase - acol + 3) >> 2) : xlim;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const bool ok = aon & (axt[i] < xlim) & (adr[i] < rlim) & (XS * axt[i] < wlimA);
-            ra[i] = buf_load16(ar, oob_unless(ok, aconst[i] + sA));
+            bool ok = axt[i] < xlimA;
+            if (MULTIROW) ok = ok & (adr[i] < rlim);
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, ok ? aconstv[i] : OOB, sA, 0));
         }
-        const unsigned sB = (unsigned)((((row0 - rowb) * W + 4 * xbase - 1) * Cin) * 4);   // column d0 of the slice's first group
-        const unsigned cs = (unsigned)Cin * 4u;
+        // V taps: column d_j of group xt is x column 4*xt - 1 + j
+        const unsigned sB = (unsigned)((((row0 - rowb) * W + 4 * xbase) * Cin) * 4);       // tap j adds j*cs (window base: -1 row, -1 pixel)
         const int xoff = 4 * xbase - 1;
-        const bool bon = bok & live;
-        const bool rowok_uniform = (unsigned)(y0 + rB - 1) < (unsigned)H;    // exact when the slice is one image row
+        const int xl = ((unsigned)(y0 + rB - 1) < (unsigned)H) ? xlim : 0;   // one image row per slice: the kernel row decides
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            bool rowok = rowok_uniform;
+            bool ok;
             if (MULTIROW) {                                                   // narrow frames only (compile-time)
                 const int yy = y0 + bdr[i];
                 const int y = yy - (int)divH.div((unsigned)yy) * H;
-                rowok = (unsigned)(y + rB - 1) < (unsigned)H;
+                ok = ((unsigned)(y + rB - 1) < (unsigned)H) & (bxt[i] < xlim) & (bdr[i] < rlim);
+            } else {
+                ok = bxt[i] < xl;
             }
-            const bool ok = bon & rowok & (bxt[i] < xlim) & (bdr[i] < rlim);
-            const int xc = 4 * bxt[i] + xoff;                                 // x column of d0
-            const unsigned o = bconst[i] + sB;
-            rb0[i] = buf_load16(xr, oob_unless(ok & ((unsigned)(xc + j0) < (unsigned)W), o + j0 * cs));
-            rb1[i] = buf_load16(xr, oob_unless(ok & ((unsigned)(xc + j1) < (unsigned)W), o + j1 * cs));
-            rb2[i] = buf_load16(xr, oob_unless(ok & ((unsigned)(xc + j2) < (unsigned)W), o + j2 * cs));
-            rb3[i] = buf_load16(xr, oob_unless(ok & four & ((unsigned)(xc + 4) < (unsigned)W), o + 4 * cs));
+            const unsigned o = bconstv[i];
+            rb0[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                xrs, (ok & ((unsigned)(bx4[i] + (xoff + j0)) < (unsigned)W)) ? o : OOB, sB + j0 * cs, 0));
+            rb1[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                xrs, (ok & ((unsigned)(bx4[i] + (xoff + j1)) < (unsigned)W)) ? o : OOB, sB + j1 * cs, 0));
+            rb2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                xrs, (ok & ((unsigned)(bx4[i] + (xoff + j2)) < (unsigned)W)) ? o : OOB, sB + j2 * cs, 0));
+            rb3[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                xr4, (ok & ((unsigned)(bx4[i] + (xoff + 4)) < (unsigned)W)) ? o : OOB, sB + 4 * cs, 0));
         }
         ++ls;
     };
