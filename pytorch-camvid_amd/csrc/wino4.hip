@@ -20,6 +20,8 @@
 // F(2,3) (measured 6e-7 relative rms against fp64 for K = 768, direct fp32 summation: 4e-7).
 #include "conv_tile.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 namespace {
 
 // U[xi][co][r][ci] from w[co][r][s][ci]; evaluated in double, rounded once
@@ -636,14 +638,27 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino4(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // A wave's two 32-wide MFMA tiles along a dimension take INTERLEAVED rows/columns (tile t owns 2*lane + t): both
+    // operands of a lane are then adjacent in LDS and arrive with one ds_read_b64 whose 16-bit immediate offset covers the
+    // whole stage — the blocked assignment (tile t owns t*32 + lane) cost a ds_read2_b32 plus a v_add per fetch, and the
+    // fp32 MFMAs pay for every VALU instruction.  The epilogue maps (tile, lane) back accordingly.
     auto mma_part = [&](const float* acol_, const float* bcol_, int s0, int s1) {
 #pragma unroll
         for (int s = s0; s < s1; ++s) {
             float a[TM], b[TN];
+            if (TM == 2) {
+                const f32x2 av = *reinterpret_cast<const f32x2*>(acol_ + 2 * s * BM);
+                a[0] = av[0]; a[TM - 1] = av[1];
+            } else {
+                a[0] = acol_[2 * s * BM];
+            }
+            if (TN == 2) {
+                const f32x2 bv = *reinterpret_cast<const f32x2*>(bcol_ + 2 * s * BN);
+                b[0] = bv[0]; b[TN - 1] = bv[1];
+            } else {
 #pragma unroll
-            for (int t = 0; t < TM; ++t) a[t] = acol_[2 * s * BM + t * 32];
-#pragma unroll
-            for (int t = 0; t < TN; ++t) b[t] = bcol_[2 * s * BN + t * 32];
+                for (int t = 0; t < TN; ++t) b[t] = bcol_[2 * s * BN + t * 32];
+            }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -657,8 +672,8 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino4(
     store_stage(smem);
     issue();
     __syncthreads();
-    const int aco = lh * BM + wm * TM * 32 + li;
-    const int bco = BK * BM + lh * BN + wn * TN * 32 + li;
+    const int aco = lh * BM + wm * TM * 32 + (TM == 2 ? 2 * li : li);
+    const int bco = BK * BM + lh * BN + wn * TN * 32 + (TN == 2 ? 2 * li : li);
     float* const buf0 = smem;
     float* const buf1 = smem + STAGE;
     // Imposed instruction order of a K step (128-row tile: 60-64 MFMAs): four phases separated by scheduling fences, each
@@ -724,10 +739,11 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, 2) void k_wgrad_wino4(
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-            const int col = n0 + wn * TN * 32 + tn * 32 + li;
+            const int col = n0 + wn * TN * 32 + (TN == 2 ? 2 * li + tn : tn * 32 + li);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = c0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int im = (r & 3) + 8 * (r >> 2) + 4 * lh;           // row of the 32x32 MFMA tile
+                const int row = c0 + wm * TM * 32 + (TM == 2 ? 2 * im + tm : tm * 32 + im);
                 if (row < Cout && col < K3) out[(size_t)row * K3 + col] = acc[tm][tn][r];
             }
         }
