@@ -19,9 +19,9 @@ out = {}
 for n, e in sorted(res.items(), key=lambda kv: -kv[1]["_t"])[:12]:
     k = len(seen[n]); gui = e["GRBM_GUI_ACTIVE"]
     out[n] = {"launches": k, "avg_us": round(e["_t"] / k * 1e6, 1),
-              "gui_active_cycles_per_launch": round(gui / k), "implied_clock_GHz": round(gui / e["_t"] / 1e9, 3) if e["_t"] else None,
-              # 1024 SIMDs; SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs
-              "mfma_busy_frac_of_simd_cycles": round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024), 4) if gui else None,
+              # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
+              "gui_active_cycles_per_launch_per_xcd": round(gui / 8 / k), "clock_GHz": round(gui / 8 / e["_t"] / 1e9, 3) if e["_t"] else None,
+              "mfma_busy_frac_of_simd_cycles": round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / 8 * 1024), 4) if gui else None,
               "wait_any_frac": round(e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"], 3) if e["SQ_WAVE_CYCLES"] else None,
               "wait_inst_any_frac": round(e["SQ_WAIT_INST_ANY"] / e["SQ_WAVE_CYCLES"], 3) if e["SQ_WAVE_CYCLES"] else None,
               "active_inst_frac": round(e["SQ_ACTIVE_INST_ANY"] / e["SQ_WAVE_CYCLES"], 3) if e["SQ_WAVE_CYCLES"] else None,
