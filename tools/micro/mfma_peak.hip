@@ -6,6 +6,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int LDT = 36;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s\n", hipGetErrorString(e_)); return; } } while (0)
 
@@ -27,6 +28,9 @@ __global__ __launch_bounds__(256, 2) void k(float* out, const float* src, int it
     f32x4 ld[NL > 0 ? NL : 1];
     for (int i = 0; i < (NL > 0 ? NL : 1); ++i) ld[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float v[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
+    f32x2 pv[8];
+    for (int q = 0; q < 8; ++q) pv[q] = f32x2{(float)q, (float)q + 0.5f};
+    const f32x2 pc = {1.0001f, 0.9999f}, pd = {0.5f, 0.25f};
     unsigned off = (unsigned)(blockIdx.x * 256 + tid) * 16u;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -45,6 +49,10 @@ __global__ __launch_bounds__(256, 2) void k(float* out, const float* src, int it
             if (MODE & 4) {
 #pragma unroll
                 for (int q = 0; q < NV / 4; ++q) v[q & 7] = fmaf(v[q & 7], 1.0001f, 0.5f);   /* 8 independent chains */
+            }
+            if (MODE & 128) {
+#pragma unroll
+                for (int q = 0; q < NV / 4; ++q) pv[q & 7] = __builtin_elementwise_fma(pv[q & 7], pc, pd);   /* v_pk_fma_f32 */
             }
             if ((MODE & 8) && kk == 1) {
 #pragma unroll
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void k(float* out, const float* src, int it
     }
     float s = 0.f;
     for (int a_ = 0; a_ < 2; ++a_) for (int b_ = 0; b_ < 2; ++b_) for (int r = 0; r < 16; ++r) s += acc[a_][b_][r];
-    for (int q = 0; q < 8; ++q) s += v[q];
+    for (int q = 0; q < 8; ++q) s += v[q] + pv[q][0] + pv[q][1];
     for (int q = 0; q < (NL > 0 ? NL : 1); ++q) s += ld[q][0];
     out[blockIdx.x * 256 + tid] = s;
 }
@@ -104,6 +112,8 @@ int main() {
     run<7, 64, 0>("+ 64 VALU fma per step", out, src);
     run<7, 256, 0>("+ 256 VALU fma per step", out, src);
     run<7, 512, 0>("+ 512 VALU fma per step", out, src);
+    run<3 + 128, 256, 0>("+ 256 v_pk_fma_f32 per step", out, src);
+    run<3 + 128, 128, 0>("+ 128 v_pk_fma_f32 per step", out, src);
     run<11, 0, 12>("+ 12 buffer loads per step", out, src);
     run<11, 0, 20>("+ 20 buffer loads per step", out, src);
     run<3 + 8 + 32, 0, 20>("+ 20 loads consumed next step by 20 VALU", out, src);
