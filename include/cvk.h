@@ -124,8 +124,15 @@ int cvk_wino4_output(const float* Mo, const float* bias, float* y, float* stats,
 /* weight-grad through the transposed F(4,3) (contract of cvk_conv3x3_wgrad; the workspace also holds the transformed
  * output-gradient planes E1..E4, float[4][N*H*ceil(W/4)][ld_dy], hence the extra ld_dy argument of the size query) */
 size_t cvk_conv3x3_wgrad_wino4_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout, int ld_dy);
-int cvk_conv3x3_wgrad_wino4(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,
-                            int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream);
+int cvk_conv3x3_wgrad_wino4(const float* x, const float* dy, const float* E_pre, float* dw, int N, int H, int W, int Cin,
+                            int Cin_pad, int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream);
+/* E_pre: NULL (the call transforms dy itself) or the planes written by cvk_bn_bwd_dx_e — the BN/ReLU-backward pass that
+ * produces dy can emit them on the way (same contract as cvk_bn_bwd_dx plus E; 4-channel vector layout only, CVK_EINVAL
+ * otherwise; `part` gets cvk_bn_bwd_e_blocks(N,H,W) partial rows of C column sums). */
+int cvk_bn_bwd_e_blocks(int N, int H, int W);
+int cvk_bn_bwd_dx_e(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
+                    const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* E, float* part,
+                    int N, int H, int W, int C, int use_batch_stats, void* stream);
 
 /* weight-grad through the transposed F(2,3) (same contract as cvk_conv3x3_wgrad; any Cin_pad % 4 == 0) */
 size_t cvk_conv3x3_wgrad_wino_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout);

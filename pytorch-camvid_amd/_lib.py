@@ -51,7 +51,10 @@ SIGNATURES = {
     "cvk_conv3x3_wino4_gemm": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_wino4_output": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_wgrad_wino4_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int, c_int]),
-    "cvk_conv3x3_wgrad_wino4": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
+    "cvk_conv3x3_wgrad_wino4": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
+    "cvk_bn_bwd_e_blocks": (c_int, [c_int, c_int, c_int]),
+    "cvk_bn_bwd_dx_e": (c_int, [View, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp,
+                                c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_wgrad_wino_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
     "cvk_conv3x3_wgrad_wino": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
     "cvk_bn_finalize_workspace_bytes": (c_size, [c_int, c_int]),

@@ -242,6 +242,85 @@ __global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dout, 
     }
 }
 
+// MODE-1 pass that also writes the F(4,3) weight-grad's transformed output-gradient planes (csrc/wino4.hip):
+//   E1 = dy0+dy1+dy2+dy3, E2 = dy0-dy1+dy2-dy3, E3 = dy0+2dy1+4dy2+8dy3, E4 = dy0-2dy1+4dy2-8dy3   per group of four columns,
+// float E[4][N*H*ceil(W/4)][ld_dy], so that the weight-grad does not have to re-read dy for them.  One thread owns a
+// 4-channel vector and walks column groups (tiles); a block covers `tiles` consecutive groups; partial column sums of dy
+// per block as in MODE 1.
+__global__ __launch_bounds__(256) void k_bn_bwd_dx_e(const float* __restrict__ dout, PixMap dm, const float* __restrict__ y, int ldy,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                    float* __restrict__ dy, int ld_dy, float* __restrict__ E,
+                                                    float* __restrict__ part, int M, int C, int W, int Wt, int Mt, int tiles,
+                                                    int cchunk, int use_batch_stats) {
+    __shared__ float red[256 * 4];
+    const int c0 = blockIdx.y * cchunk;
+    const int cw = min(cchunk, C - c0);
+    const int cvn = cw / 4;
+    const int ppp = 256 / cvn;
+    const int t = threadIdx.x;
+    const bool active = t < cvn * ppp;
+    const int cv = t % cvn, pr = t / cvn;
+    const int c = c0 + cv * 4;
+    const int tbeg = blockIdx.x * tiles, tend = min(Mt, tbeg + tiles);
+    float s0[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c);
+        f32x4 k1 = {0.f, 0.f, 0.f, 0.f}, k2 = {0.f, 0.f, 0.f, 0.f};
+        if (use_batch_stats) {
+            const float invM = 1.f / (float)M;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { k1[j] = dbeta[c + j] * invM; k2[j] = dgamma[c + j] * invM; }
+        }
+        const size_t plane = (size_t)Mt * ld_dy;
+        for (int tl = tbeg + pr; tl < tend; tl += ppp) {
+            const int row = tl / Wt, xt = tl - row * Wt;
+            const int m0 = row * W + 4 * xt;
+            f32x4 r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (4 * xt + i < W) {
+                    const int m = m0 + i;
+                    const f32x4 d = *reinterpret_cast<const f32x4*>(dout + dm.off(m) + c);
+                    const f32x4 yy = *reinterpret_cast<const f32x4*>(y + (size_t)m * ldy + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float g = (yy[j] * sc[j] + sh[j] > 0.f) ? d[j] : 0.f;
+                        const float xh = (yy[j] - mu[j]) * rs[j];
+                        const float v = sc[j] * (g - k1[j] - xh * k2[j]);
+                        r[i][j] = v;
+                        s0[j] += v;
+                    }
+                    *reinterpret_cast<f32x4*>(dy + (size_t)m * ld_dy + c) = r[i];
+                }
+            }
+            float* o = E + (size_t)tl * ld_dy + c;
+            const f32x4 a = r[0] + r[2], b = r[1] + r[3], cc = r[0] + 4.f * r[2], dd = 2.f * r[1] + 8.f * r[3];
+            *reinterpret_cast<f32x4*>(o) = a + b;
+            *reinterpret_cast<f32x4*>(o + plane) = a - b;
+            *reinterpret_cast<f32x4*>(o + 2 * plane) = cc + dd;
+            *reinterpret_cast<f32x4*>(o + 3 * plane) = cc - dd;
+        }
+    }
+    if (part == nullptr) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[t * 4 + j] = s0[j];
+    __syncthreads();
+    if (t < cvn) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.f;
+            for (int p = 0; p < ppp; ++p) a += red[(p * cvn + t) * 4 + j];
+            part[(size_t)blockIdx.x * C + c0 + t * 4 + j] = a;
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_colsum_finalize(const float* __restrict__ part, int PB, int C, float* out0,
                                                          float* out1) {
     __shared__ double red[16][64];
@@ -382,6 +461,37 @@ extern "C" int cvk_bn_bwd_dx(cvk_view dout, const float* y, int ldy, const float
     CVK_CHECK_ARG(!use_batch_stats || (dgamma && dbeta), "cvk_bn_bwd_dx: dgamma/dbeta required in training mode");
     return bn_bwd_launch(1, dout, y, ldy, scale, shift, mean, rstd, dgamma, dbeta, dy, ld_dy, dbias_part, N, H, W, C,
                          use_batch_stats, stream, "cvk_bn_bwd_dx");
+}
+
+// Fused variant of cvk_bn_bwd_dx for layers whose weight-grad runs through the transposed F(4,3): also writes the planes
+// E1..E4 (float[4][N*H*ceil(W/4)][ld_dy], columns [C, ld_dy) zero when dy's are).  Needs the vectorised layout (C, ldy,
+// ld_dy multiples of 4, 16-byte aligned pointers/strides); returns CVK_EINVAL otherwise — the caller then uses the plain
+// pass and lets cvk_conv3x3_wgrad_wino4 transform dy itself.  `part` gets cvk_bn_bwd_e_blocks(N,H,W) partial rows.
+extern "C" int cvk_bn_bwd_e_blocks(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    const int Mt = N * H * ((W + 3) / 4);
+    const int pb = cvk_bn_bwd_blocks(N * H * W);
+    const int tiles = cvk_cdiv(Mt, pb);
+    return cvk_cdiv(Mt, tiles);
+}
+
+extern "C" int cvk_bn_bwd_dx_e(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
+                               const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* E,
+                               float* part, int N, int H, int W, int C, int use_batch_stats, void* stream) {
+    CVK_CHECK_ARG(dout.ptr && y && scale && shift && mean && rstd && dy && E && dgamma && dbeta, "cvk_bn_bwd_dx_e: null pointer");
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && ldy >= C && ld_dy >= C && (long)N * H * W < (1L << 31), "cvk_bn_bwd_dx_e: bad shape");
+    const PixMap dm = make_map(dout, H, W);
+    const bool v4 = vec_ok(y, dout.ptr, scale, ldy, ld_dy, C, &dm) && cvk_aligned16(shift) && cvk_aligned16(mean) &&
+                    cvk_aligned16(rstd) && cvk_aligned16(dy) && cvk_aligned16(E);
+    CVK_CHECK_ARG(v4, "cvk_bn_bwd_dx_e: needs the 4-channel vector layout (use cvk_bn_bwd_dx)");
+    const int M = N * H * W, Wt = (W + 3) / 4, Mt = N * H * Wt;
+    const int pb = cvk_bn_bwd_blocks(M);
+    const int tiles = cvk_cdiv(Mt, pb), nb = cvk_cdiv(Mt, tiles);
+    const int cchunk = 1024;
+    dim3 grid(nb, cvk_cdiv(C, cchunk));
+    hipLaunchKernelGGL(k_bn_bwd_dx_e, grid, dim3(256), 0, (hipStream_t)stream, dout.ptr, dm, y, ldy, scale, shift, mean, rstd,
+                       dgamma, dbeta, dy, ld_dy, E, part, M, C, W, Wt, Mt, tiles, cchunk, use_batch_stats);
+    CVK_LAUNCH_RETURN("cvk_bn_bwd_dx_e");
 }
 
 extern "C" int cvk_colsum_finalize(const float* part, int PB, int C, float* out0, float* out1, void* stream) {

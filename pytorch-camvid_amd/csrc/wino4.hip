@@ -905,8 +905,8 @@ extern "C" size_t cvk_conv3x3_wgrad_wino4_workspace_bytes(int N, int H, int W, i
     return ((size_t)4 * N * H * Wt * ld_dy + (size_t)p.splits * 6 * Cout * 3 * Cin_pad) * sizeof(float);
 }
 
-extern "C" int cvk_conv3x3_wgrad_wino4(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,
-                                       int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int cvk_conv3x3_wgrad_wino4(const float* x, const float* dy, const float* E_pre, float* dw, int N, int H, int W, int Cin,
+                                       int Cin_pad, int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream) {
     CVK_CHECK_ARG(x && dy && dw && workspace, "cvk_conv3x3_wgrad_wino4: null pointer");
     CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin_pad >= Cin, "cvk_conv3x3_wgrad_wino4: bad shape");
     CVK_CHECK_ARG(Cin_pad % 4 == 0 && ld_dy % 4 == 0 && ld_dy >= Cout, "cvk_conv3x3_wgrad_wino4: Cin_pad and ld_dy must be multiples of 4, ld_dy >= Cout");
@@ -928,14 +928,17 @@ extern "C" int cvk_conv3x3_wgrad_wino4(const float* x, const float* dy, float* d
     hipStream_t s = (hipStream_t)stream;
     float* E = (float*)workspace;
     float* slab = E + e_floats;
-    {
+    if (E_pre != nullptr) {        // planes E1..E4 already written by cvk_bn_bwd_dx_e
+        CVK_CHECK_ARG(cvk_aligned16(E_pre), "cvk_conv3x3_wgrad_wino4: E_pre must be 16-byte aligned");
+    } else {
         const size_t total = (size_t)N * H * Wt * (ld_dy / 4);
         const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
         hipLaunchKernelGGL(k_wino4_dy_transform, dim3(blocks), dim3(256), 0, s, dy, ld_dy, E, N * H, W, Wt);
     }
+    const float* Euse = E_pre != nullptr ? E_pre : E;
     dim3 grid(p.tilesM * p.tilesN * p.splits * 6);
 #define CVK_WW4_LAUNCH(BM_, MR_, L_)                                                                                                       \
-    hipLaunchKernelGGL((k_wgrad_wino4<BM_, 128, 2, 2, MR_, L_>), grid, dim3(256), 0, s, x, dy, E, slab, N * H, H, W, Wt, Cin_pad, Cout, ld_dy, \
+    hipLaunchKernelGGL((k_wgrad_wino4<BM_, 128, 2, 2, MR_, L_>), grid, dim3(256), 0, s, x, dy, Euse, slab, N * H, H, W, Wt, Cin_pad, Cout, ld_dy, \
                        K3, p.chunk, p.tilesN, Mpix, p.tilesM * p.tilesN, p.nslices, p.S, p.R)
 #define CVK_WW4_PICK(BM_)                                                                         \
     do {                                                                                          \

@@ -282,10 +282,24 @@ class ConvBnRelu(Op):
             lib.cvk_bn_bwd_reduce(dO, y.data_ptr(), ldy, psc, psh, pm, pr, part.data_ptr(), N, H, W, C, s), "cvk_bn_bwd_reduce"), "byte")
         check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, gbe, gg, s), "cvk_colsum_finalize")   # dbeta, dgamma
         dy = torch.zeros(M * ldy, device=dev, dtype=_F32) if ldy != C else _empty(M * ldy, dev)
-        _timed(R, "k_bn_bwd<dx>", 12.0 * M * C, lambda: check(
-            lib.cvk_bn_bwd_dx(dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, part.data_ptr(),
-                              N, H, W, C, 1 if st.training else 0, s), "cvk_bn_bwd_dx"), "byte")
-        check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, gb, None, s), "cvk_colsum_finalize")  # conv bias grad
+        # layers whose weight-grad runs through the transposed F(4,3) get its transformed dy planes E1..E4 from this pass
+        wgrad4 = (not R.bf16) and R.wino and src.ld >= 32 and C > 32 and (R.wino4 == "always" or (R.wino4 and src.ld >= 64))
+        E = None
+        if wgrad4 and ldy == C and C % 4 == 0:
+            E = _empty(4 * N * H * ((W + 3) // 4) * ldy, dev)
+            PBe = lib.cvk_bn_bwd_e_blocks(N, H, W)
+            rc = _timed(R, "k_bn_bwd<dx+E>", (12.0 * M + 16.0 * N * H * ((W + 3) // 4)) * C, lambda: lib.cvk_bn_bwd_dx_e(
+                dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, E.data_ptr(), part.data_ptr(),
+                N, H, W, C, 1 if st.training else 0, s), "byte")
+            if rc == 0:
+                check(lib.cvk_colsum_finalize(part.data_ptr(), PBe, C, gb, None, s), "cvk_colsum_finalize")  # conv bias grad
+            else:
+                E = None            # layout not vectorisable (strided view): plain pass below, wgrad transforms dy itself
+        if E is None:
+            _timed(R, "k_bn_bwd<dx>", 12.0 * M * C, lambda: check(
+                lib.cvk_bn_bwd_dx(dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, part.data_ptr(),
+                                  N, H, W, C, 1 if st.training else 0, s), "cvk_bn_bwd_dx"), "byte")
+            check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, gb, None, s), "cvk_colsum_finalize")  # conv bias grad
         del y
         if self.src_needs_grad:
             if src.id in st.grad:
@@ -321,12 +335,13 @@ class ConvBnRelu(Op):
             _timed(R, f"k_conv3x3_wgrad_bf16<{'128' if C > 64 else '64'}, 128, 2, 2>", 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_wgrad_bf16(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
                 "cvk_conv3x3_wgrad_bf16"))
-        elif R.wino and src.ld >= 32 and C > 32 and (R.wino4 == "always" or (R.wino4 and src.ld >= 64)):
+        elif wgrad4:
             # transposed F(4,3): fastest weight-grad on every layer with >= 64 input channels (tools/bench_conv.py wgrad wwino wwino4)
             wsb = lib.cvk_conv3x3_wgrad_wino4_workspace_bytes(N, H, W, src.ld, C, ldy)
             ws = R.workspace(wsb, dev)
             _timed(R, f"k_wgrad_wino4<{'128' if C > 64 else '64'}, 128, 2, 2>", 18.0 * M * C * self.cin, lambda: check(
-                lib.cvk_conv3x3_wgrad_wino4(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
+                lib.cvk_conv3x3_wgrad_wino4(X.data_ptr(), dy.data_ptr(), E.data_ptr() if E is not None else None, gw, N, H, W,
+                                            self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
                 "cvk_conv3x3_wgrad_wino4"))
         elif R.wino and src.ld >= 32 and C > 32 and (src.ld > 64 or C > 64):   # 64->64 layers: the direct kernel is faster
             wsb = lib.cvk_conv3x3_wgrad_wino_workspace_bytes(N, H, W, src.ld, C)

@@ -70,7 +70,8 @@ def test_conv_raw_abi_beyond_2gib(cfg):
                       (lib.cvk_conv3x3_wgrad_workspace_bytes, lib.cvk_conv3x3_wgrad)
             wsb = f_ws(n, H, W, C, Co)
         ws = torch.empty(wsb // 4, device=dev())
-        check(f(xs.data_ptr(), dys.data_ptr(), dw.data_ptr(), n, H, W, C, C, Co, Co, ws.data_ptr(), wsb, s))
+        check(f(xs.data_ptr(), dys.data_ptr(), None, dw.data_ptr(), n, H, W, C, C, Co, Co, ws.data_ptr(), wsb, s) if wino == 4 else
+              f(xs.data_ptr(), dys.data_ptr(), dw.data_ptr(), n, H, W, C, C, Co, Co, ws.data_ptr(), wsb, s))
         return dw
 
     y, st = fwd(x, N)

@@ -91,7 +91,7 @@ def main():
         if "wwino4" in which and ci >= 32 and co > 32:
             dy = torch.randn(M, ldy, device=dev); dw4 = torch.empty(co, 9 * ci, device=dev)
             wsb = lib.cvk_conv3x3_wgrad_wino4_workspace_bytes(N, H, W, ci, co, ldy); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            t = timeit(lambda: check(lib.cvk_conv3x3_wgrad_wino4(x.data_ptr(), dy.data_ptr(), dw4.data_ptr(), N, H, W, ci, ci, co, ldy, ws.data_ptr(), wsb, s)))
+            t = timeit(lambda: check(lib.cvk_conv3x3_wgrad_wino4(x.data_ptr(), dy.data_ptr(), None, dw4.data_ptr(), N, H, W, ci, ci, co, ldy, ws.data_ptr(), wsb, s)))
             dwr = torch.empty(co, 9 * ci, device=dev)
             wsb2 = lib.cvk_conv3x3_wgrad_wino_workspace_bytes(N, H, W, ci, co); ws2 = torch.empty(wsb2, dtype=torch.uint8, device=dev)
             check(lib.cvk_conv3x3_wgrad_wino(x.data_ptr(), dy.data_ptr(), dwr.data_ptr(), N, H, W, ci, ci, co, ldy, ws2.data_ptr(), wsb2, s))
