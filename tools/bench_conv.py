@@ -62,13 +62,13 @@ def main():
         if "bf16" in which and ci % 32 == 0:
             t = timeit(lambda: check(lib.cvk_conv3x3_fwd_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, ci, co, ldy, s)))
             row += f" bf16 {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["bf16"][0] += flops; tot["bf16"][1] += t
-        if "wino" in which and ci % 64 == 0 and ldy > 32:
+        if "wino" in which and ci % 64 == 0:
             U = torch.empty(4 * co * 3 * ci, device=dev)
             check(lib.cvk_wino_weight_transform(w.data_ptr(), U.data_ptr(), co, ci, s))
             wsb = lib.cvk_conv3x3_wino_workspace_bytes(N, H, W, ldy); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             t = timeit(lambda: (check(lib.cvk_conv3x3_wino_gemm(x.data_ptr(), U.data_ptr(), ws.data_ptr(), N, H, W, ci, co, ldy, s)), check(lib.cvk_wino_output(ws.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, co, ldy, s))))
             row += f" wino {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["wino"][0] += flops; tot["wino"][1] += t
-        if "wino4" in which and ci % 64 == 0 and ldy > 32:
+        if "wino4" in which and ci % 64 == 0:
             yref = y.clone(); sref = stats.clone()
             U4 = torch.empty(6 * co * 3 * ci, device=dev)
             check(lib.cvk_wino4_weight_transform(w.data_ptr(), U4.data_ptr(), co, ci, s))
