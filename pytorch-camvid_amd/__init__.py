@@ -7,9 +7,9 @@ train.py's loss): UNet, SegNet, BasicConv2d, BasicConv, UpSample2d, get_model, C
 from ._lib import CvkError, build as build_library, load as load_library          # noqa: F401
 from .modules import BasicConv, BasicConv2d, SegNet, UNet, UpSample2d, get_model, set_conv_precision   # noqa: F401
 from .functional import (ConfusionMeter, CrossEntropyLoss, argmax_channels, cross_entropy, evaluate,  # noqa: F401
-                         evaluate_report, predict, preprocess_uint8)
+                         evaluate_report, predict, preprocess_uint8, DevicePrefetcher)
 from .optim import FlatAdamW  # noqa: F401
 from . import ddp  # noqa: F401
 
 __all__ = ["UNet", "SegNet", "BasicConv2d", "BasicConv", "UpSample2d", "get_model", "set_conv_precision", "CrossEntropyLoss",
-           "cross_entropy", "argmax_channels", "ConfusionMeter", "evaluate", "evaluate_report", "predict", "preprocess_uint8", "FlatAdamW", "ddp", "build_library", "load_library", "CvkError"]
+           "cross_entropy", "argmax_channels", "ConfusionMeter", "evaluate", "evaluate_report", "predict", "preprocess_uint8", "DevicePrefetcher", "FlatAdamW", "ddp", "build_library", "load_library", "CvkError"]

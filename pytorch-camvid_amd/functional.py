@@ -221,3 +221,65 @@ def predict(net, image_u8, out_size=None, mean=CAMVID_MEAN, std=CAMVID_STD):
         xi = torch.clamp((torch.arange(w, device=dev, dtype=torch.float64) * (W / w)).floor().long(), max=W - 1)
         cls = cls[yi][:, xi]
     return cls
+
+
+class DevicePrefetcher:
+    """the reference converts every frame to float on the CPU (transforms.py:485-538) and uploads 4 bytes per
+    value from pageable memory inside the step (`images.cuda()`, train.py:126-127).  This iterator takes (uint8 frames
+    [N,H,W,3] BGR, int64 masks [N,H,W]) batches from any host iterable (numpy arrays or CPU tensors), stages them in
+    pinned buffers and uploads 1 byte per value on a side stream one batch ahead of the consumer; normalisation to the
+    network's float NHWC layout happens on the device (`preprocess_uint8`).  Yields (images float32 [N,3,H,W] view, masks).
+    The yielded tensors are safe to use on the current stream (the side stream's work is awaited before they are handed out)."""
+
+    def __init__(self, batches, device="cuda", mean=CAMVID_MEAN, std=CAMVID_STD):
+        self.it = iter(batches)
+        self.dev = torch.device(device)
+        self.mean, self.std = mean, std
+        self.stream = torch.cuda.Stream(self.dev)
+        self._pin = [None, None]        # two pinned staging slots (frames, masks), reused when shapes repeat
+        self._slot = 0
+        self._next = None
+        self._stage()
+
+    def _pinned(self, slot, which, like):
+        cur = self._pin[slot]
+        buf = None if cur is None else cur[which]
+        if buf is None or buf.shape != like.shape or buf.dtype != like.dtype:
+            buf = torch.empty(like.shape, dtype=like.dtype, pin_memory=True)
+            if cur is None:
+                self._pin[slot] = [None, None]
+            self._pin[slot][which] = buf
+        return buf
+
+    def _stage(self):
+        try:
+            frames, masks = next(self.it)
+        except StopIteration:
+            self._next = None
+            return
+        frames, masks = torch.as_tensor(frames), torch.as_tensor(masks)
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
+            raise ValueError("expected uint8 frames of shape [N, H, W, 3]")
+        slot = self._slot
+        self._slot ^= 1
+        pf = self._pinned(slot, 0, frames); pf.copy_(frames)
+        pm = self._pinned(slot, 1, masks); pm.copy_(masks)
+        with torch.cuda.stream(self.stream):
+            gf = pf.to(self.dev, non_blocking=True)
+            gm = pm.to(self.dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._next = (gf, gm, ev)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._next is None:
+            raise StopIteration
+        gf, gm, ev = self._next
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_event(ev)
+        gf.record_stream(cur); gm.record_stream(cur)
+        self._stage()                                   # upload of the following batch overlaps the consumer's step
+        return preprocess_uint8(gf, self.mean, self.std), gm

@@ -315,3 +315,19 @@ def test_eval_report_and_predict_equivalents():
     assert np.array_equal(big.cpu().numpy(), want.cpu().numpy()[yi][:, xi])
     with pytest.raises(ValueError):
         A.predict(net, torch.zeros(48, 64, 3))                     # not uint8
+
+
+def test_device_prefetcher_matches_direct_upload():
+    """SURVEY §8f #3: pinned, one-batch-ahead uint8 upload + device-side normalisation == the direct path, batch by batch."""
+    import pytorch_camvid_amd as A
+    g = torch.Generator().manual_seed(9)
+    host = [(torch.randint(0, 256, (2, 24, 32, 3), generator=g, dtype=torch.uint8).numpy(),
+             torch.randint(0, 12, (2, 24, 32), generator=g)) for _ in range(5)]
+    got = list(A.DevicePrefetcher(host))
+    assert len(got) == 5
+    for (x, m), (f, t) in zip(got, host):
+        want = A.preprocess_uint8(torch.from_numpy(f).to(dev()))
+        assert x.is_cuda and x.dtype == torch.float32 and tuple(x.shape) == (2, 3, 24, 32)
+        assert torch.equal(x, want) and torch.equal(m.cpu(), t)
+    with pytest.raises(ValueError):
+        list(A.DevicePrefetcher([(torch.zeros(2, 24, 32, 3), torch.zeros(2, 24, 32, dtype=torch.long))]))
