@@ -10,9 +10,12 @@ on a per-GPU batch of 8 (SURVEY.md §8d timed region; the optimizer step is excl
 Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 
 Extra objects on the line:
-  roofline     — the dominant kernel (fp32-MFMA implicit-GEMM conv, largest share of step time): algorithmic
-                 FLOPs per launch / average launch duration, measured live with HIP events on the launch stream
-                 during extra instrumented steps after the timed region; peak = 157.3 TFLOP/s (fp32 MFMA, dense).
+  roofline     — the dominant kernel (MFMA implicit-GEMM conv, largest share of step time).  `achieved` / `frac` are
+                 the FLOPs the matrix pipe EXECUTES per second over the dense MFMA peak (a hardware fraction, <= 1):
+                 algorithmic FLOPs per launch x the kernel's executed share (Winograd F(4,3) runs 9 of 18) / average
+                 launch duration, measured live with HIP events on the launch stream during extra instrumented steps
+                 after the timed region; the algorithmic rate is kept beside it (`algorithmic_tflops`).
+                 peak = 157.3 TFLOP/s (fp32 MFMA) or 2500 TFLOP/s (bf16 MFMA, --precision bf16).
   cpu_baseline — the same loop on the host cores with the stock-torch rebuild of the reference network
                  (oracle/torch_ref.py; the reference itself is stock torch.nn and its source cannot travel to the GPU
                  box), batch 2, rank 0 at N=1 only.
@@ -40,8 +43,8 @@ H, W = 360, 480
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="unet", choices=["unet", "segnet"])
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH)
     ap.add_argument("--height", type=int, default=H)
@@ -77,14 +80,32 @@ def cpu_baseline(model, h, w):
                       f"1 warm-up + {n} timed fwd+bwd steps, {dt:.2f} s/step"}
 
 
+def self_launch(n):
+    """Run this script under torch.distributed.run with n ranks on 127.0.0.1 and pass its output through.
+    Called before any HIP call of this process (a child process, never an exec)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU ourselves (torch.distributed.run as a
+        # CHILD process, before anything here touches the GPU) and relay rank 0's JSON line.
+        raise SystemExit(self_launch(a.gpus))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {a.gpus}: pass --gpus equal to the number of ranks")
     # CVK_REHEARSAL=1: ranks share the visible GPUs and talk over gloo — a plumbing check of the N>1 path on a 1-GPU
     # box (its number is meaningless and is labelled as such); the real thing is one rank per GPU over RCCL.
     rehearsal = os.environ.get("CVK_REHEARSAL") == "1"
@@ -134,7 +155,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms = dt / a.steps * 1e3
@@ -169,16 +190,27 @@ def main():
         hbm_kernels = {k: {"launches_per_step": v[0] // 3, "ms_per_step": round(v[2] / 3 * 1e3, 3),
                            "algorithmic_GBps": round(v[1] / v[2] / 1e9, 1), "frac_of_8TBps": round(v[1] / v[2] / PEAK_HBM_BPS, 3)}
                        for k, v in mem.items()}
+        def executed_share(name):
+            # share of the algorithmic (direct-convolution) FLOPs a kernel really executes on the matrix pipe:
+            # F(4,3) Winograd 9 of 18, F(2,3) 12 of 18, direct kernels all of them
+            return 0.5 if "wino4" in name else ((2.0 / 3.0) if "wino" in name else 1.0)
+
+        def peak_of(name):
+            return PEAK_BF16_MFMA_TFLOPS if ("bf16" in name and "split" not in name) else PEAK_F32_MFMA_TFLOPS
+
+        for k, v in agg.items():
+            kernels[k]["executed_frac_of_peak"] = round(v[1] / v[2] / 1e12 * executed_share(k) / peak_of(k), 4)
         dom = max(agg.items(), key=lambda kv: kv[1][2])
         cnt, fl, sec = dom[1]
-        ach = fl / sec / 1e12
+        alg = fl / sec / 1e12                       # algorithmic TFLOP/s (SURVEY.md §8d numerator)
+        executed = executed_share(dom[0])
+        peak = peak_of(dom[0])
+        ach = alg * executed                        # FLOPs the MFMA pipe really executes per second: a hardware fraction <= 1
         allf = sum(v[1] for v in agg.values()); alls = sum(v[2] for v in agg.values())
-        # Winograd kernels execute 1/2 (F(4,3)) or 2/3 (F(2,3)) of the algorithmic (direct-convolution) FLOPs; the roofline numerator stays
-        # algorithmic, the executed-MFMA utilisation is reported beside it
-        executed = 0.5 if "wino4" in dom[0] else ((2.0 / 3.0) if "wino" in dom[0] else 1.0)   # F(4,3): 9 of 18; F(2,3): 12 of 18
-        peak = PEAK_BF16_MFMA_TFLOPS if ("bf16" in dom[0] and "split" not in dom[0]) else PEAK_F32_MFMA_TFLOPS
+        alle = sum(v[1] * executed_share(k) for k, v in agg.items())
         traffic = None
-        tp = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))[-1:]
+        pat = "r*_pmc_hbm_traffic_bf16.json" if "bf16" in dom[0] else "r*_pmc_hbm_traffic.json"
+        tp = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))[-1:]
         tp = tp[0] if tp else ""
         if os.path.exists(tp):
             for k, v in json.load(open(tp)).items():
@@ -188,9 +220,11 @@ def main():
                                          "FETCH doubled per MI355X_MICROARCH.md; recorded run, not this run)"}
         roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic,
-                "executed_mfma_tflops": round(ach * executed, 2), "executed_mfma_frac": round(ach * executed / peak, 4),
+                "algorithmic_tflops": round(alg, 2), "algorithmic_speedup_vs_peak": round(alg / peak, 4),
+                "executed_share_of_algorithmic_flops": round(executed, 4),
                 "flops_per_launch": fl / cnt, "avg_launch_us": round(sec / cnt * 1e6, 1), "launches_per_step": cnt // 3,
-                "all_conv_kernels": {"achieved": round(allf / alls / 1e12, 2), "frac": round(allf / alls / 1e12 / peak, 4),
+                "all_conv_kernels": {"algorithmic_tflops": round(allf / alls / 1e12, 2),
+                                     "executed_frac_of_peak": round(alle / alls / 1e12 / peak, 4),
                                      "ms_per_step": round(alls / 3 * 1e3, 2)}}
 
     cpu = None

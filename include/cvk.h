@@ -40,6 +40,11 @@ typedef struct cvk_view {        /* strided NHWC view, strides in floats */
     int64_t sN, sY, sX;          /* image, row, pixel strides */
 } cvk_view;
 
+typedef struct cvk_viewh {       /* strided NHWC view of a bf16 (or, where stated, fp32) tensor; strides in ELEMENTS */
+    void*   ptr;
+    int64_t sN, sY, sX;
+} cvk_viewh;
+
 int         cvk_version(void);
 const char* cvk_last_error_string(void);
 
@@ -73,23 +78,6 @@ int cvk_pack_weight_dgrad(const float* w_src, float* dst, int Cout, int Cin, int
 size_t cvk_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout);
 int cvk_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,
                       int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream);
-
-/* Opt-in reduced precision (BASELINE.json configs[3]): same contract as cvk_conv3x3_fwd with Cin % 32 == 0; operands are
- * rounded to bf16 on the way to LDS and multiplied on the bf16 matrix cores with fp32 accumulation; HBM stays fp32. */
-int cvk_conv3x3_fwd_bf16(const float* x, const float* w, const float* bias, float* y, float* stats,
-                         int N, int H, int W, int Cin, int Cout, int ldy, void* stream);
-
-/* EXPERIMENTAL fp32-accurate convolution on the bf16 matrix cores: exact 3-way bf16 split of every fp32 operand, six
- * cross-term MFMAs with fp32 accumulation (csrc/conv_split.hip).  Contract of cvk_conv3x3_fwd, Cin % 32 == 0, Cout > 32.
- * variant: 0 = 16-wide K slices, 1 = 32-wide. */
-int cvk_conv3x3_fwd_split(const float* x, const float* w, const float* bias, float* y, float* stats,
-                          int N, int H, int W, int Cin, int Cout, int ldy, int variant, void* stream);
-
-/* bf16-MFMA weight-grad (opt-in, Cout > 32): contract and workspace size of cvk_conv3x3_wgrad
- * (a workspace of cvk_conv3x3_wgrad_bf16_workspace_bytes bytes). */
-size_t cvk_conv3x3_wgrad_bf16_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout);
-int cvk_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,
-                           int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Same operator through 1-D Winograd F(2,3) along the width (1.5x fewer MFMA FLOPs; csrc/wino.hip), for Cin % 64 == 0:
  *   U  = cvk_wino_weight_transform(w)                      [4][Cout][3][Cin] from w [Cout][3][3][Cin]
@@ -186,13 +174,16 @@ int cvk_bilinear_up2_fwd(const float* x, float* out, int N, int H, int W, int C,
 int cvk_bilinear_up2_bwd(const float* dout, float* dx, int N, int H, int W, int C, void* stream);
 
 /* ---- softmax cross-entropy, mean over pixels (nn.CrossEntropyLoss(): train.py:105,130-131) --------------------
- * logits: dense NHWC rows [M][ld], target int64 [M].  fwd writes the scalar mean loss to *loss (device) using
- * `part` (float[cvk_ce_blocks(M)]) as scratch.  bwd: dlogits = (softmax - onehot) * (*grad_out) * scale / M. */
+ * logits: dense NHWC rows [M][ld] (ld <= 128), target int64 [M].  Pixels whose target equals ignore_index (torch's
+ * default -100; the reference passes none, so every CamVid class incl. Void is trained) are left out of the mean and get
+ * a zero gradient.  fwd writes loss[0] = mean over the valid pixels, loss[1] = their number, loss[2] = number of
+ * targets outside [0,C) that are not ignore_index (then loss[0] = NaN: torch raises there); `part` is scratch of
+ * 3 * cvk_ce_blocks(M) floats.  bwd: dlogits = (softmax - onehot) * (*grad_out) * scale / loss3[1]; loss3 is fwd's loss. */
 int cvk_ce_blocks(int M);
 int cvk_softmax_ce_fwd(const float* logits, int ld, const int64_t* target, float* part, float* loss,
-                       int M, int C, void* stream);
-int cvk_softmax_ce_bwd(const float* logits, int ld, const int64_t* target, const float* grad_out, float scale,
-                       float* dlogits, int ld_d, int M, int C, void* stream);
+                       int M, int C, int ignore_index, void* stream);
+int cvk_softmax_ce_bwd(const float* logits, int ld, const int64_t* target, const float* loss3, const float* grad_out,
+                       float scale, float* dlogits, int ld_d, int M, int C, int ignore_index, void* stream);
 
 /* ---- evaluation (train.py:191 argmax; utils.py:162-190 histograms) -------------------------------------------- */
 int cvk_argmax_channels(const float* logits, int ld, int64_t* out, int M, int C, void* stream);
@@ -208,6 +199,58 @@ int cvk_preprocess_u8(const uint8_t* src, float* dst, int N, int H, int W, const
 /* ---- fused AdamW over a flat fp32 buffer (torch.optim.AdamW: train.py:100,133) -------------------------------- */
 int cvk_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
+
+/* ================================================================================================================
+ * bf16-storage path (BASELINE.json configs[3] "bf16 + MFMA im2col path"; set_conv_precision(net, "bf16")).
+ * Activations and activation gradients are bf16 NHWC in HBM, products bf16 x bf16 on the matrix cores with fp32
+ * accumulation, BatchNorm statistics / parameter gradients / master weights fp32.  Same reference call sites as the
+ * fp32 entry points above (models/unet.py:11-13,25,92; train.py:131).
+ * ================================================================================================================ */
+
+/* rows the packed weight tensors are padded to (multiple of the kernel's output-channel tile), and the number of
+ * BatchNorm-statistics partials cvk_conv3x3_bf16s writes (one per 8 x 32 pixel tile) */
+int cvk_bf16s_rows_pad(int cout);
+int cvk_bf16s_stat_partials(int N, int H, int W);
+/* fp32 master weights [Cout][3][3][Cin] -> bf16 [rows_pad(Cout)][9][Cin_pad] (forward), and the rotated/transposed
+ * data-grad filter bf16 [rows_pad(Cin)][9][Cout_pad]; zero padded */
+int cvk_pack_weight_fwd_bf16(const float* w, void* out, int Cout, int Cin, int Cin_pad, void* stream);
+int cvk_pack_weight_dgrad_bf16(const float* w, void* out, int Cout, int Cin, int Cout_pad, void* stream);
+/* y[N,H,W,ldy] (bf16) = conv3x3(x[N,H,W,Cin] bf16, w bf16 [rows_pad][9][Cin]) + bias; Cin % 32 == 0.  With stats != NULL:
+ * stats[2][P][Cout] = per-tile (sum, M2 about the tile mean) of the fp32 results, counts[P] = pixels per tile,
+ * P = cvk_bf16s_stat_partials(N,H,W) -> cvk_bn_finalize_counts.  Data-grad: the same call on dy and the dgrad pack. */
+int cvk_conv3x3_bf16s(const void* x, const void* w, const float* bias, void* y, float* stats, float* counts,
+                      int N, int H, int W, int Cin, int Cout, int ldy, void* stream);
+int cvk_bn_finalize_counts(const float* stats, const float* counts, int P, int M, int C, const float* gamma, const float* beta,
+                           float* mean, float* rstd, float* scale, float* shift, float* running_mean, float* running_var,
+                           int64_t* num_batches_tracked, float momentum, float eps, void* workspace, size_t workspace_bytes,
+                           void* stream);
+/* dw fp32 [Cout][9][Cin] = sum_pixels dy (x) x_shifted; x bf16 [N,H,W,ldx], dy bf16 [N,H,W,ld_dy] (ld % 8 == 0) */
+size_t cvk_conv3x3_wgrad_bf16s_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int cvk_conv3x3_wgrad_bf16s(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int ldx, int Cout,
+                            int ld_dy, void* workspace, size_t workspace_bytes, void* stream);
+/* logical NCHW fp32 (any strides) -> dense bf16 NHWC with ld % 8 == 0, pad channels zero */
+int cvk_import_nchw_bf16(const float* src, int64_t sN, int64_t sC, int64_t sH, int64_t sW, void* dst, int ld,
+                         int N, int C, int H, int W, void* stream);
+/* out = relu(y*scale + shift): y bf16 [M][ldy]; out a view of bf16 (out_f32 = 0) or fp32 (out_f32 = 1, the logits);
+ * pool != NULL: also writes MaxPool2d(2,2)(out) as dense bf16 [N,H/2,W/2,C] (models/unet.py:92 fused into this pass) */
+int cvk_bn_relu_apply_bf16(const void* y, int ldy, const float* scale, const float* shift, cvk_viewh out, int out_f32,
+                           void* pool, int N, int H, int W, int C, void* stream);
+/* BatchNorm+ReLU backward on bf16 tensors; dout is a bf16 view, or fp32 (dout_f32 = 1: the loss gradient).
+ * part: 2 * cvk_bn_bwd_blocks_bf16(M) * C floats (reduce) / cvk_bn_bwd_blocks_bf16(M) * C floats (dx: column sums of dy,
+ * the conv bias gradient) -> cvk_colsum_finalize.  dy rows have pitch ld_dy >= C, pad columns are written as 0. */
+int cvk_bn_bwd_blocks_bf16(int M);
+int cvk_bn_bwd_reduce_bf16(cvk_viewh dout, int dout_f32, const void* y, int ldy, const float* scale, const float* shift,
+                           const float* mean, const float* rstd, float* part, int N, int H, int W, int C, void* stream);
+int cvk_bn_bwd_dx_bf16(cvk_viewh dout, int dout_f32, const void* y, int ldy, const float* scale, const float* shift,
+                       const float* mean, const float* rstd, const float* dgamma, const float* dbeta, void* dy, int ld_dy,
+                       float* dbias_part, int N, int H, int W, int C, int use_batch_stats, void* stream);
+/* MaxPool2d(2,2) backward: dout dense bf16 [N,H/2,W/2,C]; x = the pooled layer's stored input (view); dx (view) is
+ * written, or added to when accumulate != 0 */
+int cvk_maxpool2x2_bwd_bf16(const void* dout, cvk_viewh x, cvk_viewh dx, int accumulate, int N, int H, int W, int C, void* stream);
+int cvk_bilinear_up2_fwd_bf16(const void* x, void* out, int N, int H, int W, int C, void* stream);
+int cvk_bilinear_up2_bwd_bf16(const void* dout, void* dx, int N, int H, int W, int C, void* stream);
+int cvk_zero_frame_bf16(cvk_viewh buf, int N, int H, int W, int C, int y0, int x0, int h, int w, void* stream);
 
 #ifdef __cplusplus
 }

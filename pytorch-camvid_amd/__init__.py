@@ -7,9 +7,12 @@ train.py's loss): UNet, SegNet, BasicConv2d, BasicConv, UpSample2d, get_model, C
 from ._lib import CvkError, build as build_library, load as load_library          # noqa: F401
 from .modules import BasicConv, BasicConv2d, SegNet, UNet, UpSample2d, get_model, set_conv_precision   # noqa: F401
 from .functional import (ConfusionMeter, CrossEntropyLoss, argmax_channels, cross_entropy, evaluate,  # noqa: F401
-                         evaluate_report, predict, preprocess_uint8, DevicePrefetcher)
+                         evaluate_report, predict, preprocess_uint8, DevicePrefetcher, last_ce_status)
 from .optim import FlatAdamW  # noqa: F401
 from . import ddp  # noqa: F401
+from .checkpoint import (save_checkpoint, load_checkpoint, latest_checkpoint, checkpoint_epoch, resume,   # noqa: F401
+                         save_policy, reference_state_dict)
 
 __all__ = ["UNet", "SegNet", "BasicConv2d", "BasicConv", "UpSample2d", "get_model", "set_conv_precision", "CrossEntropyLoss",
-           "cross_entropy", "argmax_channels", "ConfusionMeter", "evaluate", "evaluate_report", "predict", "preprocess_uint8", "DevicePrefetcher", "FlatAdamW", "ddp", "build_library", "load_library", "CvkError"]
+           "cross_entropy", "last_ce_status", "argmax_channels", "ConfusionMeter", "evaluate", "evaluate_report", "predict", "preprocess_uint8", "DevicePrefetcher", "FlatAdamW", "ddp", "save_checkpoint", "load_checkpoint", "latest_checkpoint", "checkpoint_epoch", "resume", "save_policy",
+           "reference_state_dict", "build_library", "load_library", "CvkError"]

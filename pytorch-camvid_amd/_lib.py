@@ -24,6 +24,11 @@ class View(ctypes.Structure):
     _fields_ = [("ptr", ctypes.c_void_p), ("sN", ctypes.c_int64), ("sY", ctypes.c_int64), ("sX", ctypes.c_int64)]
 
 
+class ViewH(ctypes.Structure):
+    """cvk_viewh: strided NHWC view of a bf16 / fp32 tensor, strides in elements."""
+    _fields_ = [("ptr", ctypes.c_void_p), ("sN", ctypes.c_int64), ("sY", ctypes.c_int64), ("sX", ctypes.c_int64)]
+
+
 # name -> (restype, argtypes); the list is checked against include/cvk.h by tests/test_abi.py
 SIGNATURES = {
     "cvk_version": (c_int, []),
@@ -32,10 +37,6 @@ SIGNATURES = {
     "cvk_export_nchw": (c_int, [c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_zero_frame": (c_int, [View, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
-    "cvk_conv3x3_fwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
-    "cvk_conv3x3_wgrad_bf16_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
-    "cvk_conv3x3_wgrad_bf16": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
-    "cvk_conv3x3_fwd_split": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_pack_weight_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "cvk_pack_weight_dgrad": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_wgrad_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
@@ -75,11 +76,30 @@ SIGNATURES = {
     "cvk_bilinear_up2_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_bilinear_up2_bwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_ce_blocks": (c_int, [c_int]),
-    "cvk_softmax_ce_fwd": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
-    "cvk_softmax_ce_bwd": (c_int, [c_vp, c_int, c_vp, c_vp, c_float, c_vp, c_int, c_int, c_int, c_vp]),
+    "cvk_softmax_ce_fwd": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "cvk_softmax_ce_bwd": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_float, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_argmax_channels": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp]),
     "cvk_confusion_accumulate": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "cvk_preprocess_u8": (c_int, [c_vp, c_vp, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_vp]),
+    "cvk_bf16s_rows_pad": (c_int, [c_int]),
+    "cvk_bf16s_stat_partials": (c_int, [c_int, c_int, c_int]),
+    "cvk_pack_weight_fwd_bf16": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "cvk_pack_weight_dgrad_bf16": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "cvk_conv3x3_bf16s": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_bn_finalize_counts": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                       c_float, c_float, c_vp, c_size, c_vp]),
+    "cvk_conv3x3_wgrad_bf16s_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
+    "cvk_conv3x3_wgrad_bf16s": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
+    "cvk_import_nchw_bf16": (c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_bn_relu_apply_bf16": (c_int, [c_vp, c_int, c_vp, c_vp, ViewH, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_bn_bwd_blocks_bf16": (c_int, [c_int]),
+    "cvk_bn_bwd_reduce_bf16": (c_int, [ViewH, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_bn_bwd_dx_bf16": (c_int, [ViewH, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp,
+                                   c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_maxpool2x2_bwd_bf16": (c_int, [c_vp, ViewH, ViewH, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_bilinear_up2_fwd_bf16": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_bilinear_up2_bwd_bf16": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_zero_frame_bf16": (c_int, [ViewH, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_adamw_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_float, c_float, c_float, c_float, c_float, c_int, c_vp]),
 }
 

@@ -55,6 +55,35 @@ __global__ __launch_bounds__(256) void k_bn_stats_l1(const float* __restrict__ s
     }
 }
 
+// level 1 for partials of ARBITRARY size (the bf16-storage convolution reduces per 8 x 32 pixel tile, ragged at the frame
+// border): cnt[p] = number of pixels behind partial p.  Same outputs as k_bn_stats_l1.
+__global__ __launch_bounds__(256) void k_bn_stats_l1_counts(const float* __restrict__ stats, const float* __restrict__ cnt,
+                                                           double* __restrict__ ws, int P, int C, int rows_per_g) {
+    __shared__ double red[3][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int g = threadIdx.x >> 6;
+    const int pbeg = blockIdx.y * rows_per_g, pend = min(P, pbeg + rows_per_g);
+    double a = 0.0, b = 0.0, q = 0.0;
+    if (c < C)
+        for (int p = pbeg + g; p < pend; p += 4) {
+            const double s0 = stats[(size_t)p * C + c];
+            a += s0;
+            b += stats[(size_t)(P + p) * C + c];
+            q += s0 * s0 / (double)cnt[p];
+        }
+    red[0][g][threadIdx.x & 63] = a;
+    red[1][g][threadIdx.x & 63] = b;
+    red[2][g][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        const int l = threadIdx.x;
+        double* o = ws + ((size_t)blockIdx.y * C + c) * 3;
+        o[0] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+        o[1] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+        o[2] = (red[2][0][l] + red[2][1][l]) + (red[2][2][l] + red[2][3][l]);
+    }
+}
+
 // level 2: one thread per channel; M2 = sum q_p + sum s_p^2/n_p - S^2/M (Chan, evaluated in fp64)
 __global__ __launch_bounds__(256) void k_bn_stats_l2(const double* __restrict__ ws, int G, int M, int C, const float* __restrict__ gamma,
                               const float* __restrict__ beta, float* mean, float* rstd, float* scale, float* shift,
@@ -390,6 +419,27 @@ extern "C" int cvk_bn_finalize(const float* stats, int P, int M, int C, const fl
     hipLaunchKernelGGL(k_bn_stats_l2, dim3(cvk_cdiv(C, 64)), dim3(256), 0, s, (const double*)workspace, G, M, C, gamma, beta, mean,
                        rstd, scale, shift, running_mean, running_var, num_batches_tracked, momentum, eps);
     CVK_LAUNCH_RETURN("cvk_bn_finalize");
+}
+
+extern "C" int cvk_bn_finalize_counts(const float* stats, const float* counts, int P, int M, int C, const float* gamma, const float* beta,
+                                      float* mean, float* rstd, float* scale, float* shift, float* running_mean, float* running_var,
+                                      int64_t* num_batches_tracked, float momentum, float eps, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    CVK_CHECK_ARG(stats && counts && gamma && beta && mean && rstd && scale && shift && workspace, "cvk_bn_finalize_counts: null pointer");
+    CVK_CHECK_ARG(P > 0 && C > 0 && M > 0, "cvk_bn_finalize_counts: bad sizes");
+    CVK_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "cvk_bn_finalize_counts: running_mean/var must come together");
+    CVK_CHECK_ARG((((uintptr_t)workspace) & 7u) == 0, "cvk_bn_finalize_counts: workspace must be 8-byte aligned");
+    if (workspace_bytes < cvk_bn_finalize_workspace_bytes(P, C)) {
+        cvk_set_error("cvk_bn_finalize_counts: workspace too small");
+        return CVK_EWORKSPACE;
+    }
+    const int G = P < 32 ? 1 : (P / 32 < 64 ? P / 32 : 64);
+    const int rows_per_g = cvk_cdiv(P, G);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bn_stats_l1_counts, dim3(cvk_cdiv(C, 64), G), dim3(256), 0, s, stats, counts, (double*)workspace, P, C, rows_per_g);
+    hipLaunchKernelGGL(k_bn_stats_l2, dim3(cvk_cdiv(C, 64)), dim3(256), 0, s, (const double*)workspace, G, M, C, gamma, beta, mean,
+                       rstd, scale, shift, running_mean, running_var, num_batches_tracked, momentum, eps);
+    CVK_LAUNCH_RETURN("cvk_bn_finalize_counts");
 }
 
 extern "C" int cvk_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,

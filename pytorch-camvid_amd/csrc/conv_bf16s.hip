@@ -1,0 +1,552 @@
+// conv_bf16s.hip — 3x3 convolution on bf16 NHWC tensors (BASELINE.json configs[3]: "bf16 + MFMA im2col path").
+//
+// Forward (models/unet.py:11 nn.Conv2d(3x3, pad 1)) and data-grad (the same kernel on the rotated/transposed filter):
+//     Y[n,y,x,co] = bias[co] + sum_{tap,ci} X[n, y+dy, x+dx, ci] * Wt[co][tap][ci]          tap = 3*(dy+1) + (dx+1)
+// X, Wt, Y are bf16 in HBM; products are v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the BatchNorm statistics
+// partials are taken from the fp32 accumulators.
+//
+// Structure (one workgroup = 256 threads = one 8 x 32 pixel tile x BN output channels):
+//   * the input tile WITH ITS HALO (10 x 34 pixels, pitch 36) x 32 channels is staged ONCE per channel slice and
+//     all nine taps read it at shifted LDS addresses: global->LDS bytes for the activations drop 6.4x against
+//     per-tap im2col staging (the round-1 kernel was L2->LDS staging-bound at 22 % of the bf16 peak);
+//   * staging is LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPR round trip, no ds_write):
+//     the slab of channel slice cs+1 arrives while the nine taps of slice cs run, the weight tile of step s+2 while
+//     step s runs (ring of three), counted s_waitcnt vmcnt + raw s_barrier so loads stay in flight across barriers;
+//   * the LDS images are lane-linear (DMA) and XOR-swizzled through the SOURCE address: 16-byte chunk c of halo pixel
+//     (hy,hx) lives at position c ^ ((hx>>2)&3) ^ (hy&3) of its 64-byte row, weights row n at c ^ ((n>>2)&3):
+//     every ds_read_b128 of an MFMA operand (32 rows x 16 B, one 16-lane group = 16 distinct 16-byte slots) is
+//     bank-conflict free for all nine tap shifts;
+//   * MFMA orientation D[cout][pixel] = Wt-tile (A operand) x pixel-tile (B operand): a lane ends up with four
+//     consecutive output channels of one pixel per register quad -> 8-byte packed bf16 stores along NHWC rows.
+//   * out-of-frame halo pixels (conv zero padding, ragged tiles) are DMA'd from a zero page.
+#include "cvk_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CK = 32;                 // channels per K slice: 64-byte pixel rows in LDS
+constexpr int TH = 8, TW = 32;         // output tile: 8 rows x 32 columns = 256 pixels (eight 32-pixel MFMA blocks)
+constexpr int HP = TW + 4;             // halo row pitch in pixels (34 used; 36 keeps the row term of the swizzle uniform)
+constexpr int SLAB_PIECES = 24;        // 16-pixel DMA pieces per slab buffer: (TH+2)*HP = 360 pixels -> 23, padded to 6 per wave
+constexpr int SLAB_BYTES = SLAB_PIECES * 1024;
+
+__device__ __attribute__((aligned(64))) const unsigned int g_zero_page[16] = {0};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+__device__ __forceinline__ void dma16(const void* g, char* lds_base) {
+    // one 16-byte LDS-DMA per lane: LDS destination = wave-uniform lds_base + 16 * lane
+    __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)lds_base, 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ bf16x8 lds_read16(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+// BN = output channels per workgroup (128 or 64).  STATS: fused BatchNorm statistics partials (training forward).
+// bias may be NULL (data-grad).
+template <int BN, bool STATS>
+__global__ __launch_bounds__(256, 2) void k_conv_bf16s(const __bf16* __restrict__ X, const __bf16* __restrict__ Wt,
+                                                      const float* __restrict__ bias, __bf16* __restrict__ Y,
+                                                      float* __restrict__ stats, float* __restrict__ cnt, int H, int W, int Cin,
+                                                      int Cout, int ldy, int tilesX, int tilesY, int tilesN, int P) {
+    constexpr int WC = BN / 64;            // waves along the output-channel dimension (64 channels = 2 MFMA tiles each)
+    constexpr int WP = 4 / WC;             // waves along the pixel dimension
+    constexpr int TP = 8 / WP;             // 32-pixel blocks (tile rows) per wave
+    constexpr int TC = 2;                  // 32-channel MFMA tiles per wave
+    constexpr int NBP = BN / 64;           // weight DMA pieces (16 rows x 64 B) per wave per step
+    constexpr int BSLOT = BN * 64;         // bytes per weight ring slot
+    constexpr int MAIN_BYTES = 2 * SLAB_BYTES + 3 * BSLOT;
+    constexpr int STAT_BYTES = STATS ? BN * 32 * WP * 2 * 4 : 0;      // epilogue scratch: [channel][32*WP partials][sum, sumsq]
+    constexpr int LDS_BYTES = MAIN_BYTES > STAT_BYTES ? MAIN_BYTES : STAT_BYTES;
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+
+    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+    char* const slab0 = smem;
+    char* const ring0 = smem + 2 * SLAB_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wc = wave % WC, wp = wave / WC;
+
+    // ---- which tile: output-channel tiles innermost, XCD-contiguous chunks of the logical order (shared slabs/halos hit one L2)
+    const int gid = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = gid % tilesN;
+    const int sp = gid / tilesN;                        // spatial tile = statistics partial index
+    const int tx = sp % tilesX;
+    const int ty = (sp / tilesX) % tilesY;
+    const int img = sp / (tilesX * tilesY);
+    const int x0 = tx * TW, y0 = ty * TH, n0 = nt * BN;
+    const __bf16* const Ximg = X + (size_t)img * H * W * Cin;
+
+    // ---- DMA source offsets (elements), fixed over the K loop --------------------------------------------------------
+    // slab pieces: at tap t < 6 wave w moves piece 4t + w; lane -> LDS row (piece*16 + lane/4), 16-byte position lane%4
+    int aoff[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int row = (4 * t + wave) * 16 + (lane >> 2);
+        const int hy = row / HP, hx = row - hy * HP;
+        const int chunk = (lane & 3) ^ ((hx >> 2) & 3) ^ (hy & 3);
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = (hy < TH + 2) & (hx < TW + 2) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+        aoff[t] = ok ? (iy * W + ix) * Cin + chunk * 8 : -1;
+    }
+    int boff[NBP];
+#pragma unroll
+    for (int i = 0; i < NBP; ++i) {
+        const int n = (wave * NBP + i) * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((n >> 2) & 3);
+        boff[i] = (n0 + n) * 9 * Cin + chunk * 8;       // the weight tensor is padded to tilesN * BN rows: always in range
+    }
+    const __bf16* const zero = reinterpret_cast<const __bf16*>(g_zero_page);
+
+    auto dma_slab_piece = [&](int t, int cs, char* slab) {
+        const __bf16* src = aoff[t] >= 0 ? Ximg + (size_t)(unsigned)aoff[t] + cs * CK : zero;
+        dma16(src, slab + (4 * t + wave) * 1024);
+    };
+    auto dma_weights = [&](int step_tap, int cs, char* slot) {
+#pragma unroll
+        for (int i = 0; i < NBP; ++i) dma16(Wt + (size_t)(unsigned)boff[i] + step_tap * Cin + cs * CK, slot + (wave * NBP + i) * 1024);
+    };
+
+    // ---- operand read addresses --------------------------------------------------------------------------------------
+    // weights (MFMA A operand): row n = wc*64 + tc*32 + r, k-chunk 2*kk + h at position (2kk+h) ^ ((n>>2)&3); tc, slot: immediates
+    const int nrow = wc * 64 + r;
+    const int wa0 = nrow * 64 + ((h ^ ((nrow >> 2) & 3)) << 4);                 // kk = 0; kk = 1 is wa0 ^ 32
+    // pixels (MFMA B operand): block j = wp*TP + tp is tile row j; tap (dy,dx): halo row j+dy, halo column r+dx
+    int pa[3];                                                                 // per dx: byte offset of the halo column + lane part of the swizzle
+    int pcl[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        pa[dx] = (r + dx) * 64;
+        pcl[dx] = h ^ (((r + dx) >> 2) & 3);
+    }
+
+    f32x16 acc[TC][TP];
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    const int ncs = Cin / CK;
+
+    // ---- prologue: slab of slice 0, weight tiles of steps 0 and 1 -------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < 6; ++t) dma_slab_piece(t, 0, slab0);
+    dma_weights(0, 0, ring0);
+    dma_weights(1, 0, ring0 + BSLOT);
+    wait_vm<NBP>();                    // everything but the step-1 weights has landed
+    __builtin_amdgcn_s_barrier();
+
+    int step = 0;
+    for (int cs = 0; cs < ncs; ++cs) {
+        char* const slab = slab0 + (cs & 1) * SLAB_BYTES + wp * TP * (HP * 64);      // this wave's first tile row
+        char* const slab_next = slab0 + ((cs + 1) & 1) * SLAB_BYTES;
+        const int csn = min(cs + 1, ncs - 1);     // past the end the DMAs re-load the last slice into buffers nobody reads:
+                                                  // no branch in the step, uniform vmcnt bookkeeping
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++step) {
+            // (1) DMA: weight tile of step + 2 into the ring slot read in step - 1, one slab piece of the next slice
+            {
+                const int s2 = step + 2;
+                const int tap2 = tap + 2 >= 9 ? tap + 2 - 9 : tap + 2;
+                const int cs2 = tap + 2 >= 9 ? csn : cs;
+                dma_weights(tap2, cs2, ring0 + (s2 % 3) * BSLOT);
+                if (tap < 6) dma_slab_piece(tap, csn, slab_next);
+            }
+            // (2) MFMAs of this step
+            const int dy = tap / 3, dx = tap % 3;
+            const char* const wslot = ring0 + (step % 3) * BSLOT;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 a[TC], b[TP];
+#pragma unroll
+                for (int tc = 0; tc < TC; ++tc) a[tc] = lds_read16(wslot + ((wa0 ^ (kk << 5)) + tc * 32 * 64));
+#pragma unroll
+                for (int tp = 0; tp < TP; ++tp) {
+                    const int hy = wp * TP + tp + dy;                           // halo row: uniform, (tp + dy) folds into the offset
+                    const int pos = (pcl[dx] ^ (hy & 3) ^ (kk << 1)) << 4;
+                    b[tp] = lds_read16(slab + (tp + dy) * (HP * 64) + pa[dx] + pos);
+                }
+#pragma unroll
+                for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+                    for (int tp = 0; tp < TP; ++tp)
+                        acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tc], b[tp], acc[tc][tp], 0, 0, 0);
+            }
+            // (3) everything issued before this step's DMAs has landed (the step+1 weights, older slab pieces)
+            if (tap < 6) wait_vm<NBP + 1>();
+            else wait_vm<NBP>();
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    wait_vm<0>();                       // drain the redundant tail DMAs before LDS is reused below
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue -----------------------------------------------------------------------------------------------------
+    // acc[tc][tp][i]: output channel n0 + wc*64 + tc*32 + (i&3) + 8*(i>>2) + 4*h, pixel (y0 + wp*TP + tp, x0 + r)
+    const int px = x0 + r;
+    const bool colok = px < W;
+    float s[TC][16], q[TC][16];
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = n0 + wc * 64 + tc * 32 + 8 * g + 4 * h;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (bias != nullptr && co < Cout) bv = *reinterpret_cast<const f32x4*>(bias + co);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[tc][4 * g + j] = 0.f; q[tc][4 * g + j] = 0.f; }
+#pragma unroll
+            for (int tp = 0; tp < TP; ++tp) {
+                const int py = y0 + wp * TP + tp;
+                const bool ok = colok & (py < H);
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[tc][tp][4 * g + j] + bv[j];
+                if (ok) {
+                    if (STATS) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { s[tc][4 * g + j] += v[j]; q[tc][4 * g + j] += v[j] * v[j]; }
+                    }
+                    if (co < ldy) {
+                        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        *reinterpret_cast<bf16x4*>(Y + ((size_t)(img * H + py) * W + px) * ldy + co) = o;
+                    }
+                }
+            }
+        }
+    }
+    if (!STATS) return;
+    // per channel: 32 lanes x WP waves hold partial (sum, sum of squares) over their pixels -> LDS [channel][64 partials][2]
+    float* const red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ch = wc * 64 + tc * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int part = wp * 32 + r;                                      // 0 .. 32*WP-1
+            float2 v2 = {s[tc][i], q[tc][i]};
+            *reinterpret_cast<float2*>(red + ((size_t)ch * (32 * WP) + part) * 2) = v2;
+        }
+    __syncthreads();
+    if (tid < BN) {
+        const int co = n0 + tid;
+        double S = 0.0, Q = 0.0;
+        const float2* p = reinterpret_cast<const float2*>(red) + (size_t)tid * (32 * WP);
+#pragma unroll 8
+        for (int i = 0; i < 32 * WP; ++i) { S += (double)p[i].x; Q += (double)p[i].y; }
+        const int nvalid = min(TH, H - y0) * min(TW, W - x0);
+        if (co < Cout) {
+            double m2 = Q - S * S / (double)nvalid;
+            stats[(size_t)sp * Cout + co] = (float)S;
+            stats[(size_t)(P + sp) * Cout + co] = (float)(m2 > 0.0 ? m2 : 0.0);
+        }
+        if (nt == 0 && tid == 0) cnt[sp] = (float)nvalid;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ operand preparation
+// fp32 master weights, physical [Cout][3][3][Cin] (channels_last OIHW) -> bf16 [rows_pad][9][Cin_pad], zero padded.
+__global__ void k_pack_w_fwd_bf16(const float* __restrict__ w, __bf16* __restrict__ out, int Cout, int Cin, int rows_pad, int Cin_pad) {
+    const size_t total = (size_t)rows_pad * 9 * Cin_pad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin_pad);
+        const size_t rt = i / Cin_pad;
+        const int tap = (int)(rt % 9), co = (int)(rt / 9);
+        out[i] = (co < Cout && ci < Cin) ? (__bf16)w[((size_t)co * 9 + tap) * Cin + ci] : (__bf16)0.f;
+    }
+}
+
+// data-grad filter: out[ci][tap'][co] = w[co][8 - tap'][ci]  (rotated by 180 degrees, channels transposed), bf16, zero padded
+__global__ void k_pack_w_dgrad_bf16(const float* __restrict__ w, __bf16* __restrict__ out, int Cout, int Cin, int rows_pad, int Cout_pad) {
+    const size_t total = (size_t)rows_pad * 9 * Cout_pad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout_pad);
+        const size_t rt = i / Cout_pad;
+        const int tap = (int)(rt % 9), ci = (int)(rt / 9);
+        out[i] = (co < Cout && ci < Cin) ? (__bf16)w[((size_t)co * 9 + (8 - tap)) * Cin + ci] : (__bf16)0.f;
+    }
+}
+
+inline int bf16s_bn(int cout) { return cout > 64 ? 128 : 64; }
+
+}  // namespace
+
+extern "C" int cvk_bf16s_rows_pad(int cout) {
+    if (cout <= 0) return 0;
+    const int bn = bf16s_bn(cout);
+    return cvk_cdiv(cout, bn) * bn;
+}
+
+extern "C" int cvk_bf16s_stat_partials(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    return N * cvk_cdiv(H, TH) * cvk_cdiv(W, TW);
+}
+
+extern "C" int cvk_pack_weight_fwd_bf16(const float* w, void* out, int Cout, int Cin, int Cin_pad, void* stream) {
+    CVK_CHECK_ARG(w && out && Cout > 0 && Cin > 0 && Cin_pad >= Cin && Cin_pad % CK == 0, "cvk_pack_weight_fwd_bf16: bad arguments");
+    const int rows = cvk_bf16s_rows_pad(Cout);
+    const size_t total = (size_t)rows * 9 * Cin_pad;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_pack_w_fwd_bf16, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)out, Cout, Cin, rows, Cin_pad);
+    CVK_LAUNCH_RETURN("cvk_pack_weight_fwd_bf16");
+}
+
+extern "C" int cvk_pack_weight_dgrad_bf16(const float* w, void* out, int Cout, int Cin, int Cout_pad, void* stream) {
+    CVK_CHECK_ARG(w && out && Cout > 0 && Cin > 0 && Cout_pad >= Cout && Cout_pad % CK == 0, "cvk_pack_weight_dgrad_bf16: bad arguments");
+    const int rows = cvk_bf16s_rows_pad(Cin);
+    const size_t total = (size_t)rows * 9 * Cout_pad;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_pack_w_dgrad_bf16, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)out, Cout, Cin, rows, Cout_pad);
+    CVK_LAUNCH_RETURN("cvk_pack_weight_dgrad_bf16");
+}
+
+extern "C" int cvk_conv3x3_bf16s(const void* x, const void* w, const float* bias, void* y, float* stats, float* counts, int N, int H,
+                                 int W, int Cin, int Cout, int ldy, void* stream) {
+    CVK_CHECK_ARG(x && w && y, "cvk_conv3x3_bf16s: null pointer");
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout && ldy % 4 == 0, "cvk_conv3x3_bf16s: bad shape (ldy must be a multiple of 4)");
+    CVK_CHECK_ARG(Cin > 0 && Cin % CK == 0, "cvk_conv3x3_bf16s: Cin=%d must be a multiple of %d (pad the tensor)", Cin, CK);
+    CVK_CHECK_ARG((stats == nullptr) == (counts == nullptr), "cvk_conv3x3_bf16s: stats and counts come together");
+    CVK_CHECK_ARG(stats == nullptr || Cout % 4 == 0, "cvk_conv3x3_bf16s: Cout must be a multiple of 4 with statistics");
+    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(w) && (((uintptr_t)y) & 7u) == 0, "cvk_conv3x3_bf16s: misaligned pointer");
+    CVK_CHECK_ARG((long)H * W * Cin < (1L << 31) && (long)cvk_bf16s_rows_pad(Cout) * 9 * Cin < (1L << 31), "cvk_conv3x3_bf16s: one image or the weight tensor exceeds 2^31 elements");
+    const int tilesX = cvk_cdiv(W, TW), tilesY = cvk_cdiv(H, TH);
+    const int bn = bf16s_bn(Cout);
+    const int tilesN = cvk_cdiv(Cout, bn);
+    const long P = (long)N * tilesX * tilesY;
+    CVK_CHECK_ARG(P * tilesN < (1L << 31), "cvk_conv3x3_bf16s: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)(P * tilesN)), block(256);
+#define CVK_BS_LAUNCH(BN_, ST_)                                                                                              \
+    hipLaunchKernelGGL((k_conv_bf16s<BN_, ST_>), grid, block, 0, s, (const __bf16*)x, (const __bf16*)w, bias, (__bf16*)y, stats, counts, \
+                       H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, (int)P)
+    if (bn == 128) { if (stats) CVK_BS_LAUNCH(128, true); else CVK_BS_LAUNCH(128, false); }
+    else           { if (stats) CVK_BS_LAUNCH(64, true); else CVK_BS_LAUNCH(64, false); }
+#undef CVK_BS_LAUNCH
+    CVK_LAUNCH_RETURN("cvk_conv3x3_bf16s");
+}
+
+// ================================================================================================ weight-grad (bf16 storage)
+// dW[co][tap][ci] = sum_pixels dy[p][co] * x[p + tap][ci]   (reference: the weight gradient of nn.Conv2d, train.py:131)
+// GEMM per tap: D[co][ci] += dy^T[co][pixel] * x_shifted[pixel][ci], K = pixels.  One workgroup (4 waves, one per SIMD,
+// the whole 160 KiB LDS) owns a 64 x 64 (co, ci) block of all nine taps and walks a range of 8 x 32 pixel tiles:
+//   * per tile the dy tile (256 px x 64 co) and the x tile WITH HALO (10 x 34 px x 64 ci) are DMA'd into LDS once and the
+//     nine taps read x at shifted addresses (the im2col weight-grad of round 1 re-staged x nine times and synchronised
+//     every 8 MFMAs; here a phase is 144 MFMAs per wave between two barriers);
+//   * both operands are pixel-major in LDS but the MFMA wants 8 consecutive K (= pixel) values per lane:
+//     ds_read_b64_tr_b16 (hardware 4x16 transpose).  128-byte rows; 16-byte chunk c of LDS row p sits at position
+//     c ^ (4 * ((p>>1)&1)) (swizzled through the DMA source address) -> the four rows x two 16-lane groups of a 32-lane
+//     half hit 64 distinct banks; all tap / k-step terms are immediates on four per-lane base addresses;
+//   * double-buffered: the DMA of tile t+1 is issued before the MFMAs of tile t.
+// Each wave keeps its 32 x 32 (co, ci) sub-block of all nine taps in 144 accumulator registers.  Partial sums over the
+// tile ranges go to fp32 slabs [split][Cout][9][Cin], reduced in a fixed order by k_wgrad_reduce_bf16s (deterministic).
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WG_XROWS = (TH + 2) * HP;                 // 360 LDS rows (halo pixels) of 128 B
+constexpr int WG_XPIECES = 48;                          // 8-row DMA pieces, 45 needed, 12 per wave
+constexpr int WG_XBYTES = WG_XPIECES * 1024;
+constexpr int WG_DPIECES = 32;                          // dy tile: 256 rows of 128 B, 8 pieces per wave
+constexpr int WG_DBYTES = WG_DPIECES * 1024;
+constexpr int WG_STAGE = WG_XBYTES + WG_DBYTES;         // 80 KiB per stage
+
+__device__ __forceinline__ bf16x8 tr_read8(const char* p) {
+    // rows p .. p+3 (first read) and p+4 .. p+7 (second read, 4 LDS rows = 512 B further) -> 8 consecutive K values
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 512));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__global__ __launch_bounds__(256, 1) void k_wgrad_bf16s(const __bf16* __restrict__ X, const __bf16* __restrict__ DY,
+                                                       float* __restrict__ slab, int H, int W, int ldx, int ld_dy, int Cout,
+                                                       int Cin, int tilesX, int tilesY, int ntiles, int tiles_per_split,
+                                                       int nblk_ci, int nblk) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * WG_STAGE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int wco = wave >> 1, wci = wave & 1;
+
+    const int gid = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int blk = gid % nblk, split = gid / nblk;      // blocks of one pixel range are neighbours (one XCD's L2)
+    const int cob = blk / nblk_ci, cib = blk % nblk_ci;
+    const int t0 = split * tiles_per_split;
+    const int t1 = min(ntiles, t0 + tiles_per_split);
+    const __bf16* const zero = reinterpret_cast<const __bf16*>(g_zero_page);
+
+    // ---- static part of the DMA source mapping --------------------------------------------------------------------------
+    // x slab: piece q (0..11) of this wave covers LDS rows (wave*12 + q)*8 + lane/8, 16-byte position lane%8
+    int xs_hy[12], xs_hx[12], xs_ch[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+        const int row = (wave * 12 + q) * 8 + (lane >> 3);
+        const int hy = row / HP, hx = row - hy * HP;
+        const int chunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
+        const bool ok = (row < WG_XROWS) & (hx < TW + 2) & (cib * 64 + chunk * 8 < ldx);
+        xs_hy[q] = ok ? hy : -100000;
+        xs_hx[q] = hx;
+        xs_ch[q] = cib * 64 + chunk * 8;
+    }
+    int ds_py[8], ds_px[8], ds_ch[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int row = (wave * 8 + q) * 8 + (lane >> 3);      // tile pixel index: py*32 + px
+        const int chunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
+        const bool ok = cob * 64 + chunk * 8 < ld_dy;
+        ds_py[q] = ok ? row >> 5 : 100000;
+        ds_px[q] = row & 31;
+        ds_ch[q] = cob * 64 + chunk * 8;
+    }
+    auto stage = [&](int t, char* buf) {
+        const int tx = t % tilesX, ty = (t / tilesX) % tilesY, img = t / (tilesX * tilesY);
+        const int x0 = tx * TW, y0 = ty * TH;
+        const size_t ibase = (size_t)img * H * W;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const int iy = y0 - 1 + xs_hy[q], ix = x0 - 1 + xs_hx[q];
+            const bool ok = ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+            const __bf16* src = ok ? X + (ibase + (size_t)iy * W + ix) * ldx + xs_ch[q] : zero;
+            dma16(src, buf + (wave * 12 + q) * 1024);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int iy = y0 + ds_py[q], ix = x0 + ds_px[q];
+            const bool ok = (iy < H) & (ix < W);
+            const __bf16* src = ok ? DY + (ibase + (size_t)iy * W + ix) * ld_dy + ds_ch[q] : zero;
+            dma16(src, buf + WG_XBYTES + (wave * 8 + q) * 1024);
+        }
+    };
+
+    // ---- transposed-read lane addresses -----------------------------------------------------------------------------------
+    // 16-lane group g1 = (lane>>4)&1 covers matrix columns 16*g1 .. +15; inside it lane 4*tq + tp supplies LDS row tq
+    // (first read; +4 second), columns 4*tp .. 4*tp+3.  K half h: pixels 8h .. 8h+7 of the 16-pixel k-step.
+    const int tq = (lane & 15) >> 2, tp = lane & 3, g1 = (lane >> 4) & 1;
+    auto lane_addr = [&](int row_lane, int col_local) {      // byte offset in an image of 128-byte rows, row term = row_lane
+        const int chunk = col_local >> 3;
+        return row_lane * 128 + ((chunk ^ (((row_lane >> 1) & 1) << 2)) << 4) + (col_local & 7) * 2;
+    };
+    const int rl = 8 * h + tq;
+    const int a_base = WG_XBYTES + lane_addr(rl, wco * 32 + 16 * g1 + 4 * tp);           // dy tile
+    int b_base[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) b_base[dx] = lane_addr(rl + dx, wci * 32 + 16 * g1 + 4 * tp);
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    if (t0 < t1) stage(t0, smem);
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int t = t0; t < t1; ++t) {
+        char* const buf = smem + cur * WG_STAGE;
+        if (t + 1 < t1) stage(t + 1, smem + (cur ^ 1) * WG_STAGE);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int ry = ks >> 1, xh = ks & 1;
+            const bf16x8 a = tr_read8(buf + a_base + (ry * 32 + xh * 16) * 128);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const bf16x8 b = tr_read8(buf + b_base[dx] + ((ry + dy) * HP + xh * 16) * 128);
+                    acc[3 * dy + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[3 * dy + dx], 0, 0, 0);
+                }
+        }
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        cur ^= 1;
+    }
+
+    // ---- partial slab: [split][co][tap][ci] fp32 ---------------------------------------------------------------------------
+    float* out = slab + (size_t)split * Cout * 9 * Cin;
+    const int ci = cib * 64 + wci * 32 + (lane & 31);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int co = cob * 64 + wco * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (co < Cout && ci < Cin) out[((size_t)co * 9 + tap) * Cin + ci] = acc[tap][i];
+        }
+}
+
+__global__ void k_wgrad_reduce_bf16s(const float* __restrict__ slab, float* __restrict__ dw, int splits, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int s = 0;
+        for (; s + 4 <= splits; s += 4) {
+            s0 += slab[(size_t)(s + 0) * n + i];
+            s1 += slab[(size_t)(s + 1) * n + i];
+            s2 += slab[(size_t)(s + 2) * n + i];
+            s3 += slab[(size_t)(s + 3) * n + i];
+        }
+        for (; s < splits; ++s) s0 += slab[(size_t)s * n + i];
+        dw[i] = (s0 + s1) + (s2 + s3);
+    }
+}
+
+struct WgPlan { int nblk_co, nblk_ci, ntiles, splits, tps; };
+
+inline WgPlan plan_wgrad_bf16s(int N, int H, int W, int Cin, int Cout) {
+    WgPlan p;
+    p.nblk_co = cvk_cdiv(Cout, 64);
+    p.nblk_ci = cvk_cdiv(Cin, 64);
+    p.ntiles = N * cvk_cdiv(H, TH) * cvk_cdiv(W, TW);
+    const int nblk = p.nblk_co * p.nblk_ci;
+    // one workgroup per CU: aim at a whole number of 256-workgroup rounds, at least 2 tiles per workgroup when possible
+    int splits = cvk_cdiv(512, nblk);
+    if (splits > p.ntiles) splits = p.ntiles;
+    if (splits < 1) splits = 1;
+    p.tps = cvk_cdiv(p.ntiles, splits);
+    p.splits = cvk_cdiv(p.ntiles, p.tps);
+    return p;
+}
+
+}  // namespace
+
+extern "C" size_t cvk_conv3x3_wgrad_bf16s_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    const WgPlan p = plan_wgrad_bf16s(N, H, W, Cin, Cout);
+    return (size_t)p.splits * Cout * 9 * Cin * sizeof(float);
+}
+
+// x: bf16 [N,H,W,ldx] (channels Cin..ldx-1 are never read as valid), dy: bf16 [N,H,W,ld_dy]; dw: fp32 [Cout][9][Cin]
+extern "C" int cvk_conv3x3_wgrad_bf16s(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int ldx, int Cout,
+                                       int ld_dy, void* workspace, size_t workspace_bytes, void* stream) {
+    CVK_CHECK_ARG(x && dy && dw && workspace, "cvk_conv3x3_wgrad_bf16s: null pointer");
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ldx >= Cin && ld_dy >= Cout, "cvk_conv3x3_wgrad_bf16s: bad shape");
+    CVK_CHECK_ARG(ldx % 8 == 0 && ld_dy % 8 == 0, "cvk_conv3x3_wgrad_bf16s: ldx and ld_dy must be multiples of 8");
+    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(dy) && cvk_aligned16(workspace), "cvk_conv3x3_wgrad_bf16s: pointers must be 16-byte aligned");
+    const WgPlan p = plan_wgrad_bf16s(N, H, W, Cin, Cout);
+    const size_t n = (size_t)Cout * 9 * Cin;
+    const size_t need = (size_t)p.splits * n * sizeof(float);
+    if (workspace_bytes < need) {
+        cvk_set_error("cvk_conv3x3_wgrad_bf16s: workspace %zu < %zu bytes", workspace_bytes, need);
+        return CVK_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = p.nblk_co * p.nblk_ci;
+    hipLaunchKernelGGL(k_wgrad_bf16s, dim3(nblk * p.splits), dim3(256), 0, s, (const __bf16*)x, (const __bf16*)dy, (float*)workspace, H, W,
+                       ldx, ld_dy, Cout, Cin, cvk_cdiv(W, TW), cvk_cdiv(H, TH), p.ntiles, p.tps, p.nblk_ci, nblk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        cvk_set_error("cvk_conv3x3_wgrad_bf16s: launch failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_wgrad_reduce_bf16s, dim3(blocks), dim3(256), 0, s, (const float*)workspace, dw, p.splits, n);
+    CVK_LAUNCH_RETURN("cvk_conv3x3_wgrad_bf16s");
+}

@@ -6,64 +6,160 @@
 
 namespace {
 
-constexpr int CE_ROWS_PER_BLOCK = 1024;  // 256 threads x 4 pixels
+constexpr int CE_ROWS_PER_BLOCK = 1024;  // 4 chunks of 256 pixels per workgroup
+constexpr int CE_CHUNK = 256;            // one pixel per thread per chunk
+constexpr int CE_MAX_LD = 128;           // widest pixel row staged through LDS ((ld + 1) * 1 KB of LDS)
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
     v = wave_sum(v);
+    __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(256) void k_ce_fwd(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
-                                               float* __restrict__ part, int M, int C) {
-    __shared__ float red[4];
-    float acc = 0.f;
-    const int base = blockIdx.x * CE_ROWS_PER_BLOCK;
-    for (int r = threadIdx.x; r < CE_ROWS_PER_BLOCK; r += 256) {
-        const int m = base + r;
-        if (m >= M) break;
-        const float* p = logits + (size_t)m * ld;
-        float mx = p[0];
-        for (int c = 1; c < C; ++c) mx = fmaxf(mx, p[c]);
-        float se = 0.f;
-        for (int c = 0; c < C; ++c) se += expf(p[c] - mx);
-        const int t = (int)target[m];
-        const float lt = (t >= 0 && t < C) ? p[t] : 0.f;
-        acc += (mx + logf(se)) - lt;
+// Global <-> LDS movement of one chunk: the chunk's CE_CHUNK pixel rows are `n` contiguous floats in HBM (rows of ld
+// floats); every wave instruction moves 64 consecutive float4 (1 KiB, fully used lines).  In LDS a pixel row has pitch
+// ld + 1 floats, so the per-thread row walk below (thread = pixel, column c) is bank-conflict free.
+__device__ __forceinline__ void ce_chunk_load(const float* __restrict__ g, float* lds, int n, int ld) {
+    const int pitch = ld + 1;
+    if ((ld & 3) == 0 && ((uintptr_t)g & 15u) == 0) {
+        for (int f = threadIdx.x * 4; f < n; f += CE_CHUNK * 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(g + f);
+            const int r = f / ld, c = f - r * ld;                  // ld % 4 == 0: the four floats share a row
+            float* q = lds + r * pitch + c;
+            q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3];
+        }
+    } else {
+        for (int f = threadIdx.x; f < n; f += CE_CHUNK) {
+            const int r = f / ld;
+            lds[r * pitch + (f - r * ld)] = g[f];
+        }
     }
-    const float s = block_sum_256(acc, red);
-    if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
-__global__ __launch_bounds__(256) void k_ce_finish(const float* __restrict__ part, int nb, float* loss, int M) {
-    __shared__ double red[256];
-    double a = 0.0;
-    for (int i = threadIdx.x; i < nb; i += 256) a += (double)part[i];
-    red[threadIdx.x] = a;
+__device__ __forceinline__ void ce_chunk_store(float* __restrict__ g, const float* lds, int n, int ld) {
+    const int pitch = ld + 1;
+    if ((ld & 3) == 0 && ((uintptr_t)g & 15u) == 0) {
+        for (int f = threadIdx.x * 4; f < n; f += CE_CHUNK * 4) {
+            const int r = f / ld, c = f - r * ld;
+            const float* q = lds + r * pitch + c;
+            const f32x4 v = {q[0], q[1], q[2], q[3]};
+            *reinterpret_cast<f32x4*>(g + f) = v;
+        }
+    } else {
+        for (int f = threadIdx.x; f < n; f += CE_CHUNK) {
+            const int r = f / ld;
+            g[f] = lds[r * pitch + (f - r * ld)];
+        }
+    }
+}
+
+// part[b] = sum of -log softmax(logits)[target] over the block's valid pixels, part[nb + b] = number of valid pixels,
+// part[2 nb + b] = number of pixels whose target is neither in [0, C) nor ignore_index.
+__global__ __launch_bounds__(256) void k_ce_fwd(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
+                                               float* __restrict__ part, int nb, int M, int C, int ignore_index) {
+    extern __shared__ float lds[];
+    __shared__ float red[4];
+    const int pitch = ld + 1;
+    float acc = 0.f, cnt = 0.f, bad = 0.f;
+    const int base = blockIdx.x * CE_ROWS_PER_BLOCK;
+    for (int ch = 0; ch < CE_ROWS_PER_BLOCK / CE_CHUNK; ++ch) {
+        const int m0 = base + ch * CE_CHUNK;
+        if (m0 >= M) break;
+        const int rows = min(CE_CHUNK, M - m0);
+        __syncthreads();
+        ce_chunk_load(logits + (size_t)m0 * ld, lds, rows * ld, ld);
+        __syncthreads();
+        if ((int)threadIdx.x < rows) {
+            const float* p = lds + threadIdx.x * pitch;
+            const long t = (long)target[m0 + threadIdx.x];
+            if (t != (long)ignore_index) {
+                float mx = p[0];
+                for (int c = 1; c < C; ++c) mx = fmaxf(mx, p[c]);
+                float se = 0.f;
+                for (int c = 0; c < C; ++c) se += expf(p[c] - mx);
+                if (t >= 0 && t < C) {
+                    acc += (mx + logf(se)) - p[t];
+                    cnt += 1.f;
+                } else {
+                    bad += 1.f;
+                }
+            }
+        }
+    }
+    const float s = block_sum_256(acc, red);
+    const float n = block_sum_256(cnt, red);
+    const float b = block_sum_256(bad, red);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = s;
+        part[nb + blockIdx.x] = n;
+        part[2 * nb + blockIdx.x] = b;
+    }
+}
+
+// loss[0] = mean over the valid pixels (NaN when a target was out of range: nn.CrossEntropyLoss raises there),
+// loss[1] = number of valid pixels (the backward's divisor), loss[2] = number of out-of-range targets.
+__global__ __launch_bounds__(256) void k_ce_finish(const float* __restrict__ part, int nb, float* loss) {
+    __shared__ double red[3][256];
+    double a = 0.0, n = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        a += (double)part[i];
+        n += (double)part[nb + i];
+        b += (double)part[2 * nb + i];
+    }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = n; red[2][threadIdx.x] = b;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        if (threadIdx.x < o)
+            for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *loss = (float)(red[0] / (double)M);
+    if (threadIdx.x == 0) {
+        loss[0] = red[2][0] > 0.0 ? __builtin_nanf("") : (float)(red[0][0] / red[1][0]);   // 0/0 = NaN when every pixel is ignored (as torch)
+        loss[1] = (float)red[1][0];
+        loss[2] = (float)red[2][0];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_ce_bwd(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
-                                               const float* __restrict__ grad_out, float scale, float* __restrict__ dl, int ld_d,
-                                               int M, int C) {
-    const float g = (grad_out != nullptr ? *grad_out : 1.f) * scale / (float)M;
-    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
-        const float* p = logits + (size_t)m * ld;
-        float* q = dl + (size_t)m * ld_d;
-        float mx = p[0];
-        for (int c = 1; c < C; ++c) mx = fmaxf(mx, p[c]);
-        float se = 0.f;
-        for (int c = 0; c < C; ++c) se += expf(p[c] - mx);
-        const float inv = 1.f / se;
-        const int t = (int)target[m];
-        for (int c = 0; c < C; ++c) q[c] = (expf(p[c] - mx) * inv - (c == t ? 1.f : 0.f)) * g;
-        for (int c = C; c < ld_d; ++c) q[c] = 0.f;
+                                               const float* __restrict__ loss3, const float* __restrict__ grad_out, float scale,
+                                               float* __restrict__ dl, int ld_d, int M, int C, int ignore_index) {
+    extern __shared__ float lds[];
+    const int pitch = ld + 1;
+    const float g = (grad_out != nullptr ? *grad_out : 1.f) * scale / loss3[1];
+    const int base = blockIdx.x * CE_ROWS_PER_BLOCK;
+    for (int ch = 0; ch < CE_ROWS_PER_BLOCK / CE_CHUNK; ++ch) {
+        const int m0 = base + ch * CE_CHUNK;
+        if (m0 >= M) break;
+        const int rows = min(CE_CHUNK, M - m0);
+        __syncthreads();
+        ce_chunk_load(logits + (size_t)m0 * ld, lds, rows * ld, ld);
+        __syncthreads();
+        if ((int)threadIdx.x < rows) {
+            float* p = lds + threadIdx.x * pitch;
+            const long t = (long)target[m0 + threadIdx.x];
+            if (t == (long)ignore_index) {
+                for (int c = 0; c < ld; ++c) p[c] = 0.f;
+            } else {
+                float mx = p[0];
+                for (int c = 1; c < C; ++c) mx = fmaxf(mx, p[c]);
+                float se = 0.f;
+                for (int c = 0; c < C; ++c) se += expf(p[c] - mx);
+                const float inv = 1.f / se;
+                for (int c = 0; c < C; ++c) p[c] = (expf(p[c] - mx) * inv - ((long)c == t ? 1.f : 0.f)) * g;
+                for (int c = C; c < ld; ++c) p[c] = 0.f;
+            }
+        }
+        __syncthreads();
+        if (ld_d == ld) {
+            ce_chunk_store(dl + (size_t)m0 * ld_d, lds, rows * ld, ld);
+        } else {
+            for (int f = threadIdx.x; f < rows * ld_d; f += CE_CHUNK) {
+                const int r = f / ld_d, c = f - r * ld_d;
+                dl[(size_t)m0 * ld_d + f] = c < ld ? lds[r * pitch + c] : 0.f;
+            }
+        }
     }
 }
 
@@ -145,20 +241,22 @@ extern "C" int cvk_preprocess_u8(const uint8_t* src, float* dst, int N, int H, i
 extern "C" int cvk_ce_blocks(int M) { return M > 0 ? cvk_cdiv(M, CE_ROWS_PER_BLOCK) : 0; }
 
 extern "C" int cvk_softmax_ce_fwd(const float* logits, int ld, const int64_t* target, float* part, float* loss, int M, int C,
-                                  void* stream) {
+                                  int ignore_index, void* stream) {
     CVK_CHECK_ARG(logits && target && part && loss && M > 0 && C > 0 && ld >= C, "cvk_softmax_ce_fwd: bad arguments");
+    CVK_CHECK_ARG(ld <= CE_MAX_LD, "cvk_softmax_ce_fwd: pixel rows wider than %d floats are not supported (ld=%d)", CE_MAX_LD, ld);
     const int nb = cvk_ce_blocks(M);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_ce_fwd, dim3(nb), dim3(256), 0, s, logits, ld, target, part, M, C);
-    hipLaunchKernelGGL(k_ce_finish, dim3(1), dim3(256), 0, s, part, nb, loss, M);
+    hipLaunchKernelGGL(k_ce_fwd, dim3(nb), dim3(256), CE_CHUNK * (ld + 1) * sizeof(float), s, logits, ld, target, part, nb, M, C, ignore_index);
+    hipLaunchKernelGGL(k_ce_finish, dim3(1), dim3(256), 0, s, part, nb, loss);
     CVK_LAUNCH_RETURN("cvk_softmax_ce_fwd");
 }
 
-extern "C" int cvk_softmax_ce_bwd(const float* logits, int ld, const int64_t* target, const float* grad_out, float scale,
-                                  float* dlogits, int ld_d, int M, int C, void* stream) {
-    CVK_CHECK_ARG(logits && target && dlogits && M > 0 && C > 0 && ld >= C && ld_d >= C, "cvk_softmax_ce_bwd: bad arguments");
-    const int blocks = cvk_cdiv(M, 256) < 8192 ? cvk_cdiv(M, 256) : 8192;
-    hipLaunchKernelGGL(k_ce_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, ld, target, grad_out, scale, dlogits, ld_d, M, C);
+extern "C" int cvk_softmax_ce_bwd(const float* logits, int ld, const int64_t* target, const float* loss3, const float* grad_out,
+                                  float scale, float* dlogits, int ld_d, int M, int C, int ignore_index, void* stream) {
+    CVK_CHECK_ARG(logits && target && loss3 && dlogits && M > 0 && C > 0 && ld >= C && ld_d >= C, "cvk_softmax_ce_bwd: bad arguments");
+    CVK_CHECK_ARG(ld <= CE_MAX_LD, "cvk_softmax_ce_bwd: pixel rows wider than %d floats are not supported (ld=%d)", CE_MAX_LD, ld);
+    hipLaunchKernelGGL(k_ce_bwd, dim3(cvk_ce_blocks(M)), dim3(256), CE_CHUNK * (ld + 1) * sizeof(float), (hipStream_t)stream, logits, ld,
+                       target, loss3, grad_out, scale, dlogits, ld_d, M, C, ignore_index);
     CVK_LAUNCH_RETURN("cvk_softmax_ce_bwd");
 }
 

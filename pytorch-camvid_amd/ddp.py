@@ -37,8 +37,47 @@ def make_buckets(layer_ranges, bucket_floats):
     return buckets
 
 
+class _SyncCall:
+    """State of ONE backward call (engine.Runner.backward): begin() creates it, the executor calls layer_done(slot)
+    for each conv block in reverse execution order and finish() at the end.  Nothing is kept on the GradSync between
+    calls, so two backward passes through one network inside a single autograd graph do not share bucket cursors."""
+
+    def __init__(self, owner, st):
+        self.owner = owner
+        offs, params = st.goffs, st.params
+        nslots = len(params) // 4
+        self.ranges = []
+        for slot in range(nslots - 1, -1, -1):                       # completion order == ascending flat offsets
+            lo = offs[4 * slot]
+            hi = offs[4 * slot + 3] + (params[4 * slot + 3].numel() + 3) // 4 * 4
+            self.ranges.append((lo, hi))
+        self.buckets = make_buckets(self.ranges, owner.bucket_floats)
+        self.next_bucket = 0
+        self.layers_done = 0
+        self.work = []
+        self.launched = []
+
+    def layer_done(self, st, slot):
+        self.layers_done += 1
+        done_upto = self.ranges[self.layers_done - 1][1]
+        while self.next_bucket < len(self.buckets) and self.buckets[self.next_bucket][1] <= done_upto:
+            lo, hi, _ = self.buckets[self.next_bucket]
+            self.owner._issue(self, st.gflat[lo:hi])
+            self.launched.append((lo, hi))
+            self.next_bucket += 1
+
+    def finish(self, st):
+        assert self.next_bucket == len(self.buckets), "a gradient bucket was never completed"
+        for w, t in self.work:
+            w.wait()                       # nccl: makes the current stream wait for the collective; no host sync
+            if t is not None:
+                t.div_(self.owner.world)
+        self.work = []
+        self.owner.launched = self.launched
+
+
 class GradSync:
-    """Called by engine.Runner.backward: begin() -> layer_done(slot) for each conv block in reverse order -> finish()."""
+    """Bucketed gradient all-reduce hooked into engine.Runner.backward (begin() -> a per-call _SyncCall)."""
 
     def __init__(self, process_group=None, bucket_mb=32.0, always_issue=False):
         self.pg = process_group
@@ -46,46 +85,24 @@ class GradSync:
         self.bucket_floats = int(bucket_mb * (1 << 20) / 4)
         self.world = dist.get_world_size(process_group)
         self._native_avg = dist.get_backend(process_group) == "nccl"
-        self.launched = []       # (begin, end) of the buckets issued during the last backward (introspection/tests)
+        self.launched = []       # (begin, end) of the buckets issued during the last finished backward (introspection/tests)
 
     def begin(self, st, plan=None):
-        offs, params = st.goffs, st.params
-        nslots = len(params) // 4
-        self._ranges = []
-        for slot in range(nslots - 1, -1, -1):                       # completion order == ascending flat offsets
-            lo = offs[4 * slot]
-            hi = offs[4 * slot + 3] + (params[4 * slot + 3].numel() + 3) // 4 * 4
-            self._ranges.append((lo, hi))
-        self._buckets = make_buckets(self._ranges, self.bucket_floats)
-        self._next_bucket = 0
-        self._layers_done = 0
-        self._work = []
-        self.launched = []
+        return _SyncCall(self, st)
 
-    def layer_done(self, st, slot):
-        self._layers_done += 1
-        done_upto = self._ranges[self._layers_done - 1][1]
-        while self._next_bucket < len(self._buckets) and self._buckets[self._next_bucket][1] <= done_upto:
-            lo, hi, _ = self._buckets[self._next_bucket]
-            self._issue(st.gflat[lo:hi])
-            self.launched.append((lo, hi))
-            self._next_bucket += 1
-
-    def _issue(self, t):
+    def _issue(self, call, t):
         if self.world == 1 and not self.always_issue:
             return
         if self._native_avg:
-            self._work.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.pg, async_op=True), None))
-        else:  # gloo (CPU rehearsal) has no AVG
-            self._work.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), t))
-
-    def finish(self, st):
-        assert self._next_bucket == len(self._buckets), "a gradient bucket was never completed"
-        for w, t in self._work:
-            w.wait()                       # nccl: makes the current stream wait for the collective; no host sync
-            if t is not None:
-                t.div_(self.world)
-        self._work = []
+            call.work.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.pg, async_op=True), None))
+        elif t.is_cuda:
+            # gloo rehearsal with the real engine on a GPU (tests, CVK_REHEARSAL): gloo moves host memory, so the bucket
+            # is staged through the CPU synchronously — a plumbing path, never a measurement
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
+            t.copy_(h.div_(self.world))
+        else:  # gloo on CPU tensors has no AVG
+            call.work.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), t))
 
 
 class DataParallel(nn.Module):
@@ -105,7 +122,13 @@ class DataParallel(nn.Module):
                 for t in list(module.parameters()) + list(module.buffers()):
                     # conv weights are stored channels_last: broadcast their dense [Cout][3][3][Cin] view
                     v = t.permute(0, 2, 3, 1) if t.dim() == 4 and not t.is_contiguous() else t
-                    dist.broadcast(v if v.is_contiguous() else t.data, src=0, group=process_group)
+                    v = v if v.is_contiguous() else t.data
+                    if self.sync._native_avg or not v.is_cuda:
+                        dist.broadcast(v, src=0, group=process_group)
+                    else:                                   # gloo + GPU tensors (rehearsal): through host memory
+                        h = v.cpu()
+                        dist.broadcast(h, src=0, group=process_group)
+                        v.copy_(h)
         runner_of(module).grad_sync = self.sync
 
     def forward(self, x):

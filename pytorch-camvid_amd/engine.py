@@ -15,7 +15,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import View, check
+from ._lib import View, ViewH, check
 
 _F32 = torch.float32
 
@@ -24,12 +24,21 @@ def pad4(c):
     return (c + 3) // 4 * 4
 
 
-class ActBuf:
-    """Logical NHWC activation buffer [N,H,W,C] stored with pixel stride ld = pad4(C)."""
-    __slots__ = ("id", "N", "H", "W", "C", "ld", "name")
+_BF16 = torch.bfloat16
 
-    def __init__(self, id_, N, H, W, C, name=""):
-        self.id, self.N, self.H, self.W, self.C, self.ld, self.name = id_, N, H, W, C, pad4(C), name
+
+class ActBuf:
+    """Logical NHWC activation buffer [N,H,W,C] stored with pixel stride ld: fp32 with ld = pad4(C), or (bf16-storage
+    plans) bf16 with ld = C rounded up to 8, at least 32 — the K-slice of the bf16 convolution kernels."""
+    __slots__ = ("id", "N", "H", "W", "C", "ld", "name", "dtype")
+
+    def __init__(self, id_, N, H, W, C, name="", dtype=_F32):
+        self.id, self.N, self.H, self.W, self.C, self.name, self.dtype = id_, N, H, W, C, name, dtype
+        self.ld = pad4(C) if dtype == _F32 else max(32, (C + 7) // 8 * 8)
+
+    @property
+    def esize(self):
+        return 4 if self.dtype == _F32 else 2
 
     @property
     def M(self):
@@ -54,6 +63,12 @@ class BufView:
         b = self.buf
         ptr = tensor.data_ptr() + 4 * ((self.y0 * b.W + self.x0) * b.ld + self.c0)
         return View(ptr, b.H * b.W * b.ld, b.W * b.ld, b.ld)
+
+    def hview(self, tensor):
+        """cvk_viewh (strides in elements of the buffer's dtype) — the bf16-storage kernels' view type."""
+        b = self.buf
+        ptr = tensor.data_ptr() + b.esize * ((self.y0 * b.W + self.x0) * b.ld + self.c0)
+        return ViewH(ptr, b.H * b.W * b.ld, b.W * b.ld, b.ld)
 
     @property
     def is_full(self):
@@ -137,19 +152,10 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
             lib.cvk_wino_output(ws.data_ptr(), bias, y.data_ptr(), sp, N, H, W, cout, ldy, s), "cvk_wino_output"), "byte")
 
 
-def bf16_ok(R, k_ch):
-    return R.bf16 and k_ch % 32 == 0
-
-
-def split_ok(R, k_ch, n_cols):
-    return R.split and k_ch % 32 == 0 and n_cols > 32
-
-
 def conv_kernel_name(kind, n_cols, k_ch=32):
     """Mirror of the tile dispatch in csrc/conv3x3.hip / wino.hip: the kernel-trace name."""
-    if kind in ("bf16_fwd", "bf16_dgrad"):
-        t = "128, 128, 2, 2" if n_cols > 64 else ("128, 64, 2, 2" if n_cols > 32 else "256, 32, 4, 1")
-        return f"k_conv3x3_igemm_bf16<{t}, {'true' if kind == 'bf16_fwd' else 'false'}>"
+    if kind in ("bf16_fwd", "bf16_dgrad"):       # csrc/conv_bf16s.hip: k_conv_bf16s<BN, STATS>
+        return f"k_conv_bf16s<{128 if n_cols > 64 else 64}, {'true' if kind == 'bf16_fwd' else 'false'}>"
     if kind == "wino4":
         return "k_conv3x3_wino4<128, 128, 2, 2>" if n_cols > 64 else ("k_conv3x3_wino4<128, 64, 2, 2>" if n_cols > 32 else "k_conv3x3_wino4<128, 32, 4, 1>")
     if kind == "wino":
@@ -163,17 +169,20 @@ def conv_kernel_name(kind, n_cols, k_ch=32):
     return f"k_conv3x3_igemm<{t}, {'true' if kind == 'fwd' else 'false'}, {'true' if k_ch % 32 == 0 else 'false'}>"
 
 
+PROF = None     # bench.py sets this to a list: every _timed call then appends (kernel name, work, start event, end event, unit)
+
+
 def _timed(R, name, work, fn, unit="flop"):
-    """Run fn(); when a profile list is attached (bench.py), bracket it with HIP events on the launch stream.
-    `work` is the ALGORITHMIC work of the call: FLOPs for the conv kernels, HBM bytes (each input read once, each
-    output written once, fp32) for the memory-bound kernels."""
-    if R.prof is None:
+    """Run fn(); when a profile list is attached (bench.py sets engine.PROF), bracket it with HIP events on the launch
+    stream.  `work` is the ALGORITHMIC work of the call: FLOPs for the conv kernels, HBM bytes (each input read once,
+    each output written once, at the storage dtype) for the memory-bound kernels."""
+    if PROF is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = fn()
     e1.record()
-    R.prof.append((name, work, e0, e1, unit))
+    PROF.append((name, work, e0, e1, unit))
     return r
 
 
@@ -194,6 +203,7 @@ class ConvBnRelu(Op):
     def __init__(self, src, dst, pslot, holder, cin, cout, src_needs_grad):
         self.src, self.dst, self.pslot, self.holder = src, dst, pslot, holder
         self.cin, self.cout, self.src_needs_grad = cin, cout, src_needs_grad
+        self.pool_dst = None        # bf16 plans: the ActBuf of a MaxPool2d(2,2) of this block's output, written by the BN-apply pass
         assert src.C == cin and dst.C == cout and dst.H == src.H and dst.W == src.W
 
     def _weight_fwd(self, R, st, w):
@@ -207,19 +217,11 @@ class ConvBnRelu(Op):
         return out
 
     def _conv(self, R, st, X, wk, b, y, stats, kind):
-        """y = conv3x3(X, wk) + b (+ BN statistics partials): Winograd F(2,3) kernel when eligible, else direct."""
+        """y = conv3x3(X, wk) + b (+ BN statistics partials): Winograd kernels when eligible, else direct."""
         lib, s, src = R.lib, st.stream, self.src
         N, H, W, M, C, ldy = src.N, src.H, src.W, src.M, self.cout, pad4(self.cout)
         sp = stats.data_ptr() if stats is not None else None
-        if split_ok(R, src.ld, ldy):
-            _timed(R, f"k_conv3x3_igemm_split<{'128, 128' if ldy > 64 else '128, 64'}, 2, 2, {'true' if stats is not None else 'false'}, 16>", 18.0 * M * C * self.cin, lambda: check(
-                lib.cvk_conv3x3_fwd_split(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy, 0, s),
-                "cvk_conv3x3_fwd_split"))
-        elif bf16_ok(R, src.ld):
-            _timed(R, conv_kernel_name("bf16_fwd", ldy), 18.0 * M * C * self.cin, lambda: check(
-                lib.cvk_conv3x3_fwd_bf16(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy, s),
-                "cvk_conv3x3_fwd_bf16"))
-        elif wino_ok(R, src.ld, ldy):
+        if wino_ok(R, src.ld, ldy):
             wino_conv(R, lib, s, X, wk, b.data_ptr(), y, sp, N, H, W, src.ld, C, ldy, 18.0 * M * C * self.cin)
         else:
             _timed(R, conv_kernel_name("fwd", ldy, src.ld), 18.0 * M * C * self.cin, lambda: check(
@@ -227,6 +229,8 @@ class ConvBnRelu(Op):
                 "cvk_conv3x3_fwd"))
 
     def fwd(self, R, st):
+        if st.plan.bf16:
+            return self._fwd_bf16(R, st)
         lib, s = R.lib, st.stream
         src, dst = self.src, self.dst
         X = st.act[src.id]
@@ -265,6 +269,8 @@ class ConvBnRelu(Op):
             st.saved[self.idx] = (y, bnp)
 
     def bwd(self, R, st):
+        if st.plan.bf16:
+            return self._bwd_bf16(R, st)
         lib, s = R.lib, st.stream
         src, dst = self.src, self.dst
         y, bnp = st.saved.pop(self.idx)
@@ -283,7 +289,7 @@ class ConvBnRelu(Op):
         check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, gbe, gg, s), "cvk_colsum_finalize")   # dbeta, dgamma
         dy = torch.zeros(M * ldy, device=dev, dtype=_F32) if ldy != C else _empty(M * ldy, dev)
         # layers whose weight-grad runs through the transposed F(4,3) get its transformed dy planes E1..E4 from this pass
-        wgrad4 = (not R.bf16) and R.wino and src.ld >= 32 and C > 32 and (R.wino4 == "always" or (R.wino4 and src.ld >= 64))
+        wgrad4 = R.wino and src.ld >= 32 and C > 32 and (R.wino4 == "always" or (R.wino4 and src.ld >= 64))
         E = None
         if wgrad4 and ldy == C and C % 4 == 0:
             E = _empty(4 * N * H * ((W + 3) // 4) * ldy, dev)
@@ -311,31 +317,16 @@ class ConvBnRelu(Op):
                 check(lib.cvk_pack_weight_dgrad(wc.data_ptr(), wd_.data_ptr(), C, self.cin, src.ld, ldy, s), "cvk_pack_weight_dgrad")
                 return wd_
             dX = _empty(M * src.ld, dev).view(N, H, W, src.ld)
-            if not wino_ok(R, ldy, src.ld) or split_ok(R, ldy, src.ld) or bf16_ok(R, ldy):
-                wd = packed()
-            if split_ok(R, ldy, src.ld):
-                _timed(R, f"k_conv3x3_igemm_split<{'128, 128' if src.ld > 64 else '128, 64'}, 2, 2, false, 16>", 18.0 * M * C * self.cin, lambda: check(
-                    lib.cvk_conv3x3_fwd_split(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, 0, s),
-                    "cvk_conv3x3_fwd_split(dgrad)"))
-            elif bf16_ok(R, ldy):
-                _timed(R, conv_kernel_name("bf16_dgrad", src.ld), 18.0 * M * C * self.cin, lambda: check(
-                    lib.cvk_conv3x3_fwd_bf16(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
-                    "cvk_conv3x3_fwd_bf16(dgrad)"))
-            elif wino_ok(R, ldy, src.ld):
+            if wino_ok(R, ldy, src.ld):
                 wino_conv(R, lib, s, dy, packed, None, dX, None, N, H, W, ldy, src.ld, src.ld, 18.0 * M * C * self.cin, "(dgrad)",
                           dgrad_of=(wc, C, self.cin))
             else:
+                wd = packed()
                 _timed(R, conv_kernel_name("dgrad", src.ld, ldy), 18.0 * M * C * self.cin, lambda: check(
                     lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
                     "cvk_conv3x3_fwd(dgrad)"))
             st.grad[src.id] = dX
-        if R.bf16 and C > 32:
-            wsb = lib.cvk_conv3x3_wgrad_bf16_workspace_bytes(N, H, W, src.ld, C)
-            ws = R.workspace(wsb, dev)
-            _timed(R, f"k_conv3x3_wgrad_bf16<{'128' if C > 64 else '64'}, 128, 2, 2>", 18.0 * M * C * self.cin, lambda: check(
-                lib.cvk_conv3x3_wgrad_bf16(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
-                "cvk_conv3x3_wgrad_bf16"))
-        elif wgrad4:
+        if wgrad4:
             # transposed F(4,3): fastest weight-grad on every layer with >= 64 input channels (tools/bench_conv.py wgrad wwino wwino4)
             wsb = lib.cvk_conv3x3_wgrad_wino4_workspace_bytes(N, H, W, src.ld, C, ldy)
             ws = R.workspace(wsb, dev)
@@ -357,18 +348,126 @@ class ConvBnRelu(Op):
                 "cvk_conv3x3_wgrad"))
         R.grads_ready(st, self.pslot)
 
+    # ---- bf16-storage mode (BASELINE.json configs[3]; csrc/conv_bf16s.hip, csrc/elem_bf16.hip) ------------------------
+    def _fwd_bf16(self, R, st):
+        """bf16 NHWC activations in HBM: conv (bf16 MFMA, fp32 accumulate, fp32 statistics from the accumulators) writes
+        the pre-BN tensor y as bf16; ONE elementwise pass applies BN + ReLU, writes the bf16 activation through the
+        (concat) view and, for encoder stages, the 2x2 max-pooled tensor as well."""
+        lib, s = R.lib, st.stream
+        src, dst = self.src, self.dst
+        X = st.act[src.id]
+        w, b, gamma, beta = st.params[4 * self.pslot:4 * self.pslot + 4]
+        dev = X.device
+        N, H, W, M, C = src.N, src.H, src.W, src.M, self.cout
+        if C % 4:
+            raise NotImplementedError("bf16 mode needs output channel counts that are multiples of 4")
+        wc = w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last)
+        wb = torch.empty(lib.cvk_bf16s_rows_pad(C) * 9 * src.ld, device=dev, dtype=_BF16)
+        check(lib.cvk_pack_weight_fwd_bf16(wc.data_ptr(), wb.data_ptr(), C, self.cin, src.ld, s), "cvk_pack_weight_fwd_bf16")
+        y = torch.empty(M * C, device=dev, dtype=_BF16)
+        bnp = _empty(4 * C, dev)
+        pm, pr, psc, psh = (bnp.data_ptr() + 4 * C * i for i in range(4))
+        conv, bn = self.holder.conv_bn()
+        flops = 18.0 * M * C * self.cin
+        if st.training:
+            if M <= 1:
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size {[N, C, H, W]}")
+            P = lib.cvk_bf16s_stat_partials(N, H, W)
+            stats = _empty(2 * P * C + P, dev)
+            cnt = stats.data_ptr() + 4 * 2 * P * C
+            _timed(R, conv_kernel_name("bf16_fwd", C), flops, lambda: check(
+                lib.cvk_conv3x3_bf16s(X.data_ptr(), wb.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), cnt, N, H, W, src.ld, C, C, s),
+                "cvk_conv3x3_bf16s"))
+            wsb = lib.cvk_bn_finalize_workspace_bytes(P, C)
+            ws = R.workspace(wsb, dev)
+            track = bn.track_running_stats and bn.running_mean is not None
+            mom = 0.1 if bn.momentum is None else float(bn.momentum)
+            check(lib.cvk_bn_finalize_counts(stats.data_ptr(), cnt, P, M, C, gamma.data_ptr(), beta.data_ptr(), pm, pr, psc, psh,
+                                             bn.running_mean.data_ptr() if track else None,
+                                             bn.running_var.data_ptr() if track else None,
+                                             bn.num_batches_tracked.data_ptr() if track else None,
+                                             mom, float(bn.eps), ws.data_ptr(), wsb, s), "cvk_bn_finalize_counts")
+        else:
+            _timed(R, conv_kernel_name("bf16_dgrad", C), flops, lambda: check(
+                lib.cvk_conv3x3_bf16s(X.data_ptr(), wb.data_ptr(), b.data_ptr(), y.data_ptr(), None, None, N, H, W, src.ld, C, C, s),
+                "cvk_conv3x3_bf16s"))
+            check(lib.cvk_bn_eval_params(gamma.data_ptr(), beta.data_ptr(), bn.running_mean.data_ptr(),
+                                         bn.running_var.data_ptr(), pm, pr, psc, psh, C, float(bn.eps), s), "cvk_bn_eval_params")
+        out = R.alloc_act(st, dst.buf, dev)
+        out_f32 = 1 if dst.buf.dtype == _F32 else 0
+        pool = None
+        if self.pool_dst is not None:
+            pool = R.alloc_act(st, self.pool_dst, dev)
+        nbytes = (2.0 + (4.0 if out_f32 else 2.0)) * M * C + (0.5 * M * C if pool is not None else 0.0)
+        _timed(R, "k_apply_bf16" + ("<pool>" if pool is not None else ""), nbytes, lambda: check(
+            lib.cvk_bn_relu_apply_bf16(y.data_ptr(), C, psc, psh, dst.hview(out), out_f32, pool.data_ptr() if pool is not None else None,
+                                       N, H, W, C, s), "cvk_bn_relu_apply_bf16"), "byte")
+        if st.need_grad:
+            st.saved[self.idx] = (y, bnp)
+
+    def _bwd_bf16(self, R, st):
+        lib, s = R.lib, st.stream
+        src, dst = self.src, self.dst
+        y, bnp = st.saved.pop(self.idx)
+        X = st.act[src.id]
+        dev = X.device
+        N, H, W, M, C = src.N, src.H, src.W, src.M, self.cout
+        pm, pr, psc, psh = (bnp.data_ptr() + 4 * C * i for i in range(4))
+        w = st.params[4 * self.pslot]
+        gw, gb, gg, gbe = R.grad_ptrs(st, self.pslot)
+        G = st.grad[dst.buf.id]
+        dO = dst.hview(G)
+        do_f32 = 1 if dst.buf.dtype == _F32 else 0
+        esz = 4.0 if do_f32 else 2.0
+        PB = lib.cvk_bn_bwd_blocks_bf16(M)
+        part = _empty(2 * PB * C, dev)
+        _timed(R, "k_bnbwd_bf16<reduce>", (esz + 2.0) * M * C, lambda: check(
+            lib.cvk_bn_bwd_reduce_bf16(dO, do_f32, y.data_ptr(), C, psc, psh, pm, pr, part.data_ptr(), N, H, W, C, s),
+            "cvk_bn_bwd_reduce_bf16"), "byte")
+        check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, gbe, gg, s), "cvk_colsum_finalize")   # dbeta, dgamma
+        ld_dy = max(32, C)                              # the data-grad GEMM reads dy in 32-channel K slices
+        dy = torch.empty(M * ld_dy, device=dev, dtype=_BF16)
+        _timed(R, "k_bnbwd_bf16<dx>", (esz + 4.0) * M * C, lambda: check(
+            lib.cvk_bn_bwd_dx_bf16(dO, do_f32, y.data_ptr(), C, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ld_dy, part.data_ptr(),
+                                   N, H, W, C, 1 if st.training else 0, s), "cvk_bn_bwd_dx_bf16"), "byte")
+        check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, gb, None, s), "cvk_colsum_finalize")  # conv bias grad
+        del y
+        wc = w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last)
+        flops = 18.0 * M * C * self.cin
+        if self.src_needs_grad:
+            if src.id in st.grad:
+                raise NotImplementedError("conv data-grad must be the first writer of its input's gradient buffer")
+            wd = torch.empty(lib.cvk_bf16s_rows_pad(self.cin) * 9 * ld_dy, device=dev, dtype=_BF16)
+            check(lib.cvk_pack_weight_dgrad_bf16(wc.data_ptr(), wd.data_ptr(), C, self.cin, ld_dy, s), "cvk_pack_weight_dgrad_bf16")
+            dX = torch.empty((N, H, W, src.ld), device=dev, dtype=_BF16)
+            _timed(R, conv_kernel_name("bf16_dgrad", self.cin), flops, lambda: check(
+                lib.cvk_conv3x3_bf16s(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, None, N, H, W, ld_dy, self.cin, src.ld, s),
+                "cvk_conv3x3_bf16s(dgrad)"))
+            st.grad[src.id] = dX
+        wsb = lib.cvk_conv3x3_wgrad_bf16s_workspace_bytes(N, H, W, self.cin, C)
+        ws = R.workspace(wsb, dev)
+        _timed(R, "k_wgrad_bf16s", flops, lambda: check(
+            lib.cvk_conv3x3_wgrad_bf16s(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ld_dy, ws.data_ptr(), wsb, s),
+            "cvk_conv3x3_wgrad_bf16s"))
+        R.grads_ready(st, self.pslot)
+
 
 class MaxPool(Op):
     """nn.MaxPool2d(2,2) (models/unet.py:92) / with indices (models/segnet.py:79)."""
 
     def __init__(self, src_view, dst_buf, keep_code):
         self.src, self.dst, self.keep_code = src_view, dst_buf, keep_code
+        self.fused = False          # bf16 plans: produced by the preceding block's BN-apply pass
         if src_view.H < 2 or src_view.W < 2:
             raise RuntimeError(f"max_pool2d: input {src_view.H}x{src_view.W} is too small for a 2x2 window")
 
     def fwd(self, R, st):
         v, d = self.src, self.dst
         X = st.act[v.buf.id]
+        if st.plan.bf16:
+            if not self.fused:
+                raise NotImplementedError("bf16 mode: a max pool must directly follow a conv block (it is fused into its BN pass)")
+            return                                      # the producing block's BN-apply pass already wrote st.act[d.id]
         out = R.alloc_act(st, d, X.device)
         code = None
         if self.keep_code:
@@ -389,6 +488,12 @@ class MaxPool(Op):
                 st.grad[v.buf.id] = torch.zeros_like(X)
             else:
                 st.grad[v.buf.id] = torch.empty_like(X)
+        if st.plan.bf16:
+            _timed(R, "k_pool_bwd_bf16", (2.0 * 0.25 + 2.0 + (4.0 if acc else 2.0)) * v.buf.N * v.H * v.W * v.C, lambda: check(
+                R.lib.cvk_maxpool2x2_bwd_bf16(st.grad[d.id].data_ptr(), v.hview(X), v.hview(st.grad[v.buf.id]), 1 if acc else 0,
+                                              v.buf.N, v.H, v.W, v.C, st.stream), "cvk_maxpool2x2_bwd_bf16"), "byte")
+            st.grad.pop(d.id)
+            return
         code = st.saved.get(self.idx)
         _timed(R, "k_pool_scatter(bwd)", (13.0 if acc else 9.0) * v.buf.N * v.H * v.W * v.C, lambda: check(
             R.lib.cvk_maxpool2x2_bwd(st.grad[d.id].data_ptr(), v.cview(X), code.data_ptr() if code is not None else None,
@@ -404,6 +509,8 @@ class Unpool(Op):
         self.src, self.pool, self.dst = src_buf, pool_op, dst_buf
 
     def fwd(self, R, st):
+        if st.plan.bf16:
+            raise NotImplementedError("bf16 mode covers the UNet operator set (BASELINE.json configs[3]); SegNet's unpooling runs in fp32 mode")
         V = st.act[self.src.id]
         code = st.saved[self.pool.idx]
         d = self.dst
@@ -432,6 +539,10 @@ class Upsample(Op):
         X = st.act[self.src.id]
         out = R.alloc_act(st, self.dst, X.device)
         b = self.src
+        if st.plan.bf16:
+            _timed(R, "k_bilinear_fwd_bf16", 10.0 * b.M * b.ld, lambda: check(
+                R.lib.cvk_bilinear_up2_fwd_bf16(X.data_ptr(), out.data_ptr(), b.N, b.H, b.W, b.ld, st.stream), "cvk_bilinear_up2_fwd_bf16"), "byte")
+            return
         _timed(R, "k_bilinear_fwd", 20.0 * b.M * b.ld, lambda: check(
             R.lib.cvk_bilinear_up2_fwd(X.data_ptr(), out.data_ptr(), b.N, b.H, b.W, b.ld, st.stream), "cvk_bilinear_up2_fwd"), "byte")
 
@@ -439,8 +550,12 @@ class Upsample(Op):
         g = st.grad.pop(self.dst.id)
         b = self.src
         dx = torch.empty_like(st.act[b.id])
-        _timed(R, "k_bilinear_bwd", 20.0 * b.M * b.ld, lambda: check(
-            R.lib.cvk_bilinear_up2_bwd(g.data_ptr(), dx.data_ptr(), b.N, b.H, b.W, b.ld, st.stream), "cvk_bilinear_up2_bwd"), "byte")
+        if st.plan.bf16:
+            _timed(R, "k_bilinear_bwd_bf16", 10.0 * b.M * b.ld, lambda: check(
+                R.lib.cvk_bilinear_up2_bwd_bf16(g.data_ptr(), dx.data_ptr(), b.N, b.H, b.W, b.ld, st.stream), "cvk_bilinear_up2_bwd_bf16"), "byte")
+        else:
+            _timed(R, "k_bilinear_bwd", 20.0 * b.M * b.ld, lambda: check(
+                R.lib.cvk_bilinear_up2_bwd(g.data_ptr(), dx.data_ptr(), b.N, b.H, b.W, b.ld, st.stream), "cvk_bilinear_up2_bwd"), "byte")
         assert b.id not in st.grad
         st.grad[b.id] = dx
 
@@ -456,6 +571,9 @@ class ZeroFrame(Op):
         b = v.buf
         t = R.alloc_act(st, b, st.device)
         chan = BufView(b, v.c0, v.C, 0, 0, b.H, b.W)
+        if st.plan.bf16:
+            check(R.lib.cvk_zero_frame_bf16(chan.hview(t), b.N, b.H, b.W, v.C, v.y0, v.x0, v.H, v.W, st.stream), "cvk_zero_frame_bf16")
+            return
         check(R.lib.cvk_zero_frame(chan.cview(t), b.N, b.H, b.W, v.C, v.y0, v.x0, v.H, v.W, st.stream), "cvk_zero_frame")
 
 
@@ -463,15 +581,17 @@ class ZeroFrame(Op):
 class Plan:
     """Recorded op list for one (N, H, W) input geometry."""
 
-    def __init__(self, N, cin, H, W):
+    def __init__(self, N, cin, H, W, bf16=False):
         self.N, self.cin, self.H, self.W = N, cin, H, W
+        self.bf16 = bool(bf16)      # bf16-storage plan: activation buffers are bf16 (the logits buffer stays fp32)
         self.bufs, self.ops, self.holders = [], [], []
+        self._producer = {}         # (buffer id, first channel) -> the ConvBnRelu op that writes that view
         self.input = self.new_buf(cin, H, W, "input")
         self.output = None
         self.input_needs_grad = False
 
-    def new_buf(self, C, H, W, name=""):
-        b = ActBuf(len(self.bufs), self.N, H, W, C, name)
+    def new_buf(self, C, H, W, name="", f32=False):
+        b = ActBuf(len(self.bufs), self.N, H, W, C, name, _BF16 if (self.bf16 and not f32) else _F32)
         self.bufs.append(b)
         return b
 
@@ -491,12 +611,18 @@ class Plan:
         pslot = len(self.holders)
         self.holders.append(holder)
         needs = src_buf is not self.input or self.input_needs_grad
-        self.add(ConvBnRelu(src_buf, dst_view, pslot, holder, cin, cout, needs))
+        op = self.add(ConvBnRelu(src_buf, dst_view, pslot, holder, cin, cout, needs))
+        self._producer[(dst_view.buf.id, dst_view.c0)] = op
         return dst_view
 
     def maxpool(self, src_view, keep_code=False):
         dst = self.new_buf(src_view.C, src_view.H // 2, src_view.W // 2, "pool")
-        return self.add(MaxPool(src_view, dst, keep_code))
+        op = self.add(MaxPool(src_view, dst, keep_code))
+        prod = self._producer.get((src_view.buf.id, src_view.c0))
+        if self.bf16 and not keep_code and prod is not None and prod.dst.C == src_view.C and prod.pool_dst is None:
+            prod.pool_dst = dst         # the block's BN-apply pass writes the pooled tensor too (csrc/elem_bf16.hip)
+            op.fused = True
+        return op
 
     def unpool(self, src_buf, pool_op):
         v = pool_op.src
@@ -512,6 +638,16 @@ class Plan:
     def zero_frame(self, view):
         self.add(ZeroFrame(view))
 
+    def seal(self):
+        """Called once after recording.  bf16-storage plans hand their result (the logits) to the caller and to the loss
+        in fp32: the buffer of the output view becomes an fp32 buffer (written by the last block's BN-apply pass)."""
+        if self.bf16:
+            b = self.output.buf
+            if not self.output.is_full:
+                raise NotImplementedError("bf16 mode: the network output must be a whole buffer")
+            b.dtype = _F32
+            b.ld = pad4(b.C)
+
 
 class Runner:
     """Executes a Plan.  One Runner per module instance; plans are cached per input geometry."""
@@ -522,10 +658,7 @@ class Runner:
         self.grad_sync = None       # set by ddp.DataParallel
         self.wino = WINO_DEFAULT
         self.wino4 = WINO4_DEFAULT
-        self.bf16 = False           # opt-in: bf16-MFMA convolutions (modules.set_conv_precision)
-        self.split = False          # opt-in, experimental: fp32-accurate 3-way bf16 split forward / data-grad
-        self.prof = None            # list collecting (kernel name, flops, start event, end event) when bench.py profiles
-        self._flat = [None, None]   # alternating flat gradient buffers (see grad_flat)
+        self.bf16 = False           # opt-in: bf16-storage mode (modules.set_conv_precision; BASELINE.json configs[3])
 
     def workspace(self, nbytes, dev):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
@@ -536,7 +669,7 @@ class Runner:
         t = st.act.get(buf.id)
         if t is None:
             shape = (buf.N, buf.H, buf.W, buf.ld)
-            t = torch.zeros(shape, device=dev, dtype=_F32) if buf.ld != buf.C else torch.empty(shape, device=dev, dtype=_F32)
+            t = torch.zeros(shape, device=dev, dtype=buf.dtype) if buf.ld != buf.C else torch.empty(shape, device=dev, dtype=buf.dtype)
             st.act[buf.id] = t
         return t
 
@@ -561,7 +694,15 @@ class Runner:
         st.stream = torch.cuda.current_stream(dev).cuda_stream
         inb = plan.input
         xp = x.permute(0, 2, 3, 1)
-        if inb.ld == inb.C and xp.is_contiguous():
+        if plan.bf16:
+            if plan.input_needs_grad:
+                raise NotImplementedError("bf16 mode does not return a gradient for the network input")
+            t = torch.empty((inb.N, inb.H, inb.W, inb.ld), device=dev, dtype=_BF16)
+            sN, sC, sH, sW = x.stride()
+            check(self.lib.cvk_import_nchw_bf16(x.data_ptr(), sN, sC, sH, sW, t.data_ptr(), inb.ld, inb.N, inb.C, inb.H, inb.W,
+                                                st.stream), "cvk_import_nchw_bf16")
+            st.act[inb.id] = t
+        elif inb.ld == inb.C and xp.is_contiguous():
             st.act[inb.id] = xp                               # already dense NHWC: zero-copy
         else:
             t = torch.empty((inb.N, inb.H, inb.W, inb.ld), device=dev, dtype=_F32)
@@ -583,10 +724,12 @@ class Runner:
         st.stream = torch.cuda.current_stream(dev).cuda_stream
         params = st.params
         st.goffs, total = self.layout_grads(plan, params)
-        st.gflat = self.grad_flat(total, dev, params, st.goffs)
-        st.sync = self.grad_sync
-        if st.sync is not None:
-            st.sync.begin(st, plan)
+        # A FRESH flat buffer per backward call (caching allocator: the block freed by `p.grad = None` comes straight
+        # back).  The returned .grad tensors are views of it and autograd may hold them for as long as it likes (a
+        # second pass through the same network inside one graph, torch.autograd.grad results the caller keeps, manual
+        # accumulation across zero_grad(set_to_none=True)): no later backward ever writes into memory handed out here.
+        st.gflat = torch.empty(total, device=dev, dtype=_F32)
+        st.sync = self.grad_sync.begin(st, plan) if self.grad_sync is not None else None
         ob = plan.output.buf
         gp = gout.permute(0, 2, 3, 1)
         if ob.ld == ob.C and gp.is_contiguous():
@@ -618,18 +761,6 @@ class Runner:
             st.sync.finish(st)
         st.act.clear(); st.saved.clear(); st.grad.clear()
         return dx, grads
-
-    def grad_flat(self, total, dev, params, offs):
-        """Pick a flat buffer that no live `.grad` aliases (autograd accumulates INTO an existing .grad; writing our
-        fresh gradients over it first would double them).  With zero_grad(set_to_none=True) slot 0 is always free."""
-        for k in range(2):
-            f = self._flat[k]
-            if f is None or f.numel() != total or f.device != dev:
-                f = self._flat[k] = torch.empty(total, device=dev, dtype=_F32)
-            lo, hi = f.data_ptr(), f.data_ptr() + 4 * total
-            if not any(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in params):
-                return f
-        return torch.empty(total, device=dev, dtype=_F32)
 
 
 def layout_grads(params):

@@ -34,7 +34,7 @@ def _as_nhwc(logits):
 
 class _CrossEntropy(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, grad_scale):
+    def forward(ctx, logits, target, grad_scale, ignore_index=-100):
         lib = _lib.load()
         if not logits.is_cuda:
             raise RuntimeError("pytorch_camvid_amd.CrossEntropyLoss needs HIP tensors (no CPU fallback)")
@@ -46,42 +46,63 @@ class _CrossEntropy(torch.autograd.Function):
         lg, ld = _as_nhwc(logits)
         tg = target.contiguous()
         M = N * H * W
-        part = torch.empty(lib.cvk_ce_blocks(M), device=logits.device, dtype=torch.float32)
-        loss = torch.empty((), device=logits.device, dtype=torch.float32)
-        check(lib.cvk_softmax_ce_fwd(lg.data_ptr(), ld, tg.data_ptr(), part.data_ptr(), loss.data_ptr(), M, C, _stream(logits)),
-              "cvk_softmax_ce_fwd")
-        ctx.save_for_backward(lg, tg)
-        ctx.meta = (N, C, H, W, ld, grad_scale)
-        return loss
+        part = torch.empty(3 * lib.cvk_ce_blocks(M), device=logits.device, dtype=torch.float32)
+        loss3 = torch.empty(3, device=logits.device, dtype=torch.float32)     # mean loss | valid pixels | out-of-range targets
+        e0 = e1 = None
+        from . import engine
+        engine._timed(None, "k_ce_fwd", 4.0 * M * ld + 8.0 * M, lambda: check(
+            lib.cvk_softmax_ce_fwd(lg.data_ptr(), ld, tg.data_ptr(), part.data_ptr(), loss3.data_ptr(), M, C, int(ignore_index),
+                                   _stream(logits)), "cvk_softmax_ce_fwd"), "byte")
+        ctx.save_for_backward(lg, tg, loss3)
+        ctx.meta = (N, C, H, W, ld, grad_scale, int(ignore_index))
+        _CrossEntropy.last_status = loss3
+        return loss3[0]
 
     @staticmethod
     def backward(ctx, gout):
         lib = _lib.load()
-        lg, tg = ctx.saved_tensors
-        N, C, H, W, ld, grad_scale = ctx.meta
+        lg, tg, loss3 = ctx.saved_tensors
+        N, C, H, W, ld, grad_scale, ignore_index = ctx.meta
         M = N * H * W
         d = torch.empty((N, H, W, C), device=lg.device, dtype=torch.float32)
         g = gout.contiguous()
-        check(lib.cvk_softmax_ce_bwd(lg.data_ptr(), ld, tg.data_ptr(), g.data_ptr(), float(grad_scale), d.data_ptr(), C, M, C,
-                                     _stream(lg)), "cvk_softmax_ce_bwd")
-        return d.permute(0, 3, 1, 2), None, None
+        from . import engine
+        engine._timed(None, "k_ce_bwd", 4.0 * M * ld + 8.0 * M + 4.0 * M * C, lambda: check(
+            lib.cvk_softmax_ce_bwd(lg.data_ptr(), ld, tg.data_ptr(), loss3.data_ptr(), g.data_ptr(), float(grad_scale), d.data_ptr(),
+                                   C, M, C, ignore_index, _stream(lg)), "cvk_softmax_ce_bwd"), "byte")
+        return d.permute(0, 3, 1, 2), None, None, None
 
 
 class CrossEntropyLoss(nn.Module):
-    """Drop-in for the reference's `nn.CrossEntropyLoss()` (train.py:105): defaults only — reduction='mean', no class
-    weights, no label smoothing; targets are int64 class indices in [0, C).  `grad_scale` multiplies the backward only
-    (data-parallel training folds 1/world_size in here so the gradient all-reduce is a plain sum)."""
+    """Drop-in for the reference's `nn.CrossEntropyLoss()` (train.py:105): reduction='mean', no class weights, no label
+    smoothing; targets are int64 class indices in [0, C) or `ignore_index` (default -100 as in torch: such pixels are
+    left out of the mean and get no gradient).  Any other out-of-range target makes the loss NaN — torch raises a
+    device-side assert there; raising here would need a host sync in every step — and `last_ce_status()` reports the
+    count.  `grad_scale` multiplies the backward only (data-parallel training can fold 1/world_size in here)."""
 
-    def __init__(self, grad_scale=1.0):
+    def __init__(self, grad_scale=1.0, ignore_index=-100):
         super().__init__()
         self.grad_scale = grad_scale
+        self.ignore_index = ignore_index
 
     def forward(self, logits, target):
-        return _CrossEntropy.apply(logits, target, self.grad_scale)
+        return _CrossEntropy.apply(logits, target, self.grad_scale, self.ignore_index)
 
 
-def cross_entropy(logits, target):
-    return _CrossEntropy.apply(logits, target, 1.0)
+def cross_entropy(logits, target, ignore_index=-100):
+    return _CrossEntropy.apply(logits, target, 1.0, ignore_index)
+
+
+def last_ce_status():
+    """(valid pixels, out-of-range targets) of the most recent cross-entropy forward — one device->host copy; raises
+    IndexError like torch's `Target out of bounds` when the second number is not zero."""
+    st = getattr(_CrossEntropy, "last_status", None)
+    if st is None:
+        raise RuntimeError("no cross-entropy forward has run yet")
+    _, valid, bad = st.cpu().tolist()
+    if bad:
+        raise IndexError(f"Target out of bounds: {int(bad)} pixels have a class index outside [0, C) that is not ignore_index")
+    return int(valid), int(bad)
 
 
 def argmax_channels(logits):
@@ -237,6 +258,7 @@ class DevicePrefetcher:
         self.mean, self.std = mean, std
         self.stream = torch.cuda.Stream(self.dev)
         self._pin = [None, None]        # two pinned staging slots (frames, masks), reused when shapes repeat
+        self._busy = [None, None]       # per slot: event recorded after the H2D copies that READ its pinned buffers
         self._slot = 0
         self._next = None
         self._stage()
@@ -262,6 +284,8 @@ class DevicePrefetcher:
             raise ValueError("expected uint8 frames of shape [N, H, W, 3]")
         slot = self._slot
         self._slot ^= 1
+        if self._busy[slot] is not None:
+            self._busy[slot].synchronize()              # the upload that last read this slot must be done before the host overwrites it
         pf = self._pinned(slot, 0, frames); pf.copy_(frames)
         pm = self._pinned(slot, 1, masks); pm.copy_(masks)
         with torch.cuda.stream(self.stream):
@@ -269,6 +293,7 @@ class DevicePrefetcher:
             gm = pm.to(self.dev, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
+        self._busy[slot] = ev
         self._next = (gf, gm, ev)
 
     def __iter__(self):

@@ -67,10 +67,37 @@ class FlatAdamW(torch.optim.Optimizer):
             self._gbuf[o:o + p.numel()].view(g.shape).copy_(g)
         return self._gbuf
 
+    def _check_homes(self):
+        """The module must still read its weights from the flat buffer: net.to()/.cuda()/.float() after construction
+        re-homes p.data and step() would then update memory nobody reads."""
+        base = self._flat.data_ptr()
+        for p, o in zip(self._plist, self._offs):
+            if p.data_ptr() != base + 4 * o:
+                raise RuntimeError("FlatAdamW: a parameter no longer lives in the optimizer's flat buffer (the network was "
+                                   "moved or cast after the optimizer was built); construct FlatAdamW after net.to(device)")
+
+    # ---- optimizer state: exp_avg / exp_avg_sq / step travel with state_dict() like torch.optim.AdamW's do ----------
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["flat_adamw"] = {"step": self._step, "exp_avg": self._m.clone(), "exp_avg_sq": self._v.clone(),
+                            "offsets": list(self._offs)}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        extra = state_dict.pop("flat_adamw", None)
+        super().load_state_dict(state_dict)
+        if extra is not None:
+            if list(extra["offsets"]) != list(self._offs) or extra["exp_avg"].numel() != self._m.numel():
+                raise ValueError("FlatAdamW.load_state_dict: the saved state belongs to a different network layout")
+            self._step = int(extra["step"])
+            self._m.copy_(extra["exp_avg"]); self._v.copy_(extra["exp_avg_sq"])
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
+        self._check_homes()
         self._step += 1
         grad = self._flat_grad()
         lib = _lib.load()

@@ -40,15 +40,15 @@ def run(rank, world, port, out_dir, bucket_mb):
     st.goffs, total = engine.layout_grads(params)
     st.gflat = torch.zeros(total)
     sync = ddp.GradSync(bucket_mb=bucket_mb)
-    sync.begin(st)
+    call = sync.begin(st)
     nslots = len(params) // 4
     for slot in range(nslots - 1, -1, -1):                   # backward order: last layer first
         for j in range(4):
             p = params[4 * slot + j]
             o = st.goffs[4 * slot + j]
             st.gflat[o:o + p.numel()] = p.grad.reshape(-1)
-        sync.layer_done(st, slot)
-    sync.finish(st)
+        call.layer_done(st, slot)
+    call.finish(st)
     torch.save({"flat": st.gflat, "offs": st.goffs, "launched": sync.launched, "total": total,
                 "local": [p.grad.clone() for p in params]}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()

@@ -35,7 +35,7 @@ from models.segnet import SegNet, BasicConv              # noqa: E402
 import utils as ref_utils                                # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
-torch.set_num_threads(8)
+torch.set_num_threads(int(os.environ.get("GOLD_THREADS", "8")))
 torch.backends.mkldnn.enabled = True
 
 
@@ -281,6 +281,117 @@ def gold_miou():
     save("miou_intersect_union", **d)
 
 
+# ---------------------------------------------------------------- round 2: headline-size and protocol fixtures
+def _fullsize_case(kind, seed, shape, data_seed, tag, slice_hw):
+    """One fwd+bwd of the imported reference at a BASELINE.json workload: loss, logits checksum + strided slice,
+    per-parameter gradient norms, BN running statistics checksums (no full tensors: the fixtures stay small)."""
+    torch.manual_seed(seed)
+    net = UNet(3, 12) if kind == "unet" else SegNet(3, 12)
+    net.train()
+    n, _, h, w = shape
+    g = torch.Generator().manual_seed(data_seed)
+    x = torch.randn(n, 3, h, w, generator=g)
+    t = torch.randint(0, 12, (n, h, w), generator=g)
+    out = net(x)
+    loss = nn.CrossEntropyLoss()(out, t)
+    loss.backward()
+    sh, sw = slice_hw
+    d = {"meta": json.dumps({"kind": kind, "seed": seed, "shape": list(shape), "data_seed": data_seed,
+                              "slice": [sh, sw], "torch": torch.__version__}),
+         "loss": npy(loss), "logits_sum": np.float64(out.double().sum().item()),
+         "logits_abs_sum": np.float64(out.double().abs().sum().item()),
+         "logits_sq_sum": np.float64((out.double() ** 2).sum().item()),
+         "logits_slice": npy(out[:, :, ::sh, ::sw]),
+         "param_names": np.array([k for k, _ in net.named_parameters()]),
+         "grad_l2": np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()]),
+         "grad_absmax": np.array([float(p.grad.abs().max()) for _, p in net.named_parameters()])}
+    for k, p in net.named_parameters():
+        if p.dim() == 4:
+            d["gs." + k] = npy(p.grad.flatten()[:64])
+    sd = net.state_dict()
+    d["bn_mean_l2"] = np.array([float(v.double().norm()) for k, v in sd.items() if k.endswith("running_mean")])
+    d["bn_var_l2"] = np.array([float(v.double().norm()) for k, v in sd.items() if k.endswith("running_var")])
+    print(tag, "loss", float(loss), flush=True)
+    save(tag, **d)
+
+
+def gold_batch8():
+    """BASELINE.json configs[1]: UNet(3,12), 8x3x360x480, seed 0 / data seed 1234 (bench.py's batch)."""
+    _fullsize_case("unet", 0, (8, 3, 360, 480), 1234, "unet_s0_8x360x480", (40, 48))
+
+
+def gold_config3():
+    """BASELINE.json configs[3] workload: UNet(3,12), 4x3x720x960 (the reference computes it in fp32 on CPU; the
+    bf16 path is compared against it with the tolerance derived in tests/golden/drift.json)."""
+    _fullsize_case("unet", 0, (4, 3, 720, 960), 1234, "unet_s0_4x720x960", (80, 96))
+
+
+def gold_segnet_stable():
+    """A SegNet golden whose bottleneck is not arg-max-chaotic (replaces the skipped forced-F(4,3) case): 2x3x96x128,
+    BatchNorm sees 24 samples at the 3x4 bottleneck."""
+    net_case("segnet", 4, (2, 3, 96, 128), 80, "segnet_s4_2x96x128")
+
+
+PROTO = dict(steps=300, batch=2, h=360, w=480, lr=5e-4, val_batches=4, noise=0.5, cell=8)
+
+
+def proto_batch(i, val=False):
+    """Synthetic learnable segmentation batch i of the configs[0] protocol: 12-class blobs on an 8x8-pixel grid, the
+    pixel colour is the class colour plus gaussian noise.  Deterministic in (i, val) only."""
+    P = PROTO
+    pal = torch.randn(12, 3, generator=torch.Generator().manual_seed(99))
+    g = torch.Generator().manual_seed((500000 if val else 100000) + i)
+    coarse = torch.randint(0, 12, (P["batch"], P["h"] // P["cell"], P["w"] // P["cell"]), generator=g)
+    masks = coarse.repeat_interleave(P["cell"], 1).repeat_interleave(P["cell"], 2).contiguous()
+    images = pal[masks].permute(0, 3, 1, 2).contiguous() + P["noise"] * torch.randn(P["batch"], 3, P["h"], P["w"], generator=g)
+    return images, masks
+
+
+def gold_protocol(perturb):
+    """BASELINE.json configs[0] / SURVEY 8d(ii): the reference's loop train.py:100-134 (AdamW lr 5e-4 wd 0,
+    OneCycleLR(max_lr, steps_per_epoch, epochs=1), CrossEntropyLoss) on CPU, batch 2 x 3x360x480, one 300-step epoch
+    of synthetic labels, then the validation pass train.py:169-206 with utils.intersect_and_union (mIoU over the 11
+    non-void classes, sums accumulated over the whole set).  perturb=1 repeats the run with a 1e-6 relative input
+    perturbation: the distance between the two curves is the reference's own reproducibility and derives the tolerance."""
+    P = PROTO
+    torch.manual_seed(0)
+    net = UNet(3, 12); net.train()
+    opt = torch.optim.AdamW(net.parameters(), lr=P["lr"], weight_decay=0)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=P["lr"], steps_per_epoch=P["steps"], epochs=1)
+    lossf = nn.CrossEntropyLoss()
+    losses = []
+    import time
+    t0 = time.time()
+    for it in range(P["steps"]):
+        x, m = proto_batch(it)
+        if perturb:
+            x = x * (1 + 1e-6 * torch.randn(x.shape, generator=torch.Generator().manual_seed(7 + it)))
+        opt.zero_grad()
+        l = lossf(net(x), m)
+        l.backward()
+        opt.step(); sched.step()
+        losses.append(float(l))
+        if it % 10 == 0:
+            print("proto", perturb, it, float(l), f"{time.time() - t0:.0f}s", flush=True)
+    net.eval()
+    ti = np.zeros(12); tu = np.zeros(12)
+    vloss = []
+    with torch.no_grad():
+        for i in range(P["val_batches"]):
+            x, m = proto_batch(i, val=True)
+            o = net(x)
+            vloss.append(float(lossf(o, m)))
+            pr = o.argmax(dim=1)
+            for b in range(pr.shape[0]):
+                a, u, _, _ = ref_utils.intersect_and_union(pr[b].numpy(), m[b].numpy(), 12, 11)
+                ti += a; tu += u
+    iou = ti[:11] / np.maximum(tu[:11], 1)
+    d = {"meta": json.dumps(dict(P, perturb=perturb, torch=torch.__version__)), "losses": np.array(losses),
+         "val_loss": np.array(vloss), "inter": ti, "union": tu, "miou": np.float64(iou.mean())}
+    print("proto", perturb, "mIoU", iou.mean(), "val loss", vloss, flush=True)
+    save("protocol_unet_2x360x480_run%d" % perturb, **d)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ops", "nets", "full", "miou"]
     if "ops" in which:
@@ -291,3 +402,13 @@ if __name__ == "__main__":
         gold_miou()
     if "full" in which:
         gold_fullsize()
+    if "b8" in which:
+        gold_batch8()
+    if "c3" in which:
+        gold_config3()
+    if "segnet2" in which:
+        gold_segnet_stable()
+    if "proto0" in which:
+        gold_protocol(0)
+    if "proto1" in which:
+        gold_protocol(1)

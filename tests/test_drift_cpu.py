@@ -1,0 +1,85 @@
+"""The tolerances of the GPU parity tests are derived, not chosen: tests/golden/drift.json holds the measured
+reproducibility of the reference graph (fp32 vs fp64, fp32 vs 1e-6 input noise) and the measured cost of bf16 storage
+(oracle/bf16_emul.py vs fp32).  This CPU test re-measures the cheapest case and checks (a) the committed measurements
+are of the magnitude a fresh measurement gives, (b) every committed tolerance follows from them by the stated rule."""
+import importlib.util
+import json
+import os
+
+import numpy as np
+import torch
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _md():
+    spec = importlib.util.spec_from_file_location("make_drift", os.path.join(G, "make_drift.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_tolerances_follow_the_rule():
+    md = _md()
+    d = json.load(open(os.path.join(G, "drift.json")))
+    assert d["rule"]["safety"] == md.SAFETY
+    for k, v in d["trajectory"].items():
+        assert np.allclose(d["trajectory_tolerance"][k], md.tolerance_from(v)), k
+        assert d["trajectory_tolerance"][k][0] == md.FLOOR[0]               # step 1 is a pure forward: no drift to speak of
+        assert v["drift_fp64"][0] < 1e-6 and v["drift_noise"][0] < 2e-6
+    for k, v in d["bf16_cost"].items():
+        assert d["bf16_tolerance"][k] == md.bf16_tolerance(v), k
+    for k, v in d["bf16_emul_noise"].items():
+        assert d["bf16_emul_tolerance"][k] == md.bf16_emul_tolerance(v), k
+    # every fixture the GPU tests read is there
+    for k in ("unet_s0_2x48x64", "segnet_s0_2x64x96", "unet_s0_2x360x480"):
+        assert k in d["trajectory_tolerance"], k
+    for k in ("unet_2x96x128", "unet_4x720x960"):
+        assert k in d["bf16_tolerance"] and k in d["bf16_emul_tolerance"], k
+        assert os.path.exists(os.path.join(G, f"bf16emu_unet_s0_{k.split('_')[1]}.npz"))
+
+
+def test_trajectory_drift_remeasured():
+    """UNet 2x48x64, 4 AdamW steps: fp32 vs fp64 and one noise seed, measured here and now."""
+    md = _md()
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    d = json.load(open(os.path.join(G, "drift.json")))["trajectory"]["unet_s0_2x48x64"]
+    gold = dict(np.load(os.path.join(G, "unet_s0_2x48x64.npz")))
+    a = md.trajectory("unet", 0, (2, 48, 64), 1234, 4, total_steps=40)
+    assert np.abs(a - gold["traj_losses"]).max() < 5e-3 and abs(a[0] - gold["traj_losses"][0]) < 2e-6   # the oracle runs the reference's curve
+    b = md.trajectory("unet", 0, (2, 48, 64), 1234, 4, total_steps=40, dtype=torch.float64)
+    fresh = np.abs(a - b)
+    committed = np.maximum(np.array(d["drift_fp64"]), np.array(d["drift_noise"]))
+    # the drift is chaotic (one more sample of the same distribution): the committed bound, times the safety factor,
+    # must cover a fresh measurement, and the first step (no optimizer step yet) must be exact to fp32 rounding
+    tol = np.array(md.tolerance_from(d))
+    assert (fresh <= tol).all(), (fresh, tol)
+    assert fresh[0] < 1e-6 and committed[-1] > 1e-5
+
+
+def test_bf16_emulation_rounding_points():
+    """oracle/bf16_emul.py rounds exactly the tensors it says: values are bf16-representable where stored, the logits
+    and parameter gradients are not rounded, and switching the rounding off reproduces the fp32 graph."""
+    from oracle import torch_ref as R, bf16_emul as E
+    torch.manual_seed(0)
+    net = R.build("unet", 3, 12).train()
+    x, t = R.synthetic_batch(1, 32, 48, 3)
+    out = E.unet_forward(net, x)
+    assert not torch.equal(out, E._r(out))                        # fp32 logits
+    blk = net.down1[0]
+    a = E.basic_conv(blk, x)
+    assert torch.equal(a, E._r(a))                                # a stored activation is bf16-representable
+    loss = torch.nn.functional.cross_entropy(out, t); loss.backward()
+    g = net.down3[0].conv[0].weight.grad
+    assert not torch.equal(g, E._r(g))                            # parameter gradients stay fp32
+    saved = E._r
+    try:
+        E._r = lambda v: v
+        torch.manual_seed(0)
+        n2 = R.build("unet", 3, 12).train()
+        o2 = E.unet_forward(n2, x)
+        torch.manual_seed(0)
+        n3 = R.build("unet", 3, 12).train()
+        assert torch.allclose(o2, n3(x), rtol=1e-5, atol=1e-6)
+    finally:
+        E._r = saved

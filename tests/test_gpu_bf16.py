@@ -1,0 +1,222 @@
+"""bf16-storage mode (BASELINE.json configs[3]; csrc/conv_bf16s.hip, csrc/elem_bf16.hip) on the GPU.
+
+Oracles: torch on the SAME bf16-rounded operands for the raw C-ABI kernels (fp32 accumulation both sides: agreement to
+summation order + one output rounding), oracle/bf16_emul.py (the reference graph with the device's rounding points) for
+blocks and whole networks, and the reference-generated fp32 fixture at the configs[3] workload with the tolerance that
+tests/golden/drift.json derives from the emulation."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+BF = torch.bfloat16
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rb(t):
+    return t.to(BF).to(torch.float32)
+
+
+CONV_CASES = [  # (N, H, W, Cin, Cout)  ragged tiles, one / many channel slices, both output tiles, stem- and head-like padding
+    (2, 8, 32, 32, 64), (1, 13, 45, 64, 128), (2, 9, 70, 32, 12), (1, 24, 40, 128, 256), (3, 5, 7, 64, 64), (1, 17, 33, 96, 192),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_bf16s_raw_abi(case):
+    """cvk_conv3x3_bf16s (+ statistics, counts, finalize) and the data-grad packing against torch on identical bf16 operands."""
+    from pytorch_camvid_amd import _lib
+    from pytorch_camvid_amd._lib import check
+    lib = _lib.load()
+    N, H, W, Ci, Co = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = rb(torch.randn(N, Ci, H, W, generator=g))
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * (2.0 / (9 * Ci)) ** 0.5
+    b = torch.randn(Co, generator=g) * 0.1
+    want = F.conv2d(x, rb(w), b, padding=1)                                     # fp32 accumulate of bf16 operands
+    xd = x.permute(0, 2, 3, 1).contiguous().to(BF).to(dev())                    # NHWC bf16
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev())                           # [Cout][3][3][Cin] fp32 master
+    bd = b.to(dev())
+    rows = lib.cvk_bf16s_rows_pad(Co)
+    wp = torch.full((rows * 9 * Ci,), float("nan"), device=dev(), dtype=BF)
+    check(lib.cvk_pack_weight_fwd_bf16(wd.data_ptr(), wp.data_ptr(), Co, Ci, Ci, stream()))
+    ldy = Co
+    y = torch.full((N, H, W, ldy), float("nan"), device=dev(), dtype=BF)
+    P = lib.cvk_bf16s_stat_partials(N, H, W)
+    stats = torch.full((2 * P * Co + P,), float("nan"), device=dev())
+    cnt_ptr = stats.data_ptr() + 4 * 2 * P * Co
+    check(lib.cvk_conv3x3_bf16s(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), y.data_ptr(), stats.data_ptr(), cnt_ptr, N, H, W, Ci, Co, ldy, stream()))
+    got = y.float().permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(got).all()
+    # one bf16 rounding of the stored result (2^-9 relative) on top of fp32 summation-order noise
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2.0 ** -8, atol=2e-3 * float(want.abs().max()) * 2.0 ** -8 + 1e-6)
+    cnt = stats[2 * P * Co:].cpu()
+    assert cnt.sum().item() == N * H * W
+    M = N * H * W
+    mean = torch.empty(Co, device=dev()); rstd = torch.empty_like(mean); sc = torch.empty_like(mean); sh = torch.empty_like(mean)
+    gamma = torch.ones(Co, device=dev()); beta = torch.zeros(Co, device=dev())
+    wsb = lib.cvk_bn_finalize_workspace_bytes(P, Co)
+    ws = torch.empty(max(wsb, 8), device=dev(), dtype=torch.uint8)
+    check(lib.cvk_bn_finalize_counts(stats.data_ptr(), cnt_ptr, P, M, Co, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                     sc.data_ptr(), sh.data_ptr(), None, None, None, 0.1, 1e-5, ws.data_ptr(), wsb, stream()))
+    wm = want.double().mean(dim=(0, 2, 3)); wv = want.double().var(dim=(0, 2, 3), unbiased=False)
+    np.testing.assert_allclose(mean.cpu().numpy(), wm.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rstd.cpu().numpy(), (1.0 / torch.sqrt(wv + 1e-5)).numpy(), rtol=2e-4)
+    # data-grad: dX = conv(dy, rotated/transposed filter); dy has a padded pitch like the engine's (max(32, Cout))
+    ld_dy = max(32, Co)
+    dy = rb(torch.randn(N, Co, H, W, generator=g))
+    dyd = torch.zeros((N, H, W, ld_dy), device=dev(), dtype=BF)
+    dyd[..., :Co] = dy.permute(0, 2, 3, 1).to(BF).to(dev())
+    wdp = torch.full((lib.cvk_bf16s_rows_pad(Ci) * 9 * ld_dy,), float("nan"), device=dev(), dtype=BF)
+    check(lib.cvk_pack_weight_dgrad_bf16(wd.data_ptr(), wdp.data_ptr(), Co, Ci, ld_dy, stream()))
+    dx = torch.full((N, H, W, Ci), float("nan"), device=dev(), dtype=BF)
+    check(lib.cvk_conv3x3_bf16s(dyd.data_ptr(), wdp.data_ptr(), None, dx.data_ptr(), None, None, N, H, W, ld_dy, Ci, Ci, stream()))
+    want_dx = F.conv_transpose2d(dy, rb(w), padding=1)
+    gdx = dx.float().permute(0, 3, 1, 2).cpu()
+    np.testing.assert_allclose(gdx.numpy(), want_dx.numpy(), rtol=2.0 ** -8, atol=float(want_dx.abs().max()) * 2.0 ** -8 * 2e-3 + 1e-6)
+    # weight-grad: fp32 result of bf16 operands
+    dw = torch.full((Co, 3, 3, Ci), float("nan"), device=dev())
+    wsb = lib.cvk_conv3x3_wgrad_bf16s_workspace_bytes(N, H, W, Ci, Co)
+    ws = torch.empty(wsb, device=dev(), dtype=torch.uint8)
+    check(lib.cvk_conv3x3_wgrad_bf16s(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), N, H, W, Ci, Ci, Co, ld_dy, ws.data_ptr(), wsb, stream()))
+    xr = x.clone().requires_grad_(True); wr = rb(w).clone().requires_grad_(True)
+    (F.conv2d(xr, wr, None, padding=1) * dy).sum().backward()
+    gw = dw.permute(0, 3, 1, 2).cpu()
+    scale = float(wr.grad.abs().max())
+    np.testing.assert_allclose(gw.numpy(), wr.grad.numpy(), rtol=2e-4, atol=2e-5 * scale)
+
+
+def _stage_pair(ci, c1, c2, seed):
+    import pytorch_camvid_amd as A
+    from pytorch_camvid_amd.modules import _Stage
+    from oracle import torch_ref as R
+    torch.manual_seed(seed)
+    ref = torch.nn.Sequential(R._CBR(ci, c1), R._CBR(c1, c2)).train()
+    mine = _Stage(A.BasicConv2d(ci, c1), A.BasicConv2d(c1, c2))
+    mine.load_state_dict(ref.state_dict())
+    with torch.no_grad():
+        for m in (ref, mine):
+            for k, p in m.named_parameters():
+                if k.endswith("conv.1.weight"):
+                    p.mul_(0).add_(torch.linspace(0.5, 1.5, p.numel()))
+                if k.endswith("conv.1.bias"):
+                    p.mul_(0).add_(torch.linspace(-0.3, 0.3, p.numel()))
+    return ref, mine
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 64, 2, 16, 40), (64, 128, 12, 2, 9, 33), (128, 64, 64, 1, 24, 70)])
+def test_two_block_stage_vs_emulation(shape):
+    """Two conv+BN+ReLU blocks in bf16 mode against oracle/bf16_emul.py: output, running statistics and all parameter
+    gradients (weight-grad, BN backward, the data-grad between the blocks)."""
+    import pytorch_camvid_amd as A
+    from oracle import bf16_emul as E
+    ci, c1, c2, n, h, w = shape
+    ref, mine = _stage_pair(ci, c1, c2, seed=ci + c2)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, ci, h, w, generator=g)
+    r = torch.randn(n, c2, h, w, generator=g)
+    want = E._stage(ref, E._r(x), last=True)
+    (want * r).sum().backward()
+    mine = A.set_conv_precision(mine.to(dev()).train(), "bf16")
+    out = mine(x.to(dev()))
+    assert out.dtype == torch.float32 and tuple(out.shape) == (n, c2, h, w)
+    (out * r.to(dev())).sum().backward()
+    rel = float((out.detach().cpu() - want.detach()).norm() / want.detach().norm())
+    assert rel < 4e-3, rel                                  # same rounding points; residual = bf16 ulp flips from fp32 summation order
+    for (k, a), (_, b) in zip(ref.named_parameters(), mine.named_parameters()):
+        ga, gb = a.grad, b.grad.cpu()
+        if k.endswith("conv.0.bias"):
+            assert gb.abs().max() <= 2e-2 * float(dict(ref.named_parameters())[k.replace("bias", "weight")].grad.abs().max()) + 1e-3, k
+            continue
+        e = float((ga - gb).norm() / ga.norm())
+        assert e < 2e-2, (k, e)
+    for (k, a), (_, b) in zip(ref.named_buffers(), mine.named_buffers()):
+        if "num_batches" in k:
+            assert int(a) == int(b)
+        else:
+            np.testing.assert_allclose(b.cpu().numpy(), a.numpy(), rtol=2e-3, atol=2e-4, err_msg=k)
+    # eval mode: running statistics, bias through the statistics-free kernel
+    ref.eval(); mine.eval()
+    with torch.no_grad():
+        we = E._stage(ref, E._r(x), last=True)
+        oe = mine(x.to(dev()))
+    assert float((oe.cpu() - we).norm() / we.norm()) < 4e-3
+
+
+def _net_metrics(net, out, loss, ref):
+    names = list(ref["param_names"])
+    g = np.array([float(p.grad.double().norm()) for p in net.parameters()])
+    bias = np.array([k.endswith("conv.0.bias") for k in names])
+    dev_ = (np.abs(g - ref["grad_l2"]) / ref["grad_l2"])[~bias]
+    meta = json.loads(str(ref["meta"]))
+    sh, sw = meta["slice"]
+    sl = out.detach()[:, :, ::sh, ::sw].cpu().numpy()
+    return {"loss_abs": abs(loss - float(ref["loss"])),
+            "logits_rel_l2": float(np.linalg.norm(sl - ref["logits_slice"]) / np.linalg.norm(ref["logits_slice"])),
+            "logits_sq_rel": abs(float((out.detach().double() ** 2).sum()) - float(ref["logits_sq_sum"])) / float(ref["logits_sq_sum"]),
+            "grad_norm_rel_median": float(np.median(dev_)), "grad_norm_rel_max": float(dev_.max())}
+
+
+def _run_unet_bf16(shape, seed=0, data_seed=1234):
+    import pytorch_camvid_amd as A
+    n, h, w = shape
+    torch.manual_seed(seed)
+    net = A.set_conv_precision(A.UNet(3, 12).to(dev()).train(), "bf16")
+    g = torch.Generator().manual_seed(data_seed)
+    x = torch.randn(n, 3, h, w, generator=g).to(dev()); t = torch.randint(0, 12, (n, h, w), generator=g).to(dev())
+    out = net(x)
+    loss = A.CrossEntropyLoss()(out, t)
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    return net, out, loss.item()
+
+
+def test_unet_bf16_vs_emulation_2x96x128():
+    """Whole UNet, bf16 mode, against the emulation fixture (tests/golden/make_drift.py bf16small): tolerance =
+    bf16_emul_tolerance of drift.json = 4 x the emulation's own sensitivity to a 1e-6 input perturbation."""
+    d = json.load(open(os.path.join(G, "drift.json")))
+    tol = d["bf16_emul_tolerance"]["unet_2x96x128"]
+    ref = dict(np.load(os.path.join(G, "bf16emu_unet_s0_2x96x128.npz")))
+    net, out, loss = _run_unet_bf16((2, 96, 128))
+    m = _net_metrics(net, out, loss, ref)
+    print("bf16 vs emulation 2x96x128:", m, tol)
+    for k in ("loss_abs", "logits_rel_l2", "grad_norm_rel_median", "grad_norm_rel_max"):
+        assert m[k] <= tol[k], (k, m[k], tol[k])
+    # determinism of the bf16 path
+    net2, out2, loss2 = _run_unet_bf16((2, 96, 128))
+    assert loss2 == loss and torch.equal(out, out2)
+    for a, b in zip(net.parameters(), net2.parameters()):
+        assert torch.equal(a.grad, b.grad)
+
+
+def test_unet_bf16_config3_workload():
+    """BASELINE.json configs[3]: UNet 4x3x720x960 through the bf16 path.  (1) against the emulation of the same rounding
+    points at the same workload (bf16emu fixture, tolerance 4 x its noise floor); (2) against the REFERENCE's fp32 run
+    (unet_s0_4x720x960.npz, generated by importing the reference) within the bf16 storage cost the emulation measures
+    (drift.json bf16_tolerance = 3 x emulated-bf16-vs-fp32)."""
+    d = json.load(open(os.path.join(G, "drift.json")))
+    net, out, loss = _run_unet_bf16((4, 720, 960))
+    emu = dict(np.load(os.path.join(G, "bf16emu_unet_s0_4x720x960.npz")))
+    tol_e = d["bf16_emul_tolerance"]["unet_4x720x960"]
+    m = _net_metrics(net, out, loss, emu)
+    print("bf16 vs emulation 4x720x960:", m, tol_e)
+    for k in ("loss_abs", "logits_rel_l2", "grad_norm_rel_median", "grad_norm_rel_max"):
+        assert m[k] <= tol_e[k], (k, m[k], tol_e[k])
+    ref = dict(np.load(os.path.join(G, "unet_s0_4x720x960.npz")))
+    tol_r = d["bf16_tolerance"]["unet_4x720x960"]
+    r = _net_metrics(net, out, loss, ref)
+    print("bf16 vs reference fp32 4x720x960:", r, tol_r)
+    assert r["loss_abs"] <= tol_r["loss_abs"] and r["logits_rel_l2"] <= tol_r["logits_rel_l2"]
+    assert r["grad_norm_rel_median"] <= tol_r["grad_norm_rel_median"] and r["grad_norm_rel_max"] <= tol_r["grad_norm_rel_max"]

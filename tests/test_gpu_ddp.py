@@ -1,0 +1,95 @@
+"""The N>1 path through the real executor: two ranks on one GPU, engine + ddp.DataParallel, gradients
+exchanged over gloo.  Checked against the equivalence statement of SURVEY.md §8e: N ranks x batch b == ONE process that
+runs the N shards as separate BatchNorm groups with the same weights and averages the gradients."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_two_ranks_real_engine_equal_grouped_bn_single_process():
+    import pytorch_camvid_amd as A
+    from oracle import torch_ref as R
+    from tests.ddp_gpu_worker import run
+    shape = (2, 48, 64)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(run, args=(2, free_port(), d, shape, 8.0), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "rank0.pt")); r1 = torch.load(os.path.join(d, "rank1.pt"))
+    # rank 0's parameters were broadcast: both ranks started from the same weights and ended with the same gradients
+    for a, b in zip(r0["w0"], r1["w0"]):
+        assert torch.equal(a, b)
+    for a, b in zip(r0["grads"], r1["grads"]):
+        assert torch.equal(a, b)
+    assert len(r0["launched"]) >= 4 and r0["launched"][0][0] == 0
+    assert r0["loss"] != r1["loss"]                                  # the shards differ
+    # single process, same weights, the two shards as separate BN groups, mean of the gradients
+    dev = torch.device("cuda:0")
+    torch.manual_seed(100)
+    net = A.UNet(3, 12).to(dev).train()
+    for p, w in zip(net.parameters(), r0["w0"]):
+        assert torch.equal(p.detach().cpu(), w)                      # seed 100 == rank 0's init
+    lossf = A.CrossEntropyLoss()
+    shard_grads, losses = [], []
+    for rank in range(2):
+        g = torch.Generator().manual_seed(1234 + rank)
+        x = torch.randn(shape[0], 3, shape[1], shape[2], generator=g).to(dev)
+        t = torch.randint(0, 12, shape, generator=g).to(dev)
+        for p in net.parameters():
+            p.grad = None
+        l = lossf(net(x), t); l.backward()
+        losses.append(l.item())
+        shard_grads.append([p.grad.detach().cpu().clone() for p in net.parameters()])
+    assert losses[0] == r0["loss"] and losses[1] == r1["loss"]       # per-rank BatchNorm statistics, bitwise deterministic kernels
+    for i, (a, b) in enumerate(zip(*shard_grads)):
+        want = (a + b) / 2
+        assert torch.allclose(r0["grads"][i], want, rtol=1e-6, atol=1e-12), i
+    # and against the oracle (stock torch on CPU) for the same grouped formulation
+    torch.manual_seed(100)
+    ref = R.build("unet", 3, 12).train()
+    acc = None
+    for rank in range(2):
+        x, t = R.synthetic_batch(shape[0], shape[1], shape[2], 1234 + rank)
+        R.fwd_bwd_step(ref, x, t)
+        gs = [p.grad.clone() for p in ref.parameters()]
+        acc = gs if acc is None else [u + v for u, v in zip(acc, gs)]
+    rel = []
+    for (k, p), got, want in zip(ref.named_parameters(), r0["grads"], acc):
+        if k.endswith("conv.0.bias"):
+            continue
+        want = want / 2
+        rel.append(float((got - want).norm() / want.norm()))
+    rel = np.array(rel)
+    assert np.median(rel) < 2e-3 and rel.max() < 0.3, (np.median(rel), rel.max())   # tiny-geometry whole-net grads: see test_gpu_nets
+
+
+def test_bench_rehearsal_self_launch(tmp_path):
+    """`python bench.py --gpus 2` with no launcher starts its own ranks (child torch.distributed.run) and prints ONE JSON
+    line with n_gpus 2; CVK_REHEARSAL=1 lets the two ranks share this box's single GPU over gloo (not a measurement)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CVK_REHEARSAL="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--height", "96", "--width", "128", "--no-cpu-baseline", "--no-kernel-profile"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["value"] > 0 and "REHEARSAL" in rec["data"]
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "rehearsal_n2.json"), "w") as f:
+        f.write(lines[0] + "\n")

@@ -1,0 +1,157 @@
+"""Round-2 GPU tests: checkpoint round trip through the HIP network, torch.jit.trace survivability (reference
+train.py:97), two passes through one network inside one autograd graph, optimizer state, prefetcher slot reuse."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def test_checkpoint_reference_layout_load_eval_roundtrip(tmp_path):
+    """A reference-layout .pth (dense OIHW weights, int64 num_batches_tracked, non-trivial running statistics) written
+    from the stock-torch rebuild -> load into the HIP net -> the eval-mode logits of the file's weights -> save again
+    -> bit-equal file contents (reference train.py:88-93,232-240)."""
+    import pytorch_camvid_amd as A
+    from oracle import torch_ref as R
+    for kind, shape in (("unet", (2, 45, 60)), ("segnet", (2, 64, 96))):
+        torch.manual_seed(11)
+        ref = R.build(kind, 3, 12).train()
+        x, t = R.synthetic_batch(shape[0], shape[1], shape[2], 21)
+        with torch.no_grad():
+            for _ in range(2):
+                ref(x)                                    # two training-mode passes: running stats leave their init values
+        ref.eval()
+        with torch.no_grad():
+            want = ref(x)
+        src = str(tmp_path / "checkpoints" / "ref" / "30-best.pth")
+        os.makedirs(os.path.dirname(src))
+        torch.save(ref.state_dict(), src)
+        torch.manual_seed(12)
+        net = A.get_model(kind, 3, 12).to(dev())
+        trained, path = A.resume(net, str(tmp_path / "checkpoints"))
+        assert trained == 30 and path == os.path.abspath(src)
+        net.eval()
+        with torch.no_grad():
+            got = net(x.to(dev()))
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-3, atol=3e-4)
+        assert (A.argmax_channels(got).cpu() == want.argmax(1)).float().mean() > 0.995
+        out = A.save_checkpoint(net, str(tmp_path / "checkpoints" / "mine"), 31, "regular")
+        a = torch.load(src); b = torch.load(out, map_location="cpu")
+        assert list(a.keys()) == list(b.keys())
+        for k in a:
+            assert a[k].dtype == b[k].dtype and b[k].is_contiguous() and torch.equal(a[k], b[k]), k
+        import shutil
+        shutil.rmtree(tmp_path / "checkpoints")
+
+
+def test_jit_trace_survives_like_add_graph():
+    """reference train.py:97 -> utils.py:10-13: `writer.add_graph(net, tensor)` = torch.jit.trace(net, tensor,
+    strict=False) under no_grad on a train-mode net with a (1,3,480,360) tensor.  tensorboard is not installed here, so
+    the trace call itself is what is exercised, with its default re-run check."""
+    import pytorch_camvid_amd as A
+    torch.manual_seed(0)
+    net = A.UNet(3, 12).to(dev())                        # train mode, as at train.py:97
+    tensor = torch.randn(1, 3, 96, 64).to(next(net.parameters()).device)
+    nbt0 = int(net.down1[0].conv[1].num_batches_tracked)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        traced = torch.jit.trace(net, tensor, strict=False)
+        out = traced(tensor)
+    assert tuple(out.shape) == (1, 12, 96, 64) and torch.isfinite(out).all()
+    assert int(net.down1[0].conv[1].num_batches_tracked) > nbt0          # the traced passes update BN statistics like the reference's
+    # the network still trains normally afterwards
+    x = torch.randn(2, 3, 48, 64, device=dev()); t = torch.randint(0, 12, (2, 48, 64), device=dev())
+    A.CrossEntropyLoss()(net(x), t).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_two_passes_through_one_network_in_one_graph():
+    """loss = L(net(x1)) + L(net(x2)) must give g1 + g2, and gradients the caller keeps across
+    zero_grad(set_to_none=True) must not be overwritten by the next backward."""
+    import pytorch_camvid_amd as A
+    from oracle import torch_ref as R
+    torch.manual_seed(0)
+    net = A.UNet(3, 12).to(dev()).train()
+    torch.manual_seed(0)
+    ref = R.build("unet", 3, 12).train()
+    x1, t1 = R.synthetic_batch(2, 48, 64, 31)
+    x2, t2 = R.synthetic_batch(2, 48, 64, 32)
+    lossf = A.CrossEntropyLoss()
+    (lossf(net(x1.to(dev())), t1.to(dev())) + lossf(net(x2.to(dev())), t2.to(dev()))).backward()
+    both = [p.grad.clone() for p in net.parameters()]
+    singles = []
+    for x, t in ((x1, t1), (x2, t2)):
+        for p in net.parameters():
+            p.grad = None
+        lossf(net(x.to(dev())), t.to(dev())).backward()
+        singles.append([p.grad for p in net.parameters()])          # kept across the next zero_grad + backward on purpose
+    for i, (g, a, b) in enumerate(zip(both, *singles)):
+        assert torch.allclose(g, a + b, rtol=1e-5, atol=1e-10), i
+    assert not torch.equal(singles[0][0], singles[1][0])             # the kept gradients of pass 1 were not overwritten by pass 2
+    (torch.nn.functional.cross_entropy(ref(x1), t1) + torch.nn.functional.cross_entropy(ref(x2), t2)).backward()
+    gw = dict(net.named_parameters())["output.conv.0.weight"]
+    k = list(dict(net.named_parameters())).index("output.conv.0.weight")
+    rw = dict(ref.named_parameters())["output.conv.0.weight"].grad
+    assert float((both[k].cpu() - rw).norm() / rw.norm()) < 2e-3
+    ag = torch.autograd.grad(lossf(net(x1.to(dev())), t1.to(dev())), list(net.parameters()))
+    lossf(net(x2.to(dev())), t2.to(dev())).backward()
+    assert torch.equal(ag[0], singles[0][0])                         # autograd.grad results survive a later backward
+
+
+def test_flat_adamw_state_dict_and_rehome_guard():
+    import pytorch_camvid_amd as A
+    torch.manual_seed(0)
+    net = A.UNet(3, 12).to(dev()).train()
+    opt = A.FlatAdamW(net, lr=1e-3, weight_decay=0.0)
+    x = torch.randn(2, 3, 32, 32, device=dev()); t = torch.randint(0, 12, (2, 32, 32), device=dev())
+    lossf = A.CrossEntropyLoss()
+    for _ in range(2):
+        opt.zero_grad(); lossf(net(x), t).backward(); opt.step()
+    sd = opt.state_dict()
+    assert sd["flat_adamw"]["step"] == 2 and float(sd["flat_adamw"]["exp_avg_sq"].sum()) > 0
+    net_sd = {k: v.clone() for k, v in net.state_dict().items()}
+    opt.zero_grad(); lossf(net(x), t).backward(); opt.step()
+    after3 = [p.detach().clone() for p in net.parameters()]
+    # resume: fresh net + optimizer, load both states, take the same third step -> identical parameters
+    torch.manual_seed(1)
+    net2 = A.UNet(3, 12).to(dev()).train()
+    net2.load_state_dict(net_sd)
+    opt2 = A.FlatAdamW(net2, lr=1e-3, weight_decay=0.0)
+    opt2.load_state_dict(sd)
+    opt2.zero_grad(); lossf(net2(x), t).backward(); opt2.step()
+    for a, b in zip(after3, net2.parameters()):
+        assert torch.equal(a, b)
+    net2.float().cpu()
+    net2.to(dev())                                                    # re-homes the parameters away from the flat buffer
+    lossf(net2(x), t).backward()
+    with pytest.raises(RuntimeError, match="flat buffer"):
+        opt2.step()
+
+
+def test_unet_fullsize_batch2_all_three_losses():
+    """All three reference losses of the 2x3x360x480 golden: AdamW + OneCycleLR(steps_per_epoch=300,
+    epochs=1), tolerance per step from tests/golden/drift.json (fp32-vs-fp64 drift of the reference graph)."""
+    import json
+    import pytorch_camvid_amd as A
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    d = dict(np.load(os.path.join(G, "unet_s0_2x360x480.npz")))
+    tol = json.load(open(os.path.join(G, "drift.json")))["trajectory_tolerance"]["unet_s0_2x360x480"]
+    torch.manual_seed(0)
+    net = A.UNet(3, 12).to(dev()).train()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(2, 3, 360, 480, generator=g).to(dev()); t = torch.randint(0, 12, (2, 360, 480), generator=g).to(dev())
+    opt = torch.optim.AdamW(net.parameters(), lr=5e-4, weight_decay=0)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=5e-4, steps_per_epoch=300, epochs=1)
+    lossf = A.CrossEntropyLoss()
+    for i in range(3):
+        opt.zero_grad()
+        l = lossf(net(x), t); l.backward()
+        opt.step(); sched.step()
+        assert abs(l.item() - float(d["traj_losses"][i])) < tol[i], (i, l.item(), float(d["traj_losses"][i]), tol[i])

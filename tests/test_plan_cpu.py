@@ -9,6 +9,7 @@ from pytorch_camvid_amd import engine
 def build_plan(net, n, c, h, w):
     plan = engine.Plan(n, c, h, w)
     plan.output = net._emit(plan, plan.input)
+    plan.seal()
     return plan
 
 
