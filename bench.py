@@ -49,8 +49,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH)
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp32_split"],
-                    help="bf16 = opt-in bf16-MFMA forward/data-grad convolutions (configs[3] path); the headline is fp32")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16 = bf16-storage mode (BASELINE.json configs[3]: --precision bf16 --height 720 --width 960 --batch 4); the headline is fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--with-optimizer", action="store_true", help="also time AdamW steps (reported separately)")
@@ -175,16 +175,16 @@ def main():
     kernels = None
     hbm_kernels = None
     if not a.no_kernel_profile:
-        R = runner_of(net)
-        R.prof = []
+        from pytorch_camvid_amd import engine
+        engine.PROF = []
         for _ in range(3):
             step()
         torch.cuda.synchronize(dev)
         agg, mem = {}, {}
-        for name, work, e0, e1, unit in R.prof:
+        for name, work, e0, e1, unit in engine.PROF:
             d = (agg if unit == "flop" else mem).setdefault(name, [0, 0.0, 0.0])
             d[0] += 1; d[1] += work; d[2] += e0.elapsed_time(e1) * 1e-3
-        R.prof = None
+        engine.PROF = None
         kernels = {k: {"launches_per_step": v[0] // 3, "avg_us": round(v[2] / v[0] * 1e6, 1),
                        "tflops": round(v[1] / v[2] / 1e12, 2), "ms_per_step": round(v[2] / 3 * 1e3, 3)} for k, v in agg.items()}
         hbm_kernels = {k: {"launches_per_step": v[0] // 3, "ms_per_step": round(v[2] / 3 * 1e3, 3),
@@ -237,10 +237,9 @@ def main():
                       else f"images/sec fwd+bwd {a.model} 3x{a.height}x{a.width} bs={a.batch} ({a.precision})",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": "bf16-mfma convs (f32 accumulate, f32 tensors in HBM)",
-                      "fp32_split": "f32-accurate 3-way bf16 split on bf16 MFMA (fwd/dgrad), f32 elsewhere"}[a.precision], "data": "synthetic" + (" (REHEARSAL: ranks share a GPU over gloo — not a measurement)" if rehearsal else ""),
-            "config": {"workload": f"{a.model.upper() if a.model=='unet' else 'SegNet'}(3,12) train fwd+bwd+CE, per-GPU batch {a.batch} x 3x{a.height}x{a.width} fp32 "
-                                   f"(BASELINE.json configs[1]{' x N ranks, RCCL grad all-reduce (configs[2])' if world > 1 else ''})",
+            "dtype": {"fp32": "f32", "bf16": "bf16 (bf16 activations/gradients in HBM, bf16 MFMA with f32 accumulate, f32 statistics/parameters)"}[a.precision], "data": "synthetic" + (" (REHEARSAL: ranks share a GPU over gloo — not a measurement)" if rehearsal else ""),
+            "config": {"workload": f"{a.model.upper() if a.model=='unet' else 'SegNet'}(3,12) train fwd+bwd+CE, per-GPU batch {a.batch} x 3x{a.height}x{a.width} {a.precision} "
+                                   f"(BASELINE.json {'configs[3]' if a.precision == 'bf16' else 'configs[1]'}{' x N ranks, RCCL grad all-reduce (configs[2])' if world > 1 else ''})",
                        "global_batch": world * a.batch, "parallelism": f"dp{world}", "timed_region": "zero_grad+forward+CE+backward"
                                    + ("+allreduce" if world > 1 else ""), "loss": round(float(loss.item()), 6)},
             "roofline": roof, "cpu_baseline": cpu,

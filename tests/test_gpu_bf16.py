@@ -116,10 +116,14 @@ def _stage_pair(ci, c1, c2, seed):
     return ref, mine
 
 
-@pytest.mark.parametrize("shape", [(3, 64, 64, 2, 16, 40), (64, 128, 12, 2, 9, 33), (128, 64, 64, 1, 24, 70)])
+@pytest.mark.parametrize("shape", [(3, 64, 64, 4, 64, 96), (64, 128, 12, 2, 48, 66), (128, 64, 64, 2, 40, 70)])
 def test_two_block_stage_vs_emulation(shape):
     """Two conv+BN+ReLU blocks in bf16 mode against oracle/bf16_emul.py: output, running statistics and all parameter
-    gradients (weight-grad, BN backward, the data-grad between the blocks)."""
+    gradients (weight-grad, BN backward, the data-grad between the blocks).
+    Gradient tolerance, derived in the test: with a random upstream gradient every ReLU-mask flip moves a gradient sum by
+    O(1), so two runs whose outputs differ by delta differ by ~sqrt(delta) in the gradients (measured: emulation vs fp32
+    5-9 %, device vs emulation 1-3 %, tools/dbg_bf16s.py).  The device must sit clearly CLOSER to the emulation (the
+    declared rounding points) than the emulation sits to fp32: at most 0.6 x that distance per tensor, and < 3 % absolute."""
     import pytorch_camvid_amd as A
     from oracle import bf16_emul as E
     ci, c1, c2, n, h, w = shape
@@ -129,6 +133,9 @@ def test_two_block_stage_vs_emulation(shape):
     r = torch.randn(n, c2, h, w, generator=g)
     want = E._stage(ref, E._r(x), last=True)
     (want * r).sum().backward()
+    ref32, _ = _stage_pair(ci, c1, c2, seed=ci + c2)
+    (ref32(x) * r).sum().backward()
+    cost = {k: float((a.grad - c.grad).norm() / c.grad.norm()) for (k, a), (_, c) in zip(ref.named_parameters(), ref32.named_parameters())}
     mine = A.set_conv_precision(mine.to(dev()).train(), "bf16")
     out = mine(x.to(dev()))
     assert out.dtype == torch.float32 and tuple(out.shape) == (n, c2, h, w)
@@ -141,7 +148,7 @@ def test_two_block_stage_vs_emulation(shape):
             assert gb.abs().max() <= 2e-2 * float(dict(ref.named_parameters())[k.replace("bias", "weight")].grad.abs().max()) + 1e-3, k
             continue
         e = float((ga - gb).norm() / ga.norm())
-        assert e < 2e-2, (k, e)
+        assert e < 3e-2 and e < 0.6 * cost[k], (k, e, cost[k])
     for (k, a), (_, b) in zip(ref.named_buffers(), mine.named_buffers()):
         if "num_batches" in k:
             assert int(a) == int(b)
