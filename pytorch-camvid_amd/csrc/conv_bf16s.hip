@@ -42,6 +42,20 @@ __device__ __forceinline__ void dma16(const void* g, char* lds_base) {
     __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)lds_base, 16, 0, 0);
 }
 
+// The same DMA hidden from hipcc's wait-count pass (inline asm; M0 = LDS byte address, written in the statement that
+// uses it).  hipcc orders every ds_read behind a tracked LDS-DMA with s_waitcnt vmcnt(0) when it cannot disambiguate
+// the addresses — that serialises a double-buffered phase (DMA of tile t+1, then the MFMAs of tile t).  With the DMA in
+// asm the ordering is ours: counted s_waitcnt vmcnt + s_barrier before the buffer is read.
+__device__ __forceinline__ void dma16_asm(const void* g, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_byte_addr) : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ bf16x8 lds_read16(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -57,9 +71,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16s(const __bf16* __restrict_
     constexpr int WP = 4 / WC;             // waves along the pixel dimension
     constexpr int TP = 8 / WP;             // 32-pixel blocks (tile rows) per wave
     constexpr int TC = 2;                  // 32-channel MFMA tiles per wave
-    constexpr int NBP = BN / 64;           // weight DMA pieces (16 rows x 64 B) per wave per step
-    constexpr int BSLOT = BN * 64;         // bytes per weight ring slot
-    constexpr int MAIN_BYTES = 2 * SLAB_BYTES + 3 * BSLOT;
+    constexpr int TPS = BN == 64 ? 3 : 1;  // taps per step (= per barrier): the 64-channel tile has only 8 MFMAs per wave and
+                                           // tap, so it runs a whole kernel row between two barriers
+    constexpr int SPC = 9 / TPS;           // steps per channel slice
+    constexpr int RING = TPS == 3 ? 2 : 3; // weight ring depth in steps (LDS budget: 2 workgroups per CU)
+    constexpr int NBP = BN / 64;           // weight DMA pieces (16 rows x 64 B) per wave per tap
+    constexpr int BTAP = BN * 64;          // bytes of one tap's weight tile
+    constexpr int BSLOT = BTAP * TPS;      // bytes per weight ring slot (one step)
+    constexpr int SLABPS = 6 / (TPS == 3 ? 3 : 6);   // slab DMA pieces per wave and step (during the first 6 / SLABPS steps of a slice)
+    constexpr int MAIN_BYTES = 2 * SLAB_BYTES + RING * BSLOT;
     constexpr int STAT_BYTES = STATS ? BN * 32 * WP * 2 * 4 : 0;      // epilogue scratch: [channel][32*WP partials][sum, sumsq]
     constexpr int LDS_BYTES = MAIN_BYTES > STAT_BYTES ? MAIN_BYTES : STAT_BYTES;
     static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
@@ -85,7 +105,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16s(const __bf16* __restrict_
     const __bf16* const Ximg = X + (size_t)img * H * W * Cin;
 
     // ---- DMA source offsets (elements), fixed over the K loop --------------------------------------------------------
-    // slab pieces: at tap t < 6 wave w moves piece 4t + w; lane -> LDS row (piece*16 + lane/4), 16-byte position lane%4
+    // slab pieces: wave w moves pieces 4t + w, t = 0..5 (spread over the steps of the previous slice);
+    // lane -> LDS row (piece*16 + lane/4), 16-byte position lane%4
     int aoff[6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
@@ -109,9 +130,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16s(const __bf16* __restrict_
         const __bf16* src = aoff[t] >= 0 ? Ximg + (size_t)(unsigned)aoff[t] + cs * CK : zero;
         dma16(src, slab + (4 * t + wave) * 1024);
     };
-    auto dma_weights = [&](int step_tap, int cs, char* slot) {
+    auto dma_weights = [&](int sidx, int cs, char* slot) {      // the TPS taps of step sidx of slice cs
 #pragma unroll
-        for (int i = 0; i < NBP; ++i) dma16(Wt + (size_t)(unsigned)boff[i] + step_tap * Cin + cs * CK, slot + (wave * NBP + i) * 1024);
+        for (int j = 0; j < TPS; ++j)
+#pragma unroll
+            for (int i = 0; i < NBP; ++i)
+                dma16(Wt + (size_t)(unsigned)boff[i] + (sidx * TPS + j) * Cin + cs * CK, slot + j * BTAP + (wave * NBP + i) * 1024);
     };
 
     // ---- operand read addresses --------------------------------------------------------------------------------------
@@ -137,12 +161,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16s(const __bf16* __restrict_
 
     const int ncs = Cin / CK;
 
-    // ---- prologue: slab of slice 0, weight tiles of steps 0 and 1 -------------------------------------------------------
+    // ---- prologue: slab of slice 0, weight tiles of the first RING - 1 steps ------------------------------------------------
 #pragma unroll
     for (int t = 0; t < 6; ++t) dma_slab_piece(t, 0, slab0);
     dma_weights(0, 0, ring0);
-    dma_weights(1, 0, ring0 + BSLOT);
-    wait_vm<NBP>();                    // everything but the step-1 weights has landed
+    if (RING == 3) {
+        dma_weights(1, 0, ring0 + BSLOT);
+        wait_vm<NBP * TPS>();          // everything but the step-1 weights has landed
+    } else {
+        wait_vm<0>();
+    }
     __builtin_amdgcn_s_barrier();
 
     int step = 0;
@@ -152,38 +180,53 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16s(const __bf16* __restrict_
         const int csn = min(cs + 1, ncs - 1);     // past the end the DMAs re-load the last slice into buffers nobody reads:
                                                   // no branch in the step, uniform vmcnt bookkeeping
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap, ++step) {
-            // (1) DMA: weight tile of step + 2 into the ring slot read in step - 1, one slab piece of the next slice
+        for (int sidx = 0; sidx < SPC; ++sidx, ++step) {
+            // (1) DMA: weights of step + RING - 1 into the ring slot read in step - 1, slab pieces of the next slice
             {
-                const int s2 = step + 2;
-                const int tap2 = tap + 2 >= 9 ? tap + 2 - 9 : tap + 2;
-                const int cs2 = tap + 2 >= 9 ? csn : cs;
-                dma_weights(tap2, cs2, ring0 + (s2 % 3) * BSLOT);
-                if (tap < 6) dma_slab_piece(tap, csn, slab_next);
+                constexpr int AHEAD = RING - 1;
+                const int s2 = step + AHEAD;
+                const int sidx2 = sidx + AHEAD >= SPC ? sidx + AHEAD - SPC : sidx + AHEAD;
+                const int cs2 = sidx + AHEAD >= SPC ? csn : cs;
+                dma_weights(sidx2, cs2, ring0 + (s2 % RING) * BSLOT);
+                if (sidx * SLABPS < 6) {
+#pragma unroll
+                    for (int j = 0; j < SLABPS; ++j) dma_slab_piece(sidx * SLABPS + j, csn, slab_next);
+                }
             }
             // (2) MFMAs of this step
-            const int dy = tap / 3, dx = tap % 3;
-            const char* const wslot = ring0 + (step % 3) * BSLOT;
+            const char* const wslot = ring0 + (step % RING) * BSLOT;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 a[TC], b[TP];
+            for (int j = 0; j < TPS; ++j) {
+                const int tap = sidx * TPS + j;
+                const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
-                for (int tc = 0; tc < TC; ++tc) a[tc] = lds_read16(wslot + ((wa0 ^ (kk << 5)) + tc * 32 * 64));
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8 a[TC], b[TP];
 #pragma unroll
-                for (int tp = 0; tp < TP; ++tp) {
-                    const int hy = wp * TP + tp + dy;                           // halo row: uniform, (tp + dy) folds into the offset
-                    const int pos = (pcl[dx] ^ (hy & 3) ^ (kk << 1)) << 4;
-                    b[tp] = lds_read16(slab + (tp + dy) * (HP * 64) + pa[dx] + pos);
+                    for (int tc = 0; tc < TC; ++tc) a[tc] = lds_read16(wslot + j * BTAP + ((wa0 ^ (kk << 5)) + tc * 32 * 64));
+#pragma unroll
+                    for (int tp = 0; tp < TP; ++tp) {
+                        const int hy = wp * TP + tp + dy;                       // halo row: uniform, (tp + dy) folds into the offset
+                        const int pos = (pcl[dx] ^ (hy & 3) ^ (kk << 1)) << 4;
+                        b[tp] = lds_read16(slab + (tp + dy) * (HP * 64) + pa[dx] + pos);
+                    }
+#pragma unroll
+                    for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+                        for (int tp = 0; tp < TP; ++tp)
+                            acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tc], b[tp], acc[tc][tp], 0, 0, 0);
                 }
-#pragma unroll
-                for (int tc = 0; tc < TC; ++tc)
-#pragma unroll
-                    for (int tp = 0; tp < TP; ++tp)
-                        acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tc], b[tp], acc[tc][tp], 0, 0, 0);
             }
-            // (3) everything issued before this step's DMAs has landed (the step+1 weights, older slab pieces)
-            if (tap < 6) wait_vm<NBP + 1>();
-            else wait_vm<NBP>();
+            // (3) ring of 3: everything issued before this step's DMAs has landed (the step+1 weights, older slab pieces).
+            //     ring of 2: this step's weight DMAs feed the NEXT step and must land; the slab pieces (issued after them)
+            //     may stay in flight except at the end of the slice.
+            if (RING == 3) {
+                if (sidx * SLABPS < 6) wait_vm<NBP * TPS + SLABPS>();
+                else wait_vm<NBP * TPS>();
+            } else {
+                if (sidx == SPC - 1) wait_vm<0>();
+                else wait_vm<SLABPS>();
+            }
             __builtin_amdgcn_s_barrier();
         }
     }
@@ -237,14 +280,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16s(const __bf16* __restrict_
             *reinterpret_cast<float2*>(red + ((size_t)ch * (32 * WP) + part) * 2) = v2;
         }
     __syncthreads();
-    if (tid < BN) {
-        const int co = n0 + tid;
+    {
+        // all 256 threads: BN channels x (256 / BN) segments of the 32*WP partials, fp64, fixed order; segments meet through
+        // DPP-free shuffles inside a wave (consecutive lanes hold the segments of one channel)
+        constexpr int SEG = 256 / BN;                       // 2 (BN = 128) or 4 (BN = 64)
+        constexpr int PER = 32 * WP / SEG;
+        const int chl = tid / SEG, sg = tid % SEG;
+        const float2* p = reinterpret_cast<const float2*>(red) + (size_t)chl * (32 * WP) + sg * PER;
         double S = 0.0, Q = 0.0;
-        const float2* p = reinterpret_cast<const float2*>(red) + (size_t)tid * (32 * WP);
 #pragma unroll 8
-        for (int i = 0; i < 32 * WP; ++i) { S += (double)p[i].x; Q += (double)p[i].y; }
+        for (int i = 0; i < PER; ++i) { S += (double)p[i].x; Q += (double)p[i].y; }
+#pragma unroll
+        for (int o = 1; o < SEG; o <<= 1) {
+            S += __shfl_xor(S, o, 64);
+            Q += __shfl_xor(Q, o, 64);
+        }
+        const int co = n0 + chl;
         const int nvalid = min(TH, H - y0) * min(TW, W - x0);
-        if (co < Cout) {
+        if (sg == 0 && co < Cout) {
             double m2 = Q - S * S / (double)nvalid;
             stats[(size_t)sp * Cout + co] = (float)S;
             stats[(size_t)(P + sp) * Cout + co] = (float)(m2 > 0.0 ? m2 : 0.0);
@@ -407,23 +460,25 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_bf16s(const __bf16* __restrict
         ds_px[q] = row & 31;
         ds_ch[q] = cob * 64 + chunk * 8;
     }
-    auto stage = [&](int t, char* buf) {
+    const unsigned smem_addr = lds_addr_of(smem);
+    auto stage = [&](int t, int which) {
         const int tx = t % tilesX, ty = (t / tilesX) % tilesY, img = t / (tilesX * tilesY);
         const int x0 = tx * TW, y0 = ty * TH;
-        const size_t ibase = (size_t)img * H * W;
+        const long ibase = (long)img * H * W;
+        const unsigned buf = smem_addr + which * WG_STAGE;
 #pragma unroll
         for (int q = 0; q < 12; ++q) {
             const int iy = y0 - 1 + xs_hy[q], ix = x0 - 1 + xs_hx[q];
             const bool ok = ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
-            const __bf16* src = ok ? X + (ibase + (size_t)iy * W + ix) * ldx + xs_ch[q] : zero;
-            dma16(src, buf + (wave * 12 + q) * 1024);
+            const long off = ok ? ((ibase + (long)iy * W + ix) * ldx + xs_ch[q]) : 0;
+            dma16_asm(ok ? (const void*)(X + off) : (const void*)zero, buf + (wave * 12 + q) * 1024);
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int iy = y0 + ds_py[q], ix = x0 + ds_px[q];
             const bool ok = (iy < H) & (ix < W);
-            const __bf16* src = ok ? DY + (ibase + (size_t)iy * W + ix) * ld_dy + ds_ch[q] : zero;
-            dma16(src, buf + WG_XBYTES + (wave * 8 + q) * 1024);
+            const long off = ok ? ((ibase + (long)iy * W + ix) * ld_dy + ds_ch[q]) : 0;
+            dma16_asm(ok ? (const void*)(DY + off) : (const void*)zero, buf + WG_XBYTES + (wave * 8 + q) * 1024);
         }
     };
 
@@ -447,13 +502,13 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_bf16s(const __bf16* __restrict
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    if (t0 < t1) stage(t0, smem);
+    if (t0 < t1) stage(t0, 0);
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     int cur = 0;
     for (int t = t0; t < t1; ++t) {
         char* const buf = smem + cur * WG_STAGE;
-        if (t + 1 < t1) stage(t + 1, smem + (cur ^ 1) * WG_STAGE);
+        if (t + 1 < t1) stage(t + 1, cur ^ 1);
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             const int ry = ks >> 1, xh = ks & 1;
