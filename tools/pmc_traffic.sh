@@ -2,7 +2,7 @@
 # HBM traffic of the conv kernels from PMC counters (separate passes, as MI355X_MICROARCH.md §HBM prescribes).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile > /dev/null 2> gpurun_out/pmc_$c.err
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile $BENCH_ARGS > /dev/null 2> gpurun_out/pmc_$c.err
 done
 python - <<'PY'
 import csv, glob, collections, json
