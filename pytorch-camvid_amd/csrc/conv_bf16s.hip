@@ -19,6 +19,8 @@
 //   * MFMA orientation D[cout][pixel] = Wt-tile (A operand) x pixel-tile (B operand): a lane ends up with four
 //     consecutive output channels of one pixel per register quad -> 8-byte packed bf16 stores along NHWC rows.
 //   * out-of-frame halo pixels (conv zero padding, ragged tiles) are DMA'd from a zero page.
+#include <stdlib.h>
+#include <type_traits>
 #include "cvk_common.h"
 
 namespace {
@@ -50,6 +52,11 @@ __device__ __forceinline__ void dma16_asm(const void* g, unsigned lds_byte_addr)
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds_byte_addr) : "memory");
+}
+
+// variant for kernels that use no compiler-issued LDS-DMA (nothing of hipcc's lives in M0): no save/restore
+__device__ __forceinline__ void dma16_asm_m0(const void* g, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_byte_addr) : "memory");
 }
 
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
@@ -389,7 +396,7 @@ extern "C" int cvk_conv3x3_bf16s(const void* x, const void* w, const float* bias
 
 // ================================================================================================ weight-grad (bf16 storage)
 // dW[co][tap][ci] = sum_pixels dy[p][co] * x[p + tap][ci]   (reference: the weight gradient of nn.Conv2d, train.py:131)
-// GEMM per tap: D[co][ci] += dy^T[co][pixel] * x_shifted[pixel][ci], K = pixels.  One workgroup (4 waves, one per SIMD,
+// GEMM per tap: D[co][ci] += dy^T[co][pixel] * x_shifted[pixel][ci], K = pixels.  One workgroup (8 waves, two per SIMD,
 // the whole 160 KiB LDS) owns a 64 x 64 (co, ci) block of all nine taps and walks a range of 8 x 32 pixel tiles:
 //   * per tile the dy tile (256 px x 64 co) and the x tile WITH HALO (10 x 34 px x 64 ci) are DMA'd into LDS once and the
 //     nine taps read x at shifted addresses (the im2col weight-grad of round 1 re-staged x nine times and synchronised
@@ -419,16 +426,23 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* p) {
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-__global__ __launch_bounds__(256, 1) void k_wgrad_bf16s(const __bf16* __restrict__ X, const __bf16* __restrict__ DY,
+// 8 waves: wave w owns quadrant (w & 3) = (co half, ci half) of the 64 x 64 block; waves 0-3 accumulate taps 0..4, waves
+// 4-7 taps 5..8 (80 / 64 accumulator registers: two waves per SIMD fit the 512-entry register file without spills).  Measured ablation of the 4-wave version (one wave per SIMD; DMA off / MFMA
+// off / both off): the transposed LDS reads (320 per wave and tile, the LDS array's full 256 B/clk), the MFMAs and the DMA
+// each need 1.2-1.9 us per tile but ran almost back to back (3.5-4.8 us): one in-order wave cannot overlap them.  Two
+// waves per SIMD can.  DBG (timing experiments only, wrong results): 1 = no DMA after the first tile, 2 = no MFMAs.
+template <int DBG = 0>
+__global__ __launch_bounds__(512, 2) void k_wgrad_bf16s(const __bf16* __restrict__ X, const __bf16* __restrict__ DY,
                                                        float* __restrict__ slab, int H, int W, int ldx, int ld_dy, int Cout,
                                                        int Cin, int tilesX, int tilesY, int ntiles, int tiles_per_split,
                                                        int nblk_ci, int nblk) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * WG_STAGE];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // 0..7
     const int h = lane >> 5;
-    const int wco = wave >> 1, wci = wave & 1;
+    const int quad = wave & 3, tg = wave >> 2;             // tap group: 0 -> taps 0..4, 1 -> taps 5..8
+    const int wco = quad >> 1, wci = quad & 1;
 
     const int gid = cvk_xcd_remap(blockIdx.x, gridDim.x);
     const int blk = gid % nblk, split = gid / nblk;      // blocks of one pixel range are neighbours (one XCD's L2)
@@ -437,49 +451,56 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_bf16s(const __bf16* __restrict
     const int t1 = min(ntiles, t0 + tiles_per_split);
     const __bf16* const zero = reinterpret_cast<const __bf16*>(g_zero_page);
 
-    // ---- static part of the DMA source mapping --------------------------------------------------------------------------
-    // x slab: piece q (0..11) of this wave covers LDS rows (wave*12 + q)*8 + lane/8, 16-byte position lane%8
-    int xs_hy[12], xs_hx[12], xs_ch[12];
+    // ---- DMA source mapping: per piece a 32-bit element offset relative to the tile's first pixel and the packed halo
+    //      coordinates for the frame test; per tile only a 64-bit base and a few uniform bounds change -------------------
+    // x slab: piece q (0..5) of this wave covers LDS rows (wave*6 + q)*8 + lane/8, 16-byte position lane%8
+    int xs_off[6], xs_yx[6];
 #pragma unroll
-    for (int q = 0; q < 12; ++q) {
-        const int row = (wave * 12 + q) * 8 + (lane >> 3);
+    for (int q = 0; q < 6; ++q) {
+        const int row = (wave * 6 + q) * 8 + (lane >> 3);
         const int hy = row / HP, hx = row - hy * HP;
         const int chunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
         const bool ok = (row < WG_XROWS) & (hx < TW + 2) & (cib * 64 + chunk * 8 < ldx);
-        xs_hy[q] = ok ? hy : -100000;
-        xs_hx[q] = hx;
-        xs_ch[q] = cib * 64 + chunk * 8;
+        xs_off[q] = ((hy - 1) * W + (hx - 1)) * ldx + cib * 64 + chunk * 8;
+        xs_yx[q] = ok ? (hy << 8) | hx : 0x7F7F;               // static rejects fail every frame test
     }
-    int ds_py[8], ds_px[8], ds_ch[8];
+    int ds_off[4], ds_yx[4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int row = (wave * 8 + q) * 8 + (lane >> 3);      // tile pixel index: py*32 + px
+    for (int q = 0; q < 4; ++q) {
+        const int row = (wave * 4 + q) * 8 + (lane >> 3);      // tile pixel index: py*32 + px
         const int chunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
         const bool ok = cob * 64 + chunk * 8 < ld_dy;
-        ds_py[q] = ok ? row >> 5 : 100000;
-        ds_px[q] = row & 31;
-        ds_ch[q] = cob * 64 + chunk * 8;
+        ds_off[q] = ((row >> 5) * W + (row & 31)) * ld_dy + cob * 64 + chunk * 8;
+        ds_yx[q] = ok ? ((row >> 5) << 8) | (row & 31) : 0x7F7F;
     }
     const unsigned smem_addr = lds_addr_of(smem);
-    auto stage = [&](int t, int which) {
+    const __bf16* sx_base = X;
+    const __bf16* sd_base = DY;
+    int s_ylo = 0, s_yn = 0, s_xlo = 0, s_xn = 0, s_dyn = 0, s_dxn = 0;
+    unsigned s_buf = 0;
+    auto stage_begin = [&](int t, int which) {
         const int tx = t % tilesX, ty = (t / tilesX) % tilesY, img = t / (tilesX * tilesY);
         const int x0 = tx * TW, y0 = ty * TH;
-        const long ibase = (long)img * H * W;
-        const unsigned buf = smem_addr + which * WG_STAGE;
-#pragma unroll
-        for (int q = 0; q < 12; ++q) {
-            const int iy = y0 - 1 + xs_hy[q], ix = x0 - 1 + xs_hx[q];
-            const bool ok = ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
-            const long off = ok ? ((ibase + (long)iy * W + ix) * ldx + xs_ch[q]) : 0;
-            dma16_asm(ok ? (const void*)(X + off) : (const void*)zero, buf + (wave * 12 + q) * 1024);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int iy = y0 + ds_py[q], ix = x0 + ds_px[q];
-            const bool ok = (iy < H) & (ix < W);
-            const long off = ok ? ((ibase + (long)iy * W + ix) * ld_dy + ds_ch[q]) : 0;
-            dma16_asm(ok ? (const void*)(DY + off) : (const void*)zero, buf + WG_XBYTES + (wave * 8 + q) * 1024);
-        }
+        const long pix = ((long)img * H + y0) * W + x0;
+        sx_base = X + pix * ldx;
+        sd_base = DY + pix * ld_dy;
+        // halo pixel (hy,hx) is inside the frame iff ylo <= hy < ylo + yn and xlo <= hx < xlo + xn
+        s_ylo = y0 == 0 ? 1 : 0;  s_yn = min(TH + 2, H - y0 + 1) - s_ylo;
+        s_xlo = x0 == 0 ? 1 : 0;  s_xn = min(TW + 2, W - x0 + 1) - s_xlo;
+        s_dyn = min(TH, H - y0);  s_dxn = min(TW, W - x0);
+        s_buf = smem_addr + which * WG_STAGE;
+    };
+    auto stage_x = [&](int q) {
+        if (DBG & 1) return;
+        const bool ok = ((unsigned)((xs_yx[q] >> 8) - s_ylo) < (unsigned)s_yn) & ((unsigned)((xs_yx[q] & 255) - s_xlo) < (unsigned)s_xn);
+        const __bf16* p = sx_base + xs_off[q];
+        dma16_asm_m0(ok ? (const void*)p : (const void*)zero, s_buf + (wave * 6 + q) * 1024);
+    };
+    auto stage_d = [&](int q) {
+        if (DBG & 1) return;
+        const bool ok = ((ds_yx[q] >> 8) < s_dyn) & ((ds_yx[q] & 255) < s_dxn);
+        const __bf16* p = sd_base + ds_off[q];
+        dma16_asm_m0(ok ? (const void*)p : (const void*)zero, s_buf + WG_XBYTES + (wave * 4 + q) * 1024);
     };
 
     // ---- transposed-read lane addresses -----------------------------------------------------------------------------------
@@ -496,46 +517,88 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_bf16s(const __bf16* __restrict
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) b_base[dx] = lane_addr(rl + dx, wci * 32 + 16 * g1 + 4 * tp);
 
-    f32x16 acc[9];
+    // One tile for one wave: 16 k-steps (16 pixels each) x its NT taps.  Fragments: fa double-buffered, fb[j] reloaded in
+    // place right after its MFMA (the MFMA has latched its operands when the LDS data returns), order pinned with
+    // sched_barrier: every operand is requested a whole k-step before its use.  The tile body is one basic block
+    // (MORE is a template flag, not a branch).
+    auto run = [&](auto t0_tag, auto nt_tag) {
+        constexpr int TAP0 = decltype(t0_tag)::value, NT = decltype(nt_tag)::value;
+        f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        auto tile_body = [&](char* buf, auto more_tag) {
+            constexpr bool MORE = decltype(more_tag)::value;
+            bf16x8 fa[2], fb[NT];
+            auto a_addr = [&](int ks) { return buf + a_base + ((ks >> 1) * 32 + (ks & 1) * 16) * 128; };
+            auto b_addr = [&](int ks, int j) {
+                const int tap = TAP0 + j;
+                return buf + b_base[tap % 3] + (((ks >> 1) + tap / 3) * HP + (ks & 1) * 16) * 128;
+            };
+            fa[0] = tr_read8(a_addr(0));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = tr_read8(b_addr(0, j));
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const int cs_ = ks & 1, ns_ = cs_ ^ 1;
+                if (MORE && ks < 2) {    // this wave's 10 DMA pieces of the next tile go out at the start of the tile: the whole
+                                         // tile (~2 us of MFMAs) covers their flight (issued late, HBM latency showed at the barrier)
+                    if (ks == 0) {
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) stage_x(q);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) stage_d(q);
+                    }
+                }
+                if (ks + 1 < 16) fa[ns_] = tr_read8(a_addr(ks + 1));
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (!(DBG & 2)) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cs_], fb[j], acc[j], 0, 0, 0);
+                    else asm volatile("" :: "v"(fb[j]), "v"(fa[cs_]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks + 1 < 16 && !((DBG & 4) && (j & 1))) fb[j] = tr_read8(b_addr(ks + 1, j));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        int cur = 0;
+        for (int t = t0; t < t1; ++t) {
+            char* const buf = smem + cur * WG_STAGE;
+            if (t + 1 < t1) {
+                stage_begin(t + 1, cur ^ 1);
+                tile_body(buf, std::true_type{});
+            } else {
+                tile_body(buf, std::false_type{});
+            }
+            wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            cur ^= 1;
+        }
+        // ---- partial slab: [split][co][tap][ci] fp32 -----------------------------------------------------------------------
+        float* out = slab + (size_t)split * Cout * 9 * Cin;
+        const int ci = cib * 64 + wci * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = cob * 64 + wco * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (co < Cout && ci < Cin) out[((size_t)co * 9 + TAP0 + j) * Cin + ci] = acc[j][i];
+            }
+    };
 
-    if (t0 < t1) stage(t0, 0);
+    if (t0 < t1) {
+        stage_begin(t0, 0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) stage_x(q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stage_d(q);
+    }
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
-    int cur = 0;
-    for (int t = t0; t < t1; ++t) {
-        char* const buf = smem + cur * WG_STAGE;
-        if (t + 1 < t1) stage(t + 1, cur ^ 1);
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const int ry = ks >> 1, xh = ks & 1;
-            const bf16x8 a = tr_read8(buf + a_base + (ry * 32 + xh * 16) * 128);
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const bf16x8 b = tr_read8(buf + b_base[dx] + ((ry + dy) * HP + xh * 16) * 128);
-                    acc[3 * dy + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[3 * dy + dx], 0, 0, 0);
-                }
-        }
-        wait_vm<0>();
-        __builtin_amdgcn_s_barrier();
-        cur ^= 1;
-    }
-
-    // ---- partial slab: [split][co][tap][ci] fp32 ---------------------------------------------------------------------------
-    float* out = slab + (size_t)split * Cout * 9 * Cin;
-    const int ci = cib * 64 + wci * 32 + (lane & 31);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int co = cob * 64 + wco * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (co < Cout && ci < Cin) out[((size_t)co * 9 + tap) * Cin + ci] = acc[tap][i];
-        }
+    if (tg == 0) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+    else run(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
 }
 
 __global__ void k_wgrad_reduce_bf16s(const float* __restrict__ slab, float* __restrict__ dw, int splits, size_t n) {
@@ -561,8 +624,10 @@ inline WgPlan plan_wgrad_bf16s(int N, int H, int W, int Cin, int Cout) {
     p.nblk_ci = cvk_cdiv(Cin, 64);
     p.ntiles = N * cvk_cdiv(H, TH) * cvk_cdiv(W, TW);
     const int nblk = p.nblk_co * p.nblk_ci;
-    // one workgroup per CU: aim at a whole number of 256-workgroup rounds, at least 2 tiles per workgroup when possible
-    int splits = cvk_cdiv(512, nblk);
+    // one workgroup per CU: ONE round of 256 workgroups when every workgroup still gets >= 4 tiles (fewer partial slabs to
+    // write and reduce), else two rounds
+    int splits = cvk_cdiv(256, nblk);
+    if (splits * 4 > p.ntiles) splits = cvk_cdiv(512, nblk);
     if (splits > p.ntiles) splits = p.ntiles;
     if (splits < 1) splits = 1;
     p.tps = cvk_cdiv(p.ntiles, splits);
@@ -594,8 +659,16 @@ extern "C" int cvk_conv3x3_wgrad_bf16s(const void* x, const void* dy, float* dw,
     }
     hipStream_t s = (hipStream_t)stream;
     const int nblk = p.nblk_co * p.nblk_ci;
-    hipLaunchKernelGGL(k_wgrad_bf16s, dim3(nblk * p.splits), dim3(256), 0, s, (const __bf16*)x, (const __bf16*)dy, (float*)workspace, H, W,
-                       ldx, ld_dy, Cout, Cin, cvk_cdiv(W, TW), cvk_cdiv(H, TH), p.ntiles, p.tps, p.nblk_ci, nblk);
+    static const int dbg = getenv("CVK_WGRAD_DBG") ? atoi(getenv("CVK_WGRAD_DBG")) : 0;      // timing experiments only
+#define CVK_WG_LAUNCH(D_) hipLaunchKernelGGL((k_wgrad_bf16s<D_>), dim3(nblk * p.splits), dim3(512), 0, s, (const __bf16*)x, (const __bf16*)dy, (float*)workspace, H, W, \
+                           ldx, ld_dy, Cout, Cin, cvk_cdiv(W, TW), cvk_cdiv(H, TH), p.ntiles, p.tps, p.nblk_ci, nblk)
+    if (dbg == 1) CVK_WG_LAUNCH(1);
+    else if (dbg == 2) CVK_WG_LAUNCH(2);
+    else if (dbg == 3) CVK_WG_LAUNCH(3);
+    else if (dbg == 4) CVK_WG_LAUNCH(4);
+    else if (dbg == 5) CVK_WG_LAUNCH(5);
+    else CVK_WG_LAUNCH(0);
+#undef CVK_WG_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         cvk_set_error("cvk_conv3x3_wgrad_bf16s: launch failed: %s", hipGetErrorString(e));

@@ -1,0 +1,59 @@
+"""BASELINE.json configs[0] / SURVEY.md 8d(ii): the reference's training loop (train.py:100-134: AdamW lr 5e-4 wd 0,
+OneCycleLR(max_lr, steps_per_epoch=300, epochs=1), CrossEntropyLoss) and validation pass (train.py:169-206, mIoU from
+utils.intersect_and_union sums over the whole set) for ONE 300-step epoch at batch 2 x 3x360x480 on synthetic labels.
+The fixture (tests/golden/protocol_unet_2x360x480_run0.npz) is the imported reference run on CPU; run1 is the same run
+with a 1e-6 relative input perturbation — the distance between the two reference curves is the reference's own
+reproducibility and derives the tolerance (4 x its maximum; mIoU additionally within BASELINE.json's +-0.005)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+sys.path.insert(0, G)
+
+
+def test_one_epoch_loss_curve_and_miou_match_the_reference_run():
+    import pytorch_camvid_amd as A
+    from protocol_data import PROTO, proto_batch
+    r0 = dict(np.load(os.path.join(G, "protocol_unet_2x360x480_run0.npz")))
+    r1 = dict(np.load(os.path.join(G, "protocol_unet_2x360x480_run1.npz")))
+    P = PROTO
+    spread = np.abs(r0["losses"] - r1["losses"])
+    assert spread[0] == 0.0 and spread.max() < 5e-3                   # the fixture pair itself: identical start, close curves
+    tol = np.maximum(4.0 * np.maximum.accumulate(spread), 2e-5)       # non-decreasing envelope; first step is a pure forward
+    tol[1:] = np.maximum(tol[1:], 4.0 * spread.max() * 0.1)           # early steps: at least a tenth of the curve's spread
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = A.UNet(3, 12).to(dev).train()
+    opt = torch.optim.AdamW(net.parameters(), lr=P["lr"], weight_decay=0)                                   # train.py:100
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=P["lr"], steps_per_epoch=P["steps"], epochs=1)   # train.py:103-104
+    lossf = A.CrossEntropyLoss()
+    losses = []
+    for it in range(P["steps"]):
+        x, m = proto_batch(it)
+        opt.zero_grad()
+        loss = lossf(net(x.to(dev)), m.to(dev))
+        loss.backward()
+        opt.step(); sched.step()
+        losses.append(loss.detach())
+    losses = torch.stack(losses).cpu().numpy()
+    d = np.abs(losses - r0["losses"])
+    worst = int(np.argmax(d / tol))
+    print(f"protocol: max |loss - ref| {d.max():.2e} (reference pair {spread.max():.2e}); final {losses[-1]:.5f} vs {r0['losses'][-1]:.5f}")
+    assert (d <= tol).all(), (worst, float(d[worst]), float(tol[worst]), float(losses[worst]), float(r0["losses"][worst]))
+    val = [tuple(t.to(dev) for t in proto_batch(i, val=True)) for i in range(P["val_batches"])]
+    rep = A.evaluate_report(net, val, num_classes=12, ignore_index=11)
+    ref_miou = float(r0["miou"])
+    print(f"protocol: mIoU {rep['miou']:.5f} vs reference {ref_miou:.5f} (reference pair differs by {abs(ref_miou - float(r1['miou'])):.1e})")
+    assert abs(rep["miou"] - ref_miou) <= 0.005                         # BASELINE.json: mIoU +-0.005
+    assert abs(rep["miou"] - ref_miou) <= max(2e-3, 10 * abs(ref_miou - float(r1["miou"])))
+    assert abs(rep["loss"] - float(np.mean(r0["val_loss"]))) < 5e-3
+    # the histograms the reference's utils.intersect_and_union accumulated (per class, 11 non-void classes)
+    h = None
+    inter = np.asarray(r0["inter"][:11]); union = np.asarray(r0["union"][:11])
+    iou_ref = inter / union
+    assert np.abs(rep["iou"].numpy()[:11] - iou_ref).max() < 0.01
