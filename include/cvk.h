@@ -209,16 +209,18 @@ int cvk_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * ================================================================================================================ */
 
 /* rows the packed weight tensors are padded to (multiple of the kernel's output-channel tile), and the number of
- * BatchNorm-statistics partials cvk_conv3x3_bf16s writes (one per 8 x 32 pixel tile) */
+ * BatchNorm-statistics partials cvk_conv3x3_bf16s writes for a layer (one per 8 x 32 pixel tile, or one per strip of
+ * tiles for the <= 64 x 64 channel layers); cvk_bf16s_stat_partials is the upper bound over all layers */
 int cvk_bf16s_rows_pad(int cout);
 int cvk_bf16s_stat_partials(int N, int H, int W);
+int cvk_bf16s_stat_partials_c(int N, int H, int W, int Cin, int Cout);
 /* fp32 master weights [Cout][3][3][Cin] -> bf16 [rows_pad(Cout)][9][Cin_pad] (forward), and the rotated/transposed
  * data-grad filter bf16 [rows_pad(Cin)][9][Cout_pad]; zero padded */
 int cvk_pack_weight_fwd_bf16(const float* w, void* out, int Cout, int Cin, int Cin_pad, void* stream);
 int cvk_pack_weight_dgrad_bf16(const float* w, void* out, int Cout, int Cin, int Cout_pad, void* stream);
 /* y[N,H,W,ldy] (bf16) = conv3x3(x[N,H,W,Cin] bf16, w bf16 [rows_pad][9][Cin]) + bias; Cin % 32 == 0.  With stats != NULL:
  * stats[2][P][Cout] = per-tile (sum, M2 about the tile mean) of the fp32 results, counts[P] = pixels per tile,
- * P = cvk_bf16s_stat_partials(N,H,W) -> cvk_bn_finalize_counts.  Data-grad: the same call on dy and the dgrad pack. */
+ * P = cvk_bf16s_stat_partials_c(N,H,W,Cin,Cout) -> cvk_bn_finalize_counts.  Data-grad: the same call on dy and the dgrad pack. */
 int cvk_conv3x3_bf16s(const void* x, const void* w, const float* bias, void* y, float* stats, float* counts,
                       int N, int H, int W, int Cin, int Cout, int ldy, void* stream);
 int cvk_bn_finalize_counts(const float* stats, const float* counts, int P, int M, int C, const float* gamma, const float* beta,

@@ -83,6 +83,7 @@ SIGNATURES = {
     "cvk_preprocess_u8": (c_int, [c_vp, c_vp, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_vp]),
     "cvk_bf16s_rows_pad": (c_int, [c_int]),
     "cvk_bf16s_stat_partials": (c_int, [c_int, c_int, c_int]),
+    "cvk_bf16s_stat_partials_c": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "cvk_pack_weight_fwd_bf16": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "cvk_pack_weight_dgrad_bf16": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_bf16s": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),

@@ -313,6 +313,224 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16s(const __bf16* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 64 x 64 strip kernel
+// Layers with <= 64 input AND <= 64 output channels (down1.1 / up4.1 and their data-grads, the stem, the head): a tile is
+// only 3-6 kernel-row steps of 24 MFMAs.  In k_conv_bf16s<64> every step waits for the next step's weight DMA, i.e. one
+// L2 round trip (1-2 us under load) per 0.3 us of MFMAs: measured 10-15 us per tile against 2 us of matrix work (PMC:
+// matrix pipe 28 % busy).  Here the WHOLE filter (<= 2 slices x 9 taps x 64 x 32 bf16 = 72 KiB) is loaded into LDS once
+// per workgroup and a workgroup walks a STRIP of consecutive tiles without draining:
+//   * LDS: filter 72 KiB + two slab buffers 48 KiB = 120 KiB -> one workgroup per CU (the 512-entry register file then
+//     holds the per-lane statistics sums of the whole strip without spills);
+//   * waves 0-1 issue the slab DMA of the NEXT slice (possibly of the next tile) at the start of a slice and wait for it
+//     at its end — a whole slice of flight time, and nothing else is in their in-order vmcnt queue; waves 2-3 issue none,
+//     so result stores never delay a DMA wait;
+//   * one barrier per slice (72 MFMAs per wave) instead of one per step;
+//   * BatchNorm statistics accumulate per lane over the strip: one LDS reduction and ONE partial per strip.
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 1) void k_conv_bf16s_strip(const __bf16* __restrict__ X, const __bf16* __restrict__ Wt,
+                                                            const float* __restrict__ bias, __bf16* __restrict__ Y,
+                                                            float* __restrict__ stats, float* __restrict__ cnt, int H, int W,
+                                                            int Cin, int Cout, int ldy, int tilesX, int tilesY, int ntiles,
+                                                            int strip_len, int P) {
+    constexpr int BN = 64, TP = 2, TC = 2;
+    constexpr int BTAP = BN * 64;                                       // one tap's weight tile (64 rows x 64 B)
+    constexpr int WBYTES = 2 * 9 * BTAP;                                // resident filter: up to two channel slices
+    constexpr int LDS_BYTES = 2 * SLAB_BYTES + WBYTES;                  // 120 KiB (statistics scratch reuses it: 64 KiB)
+    static_assert(LDS_BYTES >= BN * 128 * 2 * 4, "statistics scratch");
+    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+    const unsigned smem_addr = lds_addr_of(smem);
+    const unsigned w_addr = smem_addr + 2 * SLAB_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wp = wave;                                                // tile rows 2*wp, 2*wp + 1
+    const bool slab_role = wave < 2;
+
+    const int strip = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int t_begin = strip * strip_len, t_end = min(ntiles, t_begin + strip_len);
+    const __bf16* const zero = reinterpret_cast<const __bf16*>(g_zero_page);
+    const int ncs = Cin / CK;                                           // 1 or 2
+
+    // ---- slab DMA mapping (waves 0-1): off[q], q = 0..11: element offset of piece (wave*12 + q) relative to the tile's first
+    //      pixel; the piece covers LDS rows piece*16 + lane/4 (halo pixel hy = row / 36, hx = row % 36), 16-byte position
+    //      lane%4.  Rows no tap reads (hy > 9, hx > 33) point at the tile origin.  The frame test is needed on border tiles
+    //      only and recomputes (hy, hx) there.
+    int sl_off[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+        const int row = ((wave & 1) * 12 + q) * 16 + (lane >> 2);
+        const int hy = (row * 1821) >> 16, hx = row - hy * HP;
+        const int chunk = (lane & 3) ^ ((hx >> 2) & 3) ^ (hy & 3);
+        const bool used = (hy < TH + 2) & (hx < TW + 2);
+        sl_off[q] = used ? ((hy - 1) * W + (hx - 1)) * Cin + chunk * 8 : 0;
+    }
+    struct TileGeo { int img, y0, x0; };
+    auto geo_of = [&](int t) {
+        TileGeo g;
+        const int tx = t % tilesX, ty = (t / tilesX) % tilesY;
+        g.img = t / (tilesX * tilesY);
+        g.x0 = tx * TW; g.y0 = ty * TH;
+        return g;
+    };
+    auto dma_slab = [&](const TileGeo& g, int cs, unsigned slab) {
+        const __bf16* const xbase = X + (((long)g.img * H + g.y0) * W + g.x0) * Cin + cs * CK;
+        const bool interior = (g.y0 > 0) & (g.x0 > 0) & (g.y0 + TH + 1 <= H) & (g.x0 + TW + 1 <= W);
+        if (interior) {
+#pragma unroll
+            for (int q = 0; q < 12; ++q) dma16_asm_m0(xbase + sl_off[q], slab + (wave * 12 + q) * 1024);
+        } else {
+            const int ylo = g.y0 == 0 ? 1 : 0, yn = min(TH + 2, H - g.y0 + 1) - ylo;
+            const int xlo = g.x0 == 0 ? 1 : 0, xn = min(TW + 2, W - g.x0 + 1) - xlo;
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                const int row = (wave * 12 + q) * 16 + (lane >> 2);
+                const int hy = (row * 1821) >> 16, hx = row - hy * HP;
+                const bool ok = ((unsigned)(hy - ylo) < (unsigned)yn) & ((unsigned)(hx - xlo) < (unsigned)xn);
+                dma16_asm_m0(ok ? (const void*)(xbase + sl_off[q]) : (const void*)zero, slab + (wave * 12 + q) * 1024);
+            }
+        }
+    };
+
+    // ---- prologue: the whole filter (all four waves: ncs x 9 taps x 4 pieces of 16 rows), the first slab ----------------------
+    {
+        const int n = lane >> 2;                                        // row inside a 16-row piece
+        const int npieces = ncs * 36;
+        for (int pi = wave; pi < npieces; pi += 4) {                    // uniform trip count per wave
+            const int cs = pi / 36, rem = pi - cs * 36, tap = rem >> 2, rp = rem & 3;
+            const int row = rp * 16 + n;
+            const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+            dma16_asm_m0(Wt + ((long)row * 9 + tap) * Cin + cs * CK + chunk * 8, w_addr + (cs * 9 + tap) * BTAP + rp * 1024);
+        }
+    }
+    TileGeo geo = geo_of(t_begin < t_end ? t_begin : 0);
+    if (slab_role && t_begin < t_end) dma_slab(geo, 0, smem_addr);
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+
+    // ---- operand read addresses (as k_conv_bf16s, one output-channel wave column) ----------------------------------------------
+    const int wa0 = r * 64 + ((h ^ ((r >> 2) & 3)) << 4);
+    int pa[3], pcl[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        pa[dx] = (r + dx) * 64;
+        pcl[dx] = h ^ (((r + dx) >> 2) & 3);
+    }
+
+    f32x16 acc[TC][TP];
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    float ss[TC][16], qq[TC][16];
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { ss[a][i] = 0.f; qq[a][i] = 0.f; }
+    int nvalid = 0;
+    const int out_lane = (2 * wp * W + r) * ldy + 4 * h;                // elements, relative to the tile's first pixel
+
+    int vis = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+        const bool last_tile = t + 1 >= t_end;
+        for (int cs = 0; cs < ncs; ++cs, ++vis) {
+            const char* const slab = smem + (vis & 1) * SLAB_BYTES + 2 * wp * (HP * 64);
+            const unsigned slab_next = smem_addr + ((vis + 1) & 1) * SLAB_BYTES;
+            const bool last_cs = cs + 1 >= ncs;
+            if (slab_role) {                                            // the next slice's slab: this slice's 72 MFMAs cover its flight
+                if (!last_cs) dma_slab(geo, cs + 1, slab_next);
+                else if (!last_tile) dma_slab(geo_of(t + 1), 0, slab_next);
+            }
+            const char* const wsl = smem + 2 * SLAB_BYTES + cs * 9 * BTAP;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8 a[TC], b[TP];
+#pragma unroll
+                    for (int tc = 0; tc < TC; ++tc) a[tc] = lds_read16(wsl + tap * BTAP + ((wa0 ^ (kk << 5)) + tc * 32 * 64));
+#pragma unroll
+                    for (int tp = 0; tp < TP; ++tp) {
+                        const int hy = 2 * wp + tp + dy;
+                        const int pos = (pcl[dx] ^ (hy & 3) ^ (kk << 1)) << 4;
+                        b[tp] = lds_read16(slab + (tp + dy) * (HP * 64) + pa[dx] + pos);
+                    }
+#pragma unroll
+                    for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+                        for (int tp = 0; tp < TP; ++tp)
+                            acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tc], b[tp], acc[tc][tp], 0, 0, 0);
+                }
+            }
+            if (slab_role) wait_vm<0>();                               // next slab landed (and this wave's older stores)
+            __builtin_amdgcn_s_barrier();
+        }
+        // ---- tile finished: bias, statistics, bf16 stores (range-checked buffer stores: ragged tiles, padded channels) --------
+        {
+            const int py0 = geo.y0 + 2 * wp, px = geo.x0 + r;
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(Y + (((long)geo.img * H + geo.y0) * W + geo.x0) * ldy), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+            for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = tc * 32 + 8 * g + 4 * h;
+                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                    if (bias != nullptr && co < Cout) bv = *reinterpret_cast<const f32x4*>(bias + co);
+#pragma unroll
+                    for (int tp = 0; tp < TP; ++tp) {
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { v[j] = acc[tc][tp][4 * g + j] + bv[j]; acc[tc][tp][4 * g + j] = 0.f; }
+                        const bool ok = (px < W) & (py0 + tp < H);
+                        if (STATS && ok) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { ss[tc][4 * g + j] += v[j]; qq[tc][4 * g + j] += v[j] * v[j]; }
+                        }
+                        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        const unsigned off = (unsigned)(out_lane + tp * W * ldy + co - 4 * h) * 2u;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, o), yr, (ok & (co < ldy)) ? off : 0x80000000u, 0, 0);
+                    }
+                }
+            nvalid += min(TH, H - geo.y0) * min(TW, W - geo.x0);
+            if (!last_tile) geo = geo_of(t + 1);
+        }
+    }
+    if (!STATS) return;
+    __builtin_amdgcn_s_barrier();
+    float* const red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ch = tc * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const float2 v2 = {ss[tc][i], qq[tc][i]};
+            *reinterpret_cast<float2*>(red + ((size_t)ch * 128 + wp * 32 + r) * 2) = v2;
+        }
+    __syncthreads();
+    {
+        const int chl = tid >> 2, sg = tid & 3;                          // 64 channels x 4 segments of 32 partials
+        const float2* p = reinterpret_cast<const float2*>(red) + (size_t)chl * 128 + sg * 32;
+        double S = 0.0, Q = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) { S += (double)p[i].x; Q += (double)p[i].y; }
+        S += __shfl_xor(S, 1, 64); Q += __shfl_xor(Q, 1, 64);
+        S += __shfl_xor(S, 2, 64); Q += __shfl_xor(Q, 2, 64);
+        if (sg == 0 && chl < Cout && nvalid > 0) {
+            const double m2 = Q - S * S / (double)nvalid;
+            stats[(size_t)strip * Cout + chl] = (float)S;
+            stats[(size_t)(P + strip) * Cout + chl] = (float)(m2 > 0.0 ? m2 : 0.0);
+        }
+        if (tid == 0) cnt[strip] = (float)nvalid;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ operand preparation
 // fp32 master weights, physical [Cout][3][3][Cin] (channels_last OIHW) -> bf16 [rows_pad][9][Cin_pad], zero padded.
 __global__ void k_pack_w_fwd_bf16(const float* __restrict__ w, __bf16* __restrict__ out, int Cout, int Cin, int rows_pad, int Cin_pad) {
@@ -346,7 +564,23 @@ extern "C" int cvk_bf16s_rows_pad(int cout) {
     return cvk_cdiv(cout, bn) * bn;
 }
 
-extern "C" int cvk_bf16s_stat_partials(int N, int H, int W) {
+// the 64 x 64 strip kernel (resident filter, one workgroup per CU) serves layers with Cin <= 64 and Cout <= 64; a strip is
+// ntiles / 256 tiles (one round of workgroups), at least 1
+static bool use_strip(int Cin, int Cout) { return Cin <= 64 && Cout <= 64; }
+static int strip_len_for(int ntiles) {
+    int len = cvk_cdiv(ntiles, 256);
+    return len < 1 ? 1 : len;
+}
+
+/* number of BatchNorm-statistics partials cvk_conv3x3_bf16s writes for this layer */
+extern "C" int cvk_bf16s_stat_partials_c(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    const int ntiles = N * cvk_cdiv(H, TH) * cvk_cdiv(W, TW);
+    if (!use_strip(Cin, Cout)) return ntiles;
+    return cvk_cdiv(ntiles, strip_len_for(ntiles));
+}
+
+extern "C" int cvk_bf16s_stat_partials(int N, int H, int W) {       /* upper bound for any Cout */
     if (N <= 0 || H <= 0 || W <= 0) return 0;
     return N * cvk_cdiv(H, TH) * cvk_cdiv(W, TW);
 }
@@ -388,8 +622,19 @@ extern "C" int cvk_conv3x3_bf16s(const void* x, const void* w, const float* bias
 #define CVK_BS_LAUNCH(BN_, ST_)                                                                                              \
     hipLaunchKernelGGL((k_conv_bf16s<BN_, ST_>), grid, block, 0, s, (const __bf16*)x, (const __bf16*)w, bias, (__bf16*)y, stats, counts, \
                        H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, (int)P)
-    if (bn == 128) { if (stats) CVK_BS_LAUNCH(128, true); else CVK_BS_LAUNCH(128, false); }
-    else           { if (stats) CVK_BS_LAUNCH(64, true); else CVK_BS_LAUNCH(64, false); }
+    static const int no_strip = getenv("CVK_BF16S_NO_STRIP") ? atoi(getenv("CVK_BF16S_NO_STRIP")) : 0;     // A/B timing only
+    if (use_strip(Cin, Cout) && !no_strip) {
+        const int ntiles = (int)P;
+        const int slen = strip_len_for(ntiles);
+        const int nstrips = cvk_cdiv(ntiles, slen);
+        if (stats)
+            hipLaunchKernelGGL((k_conv_bf16s_strip<true>), dim3(nstrips), block, 0, s, (const __bf16*)x, (const __bf16*)w, bias, (__bf16*)y, stats, counts,
+                               H, W, Cin, Cout, ldy, tilesX, tilesY, ntiles, slen, nstrips);
+        else
+            hipLaunchKernelGGL((k_conv_bf16s_strip<false>), dim3(nstrips), block, 0, s, (const __bf16*)x, (const __bf16*)w, bias, (__bf16*)y, stats, counts,
+                               H, W, Cin, Cout, ldy, tilesX, tilesY, ntiles, slen, nstrips);
+    } else if (bn == 128) { if (stats) CVK_BS_LAUNCH(128, true); else CVK_BS_LAUNCH(128, false); }
+    else { if (stats) CVK_BS_LAUNCH(64, true); else CVK_BS_LAUNCH(64, false); }
 #undef CVK_BS_LAUNCH
     CVK_LAUNCH_RETURN("cvk_conv3x3_bf16s");
 }

@@ -372,7 +372,7 @@ class ConvBnRelu(Op):
         if st.training:
             if M <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {[N, C, H, W]}")
-            P = lib.cvk_bf16s_stat_partials(N, H, W)
+            P = lib.cvk_bf16s_stat_partials_c(N, H, W, src.ld, C)
             stats = _empty(2 * P * C + P, dev)
             cnt = stats.data_ptr() + 4 * 2 * P * C
             _timed(R, conv_kernel_name("bf16_fwd", C), flops, lambda: check(

@@ -54,7 +54,7 @@ def test_conv_bf16s_raw_abi(case):
     check(lib.cvk_pack_weight_fwd_bf16(wd.data_ptr(), wp.data_ptr(), Co, Ci, Ci, stream()))
     ldy = Co
     y = torch.full((N, H, W, ldy), float("nan"), device=dev(), dtype=BF)
-    P = lib.cvk_bf16s_stat_partials(N, H, W)
+    P = lib.cvk_bf16s_stat_partials_c(N, H, W, Ci, Co)
     stats = torch.full((2 * P * Co + P,), float("nan"), device=dev())
     cnt_ptr = stats.data_ptr() + 4 * 2 * P * Co
     check(lib.cvk_conv3x3_bf16s(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), y.data_ptr(), stats.data_ptr(), cnt_ptr, N, H, W, Ci, Co, ldy, stream()))

@@ -226,6 +226,46 @@ def test_conv_block_vs_oracle_seeded(shape):
     close(m.conv[1].bias.grad, g_o["conv.1.bias"], 1e-3, 1e-4 * float(np.abs(g_o["conv.1.bias"]).max()), "dbeta")
 
 
+@pytest.mark.parametrize("shape", [(4, 1024, 6, 8, 512), (1, 512, 45, 60, 512), (2, 1024, 22, 30, 1024)])
+def test_conv_block_deep_layer_shapes_vs_fp64(shape):
+    """Per-operator parity at the REAL deep-layer shapes of the UNet (the largest Cin against the oracle was
+    128): up1.0-like 1024->512, down4.1 512->512 at 45x60, down5.1 1024->1024 at 22x30 — K = 9*1024 accumulations checked
+    directly against an fp64 run of the reference block (oracle/torch_ref._CBR in double), both the engine's default
+    kernel choice and forced F(4,3)."""
+    import pytorch_camvid_amd as A
+    from pytorch_camvid_amd.modules import runner_of
+    from oracle import torch_ref as R
+    n, ci, h, w, co = shape
+    torch.manual_seed(sum(shape))
+    ref = R._CBR(ci, co).double().train()
+    with torch.no_grad():
+        ref.conv[1].weight.uniform_(0.5, 1.5); ref.conv[1].bias.uniform_(-0.3, 0.3)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, ci, h, w, generator=g); r = torch.randn(n, co, h, w, generator=g)
+    xr = x.double().requires_grad_(True)
+    want = ref(xr)
+    (want * r.double()).sum().backward()
+    for mode in (None, "always"):
+        m = A.BasicConv2d(ci, co)
+        m.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+        m = m.to(dev()).train()
+        if mode:
+            runner_of(m).wino4 = mode
+        xg = x.to(dev()).requires_grad_(True)
+        y = m(xg)
+        (y * r.to(dev())).sum().backward()
+
+        def rel(a, b):
+            b = b.float()
+            return float((a.detach().cpu() - b).norm() / b.norm())
+        tol = 2e-6 if mode is None else 4e-6                     # relative L2: fp32 rounding of a K = 9216 accumulation; F(4,3) ~2.5x coarser
+        assert rel(y, want) < tol, (mode, "fwd", rel(y, want))
+        assert rel(xg.grad, xr.grad) < 5 * tol, (mode, "dx", rel(xg.grad, xr.grad))
+        assert rel(m.conv[0].weight.grad, ref.conv[0].weight.grad) < 5 * tol, (mode, "dW", rel(m.conv[0].weight.grad, ref.conv[0].weight.grad))
+        assert rel(m.conv[1].weight.grad, ref.conv[1].weight.grad) < 5 * tol and rel(m.conv[1].bias.grad, ref.conv[1].bias.grad) < 5 * tol
+        np.testing.assert_allclose(y.detach().cpu().numpy(), want.detach().float().numpy(), rtol=1e-4, atol=2e-5 * float(want.abs().max()))
+
+
 def test_errors_match_reference_classes():
     import pytorch_camvid_amd as A
     with pytest.raises(ValueError):

@@ -40,7 +40,7 @@ for name, ci, co, d in LAYERS:
     wp = torch.empty(lib.cvk_bf16s_rows_pad(co) * 9 * ldx, device=dev, dtype=BF)
     check(lib.cvk_pack_weight_fwd_bf16(wt.data_ptr(), wp.data_ptr(), co, ci, ldx, s))
     y = torch.empty(M * co, device=dev, dtype=BF)
-    P = lib.cvk_bf16s_stat_partials(N, h, w)
+    P = lib.cvk_bf16s_stat_partials_c(N, h, w, ldx, co)
     st = torch.empty(2 * P * co + P, device=dev)
     flops = 18.0 * M * ci * co
     t = timeit(lambda: check(lib.cvk_conv3x3_bf16s(x.data_ptr(), wp.data_ptr(), b.data_ptr(), y.data_ptr(), st.data_ptr(), st.data_ptr() + 8 * P * co, N, h, w, ldx, co, co, s)))
