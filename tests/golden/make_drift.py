@@ -119,7 +119,7 @@ def bf16_fixture(shape, tag, slice_hw, seed=0, data_seed=1234, noise_seeds=(7, 8
     le, oe = E.fwd_bwd_step(emu, x, t)
     base = _summ(emu, oe, le, slice_hw)
     g0 = base["grad_l2"]
-    noise = {"loss_abs": 0.0, "logits_rel_l2": 0.0, "grad_norm_rel_median": 0.0, "grad_norm_rel_max": 0.0}
+    noise = {"loss_abs": 0.0, "logits_rel_l2": 0.0, "logits_sq_rel": 0.0, "grad_norm_rel_median": 0.0, "grad_norm_rel_max": 0.0}
     bias = np.array([k.endswith("conv.0.bias") for k in base["param_names"]])
     for ns in noise_seeds:
         torch.manual_seed(seed)
@@ -130,6 +130,8 @@ def bf16_fixture(shape, tag, slice_hw, seed=0, data_seed=1234, noise_seeds=(7, 8
         dev = (np.abs(g2 - g0) / g0)[~bias]
         noise["loss_abs"] = max(noise["loss_abs"], abs(float(l2) - float(le)))
         noise["logits_rel_l2"] = max(noise["logits_rel_l2"], float((o2.detach() - oe.detach()).norm() / oe.detach().norm()))
+        sq0 = float((oe.detach().double() ** 2).sum()); sq2 = float((o2.detach().double() ** 2).sum())
+        noise["logits_sq_rel"] = max(noise["logits_sq_rel"], abs(sq2 - sq0) / sq0)
         noise["grad_norm_rel_median"] = max(noise["grad_norm_rel_median"], float(np.median(dev)))
         noise["grad_norm_rel_max"] = max(noise["grad_norm_rel_max"], float(dev.max()))
         del e2, o2
@@ -142,6 +144,7 @@ def bf16_fixture(shape, tag, slice_hw, seed=0, data_seed=1234, noise_seeds=(7, 8
 def bf16_emul_tolerance(nz):
     """HIP bf16 path vs the emulation: SAFETY x the emulation's own noise floor, with floors for one bf16 ulp effects."""
     return {"loss_abs": max(2e-4, SAFETY * nz["loss_abs"]), "logits_rel_l2": max(2e-3, SAFETY * nz["logits_rel_l2"]),
+            "logits_sq_rel": max(5e-4, SAFETY * nz.get("logits_sq_rel", 0.0)),
             "grad_norm_rel_median": max(2e-3, SAFETY * nz["grad_norm_rel_median"]),
             "grad_norm_rel_max": max(2e-2, SAFETY * nz["grad_norm_rel_max"])}
 

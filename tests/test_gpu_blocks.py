@@ -231,7 +231,9 @@ def test_conv_block_deep_layer_shapes_vs_fp64(shape):
     """Per-operator parity at the REAL deep-layer shapes of the UNet (the largest Cin against the oracle was
     128): up1.0-like 1024->512, down4.1 512->512 at 45x60, down5.1 1024->1024 at 22x30 — K = 9*1024 accumulations checked
     directly against an fp64 run of the reference block (oracle/torch_ref._CBR in double), both the engine's default
-    kernel choice and forced F(4,3)."""
+    kernel choice and forced F(4,3).  The BatchNorm shift is set to +8..9 so that no ReLU mask sits near zero: with a
+    random upstream gradient a single fp32-vs-fp64 mask flip moves a gradient element by O(1) (measured 7e-4 relative L2
+    on dx at beta in [-0.3, 0.3]), which would hide the 1e-6-level accuracy of the data-grad / weight-grad GEMMs."""
     import pytorch_camvid_amd as A
     from pytorch_camvid_amd.modules import runner_of
     from oracle import torch_ref as R
@@ -239,7 +241,7 @@ def test_conv_block_deep_layer_shapes_vs_fp64(shape):
     torch.manual_seed(sum(shape))
     ref = R._CBR(ci, co).double().train()
     with torch.no_grad():
-        ref.conv[1].weight.uniform_(0.5, 1.5); ref.conv[1].bias.uniform_(-0.3, 0.3)
+        ref.conv[1].weight.uniform_(0.5, 1.5); ref.conv[1].bias.uniform_(8.0, 9.0)
     g = torch.Generator().manual_seed(1)
     x = torch.randn(n, ci, h, w, generator=g); r = torch.randn(n, co, h, w, generator=g)
     xr = x.double().requires_grad_(True)
@@ -257,7 +259,7 @@ def test_conv_block_deep_layer_shapes_vs_fp64(shape):
 
         def rel(a, b):
             b = b.float()
-            return float((a.detach().cpu() - b).norm() / b.norm())
+            return float((a.detach().cpu() - b.detach()).norm() / b.detach().norm())
         tol = 2e-6 if mode is None else 4e-6                     # relative L2: fp32 rounding of a K = 9216 accumulation; F(4,3) ~2.5x coarser
         assert rel(y, want) < tol, (mode, "fwd", rel(y, want))
         assert rel(xg.grad, xr.grad) < 5 * tol, (mode, "dx", rel(xg.grad, xr.grad))
