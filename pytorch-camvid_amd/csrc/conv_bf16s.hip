@@ -314,60 +314,76 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16s(const __bf16* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ 64 x 64 strip kernel
-// Layers with <= 64 input AND <= 64 output channels (down1.1 / up4.1 and their data-grads, the stem, the head): a tile is
-// only 3-6 kernel-row steps of 24 MFMAs.  In k_conv_bf16s<64> every step waits for the next step's weight DMA, i.e. one
-// L2 round trip (1-2 us under load) per 0.3 us of MFMAs: measured 10-15 us per tile against 2 us of matrix work (PMC:
-// matrix pipe 28 % busy).  Here the WHOLE filter (<= 2 slices x 9 taps x 64 x 32 bf16 = 72 KiB) is loaded into LDS once
-// per workgroup and a workgroup walks a STRIP of consecutive tiles without draining:
-//   * LDS: filter 72 KiB + two slab buffers 48 KiB = 120 KiB -> one workgroup per CU (the 512-entry register file then
-//     holds the per-lane statistics sums of the whole strip without spills);
-//   * waves 0-1 issue the slab DMA of the NEXT slice (possibly of the next tile) at the start of a slice and wait for it
-//     at its end — a whole slice of flight time, and nothing else is in their in-order vmcnt queue; waves 2-3 issue none,
-//     so result stores never delay a DMA wait;
-//   * one barrier per slice (72 MFMAs per wave) instead of one per step;
-//   * BatchNorm statistics accumulate per lane over the strip: one LDS reduction and ONE partial per strip.
+// Layers with <= 64 input AND <= 64 output channels (down1.1 / up4.1 and their data-grads, the stem, the head).  Their
+// operands stream from HBM at 288 FLOP per byte — at the ridge of the bf16 roofline — and a tile is only 2 us of MFMAs,
+// so the one-tile-per-workgroup kernel is bound by how many bytes it keeps in flight: one 24 KiB slab per workgroup at
+// 4-5 us loaded HBM latency is ~10 us per tile (measured; a version with the filter resident in LDS and one barrier per
+// slice stayed at 10 us: the filter traffic was not the limit).  Little's law asks for ~100 KiB in flight per CU, and LDS
+// is the only place to land them, so the filter moves to REGISTERS:
+//   * one workgroup per CU, four waves with the whole 512-entry register file each: every wave holds the complete
+//     64 x (9 x Cin) filter as MFMA A-operand fragments (288 VGPRs for Cin = 64), 64 accumulators, and per-lane
+//     BatchNorm sums for the whole strip;
+//   * LDS holds THREE full-channel slabs (halo tile x Cin, 45 KiB each): while tile t is multiplied, tiles t+1 and t+2 are
+//     in flight — 90 KiB per CU;
+//   * a workgroup walks a strip of consecutive tiles; one barrier per tile; results leave as range-checked buffer stores
+//     (every store instruction issues unconditionally, so the counted s_waitcnt vmcnt that guards slab t+1 can step over
+//     the stores of tiles t-1 and t that sit behind it in the in-order queue);
+//   * statistics: per-lane sums over the strip, one LDS reduction, ONE partial per strip.
+// LDS rows are 2*Cin bytes per halo pixel; 16-byte chunk c of LDS row p sits at c ^ ((p >> 1) & (NCH-1)) (NCH = chunks per
+// row): the 16 rows of a ds_read_b128 lane group cover all residues mod 16, so (p & 1, (p >> 1) & 7) is a bijection onto
+// the sixteen 16-byte slots of a 256-byte bank row for every tap shift.
 typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
 
-template <bool STATS>
-__global__ __launch_bounds__(256, 1) void k_conv_bf16s_strip(const __bf16* __restrict__ X, const __bf16* __restrict__ Wt,
+template <int NCS, bool STATS, int NW>  // NCS = Cin / 32 (1: the stem's padded input, 2: 64 channels); NW waves (4 or 8)
+__global__ __launch_bounds__(64 * NW, NW / 4) void k_conv_bf16s_strip(const __bf16* __restrict__ X, const __bf16* __restrict__ Wt,
                                                             const float* __restrict__ bias, __bf16* __restrict__ Y,
                                                             float* __restrict__ stats, float* __restrict__ cnt, int H, int W,
-                                                            int Cin, int Cout, int ldy, int tilesX, int tilesY, int ntiles,
+                                                            int Cout, int ldy, int tilesX, int tilesY, int ntiles,
                                                             int strip_len, int P) {
-    constexpr int BN = 64, TP = 2, TC = 2;
-    constexpr int BTAP = BN * 64;                                       // one tap's weight tile (64 rows x 64 B)
-    constexpr int WBYTES = 2 * 9 * BTAP;                                // resident filter: up to two channel slices
-    constexpr int LDS_BYTES = 2 * SLAB_BYTES + WBYTES;                  // 120 KiB (statistics scratch reuses it: 64 KiB)
-    static_assert(LDS_BYTES >= BN * 128 * 2 * 4, "statistics scratch");
-    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+    constexpr int Cin = 32 * NCS, TP = 16 / NW, NK = 2 * NCS;            // NK = 16-channel MFMA k-steps per tap; TP tile rows per wave
+    constexpr int ROWB = 2 * Cin, NCH = ROWB / 16;                      // LDS row bytes, 16-byte chunks per row
+    constexpr int ROWS = (TH + 2) * HP;                                 // 360 halo pixels
+    constexpr int PPR = 1024 / ROWB;                                    // rows per 1 KiB DMA piece
+    constexpr int NPIECE = (ROWS + PPR - 1) / PPR;                      // 45 (Cin 64) / 23 (Cin 32)
+    constexpr int PPW = (NPIECE + NW - 1) / NW;                         // pieces per wave
+    constexpr int SLABB = PPW * NW * 1024;                               // slab buffer bytes (48 / 24 KiB)
+    constexpr int NBUF = 3;
+    static_assert(NBUF * SLABB <= 160 * 1024 && NBUF * SLABB >= 64 * 16 * NW * 2 * 4, "LDS budget / statistics scratch");
+    constexpr int NST = TP * 4;                                         // buffer stores per wave and tile
+    __shared__ __attribute__((aligned(1024))) char smem[NBUF * SLABB];
     const unsigned smem_addr = lds_addr_of(smem);
-    const unsigned w_addr = smem_addr + 2 * SLAB_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int wp = wave;                                                // tile rows 2*wp, 2*wp + 1
-    const bool slab_role = wave < 2;
+    const int wc = wave & 1, wp = wave >> 1;                            // output channels 32*wc .. +31, tile rows TP*wp .. +TP-1
 
     const int strip = cvk_xcd_remap(blockIdx.x, gridDim.x);
     const int t_begin = strip * strip_len, t_end = min(ntiles, t_begin + strip_len);
     const __bf16* const zero = reinterpret_cast<const __bf16*>(g_zero_page);
-    const int ncs = Cin / CK;                                           // 1 or 2
 
-    // ---- slab DMA mapping (waves 0-1): off[q], q = 0..11: element offset of piece (wave*12 + q) relative to the tile's first
-    //      pixel; the piece covers LDS rows piece*16 + lane/4 (halo pixel hy = row / 36, hx = row % 36), 16-byte position
-    //      lane%4.  Rows no tap reads (hy > 9, hx > 33) point at the tile origin.  The frame test is needed on border tiles
-    //      only and recomputes (hy, hx) there.
-    int sl_off[12];
+    // ---- this wave's half of the filter in registers (144 VGPRs for Cin = 64): A fragment (tap, ks): row wc*32 + r,
+    //      channels 16*ks + 8h .. +7.  A wave owns 32 output channels x 4 tile rows: one LDS read per MFMA, and the
+    //      accumulators (64), statistics sums (32) and filter fit without spills.
+    bf16x8 wreg[9][NK];
 #pragma unroll
-    for (int q = 0; q < 12; ++q) {
-        const int row = ((wave & 1) * 12 + q) * 16 + (lane >> 2);
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks)
+            wreg[tap][ks] = *reinterpret_cast<const bf16x8*>(Wt + ((size_t)(wc * 32 + r) * 9 + tap) * Cin + ks * 16 + 8 * h);
+
+    // ---- slab DMA mapping: piece wave*PPW + q covers LDS rows piece*PPR + lane/NCH, 16-byte position lane % NCH ----------------
+    // (only the packed halo coordinate is kept per piece: the source offset is a handful of VALU ops per tile, a register is not)
+    int sl_yx[PPW];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int row = (wave * PPW + q) * PPR + lane / NCH;
         const int hy = (row * 1821) >> 16, hx = row - hy * HP;
-        const int chunk = (lane & 3) ^ ((hx >> 2) & 3) ^ (hy & 3);
-        const bool used = (hy < TH + 2) & (hx < TW + 2);
-        sl_off[q] = used ? ((hy - 1) * W + (hx - 1)) * Cin + chunk * 8 : 0;
+        const bool used = (row < ROWS) & (hx < TW + 2);
+        sl_yx[q] = used ? (hy << 8) | hx : 0x7F7F;
     }
+    const int sl_chunk = lane % NCH;
     struct TileGeo { int img, y0, x0; };
     auto geo_of = [&](int t) {
         TileGeo g;
@@ -376,152 +392,131 @@ __global__ __launch_bounds__(256, 1) void k_conv_bf16s_strip(const __bf16* __res
         g.x0 = tx * TW; g.y0 = ty * TH;
         return g;
     };
-    auto dma_slab = [&](const TileGeo& g, int cs, unsigned slab) {
-        const __bf16* const xbase = X + (((long)g.img * H + g.y0) * W + g.x0) * Cin + cs * CK;
-        const bool interior = (g.y0 > 0) & (g.x0 > 0) & (g.y0 + TH + 1 <= H) & (g.x0 + TW + 1 <= W);
-        if (interior) {
+    auto dma_slab = [&](int t, unsigned slab) {                          // PPW DMA instructions, always (t clamped by the caller)
+        const TileGeo g = geo_of(t);
+        const __bf16* const xbase = X + (((long)g.img * H + g.y0) * W + g.x0) * Cin;
+        const int ylo = g.y0 == 0 ? 1 : 0, yn = min(TH + 2, H - g.y0 + 1) - ylo;
+        const int xlo = g.x0 == 0 ? 1 : 0, xn = min(TW + 2, W - g.x0 + 1) - xlo;
 #pragma unroll
-            for (int q = 0; q < 12; ++q) dma16_asm_m0(xbase + sl_off[q], slab + (wave * 12 + q) * 1024);
-        } else {
-            const int ylo = g.y0 == 0 ? 1 : 0, yn = min(TH + 2, H - g.y0 + 1) - ylo;
-            const int xlo = g.x0 == 0 ? 1 : 0, xn = min(TW + 2, W - g.x0 + 1) - xlo;
-#pragma unroll
-            for (int q = 0; q < 12; ++q) {
-                const int row = (wave * 12 + q) * 16 + (lane >> 2);
-                const int hy = (row * 1821) >> 16, hx = row - hy * HP;
-                const bool ok = ((unsigned)(hy - ylo) < (unsigned)yn) & ((unsigned)(hx - xlo) < (unsigned)xn);
-                dma16_asm_m0(ok ? (const void*)(xbase + sl_off[q]) : (const void*)zero, slab + (wave * 12 + q) * 1024);
-            }
+        for (int q = 0; q < PPW; ++q) {
+            const int hy = sl_yx[q] >> 8, hx = sl_yx[q] & 255;
+            const bool ok = ((unsigned)(hy - ylo) < (unsigned)yn) & ((unsigned)(hx - xlo) < (unsigned)xn);
+            const int off = ((hy - 1) * W + (hx - 1)) * Cin + ((sl_chunk ^ ((hx >> 1) & (NCH - 1))) << 3);
+            dma16_asm_m0(ok ? (const void*)(xbase + off) : (const void*)zero, slab + (wave * PPW + q) * 1024);
         }
     };
 
-    // ---- prologue: the whole filter (all four waves: ncs x 9 taps x 4 pieces of 16 rows), the first slab ----------------------
-    {
-        const int n = lane >> 2;                                        // row inside a 16-row piece
-        const int npieces = ncs * 36;
-        for (int pi = wave; pi < npieces; pi += 4) {                    // uniform trip count per wave
-            const int cs = pi / 36, rem = pi - cs * 36, tap = rem >> 2, rp = rem & 3;
-            const int row = rp * 16 + n;
-            const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-            dma16_asm_m0(Wt + ((long)row * 9 + tap) * Cin + cs * CK + chunk * 8, w_addr + (cs * 9 + tap) * BTAP + rp * 1024);
-        }
-    }
-    TileGeo geo = geo_of(t_begin < t_end ? t_begin : 0);
-    if (slab_role && t_begin < t_end) dma_slab(geo, 0, smem_addr);
-    wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-
-    // ---- operand read addresses (as k_conv_bf16s, one output-channel wave column) ----------------------------------------------
-    const int wa0 = r * 64 + ((h ^ ((r >> 2) & 3)) << 4);
-    int pa[3], pcl[3];
+    // ---- operand read addresses: B fragment of tile row j (= 2*wp + tp + dy), halo column r + dx, k-step ks ---------------------
+    // LDS row p = j*HP + r + dx; chunk 2*ks + h at position (2*ks + h) ^ ((p >> 1) & (NCH-1))
+    // B-fragment lane addresses: halo column hx = r + dx, chunk 2*ks + h at position (2*ks + h) ^ ((hx >> 1) & (NCH-1)); the
+    // row term (tile row + dy) is a multiple of the 256-byte bank row pair and stays an immediate
+    // row term (tile row + dy) is a multiple of the 256-byte bank row pair and stays an immediate; ks enters as an XOR of bits 5-6
+    int fb[3];
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-        pa[dx] = (r + dx) * 64;
-        pcl[dx] = h ^ (((r + dx) >> 2) & 3);
-    }
-
-    f32x16 acc[TC][TP];
+    for (int dx = 0; dx < 3; ++dx) fb[dx] = (r + dx) * ROWB + ((h ^ (((r + dx) >> 1) & (NCH - 1))) << 4);
+    float ss[16], qq[16];
 #pragma unroll
-    for (int a = 0; a < TC; ++a)
+    for (int i = 0; i < 16; ++i) { ss[i] = 0.f; qq[i] = 0.f; }
+    int nvalid = 0;
+    const int out_lane = (TP * wp * W + r) * ldy + wc * 32 + 4 * h;      // elements, relative to the tile's first pixel
+
+    // ---- prologue: slabs of the first two tiles -----------------------------------------------------------------------------
+    const int last = max(t_end - 1, t_begin);
+    dma_slab(min(t_begin, last), smem_addr);
+    dma_slab(min(t_begin + 1, last), smem_addr + SLABB);
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int bi = (t - t_begin) % NBUF;
+        // this wave's pieces of slab t have landed: behind them in its queue sit at most the stores of tiles t-2 and t-1 and
+        // the pieces of slab t+1 (the prologue and the first tiles have fewer, a larger count only waits longer)
+        if (t == t_begin) wait_vm<PPW>();
+        else if (t == t_begin + 1) wait_vm<PPW + NST>();
+        else wait_vm<PPW + 2 * NST>();
+        __builtin_amdgcn_s_barrier();                                   // slab t complete for everyone; buffer of tile t-1 free
+        dma_slab(min(t + 2, last), smem_addr + ((bi + 2) % NBUF) * SLABB);
+
+        const char* const slab = smem + bi * SLABB + TP * wp * (HP * ROWB);      // this wave's first halo row
+        f32x16 acc[TP];
 #pragma unroll
         for (int b = 0; b < TP; ++b)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-    float ss[TC][16], qq[TC][16];
+            for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+        // A B fragment (halo row hr, column shift dx, k-step ks) serves the up to three output rows hr - dy of this wave, so a
+        // wave reads (TP+2)*3*NK fragments for its 9*NK*TP MFMAs — LDS bandwidth (128 B/clk/CU: one fragment read per MFMA
+        // from all four SIMDs is exactly the MFMA rate) stops being the co-limiter.  hr is the inner index, so consecutive
+        // MFMAs rotate through the accumulators.  Nothing but the instruction order hides the LDS latency within a wave: the
+        // read of fragment i+1 is pinned (sched_barrier) in front of the MFMAs of fragment i.
+        constexpr int NF = 3 * NK * (TP + 2);
+        auto frag = [&](int i) {                                         // lane base [dx] ^ ks bits + immediate row offset
+            const int hr = i % (TP + 2), dx = (i / (TP + 2)) / NK, ks = (i / (TP + 2)) % NK;
+            return lds_read16(slab + (fb[dx] ^ (ks << 5)) + hr * (HP * ROWB));
+        };
+        bf16x8 bq[2];
+        bq[0] = frag(0);
 #pragma unroll
-    for (int a = 0; a < TC; ++a)
+        for (int dk = 0; dk < 3 * NK; ++dk) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { ss[a][i] = 0.f; qq[a][i] = 0.f; }
-    int nvalid = 0;
-    const int out_lane = (2 * wp * W + r) * ldy + 4 * h;                // elements, relative to the tile's first pixel
-
-    int vis = 0;
-    for (int t = t_begin; t < t_end; ++t) {
-        const bool last_tile = t + 1 >= t_end;
-        for (int cs = 0; cs < ncs; ++cs, ++vis) {
-            const char* const slab = smem + (vis & 1) * SLAB_BYTES + 2 * wp * (HP * 64);
-            const unsigned slab_next = smem_addr + ((vis + 1) & 1) * SLAB_BYTES;
-            const bool last_cs = cs + 1 >= ncs;
-            if (slab_role) {                                            // the next slice's slab: this slice's 72 MFMAs cover its flight
-                if (!last_cs) dma_slab(geo, cs + 1, slab_next);
-                else if (!last_tile) dma_slab(geo_of(t + 1), 0, slab_next);
-            }
-            const char* const wsl = smem + 2 * SLAB_BYTES + cs * 9 * BTAP;
+            for (int hr = 0; hr < TP + 2; ++hr) {
+                const int i = dk * (TP + 2) + hr;
+                if (i + 1 < NF) bq[(i + 1) & 1] = frag(i + 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int dy = tap / 3, dx = tap % 3;
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    bf16x8 a[TC], b[TP];
-#pragma unroll
-                    for (int tc = 0; tc < TC; ++tc) a[tc] = lds_read16(wsl + tap * BTAP + ((wa0 ^ (kk << 5)) + tc * 32 * 64));
-#pragma unroll
-                    for (int tp = 0; tp < TP; ++tp) {
-                        const int hy = 2 * wp + tp + dy;
-                        const int pos = (pcl[dx] ^ (hy & 3) ^ (kk << 1)) << 4;
-                        b[tp] = lds_read16(slab + (tp + dy) * (HP * 64) + pa[dx] + pos);
-                    }
-#pragma unroll
-                    for (int tc = 0; tc < TC; ++tc)
-#pragma unroll
-                        for (int tp = 0; tp < TP; ++tp)
-                            acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tc], b[tp], acc[tc][tp], 0, 0, 0);
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int tp = hr - dy;
+                    if (tp >= 0 && tp < TP)
+                        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[dy * 3 + dk / NK][dk % NK], bq[i & 1], acc[tp], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (slab_role) wait_vm<0>();                               // next slab landed (and this wave's older stores)
-            __builtin_amdgcn_s_barrier();
         }
-        // ---- tile finished: bias, statistics, bf16 stores (range-checked buffer stores: ragged tiles, padded channels) --------
+        // ---- tile finished: bias, statistics, bf16 buffer stores (NST instructions, always issued) ----------------------------
         {
-            const int py0 = geo.y0 + 2 * wp, px = geo.x0 + r;
+            const TileGeo geo = geo_of(t);
+            const int py0 = geo.y0 + TP * wp, px = geo.x0 + r;
             const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(Y + (((long)geo.img * H + geo.y0) * W + geo.x0) * ldy), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
-            for (int tc = 0; tc < TC; ++tc)
+            for (int g = 0; g < 4; ++g) {
+                const int co = wc * 32 + 8 * g + 4 * h;
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (bias != nullptr && co < Cout) bv = *reinterpret_cast<const f32x4*>(bias + co);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co = tc * 32 + 8 * g + 4 * h;
-                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                    if (bias != nullptr && co < Cout) bv = *reinterpret_cast<const f32x4*>(bias + co);
+                for (int tp = 0; tp < TP; ++tp) {
+                    float v[4];
 #pragma unroll
-                    for (int tp = 0; tp < TP; ++tp) {
-                        float v[4];
+                    for (int j = 0; j < 4; ++j) v[j] = acc[tp][4 * g + j] + bv[j];
+                    const bool ok = (px < W) & (py0 + tp < H);
+                    if (STATS && ok) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { v[j] = acc[tc][tp][4 * g + j] + bv[j]; acc[tc][tp][4 * g + j] = 0.f; }
-                        const bool ok = (px < W) & (py0 + tp < H);
-                        if (STATS && ok) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { ss[tc][4 * g + j] += v[j]; qq[tc][4 * g + j] += v[j] * v[j]; }
-                        }
-                        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                        const unsigned off = (unsigned)(out_lane + tp * W * ldy + co - 4 * h) * 2u;
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, o), yr, (ok & (co < ldy)) ? off : 0x80000000u, 0, 0);
+                        for (int j = 0; j < 4; ++j) { ss[4 * g + j] += v[j]; qq[4 * g + j] += v[j] * v[j]; }
                     }
+                    const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    const unsigned off = (unsigned)(out_lane + tp * W * ldy + 8 * g) * 2u;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, o), yr, (ok & (co < ldy)) ? off : 0x80000000u, 0, 0);
                 }
+            }
             nvalid += min(TH, H - geo.y0) * min(TW, W - geo.x0);
-            if (!last_tile) geo = geo_of(t + 1);
         }
     }
     if (!STATS) return;
+    wait_vm<0>();                                                       // the redundant tail DMAs must not land in the scratch below
     __builtin_amdgcn_s_barrier();
     float* const red = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int tc = 0; tc < TC; ++tc)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ch = tc * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            const float2 v2 = {ss[tc][i], qq[tc][i]};
-            *reinterpret_cast<float2*>(red + ((size_t)ch * 128 + wp * 32 + r) * 2) = v2;
-        }
+    for (int i = 0; i < 16; ++i) {
+        const int ch = wc * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const float2 v2 = {ss[i], qq[i]};
+        *reinterpret_cast<float2*>(red + ((size_t)ch * (16 * NW) + wp * 32 + r) * 2) = v2;
+    }
     __syncthreads();
     {
-        const int chl = tid >> 2, sg = tid & 3;                          // 64 channels x 4 segments of 32 partials
-        const float2* p = reinterpret_cast<const float2*>(red) + (size_t)chl * 128 + sg * 32;
+        const int chl = tid / NW, sg = tid % NW;                         // 64 channels x NW segments of 16 partials
+        const float2* p = reinterpret_cast<const float2*>(red) + (size_t)chl * (16 * NW) + sg * 16;
         double S = 0.0, Q = 0.0;
 #pragma unroll 8
-        for (int i = 0; i < 32; ++i) { S += (double)p[i].x; Q += (double)p[i].y; }
-        S += __shfl_xor(S, 1, 64); Q += __shfl_xor(Q, 1, 64);
-        S += __shfl_xor(S, 2, 64); Q += __shfl_xor(Q, 2, 64);
+        for (int i = 0; i < 16; ++i) { S += (double)p[i].x; Q += (double)p[i].y; }
+#pragma unroll
+        for (int o = 1; o < NW; o <<= 1) { S += __shfl_xor(S, o, 64); Q += __shfl_xor(Q, o, 64); }
         if (sg == 0 && chl < Cout && nvalid > 0) {
             const double m2 = Q - S * S / (double)nvalid;
             stats[(size_t)strip * Cout + chl] = (float)S;
@@ -564,9 +559,9 @@ extern "C" int cvk_bf16s_rows_pad(int cout) {
     return cvk_cdiv(cout, bn) * bn;
 }
 
-// the 64 x 64 strip kernel (resident filter, one workgroup per CU) serves layers with Cin <= 64 and Cout <= 64; a strip is
+// the 64 x 64 strip kernel (filter in registers, one workgroup per CU) serves layers with Cin in {32, 64} and Cout <= 64; a strip is
 // ntiles / 256 tiles (one round of workgroups), at least 1
-static bool use_strip(int Cin, int Cout) { return Cin <= 64 && Cout <= 64; }
+static bool use_strip(int Cin, int Cout) { return (Cin == 32 || Cin == 64) && Cout <= 64; }
 static int strip_len_for(int ntiles) {
     int len = cvk_cdiv(ntiles, 256);
     return len < 1 ? 1 : len;
@@ -627,12 +622,18 @@ extern "C" int cvk_conv3x3_bf16s(const void* x, const void* w, const float* bias
         const int ntiles = (int)P;
         const int slen = strip_len_for(ntiles);
         const int nstrips = cvk_cdiv(ntiles, slen);
-        if (stats)
-            hipLaunchKernelGGL((k_conv_bf16s_strip<true>), dim3(nstrips), block, 0, s, (const __bf16*)x, (const __bf16*)w, bias, (__bf16*)y, stats, counts,
-                               H, W, Cin, Cout, ldy, tilesX, tilesY, ntiles, slen, nstrips);
-        else
-            hipLaunchKernelGGL((k_conv_bf16s_strip<false>), dim3(nstrips), block, 0, s, (const __bf16*)x, (const __bf16*)w, bias, (__bf16*)y, stats, counts,
-                               H, W, Cin, Cout, ldy, tilesX, tilesY, ntiles, slen, nstrips);
+        static const int strip_nw = getenv("CVK_STRIP_NW") ? atoi(getenv("CVK_STRIP_NW")) : 0;
+#define CVK_STRIP(NCS_, ST_, NW_) hipLaunchKernelGGL((k_conv_bf16s_strip<NCS_, ST_, NW_>), dim3(nstrips), dim3(64 * NW_), 0, s, (const __bf16*)x, \
+                           (const __bf16*)w, bias, (__bf16*)y, stats, counts, H, W, Cout, ldy, tilesX, tilesY, ntiles, slen, nstrips)
+        if (Cin == 64) {
+            if (stats) CVK_STRIP(2, true, 4);
+            else if (strip_nw == 4) CVK_STRIP(2, false, 4);
+            else CVK_STRIP(2, false, 8);
+        } else {
+            if (stats) { if (strip_nw == 4) CVK_STRIP(1, true, 4); else CVK_STRIP(1, true, 8); }
+            else       { if (strip_nw == 4) CVK_STRIP(1, false, 4); else CVK_STRIP(1, false, 8); }
+        }
+#undef CVK_STRIP
     } else if (bn == 128) { if (stats) CVK_BS_LAUNCH(128, true); else CVK_BS_LAUNCH(128, false); }
     else { if (stats) CVK_BS_LAUNCH(64, true); else CVK_BS_LAUNCH(64, false); }
 #undef CVK_BS_LAUNCH
