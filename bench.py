@@ -181,33 +181,35 @@ def main():
             step()
         torch.cuda.synchronize(dev)
         agg, mem = {}, {}
-        for name, work, e0, e1, unit in engine.PROF:
-            d = (agg if unit == "flop" else mem).setdefault(name, [0, 0.0, 0.0])
+        def executed_share(name):
+            # share of the algorithmic (direct-convolution) FLOPs a kernel really executes on the matrix pipe:
+            # F(4,3) Winograd 9 of 18, F(2,3) 12 of 18, direct kernels all of them (2-D F(4x4,3x3): 4.5 of 18 times the
+            # tile padding — the engine passes the executed count per call)
+            return 0.5 if "wino4" in name else ((2.0 / 3.0) if "wino" in name else 1.0)
+
+        for name, work, e0, e1, unit, executed in engine.PROF:
+            d = (agg if unit == "flop" else mem).setdefault(name, [0, 0.0, 0.0, 0.0])
             d[0] += 1; d[1] += work; d[2] += e0.elapsed_time(e1) * 1e-3
+            d[3] += executed if executed is not None else work * executed_share(name)
         engine.PROF = None
         kernels = {k: {"launches_per_step": v[0] // 3, "avg_us": round(v[2] / v[0] * 1e6, 1),
                        "tflops": round(v[1] / v[2] / 1e12, 2), "ms_per_step": round(v[2] / 3 * 1e3, 3)} for k, v in agg.items()}
         hbm_kernels = {k: {"launches_per_step": v[0] // 3, "ms_per_step": round(v[2] / 3 * 1e3, 3),
                            "algorithmic_GBps": round(v[1] / v[2] / 1e9, 1), "frac_of_8TBps": round(v[1] / v[2] / PEAK_HBM_BPS, 3)}
                        for k, v in mem.items()}
-        def executed_share(name):
-            # share of the algorithmic (direct-convolution) FLOPs a kernel really executes on the matrix pipe:
-            # F(4,3) Winograd 9 of 18, F(2,3) 12 of 18, direct kernels all of them
-            return 0.5 if "wino4" in name else ((2.0 / 3.0) if "wino" in name else 1.0)
-
         def peak_of(name):
             return PEAK_BF16_MFMA_TFLOPS if ("bf16" in name and "split" not in name) else PEAK_F32_MFMA_TFLOPS
 
         for k, v in agg.items():
-            kernels[k]["executed_frac_of_peak"] = round(v[1] / v[2] / 1e12 * executed_share(k) / peak_of(k), 4)
+            kernels[k]["executed_frac_of_peak"] = round(v[3] / v[2] / 1e12 / peak_of(k), 4)
         dom = max(agg.items(), key=lambda kv: kv[1][2])
-        cnt, fl, sec = dom[1]
+        cnt, fl, sec, exe = dom[1]
         alg = fl / sec / 1e12                       # algorithmic TFLOP/s (SURVEY.md §8d numerator)
-        executed = executed_share(dom[0])
+        executed = exe / fl
         peak = peak_of(dom[0])
-        ach = alg * executed                        # FLOPs the MFMA pipe really executes per second: a hardware fraction <= 1
+        ach = exe / sec / 1e12                      # FLOPs the MFMA pipe really executes per second: a hardware fraction <= 1
         allf = sum(v[1] for v in agg.values()); alls = sum(v[2] for v in agg.values())
-        alle = sum(v[1] * executed_share(k) for k, v in agg.items())
+        alle = sum(v[3] for v in agg.values())
         traffic = None
         pat = "r*_pmc_hbm_traffic_bf16.json" if "bf16" in dom[0] else "r*_pmc_hbm_traffic.json"
         tp = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))[-1:]

@@ -109,6 +109,30 @@ int cvk_conv3x3_wino4_gemm(const float* x, const float* U, float* Mo, int N, int
 int cvk_wino4_output(const float* Mo, const float* bias, float* y, float* stats, int N, int H, int W, int Cout, int ldy,
                      int ksplit, void* stream);
 
+/* 2-D Winograd F(4x4,3x3) for channel-heavy layers (csrc/wino2d.hip): forward / data-grad of nn.Conv2d(k=3,pad=1)
+ * (reference models/unet.py:11, bwd of train.py:131) as 36 batched GEMMs over T = cvk_w2d_tiles(N,H,W) 4x4 output tiles.
+ *   U = cvk_w2d_weight_transform(w)        float[36][Cout][Cin] from w [Cout][3][3][Cin] (data-grad: from the
+ *                                          cvk_pack_weight_dgrad pack, roles of Cin / Cout exchanged)
+ *   cvk_conv3x3_w2d(x, U, ...)             input transform -> GEMMs -> output transform + bias; x dense [N,H,W,Cin],
+ *                                          Cin % 32 == 0, Cout % 4 == 0, Cout >= 64; workspace of
+ *                                          cvk_conv3x3_w2d_workspace_bytes(N,H,W,Cin,Cout) bytes.
+ *   stats/counts (both or neither): BatchNorm statistics partials float[2][P][Cout] (sum, M2 about the partial mean) and
+ *   float[P] pixel counts, P = cvk_w2d_stat_partials(N,H,W) -> cvk_bn_finalize_counts. */
+int cvk_w2d_tiles(int N, int H, int W);
+int cvk_w2d_stat_partials(int N, int H, int W);
+size_t cvk_conv3x3_w2d_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int cvk_w2d_weight_transform(const float* w, float* U, int Cout, int Cin, void* stream);
+int cvk_conv3x3_w2d(const float* x, const float* U, const float* bias, float* y, float* stats, float* counts, int N, int H,
+                    int W, int Cin, int Cout, int ldy, void* workspace, size_t workspace_bytes, void* stream);
+/* the three passes of cvk_conv3x3_w2d, callable (and timed) one by one: V float[36][T][Cin], Mo float[f][36][T][Cout] with
+ * f = cvk_w2d_ksplit(T, Cin, Cout) K-range planes (the tiles of the last partial round of workgroups are split in K; the
+ * output pass adds the planes in a fixed order and therefore takes Cin as well) */
+int cvk_w2d_ksplit(int T, int Cin, int Cout);
+int cvk_w2d_input_transform(const float* x, float* V, int N, int H, int W, int Cin, void* stream);
+int cvk_w2d_gemm(const float* V, const float* U, float* Mo, int T, int Cin, int Cout, void* stream);
+int cvk_w2d_output(const float* Mo, const float* bias, float* y, float* stats, float* counts, int N, int H, int W, int Cin,
+                   int Cout, int ldy, void* stream);
+
 /* weight-grad through the transposed F(4,3) (contract of cvk_conv3x3_wgrad; the workspace also holds the transformed
  * output-gradient planes E1..E4, float[4][N*H*ceil(W/4)][ld_dy], hence the extra ld_dy argument of the size query) */
 size_t cvk_conv3x3_wgrad_wino4_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout, int ld_dy);

@@ -51,6 +51,15 @@ SIGNATURES = {
     "cvk_conv3x3_wino4_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
     "cvk_conv3x3_wino4_gemm": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_wino4_output": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_w2d_tiles": (c_int, [c_int, c_int, c_int]),
+    "cvk_w2d_stat_partials": (c_int, [c_int, c_int, c_int]),
+    "cvk_conv3x3_w2d_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
+    "cvk_w2d_weight_transform": (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
+    "cvk_w2d_input_transform": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_w2d_gemm": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "cvk_w2d_ksplit": (c_int, [c_int, c_int, c_int]),
+    "cvk_w2d_output": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_conv3x3_w2d": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
     "cvk_conv3x3_wgrad_wino4_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "cvk_conv3x3_wgrad_wino4": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
     "cvk_bn_bwd_e_blocks": (c_int, [c_int, c_int, c_int]),

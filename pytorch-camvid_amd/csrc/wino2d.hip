@@ -1,0 +1,415 @@
+// libcvk — 2-D Winograd F(4x4, 3x3) for the deep fp32 layers (>= 256 channels on both sides at <= 90 x 120 pixels).
+//
+// Replaces: nn.Conv2d(k=3, pad=1) forward and data-grad of BasicConv2d (reference models/unet.py:5-17, bwd of train.py:131)
+// on the layers where 36 transform-domain GEMMs  M_xi[tiles][Cout] = V_xi[tiles][Cin] * U_xi[Cout][Cin]^T  beat the 1-D
+// F(4,3) kernels of wino4.hip:  2.25 multiplies per output and input channel instead of 4.5 (direct: 9).  The price is
+// three HBM passes (input transform 1 read + 2.25 writes, product planes 2.25 writes + 2.25 reads, output 1 write), which
+// is why only channel-heavy layers take this path (cost model: engine.py wino2d_pays).
+//   V = B^T d B   (6 x 6 input tile, zero padded)      U = G g G^T      y = A^T [ sum_ci U (.) V ] A   (4 x 4 outputs)
+// with the points 0, +-1, +-2, inf of wino4.hip.  Rounding: 2-3e-6 relative L2 per layer in fp32 (1-D F(4,3): 6-8e-7, direct
+// 2.5e-7; tests/test_gpu_blocks.py derives its tolerance from a numpy restatement of exactly these transforms).
+//
+// The GEMM has NO address arithmetic in its K loop: both operands are K-contiguous rows, staged by LDS-DMA
+// (global_load_lds_dwordx4, 1 KiB per wave instruction) into a ring of three stages, so the vector ALU — which shares issue
+// slots with the fp32 MFMA (tools/micro/mfma_peak.hip) — only runs ds_reads.
+#include "cvk_common.h"
+#include "lds_dma.h"
+
+namespace {
+
+constexpr int W2_BN = 128;          // output columns (channels) per workgroup
+constexpr int W2_BK = 32;           // K slice: 32 floats = 128-byte LDS rows
+constexpr int W2_TB = 16;           // tiles per statistics partial / output-transform block
+
+// ---- 1-D transforms (applied along rows, then along columns) ---------------------------------------------------------------
+// B^T d
+template <typename T>
+__device__ __forceinline__ void w2_bt(const T* d, T* v) {
+    const T a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+    v[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    v[1] = a + b;
+    v[2] = a - b;
+    v[3] = c + e;
+    v[4] = c - e;
+    v[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+// A^T m
+template <typename T>
+__device__ __forceinline__ void w2_at(const T* m, T* y) {
+    const T s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    y[0] = m[0] + s12 + s34;
+    y[1] = d12 + 2.f * d34;
+    y[2] = s12 + 4.f * s34;
+    y[3] = d12 + 8.f * d34 + m[5];
+}
+// G g
+__device__ __forceinline__ void w2_g(const float* g, float* u) {
+    const float t = g[0] + g[2];
+    u[0] = 0.25f * g[0];
+    u[1] = (-1.f / 6.f) * (t + g[1]);
+    u[2] = (-1.f / 6.f) * (t - g[1]);
+    const float q = (1.f / 24.f) * g[0] + (1.f / 6.f) * g[2];
+    u[3] = q + (1.f / 12.f) * g[1];
+    u[4] = q - (1.f / 12.f) * g[1];
+    u[5] = g[2];
+}
+
+// ---- input transform: x [N,H,W,C] -> V [36][T][C], T = N * ceil(H/4) * ceil(W/4); one thread = one tile x 4 channels ----------
+__global__ __launch_bounds__(256) void k_w2d_input(const float* __restrict__ X, float* __restrict__ V, int H, int W, int C,
+                                                  int th, int tw, int T) {
+    const int cvn = C >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int t = (int)(idx / cvn), c = (int)(idx % cvn) * 4;
+    if (t >= T) return;
+    const int n = t / (th * tw), r = t - n * th * tw, ty = r / tw, tx = r - ty * tw;
+    const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+    const float* const xb = X + (size_t)n * H * W * C + c;
+    f32x4 w[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        f32x4 d[6], v[6];
+        const int xx = x0 + j;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int yy = y0 + i;
+            const bool ok = ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            d[i] = ok ? *reinterpret_cast<const f32x4*>(xb + ((size_t)yy * W + xx) * C) : zero;
+        }
+        w2_bt(d, v);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i][j] = v[i];
+    }
+    const size_t plane = (size_t)T * C;
+    float* const vb = V + (size_t)t * C + c;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        f32x4 v[6];
+        w2_bt(w[i], v);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(vb + (size_t)(i * 6 + j) * plane) = v[j];
+    }
+}
+
+// ---- weight transform: w [Co][3][3][Ci] -> U [36][Co][Ci]; one thread = one (co, ci) --------------------------------------------
+__global__ __launch_bounds__(256) void k_w2d_weight(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci) {
+    const size_t total = (size_t)Co * Ci;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int ci = (int)(i % Ci);
+        const size_t co = i / Ci;
+        float g[3][3], a[6][3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) g[k / 3][k % 3] = Wt[(co * 9 + k) * Ci + ci];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {                 // along ky
+            const float col[3] = {g[0][kx], g[1][kx], g[2][kx]};
+            float u[6];
+            w2_g(col, u);
+#pragma unroll
+            for (int p = 0; p < 6; ++p) a[p][kx] = u[p];
+        }
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {                    // along kx
+            float u[6];
+            w2_g(a[p], u);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) U[(size_t)(p * 6 + q) * total + i] = u[q];
+        }
+    }
+}
+
+// ---- batched GEMM  D_xi[T][ldd] = A_xi[T][K] * B_xi[Nn][K]^T,  xi = 0..35 ------------------------------------------------------
+// Workgroup: BM x 128 tile, BM/32 waves in a (BM/64) x 2 grid of 64 x 64 wave tiles (2 x 2 MFMA 32x32x2 blocks, 64
+// accumulator registers).  LDS: NSTG stages of (BM + 128) rows x 128 bytes; 16-byte chunk c of row r sits at position
+// c ^ ((r >> 1) & 7) (applied through the DMA source address), so the sixteen rows of a ds_read_b128 phase hit sixteen
+// different 16-byte bank groups.  A lane's b128 holds k = 8s + 4h + {0..3} of its row: four MFMAs per read, the same K
+// permutation on both operands.  Per K slice: counted wait for the slice's own DMA pieces, one barrier, DMA of slice
+// + NSTG - 1.  <256, 3>: 8 waves, 144 KiB, one workgroup per CU; <128, 2>: 4 waves, 64 KiB, two per CU (few-tile layers).
+// Tail: the tiles of the last, partial round of workgroups (ids >= split_start) are cut into f K-ranges, one workgroup
+// each; range p writes plane p of D (plane stride part_stride) and the output transform adds the planes in a fixed order.
+template <int BM, int NSTG>
+__global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void k_w2d_gemm(const float* __restrict__ A, const float* __restrict__ B,
+                                                                       float* __restrict__ D, int T, int Nn, int K, int ldd,
+                                                                       int tilesM, int tilesN, int split_start, int f,
+                                                                       size_t part_stride) {
+    constexpr int NW = BM / 32, ROWS = BM + W2_BN, PIECES = ROWS / 8, PPW = PIECES / NW, STAGE = ROWS * 128;
+    static_assert(PIECES % NW == 0 && NSTG * STAGE * (BM == 256 ? 1 : 2) <= 160 * 1024 && (NSTG == 2 || NSTG == 3), "stage geometry");
+    __shared__ __attribute__((aligned(1024))) char smem[NSTG * STAGE];
+    const unsigned smem_addr = cvk_lds_addr(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // full-round workgroups and tail workgroups are dealt to the XCDs separately (both in contiguous logical chunks)
+    const int nK = K / W2_BK;
+    int id, kb = 0, ke = nK;
+    if ((int)blockIdx.x < split_start) {
+        id = cvk_xcd_remap(blockIdx.x, split_start);
+    } else {
+        const int q = cvk_xcd_remap(blockIdx.x - split_start, gridDim.x - split_start);
+        const int part = q % f;
+        id = split_start + q / f;
+        kb = part * nK / f;
+        ke = (part + 1) * nK / f;
+        D += (size_t)part * part_stride;
+    }
+    const int tn = id % tilesN, tm = (id / tilesN) % tilesM, xi = id / (tilesN * tilesM);
+    A += (size_t)xi * T * K;
+    B += (size_t)xi * Nn * K;
+    D += (size_t)xi * T * ldd;
+    const int row0 = tm * BM, col0 = tn * W2_BN;
+
+    // DMA mapping: piece wave*PPW + q = LDS rows 8*piece + lane/8; rows < BM are A rows, the rest B rows (clamped: rows beyond
+    // the matrix re-read its last row, their products are never stored)
+    const float* src[PPW];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int row = (wave * PPW + q) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        src[q] = (row < BM ? A + (size_t)min(row0 + row, T - 1) * K : B + (size_t)min(col0 + row - BM, Nn - 1) * K) + chunk * 4;
+    }
+    auto issue = [&](int ks, int buf) {
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) cvk_dma16(src[q] + ks * W2_BK, smem_addr + buf * STAGE + (wave * PPW + q) * 1024);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment addresses: row block base + lane row r, chunk (2s + h) ^ ((r >> 1) & 7); s enters as an XOR of bits 5-6
+    const int lane_off = r * 128 + ((h ^ ((r >> 1) & 7)) << 4);
+    const int a_off = wm * 64 * 128 + lane_off, b_off = (BM + wn * 64) * 128 + lane_off;
+
+#pragma unroll
+    for (int d = 0; d < NSTG - 1; ++d) issue(min(kb + d, ke - 1), d);
+    int buf = 0;
+    for (int ks = kb; ks < ke; ++ks) {
+        cvk_wait_vm<(NSTG - 2) * PPW>();                  // this wave's pieces of slice ks (later slices may be in flight)
+        __builtin_amdgcn_s_barrier();                     // slice ks complete; stage of slice ks-1 free
+        issue(min(ks + NSTG - 1, ke - 1), buf == 0 ? NSTG - 1 : buf - 1);      // (buf + NSTG - 1) % NSTG
+        const char* const st = smem + buf * STAGE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(st + ((a_off + i * 32 * 128) ^ (s << 5)));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4*>(st + ((b_off + j * 32 * 128) ^ (s << 5)));
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+        }
+        buf = buf == NSTG - 1 ? 0 : buf + 1;
+    }
+    cvk_wait_vm<0>();                                     // the redundant tail DMAs land before the workgroup's LDS is released
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col0 + wn * 64 + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = row0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < T && col < Nn) D[(size_t)row * ldd + col] = acc[i][j][e];
+            }
+        }
+}
+
+// ---- output transform: M [36][T][ldm] -> y [N,H,W,ldy] (+bias, + BatchNorm statistics partials with pixel counts) ----------------
+// block = W2_TB tiles x CH channels (CH = 4 * cvn <= 256); thread = one channel vector, tiles pl apart
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_w2d_output(const float* __restrict__ Mo, int ldm, const float* __restrict__ bias,
+                                                   float* __restrict__ Y, int ldy, float* __restrict__ stats,
+                                                   float* __restrict__ counts, int P, int H, int W, int th, int tw, int T,
+                                                   int Cout, int cvn, int BM, int tmn, int tilesN, int split_start, int f) {
+    __shared__ float red[2][1024];
+    const int t = threadIdx.x;
+    const int pl = 256 / cvn, cv = t % cvn, lanep = t / cvn;
+    const int c = (blockIdx.y * cvn + cv) * 4;
+    const bool cok = c < Cout;                          // Cout % 4 == 0 (checked by the host)
+    f32x4 sh = {0.f, 0.f, 0.f, 0.f};
+    if (cok && bias != nullptr) sh = *reinterpret_cast<const f32x4*>(bias + c);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    const size_t plane = (size_t)T * ldm;
+    const int tile_end = min(T, (int)(blockIdx.x + 1) * W2_TB);
+    for (int tile = blockIdx.x * W2_TB + lanep; tile < tile_end && cok; tile += pl) {
+        const int n = tile / (th * tw), rr = tile - n * th * tw, ty = rr / tw, tx = rr - ty * tw;
+        const float* const mp = Mo + (size_t)tile * ldm + c;
+        // GEMM tile of plane xi: xi * tmn + (tile / BM) * tilesN + c / 128; ids >= split_start carry f K-range planes
+        const int xi0 = f > 1 ? (split_start - ((tile / BM) * tilesN + c / W2_BN) + tmn - 1) / tmn : 36;
+        f32x4 z[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            f32x4 m[6], y4[4];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                m[i] = *reinterpret_cast<const f32x4*>(mp + (size_t)(i * 6 + j) * plane);
+                if (i * 6 + j >= xi0)
+                    for (int k = 1; k < f; ++k) m[i] += *reinterpret_cast<const f32x4*>(mp + (size_t)(k * 36 + i * 6 + j) * plane);
+            }
+            w2_at(m, y4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[i][j] = y4[i];
+        }
+        const int yb = 4 * ty, xb = 4 * tx;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 o[4];
+            w2_at(z[i], o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (yb + i < H && xb + j < W) {
+                    *reinterpret_cast<f32x4*>(Y + ((size_t)(n * H + yb + i) * W + xb + j) * ldy + c) = o[j] + sh;
+                    if (STATS) { s1 += o[j]; s2 += o[j] * o[j]; }
+                }
+            }
+        }
+    }
+    if (!STATS) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[0][t * 4 + j] = s1[j];
+        red[1][t * 4 + j] = s2[j];
+    }
+    __syncthreads();
+    if (t < cvn && c < Cout) {
+        int cnt = 0;
+        for (int tile = blockIdx.x * W2_TB; tile < tile_end; ++tile) {
+            const int rr = tile % (th * tw), ty = rr / tw, tx = rr - ty * tw;
+            cnt += min(4, H - 4 * ty) * min(4, W - 4 * tx);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.f, b = 0.f;
+            for (int p = 0; p < pl; ++p) {
+                a += red[0][(p * cvn + t) * 4 + j];
+                b += red[1][(p * cvn + t) * 4 + j];
+            }
+            const float m2 = b - a * a / (float)cnt;     // about the partial mean; sums exclude the bias (shift invariance)
+            stats[(size_t)blockIdx.x * Cout + c + j] = a + (float)cnt * sh[j];
+            stats[(size_t)(P + blockIdx.x) * Cout + c + j] = m2 > 0.f ? m2 : 0.f;
+        }
+        if (t == 0 && blockIdx.y == 0) counts[blockIdx.x] = (float)cnt;
+    }
+}
+
+inline int w2_tiles(int N, int H, int W) { return N * ((H + 3) / 4) * ((W + 3) / 4); }
+
+}  // namespace
+
+extern "C" int cvk_w2d_tiles(int N, int H, int W) { return (N > 0 && H > 0 && W > 0) ? w2_tiles(N, H, W) : 0; }
+
+extern "C" int cvk_w2d_stat_partials(int N, int H, int W) { return (N > 0 && H > 0 && W > 0) ? cvk_cdiv(w2_tiles(N, H, W), W2_TB) : 0; }
+
+// How the 36 GEMMs are cut into workgroups: tile height, grid, and the K split of the last partial round.
+struct W2Plan { int BM, tilesM, tilesN, NT, split_start, f; };
+static W2Plan plan_w2d(int T, int Cin, int Cout) {
+    W2Plan p;
+    const double pad256 = (double)cvk_cdiv(T, 256) * 256 / T, pad128 = (double)cvk_cdiv(T, 128) * 128 / T;
+    p.BM = (T <= 128 || pad256 > 1.1 * pad128) ? 128 : 256;
+    p.tilesM = cvk_cdiv(T, p.BM);
+    p.tilesN = cvk_cdiv(Cout, W2_BN);
+    p.NT = 36 * p.tilesM * p.tilesN;
+    const int slots = p.BM == 256 ? 256 : 512;            // resident workgroups
+    const int nK = Cin / W2_BK;
+    const int full = p.NT / slots * slots, R = p.NT - full;
+    p.f = 1;
+    if (R > 0) {
+        p.f = slots / R < 4 ? slots / R : 4;
+        if (p.f > nK / 4) p.f = nK / 4;
+        if (p.f < 1) p.f = 1;
+    }
+    p.split_start = p.f > 1 ? full : p.NT;
+    return p;
+}
+
+extern "C" int cvk_w2d_ksplit(int T, int Cin, int Cout) {
+    if (T <= 0 || Cin < 32 || Cout <= 0) return 0;
+    return plan_w2d(T, Cin, Cout).f;
+}
+
+extern "C" size_t cvk_conv3x3_w2d_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin < 32 || Cout <= 0) return 0;
+    const int T = w2_tiles(N, H, W);
+    return (size_t)36 * T * ((size_t)Cin + (size_t)plan_w2d(T, Cin, Cout).f * Cout) * sizeof(float);
+}
+
+extern "C" int cvk_w2d_weight_transform(const float* w, float* U, int Cout, int Cin, void* stream) {
+    CVK_CHECK_ARG(w && U && Cout > 0 && Cin > 0, "cvk_w2d_weight_transform: bad arguments");
+    const size_t total = (size_t)Cout * Cin;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(k_w2d_weight, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
+    CVK_LAUNCH_RETURN("cvk_w2d_weight_transform");
+}
+
+extern "C" int cvk_w2d_input_transform(const float* x, float* V, int N, int H, int W, int Cin, void* stream) {
+    CVK_CHECK_ARG(x && V && N > 0 && H > 0 && W > 0 && Cin >= 4 && Cin % 4 == 0, "cvk_w2d_input_transform: bad arguments");
+    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(V), "cvk_w2d_input_transform: pointers must be 16-byte aligned");
+    const int th = (H + 3) / 4, tw = (W + 3) / 4, T = N * th * tw;
+    const long threads = (long)T * (Cin / 4);
+    hipLaunchKernelGGL(k_w2d_input, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, V, H, W, Cin, th, tw, T);
+    CVK_LAUNCH_RETURN("cvk_w2d_input_transform");
+}
+
+extern "C" int cvk_w2d_gemm(const float* V, const float* U, float* Mo, int T, int Cin, int Cout, void* stream) {
+    CVK_CHECK_ARG(V && U && Mo && T > 0, "cvk_w2d_gemm: bad arguments");
+    CVK_CHECK_ARG(Cin >= 32 && Cin % 32 == 0 && Cout > 0, "cvk_w2d_gemm: Cin=%d must be a multiple of 32", Cin);
+    CVK_CHECK_ARG(cvk_aligned16(V) && cvk_aligned16(U) && cvk_aligned16(Mo), "cvk_w2d_gemm: pointers must be 16-byte aligned");
+    CVK_CHECK_ARG((long)T * 36 * (Cin > Cout ? Cin : Cout) < (1L << 40), "cvk_w2d_gemm: tensor too large");
+    const W2Plan p = plan_w2d(T, Cin, Cout);
+    const dim3 grid(p.split_start + (p.NT - p.split_start) * p.f);
+    const size_t part_stride = (size_t)36 * T * Cout;
+    hipStream_t s = (hipStream_t)stream;
+    if (p.BM == 256)
+        hipLaunchKernelGGL((k_w2d_gemm<256, 3>), grid, dim3(512), 0, s, V, U, Mo, T, Cout, Cin, Cout, p.tilesM, p.tilesN, p.split_start, p.f, part_stride);
+    else
+        hipLaunchKernelGGL((k_w2d_gemm<128, 2>), grid, dim3(256), 0, s, V, U, Mo, T, Cout, Cin, Cout, p.tilesM, p.tilesN, p.split_start, p.f, part_stride);
+    CVK_LAUNCH_RETURN("cvk_w2d_gemm");
+}
+
+extern "C" int cvk_w2d_output(const float* Mo, const float* bias, float* y, float* stats, float* counts, int N, int H, int W,
+                              int Cin, int Cout, int ldy, void* stream) {
+    CVK_CHECK_ARG(Mo && y && N > 0 && H > 0 && W > 0, "cvk_w2d_output: bad arguments");
+    CVK_CHECK_ARG(Cout >= 64 && Cout % 4 == 0 && ldy >= Cout && ldy % 4 == 0, "cvk_w2d_output: needs Cout %% 4 == 0, Cout >= 64 (got %d)", Cout);
+    CVK_CHECK_ARG((stats == nullptr) == (counts == nullptr), "cvk_w2d_output: stats and counts go together");
+    CVK_CHECK_ARG(cvk_aligned16(Mo) && cvk_aligned16(y), "cvk_w2d_output: pointers must be 16-byte aligned");
+    const int th = (H + 3) / 4, tw = (W + 3) / 4, T = N * th * tw;
+    CVK_CHECK_ARG(Cin >= 32 && Cin % 32 == 0, "cvk_w2d_output: Cin (the GEMM depth, which fixes the K split of the planes) must be a multiple of 32");
+    const int cvn = Cout / 4 >= 64 ? 64 : (Cout / 4 >= 32 ? 32 : 16);
+    const int P = cvk_cdiv(T, W2_TB);
+    const W2Plan p = plan_w2d(T, Cin, Cout);
+    dim3 grid(P, cvk_cdiv(Cout / 4, cvn));
+    hipStream_t s = (hipStream_t)stream;
+    if (stats)
+        hipLaunchKernelGGL(k_w2d_output<true>, grid, dim3(256), 0, s, Mo, Cout, bias, y, ldy, stats, counts, P, H, W, th, tw, T, Cout, cvn,
+                           p.BM, p.tilesM * p.tilesN, p.tilesN, p.split_start, p.f);
+    else
+        hipLaunchKernelGGL(k_w2d_output<false>, grid, dim3(256), 0, s, Mo, Cout, bias, y, ldy, stats, counts, P, H, W, th, tw, T, Cout, cvn,
+                           p.BM, p.tilesM * p.tilesN, p.tilesN, p.split_start, p.f);
+    CVK_LAUNCH_RETURN("cvk_w2d_output");
+}
+
+extern "C" int cvk_conv3x3_w2d(const float* x, const float* U, const float* bias, float* y, float* stats, float* counts,
+                               int N, int H, int W, int Cin, int Cout, int ldy, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    CVK_CHECK_ARG(workspace && N > 0 && H > 0 && W > 0, "cvk_conv3x3_w2d: bad arguments");
+    CVK_CHECK_ARG(cvk_aligned16(workspace) && workspace_bytes >= cvk_conv3x3_w2d_workspace_bytes(N, H, W, Cin, Cout),
+                  "cvk_conv3x3_w2d: workspace too small or misaligned");
+    const int T = w2_tiles(N, H, W);
+    float* const V = (float*)workspace;
+    float* const Mo = V + (size_t)36 * T * Cin;
+    int rc = cvk_w2d_input_transform(x, V, N, H, W, Cin, stream);
+    if (rc == CVK_OK) rc = cvk_w2d_gemm(V, U, Mo, T, Cin, Cout, stream);
+    if (rc == CVK_OK) rc = cvk_w2d_output(Mo, bias, y, stats, counts, N, H, W, Cin, Cout, ldy, stream);
+    return rc;
+}

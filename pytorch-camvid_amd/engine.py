@@ -121,12 +121,48 @@ def wino4_pays(N, H, W, k_ch, n_cols):
     return -(-(N * H * ((W + 1) // 2)) // 128) * tn * 4 > 256
 
 
+# 2-D F(4x4,3x3) (csrc/wino2d.hip) for the channel-heavy layers: 2.25 multiplies per output and input channel instead of
+# the 4.5 of the 1-D kernels, paid for with three HBM passes over transform-domain planes.  "0": off, "1": where it pays,
+# "always": every eligible layer (tests).
+WINO2D_DEFAULT = {"0": False, "1": True, "always": "always"}[os.environ.get("CVK_WINO2D", "1")]
+
+
+def wino2d_ok(k_ch, cout, ldy):
+    return k_ch % 32 == 0 and cout % 4 == 0 and cout >= 64 and ldy % 4 == 0
+
+
+def wino2d_pays(N, H, W, k_ch, cout):
+    """Measured at the UNet batch-8 shapes (tools/bench_conv.py wino4 w2d [--rev]): the 36 batched GEMMs + transforms beat
+    F(4,3) + its output pass by 13-31 % once Cin*Cout >= 256*256 (256->256 @ 90x120 ... 1024->512 @ 45x60), by 10-13 % for
+    128<->256 channels at 180x240, and lose below that (the transform passes cost more than the saved multiplies)."""
+    T = N * ((H + 3) // 4) * ((W + 3) // 4)
+    return T >= 256 and (k_ch * cout >= 65536 or (k_ch * cout >= 32768 and T >= 16384))
+
+
 def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what="", dgrad_of=None):
     """y[N,H,W,ldy] = conv3x3(x[N,H,W,k_ch], w[cout][3][3][k_ch]) (+bias, +BN statistics partials at sp) through the 1-D
     Winograd kernels: weight transform -> implicit GEMMs M_xi -> output transform.  F(4,3) when R.wino4, else F(2,3).
     Data-grad: `w` is a callable returning the rotated/transposed pack (built only if a kernel needs it) and
-    dgrad_of = (forward weights [Cout_f][3][3][Cin_f], Cout_f, Cin_f) lets F(4,3) transform straight from them."""
+    dgrad_of = (forward weights [Cout_f][3][3][Cin_f], Cout_f, Cin_f) lets F(4,3) transform straight from them.
+    Returns None, or (P, counts pointer) when the statistics partials at sp carry explicit pixel counts (2-D path:
+    P = cvk_w2d_stat_partials partials of [sum | M2] followed by the counts -> cvk_bn_finalize_counts)."""
     M = N * H * W
+    if wino2d_ok(k_ch, cout, ldy) and (R.wino2d == "always" or (R.wino2d and wino2d_pays(N, H, W, k_ch, cout))):
+        w = w() if callable(w) else w
+        U = _empty(36 * cout * k_ch, x.device)
+        check(lib.cvk_w2d_weight_transform(w.data_ptr(), U.data_ptr(), cout, k_ch, s), "cvk_w2d_weight_transform")
+        ws = R.workspace(lib.cvk_conv3x3_w2d_workspace_bytes(N, H, W, k_ch, cout), x.device)
+        T = lib.cvk_w2d_tiles(N, H, W)
+        V, Mo = ws.data_ptr(), ws.data_ptr() + 4 * 36 * T * k_ch
+        P2 = lib.cvk_w2d_stat_partials(N, H, W)
+        cnt = sp + 4 * 2 * P2 * cout if sp is not None else None
+        _timed(R, "k_w2d_input", 4.0 * (M + 36 * T) * k_ch, lambda: check(
+            lib.cvk_w2d_input_transform(x.data_ptr(), V, N, H, W, k_ch, s), "cvk_w2d_input_transform" + what), "byte")
+        _timed(R, "k_w2d_gemm", flops, lambda: check(lib.cvk_w2d_gemm(V, U.data_ptr(), Mo, T, k_ch, cout, s), "cvk_w2d_gemm" + what),
+               executed=72.0 * T * k_ch * cout)       # 36 GEMMs of T x k_ch x cout really run on the matrix pipe
+        _timed(R, "k_w2d_output", 4.0 * (36 * T + M) * cout, lambda: check(
+            lib.cvk_w2d_output(Mo, bias, y.data_ptr(), sp, cnt, N, H, W, k_ch, cout, ldy, s), "cvk_w2d_output" + what), "byte")
+        return (P2, cnt) if sp is not None else None
     if R.wino4 == "always" or (R.wino4 and wino4_pays(N, H, W, k_ch, ldy)):
         U = _empty(6 * cout * 3 * k_ch, x.device)
         if dgrad_of is not None and dgrad_of[1] == k_ch and dgrad_of[2] == cout:       # no channel padding on either side
@@ -169,20 +205,21 @@ def conv_kernel_name(kind, n_cols, k_ch=32):
     return f"k_conv3x3_igemm<{t}, {'true' if kind == 'fwd' else 'false'}, {'true' if k_ch % 32 == 0 else 'false'}>"
 
 
-PROF = None     # bench.py sets this to a list: every _timed call then appends (kernel name, work, start event, end event, unit)
+PROF = None     # bench.py sets this to a list: every _timed call then appends (kernel name, work, start event, end event, unit, executed)
 
 
-def _timed(R, name, work, fn, unit="flop"):
+def _timed(R, name, work, fn, unit="flop", executed=None):
     """Run fn(); when a profile list is attached (bench.py sets engine.PROF), bracket it with HIP events on the launch
     stream.  `work` is the ALGORITHMIC work of the call: FLOPs for the conv kernels, HBM bytes (each input read once,
-    each output written once, at the storage dtype) for the memory-bound kernels."""
+    each output written once, at the storage dtype) for the memory-bound kernels.  `executed`: FLOPs the kernel really
+    issues to the matrix pipe when that is not a fixed share of `work` (bench.py knows the fixed shares by kernel name)."""
     if PROF is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = fn()
     e1.record()
-    PROF.append((name, work, e0, e1, unit))
+    PROF.append((name, work, e0, e1, unit, executed))
     return r
 
 
@@ -222,7 +259,7 @@ class ConvBnRelu(Op):
         N, H, W, M, C, ldy = src.N, src.H, src.W, src.M, self.cout, pad4(self.cout)
         sp = stats.data_ptr() if stats is not None else None
         if wino_ok(R, src.ld, ldy):
-            wino_conv(R, lib, s, X, wk, b.data_ptr(), y, sp, N, H, W, src.ld, C, ldy, 18.0 * M * C * self.cin)
+            return wino_conv(R, lib, s, X, wk, b.data_ptr(), y, sp, N, H, W, src.ld, C, ldy, 18.0 * M * C * self.cin)
         else:
             _timed(R, conv_kernel_name("fwd", ldy, src.ld), 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy, s),
@@ -245,19 +282,24 @@ class ConvBnRelu(Op):
         conv, bn = self.holder.conv_bn()
         if st.training:
             P = (M + _lib.CVK_STAT_ROWS - 1) // _lib.CVK_STAT_ROWS
-            stats = _empty(2 * P * C, dev)
+            Pm = max(P, lib.cvk_w2d_stat_partials(N, H, W))     # room for either partial layout (+ the 2-D path's counts)
+            stats = _empty(2 * Pm * C + Pm, dev)
             if M <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {[N, C, H, W]}")
-            self._conv(R, st, X, wk, b, y, stats, "fwd")
+            counted = self._conv(R, st, X, wk, b, y, stats, "fwd")
             wsb = lib.cvk_bn_finalize_workspace_bytes(P, C)
             ws = R.workspace(wsb, dev)
             track = bn.track_running_stats and bn.running_mean is not None
             mom = 0.1 if bn.momentum is None else float(bn.momentum)
-            check(lib.cvk_bn_finalize(stats.data_ptr(), P, M, C, gamma.data_ptr(), beta.data_ptr(), pm, pr, psc, psh,
-                                      bn.running_mean.data_ptr() if track else None,
-                                      bn.running_var.data_ptr() if track else None,
-                                      bn.num_batches_tracked.data_ptr() if track else None,
-                                      mom, float(bn.eps), ws.data_ptr(), wsb, s), "cvk_bn_finalize")
+            run = (bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
+                   bn.num_batches_tracked.data_ptr() if track else None)
+            if counted is None:
+                check(lib.cvk_bn_finalize(stats.data_ptr(), P, M, C, gamma.data_ptr(), beta.data_ptr(), pm, pr, psc, psh, *run,
+                                          mom, float(bn.eps), ws.data_ptr(), wsb, s), "cvk_bn_finalize")
+            else:       # partials with explicit pixel counts (2-D Winograd path: P2 <= P partials in the same buffer)
+                check(lib.cvk_bn_finalize_counts(stats.data_ptr(), counted[1], counted[0], M, C, gamma.data_ptr(), beta.data_ptr(),
+                                                 pm, pr, psc, psh, *run, mom, float(bn.eps), ws.data_ptr(), wsb, s),
+                      "cvk_bn_finalize_counts")
         else:
             self._conv(R, st, X, wk, b, y, None, "fwd")
             check(lib.cvk_bn_eval_params(gamma.data_ptr(), beta.data_ptr(), bn.running_mean.data_ptr(),
@@ -658,6 +700,7 @@ class Runner:
         self.grad_sync = None       # set by ddp.DataParallel
         self.wino = WINO_DEFAULT
         self.wino4 = WINO4_DEFAULT
+        self.wino2d = WINO2D_DEFAULT
         self.bf16 = False           # opt-in: bf16-storage mode (modules.set_conv_precision; BASELINE.json configs[3])
 
     def workspace(self, nbytes, dev):

@@ -83,3 +83,47 @@ def test_bf16_emulation_rounding_points():
         assert torch.allclose(o2, n3(x), rtol=1e-5, atol=1e-6)
     finally:
         E._r = saved
+
+
+def test_winograd2d_rounding():
+    """Derives the tolerance of the 2-D Winograd F(4x4,3x3) path (csrc/wino2d.hip): a numpy fp32 restatement of exactly its
+    transforms (points 0, +-1, +-2, inf; V = B^T d B, U = G g G^T, y = A^T M A) against an fp64 direct convolution at the
+    deep-layer channel counts, next to a plain fp32 direct convolution.  The GPU tests use 3 x the error measured here."""
+    rng = np.random.default_rng(0)
+    BT = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=np.float64)
+    G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=np.float64)
+    AT = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=np.float64)
+
+    def direct(x, w):
+        H, W = x.shape[0] - 2, x.shape[1] - 2
+        y = np.zeros((H, W, w.shape[0]), dtype=x.dtype)
+        for dy in range(3):
+            for dx in range(3):
+                y += x[dy:dy + H, dx:dx + W, :] @ w[:, dy, dx, :].T
+        return y
+
+    def w2d(x, w):
+        f = np.float32
+        H, W = x.shape[0] - 2, x.shape[1] - 2
+        U = np.einsum('ij,ojkc,lk->iloc', G.astype(f), w.astype(f), G.astype(f)).astype(f)
+        y = np.zeros((H, W, w.shape[0]), dtype=f)
+        bt, at = BT.astype(f), AT.astype(f)
+        for ty in range(0, H, 4):
+            for tx in range(0, W, 4):
+                d = x[ty:ty + 6, tx:tx + 6, :].astype(f)
+                V = np.einsum('ikc,lk->ilc', np.einsum('ij,jkc->ikc', bt, d), bt)
+                M = np.einsum('ilc,iloc->ilo', V, U)
+                y[ty:ty + 4, tx:tx + 4, :] = np.einsum('jlo,kl->jko', np.einsum('ji,ilo->jlo', at, M), at)
+        return y
+
+    for ci, co in ((1024, 512), (512, 512)):
+        H, W = 8, 12
+        x = np.maximum(rng.standard_normal((H + 2, W + 2, ci)), 0)
+        x[0] = x[-1] = 0; x[:, 0] = x[:, -1] = 0
+        b = 1 / np.sqrt(9 * ci)
+        w = rng.uniform(-b, b, (co, 3, 3, ci))
+        ref = direct(x, w)
+        n = np.linalg.norm(ref)
+        e_direct = np.linalg.norm(direct(x.astype(np.float32), w.astype(np.float32)) - ref) / n
+        e_w2d = np.linalg.norm(w2d(x, w) - ref) / n
+        assert e_direct < 5e-7 and 1e-6 < e_w2d < 3e-6, (ci, co, e_direct, e_w2d)      # GPU tolerance: 9e-6 = 3 x 3e-6

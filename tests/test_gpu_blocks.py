@@ -247,11 +247,12 @@ def test_conv_block_deep_layer_shapes_vs_fp64(shape):
     xr = x.double().requires_grad_(True)
     want = ref(xr)
     (want * r.double()).sum().backward()
-    for mode in (None, "always"):
+    for mode in (None, "always", "w2d"):
         m = A.BasicConv2d(ci, co)
         m.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
         m = m.to(dev()).train()
-        if mode:
+        runner_of(m).wino2d = "always" if mode == "w2d" else False
+        if mode == "always":
             runner_of(m).wino4 = mode
         xg = x.to(dev()).requires_grad_(True)
         y = m(xg)
@@ -260,7 +261,9 @@ def test_conv_block_deep_layer_shapes_vs_fp64(shape):
         def rel(a, b):
             b = b.float()
             return float((a.detach().cpu() - b.detach()).norm() / b.detach().norm())
-        tol = 2e-6 if mode is None else 4e-6                     # relative L2: fp32 rounding of a K = 9216 accumulation; F(4,3) ~2.5x coarser
+        # relative L2: fp32 rounding of a K = 9216 accumulation; F(4,3) ~2.5x coarser; 2-D F(4x4,3x3) 2.1-2.8e-6 in a numpy
+        # fp32 restatement of its transforms at these channel counts (tests/test_drift_cpu.py::test_winograd2d_rounding), x3
+        tol = {None: 2e-6, "always": 4e-6, "w2d": 9e-6}[mode]
         assert rel(y, want) < tol, (mode, "fwd", rel(y, want))
         assert rel(xg.grad, xr.grad) < 5 * tol, (mode, "dx", rel(xg.grad, xr.grad))
         assert rel(m.conv[0].weight.grad, ref.conv[0].weight.grad) < 5 * tol, (mode, "dW", rel(m.conv[0].weight.grad, ref.conv[0].weight.grad))
@@ -302,14 +305,15 @@ def test_winograd_and_direct_kernels_agree(shape):
     out_o, cache = O.basic_conv_fwd(x.numpy(), p, "", train=True)
     dx_o, g_o = O.basic_conv_bwd(r.numpy(), cache, p)
     m = m.to(dev()).train()
-    for wino, wino4 in ((False, False), (True, False), (True, "always")):     # direct, F(2,3), F(4,3) forward/data-grad
-        runner_of(m).wino, runner_of(m).wino4 = wino, wino4
+    for wino, wino4, wino2d in ((False, False, False), (True, False, False), (True, "always", False), (True, False, "always")):
+        # direct, F(2,3), F(4,3), 2-D F(4x4,3x3) forward/data-grad
+        runner_of(m).wino, runner_of(m).wino4, runner_of(m).wino2d = wino, wino4, wino2d
         for q in m.parameters():
             q.grad = None
         xg = x.to(dev()).requires_grad_(True)
         y = m(xg)
         (y * r.to(dev())).sum().backward()
-        tag = f"wino={wino} wino4={wino4}"
+        tag = f"wino={wino} wino4={wino4} wino2d={wino2d}"
         close(y, out_o, 1e-4, 3e-5 * max(1.0, float(np.abs(out_o).max())), f"fwd {tag}")
         close(xg.grad, dx_o, 1e-3, 2e-4 * float(np.abs(dx_o).max()), f"dx {tag}")
         close(m.conv[0].weight.grad, g_o["conv.0.weight"], 1e-3, 2e-4 * float(np.abs(g_o["conv.0.weight"]).max()), f"dW {tag}")
@@ -330,29 +334,35 @@ def _fuzz_shapes(n, seed):
 def test_winograd43_fuzz_against_direct_kernels(shape):
     """Random geometries (every W mod 4, single rows/columns, channel counts that are not multiples of the 128-wide
     tiles, K-split and multi-row slice variants) through the forced F(4,3) forward / data-grad / weight-grad kernels
+    and the forced 2-D F(4x4,3x3) forward / data-grad (tiles cut by the bottom and right edges, partial GEMM tiles)
     against the direct implicit-GEMM kernels of the same library — two independent implementations of the operator.
-    Forward: 3e-5 of the output scale; gradients: relative L2 1e-3 (ReLU-mask flips move single elements)."""
+    Forward: 3e-5 of the output scale; gradients: relative L2 1e-4 — rounding only: the BatchNorm shift keeps every ReLU
+    mask away from zero (with masks near zero single flips moved dx by 1.3e-3 on the 2-D path, hiding the GEMM accuracy;
+    the deep-layer test measures <= 2e-5 for F(4,3) and the 2-D transforms round ~3.5x coarser)."""
     import pytorch_camvid_amd as A
     from pytorch_camvid_amd.modules import runner_of
     n, ci, h, w, co = shape
     torch.manual_seed(11)
     m = A.BasicConv2d(ci, co).to(dev()).train()
+    with torch.no_grad():       # BatchNorm shift +8..9: no ReLU mask sits near zero, so the gradients compare the GEMMs themselves
+        m.conv[1].weight.uniform_(0.5, 1.5); m.conv[1].bias.uniform_(8.0, 9.0)
     g = torch.Generator(device="cuda").manual_seed(3)
     x = torch.randn(n, ci, h, w, device=dev(), generator=g)
     r = torch.randn(n, co, h, w, device=dev(), generator=g)
     res = {}
-    for mode, (wino, wino4) in (("direct", (False, False)), ("f43", (True, "always"))):
-        runner_of(m).wino, runner_of(m).wino4 = wino, wino4
+    for mode, (wino, wino4, wino2d) in (("direct", (False, False, False)), ("f43", (True, "always", False)), ("w2d", (True, False, "always"))):
+        runner_of(m).wino, runner_of(m).wino4, runner_of(m).wino2d = wino, wino4, wino2d
         for q in m.parameters():
             q.grad = None
         xg = x.clone().requires_grad_(True)
         y = m(xg)
         (y * r).sum().backward()
         res[mode] = (y.detach().clone(), xg.grad.clone(), m.conv[0].weight.grad.clone(), m.conv[1].weight.grad.clone())
-    ya, yb = res["f43"][0], res["direct"][0]
-    assert torch.isfinite(ya).all() and (ya - yb).abs().max().item() <= 3e-5 * max(1.0, yb.abs().max().item()) + 1e-6, shape
-    if n * h * w > 8:          # BatchNorm over a handful of samples is ill-conditioned: gradients only for real batches
-        for a, b, what in zip(res["f43"][1:], res["direct"][1:], ("dx", "dW", "dgamma")):
-            den = b.double().norm().item()
-            rel = (a - b).double().norm().item() / max(den, 1e-12)
-            assert torch.isfinite(a).all() and rel <= 1e-3, (shape, what, rel)
+    for mode in ("f43", "w2d"):
+        ya, yb = res[mode][0], res["direct"][0]
+        assert torch.isfinite(ya).all() and (ya - yb).abs().max().item() <= 3e-5 * max(1.0, yb.abs().max().item()) + 1e-6, (shape, mode)
+        if n * h * w > 8:          # BatchNorm over a handful of samples is ill-conditioned: gradients only for real batches
+            for a, b, what in zip(res[mode][1:], res["direct"][1:], ("dx", "dW", "dgamma")):
+                den = b.double().norm().item()
+                rel = (a - b).double().norm().item() / max(den, 1e-12)
+                assert torch.isfinite(a).all() and rel <= 1e-4, (shape, mode, what, rel)

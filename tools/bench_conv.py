@@ -14,6 +14,9 @@ LAYERS = [  # name, Cin, Cout, H, W
     ("ups4.conv", 128, 64, 360, 480), ("up4.0", 128, 64, 360, 480), ("output", 64, 12, 360, 480),
 ]
 
+if "--rev" in sys.argv:        # data-grad shapes: channel roles exchanged
+    sys.argv.remove("--rev")
+    LAYERS = [(n, co, ci, h, w) for (n, ci, co, h, w) in LAYERS if ci >= 64 and co >= 64]
 COLD = "--cold" in sys.argv
 if COLD:
     sys.argv.remove("--cold")
@@ -55,13 +58,6 @@ def main():
         if "fwd" in which:
             t = timeit(lambda: check(lib.cvk_conv3x3_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, ci, co, ldy, s)))
             row += f" fwd {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["fwd"][0] += flops; tot["fwd"][1] += t
-        for var in (0, 1):
-            if f"split{var}" in which and ci % 32 == 0 and co > 32:
-                t = timeit(lambda: check(lib.cvk_conv3x3_fwd_split(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, ci, co, ldy, var, s)))
-                row += f" split{var} {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot[f"split{var}"][0] += flops; tot[f"split{var}"][1] += t
-        if "bf16" in which and ci % 32 == 0:
-            t = timeit(lambda: check(lib.cvk_conv3x3_fwd_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, ci, co, ldy, s)))
-            row += f" bf16 {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["bf16"][0] += flops; tot["bf16"][1] += t
         if "wino" in which and ci % 64 == 0:
             U = torch.empty(4 * co * 3 * ci, device=dev)
             check(lib.cvk_wino_weight_transform(w.data_ptr(), U.data_ptr(), co, ci, s))
@@ -79,6 +75,19 @@ def main():
             err = (y - yref).abs().max().item() / yref.abs().max().item() if "wino" in which else float("nan")
             serr = (stats - sref).abs().max().item() / sref.abs().max().item() if "wino" in which else float("nan")
             row += f" wino4 gemm {tg*1e6:7.1f} out {to*1e6:6.1f}us {flops/t/1e12:6.1f}TF (gemm {flops/tg/1e12:6.1f}) err {err:.1e} {serr:.1e}"; tot["wino4"][0] += flops; tot["wino4"][1] += t
+        if "w2d" in which and ci % 32 == 0 and co >= 64 and co % 4 == 0:
+            yref = y.clone()
+            U2 = torch.empty(36 * co * ci, device=dev)
+            tw_ = timeit(lambda: check(lib.cvk_w2d_weight_transform(w.data_ptr(), U2.data_ptr(), co, ci, s)))
+            wsb = lib.cvk_conv3x3_w2d_workspace_bytes(N, H, W, ci, co); ws2 = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            P2 = lib.cvk_w2d_stat_partials(N, H, W); st2 = torch.zeros(2 * P2 * co + P2, device=dev)
+            y.zero_()
+            t = timeit(lambda: check(lib.cvk_conv3x3_w2d(x.data_ptr(), U2.data_ptr(), b.data_ptr(), y.data_ptr(), st2.data_ptr(), st2.data_ptr() + 8 * P2 * co,
+                                                         N, H, W, ci, co, ldy, ws2.data_ptr(), wsb, s)))
+            err = (y - yref).abs().max().item() / max(yref.abs().max().item(), 1e-30)
+            ssum = st2[:P2 * co].view(P2, co).sum(0); serr = (ssum - y[:, :co].sum(0)).abs().max().item() / y[:, :co].sum(0).abs().max().item()
+            cnt = st2[2 * P2 * co:].sum().item()
+            row += f" w2d {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF (wt {tw_*1e6:.1f}us) err {err:.1e} sum {serr:.1e} cnt {cnt:.0f}/{M}"; tot["w2d"][0] += flops; tot["w2d"][1] += t
         if "dgrad" in which and name != "down1.0":
             dy = torch.randn(M, ldy, device=dev); wd = torch.randn(ci, 9 * ldy, device=dev) * 0.05; dx = torch.empty(M, ci, device=dev)
             t = timeit(lambda: check(lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), None, N, H, W, ldy, ci, ci, s)))
@@ -97,11 +106,6 @@ def main():
             check(lib.cvk_conv3x3_wgrad_wino(x.data_ptr(), dy.data_ptr(), dwr.data_ptr(), N, H, W, ci, ci, co, ldy, ws2.data_ptr(), wsb2, s))
             err = (dw4 - dwr).abs().max().item() / dwr.abs().max().item()
             row += f" wwino4 {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF err {err:.1e}"; tot["wwino4"][0] += flops; tot["wwino4"][1] += t
-        if "wbf16" in which and co > 32:
-            dy = torch.randn(M, ldy, device=dev); dw = torch.empty(co, 9 * ci, device=dev)
-            wsb = lib.cvk_conv3x3_wgrad_bf16_workspace_bytes(N, H, W, ci, co); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            t = timeit(lambda: check(lib.cvk_conv3x3_wgrad_bf16(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, H, W, ci, ci, co, ldy, ws.data_ptr(), wsb, s)))
-            row += f" wbf16 {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["wbf16"][0] += flops; tot["wbf16"][1] += t
         if "wgrad" in which:
             dy = torch.randn(M, ldy, device=dev); dw = torch.empty(co, 9 * ci, device=dev)
             wsb = lib.cvk_conv3x3_wgrad_workspace_bytes(N, H, W, ci, co); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
