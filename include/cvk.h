@@ -133,6 +133,11 @@ int cvk_w2d_gemm(const float* V, const float* U, float* Mo, int T, int Cin, int 
 int cvk_w2d_output(const float* Mo, const float* bias, float* y, float* stats, float* counts, int N, int H, int W, int Cin,
                    int Cout, int ldy, void* stream);
 
+/* weight-grad through the transposed 2-D F(4x4,3x3) (contract of cvk_conv3x3_wgrad; channel counts multiples of 4):
+ * dW = G^T [ sum_tiles (A dy A^T) (.) (B^T x B) ] G, 36 GEMMs whose depth is the tile index */
+size_t cvk_conv3x3_wgrad_w2d_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout);
+int cvk_conv3x3_wgrad_w2d(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad, int Cout,
+                          int ld_dy, void* workspace, size_t workspace_bytes, void* stream);
 /* weight-grad through the transposed F(4,3) (contract of cvk_conv3x3_wgrad; the workspace also holds the transformed
  * output-gradient planes E1..E4, float[4][N*H*ceil(W/4)][ld_dy], hence the extra ld_dy argument of the size query) */
 size_t cvk_conv3x3_wgrad_wino4_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout, int ld_dy);

@@ -57,6 +57,8 @@ SIGNATURES = {
     "cvk_w2d_weight_transform": (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
     "cvk_w2d_input_transform": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_w2d_gemm": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "cvk_conv3x3_wgrad_w2d_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
+    "cvk_conv3x3_wgrad_w2d": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
     "cvk_w2d_ksplit": (c_int, [c_int, c_int, c_int]),
     "cvk_w2d_output": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_w2d": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),

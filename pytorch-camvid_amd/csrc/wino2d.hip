@@ -18,7 +18,6 @@
 namespace {
 
 constexpr int W2_BN = 128;          // output columns (channels) per workgroup
-constexpr int W2_BK = 32;           // K slice: 32 floats = 128-byte LDS rows
 constexpr int W2_TB = 16;           // tiles per statistics partial / output-transform block
 
 // ---- 1-D transforms (applied along rows, then along columns) ---------------------------------------------------------------
@@ -55,12 +54,18 @@ __device__ __forceinline__ void w2_g(const float* g, float* u) {
 }
 
 // ---- input transform: x [N,H,W,C] -> V [36][T][C], T = N * ceil(H/4) * ceil(W/4); one thread = one tile x 4 channels ----------
+// Rows T <= t < Tpad (weight-grad: the tile index is the GEMM depth, padded to whole K slices) are written as zeros.
 __global__ __launch_bounds__(256) void k_w2d_input(const float* __restrict__ X, float* __restrict__ V, int H, int W, int C,
-                                                  int th, int tw, int T) {
+                                                  int th, int tw, int T, int Tpad) {
     const int cvn = C >> 2;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int t = (int)(idx / cvn), c = (int)(idx % cvn) * 4;
-    if (t >= T) return;
+    if (t >= Tpad) return;
+    if (t >= T) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        for (int xi = 0; xi < 36; ++xi) *reinterpret_cast<f32x4*>(V + ((size_t)xi * Tpad + t) * C + c) = zero;
+        return;
+    }
     const int n = t / (th * tw), r = t - n * th * tw, ty = r / tw, tx = r - ty * tw;
     const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
     const float* const xb = X + (size_t)n * H * W * C + c;
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256) void k_w2d_input(const float* __restrict__ X, 
 #pragma unroll
         for (int i = 0; i < 6; ++i) w[i][j] = v[i];
     }
-    const size_t plane = (size_t)T * C;
+    const size_t plane = (size_t)Tpad * C;
     float* const vb = V + (size_t)t * C + c;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -124,16 +129,20 @@ __global__ __launch_bounds__(256) void k_w2d_weight(const float* __restrict__ Wt
 // c ^ ((r >> 1) & 7) (applied through the DMA source address), so the sixteen rows of a ds_read_b128 phase hit sixteen
 // different 16-byte bank groups.  A lane's b128 holds k = 8s + 4h + {0..3} of its row: four MFMAs per read, the same K
 // permutation on both operands.  Per K slice: counted wait for the slice's own DMA pieces, one barrier, DMA of slice
-// + NSTG - 1.  <256, 3>: 8 waves, 144 KiB, one workgroup per CU; <128, 2>: 4 waves, 64 KiB, two per CU (few-tile layers).
+// + NSTG - 1.  Used as <128, 32, 2, 2>: 4 waves, 64 KiB, two workgroups per CU — co-residency (one workgroup's prologue and
+// store epilogue under the other's MFMAs) is worth more than the larger tile: <256, 32, 3> (8 waves, 144 KiB, one per CU) was
+// 3-9 % slower on every layer, <128, 16, 3> (three per CU) and <256, 16, 2> (two per CU) within +-3 % (tools/bench_conv.py w2d).
 // Tail: the tiles of the last, partial round of workgroups (ids >= split_start) are cut into f K-ranges, one workgroup
 // each; range p writes plane p of D (plane stride part_stride) and the output transform adds the planes in a fixed order.
-template <int BM, int NSTG>
-__global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void k_w2d_gemm(const float* __restrict__ A, const float* __restrict__ B,
-                                                                       float* __restrict__ D, int T, int Nn, int K, int ldd,
-                                                                       int tilesM, int tilesN, int split_start, int f,
-                                                                       size_t part_stride) {
-    constexpr int NW = BM / 32, ROWS = BM + W2_BN, PIECES = ROWS / 8, PPW = PIECES / NW, STAGE = ROWS * 128;
-    static_assert(PIECES % NW == 0 && NSTG * STAGE * (BM == 256 ? 1 : 2) <= 160 * 1024 && (NSTG == 2 || NSTG == 3), "stage geometry");
+template <int BM, int BK, int NSTG, int WPS>      // tile rows, K slice (floats), LDS stages, waves per SIMD the kernel is built for
+__global__ __launch_bounds__(BM * 2, WPS) void k_w2d_gemm(const float* __restrict__ A, const float* __restrict__ B,
+                                                         float* __restrict__ D, int T, int Nn, int K, int ldd, int tilesM,
+                                                         int tilesN, int split_start, int f, size_t part_stride) {
+    constexpr int NW = BM / 32, ROWS = BM + W2_BN, ROWB = BK * 4, RPP = 1024 / ROWB, NCH = ROWB / 16;   // rows per 1 KiB DMA piece, chunks per row
+    constexpr int PIECES = ROWS / RPP, PPW = PIECES / NW, STAGE = ROWS * ROWB, NS = BK / 8;
+    constexpr int SWS = NCH == 8 ? 1 : 2;               // swizzle: chunk c of row r at c ^ ((r >> SWS) & (NCH-1))
+    static_assert(PIECES % NW == 0 && (NSTG == 2 || NSTG == 3) && (BK == 16 || BK == 32), "stage geometry");
+    static_assert(NSTG * STAGE * (WPS * 4 / NW) <= 160 * 1024, "LDS budget of the co-resident workgroups");
     __shared__ __attribute__((aligned(1024))) char smem[NSTG * STAGE];
     const unsigned smem_addr = cvk_lds_addr(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void k_w2d_gemm(const fl
     const int wm = wave >> 1, wn = wave & 1;
 
     // full-round workgroups and tail workgroups are dealt to the XCDs separately (both in contiguous logical chunks)
-    const int nK = K / W2_BK;
+    const int nK = K / BK;
     int id, kb = 0, ke = nK;
     if ((int)blockIdx.x < split_start) {
         id = cvk_xcd_remap(blockIdx.x, split_start);
@@ -160,18 +169,18 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void k_w2d_gemm(const fl
     D += (size_t)xi * T * ldd;
     const int row0 = tm * BM, col0 = tn * W2_BN;
 
-    // DMA mapping: piece wave*PPW + q = LDS rows 8*piece + lane/8; rows < BM are A rows, the rest B rows (clamped: rows beyond
-    // the matrix re-read its last row, their products are never stored)
+    // DMA mapping: piece wave*PPW + q = LDS rows RPP*piece + lane/NCH; rows < BM are A rows, the rest B rows (clamped: rows
+    // beyond the matrix re-read its last row, their products are never stored)
     const float* src[PPW];
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
-        const int row = (wave * PPW + q) * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int row = (wave * PPW + q) * RPP + lane / NCH;
+        const int chunk = (lane % NCH) ^ ((row >> SWS) & (NCH - 1));
         src[q] = (row < BM ? A + (size_t)min(row0 + row, T - 1) * K : B + (size_t)min(col0 + row - BM, Nn - 1) * K) + chunk * 4;
     }
     auto issue = [&](int ks, int buf) {
 #pragma unroll
-        for (int q = 0; q < PPW; ++q) cvk_dma16(src[q] + ks * W2_BK, smem_addr + buf * STAGE + (wave * PPW + q) * 1024);
+        for (int q = 0; q < PPW; ++q) cvk_dma16(src[q] + ks * BK, smem_addr + buf * STAGE + (wave * PPW + q) * 1024);
     };
 
     f32x16 acc[2][2];
@@ -182,9 +191,9 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void k_w2d_gemm(const fl
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // fragment addresses: row block base + lane row r, chunk (2s + h) ^ ((r >> 1) & 7); s enters as an XOR of bits 5-6
-    const int lane_off = r * 128 + ((h ^ ((r >> 1) & 7)) << 4);
-    const int a_off = wm * 64 * 128 + lane_off, b_off = (BM + wn * 64) * 128 + lane_off;
+    // fragment addresses: row block base + lane row r, chunk (2s + h) ^ swizzle(r); s enters as an XOR of bits 5..
+    const int lane_off = r * ROWB + ((h ^ ((r >> SWS) & (NCH - 1))) << 4);
+    const int a_off = wm * 64 * ROWB + lane_off, b_off = (BM + wn * 64) * ROWB + lane_off;
 
 #pragma unroll
     for (int d = 0; d < NSTG - 1; ++d) issue(min(kb + d, ke - 1), d);
@@ -195,12 +204,12 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void k_w2d_gemm(const fl
         issue(min(ks + NSTG - 1, ke - 1), buf == 0 ? NSTG - 1 : buf - 1);      // (buf + NSTG - 1) % NSTG
         const char* const st = smem + buf * STAGE;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NS; ++s) {
             f32x4 a[2], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(st + ((a_off + i * 32 * 128) ^ (s << 5)));
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(st + ((a_off + i * 32 * ROWB) ^ (s << 5)));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4*>(st + ((b_off + j * 32 * 128) ^ (s << 5)));
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4*>(st + ((b_off + j * 32 * ROWB) ^ (s << 5)));
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -223,6 +232,176 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void k_w2d_gemm(const fl
                 if (row < T && col < Nn) D[(size_t)row * ldd + col] = acc[i][j][e];
             }
         }
+}
+
+// ================================================================================================ weight-grad
+// dW = G^T [ sum_tiles (A dy A^T) (.) (B^T x B) ] G:  per transform index one GEMM  P_xi[Cout][Cin] = E_xi^T V_xi  whose depth
+// is the tile index (reference: the weight gradient of nn.Conv2d, bwd of train.py:131).
+// A (6 x 4) = transpose of A^T above: e0 = d0, e1 = d0+d1+d2+d3, e2 = d0-d1+d2-d3, e3 = d0+2d1+4d2+8d3, e4 = d0-2d1+4d2-8d3, e5 = d3
+template <typename T>
+__device__ __forceinline__ void w2_a(const T* d, T* e) {
+    const T s02 = d[0] + d[2], s13 = d[1] + d[3], t02 = d[0] + 4.f * d[2], t13 = 2.f * d[1] + 8.f * d[3];
+    e[0] = d[0];
+    e[1] = s02 + s13;
+    e[2] = s02 - s13;
+    e[3] = t02 + t13;
+    e[4] = t02 - t13;
+    e[5] = d[3];
+}
+
+// dy [N,H,W,ld] -> E [36][Tpad][C]; one thread = one 4 x 4 tile x 4 channels (pixels beyond the frame count as zero)
+__global__ __launch_bounds__(256) void k_w2d_dy(const float* __restrict__ DY, int ld, float* __restrict__ E, int H, int W, int C,
+                                               int th, int tw, int T, int Tpad) {
+    const int cvn = C >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int t = (int)(idx / cvn), c = (int)(idx % cvn) * 4;
+    if (t >= Tpad) return;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const size_t plane = (size_t)Tpad * C;
+    float* const eb = E + (size_t)t * C + c;
+    if (t >= T) {
+        for (int xi = 0; xi < 36; ++xi) *reinterpret_cast<f32x4*>(eb + (size_t)xi * plane) = zero;
+        return;
+    }
+    const int n = t / (th * tw), r = t - n * th * tw, ty = r / tw, tx = r - ty * tw;
+    const float* const db = DY + (size_t)n * H * W * ld + c;
+    f32x4 w[6][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 d[4], e[6];
+        const int xx = 4 * tx + j;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = 4 * ty + i;
+            d[i] = (yy < H && xx < W) ? *reinterpret_cast<const f32x4*>(db + ((size_t)yy * W + xx) * ld) : zero;
+        }
+        w2_a(d, e);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i][j] = e[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        f32x4 e[6];
+        w2_a(w[i], e);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(eb + (size_t)(i * 6 + j) * plane) = e[j];
+    }
+}
+
+// batched GEMM over the tile index:  D_xi[Mm][Nn] (plane `part`) = sum_{k in part's range} A_xi[k][Mm]^T * B_xi[k][Nn]
+// Both operands are depth-major (a depth row = lda / ldb contiguous floats).  Workgroup: 128 x 128 tile, four waves of
+// 64 x 64; LDS: two stages of 32 depth rows x (128 + 128) floats, copied by LDS-DMA as they lie (1 KiB = two depth rows of one
+// operand).  A wave's two MFMA row blocks take interleaved rows (2*rho + i) and its column blocks interleaved columns, so one
+// ds_read_b64 at depth row 2q + h delivers a lane's A values of both row blocks, another its B values: 32 reads per 64
+// MFMAs, and the results of a lane are column pairs (8-byte stores).  The depth is cut into f ranges (grid.y) when the
+// 36 * tiles workgroups alone would not fill the chip; the planes are added by k_w2d_wgrad_out in a fixed order.
+__global__ __launch_bounds__(256, 2) void k_w2d_gemm_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                       float* __restrict__ D, int Kp, int Mm, int Nn, int tilesM, int tilesN,
+                                                       int f) {
+    constexpr int STAGE = 32 * 256 * 4, PPW = 8;        // 32 KiB per stage: depth rows [k][A 128 | B 128]... kept as two 16 KiB halves
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+    const unsigned smem_addr = cvk_lds_addr(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int id = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int part = id % f, tile = id / f;
+    const int tn = tile % tilesN, tm = (tile / tilesN) % tilesM, xi = tile / (tilesN * tilesM);
+    const int nK = Kp / 32, kb = part * nK / f, ke = (part + 1) * nK / f;
+    A += (size_t)xi * Kp * lda + tm * 128;
+    B += (size_t)xi * Kp * ldb + tn * 128;
+    D += ((size_t)part * 36 + xi) * Mm * Nn;
+
+    // DMA: piece p = wave*8 + q; pieces 0..15 = A depth rows 2p, 2p+1 (LDS bytes [0, 16 KiB)), 16..31 = B (LDS [16, 32 KiB));
+    // lane = depth row lane/32 of the pair, floats 4*(lane%32) .. +3 of the 128.  Columns beyond the matrix read the
+    // neighbouring bytes of the plane (in bounds: the planes carry a slack row); their products are never stored.
+    const float* src[PPW];
+    int sstep[PPW];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int p = wave * PPW + q, pa = p & 15;
+        const int krow = pa * 2 + (lane >> 5), col = (lane & 31) * 4;
+        src[q] = p < 16 ? A + (size_t)krow * lda + col : B + (size_t)krow * ldb + col;
+        sstep[q] = p < 16 ? 32 * lda : 32 * ldb;
+    }
+    auto issue = [&](int ks, int buf) {
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) cvk_dma16(src[q] + (size_t)ks * sstep[q], smem_addr + buf * STAGE + (wave * PPW + q) * 1024);
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int a_off = h * 512 + (wm * 64 + 2 * r) * 4, b_off = 16384 + h * 512 + (wn * 64 + 2 * r) * 4;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+    if (kb < ke) issue(kb, 0);
+    int buf = 0;
+    for (int ks = kb; ks < ke; ++ks) {
+        cvk_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        issue(min(ks + 1, ke - 1), buf ^ 1);
+        const char* const st = smem + buf * STAGE;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const f32x2 a = *reinterpret_cast<const f32x2*>(st + a_off + q * 1024);
+            const f32x2 b = *reinterpret_cast<const f32x2*>(st + b_off + q * 1024);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    cvk_wait_vm<0>();
+    const int col = tn * 128 + wn * 64 + 2 * r;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = tm * 128 + wm * 64 + 2 * ((e & 3) + 8 * (e >> 2) + 4 * h) + i;
+            if (row < Mm) {
+                float* const dp = D + (size_t)row * Nn + col;
+                if (col + 1 < Nn) { const f32x2 v = {acc[i][0][e], acc[i][1][e]}; *reinterpret_cast<f32x2*>(dp) = v; }
+                else if (col < Nn) dp[0] = acc[i][0][e];
+            }
+        }
+}
+
+// dw [Co][3][3][Ci] = G^T (sum of the f planes of P [36][Co][Cip]) G; one thread = one (co, ci)
+__global__ __launch_bounds__(256) void k_w2d_wgrad_out(const float* __restrict__ P, float* __restrict__ dw, int Co, int Ci, int Cip, int f) {
+    const size_t total = (size_t)Co * Ci, plane = (size_t)Co * Cip;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int ci = (int)(idx % Ci);
+        const size_t co = idx / Ci;
+        const float* const pp = P + co * Cip + ci;
+        float t[6][3];          // rows a of P, transformed along b
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            float m[6];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                float v = pp[(size_t)(a * 6 + b) * plane];
+                for (int k = 1; k < f; ++k) v += pp[(size_t)(k * 36 + a * 6 + b) * plane];
+                m[b] = v;
+            }
+            const float s12 = m[1] + m[2], d12 = m[2] - m[1], s34 = m[3] + m[4], d34 = m[3] - m[4];
+            t[a][0] = 0.25f * m[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+            t[a][1] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+            t[a][2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + m[5];
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float s12 = t[1][kx] + t[2][kx], d12 = t[2][kx] - t[1][kx], s34 = t[3][kx] + t[4][kx], d34 = t[3][kx] - t[4][kx];
+            dw[(co * 9 + 0 + kx) * Ci + ci] = 0.25f * t[0][kx] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+            dw[(co * 9 + 3 + kx) * Ci + ci] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+            dw[(co * 9 + 6 + kx) * Ci + ci] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + t[5][kx];
+        }
+    }
 }
 
 // ---- output transform: M [36][T][ldm] -> y [N,H,W,ldy] (+bias, + BatchNorm statistics partials with pixel counts) ----------------
@@ -315,13 +494,12 @@ extern "C" int cvk_w2d_stat_partials(int N, int H, int W) { return (N > 0 && H >
 struct W2Plan { int BM, tilesM, tilesN, NT, split_start, f; };
 static W2Plan plan_w2d(int T, int Cin, int Cout) {
     W2Plan p;
-    const double pad256 = (double)cvk_cdiv(T, 256) * 256 / T, pad128 = (double)cvk_cdiv(T, 128) * 128 / T;
-    p.BM = (T <= 128 || pad256 > 1.1 * pad128) ? 128 : 256;
+    p.BM = 128;
     p.tilesM = cvk_cdiv(T, p.BM);
     p.tilesN = cvk_cdiv(Cout, W2_BN);
     p.NT = 36 * p.tilesM * p.tilesN;
-    const int slots = p.BM == 256 ? 256 : 512;            // resident workgroups
-    const int nK = Cin / W2_BK;
+    const int slots = 512;                                // resident workgroups: two per CU
+    const int nK = Cin / 32;
     const int full = p.NT / slots * slots, R = p.NT - full;
     p.f = 1;
     if (R > 0) {
@@ -357,8 +535,63 @@ extern "C" int cvk_w2d_input_transform(const float* x, float* V, int N, int H, i
     CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(V), "cvk_w2d_input_transform: pointers must be 16-byte aligned");
     const int th = (H + 3) / 4, tw = (W + 3) / 4, T = N * th * tw;
     const long threads = (long)T * (Cin / 4);
-    hipLaunchKernelGGL(k_w2d_input, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, V, H, W, Cin, th, tw, T);
+    hipLaunchKernelGGL(k_w2d_input, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, V, H, W, Cin, th, tw, T, T);
     CVK_LAUNCH_RETURN("cvk_w2d_input_transform");
+}
+
+// ---- weight-grad ---------------------------------------------------------------------------------------------------------
+struct W2WPlan { int Tpad, tilesM, tilesN, f; };
+static W2WPlan plan_w2d_wgrad(int T, int Cin_pad, int Cout) {
+    W2WPlan p;
+    p.Tpad = cvk_cdiv(T, 32) * 32;
+    p.tilesM = cvk_cdiv(Cout, 128);
+    p.tilesN = cvk_cdiv(Cin_pad, 128);
+    const int nt = 36 * p.tilesM * p.tilesN, nK = p.Tpad / 32;
+    // depth split: fill the 512 resident workgroups at least twice over, keep >= 4 slices per range, at most 16 planes
+    int f = cvk_cdiv(1024, nt);
+    if (f > nK / 4) f = nK / 4;
+    if (f > 16) f = 16;
+    if (f < 1) f = 1;
+    p.f = f;
+    return p;
+}
+
+extern "C" size_t cvk_conv3x3_wgrad_w2d_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin_pad <= 0 || Cout <= 0) return 0;
+    const W2WPlan p = plan_w2d_wgrad(w2_tiles(N, H, W), Cin_pad, Cout);
+    // V and E planes (+ one slack depth row each: partial column tiles read past the last row) and the f product planes
+    return ((size_t)36 * p.Tpad * ((size_t)Cin_pad + Cout) + 2 * 128 + (size_t)p.f * 36 * Cout * Cin_pad) * sizeof(float);
+}
+
+extern "C" int cvk_conv3x3_wgrad_w2d(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,
+                                     int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream) {
+    CVK_CHECK_ARG(x && dy && dw && workspace, "cvk_conv3x3_wgrad_w2d: null pointer");
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= Cin_pad && Cin_pad % 4 == 0 && Cout > 0 && Cout % 4 == 0 && ld_dy >= Cout && ld_dy % 4 == 0,
+                  "cvk_conv3x3_wgrad_w2d: bad shape (channel counts must be multiples of 4)");
+    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(dy) && cvk_aligned16(workspace), "cvk_conv3x3_wgrad_w2d: pointers must be 16-byte aligned");
+    CVK_CHECK_ARG(workspace_bytes >= cvk_conv3x3_wgrad_w2d_workspace_bytes(N, H, W, Cin_pad, Cout), "cvk_conv3x3_wgrad_w2d: workspace too small");
+    const int th = (H + 3) / 4, tw = (W + 3) / 4, T = N * th * tw;
+    const W2WPlan p = plan_w2d_wgrad(T, Cin_pad, Cout);
+    hipStream_t s = (hipStream_t)stream;
+    float* const V = (float*)workspace;
+    float* const E = V + (size_t)36 * p.Tpad * Cin_pad + 128;
+    float* const P = E + (size_t)36 * p.Tpad * Cout + 128;
+    {
+        const long threads = (long)p.Tpad * (Cin_pad / 4);
+        hipLaunchKernelGGL(k_w2d_input, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, V, H, W, Cin_pad, th, tw, T, p.Tpad);
+    }
+    {
+        const long threads = (long)p.Tpad * (Cout / 4);
+        hipLaunchKernelGGL(k_w2d_dy, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, dy, ld_dy, E, H, W, Cout, th, tw, T, p.Tpad);
+    }
+    hipLaunchKernelGGL(k_w2d_gemm_tn, dim3(36 * p.tilesM * p.tilesN * p.f), dim3(256), 0, s, E, Cout, V, Cin_pad, P, p.Tpad, Cout, Cin_pad,
+                       p.tilesM, p.tilesN, p.f);
+    {
+        const size_t total = (size_t)Cout * Cin;
+        const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+        hipLaunchKernelGGL(k_w2d_wgrad_out, dim3(blocks), dim3(256), 0, s, P, dw, Cout, Cin, Cin_pad, p.f);
+    }
+    CVK_LAUNCH_RETURN("cvk_conv3x3_wgrad_w2d");
 }
 
 extern "C" int cvk_w2d_gemm(const float* V, const float* U, float* Mo, int T, int Cin, int Cout, void* stream) {
@@ -370,10 +603,8 @@ extern "C" int cvk_w2d_gemm(const float* V, const float* U, float* Mo, int T, in
     const dim3 grid(p.split_start + (p.NT - p.split_start) * p.f);
     const size_t part_stride = (size_t)36 * T * Cout;
     hipStream_t s = (hipStream_t)stream;
-    if (p.BM == 256)
-        hipLaunchKernelGGL((k_w2d_gemm<256, 3>), grid, dim3(512), 0, s, V, U, Mo, T, Cout, Cin, Cout, p.tilesM, p.tilesN, p.split_start, p.f, part_stride);
-    else
-        hipLaunchKernelGGL((k_w2d_gemm<128, 2>), grid, dim3(256), 0, s, V, U, Mo, T, Cout, Cin, Cout, p.tilesM, p.tilesN, p.split_start, p.f, part_stride);
+    hipLaunchKernelGGL((k_w2d_gemm<128, 32, 2, 2>), grid, dim3(256), 0, s, V, U, Mo, T, Cout, Cin, Cout, p.tilesM, p.tilesN, p.split_start,
+                       p.f, part_stride);
     CVK_LAUNCH_RETURN("cvk_w2d_gemm");
 }
 

@@ -139,6 +139,13 @@ def wino2d_pays(N, H, W, k_ch, cout):
     return T >= 256 and (k_ch * cout >= 65536 or (k_ch * cout >= 32768 and T >= 16384))
 
 
+def wgrad2d_pays(N, H, W, k_ch, cout):
+    """Weight-grad through the 2-D transform: wins from 256 x 256 channels up (0.60-0.90 of the transposed F(4,3) time at the
+    UNet batch-8 shapes), loses below (the dy / x transform passes dominate)."""
+    T = N * ((H + 3) // 4) * ((W + 3) // 4)
+    return T >= 256 and k_ch * cout >= 65536
+
+
 def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what="", dgrad_of=None):
     """y[N,H,W,ldy] = conv3x3(x[N,H,W,k_ch], w[cout][3][3][k_ch]) (+bias, +BN statistics partials at sp) through the 1-D
     Winograd kernels: weight transform -> implicit GEMMs M_xi -> output transform.  F(4,3) when R.wino4, else F(2,3).
@@ -332,6 +339,11 @@ class ConvBnRelu(Op):
         dy = torch.zeros(M * ldy, device=dev, dtype=_F32) if ldy != C else _empty(M * ldy, dev)
         # layers whose weight-grad runs through the transposed F(4,3) get its transformed dy planes E1..E4 from this pass
         wgrad4 = R.wino and src.ld >= 32 and C > 32 and (R.wino4 == "always" or (R.wino4 and src.ld >= 64))
+        # channel-heavy layers: transposed 2-D F(4x4,3x3), 36 GEMMs over the tile index (25-40 % faster than the transposed
+        # F(4,3) from 256x256 channels up: tools/bench_conv.py ww2d); it transforms dy itself, so no E planes are needed
+        wgrad2d = (R.wino and src.ld % 4 == 0 and C % 4 == 0 and ldy == C and src.ld >= 32 and C >= 64 and
+                   (R.wino2d == "always" or (R.wino2d and wgrad2d_pays(N, H, W, src.ld, C))))
+        wgrad4 = wgrad4 and not wgrad2d
         E = None
         if wgrad4 and ldy == C and C % 4 == 0:
             E = _empty(4 * N * H * ((W + 3) // 4) * ldy, dev)
@@ -368,7 +380,14 @@ class ConvBnRelu(Op):
                     lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
                     "cvk_conv3x3_fwd(dgrad)"))
             st.grad[src.id] = dX
-        if wgrad4:
+        if wgrad2d:
+            wsb = lib.cvk_conv3x3_wgrad_w2d_workspace_bytes(N, H, W, src.ld, C)
+            ws = R.workspace(wsb, dev)
+            T = lib.cvk_w2d_tiles(N, H, W)
+            _timed(R, "k_w2d_gemm_tn", 18.0 * M * C * self.cin, lambda: check(
+                lib.cvk_conv3x3_wgrad_w2d(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
+                "cvk_conv3x3_wgrad_w2d"), executed=72.0 * (-(-T // 32) * 32) * src.ld * C)
+        elif wgrad4:
             # transposed F(4,3): fastest weight-grad on every layer with >= 64 input channels (tools/bench_conv.py wgrad wwino wwino4)
             wsb = lib.cvk_conv3x3_wgrad_wino4_workspace_bytes(N, H, W, src.ld, C, ldy)
             ws = R.workspace(wsb, dev)
