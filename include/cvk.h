@@ -119,25 +119,33 @@ int cvk_wino4_output(const float* Mo, const float* bias, float* y, float* stats,
  *   stats/counts (both or neither): BatchNorm statistics partials float[2][P][Cout] (sum, M2 about the partial mean) and
  *   float[P] pixel counts, P = cvk_w2d_stat_partials(N,H,W) -> cvk_bn_finalize_counts. */
 int cvk_w2d_tiles(int N, int H, int W);
+int cvk_w2d_tpad(int T);                      /* rows per transform plane: T rounded up to a multiple of 32 (zero rows) */
 int cvk_w2d_stat_partials(int N, int H, int W);
 size_t cvk_conv3x3_w2d_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int cvk_w2d_weight_transform(const float* w, float* U, int Cout, int Cin, void* stream);
 int cvk_conv3x3_w2d(const float* x, const float* U, const float* bias, float* y, float* stats, float* counts, int N, int H,
                     int W, int Cin, int Cout, int ldy, void* workspace, size_t workspace_bytes, void* stream);
-/* the three passes of cvk_conv3x3_w2d, callable (and timed) one by one: V float[36][T][Cin], Mo float[f][36][T][Cout] with
- * f = cvk_w2d_ksplit(T, Cin, Cout) K-range planes (the tiles of the last partial round of workgroups are split in K; the
- * output pass adds the planes in a fixed order and therefore takes Cin as well) */
+/* the three passes of cvk_conv3x3_w2d, callable (and timed) one by one.  V float[36][Tpad][Cin] + 512 bytes of slack,
+ * Tpad = cvk_w2d_tpad(T), rows beyond T zero; Mo float[f][36][T][Cout] with f = cvk_w2d_ksplit(T, Cin, Cout) K-range planes
+ * (the tiles of the last partial round of workgroups are split in K; the output pass adds the planes in a fixed order and
+ * therefore takes Cin as well) */
 int cvk_w2d_ksplit(int T, int Cin, int Cout);
 int cvk_w2d_input_transform(const float* x, float* V, int N, int H, int W, int Cin, void* stream);
 int cvk_w2d_gemm(const float* V, const float* U, float* Mo, int T, int Cin, int Cout, void* stream);
 int cvk_w2d_output(const float* Mo, const float* bias, float* y, float* stats, float* counts, int N, int H, int W, int Cin,
                    int Cout, int ldy, void* stream);
-
 /* weight-grad through the transposed 2-D F(4x4,3x3) (contract of cvk_conv3x3_wgrad; channel counts multiples of 4):
- * dW = G^T [ sum_tiles (A dy A^T) (.) (B^T x B) ] G, 36 GEMMs whose depth is the tile index */
+ * dW = G^T [ sum_tiles (A dy A^T) (.) (B^T x B) ] G, 36 GEMMs whose depth is the tile index.  x == NULL: the first
+ * 36*Tpad*Cin_pad floats of the workspace already hold V = cvk_w2d_input_transform(x) (kept from the forward pass).
+ * Passes: E float[36][Tpad][Cout] (+ slack) = cvk_w2d_dy_transform(dy); P float[f][36][Cout][Cin_pad] = cvk_w2d_gemm_tn(E, V),
+ * f = cvk_w2d_wgrad_ksplit(T, Cin_pad, Cout) depth ranges; dw = cvk_w2d_wgrad_output(P) adds them in a fixed order. */
 size_t cvk_conv3x3_wgrad_w2d_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout);
 int cvk_conv3x3_wgrad_w2d(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad, int Cout,
                           int ld_dy, void* workspace, size_t workspace_bytes, void* stream);
+int cvk_w2d_wgrad_ksplit(int T, int Cin_pad, int Cout);
+int cvk_w2d_dy_transform(const float* dy, int ld_dy, float* E, int N, int H, int W, int Cout, void* stream);
+int cvk_w2d_gemm_tn(const float* E, const float* V, float* P, int T, int Cin_pad, int Cout, void* stream);
+int cvk_w2d_wgrad_output(const float* P, float* dw, int T, int Cin, int Cin_pad, int Cout, void* stream);
 /* weight-grad through the transposed F(4,3) (contract of cvk_conv3x3_wgrad; the workspace also holds the transformed
  * output-gradient planes E1..E4, float[4][N*H*ceil(W/4)][ld_dy], hence the extra ld_dy argument of the size query) */
 size_t cvk_conv3x3_wgrad_wino4_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout, int ld_dy);

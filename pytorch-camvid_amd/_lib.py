@@ -59,6 +59,11 @@ SIGNATURES = {
     "cvk_w2d_gemm": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_wgrad_w2d_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
     "cvk_conv3x3_wgrad_w2d": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
+    "cvk_w2d_tpad": (c_int, [c_int]),
+    "cvk_w2d_wgrad_ksplit": (c_int, [c_int, c_int, c_int]),
+    "cvk_w2d_dy_transform": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_w2d_gemm_tn": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "cvk_w2d_wgrad_output": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_w2d_ksplit": (c_int, [c_int, c_int, c_int]),
     "cvk_w2d_output": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_w2d": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),

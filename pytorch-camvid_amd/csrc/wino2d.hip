@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void k_w2d_weight(const float* __restrict__ Wt
 // each; range p writes plane p of D (plane stride part_stride) and the output transform adds the planes in a fixed order.
 template <int BM, int BK, int NSTG, int WPS>      // tile rows, K slice (floats), LDS stages, waves per SIMD the kernel is built for
 __global__ __launch_bounds__(BM * 2, WPS) void k_w2d_gemm(const float* __restrict__ A, const float* __restrict__ B,
-                                                         float* __restrict__ D, int T, int Nn, int K, int ldd, int tilesM,
-                                                         int tilesN, int split_start, int f, size_t part_stride) {
+                                                         float* __restrict__ D, int T, int Tpad, int Nn, int K, int ldd,
+                                                         int tilesM, int tilesN, int split_start, int f, size_t part_stride) {
     constexpr int NW = BM / 32, ROWS = BM + W2_BN, ROWB = BK * 4, RPP = 1024 / ROWB, NCH = ROWB / 16;   // rows per 1 KiB DMA piece, chunks per row
     constexpr int PIECES = ROWS / RPP, PPW = PIECES / NW, STAGE = ROWS * ROWB, NS = BK / 8;
     constexpr int SWS = NCH == 8 ? 1 : 2;               // swizzle: chunk c of row r at c ^ ((r >> SWS) & (NCH-1))
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(BM * 2, WPS) void k_w2d_gemm(const float* __restric
         D += (size_t)part * part_stride;
     }
     const int tn = id % tilesN, tm = (id / tilesN) % tilesM, xi = id / (tilesN * tilesM);
-    A += (size_t)xi * T * K;
+    A += (size_t)xi * Tpad * K;                           // V planes carry Tpad rows (zero beyond T), the product planes T
     B += (size_t)xi * Nn * K;
     D += (size_t)xi * T * ldd;
     const int row0 = tm * BM, col0 = tn * W2_BN;
@@ -516,10 +516,14 @@ extern "C" int cvk_w2d_ksplit(int T, int Cin, int Cout) {
     return plan_w2d(T, Cin, Cout).f;
 }
 
+static inline int w2_tpad(int T) { return cvk_cdiv(T, 32) * 32; }
+
+extern "C" int cvk_w2d_tpad(int T) { return T > 0 ? w2_tpad(T) : 0; }
+
 extern "C" size_t cvk_conv3x3_w2d_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin < 32 || Cout <= 0) return 0;
     const int T = w2_tiles(N, H, W);
-    return (size_t)36 * T * ((size_t)Cin + (size_t)plan_w2d(T, Cin, Cout).f * Cout) * sizeof(float);
+    return ((size_t)36 * w2_tpad(T) * Cin + 128 + (size_t)36 * T * plan_w2d(T, Cin, Cout).f * Cout) * sizeof(float);
 }
 
 extern "C" int cvk_w2d_weight_transform(const float* w, float* U, int Cout, int Cin, void* stream) {
@@ -533,65 +537,10 @@ extern "C" int cvk_w2d_weight_transform(const float* w, float* U, int Cout, int 
 extern "C" int cvk_w2d_input_transform(const float* x, float* V, int N, int H, int W, int Cin, void* stream) {
     CVK_CHECK_ARG(x && V && N > 0 && H > 0 && W > 0 && Cin >= 4 && Cin % 4 == 0, "cvk_w2d_input_transform: bad arguments");
     CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(V), "cvk_w2d_input_transform: pointers must be 16-byte aligned");
-    const int th = (H + 3) / 4, tw = (W + 3) / 4, T = N * th * tw;
-    const long threads = (long)T * (Cin / 4);
-    hipLaunchKernelGGL(k_w2d_input, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, V, H, W, Cin, th, tw, T, T);
+    const int th = (H + 3) / 4, tw = (W + 3) / 4, T = N * th * tw, Tpad = w2_tpad(T);
+    const long threads = (long)Tpad * (Cin / 4);
+    hipLaunchKernelGGL(k_w2d_input, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, V, H, W, Cin, th, tw, T, Tpad);
     CVK_LAUNCH_RETURN("cvk_w2d_input_transform");
-}
-
-// ---- weight-grad ---------------------------------------------------------------------------------------------------------
-struct W2WPlan { int Tpad, tilesM, tilesN, f; };
-static W2WPlan plan_w2d_wgrad(int T, int Cin_pad, int Cout) {
-    W2WPlan p;
-    p.Tpad = cvk_cdiv(T, 32) * 32;
-    p.tilesM = cvk_cdiv(Cout, 128);
-    p.tilesN = cvk_cdiv(Cin_pad, 128);
-    const int nt = 36 * p.tilesM * p.tilesN, nK = p.Tpad / 32;
-    // depth split: fill the 512 resident workgroups at least twice over, keep >= 4 slices per range, at most 16 planes
-    int f = cvk_cdiv(1024, nt);
-    if (f > nK / 4) f = nK / 4;
-    if (f > 16) f = 16;
-    if (f < 1) f = 1;
-    p.f = f;
-    return p;
-}
-
-extern "C" size_t cvk_conv3x3_wgrad_w2d_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout) {
-    if (N <= 0 || H <= 0 || W <= 0 || Cin_pad <= 0 || Cout <= 0) return 0;
-    const W2WPlan p = plan_w2d_wgrad(w2_tiles(N, H, W), Cin_pad, Cout);
-    // V and E planes (+ one slack depth row each: partial column tiles read past the last row) and the f product planes
-    return ((size_t)36 * p.Tpad * ((size_t)Cin_pad + Cout) + 2 * 128 + (size_t)p.f * 36 * Cout * Cin_pad) * sizeof(float);
-}
-
-extern "C" int cvk_conv3x3_wgrad_w2d(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,
-                                     int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream) {
-    CVK_CHECK_ARG(x && dy && dw && workspace, "cvk_conv3x3_wgrad_w2d: null pointer");
-    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= Cin_pad && Cin_pad % 4 == 0 && Cout > 0 && Cout % 4 == 0 && ld_dy >= Cout && ld_dy % 4 == 0,
-                  "cvk_conv3x3_wgrad_w2d: bad shape (channel counts must be multiples of 4)");
-    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(dy) && cvk_aligned16(workspace), "cvk_conv3x3_wgrad_w2d: pointers must be 16-byte aligned");
-    CVK_CHECK_ARG(workspace_bytes >= cvk_conv3x3_wgrad_w2d_workspace_bytes(N, H, W, Cin_pad, Cout), "cvk_conv3x3_wgrad_w2d: workspace too small");
-    const int th = (H + 3) / 4, tw = (W + 3) / 4, T = N * th * tw;
-    const W2WPlan p = plan_w2d_wgrad(T, Cin_pad, Cout);
-    hipStream_t s = (hipStream_t)stream;
-    float* const V = (float*)workspace;
-    float* const E = V + (size_t)36 * p.Tpad * Cin_pad + 128;
-    float* const P = E + (size_t)36 * p.Tpad * Cout + 128;
-    {
-        const long threads = (long)p.Tpad * (Cin_pad / 4);
-        hipLaunchKernelGGL(k_w2d_input, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, V, H, W, Cin_pad, th, tw, T, p.Tpad);
-    }
-    {
-        const long threads = (long)p.Tpad * (Cout / 4);
-        hipLaunchKernelGGL(k_w2d_dy, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, dy, ld_dy, E, H, W, Cout, th, tw, T, p.Tpad);
-    }
-    hipLaunchKernelGGL(k_w2d_gemm_tn, dim3(36 * p.tilesM * p.tilesN * p.f), dim3(256), 0, s, E, Cout, V, Cin_pad, P, p.Tpad, Cout, Cin_pad,
-                       p.tilesM, p.tilesN, p.f);
-    {
-        const size_t total = (size_t)Cout * Cin;
-        const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-        hipLaunchKernelGGL(k_w2d_wgrad_out, dim3(blocks), dim3(256), 0, s, P, dw, Cout, Cin, Cin_pad, p.f);
-    }
-    CVK_LAUNCH_RETURN("cvk_conv3x3_wgrad_w2d");
 }
 
 extern "C" int cvk_w2d_gemm(const float* V, const float* U, float* Mo, int T, int Cin, int Cout, void* stream) {
@@ -603,8 +552,8 @@ extern "C" int cvk_w2d_gemm(const float* V, const float* U, float* Mo, int T, in
     const dim3 grid(p.split_start + (p.NT - p.split_start) * p.f);
     const size_t part_stride = (size_t)36 * T * Cout;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL((k_w2d_gemm<128, 32, 2, 2>), grid, dim3(256), 0, s, V, U, Mo, T, Cout, Cin, Cout, p.tilesM, p.tilesN, p.split_start,
-                       p.f, part_stride);
+    hipLaunchKernelGGL((k_w2d_gemm<128, 32, 2, 2>), grid, dim3(256), 0, s, V, U, Mo, T, w2_tpad(T), Cout, Cin, Cout, p.tilesM, p.tilesN,
+                       p.split_start, p.f, part_stride);
     CVK_LAUNCH_RETURN("cvk_w2d_gemm");
 }
 
@@ -614,8 +563,8 @@ extern "C" int cvk_w2d_output(const float* Mo, const float* bias, float* y, floa
     CVK_CHECK_ARG(Cout >= 64 && Cout % 4 == 0 && ldy >= Cout && ldy % 4 == 0, "cvk_w2d_output: needs Cout %% 4 == 0, Cout >= 64 (got %d)", Cout);
     CVK_CHECK_ARG((stats == nullptr) == (counts == nullptr), "cvk_w2d_output: stats and counts go together");
     CVK_CHECK_ARG(cvk_aligned16(Mo) && cvk_aligned16(y), "cvk_w2d_output: pointers must be 16-byte aligned");
-    const int th = (H + 3) / 4, tw = (W + 3) / 4, T = N * th * tw;
     CVK_CHECK_ARG(Cin >= 32 && Cin % 32 == 0, "cvk_w2d_output: Cin (the GEMM depth, which fixes the K split of the planes) must be a multiple of 32");
+    const int th = (H + 3) / 4, tw = (W + 3) / 4, T = N * th * tw;
     const int cvn = Cout / 4 >= 64 ? 64 : (Cout / 4 >= 32 ? 32 : 16);
     const int P = cvk_cdiv(T, W2_TB);
     const W2Plan p = plan_w2d(T, Cin, Cout);
@@ -638,9 +587,84 @@ extern "C" int cvk_conv3x3_w2d(const float* x, const float* U, const float* bias
                   "cvk_conv3x3_w2d: workspace too small or misaligned");
     const int T = w2_tiles(N, H, W);
     float* const V = (float*)workspace;
-    float* const Mo = V + (size_t)36 * T * Cin;
+    float* const Mo = V + (size_t)36 * w2_tpad(T) * Cin + 128;
     int rc = cvk_w2d_input_transform(x, V, N, H, W, Cin, stream);
     if (rc == CVK_OK) rc = cvk_w2d_gemm(V, U, Mo, T, Cin, Cout, stream);
     if (rc == CVK_OK) rc = cvk_w2d_output(Mo, bias, y, stats, counts, N, H, W, Cin, Cout, ldy, stream);
+    return rc;
+}
+
+// ---- weight-grad ---------------------------------------------------------------------------------------------------------
+struct W2WPlan { int Tpad, tilesM, tilesN, f; };
+static W2WPlan plan_w2d_wgrad(int T, int Cin_pad, int Cout) {
+    W2WPlan p;
+    p.Tpad = w2_tpad(T);
+    p.tilesM = cvk_cdiv(Cout, 128);
+    p.tilesN = cvk_cdiv(Cin_pad, 128);
+    const int nt = 36 * p.tilesM * p.tilesN, nK = p.Tpad / 32;
+    // depth split: fill the 512 resident workgroups at least twice over, keep >= 4 slices per range, at most 16 planes
+    int f = cvk_cdiv(1024, nt);
+    if (f > nK / 4) f = nK / 4;
+    if (f > 16) f = 16;
+    if (f < 1) f = 1;
+    p.f = f;
+    return p;
+}
+
+extern "C" int cvk_w2d_wgrad_ksplit(int T, int Cin_pad, int Cout) {
+    if (T <= 0 || Cin_pad <= 0 || Cout <= 0) return 0;
+    return plan_w2d_wgrad(T, Cin_pad, Cout).f;
+}
+
+extern "C" int cvk_w2d_dy_transform(const float* dy, int ld_dy, float* E, int N, int H, int W, int Cout, void* stream) {
+    CVK_CHECK_ARG(dy && E && N > 0 && H > 0 && W > 0 && Cout >= 4 && Cout % 4 == 0 && ld_dy >= Cout && ld_dy % 4 == 0, "cvk_w2d_dy_transform: bad arguments");
+    CVK_CHECK_ARG(cvk_aligned16(dy) && cvk_aligned16(E), "cvk_w2d_dy_transform: pointers must be 16-byte aligned");
+    const int th = (H + 3) / 4, tw = (W + 3) / 4, T = N * th * tw, Tpad = w2_tpad(T);
+    const long threads = (long)Tpad * (Cout / 4);
+    hipLaunchKernelGGL(k_w2d_dy, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, ld_dy, E, H, W, Cout, th, tw, T, Tpad);
+    CVK_LAUNCH_RETURN("cvk_w2d_dy_transform");
+}
+
+extern "C" int cvk_w2d_gemm_tn(const float* E, const float* V, float* P, int T, int Cin_pad, int Cout, void* stream) {
+    CVK_CHECK_ARG(E && V && P && T > 0 && Cin_pad > 0 && Cin_pad % 4 == 0 && Cout > 0 && Cout % 4 == 0, "cvk_w2d_gemm_tn: bad arguments");
+    CVK_CHECK_ARG(cvk_aligned16(E) && cvk_aligned16(V) && cvk_aligned16(P), "cvk_w2d_gemm_tn: pointers must be 16-byte aligned");
+    const W2WPlan p = plan_w2d_wgrad(T, Cin_pad, Cout);
+    hipLaunchKernelGGL(k_w2d_gemm_tn, dim3(36 * p.tilesM * p.tilesN * p.f), dim3(256), 0, (hipStream_t)stream, E, Cout, V, Cin_pad, P, p.Tpad,
+                       Cout, Cin_pad, p.tilesM, p.tilesN, p.f);
+    CVK_LAUNCH_RETURN("cvk_w2d_gemm_tn");
+}
+
+extern "C" int cvk_w2d_wgrad_output(const float* P, float* dw, int T, int Cin, int Cin_pad, int Cout, void* stream) {
+    CVK_CHECK_ARG(P && dw && T > 0 && Cin > 0 && Cin <= Cin_pad && Cout > 0, "cvk_w2d_wgrad_output: bad arguments");
+    const W2WPlan p = plan_w2d_wgrad(T, Cin_pad, Cout);
+    const size_t total = (size_t)Cout * Cin;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(k_w2d_wgrad_out, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, dw, Cout, Cin, Cin_pad, p.f);
+    CVK_LAUNCH_RETURN("cvk_w2d_wgrad_output");
+}
+
+extern "C" size_t cvk_conv3x3_wgrad_w2d_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin_pad <= 0 || Cout <= 0) return 0;
+    const W2WPlan p = plan_w2d_wgrad(w2_tiles(N, H, W), Cin_pad, Cout);
+    // V and E planes (+ 512 bytes of slack each: partial column tiles read past the last row) and the f product planes
+    return ((size_t)36 * p.Tpad * ((size_t)Cin_pad + Cout) + 2 * 128 + (size_t)p.f * 36 * Cout * Cin_pad) * sizeof(float);
+}
+
+// x == NULL: the workspace already holds V (cvk_w2d_input_transform of x, e.g. kept from the forward pass) at its start
+extern "C" int cvk_conv3x3_wgrad_w2d(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,
+                                     int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream) {
+    CVK_CHECK_ARG(dy && dw && workspace, "cvk_conv3x3_wgrad_w2d: null pointer");
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= Cin_pad && Cin_pad % 4 == 0 && Cout > 0 && Cout % 4 == 0 && ld_dy >= Cout && ld_dy % 4 == 0,
+                  "cvk_conv3x3_wgrad_w2d: bad shape (channel counts must be multiples of 4)");
+    CVK_CHECK_ARG(cvk_aligned16(workspace) && workspace_bytes >= cvk_conv3x3_wgrad_w2d_workspace_bytes(N, H, W, Cin_pad, Cout),
+                  "cvk_conv3x3_wgrad_w2d: workspace too small or misaligned");
+    const int T = w2_tiles(N, H, W), Tpad = w2_tpad(T);
+    float* const V = (float*)workspace;
+    float* const E = V + (size_t)36 * Tpad * Cin_pad + 128;
+    float* const P = E + (size_t)36 * Tpad * Cout + 128;
+    int rc = x ? cvk_w2d_input_transform(x, V, N, H, W, Cin_pad, stream) : CVK_OK;
+    if (rc == CVK_OK) rc = cvk_w2d_dy_transform(dy, ld_dy, E, N, H, W, Cout, stream);
+    if (rc == CVK_OK) rc = cvk_w2d_gemm_tn(E, V, P, T, Cin_pad, Cout, stream);
+    if (rc == CVK_OK) rc = cvk_w2d_wgrad_output(P, dw, T, Cin, Cin_pad, Cout, stream);
     return rc;
 }

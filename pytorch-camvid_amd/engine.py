@@ -146,26 +146,34 @@ def wgrad2d_pays(N, H, W, k_ch, cout):
     return T >= 256 and k_ch * cout >= 65536
 
 
-def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what="", dgrad_of=None):
+def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what="", dgrad_of=None, keep_v=None):
     """y[N,H,W,ldy] = conv3x3(x[N,H,W,k_ch], w[cout][3][3][k_ch]) (+bias, +BN statistics partials at sp) through the 1-D
     Winograd kernels: weight transform -> implicit GEMMs M_xi -> output transform.  F(4,3) when R.wino4, else F(2,3).
     Data-grad: `w` is a callable returning the rotated/transposed pack (built only if a kernel needs it) and
     dgrad_of = (forward weights [Cout_f][3][3][Cin_f], Cout_f, Cin_f) lets F(4,3) transform straight from them.
     Returns None, or (P, counts pointer) when the statistics partials at sp carry explicit pixel counts (2-D path:
-    P = cvk_w2d_stat_partials partials of [sum | M2] followed by the counts -> cvk_bn_finalize_counts)."""
+    P = cvk_w2d_stat_partials partials of [sum | M2] followed by the counts -> cvk_bn_finalize_counts).  keep_v: a list that
+    receives the transformed input V when the 2-D path runs (the layer's weight-grad reuses it)."""
     M = N * H * W
     if wino2d_ok(k_ch, cout, ldy) and (R.wino2d == "always" or (R.wino2d and wino2d_pays(N, H, W, k_ch, cout))):
         w = w() if callable(w) else w
         U = _empty(36 * cout * k_ch, x.device)
         check(lib.cvk_w2d_weight_transform(w.data_ptr(), U.data_ptr(), cout, k_ch, s), "cvk_w2d_weight_transform")
-        ws = R.workspace(lib.cvk_conv3x3_w2d_workspace_bytes(N, H, W, k_ch, cout), x.device)
         T = lib.cvk_w2d_tiles(N, H, W)
-        V, Mo = ws.data_ptr(), ws.data_ptr() + 4 * 36 * T * k_ch
+        vfl = 36 * lib.cvk_w2d_tpad(T) * k_ch + 128          # V planes + 512 bytes of slack
+        if keep_v is not None:      # the weight-grad of this layer reuses V: its own tensor instead of the shared workspace
+            Vt = _empty(vfl, x.device)
+            keep_v.append(Vt)
+            ws = R.workspace(lib.cvk_conv3x3_w2d_workspace_bytes(N, H, W, k_ch, cout) - 4 * vfl, x.device)
+            V, Mo = Vt.data_ptr(), ws.data_ptr()
+        else:
+            ws = R.workspace(lib.cvk_conv3x3_w2d_workspace_bytes(N, H, W, k_ch, cout), x.device)
+            V, Mo = ws.data_ptr(), ws.data_ptr() + 4 * vfl
         P2 = lib.cvk_w2d_stat_partials(N, H, W)
         cnt = sp + 4 * 2 * P2 * cout if sp is not None else None
         _timed(R, "k_w2d_input", 4.0 * (M + 36 * T) * k_ch, lambda: check(
             lib.cvk_w2d_input_transform(x.data_ptr(), V, N, H, W, k_ch, s), "cvk_w2d_input_transform" + what), "byte")
-        _timed(R, "k_w2d_gemm", flops, lambda: check(lib.cvk_w2d_gemm(V, U.data_ptr(), Mo, T, k_ch, cout, s), "cvk_w2d_gemm" + what),
+        _timed(R, "k_w2d_gemm<128, 32, 2, 2>", flops, lambda: check(lib.cvk_w2d_gemm(V, U.data_ptr(), Mo, T, k_ch, cout, s), "cvk_w2d_gemm" + what),
                executed=72.0 * T * k_ch * cout)       # 36 GEMMs of T x k_ch x cout really run on the matrix pipe
         _timed(R, "k_w2d_output", 4.0 * (36 * T + M) * cout, lambda: check(
             lib.cvk_w2d_output(Mo, bias, y.data_ptr(), sp, cnt, N, H, W, k_ch, cout, ldy, s), "cvk_w2d_output" + what), "byte")
@@ -260,13 +268,20 @@ class ConvBnRelu(Op):
         check(R.lib.cvk_pack_weight_fwd(wc.data_ptr(), out.data_ptr(), self.cout, self.cin, ldx, st.stream), "cvk_pack_weight_fwd")
         return out
 
-    def _conv(self, R, st, X, wk, b, y, stats, kind):
+    def _wgrad2d(self, R):
+        """Does this layer's weight-grad run through the transposed 2-D F(4x4,3x3) (csrc/wino2d.hip)?  Channel-heavy layers:
+        25-40 % faster than the transposed F(4,3) from 256 x 256 channels up (tools/bench_conv.py ww2d)."""
+        src, C = self.src, self.cout
+        return bool(R.wino and src.ld % 4 == 0 and C % 4 == 0 and pad4(C) == C and src.ld >= 32 and C >= 64 and
+                    (R.wino2d == "always" or (R.wino2d and wgrad2d_pays(src.N, src.H, src.W, src.ld, C))))
+
+    def _conv(self, R, st, X, wk, b, y, stats, kind, keep_v=None):
         """y = conv3x3(X, wk) + b (+ BN statistics partials): Winograd kernels when eligible, else direct."""
         lib, s, src = R.lib, st.stream, self.src
         N, H, W, M, C, ldy = src.N, src.H, src.W, src.M, self.cout, pad4(self.cout)
         sp = stats.data_ptr() if stats is not None else None
         if wino_ok(R, src.ld, ldy):
-            return wino_conv(R, lib, s, X, wk, b.data_ptr(), y, sp, N, H, W, src.ld, C, ldy, 18.0 * M * C * self.cin)
+            return wino_conv(R, lib, s, X, wk, b.data_ptr(), y, sp, N, H, W, src.ld, C, ldy, 18.0 * M * C * self.cin, keep_v=keep_v)
         else:
             _timed(R, conv_kernel_name("fwd", ldy, src.ld), 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy, s),
@@ -287,13 +302,14 @@ class ConvBnRelu(Op):
         bnp = _empty(4 * ldy, dev)                      # mean | rstd | scale | shift
         pm, pr, psc, psh = (bnp.data_ptr() + 4 * ldy * i for i in range(4))
         conv, bn = self.holder.conv_bn()
+        keep_v = [] if (st.need_grad and self._wgrad2d(R)) else None      # transformed input, reused by the weight-grad
         if st.training:
             P = (M + _lib.CVK_STAT_ROWS - 1) // _lib.CVK_STAT_ROWS
             Pm = max(P, lib.cvk_w2d_stat_partials(N, H, W))     # room for either partial layout (+ the 2-D path's counts)
             stats = _empty(2 * Pm * C + Pm, dev)
             if M <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {[N, C, H, W]}")
-            counted = self._conv(R, st, X, wk, b, y, stats, "fwd")
+            counted = self._conv(R, st, X, wk, b, y, stats, "fwd", keep_v=keep_v)
             wsb = lib.cvk_bn_finalize_workspace_bytes(P, C)
             ws = R.workspace(wsb, dev)
             track = bn.track_running_stats and bn.running_mean is not None
@@ -308,21 +324,21 @@ class ConvBnRelu(Op):
                                                  pm, pr, psc, psh, *run, mom, float(bn.eps), ws.data_ptr(), wsb, s),
                       "cvk_bn_finalize_counts")
         else:
-            self._conv(R, st, X, wk, b, y, None, "fwd")
+            self._conv(R, st, X, wk, b, y, None, "fwd", keep_v=keep_v)
             check(lib.cvk_bn_eval_params(gamma.data_ptr(), beta.data_ptr(), bn.running_mean.data_ptr(),
                                          bn.running_var.data_ptr(), pm, pr, psc, psh, C, float(bn.eps), s), "cvk_bn_eval_params")
         out = R.alloc_act(st, dst.buf, dev)
         _timed(R, "k_bn_relu_apply", 8.0 * M * C, lambda: check(
             lib.cvk_bn_relu_apply(y.data_ptr(), ldy, psc, psh, dst.cview(out), N, H, W, C, s), "cvk_bn_relu_apply"), "byte")
         if st.need_grad:
-            st.saved[self.idx] = (y, bnp)
+            st.saved[self.idx] = (y, bnp, keep_v[0] if keep_v else None)
 
     def bwd(self, R, st):
         if st.plan.bf16:
             return self._bwd_bf16(R, st)
         lib, s = R.lib, st.stream
         src, dst = self.src, self.dst
-        y, bnp = st.saved.pop(self.idx)
+        y, bnp, Vkept = st.saved.pop(self.idx)
         X = st.act[src.id]
         dev = X.device
         N, H, W = src.N, src.H, src.W
@@ -341,8 +357,7 @@ class ConvBnRelu(Op):
         wgrad4 = R.wino and src.ld >= 32 and C > 32 and (R.wino4 == "always" or (R.wino4 and src.ld >= 64))
         # channel-heavy layers: transposed 2-D F(4x4,3x3), 36 GEMMs over the tile index (25-40 % faster than the transposed
         # F(4,3) from 256x256 channels up: tools/bench_conv.py ww2d); it transforms dy itself, so no E planes are needed
-        wgrad2d = (R.wino and src.ld % 4 == 0 and C % 4 == 0 and ldy == C and src.ld >= 32 and C >= 64 and
-                   (R.wino2d == "always" or (R.wino2d and wgrad2d_pays(N, H, W, src.ld, C))))
+        wgrad2d = self._wgrad2d(R)
         wgrad4 = wgrad4 and not wgrad2d
         E = None
         if wgrad4 and ldy == C and C % 4 == 0:
@@ -381,12 +396,23 @@ class ConvBnRelu(Op):
                     "cvk_conv3x3_fwd(dgrad)"))
             st.grad[src.id] = dX
         if wgrad2d:
-            wsb = lib.cvk_conv3x3_wgrad_w2d_workspace_bytes(N, H, W, src.ld, C)
-            ws = R.workspace(wsb, dev)
             T = lib.cvk_w2d_tiles(N, H, W)
+            Tp = lib.cvk_w2d_tpad(T)
+            vfl, efl = 36 * Tp * src.ld + 128, 36 * Tp * C + 128
+            f = lib.cvk_w2d_wgrad_ksplit(T, src.ld, C)
+            if Vkept is None:           # forward ran another kernel (e.g. the mode changed in between): transform x now
+                Vkept = _empty(vfl, dev)
+                _timed(R, "k_w2d_input", 4.0 * (M + 36 * T) * src.ld, lambda: check(
+                    lib.cvk_w2d_input_transform(X.data_ptr(), Vkept.data_ptr(), N, H, W, src.ld, s), "cvk_w2d_input_transform(wgrad)"), "byte")
+            ws = R.workspace(4 * (efl + f * 36 * C * src.ld), dev)
+            Ep, Pp = ws.data_ptr(), ws.data_ptr() + 4 * efl
+            _timed(R, "k_w2d_dy", 4.0 * (M + 36 * T) * C, lambda: check(
+                lib.cvk_w2d_dy_transform(dy.data_ptr(), ldy, Ep, N, H, W, C, s), "cvk_w2d_dy_transform"), "byte")
             _timed(R, "k_w2d_gemm_tn", 18.0 * M * C * self.cin, lambda: check(
-                lib.cvk_conv3x3_wgrad_w2d(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
-                "cvk_conv3x3_wgrad_w2d"), executed=72.0 * (-(-T // 32) * 32) * src.ld * C)
+                lib.cvk_w2d_gemm_tn(Ep, Vkept.data_ptr(), Pp, T, src.ld, C, s), "cvk_w2d_gemm_tn"), executed=72.0 * Tp * src.ld * C)
+            _timed(R, "k_w2d_wgrad_out", 4.0 * (36 * f + 9) * C * self.cin, lambda: check(
+                lib.cvk_w2d_wgrad_output(Pp, gw, T, self.cin, src.ld, C, s), "cvk_w2d_wgrad_output"), "byte")
+            del Vkept
         elif wgrad4:
             # transposed F(4,3): fastest weight-grad on every layer with >= 64 input channels (tools/bench_conv.py wgrad wwino wwino4)
             wsb = lib.cvk_conv3x3_wgrad_wino4_workspace_bytes(N, H, W, src.ld, C, ldy)
