@@ -426,30 +426,38 @@ __global__ __launch_bounds__(256) void k_w2d_output(const float* __restrict__ Mo
         const float* const mp = Mo + (size_t)tile * ldm + c;
         // GEMM tile of plane xi: xi * tmn + (tile / BM) * tilesN + c / 128; ids >= split_start carry f K-range planes
         const int xi0 = f > 1 ? (split_start - ((tile / BM) * tilesN + c / W2_BN) + tmn - 1) / tmn : 36;
-        f32x4 z[4][6];
+        // column j of the 6 x 6 product tile: A^T along the rows, then its contribution to the four output columns
+        // (A^T[.][j] = 1,0,0,0 | 1,1,1,1 | 1,-1,1,-1 | 1,2,4,8 | 1,-2,4,-8 | 0,0,0,1): 16 accumulators instead of a 4 x 6 array,
+        // (forcing <= 128 registers through launch bounds made hipcc spill: 4x slower; it hoists all 36 loads at 215-230)
+        f32x4 o[4][4];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            f32x4 m[6], y4[4];
+            f32x4 m[6], z[4];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 m[i] = *reinterpret_cast<const f32x4*>(mp + (size_t)(i * 6 + j) * plane);
                 if (i * 6 + j >= xi0)
                     for (int k = 1; k < f; ++k) m[i] += *reinterpret_cast<const f32x4*>(mp + (size_t)(k * 36 + i * 6 + j) * plane);
             }
-            w2_at(m, y4);
+            w2_at(m, z);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) z[i][j] = y4[i];
+            for (int i = 0; i < 4; ++i) {
+                if (j == 0) { o[i][0] = z[i]; }
+                else if (j == 1) { o[i][0] += z[i]; o[i][1] = z[i]; o[i][2] = z[i]; o[i][3] = z[i]; }
+                else if (j == 2) { o[i][0] += z[i]; o[i][1] -= z[i]; o[i][2] += z[i]; o[i][3] -= z[i]; }
+                else if (j == 3) { o[i][0] += z[i]; o[i][1] += 2.f * z[i]; o[i][2] += 4.f * z[i]; o[i][3] += 8.f * z[i]; }
+                else if (j == 4) { o[i][0] += z[i]; o[i][1] -= 2.f * z[i]; o[i][2] += 4.f * z[i]; o[i][3] -= 8.f * z[i]; }
+                else { o[i][3] += z[i]; }
+            }
         }
         const int yb = 4 * ty, xb = 4 * tx;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f32x4 o[4];
-            w2_at(z[i], o);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (yb + i < H && xb + j < W) {
-                    *reinterpret_cast<f32x4*>(Y + ((size_t)(n * H + yb + i) * W + xb + j) * ldy + c) = o[j] + sh;
-                    if (STATS) { s1 += o[j]; s2 += o[j] * o[j]; }
+                    *reinterpret_cast<f32x4*>(Y + ((size_t)(n * H + yb + i) * W + xb + j) * ldy + c) = o[i][j] + sh;
+                    if (STATS) { s1 += o[i][j]; s2 += o[i][j] * o[i][j]; }
                 }
             }
         }
