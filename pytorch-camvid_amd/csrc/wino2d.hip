@@ -379,16 +379,22 @@ __global__ __launch_bounds__(256) void k_w2d_wgrad_out(const float* __restrict__
         const int ci = (int)(idx % Ci);
         const size_t co = idx / Ci;
         const float* const pp = P + co * Cip + ci;
+        // all 36 values of a plane are loaded before they are added to the running sums: 36 independent loads in flight per
+        // plane (a per-element loop over the planes left one dependent load chain per thread: 0.28 of the HBM rate)
+        float m36[36];
+#pragma unroll
+        for (int q = 0; q < 36; ++q) m36[q] = pp[(size_t)q * plane];
+        for (int k = 1; k < f; ++k) {
+            float v[36];
+#pragma unroll
+            for (int q = 0; q < 36; ++q) v[q] = pp[(size_t)(k * 36 + q) * plane];
+#pragma unroll
+            for (int q = 0; q < 36; ++q) m36[q] += v[q];
+        }
         float t[6][3];          // rows a of P, transformed along b
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-            float m[6];
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                float v = pp[(size_t)(a * 6 + b) * plane];
-                for (int k = 1; k < f; ++k) v += pp[(size_t)(k * 36 + a * 6 + b) * plane];
-                m[b] = v;
-            }
+            const float* const m = m36 + a * 6;
             const float s12 = m[1] + m[2], d12 = m[2] - m[1], s34 = m[3] + m[4], d34 = m[3] - m[4];
             t[a][0] = 0.25f * m[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
             t[a][1] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;

@@ -272,8 +272,14 @@ class ConvBnRelu(Op):
         """Does this layer's weight-grad run through the transposed 2-D F(4x4,3x3) (csrc/wino2d.hip)?  Channel-heavy layers:
         25-40 % faster than the transposed F(4,3) from 256 x 256 channels up (tools/bench_conv.py ww2d)."""
         src, C = self.src, self.cout
-        return bool(R.wino and src.ld % 4 == 0 and C % 4 == 0 and pad4(C) == C and src.ld >= 32 and C >= 64 and
-                    (R.wino2d == "always" or (R.wino2d and wgrad2d_pays(src.N, src.H, src.W, src.ld, C))))
+        if not (R.wino and src.ld % 4 == 0 and C % 4 == 0 and pad4(C) == C and src.ld >= 32 and C >= 64 and R.wino2d):
+            return False
+        if R.wino2d == "always" or wgrad2d_pays(src.N, src.H, src.W, src.ld, C):
+            return True
+        # 128 <-> 256 channels at 180x240: the x transform alone makes it a tie with the transposed F(4,3), but the forward
+        # pass of these layers already runs the 2-D path and leaves V behind (0.78 of the F(4,3) time without that pass)
+        return (wino_ok(R, src.ld, pad4(C)) and wino2d_ok(src.ld, C, pad4(C)) and wino2d_pays(src.N, src.H, src.W, src.ld, C)
+                and src.ld * C >= 32768)
 
     def _conv(self, R, st, X, wk, b, y, stats, kind, keep_v=None):
         """y = conv3x3(X, wk) + b (+ BN statistics partials): Winograd kernels when eligible, else direct."""
