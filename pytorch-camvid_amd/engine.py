@@ -158,7 +158,8 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
     if wino2d_ok(k_ch, cout, ldy) and (R.wino2d == "always" or (R.wino2d and wino2d_pays(N, H, W, k_ch, cout))):
         w = w() if callable(w) else w
         U = _empty(36 * cout * k_ch, x.device)
-        check(lib.cvk_w2d_weight_transform(w.data_ptr(), U.data_ptr(), cout, k_ch, s), "cvk_w2d_weight_transform")
+        _timed(R, "k_w2d_weight", 4.0 * (9 + 36) * cout * k_ch, lambda: check(
+            lib.cvk_w2d_weight_transform(w.data_ptr(), U.data_ptr(), cout, k_ch, s), "cvk_w2d_weight_transform"), "byte")
         T = lib.cvk_w2d_tiles(N, H, W)
         vfl = 36 * lib.cvk_w2d_tpad(T) * k_ch + 128          # V planes + 512 bytes of slack
         if keep_v is not None:      # the weight-grad of this layer reuses V: its own tensor instead of the shared workspace
@@ -181,11 +182,13 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
     if R.wino4 == "always" or (R.wino4 and wino4_pays(N, H, W, k_ch, ldy)):
         U = _empty(6 * cout * 3 * k_ch, x.device)
         if dgrad_of is not None and dgrad_of[1] == k_ch and dgrad_of[2] == cout:       # no channel padding on either side
-            check(lib.cvk_wino4_weight_transform_dgrad(dgrad_of[0].data_ptr(), U.data_ptr(), dgrad_of[1], dgrad_of[2], s),
-                  "cvk_wino4_weight_transform_dgrad")
+            _timed(R, "k_wino4_weight_dgrad", 4.0 * (9 + 18) * cout * k_ch, lambda: check(
+                lib.cvk_wino4_weight_transform_dgrad(dgrad_of[0].data_ptr(), U.data_ptr(), dgrad_of[1], dgrad_of[2], s),
+                "cvk_wino4_weight_transform_dgrad"), "byte")
         else:
             w = w() if callable(w) else w
-            check(lib.cvk_wino4_weight_transform(w.data_ptr(), U.data_ptr(), cout, k_ch, s), "cvk_wino4_weight_transform")
+            _timed(R, "k_wino4_weight", 4.0 * (9 + 18) * cout * k_ch, lambda: check(
+                lib.cvk_wino4_weight_transform(w.data_ptr(), U.data_ptr(), cout, k_ch, s), "cvk_wino4_weight_transform"), "byte")
         ws = R.workspace(lib.cvk_conv3x3_wino4_workspace_bytes(N, H, W, k_ch, ldy), x.device)
         ksplit = lib.cvk_conv3x3_wino4_ksplit(N, H, W, k_ch, ldy)
         _timed(R, conv_kernel_name("wino4", ldy), flops, lambda: check(
@@ -195,7 +198,8 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
     else:
         w = w() if callable(w) else w
         U = _empty(4 * cout * 3 * k_ch, x.device)
-        check(lib.cvk_wino_weight_transform(w.data_ptr(), U.data_ptr(), cout, k_ch, s), "cvk_wino_weight_transform")
+        _timed(R, "k_wino_weight", 4.0 * (9 + 12) * cout * k_ch, lambda: check(
+            lib.cvk_wino_weight_transform(w.data_ptr(), U.data_ptr(), cout, k_ch, s), "cvk_wino_weight_transform"), "byte")
         ws = R.workspace(lib.cvk_conv3x3_wino_workspace_bytes(N, H, W, ldy), x.device)
         _timed(R, conv_kernel_name("wino", ldy), flops, lambda: check(
             lib.cvk_conv3x3_wino_gemm(x.data_ptr(), U.data_ptr(), ws.data_ptr(), N, H, W, k_ch, cout, ldy, s), "cvk_conv3x3_wino_gemm" + what))
@@ -389,7 +393,8 @@ class ConvBnRelu(Op):
 
             def packed():       # [Cin_pad][9][Cout_pad] rotated + transposed filter for the data-grad-as-forward kernels
                 wd_ = _empty(src.ld * 9 * ldy, dev)
-                check(lib.cvk_pack_weight_dgrad(wc.data_ptr(), wd_.data_ptr(), C, self.cin, src.ld, ldy, s), "cvk_pack_weight_dgrad")
+                _timed(R, "k_pack_weight_dgrad", 4.0 * 9 * (C * self.cin + src.ld * ldy), lambda: check(
+                    lib.cvk_pack_weight_dgrad(wc.data_ptr(), wd_.data_ptr(), C, self.cin, src.ld, ldy, s), "cvk_pack_weight_dgrad"), "byte")
                 return wd_
             dX = _empty(M * src.ld, dev).view(N, H, W, src.ld)
             if wino_ok(R, ldy, src.ld):
