@@ -65,6 +65,24 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Barrier that retires a buffer: every wave first drains ITS OWN LDS reads (s_waitcnt lgkmcnt(0)), then s_barrier.  A raw
+// s_barrier does not do that: hipcc sinks the MFMAs that consume the last fragment reads of a step below the barrier, so
+// those reads are still queued in the LDS pipeline when the barrier releases the other waves — and those immediately
+// issue the DMA (or ds_write) that refills the very buffer being read.  Normally the read wins by a microsecond; it loses
+// when a co-resident workgroup floods the LDS queue (the 64 KiB statistics scratch of a finishing workgroup): single
+// weight fragments of the k-th step were then read AFTER their ring slot had been refilled — wrong accumulators in ~1 %
+// of the tiles, timing dependent, only at grids with two workgroups per CU (found by tools/det_bf16.py at the configs[3]
+// sizes; the aggregate-level test had passed).  lgkmcnt(0) costs nothing here: the reads were issued a whole step earlier.
+__device__ __forceinline__ void lds_retire_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+// the same with all of the wave's DMAs landed (before the statistics scratch overlays the operand buffers)
+__device__ __forceinline__ void lds_drain_barrier() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 __device__ __forceinline__ bf16x8 lds_read16(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
 // BN = output channels per workgroup (128 or 64).  STATS: fused BatchNorm statistics partials (training forward).
@@ -234,11 +252,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16s(const __bf16* __restrict_
                 if (sidx == SPC - 1) wait_vm<0>();
                 else wait_vm<SLABPS>();
             }
-            __builtin_amdgcn_s_barrier();
+            lds_retire_barrier();
         }
     }
-    wait_vm<0>();                       // drain the redundant tail DMAs before LDS is reused below
-    __builtin_amdgcn_s_barrier();
+    lds_drain_barrier();                // tail DMAs landed, every wave's fragment reads done: LDS is reused below
 
     // ---- epilogue -----------------------------------------------------------------------------------------------------
     // acc[tc][tp][i]: output channel n0 + wc*64 + tc*32 + (i&3) + 8*(i>>2) + 4*h, pixel (y0 + wp*TP + tp, x0 + r)
@@ -432,7 +449,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv_bf16s_strip(const __bf
         if (t == t_begin) wait_vm<PPW>();
         else if (t == t_begin + 1) wait_vm<PPW + NST>();
         else wait_vm<PPW + 2 * NST>();
-        __builtin_amdgcn_s_barrier();                                   // slab t complete for everyone; buffer of tile t-1 free
+        lds_retire_barrier();                                           // slab t complete for everyone; buffer of tile t-1 free
         dma_slab(min(t + 2, last), smem_addr + ((bi + 2) % NBUF) * SLABB);
 
         const char* const slab = smem + bi * SLABB + TP * wp * (HP * ROWB);      // this wave's first halo row
@@ -499,8 +516,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv_bf16s_strip(const __bf
         }
     }
     if (!STATS) return;
-    wait_vm<0>();                                                       // the redundant tail DMAs must not land in the scratch below
-    __builtin_amdgcn_s_barrier();
+    lds_drain_barrier();                                                // tail DMAs landed, fragment reads done: the scratch overlays the slabs
     float* const red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -819,7 +835,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_bf16s(const __bf16* __restrict
                 tile_body(buf, std::false_type{});
             }
             wait_vm<0>();
-            __builtin_amdgcn_s_barrier();
+            lds_retire_barrier();
             cur ^= 1;
         }
         // ---- partial slab: [split][co][tap][ci] fp32 -----------------------------------------------------------------------

@@ -17,3 +17,11 @@ __device__ __forceinline__ unsigned cvk_lds_addr(const void* p) {
 }
 
 template <int N> __device__ __forceinline__ void cvk_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Barrier that retires an LDS buffer which the next instructions refill: the wave's own LDS reads are drained first.  hipcc
+// sinks the MFMAs consuming the last fragment reads below a raw s_barrier, so those reads would still be queued when another
+// wave's refill is issued (csrc/conv_bf16s.hip lds_retire_barrier has the failure this caused).
+__device__ __forceinline__ void cvk_lds_retire_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}

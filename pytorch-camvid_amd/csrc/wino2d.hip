@@ -200,7 +200,7 @@ __global__ __launch_bounds__(BM * 2, WPS) void k_w2d_gemm(const float* __restric
     int buf = 0;
     for (int ks = kb; ks < ke; ++ks) {
         cvk_wait_vm<(NSTG - 2) * PPW>();                  // this wave's pieces of slice ks (later slices may be in flight)
-        __builtin_amdgcn_s_barrier();                     // slice ks complete; stage of slice ks-1 free
+        cvk_lds_retire_barrier();                         // slice ks complete; stage of slice ks-1 free (its reads drained)
         issue(min(ks + NSTG - 1, ke - 1), buf == 0 ? NSTG - 1 : buf - 1);      // (buf + NSTG - 1) % NSTG
         const char* const st = smem + buf * STAGE;
 #pragma unroll
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void k_w2d_gemm_tn(const float* __restrict_
     int buf = 0;
     for (int ks = kb; ks < ke; ++ks) {
         cvk_wait_vm<0>();
-        __builtin_amdgcn_s_barrier();
+        cvk_lds_retire_barrier();
         issue(min(ks + 1, ke - 1), buf ^ 1);
         const char* const st = smem + buf * STAGE;
 #pragma unroll

@@ -208,6 +208,59 @@ def test_unet_bf16_vs_emulation_2x96x128():
         assert torch.equal(a.grad, b.grad)
 
 
+@pytest.mark.parametrize("case", [(4, 360, 480, 64, 128), (4, 180, 240, 256, 256), (4, 45, 60, 1024, 1024), (4, 720, 960, 64, 64), (4, 360, 480, 128, 64)])
+def test_bf16_kernels_fullsize_exact_and_deterministic(case):
+    """Every bf16-storage conv kernel at grids with two workgroups per CU (the configs[3] layer sizes), three times on the
+    same operands: forward with and without the fused statistics epilogue, data-grad and weight-grad must be bitwise
+    identical run to run, the two forward variants must agree bitwise, and both must match an fp32 accumulation of the same
+    bf16 operands (the library's direct fp32 kernel) within one bf16 rounding.  Regression test for a race that only showed at
+    these sizes: fragment reads still queued in the LDS pipeline when the barrier released the refill of their ring slot
+    (csrc/conv_bf16s.hip lds_retire_barrier) — ~1 % of the tiles wrong by a few K steps, invisible to aggregate checks."""
+    from pytorch_camvid_amd import _lib
+    from pytorch_camvid_amd._lib import check
+    lib = _lib.load()
+    N, H, W, Ci, Co = case
+    g = torch.Generator(device="cuda").manual_seed(sum(case))
+    x = torch.randn(N, H, W, Ci, device=dev(), generator=g).to(BF)
+    wd = torch.randn(Co, 3, 3, Ci, device=dev(), generator=g) * (2.0 / (9 * Ci)) ** 0.5
+    b = torch.randn(Co, device=dev(), generator=g) * 0.1
+    wp = torch.zeros(lib.cvk_bf16s_rows_pad(Co) * 9 * Ci, device=dev(), dtype=BF)
+    check(lib.cvk_pack_weight_fwd_bf16(wd.data_ptr(), wp.data_ptr(), Co, Ci, Ci, stream()))
+    P = lib.cvk_bf16s_stat_partials_c(N, H, W, Ci, Co)
+    ld_dy = max(32, Co)
+    dy = torch.zeros(N, H, W, ld_dy, device=dev(), dtype=BF)
+    dy[..., :Co] = torch.randn(N, H, W, Co, device=dev(), generator=g).to(BF)
+    wdp = torch.zeros(lib.cvk_bf16s_rows_pad(Ci) * 9 * ld_dy, device=dev(), dtype=BF)
+    check(lib.cvk_pack_weight_dgrad_bf16(wd.data_ptr(), wdp.data_ptr(), Co, Ci, ld_dy, stream()))
+    wsb = lib.cvk_conv3x3_wgrad_bf16s_workspace_bytes(N, H, W, Ci, Co)
+    ws = torch.empty(wsb, device=dev(), dtype=torch.uint8)
+    yref = torch.empty(N, H, W, Co, device=dev())
+    xf = x.float().contiguous(); wf = wd.to(BF).float().contiguous()
+    check(lib.cvk_conv3x3_fwd(xf.data_ptr(), wf.data_ptr(), b.data_ptr(), yref.data_ptr(), None, N, H, W, Ci, Co, Co, stream()))
+    del xf
+    tol = 2.0 ** -8 * yref.abs() + 2e-3 * float(yref.abs().max()) * 2.0 ** -8 + 1e-6
+    ref = None
+    for rep in range(3):
+        y = torch.full((N, H, W, Co), float("nan"), device=dev(), dtype=BF)
+        st = torch.full((2 * P * Co + P,), float("nan"), device=dev())
+        check(lib.cvk_conv3x3_bf16s(x.data_ptr(), wp.data_ptr(), b.data_ptr(), y.data_ptr(), st.data_ptr(), st.data_ptr() + 8 * P * Co, N, H, W, Ci, Co, Co, stream()))
+        y2 = torch.full((N, H, W, Co), float("nan"), device=dev(), dtype=BF)
+        check(lib.cvk_conv3x3_bf16s(x.data_ptr(), wp.data_ptr(), b.data_ptr(), y2.data_ptr(), None, None, N, H, W, Ci, Co, Co, stream()))
+        dx = torch.full((N, H, W, Ci), float("nan"), device=dev(), dtype=BF)
+        check(lib.cvk_conv3x3_bf16s(dy.data_ptr(), wdp.data_ptr(), None, dx.data_ptr(), None, None, N, H, W, ld_dy, Ci, Ci, stream()))
+        dw = torch.full((Co, 3, 3, Ci), float("nan"), device=dev())
+        check(lib.cvk_conv3x3_wgrad_bf16s(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, H, W, Ci, Ci, Co, ld_dy, ws.data_ptr(), wsb, stream()))
+        assert torch.equal(y.view(torch.int16), y2.view(torch.int16)), (case, rep, "statistics epilogue changed the result")
+        assert int(((y.float() - yref).abs() > tol).sum()) == 0, (case, rep, "forward vs fp32 accumulation")
+        cur = (y.view(torch.int16), st.view(torch.int32), dx.view(torch.int16), dw.view(torch.int32))
+        if ref is None:
+            assert all(bool(torch.isfinite(t).all()) for t in (y.float(), st, dx.float(), dw))
+            ref = tuple(t.clone() for t in cur)
+        else:
+            for name, a, c in zip(("y", "stats", "dx", "dw"), ref, cur):
+                assert torch.equal(a, c), (case, rep, name, int((a != c).sum()))
+
+
 def test_unet_bf16_config3_workload():
     """BASELINE.json configs[3]: UNet 4x3x720x960 through the bf16 path.  (1) against the emulation of the same rounding
     points at the same workload (bf16emu fixture, tolerance 4 x its noise floor); (2) against the REFERENCE's fp32 run
@@ -219,13 +272,11 @@ def test_unet_bf16_config3_workload():
     tol_e = d["bf16_emul_tolerance"]["unet_4x720x960"]
     m = _net_metrics(net, out, loss, emu)
     print("bf16 vs emulation 4x720x960:", m, tol_e)
-    # Element-wise logits are NOT compared at this depth and size: every conv+BN+ReLU layer of the randomly initialised net
-    # amplifies a relative perturbation ~1.25x (x170 over 23 layers; make_drift.py: the emulation against ITSELF under a 1e-6
-    # input perturbation already differs by 8 % in the logits), and two fp32 implementations of the same rounding points
-    # differ by ~1e-5 in every conv output (summation order), which flips bf16 roundings in every layer: the logits
-    # decorrelate (measured 0.59 relative L2) while every aggregate below agrees.  The element-wise check is done where it is
-    # meaningful: per kernel (test_conv_bf16s_raw_abi), over two layers (test_two_block_stage_vs_emulation) and at 2x96x128.
-    for k in ("loss_abs", "logits_sq_rel", "grad_norm_rel_median", "grad_norm_rel_max"):
+    # Element-wise logits included: a randomly initialised UNet amplifies a relative perturbation ~1.25x per conv+BN+ReLU layer
+    # (make_drift.py: the emulation against ITSELF under a 1e-6 input perturbation moves the logits by 7.8 %), hence the
+    # tolerance of 4 x that noise floor; the device sits at 9.4 %.  (Until the LDS race fixed in round 2 — see
+    # test_bf16_kernels_fullsize_exact_and_deterministic — this figure was 59 % and had been put down to chaos: wrong.)
+    for k in ("loss_abs", "logits_rel_l2", "logits_sq_rel", "grad_norm_rel_median", "grad_norm_rel_max"):
         assert m[k] <= tol_e[k], (k, m[k], tol_e[k])
     ref = dict(np.load(os.path.join(G, "unet_s0_4x720x960.npz")))
     tol_r = d["bf16_tolerance"]["unet_4x720x960"]
@@ -233,3 +284,8 @@ def test_unet_bf16_config3_workload():
     print("bf16 vs reference fp32 4x720x960:", r, tol_r)
     assert r["loss_abs"] <= tol_r["loss_abs"] and r["logits_sq_rel"] <= 5e-3
     assert r["grad_norm_rel_median"] <= tol_r["grad_norm_rel_median"] and r["grad_norm_rel_max"] <= tol_r["grad_norm_rel_max"]
+    # bitwise reproducible at this size too (grids with two workgroups per CU: see test_bf16_kernels_fullsize_exact_and_deterministic)
+    net2, out2, loss2 = _run_unet_bf16((4, 720, 960))
+    assert loss2 == loss and torch.equal(out, out2)
+    for a, b in zip(net.parameters(), net2.parameters()):
+        assert torch.equal(a.grad, b.grad)
