@@ -228,7 +228,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dout, 
                 k2[j] = use_batch_stats ? dgamma[c + j] * invM : 0.f;
             }
         }
-        for (int m = mbeg + pr; m < mend; m += ppp) {
+#pragma unroll 4
+        for (int m = mbeg + pr; m < mend; m += ppp) {     // four iterations' loads in flight (the sums stay in order)
             const VT d = *reinterpret_cast<const VT*>(dout + dm.off(m) + c);
             const VT yy = *reinterpret_cast<const VT*>(y + (size_t)m * ldy + c);
             VT o;
@@ -469,7 +470,7 @@ extern "C" int cvk_bn_relu_apply(const float* y, int ldy, const float* scale, co
 extern "C" int cvk_bn_bwd_blocks(int M) {
     if (M <= 0) return 0;
     int pb = cvk_cdiv(M, 16);
-    pb = pb < 512 ? pb : 512;       // 2 blocks per CU keep the stream bandwidth-bound; fewer partial rows keep the fp64 finalize short
+    pb = pb < 512 ? pb : 512;       // 2 blocks per CU keep the stream bandwidth-bound (4 per CU measured no faster); fewer partial rows keep the fp64 finalize short
     const int rows = cvk_cdiv(M, pb);
     return cvk_cdiv(M, rows);       // exactly the number of row blocks the kernels launch: every partial row gets written
 }
