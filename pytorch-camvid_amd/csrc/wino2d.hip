@@ -18,7 +18,9 @@
 namespace {
 
 constexpr int W2_BN = 128;          // output columns (channels) per workgroup
-constexpr int W2_TB = 16;           // tiles per statistics partial / output-transform block
+// tiles per statistics partial / output-transform block: 16, or 4 for layers with few tiles (16 would leave the 45x60 and
+// 22x30 levels with fewer blocks than CUs)
+__host__ __device__ inline int w2_tb(int T) { return T >= 8192 ? 16 : 4; }
 
 // ---- 1-D transforms (applied along rows, then along columns) ---------------------------------------------------------------
 // B^T d
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(256) void k_w2d_wgrad_out(const float* __restrict__
 }
 
 // ---- output transform: M [36][T][ldm] -> y [N,H,W,ldy] (+bias, + BatchNorm statistics partials with pixel counts) ----------------
-// block = W2_TB tiles x CH channels (CH = 4 * cvn <= 256); thread = one channel vector, tiles pl apart
+// block = w2_tb(T) tiles x CH channels (CH = 4 * cvn <= 256); thread = one channel vector, tiles pl apart
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_w2d_output(const float* __restrict__ Mo, int ldm, const float* __restrict__ bias,
                                                    float* __restrict__ Y, int ldy, float* __restrict__ stats,
@@ -426,8 +428,9 @@ __global__ __launch_bounds__(256) void k_w2d_output(const float* __restrict__ Mo
     if (cok && bias != nullptr) sh = *reinterpret_cast<const f32x4*>(bias + c);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     const size_t plane = (size_t)T * ldm;
-    const int tile_end = min(T, (int)(blockIdx.x + 1) * W2_TB);
-    for (int tile = blockIdx.x * W2_TB + lanep; tile < tile_end && cok; tile += pl) {
+    const int TB = w2_tb(T);
+    const int tile_end = min(T, (int)(blockIdx.x + 1) * TB);
+    for (int tile = blockIdx.x * TB + lanep; tile < tile_end && cok; tile += pl) {
         const int n = tile / (th * tw), rr = tile - n * th * tw, ty = rr / tw, tx = rr - ty * tw;
         const float* const mp = Mo + (size_t)tile * ldm + c;
         // GEMM tile of plane xi: xi * tmn + (tile / BM) * tilesN + c / 128; ids >= split_start carry f K-range planes
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(256) void k_w2d_output(const float* __restrict__ Mo
     __syncthreads();
     if (t < cvn && c < Cout) {
         int cnt = 0;
-        for (int tile = blockIdx.x * W2_TB; tile < tile_end; ++tile) {
+        for (int tile = blockIdx.x * TB; tile < tile_end; ++tile) {
             const int rr = tile % (th * tw), ty = rr / tw, tx = rr - ty * tw;
             cnt += min(4, H - 4 * ty) * min(4, W - 4 * tx);
         }
@@ -502,7 +505,7 @@ inline int w2_tiles(int N, int H, int W) { return N * ((H + 3) / 4) * ((W + 3) /
 
 extern "C" int cvk_w2d_tiles(int N, int H, int W) { return (N > 0 && H > 0 && W > 0) ? w2_tiles(N, H, W) : 0; }
 
-extern "C" int cvk_w2d_stat_partials(int N, int H, int W) { return (N > 0 && H > 0 && W > 0) ? cvk_cdiv(w2_tiles(N, H, W), W2_TB) : 0; }
+extern "C" int cvk_w2d_stat_partials(int N, int H, int W) { return (N > 0 && H > 0 && W > 0) ? cvk_cdiv(w2_tiles(N, H, W), w2_tb(w2_tiles(N, H, W))) : 0; }
 
 // How the 36 GEMMs are cut into workgroups: tile height, grid, and the K split of the last partial round.
 struct W2Plan { int BM, tilesM, tilesN, NT, split_start, f; };
@@ -580,7 +583,7 @@ extern "C" int cvk_w2d_output(const float* Mo, const float* bias, float* y, floa
     CVK_CHECK_ARG(Cin >= 32 && Cin % 32 == 0, "cvk_w2d_output: Cin (the GEMM depth, which fixes the K split of the planes) must be a multiple of 32");
     const int th = (H + 3) / 4, tw = (W + 3) / 4, T = N * th * tw;
     const int cvn = Cout / 4 >= 64 ? 64 : (Cout / 4 >= 32 ? 32 : 16);
-    const int P = cvk_cdiv(T, W2_TB);
+    const int P = cvk_cdiv(T, w2_tb(T));
     const W2Plan p = plan_w2d(T, Cin, Cout);
     dim3 grid(P, cvk_cdiv(Cout / 4, cvn));
     hipStream_t s = (hipStream_t)stream;

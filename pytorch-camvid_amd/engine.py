@@ -320,7 +320,7 @@ class ConvBnRelu(Op):
             if M <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {[N, C, H, W]}")
             counted = self._conv(R, st, X, wk, b, y, stats, "fwd", keep_v=keep_v)
-            wsb = lib.cvk_bn_finalize_workspace_bytes(P, C)
+            wsb = lib.cvk_bn_finalize_workspace_bytes(Pm, C)
             ws = R.workspace(wsb, dev)
             track = bn.track_running_stats and bn.running_mean is not None
             mom = 0.1 if bn.momentum is None else float(bn.momentum)
