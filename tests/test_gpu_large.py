@@ -164,3 +164,58 @@ def test_unet_batch24_concat_beyond_2gib():
     assert all(torch.equal(a, p.grad) and torch.isfinite(p.grad).all() for a, p in zip(g1, net.parameters()))
     del net, x, t, g1
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("case", [(8, 45, 60, 1024, 512), (8, 22, 30, 512, 1024), (8, 90, 120, 256, 256), (8, 44, 60, 512, 256), (3, 37, 50, 320, 192)])
+def test_winograd2d_raw_abi_fullsize_exact_and_deterministic(case):
+    """The 2-D Winograd F(4x4,3x3) entry points through the raw C ABI at the real deep-layer grids of the batch-8 step (tile
+    counts that need several rounds of workgroups, the K-split tail and its extra product planes, ragged tile edges:
+    45 = 11*4 + 1, 22, 30, 37, 50 are not multiples of 4): forward with the statistics partials and weight-grad, three
+    times on the same operands — bitwise identical, and equal to the library's direct fp32 kernels within the rounding the
+    CPU restatement of the transforms measures (tests/test_drift_cpu.py::test_winograd2d_rounding: 2.8e-6 relative L2, x3)."""
+    from pytorch_camvid_amd import _lib
+    from pytorch_camvid_amd._lib import check
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    N, H, W, Ci, Co = case
+    g = torch.Generator(device="cuda").manual_seed(sum(case))
+    x = torch.relu(torch.randn(N, H, W, Ci, device=dev(), generator=g))
+    w = (torch.rand(Co, 9 * Ci, device=dev(), generator=g) * 2 - 1) / (9 * Ci) ** 0.5
+    b = torch.randn(Co, device=dev(), generator=g) * 0.1
+    dy = torch.randn(N, H, W, Co, device=dev(), generator=g)
+    M = N * H * W
+    # reference: direct implicit-GEMM kernels of the same library
+    yref = torch.empty(N, H, W, Co, device=dev())
+    check(lib.cvk_conv3x3_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), yref.data_ptr(), None, N, H, W, Ci, Co, Co, s))
+    dwref = torch.empty(Co, 9 * Ci, device=dev())
+    wsb = lib.cvk_conv3x3_wgrad_workspace_bytes(N, H, W, Ci, Co)
+    ws = torch.empty(wsb, device=dev(), dtype=torch.uint8)
+    check(lib.cvk_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dwref.data_ptr(), N, H, W, Ci, Ci, Co, Co, ws.data_ptr(), wsb, s))
+    U = torch.empty(36 * Co * Ci, device=dev())
+    check(lib.cvk_w2d_weight_transform(w.data_ptr(), U.data_ptr(), Co, Ci, s))
+    wsf = lib.cvk_conv3x3_w2d_workspace_bytes(N, H, W, Ci, Co)
+    wsw = lib.cvk_conv3x3_wgrad_w2d_workspace_bytes(N, H, W, Ci, Co)
+    P = lib.cvk_w2d_stat_partials(N, H, W)
+    ref = None
+    for rep in range(3):
+        wf = torch.empty(wsf, device=dev(), dtype=torch.uint8)
+        y = torch.full((N, H, W, Co), float("nan"), device=dev())
+        st = torch.full((2 * P * Co + P,), float("nan"), device=dev())
+        check(lib.cvk_conv3x3_w2d(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), st.data_ptr(), st.data_ptr() + 8 * P * Co,
+                                  N, H, W, Ci, Co, Co, wf.data_ptr(), wsf, s))
+        ww = torch.empty(wsw, device=dev(), dtype=torch.uint8)
+        dw = torch.full((Co, 9 * Ci), float("nan"), device=dev())
+        check(lib.cvk_conv3x3_wgrad_w2d(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, H, W, Ci, Ci, Co, Co, ww.data_ptr(), wsw, s))
+        rel = float((y - yref).norm() / yref.norm())
+        relw = float((dw - dwref).norm() / dwref.norm())
+        assert rel < 9e-6 and relw < 9e-6, (case, rep, rel, relw)
+        cnt = st[2 * P * Co:]
+        assert float(cnt.sum()) == M
+        ssum = st[:P * Co].view(P, Co).double().sum(0)
+        assert float((ssum - y.double().sum(dim=(0, 1, 2))).abs().max()) <= 1e-4 * float(y.double().abs().sum(dim=(0, 1, 2)).max())
+        cur = (y.view(torch.int32), st.view(torch.int32), dw.view(torch.int32))
+        if ref is None:
+            ref = tuple(t.clone() for t in cur)
+        else:
+            for name, a, c in zip(("y", "stats", "dw"), ref, cur):
+                assert torch.equal(a, c), (case, rep, name, int((a != c).sum()))
