@@ -460,10 +460,118 @@ extern "C" int cvk_pack_weight_dgrad(const float* w_src, float* dst, int Cout, i
     CVK_LAUNCH_RETURN("cvk_pack_weight_dgrad");
 }
 
+// ---- weight-grad of a conv with <= 16 output channels and 64 input channels (the 12-class head, reference models/unet.py) ----
+// dW[co][tap][ci] = sum_px dy[px][co] * x[px+tap][ci] is a 12 x 576 matrix reduced over 1.4 M pixels: the 32-row MFMA tiles of
+// k_conv3x3_wgrad waste 62 % of the matrix pipe on padding rows and it ran at 26 TFLOP/s (0.73 ms, the most expensive
+// "small" kernel of the step).  Here v_mfma_f32_16x16x4_f32: A = dy^T (16 output channels x 4 consecutive pixels of a
+// row), B = x at the tap's shift (4 pixels x 16 channels) -> 36 accumulator blocks (9 taps x 4 channel blocks, 144 VGPRs).
+// No LDS staging: a lane's B operand for the FOUR channel blocks of a tap is one 16-byte load (channel block q holds
+// channels {4j + q}: lane j's float4 at channel 4j is its element of all four blocks), so a 4-pixel group costs 9 coalesced
+// 1 KiB loads + one dy load for 36 MFMAs; the 9x re-read of x across taps/rows is served by L1/L2.
+// Waves walk (image row, 128-pixel segment) units; a workgroup's four waves are added through LDS tap by tap and leave ONE
+// partial slab [co][tap][ci] per workgroup; k_wgrad_reduce_small adds the slabs in a fixed order (deterministic).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int WGS_SEG = 32;            // 4-pixel groups per unit
+
+__global__ __launch_bounds__(256, 2) void k_wgrad_smallco(const float* __restrict__ X, const float* __restrict__ DY,
+                                                         float* __restrict__ slab, int N, int H, int W, int Cout, int ld_dy) {
+    constexpr int Cin = 64;
+    __shared__ float red[3][16][64];   // [wave-1][q*4+i][lane]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, k = lane >> 4;
+    const int groups = (W + 3) >> 2, segs = (groups + WGS_SEG - 1) / WGS_SEG;
+    const int units = N * H * segs;
+    const int wg = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int nwaves = gridDim.x * 4;
+    f32x4v acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t][q] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int u = wg * 4 + wave; u < units; u += nwaves) {
+        const int seg = u % segs, row = u / segs;          // row = n*H + y
+        const int y = row % H;
+        const float* const dyrow = DY + (size_t)row * W * ld_dy;
+        const float* const xrow = X + (size_t)row * W * Cin + 4 * j;
+        const int g0 = seg * WGS_SEG, g1 = min(groups, (seg + 1) * WGS_SEG);
+        const bool rowok[3] = {y > 0, true, y + 1 < H};                          // wave-uniform
+        // the ten loads of group g+1 are issued before the 36 MFMAs of group g (two waves per SIMD do not hide an L2 round trip)
+        float a_cur, a_nxt = 0.f;
+        f32x4v v_cur[9], v_nxt[9];
+        auto load = [&](int g, float& a, f32x4v* v) {
+            const int px = 4 * g + k;
+            a = (j < Cout && px < W) ? dyrow[(size_t)px * ld_dy + j] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int xx = px + t % 3 - 1;
+                v[t] = (rowok[t / 3] & ((unsigned)xx < (unsigned)W)) ? *reinterpret_cast<const f32x4v*>(xrow + ((long)(t / 3 - 1) * W + xx) * Cin) : zero4;
+            }
+        };
+        load(g0, a_cur, v_cur);
+        for (int g = g0; g < g1; ++g) {
+            if (g + 1 < g1) load(g + 1, a_nxt, v_nxt);
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[t][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, v_cur[t][q], acc[t][q], 0, 0, 0);
+            a_cur = a_nxt;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) v_cur[t] = v_nxt[t];
+        }
+    }
+    // acc[tap][q][i] = dW[co = 4*k + i][tap][ci = 4*j + q]; waves 1..3 hand their sums to wave 0, tap by tap
+    float* const out = slab + (size_t)blockIdx.x * Cout * 9 * Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (wave > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) red[wave - 1][q * 4 + i][lane] = acc[t][q][i];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = 4 * k + i;
+                f32x4v r;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r[q] = ((acc[t][q][i] + red[0][q * 4 + i][lane]) + red[1][q * 4 + i][lane]) + red[2][q * 4 + i][lane];
+                if (co < Cout) *reinterpret_cast<f32x4v*>(out + ((size_t)co * 9 + t) * Cin + 4 * j) = r;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// dw[i] = sum over the slabs, fixed order: 64 outputs x 4 slab segments per block, segments combined through LDS
+__global__ __launch_bounds__(256) void k_wgrad_reduce_small(const float* __restrict__ slab, float* __restrict__ dw, int splits, int n) {
+    __shared__ float part[4][64];
+    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;
+    const int per = (splits + 3) / 4, s0 = sg * per, s1 = min(splits, s0 + per);
+    float a = 0.f, b = 0.f;
+    if (i < n) {
+        int s = s0;
+        for (; s + 2 <= s1; s += 2) { a += slab[(size_t)s * n + i]; b += slab[(size_t)(s + 1) * n + i]; }
+        if (s < s1) a += slab[(size_t)s * n + i];
+    }
+    part[sg][o] = a + b;
+    __syncthreads();
+    if (sg == 0 && i < n) dw[i] = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+}
+
+constexpr int WGS_BLOCKS = 512;        // two workgroups per CU
+
+static inline bool wgrad_smallco(int Cin, int Cin_pad, int Cout) { return Cout <= 16 && Cin == 64 && Cin_pad == 64; }
+
 extern "C" size_t cvk_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin_pad <= 0 || Cout <= 0) return 0;
     const WgradPlan p = plan_wgrad(N * H * W, Cin_pad, Cout);
-    return (size_t)p.splits * Cout * 9 * Cin_pad * sizeof(float);
+    const size_t need = (size_t)p.splits * Cout * 9 * Cin_pad * sizeof(float);
+    const size_t small = wgrad_smallco(Cin_pad, Cin_pad, Cout) ? (size_t)WGS_BLOCKS * Cout * 9 * Cin_pad * sizeof(float) : 0;
+    return need > small ? need : small;
 }
 
 extern "C" int cvk_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_pad,
@@ -475,6 +583,20 @@ extern "C" int cvk_conv3x3_wgrad(const float* x, const float* dy, float* dw, int
     CVK_CHECK_ARG((long)N * H * W < (1L << 31) - 512, "cvk_conv3x3_wgrad: tensor too large for 32-bit pixel indices");
     CVK_CHECK_ARG((long)H * W * W < (1L << 32), "cvk_conv3x3_wgrad: frame too large for the multiply-high row/column split");
     const int M = N * H * W, Ktot = 9 * Cin_pad;
+    if (wgrad_smallco(Cin, Cin_pad, Cout) && (long)M * 64 < (1L << 40)) {
+        const size_t need_s = (size_t)WGS_BLOCKS * Cout * 9 * Cin_pad * sizeof(float);
+        if (workspace_bytes < need_s) {
+            cvk_set_error("cvk_conv3x3_wgrad: workspace %zu < %zu bytes", workspace_bytes, need_s);
+            return CVK_EWORKSPACE;
+        }
+        hipStream_t s = (hipStream_t)stream;
+        const int units = N * H * cvk_cdiv(cvk_cdiv(W, 4), WGS_SEG);
+        const int blocks = units < WGS_BLOCKS * 4 ? cvk_cdiv(units, 4) : WGS_BLOCKS;
+        hipLaunchKernelGGL(k_wgrad_smallco, dim3(blocks), dim3(256), 0, s, x, dy, (float*)workspace, N, H, W, Cout, ld_dy);
+        const int n = Cout * 9 * Cin;
+        hipLaunchKernelGGL(k_wgrad_reduce_small, dim3(cvk_cdiv(n, 64)), dim3(256), 0, s, (const float*)workspace, dw, blocks, n);
+        CVK_LAUNCH_RETURN("cvk_conv3x3_wgrad");
+    }
     const WgradPlan p = plan_wgrad(M, Cin_pad, Cout);
     // x and dy may exceed 2 GiB: a workgroup addresses only its own pixel range (window_rsrc)
     CVK_CHECK_ARG((long)(p.chunk + 2 * W + 2 + 2 * BK) * (Cin_pad > ld_dy ? Cin_pad : ld_dy) * 4 < (1L << 31), "cvk_conv3x3_wgrad: one pixel range exceeds the 2 GiB buffer-addressing limit");

@@ -216,6 +216,8 @@ def conv_kernel_name(kind, n_cols, k_ch=32):
     if kind == "wino":
         return "k_conv3x3_wino<128, 128, 2, 2>" if n_cols > 64 else ("k_conv3x3_wino<128, 64, 2, 2>" if n_cols > 32 else "k_conv3x3_wino<128, 32, 4, 1>")
     if kind == "wgrad":
+        if n_cols <= 16 and k_ch == 64:
+            return "k_wgrad_smallco"
         t = "128, 128, 2, 2" if n_cols > 64 else ("64, 128, 2, 2" if n_cols > 32 else "32, 256, 1, 4")
         if 32 < n_cols <= 64 and k_ch * 9 <= 64:
             t = "64, 64, 2, 2"

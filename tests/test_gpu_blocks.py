@@ -366,3 +366,37 @@ def test_winograd43_fuzz_against_direct_kernels(shape):
                 den = b.double().norm().item()
                 rel = (a - b).double().norm().item() / max(den, 1e-12)
                 assert torch.isfinite(a).all() and rel <= 1e-4, (shape, mode, what, rel)
+
+
+@pytest.mark.parametrize("case", [(2, 9, 13, 12), (1, 1, 1, 12), (3, 37, 130, 12), (2, 45, 60, 16), (1, 7, 5, 3), (2, 360, 480, 12)])
+def test_wgrad_small_cout_raw_abi(case):
+    """cvk_conv3x3_wgrad for the 12-class head (<= 16 output channels, 64 input channels: the 16x16x4-MFMA kernel
+    k_wgrad_smallco) against the fp64 weight gradient of torch's conv2d on the same operands: ragged widths (W % 4 != 0,
+    W < 4), single pixels, several row segments per image row (W > 128), the full head size; bitwise reproducible."""
+    from pytorch_camvid_amd import _lib
+    from pytorch_camvid_amd._lib import check
+    import torch.nn.functional as F
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    N, H, W, Co = case
+    Ci = 64
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Ci, H, W, generator=g); dy = torch.randn(N, Co, H, W, generator=g)
+    xr = x.double(); wr = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(xr, wr, None, padding=1) * dy.double()).sum().backward()
+    want = wr.grad.permute(0, 2, 3, 1).contiguous()                      # [Co][3][3][Ci]
+    ld = (Co + 3) // 4 * 4
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev())
+    dyd = torch.zeros(N, H, W, ld); dyd[..., :Co] = dy.permute(0, 2, 3, 1); dyd = dyd.to(dev())
+    wsb = lib.cvk_conv3x3_wgrad_workspace_bytes(N, H, W, Ci, Co)
+    outs = []
+    for rep in range(2):
+        ws = torch.empty(wsb, device=dev(), dtype=torch.uint8)
+        dw = torch.full((Co, 3, 3, Ci), float("nan"), device=dev())
+        check(lib.cvk_conv3x3_wgrad(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), N, H, W, Ci, Ci, Co, ld, ws.data_ptr(), wsb, s))
+        outs.append(dw)
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    got = outs[0].cpu().double()
+    rel = float((got - want).norm() / want.norm())
+    assert rel < 2e-6, (case, rel)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=2e-5 * float(want.abs().max()))
