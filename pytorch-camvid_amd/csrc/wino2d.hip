@@ -197,6 +197,13 @@ __global__ __launch_bounds__(BM * 2, WPS) void k_w2d_gemm(const float* __restric
     const int lane_off = r * ROWB + ((h ^ ((r >> SWS) & (NCH - 1))) << 4);
     const int a_off = wm * 64 * ROWB + lane_off, b_off = (BM + wn * 64) * ROWB + lane_off;
 
+    // Co-resident workgroups start together and run equal tiles, so their prologues (DMA round trip before the first MFMA) and
+    // store epilogues would coincide for the whole launch; the second wave of workgroups (blockIdx 256..511: the second one on
+    // each CU) starts half a tile late, and every later workgroup inherits the phase shift (it starts when a predecessor
+    // finishes): 1-4 % per layer.  (Tried without effect on this kernel: pinned fragment prefetch one k-group ahead — two
+    // waves per SIMD already hide the LDS latency — and 4- or 5-deep rings of 16-float slices.)
+    if (((blockIdx.x >> 8) & 1) && blockIdx.x < 512)
+        for (int i = 0; i < (ke - kb) * (BK / 8) / 8; ++i) __builtin_amdgcn_s_sleep(127);
 #pragma unroll
     for (int d = 0; d < NSTG - 1; ++d) issue(min(kb + d, ke - 1), d);
     int buf = 0;
