@@ -400,3 +400,42 @@ def test_wgrad_small_cout_raw_abi(case):
     rel = float((got - want).norm() / want.norm())
     assert rel < 2e-6, (case, rel)
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=2e-5 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("case", [(2, 9, 13, 12), (1, 1, 1, 12), (3, 37, 130, 12), (2, 45, 60, 16), (1, 7, 5, 3), (2, 360, 480, 12)])
+def test_conv_small_cout_raw_abi(case):
+    """cvk_conv3x3_fwd (direct implicit-GEMM kernel, 32-column tile) at the 12-class head's channel counts (<= 16 output
+    channels, 64 input channels) against torch's fp64 conv2d: output, bias, the fused BatchNorm statistics partials (64-pixel granules
+    that cross image rows and images, a ragged last granule), channel counts that are not multiples of 4; bitwise
+    reproducible; with and without statistics."""
+    from pytorch_camvid_amd import _lib
+    from pytorch_camvid_amd._lib import check
+    import torch.nn.functional as F
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    N, H, W, Co = case
+    Ci = 64
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn(N, Ci, H, W, generator=g); w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5; b = torch.randn(Co, generator=g)
+    want = F.conv2d(x.double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1).contiguous()      # [N,H,W,Co]
+    ld = (Co + 3) // 4 * 4
+    M = N * H * W; P = (M + 63) // 64
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev()); wd = w.permute(0, 2, 3, 1).contiguous().to(dev()); bd = b.to(dev())
+    outs = []
+    for rep in range(2):
+        y = torch.full((N, H, W, ld), float("nan"), device=dev()); st = torch.full((2 * P * Co,), float("nan"), device=dev())
+        check(lib.cvk_conv3x3_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), st.data_ptr(), N, H, W, Ci, Co, ld, s))
+        outs.append((y, st))
+    assert torch.equal(outs[0][0][..., :Co], outs[1][0][..., :Co]) and torch.equal(outs[0][1], outs[1][1])
+    y2 = torch.full((N, H, W, ld), float("nan"), device=dev())
+    check(lib.cvk_conv3x3_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y2.data_ptr(), None, N, H, W, Ci, Co, ld, s))
+    assert torch.equal(y2[..., :Co], outs[0][0][..., :Co])
+    got = outs[0][0][..., :Co].cpu().double()
+    assert float((got - want).norm() / want.norm()) < 2e-6
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=2e-5 * float(want.abs().max()))
+    st = outs[0][1].cpu().double().view(2, P, Co)
+    flat = want.view(M, Co)
+    for p in (0, P // 2, P - 1):
+        rows = flat[64 * p:min(M, 64 * p + 64)]
+        np.testing.assert_allclose(st[0, p].numpy(), rows.sum(0).numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(st[1, p].numpy(), ((rows - rows.mean(0)) ** 2).sum(0).numpy(), rtol=2e-3, atol=1e-4)
