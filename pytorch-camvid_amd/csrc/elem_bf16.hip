@@ -352,6 +352,41 @@ __global__ void k_bilinear_fwd_bf16(const __bf16* __restrict__ x, __bf16* __rest
     }
 }
 
+// LDS-tiled forward for 128-channel chunks (pointwise.hip k_bilinear_fwd_tiled has the reasoning): a block = 4 x 32 output
+// pixels x 128 channels; the <= 4 x 18 input pixels of the tile are loaded once as raw 16-byte vectors, the taps read LDS.
+// Same float operations as the flat kernel.
+__global__ __launch_bounds__(256) void k_bilinear_fwd_bf16_tiled(const __bf16* __restrict__ x, __bf16* __restrict__ out, int H, int W, int C,
+                                                                float sy, float sx, int tilesX) {
+    constexpr int TY = 4, TX = 32, IY = 4, IX = 18;
+    __shared__ __attribute__((aligned(16))) __bf16 tile[IY * IX * 16 * 8];
+    const int Ho = 2 * H, Wo = 2 * W;
+    const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX, c0 = blockIdx.y * 128, n = blockIdx.z;
+    const int yo0 = ty * TY, xo0 = tx * TX;
+    const int iy0 = make_tap(yo0, sy, H).i0, ix0 = make_tap(xo0, sx, W).i0;
+    const int t = threadIdx.x, cv = t & 15;
+    const __bf16* const xb = x + ((size_t)n * H * W) * C + c0 + cv * 8;
+    for (int p = t >> 4; p < IY * IX; p += 16) {
+        const int ry = p / IX, rx = p - ry * IX;
+        const int iy = min(iy0 + ry, H - 1), ix = min(ix0 + rx, W - 1);
+        *reinterpret_cast<u32x4*>(tile + (p * 16 + cv) * 8) = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * W + ix) * C);
+    }
+    __syncthreads();
+    for (int p = t >> 4; p < TY * TX; p += 16) {
+        const int oy = p / TX, ox = p - oy * TX;
+        const int yo = yo0 + oy, xo = xo0 + ox;
+        if (yo >= Ho || xo >= Wo) continue;
+        const Tap ty_ = make_tap(yo, sy, H), tx_ = make_tap(xo, sx, W);
+        const int r0 = (ty_.i0 - iy0) * IX, r1 = (ty_.i1 - iy0) * IX, q0 = tx_.i0 - ix0, q1 = tx_.i1 - ix0;
+        const FV<8> v00 = load_bf16<8>(tile + ((r0 + q0) * 16 + cv) * 8), v01 = load_bf16<8>(tile + ((r0 + q1) * 16 + cv) * 8);
+        const FV<8> v10 = load_bf16<8>(tile + ((r1 + q0) * 16 + cv) * 8), v11 = load_bf16<8>(tile + ((r1 + q1) * 16 + cv) * 8);
+        FV<8> o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            o.v[j] = ty_.l0 * (tx_.l0 * v00.v[j] + tx_.l1 * v01.v[j]) + ty_.l1 * (tx_.l0 * v10.v[j] + tx_.l1 * v11.v[j]);
+        store_bf16<8>(out + (((size_t)n * Ho + yo) * Wo + xo) * C + c0 + cv * 8, o);
+    }
+}
+
 template <int V>
 __global__ void k_bilinear_bwd_bf16(const __bf16* __restrict__ dout, __bf16* __restrict__ dx, int N, int H, int W, int C, float sy, float sx) {
     const int Ho = 2 * H, Wo = 2 * W, cvn = C / V;
@@ -505,6 +540,12 @@ static inline float ac_scale(int n_in, int n_out) { return n_out > 1 ? (float)(n
 
 extern "C" int cvk_bilinear_up2_fwd_bf16(const void* x, void* out, int N, int H, int W, int C, void* stream) {
     CVK_CHECK_ARG(x && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && cvk_aligned16(x) && cvk_aligned16(out), "cvk_bilinear_up2_fwd_bf16: bad arguments");
+    if (C % 128 == 0 && H >= 2 && W >= 2 && N <= 65535 && C / 128 <= 65535) {
+        const int tilesX = cvk_cdiv(2 * W, 32), tilesY = cvk_cdiv(2 * H, 4);
+        hipLaunchKernelGGL(k_bilinear_fwd_bf16_tiled, dim3(tilesX * tilesY, C / 128, N), dim3(256), 0, (hipStream_t)stream,
+                           (const __bf16*)x, (__bf16*)out, H, W, C, ac_scale(H, 2 * H), ac_scale(W, 2 * W), tilesX);
+        CVK_LAUNCH_RETURN("cvk_bilinear_up2_fwd_bf16");
+    }
     hipLaunchKernelGGL(k_bilinear_fwd_bf16<8>, dim3(grid_for((long)N * 4 * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
                        (const __bf16*)x, (__bf16*)out, N, H, W, C, ac_scale(H, 2 * H), ac_scale(W, 2 * W));
     CVK_LAUNCH_RETURN("cvk_bilinear_up2_fwd_bf16");
