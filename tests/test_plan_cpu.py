@@ -75,7 +75,8 @@ def test_kernel_name_mirror():
     assert engine.conv_kernel_name("fwd", 64, 4) == "k_conv3x3_igemm<128, 64, 2, 2, true, false>"
     assert engine.conv_kernel_name("dgrad", 64, 12) == "k_conv3x3_igemm<128, 64, 2, 2, false, false>"
     assert engine.conv_kernel_name("wgrad", 64, 4) == "k_conv3x3_wgrad<64, 64, 2, 2>"
-    assert engine.conv_kernel_name("wgrad", 12, 64) == "k_conv3x3_wgrad<32, 256, 1, 4>"
+    assert engine.conv_kernel_name("wgrad", 12, 64) == "k_wgrad_smallco"          # the 12-class head: 16x16x4-MFMA kernel
+    assert engine.conv_kernel_name("wgrad", 12, 128) == "k_conv3x3_wgrad<32, 256, 1, 4>"
     assert engine.conv_kernel_name("wino4", 128) == "k_conv3x3_wino4<128, 128, 2, 2>"
     assert engine.conv_kernel_name("wino4", 64) == "k_conv3x3_wino4<128, 64, 2, 2>"
 
@@ -90,3 +91,19 @@ def test_winograd_variant_choice_per_layer():
     assert not pays(8, 360, 480, 64, 12)                                           # the logits layer
     assert not pays(2, 6, 8, 512, 512) and not pays(1, 45, 60, 64, 64)             # golden-sized layers
     assert pays(50, 360, 480, 64, 64)                                              # large batches
+
+
+def test_winograd2d_choice_per_layer():
+    """engine.wino2d_pays / wgrad2d_pays: the 2-D F(4x4,3x3) path takes the channel-heavy layers of the batch-8 step
+    (measured per layer, tools/bench_conv.py) and leaves the 64/128-channel levels and golden-sized geometries to F(4,3)."""
+    f, w = engine.wino2d_pays, engine.wgrad2d_pays
+    for shape in ((8, 90, 120, 256, 256), (8, 45, 60, 256, 512), (8, 45, 60, 512, 512), (8, 22, 30, 512, 1024),
+                  (8, 22, 30, 1024, 1024), (8, 44, 60, 1024, 512), (8, 45, 60, 1024, 512), (8, 90, 120, 512, 256)):
+        assert f(*shape) and w(*shape), shape
+    assert f(8, 180, 240, 256, 128) and f(8, 180, 240, 128, 256)                  # forward / data-grad only: many tiles
+    assert not w(8, 180, 240, 256, 128)                                            # weight-grad there only with the forward's V
+    for shape in ((8, 360, 480, 64, 64), (8, 360, 480, 128, 64), (8, 180, 240, 128, 128), (8, 180, 240, 64, 128),
+                  (8, 90, 120, 128, 256), (8, 360, 480, 64, 12)):
+        assert not f(*shape) and not w(*shape), shape
+    assert not f(2, 6, 8, 512, 512) and not w(2, 6, 8, 512, 512)                  # golden-sized layers: fewer than 256 tiles
+    assert engine.wino2d_ok(256, 256, 256) and not engine.wino2d_ok(48, 256, 256) and not engine.wino2d_ok(256, 12, 12)
