@@ -650,6 +650,17 @@ extern "C" int cvk_conv3x3_bf16s(const void* x, const void* w, const float* bias
             else       { if (strip_nw == 4) CVK_STRIP(1, false, 4); else CVK_STRIP(1, false, 8); }
         }
 #undef CVK_STRIP
+    } else if (!stats && Cin == 64 && Cout == 128 && !no_strip) {
+        // 64 -> 128 channels without statistics (the data-grad of ups4 / up4.0): with only two channel slices the tile
+        // kernel is all prologue and epilogue (650 TFLOP/s); two passes of the 64 x 64 strip kernel over the halves of the
+        // filter — the input strip is read twice, 0.7 GB more — run at ~900
+        const int ntiles = (int)P;
+        const int slen = strip_len_for(ntiles);
+        const int nstrips = cvk_cdiv(ntiles, slen);
+        for (int half = 0; half < 2; ++half)
+            hipLaunchKernelGGL((k_conv_bf16s_strip<2, false, 8>), dim3(nstrips), dim3(512), 0, s, (const __bf16*)x,
+                               (const __bf16*)w + (size_t)half * 64 * 9 * Cin, bias ? bias + 64 * half : nullptr, (__bf16*)y + 64 * half,
+                               stats, counts, H, W, 64, ldy, tilesX, tilesY, ntiles, slen, nstrips);
     } else if (bn == 128) { if (stats) CVK_BS_LAUNCH(128, true); else CVK_BS_LAUNCH(128, false); }
     else { if (stats) CVK_BS_LAUNCH(64, true); else CVK_BS_LAUNCH(64, false); }
 #undef CVK_BS_LAUNCH

@@ -31,6 +31,7 @@ def rb(t):
 
 CONV_CASES = [  # (N, H, W, Cin, Cout)  ragged tiles, one / many channel slices, both output tiles, stem- and head-like padding
     (2, 8, 32, 32, 64), (1, 13, 45, 64, 128), (2, 9, 70, 32, 12), (1, 24, 40, 128, 256), (3, 5, 7, 64, 64), (1, 17, 33, 96, 192),
+    (2, 19, 37, 128, 64),      # its data-grad is 64 -> 128 channels: two passes of the 64 x 64 strip kernel
 ]
 
 
@@ -250,14 +251,16 @@ def test_bf16_kernels_fullsize_exact_and_deterministic(case):
         check(lib.cvk_conv3x3_bf16s(dy.data_ptr(), wdp.data_ptr(), None, dx.data_ptr(), None, None, N, H, W, ld_dy, Ci, Ci, stream()))
         dw = torch.full((Co, 3, 3, Ci), float("nan"), device=dev())
         check(lib.cvk_conv3x3_wgrad_bf16s(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, H, W, Ci, Ci, Co, ld_dy, ws.data_ptr(), wsb, stream()))
-        assert torch.equal(y.view(torch.int16), y2.view(torch.int16)), (case, rep, "statistics epilogue changed the result")
+        if not (Ci == 64 and Co == 128):        # 64 -> 128 without statistics runs as two passes of the strip kernel (other tap order)
+            assert torch.equal(y.view(torch.int16), y2.view(torch.int16)), (case, rep, "statistics epilogue changed the result")
         assert int(((y.float() - yref).abs() > tol).sum()) == 0, (case, rep, "forward vs fp32 accumulation")
-        cur = (y.view(torch.int16), st.view(torch.int32), dx.view(torch.int16), dw.view(torch.int32))
+        assert int(((y2.float() - yref).abs() > tol).sum()) == 0, (case, rep, "forward without statistics vs fp32 accumulation")
+        cur = (y.view(torch.int16), st.view(torch.int32), dx.view(torch.int16), dw.view(torch.int32), y2.view(torch.int16))
         if ref is None:
             assert all(bool(torch.isfinite(t).all()) for t in (y.float(), st, dx.float(), dw))
             ref = tuple(t.clone() for t in cur)
         else:
-            for name, a, c in zip(("y", "stats", "dx", "dw"), ref, cur):
+            for name, a, c in zip(("y", "stats", "dx", "dw", "y without statistics"), ref, cur):
                 assert torch.equal(a, c), (case, rep, name, int((a != c).sum()))
 
 
