@@ -155,3 +155,30 @@ def test_unet_fullsize_batch2_all_three_losses():
         l = lossf(net(x), t); l.backward()
         opt.step(); sched.step()
         assert abs(l.item() - float(d["traj_losses"][i])) < tol[i], (i, l.item(), float(d["traj_losses"][i]), tol[i])
+
+
+def test_bench_json_contract_single_gpu():
+    """`python bench.py` prints ONE JSON line with the driver's fields; the roofline fraction is a hardware fraction (executed
+    MFMA FLOPs of the dominant kernel over the dense peak, <= 1) with the algorithmic rate beside it, and the memory-bound
+    kernels (incl. the weight transforms and the 2-D Winograd transform passes) are listed with their share of 8 TB/s."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "images/s" and d["dtype"] == "f32"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and "workload" in d["config"]
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and rf["kernel"]
+    assert 0.3 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["algorithmic_tflops"] >= rf["achieved"] and 0 < rf["executed_share_of_algorithmic_flops"] <= 1.0
+    assert all(0 < v["executed_frac_of_peak"] <= 1.0 for v in d["conv_kernels"].values())
+    hk = d["hbm_kernels"]
+    for name in ("k_bn_relu_apply", "k_w2d_input", "k_w2d_output", "k_w2d_weight", "k_ce_fwd", "k_ce_bwd", "k_bilinear_fwd"):
+        assert name in hk and 0 < hk[name]["frac_of_8TBps"] <= 1.0, name
