@@ -147,8 +147,9 @@ def wgrad2d_pays(N, H, W, k_ch, cout):
 
 
 def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what="", dgrad_of=None, keep_v=None):
-    """y[N,H,W,ldy] = conv3x3(x[N,H,W,k_ch], w[cout][3][3][k_ch]) (+bias, +BN statistics partials at sp) through the 1-D
-    Winograd kernels: weight transform -> implicit GEMMs M_xi -> output transform.  F(4,3) when R.wino4, else F(2,3).
+    """y[N,H,W,ldy] = conv3x3(x[N,H,W,k_ch], w[cout][3][3][k_ch]) (+bias, +BN statistics partials at sp) through the
+    Winograd kernels: weight transform -> (input transform ->) GEMMs M_xi -> output transform.  2-D F(4x4,3x3) for the
+    channel-heavy layers (R.wino2d, wino2d_pays), else 1-D F(4,3) when R.wino4, else F(2,3).
     Data-grad: `w` is a callable returning the rotated/transposed pack (built only if a kernel needs it) and
     dgrad_of = (forward weights [Cout_f][3][3][Cin_f], Cout_f, Cin_f) lets F(4,3) transform straight from them.
     Returns None, or (P, counts pointer) when the statistics partials at sp carry explicit pixel counts (2-D path:
