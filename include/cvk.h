@@ -146,6 +146,20 @@ int cvk_w2d_wgrad_ksplit(int T, int Cin_pad, int Cout);
 int cvk_w2d_dy_transform(const float* dy, int ld_dy, float* E, int N, int H, int W, int Cout, void* stream);
 int cvk_w2d_gemm_tn(const float* E, const float* V, float* P, int T, int Cin_pad, int Cout, void* stream);
 int cvk_w2d_wgrad_output(const float* P, float* dw, int T, int Cin, int Cin_pad, int Cout, void* stream);
+/* FUSED 1-D Winograd F(4,3) (csrc/wino4f.hip; replaces nn.Conv2d(cin,cout,3,padding=1) fwd and its data-grad,
+ * /root/reference/models/unet.py:11, models/segnet.py:8, for the 64/128-channel levels): one workgroup computes all six
+ * transform indices of a 128 x 64 tile, the output transform, bias and BatchNorm statistics happen in registers — no
+ * product planes, no output pass.  Uf = cvk_wino4f_weight_transform(w): cvk_wino4f_weight_floats(Cn, Ck) floats, the
+ * K-sliced LDS image of (G g); dgrad != 0 builds the data-grad filter (180-degree rotation, channels exchanged) straight
+ * from the forward weights w [Ck][3][3][Cn].  Cin % 32 == 0.  stats/counts (both or neither): P =
+ * cvk_wino4f_stat_partials(N,H,W) partials [sum | M2 about the partial mean] [2][P][Cout] + the P pixel counts, to be
+ * reduced by cvk_bn_finalize_counts. */
+size_t cvk_wino4f_weight_floats(int Cn, int Ck);
+int cvk_wino4f_weight_transform(const float* w, float* Uf, int Cn, int Ck, int dgrad, void* stream);
+int cvk_wino4f_stat_partials(int N, int H, int W);
+int cvk_conv3x3_wino4f(const float* x, const float* Uf, const float* bias, float* y, float* stats, float* counts, int N, int H,
+                       int W, int Cin, int Cout, int ldy, void* stream);
+
 /* weight-grad through the transposed F(4,3) (contract of cvk_conv3x3_wgrad; the workspace also holds the transformed
  * output-gradient planes E1..E4, float[4][N*H*ceil(W/4)][ld_dy], hence the extra ld_dy argument of the size query) */
 size_t cvk_conv3x3_wgrad_wino4_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout, int ld_dy);

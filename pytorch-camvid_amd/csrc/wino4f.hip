@@ -1,0 +1,500 @@
+// wino4f.hip — FUSED 1-D Winograd F(4,3) 3x3 convolution for the 64/128-channel full-resolution levels
+// (reference operator: nn.Conv2d(cin,cout,3,padding=1), models/unet.py:11, models/segnet.py:8; its data-grad, bwd of train.py:131).
+//
+// Same arithmetic as wino4.hip (V = B^T d, U = G g, y = A^T m, interpolation points 0, +-1, +-2, inf; 9*M*Cin*Cout executed
+// FLOPs instead of 18), but ONE workgroup computes all six transform indices of its tile and keeps the six product tiles
+// M_0..M_5 in accumulator registers (6 x 32 per lane), so
+//   * the output transform, the bias and the BatchNorm statistics happen in registers: the six product planes (1.5x the output,
+//     written and read back by wino4.hip's k_conv3x3_wino4 + k_wino4_output) never exist — x is read once, y written once;
+//   * a pixel is loaded once per K slice for ALL six V_xi (6 loads and 12 vector ops per six V elements; the per-index kernel
+//     issued 20 loads and 18 FMAs for them) — round 3's microbenchmark (tools/micro/mfma_xwave.hip) shows that on this part
+//     every vector-ALU instruction takes >= 2 cycles of fp32-MFMA time whichever wave issues it, so the only lever is fewer of
+//     them per MFMA;
+//   * the transformed filter slices arrive by LDS-DMA in the exact LDS image order (k_wino4f_weight writes them that way):
+//     no registers, no ds_write, no address arithmetic.
+// Tile: 128 tile rows (a tile row = four output columns of one image row) x 64 output channels; K slice = 16 input channels of
+// one kernel row; LDS: two stages of 6 x (128 + 64) rows x 64 B = 144 KiB -> one workgroup (4 waves, one per SIMD) per CU,
+// so a workgroup WALKS a contiguous range of tiles (persistent strip): the slice pipeline never drains between tiles and the
+// epilogue's stores retire under the next tile's MFMAs.
+#include "conv_tile.h"
+#include "lds_dma.h"
+#include <utility>
+
+namespace {
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>) — every index is a constant
+// expression inside f (a `#pragma unroll` loop over 96 slots with per-slot branches was not unrolled: accumulators in scratch)
+template <int... Ks, class F>
+__device__ __forceinline__ void f_static_for(std::integer_sequence<int, Ks...>, F&& f) {
+    (f(std::integral_constant<int, Ks>{}), ...);
+}
+
+constexpr int F_BM = 128, F_BN = 64, F_BK = 16;
+constexpr int F_ABYTES = 6 * F_BM * 64;          // six V_xi tiles, 64-byte rows
+constexpr int F_BBYTES = 6 * F_BN * 64;          // six U_xi tiles
+constexpr int F_STAGE = F_ABYTES + F_BBYTES;     // 73728
+
+// Uf[slice][n-tile][xi][64 rows][16 floats]: row = output channel (n-tile * 64 + row), the 16 floats = K elements
+// slice*16 .. +15 of (G g)_xi, K = kernel row * Ck + input channel; 16-byte chunk c of row r is stored at c ^ ((r >> 2) & 3)
+// (the LDS image: the sixteen rows of a ds_read_b128 phase then hit sixteen different bank groups).  Rows >= Cn are zero.
+// dgrad: w is the FORWARD filter [Ck][3][3][Cn] and g_s = w[k][2-r][2-s][n] (rotated by 180 degrees, channels exchanged).
+__global__ __launch_bounds__(256) void k_wino4f_weight(const float* __restrict__ w, float* __restrict__ Uf, int Cn, int Ck,
+                                                      int tilesN, int dgrad) {
+    const int Nn = tilesN * F_BN;
+    const size_t total = (size_t)Nn * 3 * Ck;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int n, r, k;
+        if (dgrad) {       // n fastest: coalesced reads along the forward filter's input channels
+            n = (int)(i % Nn);
+            const size_t q = i / Nn;
+            k = (int)(q % Ck);
+            r = (int)(q / Ck);
+        } else {           // k fastest
+            k = (int)(i % Ck);
+            const size_t q = i / Ck;
+            r = (int)(q % 3);
+            n = (int)(q / 3);
+        }
+        double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+        if (n < Cn) {
+            if (dgrad) {
+                const float* g = w + ((size_t)(k * 3 + (2 - r)) * 3) * Cn + n;
+                g0 = g[2 * (size_t)Cn]; g1 = g[Cn]; g2 = g[0];
+            } else {
+                const float* g = w + ((size_t)(n * 3 + r) * 3) * Ck + k;
+                g0 = g[0]; g1 = g[Ck]; g2 = g[2 * (size_t)Ck];
+            }
+        }
+        const int kk = r * Ck + k, slice = kk >> 4, kf = kk & 15;
+        const int tn = n >> 6, nl = n & 63;
+        const size_t o = (((size_t)(slice * tilesN + tn) * 6) * 64 + nl) * 16 + (((kf >> 2) ^ ((nl >> 2) & 3)) << 2) + (kf & 3);
+        const size_t ps = 64 * 16;               // plane stride between transform indices
+        Uf[o] = (float)(0.25 * g0);
+        Uf[o + ps] = (float)(-(g0 + g1 + g2) / 6.0);
+        Uf[o + 2 * ps] = (float)(-(g0 - g1 + g2) / 6.0);
+        Uf[o + 3 * ps] = (float)(g0 / 24.0 + g1 / 12.0 + g2 / 6.0);
+        Uf[o + 4 * ps] = (float)(g0 / 24.0 - g1 / 12.0 + g2 / 6.0);
+        Uf[o + 5 * ps] = (float)g2;
+    }
+}
+
+// LDS-DMA with a scalar base: global address = sbase + voff (32-bit per-lane byte offset), LDS = m0 + 16 * lane.
+__device__ __forceinline__ void f_dma16(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+
+// ABL: ablation switches for timing experiments only (tools/bench_wino4f_ablate.py; 0 in the product): 1 no pixel loads,
+// 2 no transform + LDS stores, 4 no filter DMA, 8 no epilogue (outputs not written), 16 no MFMAs
+//
+// 512 threads = 8 waves, two per SIMD, in a 4 x 2 grid of 32 x 32 wave tiles (one MFMA block per transform index: 6 x 16
+// accumulator registers).  On this part a wave's own vector / LDS / memory instructions simply ADD to its MFMA time (fp32 MFMAs
+// run on the vector lanes: tools/micro/mfma_xwave.hip, and the ablation of the 4-wave version of this kernel: the side work of a
+// K step cost the same with and without MFMAs in the stream), so the staging work of one wave has to sit under the MFMAs of
+// the OTHER wave on its SIMD — with one 4-wave workgroup per CU (144 KiB of LDS) there was no other wave.
+template <bool STATS, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
+    const float* __restrict__ X, const float* __restrict__ Uf, const float* __restrict__ bias, float* __restrict__ Y,
+    float* __restrict__ stats, float* __restrict__ counts, int Mt, int H, int W, int Wt, int Cin, int Cout, int ldy,
+    int tilesN, int ntiles, int Mpix, int P) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * F_STAGE + 2048];
+    const unsigned smem_addr = cvk_lds_addr(smem);
+    float* const red = reinterpret_cast<float*>(smem + 2 * F_STAGE);     // [2 sums][4 wave rows][64 channels]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // Tiles (numbered m-tile major, n-tile fastest) are dealt to the XCDs in contiguous chunks and INTERLEAVED over the
+    // workgroups of an XCD: workgroup i of the ng on XCD k walks tiles first + i, first + i + ng, ...  The workgroups of an
+    // XCD advance in step, so at any time they cover a band of ~ng consecutive tiles (= image rows): the three reads of an
+    // image row (as kernel row 0, 1, 2 of three neighbouring tiles) and the n-tiles of one pixel range hit the XCD's L2 —
+    // with one contiguous range per workgroup every re-read came from the Infinity Cache and its latency was exposed.
+    const int G = gridDim.x;
+    const int nx = G < 8 ? G : 8;
+    const int xcd = blockIdx.x % nx, wi = blockIdx.x / nx;
+    const int ng = G / nx + (xcd < G % nx ? 1 : 0);                      // workgroups on this XCD (round-robin dispatch)
+    const int xbeg = (int)((long)xcd * ntiles / nx), xend = (int)((long)(xcd + 1) * ntiles / nx);
+    const int tbeg = xbeg + wi, tend = xend, tstride = ng;
+    if (tbeg >= tend) return;
+    const int ntw = (tend - tbeg + tstride - 1) / tstride;               // tiles of this workgroup
+    const int nS = 3 * Cin / F_BK;                                       // K slices per tile
+    const int total = ntw * nS;
+
+    const FastDiv divWt((unsigned)Wt), divH((unsigned)H);
+    // input window of the tile being loaded: starts one image row + one pixel before the tile's first pixel (possibly before
+    // the tensor: only in-frame taps are ever dereferenced); a tap (kernel row r, column j) of a tile row at pixel p then sits
+    // at the non-negative offset  ((p - first) + j) * Cin [VGPR part, range-checked]  +  r * W * Cin + channel base [SGPR
+    // part].  Re-based per tile (scalar work), so tensors may be arbitrarily larger than the 2 GiB one resource can address.
+    __amdgpu_buffer_rsrc_t xr;
+    const __amdgpu_buffer_rsrc_t null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, 0, 0x00020000);
+
+    // staging item of this thread: row tid >> 2 of the tile, 16-byte channel chunk tid & 3
+    const int srow = tid >> 2, schunk = tid & 3;
+    unsigned ibase = 0, iflag = 0;      // byte offset of (pixel d1 - first) * Cin * 4 + chunk * 16; bits 0..2 kernel rows, 3..8 columns d0..d5
+    unsigned aoff[6];
+    auto set_tile = [&](int tile) {
+        const int m0 = (tile / tilesN) * F_BM;
+        const int q0 = (int)divWt.div((unsigned)m0);
+        const int first = q0 * W + 4 * (m0 - q0 * Wt);
+        const long xfirst = ((long)first - (W + 1)) * Cin;
+        const size_t xbytes = (size_t)((long)Mpix * Cin - xfirst) * 4;
+        xr = __builtin_amdgcn_make_buffer_rsrc((void*)(X + xfirst), 0, (int)(xbytes < 0x7FFFFFFFu ? xbytes : 0x7FFFFFFFu), 0x00020000);
+        const int t = m0 + srow;
+        unsigned fl = 0, base = 0;
+        if (t < Mt) {
+            const int q = (int)divWt.div((unsigned)t), xt = t - q * Wt;
+            const int y = q - (int)divH.div((unsigned)q) * H;
+            fl = 2u | (y > 0 ? 1u : 0u) | (y + 1 < H ? 4u : 0u);
+            fl |= (xt > 0 ? 8u : 0u) | 16u;
+#pragma unroll
+            for (int j = 2; j < 6; ++j) fl |= (4 * xt + j - 1 < W) ? (8u << j) : 0u;
+            base = (unsigned)(q * W + 4 * xt - first) * (unsigned)Cin * 4u + (unsigned)schunk * 16u;
+        }
+        ibase = base;
+        iflag = fl;
+    };
+    auto regroup = [&](int r) {                          // kernel row changed: validity of the six taps
+        const unsigned cs = (unsigned)Cin * 4u;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const unsigned need = (1u << r) | (8u << j);
+            aoff[j] = oob_unless((iflag & need) == need, ibase + j * cs);
+        }
+    };
+
+    // ---- loader state (uniform): next slice whose pixels are issued into the register stage ----
+    int ltile = tbeg, lr = 0, lcib = 0, lleft = total;
+    f32x4 d[2][6];        // two register stages: a slice's pixels are in flight for almost two K steps
+    auto load_A = [&](int set, int j) {
+        const __amdgpu_buffer_rsrc_t xs = (lleft > 0 && !(ABL & 1)) ? xr : null_rsrc;   // past the last slice: zeros, no memory access
+        const unsigned so = (unsigned)((lr * W * Cin + lcib) * 4);
+        d[set][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, aoff[j], so, 0));
+    };
+    auto advance_A = [&]() {
+        --lleft;
+        lcib += F_BK;
+        const int w1 = lcib >= Cin;
+        lcib = w1 ? 0 : lcib;
+        lr += w1;
+        const int w2 = lr == 3;
+        lr = w2 ? 0 : lr;
+        ltile += w2 ? tstride : 0;
+    };
+    auto issue_A = [&](int set) {
+        if (lcib == 0) {       // the slice opens a new kernel row (or tile)
+            if (lr == 0 && ltile < tend) set_tile(ltile);
+            regroup(lr);
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) load_A(set, j);
+        advance_A();
+    };
+    // pieces of the staging work, placed one per MFMA slot by F_STEP: xform(c) computes V = B^T d of channel component c for all
+    // six transform indices (12 vector ops per six elements), write_A(stage, x) stores V_x, load_A(j) refills a register
+    f32x4 tv[6];
+    auto xform = [&](int set, int c) {
+        if (ABL & 2) return;
+        const float d0 = d[set][0][c], d1 = d[set][1][c], d2 = d[set][2][c], d3 = d[set][3][c], d4 = d[set][4][c], d5 = d[set][5][c];
+        const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
+        const float e = d4 - d2, f = d3 - d1;
+        tv[0][c] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+        tv[1][c] = a + b;
+        tv[2][c] = a - b;
+        tv[3][c] = fmaf(2.f, f, e);
+        tv[4][c] = fmaf(-2.f, f, e);
+        tv[5][c] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+    };
+    const int wr_off = srow * 64 + ((schunk ^ ((srow >> 2) & 3)) << 4);
+    auto write_A = [&](char* stage, int x) {
+        if (ABL & 2) return;
+        *reinterpret_cast<f32x4*>(stage + x * (F_BM * 64) + wr_off) = tv[x];
+    };
+    auto store_A = [&](char* stage, int set) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xform(set, c);
+#pragma unroll
+        for (int x = 0; x < 6; ++x) write_A(stage, x);
+    };
+    // ---- filter slices by LDS-DMA: slice (bslice of tile btile) -> B region of a stage; 3 pieces of 1 KiB per wave ----
+    int btn = tbeg % tilesN, bslice = 0, bleft = total;       // n-tile of the tile whose filter slices are being copied
+    const unsigned bvoff = (unsigned)(wave * 3 * 1024 + lane * 16);
+    const char* bsrc = nullptr;
+    auto dma_B_begin = [&]() {
+        // past the last slice the previous one is copied again (keeps the wait counts uniform; never read)
+        bsrc = reinterpret_cast<const char*>(Uf) + (size_t)(bslice * tilesN + btn) * F_BBYTES;
+        if (--bleft > 0) {
+            const int w = ++bslice == nS;
+            bslice = w ? 0 : bslice;
+            btn = w ? (btn + tstride) % tilesN : btn;
+        }
+    };
+    auto dma_B_piece = [&](unsigned stage_addr, int q) {
+        if (!(ABL & 4)) f_dma16(bsrc + q * 1024, bvoff, stage_addr + F_ABYTES + (wave * 3 + q) * 1024);
+    };
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[x][e] = 0.f;
+
+    const int sw = (li >> 2) & 3;
+    const int a_off = (wm * 32 + li) * 64 + ((lh ^ sw) << 4);
+    const int b_off = F_ABYTES + (wn * 32 + li) * 64 + ((lh ^ sw) << 4);
+    // One K step = 12 substeps (transform index x, half-slice kk) of 4 MFMAs; the two fragment reads of substep s+1 are
+    // issued under the MFMAs of substep s (register double buffer), see F_STEP.
+    f32x4 fa[2], fb[2];
+    auto load_frag = [&](const char* st, int sidx, int slot) {
+        const int x = sidx >> 1, kk = sidx & 1;
+        fa[slot] = *reinterpret_cast<const f32x4*>(st + ((x * (F_BM * 64) + a_off) ^ (kk << 5)));
+        fb[slot] = *reinterpret_cast<const f32x4*>(st + ((x * (F_BN * 64) + b_off) ^ (kk << 5)));
+    };
+    auto mfma1 = [&](int k) {                              // MFMA k of the step: substep k / 4, k-pair k % 4
+        if (ABL & 16) return;
+        const int sidx = k >> 2, x = sidx >> 1, slot = sidx & 1, j = k & 3;
+        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][j], fb[slot][j], acc[x], 0, 0, 0);
+    };
+
+    // y = A^T m in registers, + bias, stores, BatchNorm statistics partial of the tile (sum, M2 about the tile mean, count).
+    // Stores are range-checked buffer stores through a window that starts at the tile's first pixel (branch-free: rows
+    // beyond the tensor, ragged column groups and channels >= Cout get an out-of-range offset).
+    auto epilogue = [&](int tile) {
+        if (ABL & 8) {
+            if (tile == -1) {
+                float z = 0.f;
+#pragma unroll
+                for (int x = 0; x < 6; ++x)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) z += acc[x][e];
+                Y[tid] = z;
+            }
+            return;
+        }
+        const int mt = tile / tilesN, tn = tile - mt * tilesN;
+        const int m0 = mt * F_BM;
+        const int col = tn * F_BN + wn * 32 + li;
+        const bool cok = col < Cout;
+        const float bs = (bias != nullptr && cok) ? bias[col] : 0.f;
+        const int qb = (int)divWt.div((unsigned)m0);
+        const int pixb = qb * W + 4 * (m0 - qb * Wt);               // first pixel of the tile (uniform)
+        const size_t ybytes = ((size_t)Mpix - pixb) * ldy * 4;
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(Y + (size_t)pixb * ldy), 0,
+                                                                            (int)(ybytes < 0x7FFFFFFFu ? ybytes : 0x7FFFFFFFu), 0x00020000);
+        const unsigned ls = (unsigned)ldy * 4u;
+        float s1 = 0.f, s2 = 0.f;
+        if ((W & 3) == 0 && m0 + F_BM <= Mt && (tn + 1) * F_BN <= Cout) {
+            // whole tile, no ragged column group: pixel(t) = 4 t, every output valid.  The vector ALU only does the transform,
+            // the bias and the statistics (its instructions take matrix time on this part); a row's byte offset is uniform and
+            // travels in the scalar offset of the store.
+            const unsigned ob = (unsigned)((4 * (wm * 32 + 4 * lh)) * ldy + col) * 4u;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float m0_ = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
+                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                const float y0 = m0_ + s12 + s34, y1 = fmaf(2.f, d34, d12), y2 = fmaf(4.f, s34, s12), y3 = fmaf(8.f, d34, d12) + m5;
+#pragma unroll
+                for (int x = 0; x < 6; ++x) acc[x][e] = 0.f;
+                const unsigned so = (unsigned)(4 * ((e & 3) + 8 * (e >> 2))) * ls;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y0 + bs), yr, ob, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y1 + bs), yr, ob, so + ls, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y2 + bs), yr, ob, so + 2 * ls, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y3 + bs), yr, ob, so + 3 * ls, 0);
+                if (STATS) {
+                    s1 += (y0 + y1) + (y2 + y3);
+                    s2 += fmaf(y0, y0, y1 * y1) + fmaf(y2, y2, y3 * y3);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int t = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const float m0_ = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
+                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                const float y0 = m0_ + s12 + s34, y1 = fmaf(2.f, d34, d12), y2 = fmaf(4.f, s34, s12), y3 = fmaf(8.f, d34, d12) + m5;
+#pragma unroll
+                for (int x = 0; x < 6; ++x) acc[x][e] = 0.f;
+                const int q = (int)divWt.div((unsigned)t), xt = t - q * Wt;
+                const int nv = (t < Mt && cok) ? W - 4 * xt : 0;       // valid columns of this group
+                const unsigned o = (unsigned)((q * W + 4 * xt - pixb) * ldy + col) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y0 + bs), yr, oob_unless(nv > 0, o), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y1 + bs), yr, oob_unless(nv > 1, o), ls, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y2 + bs), yr, oob_unless(nv > 2, o), 2 * ls, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y3 + bs), yr, oob_unless(nv > 3, o), 3 * ls, 0);
+                if (STATS) {
+                    const float z0 = nv > 0 ? y0 : 0.f, z1 = nv > 1 ? y1 : 0.f, z2 = nv > 2 ? y2 : 0.f, z3 = nv > 3 ? y3 : 0.f;
+                    s1 += (z0 + z1) + (z2 + z3);
+                    s2 += fmaf(z0, z0, z1 * z1) + fmaf(z2, z2, z3 * z3);
+                }
+            }
+        }
+        if (STATS) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lh == 0) {
+                red[wm * 64 + wn * 32 + li] = s1;
+                red[256 + wm * 64 + wn * 32 + li] = s2;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const int c = tn * F_BN + tid;
+                if (c < Cout) {
+                    const int mend = min(Mt, m0 + F_BM);
+                    const int nlast = (int)divWt.div((unsigned)mend) - qb;   // ragged (last-of-row) column groups in the tile
+                    const float cnt = (float)(4 * (mend - m0) - nlast * (4 * Wt - W));
+                    const float a = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+                    const float b = (red[256 + tid] + red[320 + tid]) + (red[384 + tid] + red[448 + tid]);
+                    const float m2 = b - a * a / cnt;                  // sums exclude the bias (shift invariance)
+                    const float bc = bias != nullptr ? bias[c] : 0.f;
+                    stats[(size_t)mt * Cout + c] = a + cnt * bc;
+                    stats[(size_t)(P + mt) * Cout + c] = m2 > 0.f ? m2 : 0.f;
+                    if (tid == 0 && tn == 0) counts[mt] = cnt;
+                }
+            }
+        }
+    };
+
+    // ---- prologue: slice 0 staged, slices 1 and 2 in flight ----
+    char* const buf0 = smem;
+    char* const buf1 = smem + F_STAGE;
+    issue_A(0);                                  // slice 0 -> set 0
+    issue_A(1);                                  // slice 1 -> set 1
+    dma_B_begin();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) dma_B_piece(smem_addr, q);
+    store_A(buf0, 0);
+    issue_A(0);                                  // slice 2 -> set 0
+    cvk_wait_vm<6>();
+    cvk_lds_retire_barrier();
+
+#define F_SB() __builtin_amdgcn_sched_barrier(0)
+    // Instruction order of a K step, imposed slot by slot (a scheduling fence after every MFMA: nothing moves): 48 MFMAs per wave,
+    // each followed by at most one small piece of side work.  Slots 4s: the two fragment reads of substep s+1.  Slots 1,2,3,5: the
+    // transform of the slice staged in this step (12 vector ops per channel component; the first waits for its pixel loads, issued
+    // almost two steps earlier); 2,3,5 also one of the wave's three filter-DMA pieces each (AFTER that wait — hipcc's vmcnt for
+    // the pixels would otherwise wait for the fresh DMA too — and before this step's pixel loads: vmcnt order); 6-13 (not 8, 12):
+    // one LDS store of V and one pixel load (slice g + 3) into the register just freed.  Left to hipcc (with or without
+    // sched_group_barrier lists) the fragment reads sit right in front of their MFMAs and the transform runs as one block with
+    // the matrix pipe idle.  Tried without gain: waves 4-7 doing their side work half a step later than waves 0-3.
+    auto step = [&](auto par_, const char* cur, char* nxt, unsigned nxt_addr) {
+        constexpr int SET = 1 - decltype(par_)::value;      // register set holding the slice this step stages (slice g + 1)
+        if (lcib == 0) {       /* the slice issued in this step (g + 3) opens a new kernel row (or tile) */
+            if (lr == 0 && ltile < tend) set_tile(ltile);
+            regroup(lr);
+        }
+        dma_B_begin();
+        load_frag(cur, 0, 0);
+        F_SB();
+        f_static_for(std::make_integer_sequence<int, 48>{}, [&](auto kc_) {
+            constexpr int k_ = decltype(kc_)::value;
+            constexpr int q_ = k_;
+            mfma1(k_);
+            if constexpr ((k_ & 3) == 0) {
+                if constexpr (k_ < 44) load_frag(cur, (k_ >> 2) + 1, ((k_ >> 2) + 1) & 1);
+            } else if constexpr (q_ == 1) {
+                xform(SET, 0);                              /* waits for the six pixel loads of the slice */
+            } else if constexpr (q_ == 2 || q_ == 3) {
+                xform(SET, q_ - 1);
+                dma_B_piece(nxt_addr, q_ - 2);
+            } else if constexpr (q_ == 5) {
+                xform(SET, 3);
+                dma_B_piece(nxt_addr, 2);
+            } else if constexpr (q_ == 6 || q_ == 7) {
+                write_A(nxt, q_ - 6);
+                load_A(SET, q_ - 6);
+            } else if constexpr (q_ >= 9 && q_ <= 11) {
+                write_A(nxt, q_ - 7);
+                load_A(SET, q_ - 7);
+            } else if constexpr (q_ == 13) {
+                write_A(nxt, 5);
+                load_A(SET, 5);
+                advance_A();
+            }
+            F_SB();
+        });
+        cvk_wait_vm<6>();        // the step's DMA pieces (and, older, the previous step's pixel loads) have landed
+        cvk_lds_retire_barrier();
+    };
+    // nS is even (Cin % 32 == 0, checked by the host): every tile starts in stage 0 and the step pair below is the only copy
+    // of the K step in the code (per phase); the epilogue's global stores count in vmcnt and retire under the next tile's first step
+    for (int tile = tbeg; tile < tend; tile += tstride) {
+        for (int sp = 0; sp < nS; sp += 2) {
+            step(std::integral_constant<int, 0>{}, buf0, buf1, smem_addr + F_STAGE);
+            step(std::integral_constant<int, 1>{}, buf1, buf0, smem_addr);
+        }
+        epilogue(tile);
+    }
+#undef F_SB
+    cvk_wait_vm<0>();            // the redundant tail DMA lands before the workgroup's LDS is released
+}
+
+}  // namespace
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+static inline int f_tiles_n(int Cn) { return cvk_cdiv(Cn, F_BN); }
+
+extern "C" size_t cvk_wino4f_weight_floats(int Cn, int Ck) {
+    if (Cn <= 0 || Ck <= 0 || Ck % F_BK) return 0;
+    return (size_t)(3 * Ck / F_BK) * f_tiles_n(Cn) * 6 * F_BN * F_BK;
+}
+
+extern "C" int cvk_wino4f_weight_transform(const float* w, float* Uf, int Cn, int Ck, int dgrad, void* stream) {
+    CVK_CHECK_ARG(w && Uf && Cn > 0 && Ck > 0, "cvk_wino4f_weight_transform: bad arguments");
+    CVK_CHECK_ARG(Ck % F_BK == 0, "cvk_wino4f_weight_transform: the contraction channel count %d must be a multiple of 16", Ck);
+    CVK_CHECK_ARG(cvk_aligned16(Uf), "cvk_wino4f_weight_transform: Uf must be 16-byte aligned");
+    const size_t total = (size_t)f_tiles_n(Cn) * F_BN * 3 * Ck;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_wino4f_weight, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Uf, Cn, Ck, f_tiles_n(Cn), dgrad ? 1 : 0);
+    CVK_LAUNCH_RETURN("cvk_wino4f_weight_transform");
+}
+
+extern "C" int cvk_wino4f_stat_partials(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    return cvk_cdiv((long)N * H * ((W + 3) / 4), F_BM);
+}
+
+extern "C" int cvk_conv3x3_wino4f(const float* x, const float* Uf, const float* bias, float* y, float* stats, float* counts, int N,
+                                  int H, int W, int Cin, int Cout, int ldy, void* stream) {
+    CVK_CHECK_ARG(x && Uf && y, "cvk_conv3x3_wino4f: null pointer");
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout, "cvk_conv3x3_wino4f: bad shape");
+    CVK_CHECK_ARG(Cin >= 32 && Cin % 32 == 0, "cvk_conv3x3_wino4f: Cin=%d must be a multiple of 32", Cin);
+    CVK_CHECK_ARG((stats == nullptr) == (counts == nullptr), "cvk_conv3x3_wino4f: stats and counts go together");
+    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(Uf), "cvk_conv3x3_wino4f: x and Uf must be 16-byte aligned");
+    CVK_CHECK_ARG((long)N * H * W < (1L << 31) - 512, "cvk_conv3x3_wino4f: tensor too large for 32-bit pixel indices");
+    const int Wt = (W + 3) / 4, Mt = N * H * Wt, Mpix = N * H * W;
+    CVK_CHECK_ARG((long)Mt * Wt < (1L << 32) && (long)N * H * H < (1L << 32), "cvk_conv3x3_wino4f: frame too large for the multiply-high coordinate split");
+    const int tilesN = f_tiles_n(Cout), tilesM = cvk_cdiv(Mt, F_BM), ntiles = tilesM * tilesN;
+    // persistent strips: one workgroup per CU (144 KiB of LDS), each walks ntiles / grid consecutive tiles
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int grid = ntiles < cus ? ntiles : cus;
+    CVK_CHECK_ARG((F_BM * 4 + 3L * W + 8) * Cin * 4 < (1L << 31), "cvk_conv3x3_wino4f: a tile's input window exceeds the 2 GiB buffer-addressing limit");
+    hipStream_t s = (hipStream_t)stream;
+    if (stats)
+        hipLaunchKernelGGL(k_conv3x3_wino4f<true>, dim3(grid), dim3(512), 0, s, x, Uf, bias, y, stats, counts, Mt, H, W, Wt, Cin, Cout, ldy,
+                           tilesN, ntiles, Mpix, tilesM);
+    else
+        hipLaunchKernelGGL(k_conv3x3_wino4f<false>, dim3(grid), dim3(512), 0, s, x, Uf, bias, y, stats, counts, Mt, H, W, Wt, Cin, Cout, ldy,
+                           tilesN, ntiles, Mpix, tilesM);
+    CVK_LAUNCH_RETURN("cvk_conv3x3_wino4f");
+}
+
+#ifdef CVK_WINO4F_ABLATE
+extern "C" int cvk_conv3x3_wino4f_ablate(const float* x, const float* Uf, const float* bias, float* y, int N, int H, int W, int Cin,
+                                         int Cout, int ldy, int abl, void* stream) {
+    const int Wt = (W + 3) / 4, Mt = N * H * Wt, Mpix = N * H * W;
+    const int tilesN = f_tiles_n(Cout), tilesM = cvk_cdiv(Mt, F_BM), ntiles = tilesM * tilesN;
+    const int grid = ntiles < 256 ? ntiles : 256;
+    hipStream_t s = (hipStream_t)stream;
+#define CVK_ABL(A) case A: hipLaunchKernelGGL((k_conv3x3_wino4f<false, A>), dim3(grid), dim3(512), 0, s, x, Uf, bias, y, nullptr, nullptr, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM); break;
+    switch (abl) {
+        CVK_ABL(0) CVK_ABL(1) CVK_ABL(2) CVK_ABL(3) CVK_ABL(4) CVK_ABL(7) CVK_ABL(8) CVK_ABL(9) CVK_ABL(11) CVK_ABL(15) CVK_ABL(16) CVK_ABL(24) CVK_ABL(31)
+        default: return -1;
+    }
+#undef CVK_ABL
+    CVK_LAUNCH_RETURN("cvk_conv3x3_wino4f_ablate");
+}
+#endif

@@ -146,6 +146,14 @@ def wgrad2d_pays(N, H, W, k_ch, cout):
     return T >= 256 and k_ch * cout >= 65536
 
 
+# fused F(4,3) (csrc/wino4f.hip) instead of the per-index F(4,3) kernels + output pass: "0" off, "1" on
+WINO4F_DEFAULT = os.environ.get("CVK_WINO4F", "1") != "0"
+
+
+def wino4f_ok(k_ch, cout):
+    return k_ch % 32 == 0 and cout % 4 == 0 and cout >= 32
+
+
 def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what="", dgrad_of=None, keep_v=None):
     """y[N,H,W,ldy] = conv3x3(x[N,H,W,k_ch], w[cout][3][3][k_ch]) (+bias, +BN statistics partials at sp) through the
     Winograd kernels: weight transform -> (input transform ->) GEMMs M_xi -> output transform.  2-D F(4x4,3x3) for the
@@ -180,7 +188,25 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
         _timed(R, "k_w2d_output", 4.0 * (36 * T + M) * cout, lambda: check(
             lib.cvk_w2d_output(Mo, bias, y.data_ptr(), sp, cnt, N, H, W, k_ch, cout, ldy, s), "cvk_w2d_output" + what), "byte")
         return (P2, cnt) if sp is not None else None
-    if R.wino4 == "always" or (R.wino4 and wino4_pays(N, H, W, k_ch, ldy)):
+    use4 = R.wino4 == "always" or (R.wino4 and wino4_pays(N, H, W, k_ch, ldy))
+    if use4 and R.wino4f and wino4f_ok(k_ch, cout) and (dgrad_of is None or (dgrad_of[1] == k_ch and dgrad_of[2] == cout)):
+        # fused F(4,3) (csrc/wino4f.hip): all six transform indices in one workgroup, output transform + bias + statistics in
+        # registers — no product planes, no output pass
+        Uf = _empty(lib.cvk_wino4f_weight_floats(cout, k_ch), x.device)
+        if dgrad_of is not None:
+            _timed(R, "k_wino4f_weight", 4.0 * (9 + 18) * cout * k_ch, lambda: check(
+                lib.cvk_wino4f_weight_transform(dgrad_of[0].data_ptr(), Uf.data_ptr(), cout, k_ch, 1, s), "cvk_wino4f_weight_transform(dgrad)"), "byte")
+        else:
+            w = w() if callable(w) else w
+            _timed(R, "k_wino4f_weight", 4.0 * (9 + 18) * cout * k_ch, lambda: check(
+                lib.cvk_wino4f_weight_transform(w.data_ptr(), Uf.data_ptr(), cout, k_ch, 0, s), "cvk_wino4f_weight_transform"), "byte")
+        Pf = lib.cvk_wino4f_stat_partials(N, H, W)
+        cnt = sp + 4 * 2 * Pf * cout if sp is not None else None
+        _timed(R, "k_conv3x3_wino4f", flops, lambda: check(
+            lib.cvk_conv3x3_wino4f(x.data_ptr(), Uf.data_ptr(), bias, y.data_ptr(), sp, cnt, N, H, W, k_ch, cout, ldy, s),
+            "cvk_conv3x3_wino4f" + what), executed=0.5 * flops)
+        return (Pf, cnt) if sp is not None else None
+    if use4:
         U = _empty(6 * cout * 3 * k_ch, x.device)
         if dgrad_of is not None and dgrad_of[1] == k_ch and dgrad_of[2] == cout:       # no channel padding on either side
             _timed(R, "k_wino4_weight_dgrad", 4.0 * (9 + 18) * cout * k_ch, lambda: check(
@@ -759,6 +785,7 @@ class Runner:
         self.grad_sync = None       # set by ddp.DataParallel
         self.wino = WINO_DEFAULT
         self.wino4 = WINO4_DEFAULT
+        self.wino4f = WINO4F_DEFAULT
         self.wino2d = WINO2D_DEFAULT
         self.bf16 = False           # opt-in: bf16-storage mode (modules.set_conv_precision; BASELINE.json configs[3])
 

@@ -282,9 +282,11 @@ def gold_miou():
 
 
 # ---------------------------------------------------------------- round 2: headline-size and protocol fixtures
-def _fullsize_case(kind, seed, shape, data_seed, tag, slice_hw):
+def _fullsize_case(kind, seed, shape, data_seed, tag, slice_hw, perturb=0.0):
     """One fwd+bwd of the imported reference at a BASELINE.json workload: loss, logits checksum + strided slice,
-    per-parameter gradient norms, BN running statistics checksums (no full tensors: the fixtures stay small)."""
+    per-parameter gradient norms, BN running statistics checksums (no full tensors: the fixtures stay small).
+    perturb > 0: the input gets a relative perturbation of that size (seed 7) — the distance of that run from the
+    unperturbed one is the reference's own sensitivity and derives the test tolerances."""
     torch.manual_seed(seed)
     net = UNet(3, 12) if kind == "unet" else SegNet(3, 12)
     net.train()
@@ -292,6 +294,8 @@ def _fullsize_case(kind, seed, shape, data_seed, tag, slice_hw):
     g = torch.Generator().manual_seed(data_seed)
     x = torch.randn(n, 3, h, w, generator=g)
     t = torch.randint(0, 12, (n, h, w), generator=g)
+    if perturb:
+        x = x * (1 + perturb * torch.randn(x.shape, generator=torch.Generator().manual_seed(7)))
     out = net(x)
     loss = nn.CrossEntropyLoss()(out, t)
     loss.backward()
@@ -318,6 +322,14 @@ def _fullsize_case(kind, seed, shape, data_seed, tag, slice_hw):
 def gold_batch8():
     """BASELINE.json configs[1]: UNet(3,12), 8x3x360x480, seed 0 / data seed 1234 (bench.py's batch)."""
     _fullsize_case("unet", 0, (8, 3, 360, 480), 1234, "unet_s0_8x360x480", (40, 48))
+
+
+def gold_segnet_batch8():
+    """BASELINE.json configs[4]: SegNet(3,12), 8x3x360x480 (models/segnet.py:82-119), bench.py's batch; plus the same
+    run under a 1e-6 relative input perturbation (arg-max flips in the five pool/unpool pairs make single gradients
+    discontinuous: the pair of runs measures how far the reference moves by itself)."""
+    _fullsize_case("segnet", 0, (8, 3, 360, 480), 1234, "segnet_s0_8x360x480", (40, 48))
+    _fullsize_case("segnet", 0, (8, 3, 360, 480), 1234, "segnet_s0_8x360x480_perturbed", (40, 48), perturb=1e-6)
 
 
 def gold_config3():
@@ -393,6 +405,8 @@ if __name__ == "__main__":
         gold_fullsize()
     if "b8" in which:
         gold_batch8()
+    if "segb8" in which:
+        gold_segnet_batch8()
     if "c3" in which:
         gold_config3()
     if "segnet2" in which:

@@ -1,0 +1,102 @@
+"""Raw C-ABI parity of the FUSED 1-D Winograd F(4,3) kernels (csrc/wino4f.hip) against the fp64 operator they replace:
+nn.Conv2d(cin, cout, 3, padding=1) of /root/reference/models/unet.py:11 (forward, + the BatchNorm batch statistics the
+block's train-mode BN needs, unet.py:12) and its data-gradient (backward of train.py:131).  Tolerances: the F(4,3)
+transform constants (4, 5, 8) round 6-8e-7 relative L2 per layer (tests/test_drift_cpu.py); stated below per check."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from pytorch_camvid_amd import _lib
+    return _lib.load(), _lib.check
+
+
+def _fused_conv(x_nhwc, w_oihw, bias, stats=True, dgrad=False):
+    """x [N,H,W,Cin] fp32 cuda; w OIHW (forward filter).  dgrad: x is dy [N,H,W,Cout_f], result is dx [N,H,W,Cin_f]."""
+    lib, check = _lib()
+    s = torch.cuda.current_stream().cuda_stream
+    N, H, W, Ck = x_nhwc.shape
+    wcl = w_oihw.permute(0, 2, 3, 1).contiguous()          # [Cout][3][3][Cin]
+    Cn = w_oihw.shape[1] if dgrad else w_oihw.shape[0]
+    assert Ck == (w_oihw.shape[0] if dgrad else w_oihw.shape[1])
+    Uf = torch.empty(lib.cvk_wino4f_weight_floats(Cn, Ck), device="cuda")
+    check(lib.cvk_wino4f_weight_transform(wcl.data_ptr(), Uf.data_ptr(), Cn, Ck, 1 if dgrad else 0, s), "weight")
+    y = torch.full((N, H, W, Cn), float("nan"), device="cuda")
+    P = lib.cvk_wino4f_stat_partials(N, H, W)
+    st = torch.zeros(2 * P * Cn + P, device="cuda") if stats else None
+    check(lib.cvk_conv3x3_wino4f(x_nhwc.data_ptr(), Uf.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                 st.data_ptr() if stats else None, st.data_ptr() + 4 * 2 * P * Cn if stats else None,
+                                 N, H, W, Ck, Cn, Cn, s), "conv")
+    torch.cuda.synchronize()
+    return y, st, P
+
+
+CASES = [  # N, H, W, Cin, Cout  — ragged widths (W % 4 != 0), rows < one tile, several tiles per workgroup, 1-3 n-tiles
+    (1, 5, 7, 32, 64),
+    (2, 9, 13, 64, 64),
+    (1, 16, 36, 64, 128),
+    (2, 33, 50, 128, 64),
+    (1, 45, 60, 128, 136),
+    (3, 64, 96, 64, 64),
+    (8, 90, 120, 64, 64),      # 21600 tile rows = 169 tiles: partial last tile
+    (2, 3, 4, 512, 512),       # one column group per image row (Wt = 1), deep K: the SegNet bottleneck geometries
+    (2, 6, 8, 512, 256),
+    (2, 12, 16, 256, 256),
+    (1, 2, 3, 64, 64),         # W < 4
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", CASES)
+def test_fused_forward_and_statistics_vs_fp64(N, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)                    # the reference operator, fp64
+    y, st, P = _fused_conv(x.permute(0, 2, 3, 1).contiguous().cuda(), w.cuda(), b.cuda())
+    got = y.permute(0, 3, 1, 2).double().cpu()
+    assert torch.isfinite(got).all()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel < 3e-6, rel                                                           # F(4,3) rounding: ~7e-7 per layer
+    assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    # statistics partials: [sum | M2 about the partial mean] + counts  ->  batch mean / biased variance (unet.py:12)
+    M = N * H * W
+    sums = st[:P * Cout].view(P, Cout).double().cpu()
+    m2 = st[P * Cout:2 * P * Cout].view(P, Cout).double().cpu()
+    cnt = st[2 * P * Cout:].double().cpu()
+    assert int(cnt.sum().item()) == M
+    mean = sums.sum(0) / M
+    var = (m2.sum(0) + (cnt[:, None] * (sums / cnt[:, None] - mean) ** 2).sum(0)) / M
+    rmean, rvar = ref.mean(dim=(0, 2, 3)), ref.var(dim=(0, 2, 3), unbiased=False)
+    assert (mean - rmean).abs().max().item() < 2e-6 * max(1.0, rmean.abs().max().item())
+    assert ((var - rvar).abs() / rvar).max().item() < 2e-5
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 9, 13, 64, 64), (1, 16, 36, 64, 128), (2, 33, 50, 128, 64), (3, 64, 96, 64, 64)])
+def test_fused_data_grad_vs_fp64(N, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(7 + Cin + Cout)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    ref = F.conv_transpose2d(dy.double(), w.double(), padding=1)                     # d/dx of conv2d(x, w, padding=1)
+    dx, _, _ = _fused_conv(dy.permute(0, 2, 3, 1).contiguous().cuda(), w.cuda(), None, stats=False, dgrad=True)
+    got = dx.permute(0, 3, 1, 2).double().cpu()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel < 3e-6, rel
+
+
+def test_fused_is_deterministic_and_tile_walk_independent():
+    """Bitwise reproducible, and every image of a batch equals the same image run alone (the persistent tile walk and the
+    batch size must not change any value: the K order per output is fixed)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 40, 72, 64, generator=g).cuda()
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).cuda()
+    b = torch.randn(64, generator=g).cuda()
+    y1, s1, _ = _fused_conv(x, w, b)
+    y2, s2, _ = _fused_conv(x, w, b)
+    assert torch.equal(y1, y2) and torch.equal(s1, s2)
+    for n in range(4):
+        yn, _, _ = _fused_conv(x[n:n + 1].contiguous(), w, b)
+        assert torch.equal(yn[0], y1[n])

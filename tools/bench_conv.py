@@ -75,6 +75,16 @@ def main():
             err = (y - yref).abs().max().item() / yref.abs().max().item() if "wino" in which else float("nan")
             serr = (stats - sref).abs().max().item() / sref.abs().max().item() if "wino" in which else float("nan")
             row += f" wino4 gemm {tg*1e6:7.1f} out {to*1e6:6.1f}us {flops/t/1e12:6.1f}TF (gemm {flops/tg/1e12:6.1f}) err {err:.1e} {serr:.1e}"; tot["wino4"][0] += flops; tot["wino4"][1] += t
+        if "wino4f" in which and ci % 32 == 0 and co % 4 == 0 and ci <= 256 and co <= 256:
+            yref = y.clone()
+            Uf = torch.empty(lib.cvk_wino4f_weight_floats(co, ci), device=dev)
+            check(lib.cvk_wino4f_weight_transform(w.data_ptr(), Uf.data_ptr(), co, ci, 0, s))
+            Pf = lib.cvk_wino4f_stat_partials(N, H, W); stf = torch.zeros(2 * Pf * co + Pf, device=dev)
+            y.zero_()
+            t = timeit(lambda: check(lib.cvk_conv3x3_wino4f(x.data_ptr(), Uf.data_ptr(), b.data_ptr(), y.data_ptr(), stf.data_ptr(), stf.data_ptr() + 8 * Pf * co,
+                                                            N, H, W, ci, co, ldy, s)))
+            err = (y - yref).abs().max().item() / max(yref.abs().max().item(), 1e-30) if "wino4" in which else float("nan")
+            row += f" wino4f {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF err {err:.1e}"; tot["wino4f"][0] += flops; tot["wino4f"][1] += t
         if "w2d" in which and ci % 32 == 0 and co >= 64 and co % 4 == 0:
             yref = y.clone()
             U2 = torch.empty(36 * co * ci, device=dev)

@@ -1,0 +1,38 @@
+#!/bin/bash
+# PMC counters of the fused F(4,3) kernel on one layer (separate passes): HBM traffic, matrix-pipe / wait states, LDS.
+# usage: tools/pmc_wino4f.sh "64 64 360 480"
+ARGS=${1:-"64 64 360 480"}
+OUT=gpurun_out/pmc_w4f
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p $OUT
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
+         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVE_CYCLES" \
+         "TCC_HIT_sum TCC_MISS_sum"; do
+  tag=$(echo $c | cut -d' ' -f1)
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$tag -- python3 tools/run_wino4f.py $ARGS > /dev/null 2> $OUT/$tag.err
+done
+python3 - <<'PY'
+import csv, glob, collections, json
+res = collections.defaultdict(float); n = 0; t = 0.0; seen = set()
+for f in glob.glob("gpurun_out/pmc_w4f/*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "k_conv3x3_wino4f" not in r["Kernel_Name"]: continue
+        res[r["Counter_Name"]] += float(r["Counter_Value"])
+        key = (f, r["Dispatch_Id"])
+        if "FETCH_SIZE" in f and key not in seen:
+            seen.add(key); n += 1; t += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+k = max(n, 1)
+out = {"launches": n, "avg_us": round(t / k * 1e6, 1),
+       "read_MB_per_launch": round(2.0 * res["FETCH_SIZE"] * 1024 / k / 1e6, 1), "write_MB_per_launch": round(res["WRITE_SIZE"] * 1024 / k / 1e6, 1)}
+gui = res["GRBM_GUI_ACTIVE"]; wc = res["SQ_WAVE_CYCLES"] / 2 if res["SQ_WAVE_CYCLES"] else 0     # collected in two passes
+if gui:
+    out["mfma_busy_frac_of_simd_cycles"] = round(res["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / 8 * 1024), 4)
+for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"):
+    if wc: out[c.lower() + "_frac_of_wave_cycles"] = round(res[c] / wc, 4)
+for c in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU"):
+    out[c.lower() + "_per_launch"] = round(res[c] / k)
+if res["TCC_HIT_sum"] + res["TCC_MISS_sum"]:
+    out["l2_hit_rate"] = round(res["TCC_HIT_sum"] / (res["TCC_HIT_sum"] + res["TCC_MISS_sum"]), 4)
+json.dump(out, open("gpurun_out/pmc_w4f/summary.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
