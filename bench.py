@@ -10,15 +10,20 @@ on a per-GPU batch of 8 (SURVEY.md §8d timed region; the optimizer step is excl
 Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 
 Extra objects on the line:
-  roofline     — the dominant kernel (MFMA implicit-GEMM conv, largest share of step time).  `achieved` / `frac` are
-                 the FLOPs the matrix pipe EXECUTES per second over the dense MFMA peak (a hardware fraction, <= 1):
-                 algorithmic FLOPs per launch x the kernel's executed share (Winograd F(4,3) runs 9 of 18) / average
-                 launch duration, measured live with HIP events on the launch stream during extra instrumented steps
-                 after the timed region; the algorithmic rate is kept beside it (`algorithmic_tflops`).
-                 peak = 157.3 TFLOP/s (fp32 MFMA) or 2500 TFLOP/s (bf16 MFMA, --precision bf16).
-  cpu_baseline — the same loop on the host cores with the stock-torch rebuild of the reference network
-                 (oracle/torch_ref.py; the reference itself is stock torch.nn and its source cannot travel to the GPU
-                 box), batch 2, rank 0 at N=1 only.
+  roofline      — the dominant kernel (largest share of step time).  `achieved` / `frac` are the FLOPs the matrix pipe
+                  EXECUTES per second over the dense MFMA peak (a hardware fraction, <= 1): algorithmic FLOPs per launch x
+                  the kernel's executed share (Winograd F(4,3) runs 9 of 18) / average launch duration, measured live with
+                  HIP events on the launch stream during extra instrumented steps after the timed region; the algorithmic
+                  rate is kept beside it (`algorithmic_tflops`).  peak = 157.3 TFLOP/s (fp32 MFMA) or 2500 (bf16 MFMA).
+  cpu_baseline  — the same loop on the host cores with the stock-torch rebuild of the reference network
+                  (oracle/torch_ref.py; the reference itself is stock torch.nn and its source cannot travel to the GPU
+                  box), batch 2, rank 0 at N=1 only.
+  extra_configs — (N=1, headline configuration only) short legs of the other single-GPU configurations of BASELINE.json in the
+                  same process, after the headline measurement: configs[3] (UNet 4x3x720x960, bf16 storage + bf16 MFMA) and
+                  configs[4] (SegNet 8x3x360x480 fp32): images/s, ms/step, dominant kernel, its executed fraction of peak.
+  dp            — (N>1) what took part and how much of the exchange was exposed: device UUID / PCI bus id of every rank,
+                  distinct GPUs, gradient buckets, the compute stream's wait for the all-reduces per step (HIP events around
+                  GradSync.finish), per-rank step time min/max, the RCCL environment knobs in effect.
 """
 import argparse
 import glob
@@ -34,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak (spec), opt-in --precision bf16 only
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak (spec), bf16-storage mode only
 PEAK_HBM_BPS = 8.0e12             # MI355X_MICROARCH.md: HBM3E spec (6.29e12 measured copy)
 PER_GPU_BATCH = 8
 H, W = 360, 480
@@ -53,11 +58,29 @@ def parse():
                     help="bf16 = bf16-storage mode (BASELINE.json configs[3]: --precision bf16 --height 720 --width 960 --batch 4); the headline is fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs[3] / configs[4] legs after the headline")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (N=1; reported under `graph_replay`, never `value`)")
     ap.add_argument("--with-optimizer", action="store_true", help="also time AdamW steps (reported separately)")
     ap.add_argument("--with-input-pipeline", action="store_true",
                     help="also time the steps fed from HOST uint8 frames through DevicePrefetcher (pinned staging, 1-byte upload one "
                          "batch ahead, device-side normalisation): the PCIe-inclusive rate, reported separately, never `value`")
     return ap.parse_args()
+
+
+def config_label(model, batch, h, w, precision, world):
+    """Which BASELINE.json configuration a workload is."""
+    if model == "segnet" and (batch, h, w, precision) == (8, 360, 480, "fp32"):
+        tag = "configs[4]"
+    elif model == "unet" and (batch, h, w, precision) == (4, 720, 960, "bf16"):
+        tag = "configs[3]"
+    elif model == "unet" and (batch, h, w, precision) == (8, 360, 480, "fp32"):
+        tag = "configs[1]"
+    else:
+        tag = "not a BASELINE.json configuration"
+    if world > 1:
+        tag += " x N ranks, RCCL grad all-reduce (configs[2])" if tag == "configs[1]" else " x N ranks"
+    name = "UNET" if model == "unet" else "SegNet"
+    return f"{name}(3,12) train fwd+bwd+CE, per-GPU batch {batch} x 3x{h}x{w} {precision} (BASELINE.json {tag})"
 
 
 def cpu_baseline(model, h, w):
@@ -98,6 +121,157 @@ def self_launch(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def executed_share(name):
+    # share of the algorithmic (direct-convolution) FLOPs a kernel really executes on the matrix pipe: F(4,3) Winograd 9 of
+    # 18, F(2,3) 12 of 18, direct kernels all of them (2-D F(4x4,3x3): 4.5 of 18 times the tile padding — the engine passes
+    # the executed count per call)
+    return 0.5 if "wino4" in name else ((2.0 / 3.0) if "wino" in name else 1.0)
+
+
+def peak_of(name):
+    return PEAK_BF16_MFMA_TFLOPS if "bf16" in name else PEAK_F32_MFMA_TFLOPS
+
+
+def kernel_profile(step, dev, nprof=3):
+    """Three extra instrumented steps: HIP events around every kernel launch of the path (engine._timed), on the launch stream."""
+    from pytorch_camvid_amd import engine
+    engine.PROF = []
+    for _ in range(nprof):
+        step()
+    torch.cuda.synchronize(dev)
+    agg, mem = {}, {}
+    for name, work, e0, e1, unit, executed in engine.PROF:
+        d = (agg if unit == "flop" else mem).setdefault(name, [0, 0.0, 0.0, 0.0])
+        d[0] += 1; d[1] += work; d[2] += e0.elapsed_time(e1) * 1e-3
+        d[3] += executed if executed is not None else work * executed_share(name)
+    engine.PROF = None
+    kernels = {k: {"launches_per_step": v[0] // nprof, "avg_us": round(v[2] / v[0] * 1e6, 1),
+                   "tflops": round(v[1] / v[2] / 1e12, 2), "ms_per_step": round(v[2] / nprof * 1e3, 3),
+                   "executed_frac_of_peak": round(v[3] / v[2] / 1e12 / peak_of(k), 4)} for k, v in agg.items()}
+    hbm_kernels = {k: {"launches_per_step": v[0] // nprof, "ms_per_step": round(v[2] / nprof * 1e3, 3),
+                       "algorithmic_GBps": round(v[1] / v[2] / 1e9, 1), "frac_of_8TBps": round(v[1] / v[2] / PEAK_HBM_BPS, 3)}
+                   for k, v in mem.items()}
+    dom = max(agg.items(), key=lambda kv: kv[1][2])
+    cnt, fl, sec, exe = dom[1]
+    alg = fl / sec / 1e12                       # algorithmic TFLOP/s (SURVEY.md §8d numerator)
+    peak = peak_of(dom[0])
+    ach = exe / sec / 1e12                      # FLOPs the MFMA pipe really executes per second: a hardware fraction <= 1
+    allf = sum(v[1] for v in agg.values()); alls = sum(v[2] for v in agg.values())
+    alle = sum(v[3] for v in agg.values())
+    traffic = None
+    pat = "r*_pmc_hbm_traffic_bf16.json" if "bf16" in dom[0] else "r*_pmc_hbm_traffic.json"
+    tp = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))[-1:]
+    tp = tp[0] if tp else ""
+    if os.path.exists(tp):
+        for k, v in json.load(open(tp)).items():
+            if k.replace(" ", "") == dom[0].replace(" ", ""):
+                traffic = {"bytes_per_launch": (v["read_MB_per_launch"] + v["write_MB_per_launch"]) * 1e6,
+                           "source": "profiles/" + os.path.basename(tp) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                                     "FETCH doubled per MI355X_MICROARCH.md; recorded run, not this run)"}
+    roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": traffic,
+            "algorithmic_tflops": round(alg, 2), "algorithmic_speedup_vs_peak": round(alg / peak, 4),
+            "executed_share_of_algorithmic_flops": round(exe / fl, 4),
+            "flops_per_launch": fl / cnt, "avg_launch_us": round(sec / cnt * 1e6, 1), "launches_per_step": cnt // nprof,
+            "all_conv_kernels": {"algorithmic_tflops": round(allf / alls / 1e12, 2),
+                                 "executed_frac_of_peak": round(alle / alls / 1e12 / peak, 4),
+                                 "ms_per_step": round(alls / nprof * 1e3, 2)},
+            "hbm_bound_kernels_ms_per_step": round(sum(v[2] for v in mem.values()) / nprof * 1e3, 2)}
+    return roof, kernels, hbm_kernels
+
+
+def run_leg(A, dev, model, batch, h, w, precision, steps, warmup, profile, world=1, rank=0, rehearsal=False, want_model=False):
+    """Build the network, time `steps` steps after `warmup`, optionally profile the kernels.  Returns a dict."""
+    from pytorch_camvid_amd import ddp
+    torch.manual_seed(0)                                    # identical init on every rank (also broadcast by DataParallel)
+    net = A.get_model(model, 3, 12).to(dev).train()
+    A.set_conv_precision(net, precision)
+    wrapped = ddp.DataParallel(net) if world > 1 else net
+    lossf = A.CrossEntropyLoss()
+    g = torch.Generator().manual_seed(1234 + rank)          # per-rank shard of the global batch
+    x = torch.randn(batch, 3, h, w, generator=g).to(dev)
+    t = torch.randint(0, 12, (batch, h, w), generator=g).to(dev)
+    params = list(net.parameters())
+
+    def step():
+        for p in params:
+            p.grad = None
+        # a training step sees new weights every time (optimizer.step, outside the timed region): the derived weight tensors
+        # (Winograd-domain filters, data-grad packs, bf16 copies) are REBUILT inside every timed step, never served from the
+        # executor's cache — the cache only helps eval and repeated passes over unchanged weights
+        A.mark_weights_dirty(net)
+        loss = lossf(wrapped(x), t)
+        loss.backward()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(warmup):
+        step()
+    sync = wrapped.sync if world > 1 else None
+    if sync is not None:
+        sync.wait_events = []                               # HIP events around every GradSync.finish of the timed steps
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    fence()
+    dt_local = time.perf_counter() - t0
+    dt = dt_local
+    out = {}
+    if world > 1:
+        tt = torch.tensor([dt_local], device="cpu" if rehearsal else dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(gathered, tt)
+        per_rank = [float(v.item()) / steps * 1e3 for v in gathered]
+        dt = max(per_rank) * steps / 1e3                    # MAX over ranks
+        ev = sync.wait_events
+        sync.wait_events = None
+        exposed = [a.elapsed_time(b) for a, b in ev] if ev else []
+        out["dp_local"] = {"per_rank_ms_per_step": [round(v, 3) for v in per_rank],
+                           "allreduce_exposed_ms": round(sum(exposed) / max(len(exposed), 1), 3),
+                           "allreduce_exposed_ms_max": round(max(exposed), 3) if exposed else None,
+                           "buckets": [{"floats": hi - lo, "MB": round((hi - lo) * 4 / 2 ** 20, 1)} for lo, hi in sync.launched]}
+    out.update({"value": world * batch * steps / dt, "ms": dt / steps * 1e3, "loss": float(loss.item()), "step": step, "fence": fence,
+                "net": net, "wrapped": wrapped, "lossf": lossf, "params": params, "x": x, "t": t})
+    if profile:
+        out["roof"], out["kernels"], out["hbm_kernels"] = kernel_profile(step, dev)
+    if not want_model:
+        for k in ("step", "fence", "net", "wrapped", "lossf", "params", "x", "t"):
+            out.pop(k)
+        del net, wrapped, x, t, params
+        torch.cuda.empty_cache()
+    return out
+
+
+def dp_identity(dev, world, rehearsal):
+    """Which device each rank really runs on (all-gathered): proves N distinct GPUs took part."""
+    pr = torch.cuda.get_device_properties(dev)
+    uuid = str(getattr(pr, "uuid", ""))
+    bus = ""
+    try:
+        bus = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+    except AttributeError:
+        pass
+    me = {"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": dev.index,
+          "name": pr.name, "uuid": uuid, "pci_bus_id": bus, "pid": os.getpid()}
+    ranks = [None] * world
+    dist.all_gather_object(ranks, me)
+    ids = {(r["uuid"], r["pci_bus_id"]) for r in ranks}
+    return {"ranks_seen": ranks, "distinct_gpus": len(ids), "rehearsal": rehearsal,
+            "backend": dist.get_backend(),
+            "rccl_env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_NCHANNELS_PER_PEER", "RCCL_MSCCL_ENABLE",
+                                                        "NCCL_ALGO", "NCCL_PROTO", "HSA_ENABLE_IPC_MODE_LEGACY", "CVK_DDP_BUCKET_MB", "CVK_W2D_NO_STAGGER")
+                         if os.environ.get(k) is not None},
+            "note": "the conv grids assume an undisturbed chip (whole rounds of 256 CUs, csrc/wino2d.hip staggered start): RCCL's "
+                    "all-reduce kernels occupy NCCL_MAX_NCHANNELS workgroups while backward runs; lower it (e.g. 8-16) if "
+                    "allreduce_exposed_ms is small but ms_per_step grows with N, and set CVK_W2D_NO_STAGGER=1 to A/B the stagger."}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,8 +291,6 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import pytorch_camvid_amd as A
-    from pytorch_camvid_amd import ddp
-    from pytorch_camvid_amd.modules import runner_of
 
     if world > 1:
         if rehearsal:
@@ -126,46 +298,14 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)     # RCCL
 
-    torch.manual_seed(0)                                    # identical init on every rank (also broadcast below)
-    net = A.get_model(a.model, 3, 12).to(dev).train()
-    A.set_conv_precision(net, a.precision)
-    model = ddp.DataParallel(net) if world > 1 else net
-    lossf = A.CrossEntropyLoss()
-    g = torch.Generator().manual_seed(1234 + rank)          # per-rank shard of the global batch
-    x = torch.randn(a.batch, 3, a.height, a.width, generator=g).to(dev)
-    t = torch.randint(0, 12, (a.batch, a.height, a.width), generator=g).to(dev)
-    params = list(net.parameters())
+    headline = (a.model, a.batch, a.height, a.width, a.precision) == ("unet", PER_GPU_BATCH, H, W, "fp32")
+    leg = run_leg(A, dev, a.model, a.batch, a.height, a.width, a.precision, a.steps, a.warmup, not a.no_kernel_profile,
+                  world=world, rank=rank, rehearsal=rehearsal, want_model=True)
+    step, params, net, wrapped, lossf = leg["step"], leg["params"], leg["net"], leg["wrapped"], leg["lossf"]
 
-    def step():
-        for p in params:
-            p.grad = None
-        loss = lossf(model(x), t)
-        loss.backward()
-        return loss
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    for _ in range(a.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    ms = dt / a.steps * 1e3
-    value = world * a.batch * a.steps / dt
-
+    # The optional extra loops run on EVERY rank: at N>1 each backward issues the bucketed all-reduces, which all ranks must post.
     opt_ms = None
-    if a.with_optimizer and rank == 0:
+    if a.with_optimizer:
         opt = torch.optim.AdamW(params, lr=5e-4, weight_decay=0)
         step(); opt.step(); torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
@@ -175,10 +315,10 @@ def main():
         opt_ms = (time.perf_counter() - t1) / 5 * 1e3
 
     pipe = None
-    if a.with_input_pipeline and rank == 0:
+    if a.with_input_pipeline:
         import numpy as np
         from pytorch_camvid_amd.functional import DevicePrefetcher
-        rng = np.random.default_rng(0)
+        rng = np.random.default_rng(rank)
         nb = 6
         host = [(rng.integers(0, 256, (a.batch, a.height, a.width, 3), dtype=np.uint8),
                  rng.integers(0, 12, (a.batch, a.height, a.width)).astype(np.int64)) for _ in range(nb)]
@@ -192,101 +332,93 @@ def main():
         k = 0
         for xb, tb in it:
             if k == 2:
-                torch.cuda.synchronize(dev); t1 = time.perf_counter()
+                leg["fence"](); t1 = time.perf_counter()
             for p in params:
                 p.grad = None
-            lossf(model(xb), tb).backward()
+            A.mark_weights_dirty(net)
+            lossf(wrapped(xb), tb).backward()
             k += 1
-        torch.cuda.synchronize(dev)
+        leg["fence"]()
         dtp = (time.perf_counter() - t1) / (k - 2)
-        pipe = {"images_per_s": round(a.batch / dtp, 3), "ms_per_step": round(dtp * 1e3, 3), "steps": k - 2,
+        pipe = {"images_per_s": round(world * a.batch / dtp, 3), "ms_per_step": round(dtp * 1e3, 3), "steps": k - 2,
                 "host_bytes_per_step": int(a.batch * a.height * a.width * (3 + 8)),
                 "what": "same step fed from host uint8 BGR frames + int64 masks: pinned staging, upload on a side stream one batch "
-                        "ahead, normalisation to float NHWC on the device (functional.DevicePrefetcher)"}
+                        "ahead, normalisation to float NHWC on the device (functional.DevicePrefetcher); rank 0's clock"}
 
-    roof = None
-    kernels = None
-    hbm_kernels = None
-    if not a.no_kernel_profile:
-        from pytorch_camvid_amd import engine
-        engine.PROF = []
+    graph = None
+    if a.graph and world == 1:
+        from pytorch_camvid_amd.graph import GraphedStep
+        gs = GraphedStep(net, lossf, leg["x"], leg["t"])
         for _ in range(3):
-            step()
+            gs.replay()
         torch.cuda.synchronize(dev)
-        agg, mem = {}, {}
-        def executed_share(name):
-            # share of the algorithmic (direct-convolution) FLOPs a kernel really executes on the matrix pipe:
-            # F(4,3) Winograd 9 of 18, F(2,3) 12 of 18, direct kernels all of them (2-D F(4x4,3x3): 4.5 of 18 times the
-            # tile padding — the engine passes the executed count per call)
-            return 0.5 if "wino4" in name else ((2.0 / 3.0) if "wino" in name else 1.0)
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            gs.replay()
+        th = time.perf_counter() - t1                       # host time to enqueue a.steps replays
+        torch.cuda.synchronize(dev)
+        tg = time.perf_counter() - t1
+        graph = {"images_per_s": round(a.batch * a.steps / tg, 3), "ms_per_step": round(tg / a.steps * 1e3, 3),
+                 "host_enqueue_ms_per_step": round(th / a.steps * 1e3, 4), "loss": round(float(gs.loss.item()), 6),
+                 "what": "zero_grad + forward + CE + backward replayed from ONE captured HIP graph (pytorch_camvid_amd.graph.GraphedStep)"}
+        del gs
 
-        for name, work, e0, e1, unit, executed in engine.PROF:
-            d = (agg if unit == "flop" else mem).setdefault(name, [0, 0.0, 0.0, 0.0])
-            d[0] += 1; d[1] += work; d[2] += e0.elapsed_time(e1) * 1e-3
-            d[3] += executed if executed is not None else work * executed_share(name)
-        engine.PROF = None
-        kernels = {k: {"launches_per_step": v[0] // 3, "avg_us": round(v[2] / v[0] * 1e6, 1),
-                       "tflops": round(v[1] / v[2] / 1e12, 2), "ms_per_step": round(v[2] / 3 * 1e3, 3)} for k, v in agg.items()}
-        hbm_kernels = {k: {"launches_per_step": v[0] // 3, "ms_per_step": round(v[2] / 3 * 1e3, 3),
-                           "algorithmic_GBps": round(v[1] / v[2] / 1e9, 1), "frac_of_8TBps": round(v[1] / v[2] / PEAK_HBM_BPS, 3)}
-                       for k, v in mem.items()}
-        def peak_of(name):
-            return PEAK_BF16_MFMA_TFLOPS if ("bf16" in name and "split" not in name) else PEAK_F32_MFMA_TFLOPS
-
-        for k, v in agg.items():
-            kernels[k]["executed_frac_of_peak"] = round(v[3] / v[2] / 1e12 / peak_of(k), 4)
-        dom = max(agg.items(), key=lambda kv: kv[1][2])
-        cnt, fl, sec, exe = dom[1]
-        alg = fl / sec / 1e12                       # algorithmic TFLOP/s (SURVEY.md §8d numerator)
-        executed = exe / fl
-        peak = peak_of(dom[0])
-        ach = exe / sec / 1e12                      # FLOPs the MFMA pipe really executes per second: a hardware fraction <= 1
-        allf = sum(v[1] for v in agg.values()); alls = sum(v[2] for v in agg.values())
-        alle = sum(v[3] for v in agg.values())
-        traffic = None
-        pat = "r*_pmc_hbm_traffic_bf16.json" if "bf16" in dom[0] else "r*_pmc_hbm_traffic.json"
-        tp = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))[-1:]
-        tp = tp[0] if tp else ""
-        if os.path.exists(tp):
-            for k, v in json.load(open(tp)).items():
-                if k.replace(" ", "") == dom[0].replace(" ", ""):
-                    traffic = {"bytes_per_launch": (v["read_MB_per_launch"] + v["write_MB_per_launch"]) * 1e6,
-                               "source": "profiles/" + os.path.basename(tp) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                                         "FETCH doubled per MI355X_MICROARCH.md; recorded run, not this run)"}
-        roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic,
-                "algorithmic_tflops": round(alg, 2), "algorithmic_speedup_vs_peak": round(alg / peak, 4),
-                "executed_share_of_algorithmic_flops": round(executed, 4),
-                "flops_per_launch": fl / cnt, "avg_launch_us": round(sec / cnt * 1e6, 1), "launches_per_step": cnt // 3,
-                "all_conv_kernels": {"algorithmic_tflops": round(allf / alls / 1e12, 2),
-                                     "executed_frac_of_peak": round(alle / alls / 1e12 / peak, 4),
-                                     "ms_per_step": round(alls / 3 * 1e3, 2)}}
+    dp = None
+    if world > 1:
+        dp = dp_identity(dev, world, rehearsal)
+        dp.update(leg["dp_local"])
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.model, a.height, a.width)
 
+    # free the headline network before the extra legs
+    for k in ("step", "fence", "net", "wrapped", "lossf", "params", "x", "t"):
+        leg.pop(k, None)
+    del step, params, net, wrapped, lossf
+    torch.cuda.empty_cache()
+
+    extra = None
+    if world == 1 and headline and not a.no_extra_configs:
+        extra = []
+        es, ew = max(3, min(a.steps, 10)), max(2, min(a.warmup, 3))
+        for (m, b, hh, ww, prec) in (("unet", 4, 720, 960, "bf16"), ("segnet", 8, 360, 480, "fp32")):
+            e = run_leg(A, dev, m, b, hh, ww, prec, es, ew, True)
+            r = e["roof"]
+            extra.append({"workload": config_label(m, b, hh, ww, prec, 1), "dtype": "bf16" if prec == "bf16" else "f32",
+                          "images_per_s": round(e["value"], 3), "ms_per_step": round(e["ms"], 3), "steps": es, "warmup": ew,
+                          "loss": round(e["loss"], 6), "dominant_kernel": r["kernel"], "executed_frac_of_peak": r["frac"],
+                          "peak_tflops": r["peak"], "dominant_kernel_ms_per_step": round(r["avg_launch_us"] * r["launches_per_step"] / 1e3, 3),
+                          "all_conv_kernels": r["all_conv_kernels"], "hbm_bound_kernels_ms_per_step": r["hbm_bound_kernels_ms_per_step"]})
+
     if rank == 0:
         line = {
-            "metric": "images/sec fwd+bwd UNet 3x360x480 bs=8" if a.model == "unet" and (a.height, a.width, a.batch) == (H, W, 8) and a.precision == "fp32"
+            "metric": "images/sec fwd+bwd UNet 3x360x480 bs=8" if headline
                       else f"images/sec fwd+bwd {a.model} 3x{a.height}x{a.width} bs={a.batch} ({a.precision})",
-            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": "bf16 (bf16 activations/gradients in HBM, bf16 MFMA with f32 accumulate, f32 statistics/parameters)"}[a.precision], "data": "synthetic" + (" (REHEARSAL: ranks share a GPU over gloo — not a measurement)" if rehearsal else ""),
-            "config": {"workload": f"{a.model.upper() if a.model=='unet' else 'SegNet'}(3,12) train fwd+bwd+CE, per-GPU batch {a.batch} x 3x{a.height}x{a.width} {a.precision} "
-                                   f"(BASELINE.json {'configs[3]' if a.precision == 'bf16' else 'configs[1]'}{' x N ranks, RCCL grad all-reduce (configs[2])' if world > 1 else ''})",
+            "value": round(leg["value"], 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(leg["ms"], 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"fp32": "f32", "bf16": "bf16 (bf16 activations/gradients in HBM, bf16 MFMA with f32 accumulate, f32 statistics/parameters)"}[a.precision],
+            "data": "synthetic" + (" (REHEARSAL: ranks share a GPU over gloo — not a measurement)" if rehearsal else ""),
+            "config": {"workload": config_label(a.model, a.batch, a.height, a.width, a.precision, world),
                        "global_batch": world * a.batch, "parallelism": f"dp{world}", "timed_region": "zero_grad+forward+CE+backward"
-                                   + ("+allreduce" if world > 1 else ""), "loss": round(float(loss.item()), 6)},
-            "roofline": roof, "cpu_baseline": cpu,
+                                   + ("+allreduce" if world > 1 else ""), "loss": round(leg["loss"], 6),
+                       "derived_weights": "rebuilt in every timed step (executor cache invalidated per step, as after optimizer.step)"},
+            "roofline": leg.get("roof"), "cpu_baseline": cpu,
         }
-        if kernels:
-            line["conv_kernels"] = kernels
-        if hbm_kernels:
-            line["hbm_kernels"] = hbm_kernels
+        if leg.get("kernels"):
+            line["conv_kernels"] = leg["kernels"]
+        if leg.get("hbm_kernels"):
+            line["hbm_kernels"] = leg["hbm_kernels"]
+        if extra is not None:
+            line["extra_configs"] = extra
+        if dp is not None:
+            line["dp"] = dp
         if opt_ms is not None:
             line["adamw_ms"] = round(opt_ms, 3)
         if pipe is not None:
             line["with_input_pipeline"] = pipe
+        if graph is not None:
+            line["graph_replay"] = graph
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

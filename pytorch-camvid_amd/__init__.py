@@ -10,9 +10,11 @@ from .functional import (ConfusionMeter, CrossEntropyLoss, argmax_channels, cros
                          evaluate_report, predict, preprocess_uint8, DevicePrefetcher, last_ce_status)
 from .optim import FlatAdamW  # noqa: F401
 from . import ddp  # noqa: F401
+from .graph import GraphedStep  # noqa: F401
+from .engine import mark_weights_dirty  # noqa: F401
 from .checkpoint import (save_checkpoint, load_checkpoint, latest_checkpoint, checkpoint_epoch, resume,   # noqa: F401
                          save_policy, reference_state_dict)
 
 __all__ = ["UNet", "SegNet", "BasicConv2d", "BasicConv", "UpSample2d", "get_model", "set_conv_precision", "CrossEntropyLoss",
-           "cross_entropy", "last_ce_status", "argmax_channels", "ConfusionMeter", "evaluate", "evaluate_report", "predict", "preprocess_uint8", "DevicePrefetcher", "FlatAdamW", "ddp", "save_checkpoint", "load_checkpoint", "latest_checkpoint", "checkpoint_epoch", "resume", "save_policy",
+           "cross_entropy", "last_ce_status", "argmax_channels", "ConfusionMeter", "evaluate", "evaluate_report", "predict", "preprocess_uint8", "DevicePrefetcher", "FlatAdamW", "ddp", "GraphedStep", "mark_weights_dirty", "save_checkpoint", "load_checkpoint", "latest_checkpoint", "checkpoint_epoch", "resume", "save_policy",
            "reference_state_dict", "build_library", "load_library", "CvkError"]

@@ -499,6 +499,9 @@ static int bnbwd_launch(int mode, cvk_viewh dout, int dout_f32, const void* y, i
     hipStream_t s = (hipStream_t)stream;
     const bool v8 = C % 8 == 0 && ldy % 8 == 0 && cvk_aligned16(y) && viewok(dout, 8, dout_f32 != 0) && (mode == 0 || (ld_dy % 8 == 0 && cvk_aligned16(dy)));
     CVK_CHECK_ARG(v8 || viewok(dout, 4, dout_f32 != 0), "%s: misaligned gradient view", name);
+    // a block's 256 threads own the C / V channel vectors (pixels-per-pass = 256 / (C / V)): more than 256 vectors would leave
+    // every thread idle and the partial sums unwritten
+    CVK_CHECK_ARG(C / (v8 ? 8 : 4) <= 256, "%s: C=%d needs more than 256 channel vectors of %d (C <= 1024 for 4-wide, 2048 for 8-wide access)", name, C, v8 ? 8 : 4);
 #define CVK_BB(V_, M_, F_) hipLaunchKernelGGL((k_bnbwd_bf16<V_, M_, F_>), dim3(PB), dim3(256), 0, s, dout.ptr, dm, (const __bf16*)y, ldy, scale, shift, mean, rstd, dgamma, dbeta, (__bf16*)dy, ld_dy, part, M, C, rows, PB, use_batch_stats)
     if (v8) {
         if (mode == 0) { if (dout_f32) CVK_BB(8, 0, true); else CVK_BB(8, 0, false); }

@@ -8,7 +8,7 @@ namespace {
 
 constexpr int CE_ROWS_PER_BLOCK = 1024;  // 4 chunks of 256 pixels per workgroup
 constexpr int CE_CHUNK = 256;            // one pixel per thread per chunk
-constexpr int CE_MAX_LD = 128;           // widest pixel row staged through LDS ((ld + 1) * 1 KB of LDS)
+constexpr int CE_MAX_LD = 63;            // widest pixel row staged through LDS ((ld + 1) * 1 KiB of dynamic LDS <= 64 KiB)
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
     v = wave_sum(v);
@@ -163,6 +163,60 @@ __global__ __launch_bounds__(256) void k_ce_bwd(const float* __restrict__ logits
     }
 }
 
+// Wide pixel rows (ld > CE_MAX_LD floats, i.e. 64 classes or more): the LDS-staged kernels above would need more than 64 KiB of
+// dynamic LDS, so one thread walks its pixel's row in global memory (reference train.py:105 puts no bound on class_num).
+__global__ __launch_bounds__(256) void k_ce_fwd_rows(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
+                                                    float* __restrict__ part, int nb, int M, int C, int ignore_index) {
+    __shared__ float red[4];
+    float acc = 0.f, cnt = 0.f, bad = 0.f;
+    const int base = blockIdx.x * CE_ROWS_PER_BLOCK;
+    for (int m = base + threadIdx.x; m < min(M, base + CE_ROWS_PER_BLOCK); m += CE_CHUNK) {
+        const float* p = logits + (size_t)m * ld;
+        const long t = (long)target[m];
+        if (t == (long)ignore_index) continue;
+        float mx = p[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, p[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(p[c] - mx);
+        if (t >= 0 && t < C) {
+            acc += (mx + logf(se)) - p[t];
+            cnt += 1.f;
+        } else {
+            bad += 1.f;
+        }
+    }
+    const float s = block_sum_256(acc, red);
+    const float n = block_sum_256(cnt, red);
+    const float b = block_sum_256(bad, red);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = s;
+        part[nb + blockIdx.x] = n;
+        part[2 * nb + blockIdx.x] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ce_bwd_rows(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
+                                                    const float* __restrict__ loss3, const float* __restrict__ grad_out, float scale,
+                                                    float* __restrict__ dl, int ld_d, int M, int C, int ignore_index) {
+    const float g = (grad_out != nullptr ? *grad_out : 1.f) * scale / loss3[1];
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+        const float* p = logits + (size_t)m * ld;
+        float* o = dl + (size_t)m * ld_d;
+        const long t = (long)target[m];
+        if (t == (long)ignore_index) {
+            for (int c = 0; c < ld_d; ++c) o[c] = 0.f;
+            continue;
+        }
+        float mx = p[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, p[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(p[c] - mx);
+        const float inv = 1.f / se;
+        for (int c = 0; c < C; ++c) o[c] = (expf(p[c] - mx) * inv - ((long)c == t ? 1.f : 0.f)) * g;
+        for (int c = C; c < ld_d; ++c) o[c] = 0.f;
+    }
+}
+
 __global__ void k_argmax(const float* __restrict__ logits, int ld, int64_t* __restrict__ out, int M, int C) {
     for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
         const float* p = logits + (size_t)m * ld;
@@ -243,10 +297,12 @@ extern "C" int cvk_ce_blocks(int M) { return M > 0 ? cvk_cdiv(M, CE_ROWS_PER_BLO
 extern "C" int cvk_softmax_ce_fwd(const float* logits, int ld, const int64_t* target, float* part, float* loss, int M, int C,
                                   int ignore_index, void* stream) {
     CVK_CHECK_ARG(logits && target && part && loss && M > 0 && C > 0 && ld >= C, "cvk_softmax_ce_fwd: bad arguments");
-    CVK_CHECK_ARG(ld <= CE_MAX_LD, "cvk_softmax_ce_fwd: pixel rows wider than %d floats are not supported (ld=%d)", CE_MAX_LD, ld);
     const int nb = cvk_ce_blocks(M);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_ce_fwd, dim3(nb), dim3(256), CE_CHUNK * (ld + 1) * sizeof(float), s, logits, ld, target, part, nb, M, C, ignore_index);
+    if (ld <= CE_MAX_LD)
+        hipLaunchKernelGGL(k_ce_fwd, dim3(nb), dim3(256), CE_CHUNK * (ld + 1) * sizeof(float), s, logits, ld, target, part, nb, M, C, ignore_index);
+    else
+        hipLaunchKernelGGL(k_ce_fwd_rows, dim3(nb), dim3(256), 0, s, logits, ld, target, part, nb, M, C, ignore_index);
     hipLaunchKernelGGL(k_ce_finish, dim3(1), dim3(256), 0, s, part, nb, loss);
     CVK_LAUNCH_RETURN("cvk_softmax_ce_fwd");
 }
@@ -254,9 +310,12 @@ extern "C" int cvk_softmax_ce_fwd(const float* logits, int ld, const int64_t* ta
 extern "C" int cvk_softmax_ce_bwd(const float* logits, int ld, const int64_t* target, const float* loss3, const float* grad_out,
                                   float scale, float* dlogits, int ld_d, int M, int C, int ignore_index, void* stream) {
     CVK_CHECK_ARG(logits && target && loss3 && dlogits && M > 0 && C > 0 && ld >= C && ld_d >= C, "cvk_softmax_ce_bwd: bad arguments");
-    CVK_CHECK_ARG(ld <= CE_MAX_LD, "cvk_softmax_ce_bwd: pixel rows wider than %d floats are not supported (ld=%d)", CE_MAX_LD, ld);
-    hipLaunchKernelGGL(k_ce_bwd, dim3(cvk_ce_blocks(M)), dim3(256), CE_CHUNK * (ld + 1) * sizeof(float), (hipStream_t)stream, logits, ld,
-                       target, loss3, grad_out, scale, dlogits, ld_d, M, C, ignore_index);
+    if (ld <= CE_MAX_LD)
+        hipLaunchKernelGGL(k_ce_bwd, dim3(cvk_ce_blocks(M)), dim3(256), CE_CHUNK * (ld + 1) * sizeof(float), (hipStream_t)stream, logits, ld,
+                           target, loss3, grad_out, scale, dlogits, ld_d, M, C, ignore_index);
+    else
+        hipLaunchKernelGGL(k_ce_bwd_rows, dim3(cvk_cdiv(M, 256) < 8192 ? cvk_cdiv(M, 256) : 8192), dim3(256), 0, (hipStream_t)stream, logits, ld,
+                           target, loss3, grad_out, scale, dlogits, ld_d, M, C, ignore_index);
     CVK_LAUNCH_RETURN("cvk_softmax_ce_bwd");
 }
 

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_w2d_weight(const float* __restrict__ Wt
 template <int BM, int BK, int NSTG, int WPS>      // tile rows, K slice (floats), LDS stages, waves per SIMD the kernel is built for
 __global__ __launch_bounds__(BM * 2, WPS) void k_w2d_gemm(const float* __restrict__ A, const float* __restrict__ B,
                                                          float* __restrict__ D, int T, int Tpad, int Nn, int K, int ldd,
-                                                         int tilesM, int tilesN, int split_start, int f, size_t part_stride) {
+                                                         int tilesM, int tilesN, int split_start, int f, size_t part_stride, int stagger) {
     constexpr int NW = BM / 32, ROWS = BM + W2_BN, ROWB = BK * 4, RPP = 1024 / ROWB, NCH = ROWB / 16;   // rows per 1 KiB DMA piece, chunks per row
     constexpr int PIECES = ROWS / RPP, PPW = PIECES / NW, STAGE = ROWS * ROWB, NS = BK / 8;
     constexpr int SWS = NCH == 8 ? 1 : 2;               // swizzle: chunk c of row r at c ^ ((r >> SWS) & (NCH-1))
@@ -202,7 +202,10 @@ __global__ __launch_bounds__(BM * 2, WPS) void k_w2d_gemm(const float* __restric
     // each CU) starts half a tile late, and every later workgroup inherits the phase shift (it starts when a predecessor
     // finishes): 1-4 % per layer.  (Tried without effect on this kernel: pinned fragment prefetch one k-group ahead — two
     // waves per SIMD already hide the LDS latency — and 4- or 5-deep rings of 16-float slices.)
-    if (((blockIdx.x >> 8) & 1) && blockIdx.x < 512)
+    // Only where the assumption holds: `stagger` = number of CUs when the grid has at least two full-tile workgroups per CU
+    // (else 0, set by the host: CVK_W2D_NO_STAGGER=1 turns it off for A/B timing, e.g. beside RCCL kernels under data-parallel
+    // runs); workgroups [stagger, 2 * stagger) are the second ones dispatched to each CU.  Full-round tiles only.
+    if (stagger > 0 && (int)blockIdx.x >= stagger && (int)blockIdx.x < 2 * stagger && (int)blockIdx.x < split_start)
         for (int i = 0; i < (ke - kb) * (BK / 8) / 8; ++i) __builtin_amdgcn_s_sleep(127);
 #pragma unroll
     for (int d = 0; d < NSTG - 1; ++d) issue(min(kb + d, ke - 1), d);
@@ -576,8 +579,16 @@ extern "C" int cvk_w2d_gemm(const float* V, const float* U, float* Mo, int T, in
     const dim3 grid(p.split_start + (p.NT - p.split_start) * p.f);
     const size_t part_stride = (size_t)36 * T * Cout;
     hipStream_t s = (hipStream_t)stream;
+    static int cus = 0, no_stagger = -1;          // queried once (benign race: every thread stores the same values)
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        const char* e = getenv("CVK_W2D_NO_STAGGER");
+        no_stagger = (e != nullptr && e[0] == '1') ? 1 : 0;
+    }
+    const int stagger = (!no_stagger && (int)grid.x >= 2 * cus && p.split_start >= 2 * cus) ? cus : 0;
     hipLaunchKernelGGL((k_w2d_gemm<128, 32, 2, 2>), grid, dim3(256), 0, s, V, U, Mo, T, w2_tpad(T), Cout, Cin, Cout, p.tilesM, p.tilesN,
-                       p.split_start, p.f, part_stride);
+                       p.split_start, p.f, part_stride, stagger);
     CVK_LAUNCH_RETURN("cvk_w2d_gemm");
 }
 

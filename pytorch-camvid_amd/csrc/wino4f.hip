@@ -465,10 +465,11 @@ extern "C" int cvk_conv3x3_wino4f(const float* x, const float* Uf, const float* 
     CVK_CHECK_ARG((long)Mt * Wt < (1L << 32) && (long)N * H * H < (1L << 32), "cvk_conv3x3_wino4f: frame too large for the multiply-high coordinate split");
     const int tilesN = f_tiles_n(Cout), tilesM = cvk_cdiv(Mt, F_BM), ntiles = tilesM * tilesN;
     // persistent strips: one workgroup per CU (144 KiB of LDS), each walks ntiles / grid consecutive tiles
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    static int cus = 0;          // queried once (a benign race: every thread stores the same value); not during a stream capture
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        else cus = 256;
     }
     const int grid = ntiles < cus ? ntiles : cus;
     CVK_CHECK_ARG((F_BM * 4 + 3L * W + 8) * Cin * 4 < (1L << 31), "cvk_conv3x3_wino4f: a tile's input window exceeds the 2 GiB buffer-addressing limit");

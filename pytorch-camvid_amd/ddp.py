@@ -15,6 +15,8 @@ xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of the f
 per-link bound at ~1.6 ms, so a handful of ~25-50 MB buckets keeps each collective bandwidth-bound rather than
 latency-bound while still starting early.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -68,24 +70,36 @@ class _SyncCall:
 
     def finish(self, st):
         assert self.next_bucket == len(self.buckets), "a gradient bucket was never completed"
+        ev = None
+        if self.owner.wait_events is not None and st.gflat.is_cuda:
+            # diagnostics (bench.py): HIP events on the compute stream around its wait for the collectives = the part of
+            # the exchange that backward did not hide.  Recorded only, read after the timed region (no host sync here).
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w, t in self.work:
             w.wait()                       # nccl: makes the current stream wait for the collective; no host sync
             if t is not None:
                 t.div_(self.owner.world)
         self.work = []
+        if ev is not None:
+            ev[1].record()
+            self.owner.wait_events.append(ev)
         self.owner.launched = self.launched
 
 
 class GradSync:
     """Bucketed gradient all-reduce hooked into engine.Runner.backward (begin() -> a per-call _SyncCall)."""
 
-    def __init__(self, process_group=None, bucket_mb=32.0, always_issue=False):
+    def __init__(self, process_group=None, bucket_mb=None, always_issue=False):
+        if bucket_mb is None:       # CVK_DDP_BUCKET_MB: bucket size knob (xGMI rings are per-link bound: few large buckets)
+            bucket_mb = float(os.environ.get("CVK_DDP_BUCKET_MB", "32"))
         self.pg = process_group
         self.always_issue = always_issue     # issue the collectives even for world_size 1 (plumbing tests)
         self.bucket_floats = int(bucket_mb * (1 << 20) / 4)
         self.world = dist.get_world_size(process_group)
         self._native_avg = dist.get_backend(process_group) == "nccl"
         self.launched = []       # (begin, end) of the buckets issued during the last finished backward (introspection/tests)
+        self.wait_events = None  # a list while bench.py collects (start, end) HIP events around finish()'s stream waits
 
     def begin(self, st, plan=None):
         return _SyncCall(self, st)
@@ -112,7 +126,7 @@ class DataParallel(nn.Module):
     >>> net = DataParallel(UNet(3, 12).cuda())
     Each rank feeds its own minibatch shard; after loss.backward() every rank holds the gradient mean."""
 
-    def __init__(self, module, process_group=None, bucket_mb=32.0, broadcast=True, always_issue=False):
+    def __init__(self, module, process_group=None, bucket_mb=None, broadcast=True, always_issue=False):
         super().__init__()
         from .modules import runner_of
         self.module = module
@@ -130,6 +144,7 @@ class DataParallel(nn.Module):
                         dist.broadcast(h, src=0, group=process_group)
                         v.copy_(h)
         runner_of(module).grad_sync = self.sync
+        runner_of(module).wepoch += 1            # the broadcast rewrote the parameters in place
 
     def forward(self, x):
         return self.module(x)

@@ -154,7 +154,7 @@ def wino4f_ok(k_ch, cout):
     return k_ch % 32 == 0 and cout % 4 == 0 and cout >= 32
 
 
-def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what="", dgrad_of=None, keep_v=None):
+def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what="", dgrad_of=None, keep_v=None, wsrc=None, ck=None):
     """y[N,H,W,ldy] = conv3x3(x[N,H,W,k_ch], w[cout][3][3][k_ch]) (+bias, +BN statistics partials at sp) through the
     Winograd kernels: weight transform -> (input transform ->) GEMMs M_xi -> output transform.  2-D F(4x4,3x3) for the
     channel-heavy layers (R.wino2d, wino2d_pays), else 1-D F(4,3) when R.wino4, else F(2,3).
@@ -162,13 +162,20 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
     dgrad_of = (forward weights [Cout_f][3][3][Cin_f], Cout_f, Cin_f) lets F(4,3) transform straight from them.
     Returns None, or (P, counts pointer) when the statistics partials at sp carry explicit pixel counts (2-D path:
     P = cvk_w2d_stat_partials partials of [sum | M2] followed by the counts -> cvk_bn_finalize_counts).  keep_v: a list that
-    receives the transformed input V when the 2-D path runs (the layer's weight-grad reuses it)."""
+    receives the transformed input V when the 2-D path runs (the layer's weight-grad reuses it).  wsrc / ck: the parameter the
+    filter derives from and the layer's cache key — the transformed filter is then kept across calls (Runner.derived)."""
     M = N * H * W
+
+    def cached(kind, build):
+        return R.derived((ck, kind), wsrc, build) if (ck is not None and wsrc is not None) else build()
     if wino2d_ok(k_ch, cout, ldy) and (R.wino2d == "always" or (R.wino2d and wino2d_pays(N, H, W, k_ch, cout))):
-        w = w() if callable(w) else w
-        U = _empty(36 * cout * k_ch, x.device)
-        _timed(R, "k_w2d_weight", 4.0 * (9 + 36) * cout * k_ch, lambda: check(
-            lib.cvk_w2d_weight_transform(w.data_ptr(), U.data_ptr(), cout, k_ch, s), "cvk_w2d_weight_transform"), "byte")
+        def build_u2():
+            wt = w() if callable(w) else w
+            u = _empty(36 * cout * k_ch, x.device)
+            _timed(R, "k_w2d_weight", 4.0 * (9 + 36) * cout * k_ch, lambda: check(
+                lib.cvk_w2d_weight_transform(wt.data_ptr(), u.data_ptr(), cout, k_ch, s), "cvk_w2d_weight_transform"), "byte")
+            return u
+        U = cached("w2d", build_u2)
         T = lib.cvk_w2d_tiles(N, H, W)
         vfl = 36 * lib.cvk_w2d_tpad(T) * k_ch + 128          # V planes + 512 bytes of slack
         if keep_v is not None:      # the weight-grad of this layer reuses V: its own tensor instead of the shared workspace
@@ -192,14 +199,17 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
     if use4 and R.wino4f and wino4f_ok(k_ch, cout) and (dgrad_of is None or (dgrad_of[1] == k_ch and dgrad_of[2] == cout)):
         # fused F(4,3) (csrc/wino4f.hip): all six transform indices in one workgroup, output transform + bias + statistics in
         # registers — no product planes, no output pass
-        Uf = _empty(lib.cvk_wino4f_weight_floats(cout, k_ch), x.device)
-        if dgrad_of is not None:
-            _timed(R, "k_wino4f_weight", 4.0 * (9 + 18) * cout * k_ch, lambda: check(
-                lib.cvk_wino4f_weight_transform(dgrad_of[0].data_ptr(), Uf.data_ptr(), cout, k_ch, 1, s), "cvk_wino4f_weight_transform(dgrad)"), "byte")
-        else:
-            w = w() if callable(w) else w
-            _timed(R, "k_wino4f_weight", 4.0 * (9 + 18) * cout * k_ch, lambda: check(
-                lib.cvk_wino4f_weight_transform(w.data_ptr(), Uf.data_ptr(), cout, k_ch, 0, s), "cvk_wino4f_weight_transform"), "byte")
+        def build_uf():
+            uf = _empty(lib.cvk_wino4f_weight_floats(cout, k_ch), x.device)
+            if dgrad_of is not None:
+                _timed(R, "k_wino4f_weight", 4.0 * (9 + 18) * cout * k_ch, lambda: check(
+                    lib.cvk_wino4f_weight_transform(dgrad_of[0].data_ptr(), uf.data_ptr(), cout, k_ch, 1, s), "cvk_wino4f_weight_transform(dgrad)"), "byte")
+            else:
+                wt = w() if callable(w) else w
+                _timed(R, "k_wino4f_weight", 4.0 * (9 + 18) * cout * k_ch, lambda: check(
+                    lib.cvk_wino4f_weight_transform(wt.data_ptr(), uf.data_ptr(), cout, k_ch, 0, s), "cvk_wino4f_weight_transform"), "byte")
+            return uf
+        Uf = cached("w4f", build_uf)
         Pf = lib.cvk_wino4f_stat_partials(N, H, W)
         cnt = sp + 4 * 2 * Pf * cout if sp is not None else None
         _timed(R, "k_conv3x3_wino4f", flops, lambda: check(
@@ -207,15 +217,18 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
             "cvk_conv3x3_wino4f" + what), executed=0.5 * flops)
         return (Pf, cnt) if sp is not None else None
     if use4:
-        U = _empty(6 * cout * 3 * k_ch, x.device)
-        if dgrad_of is not None and dgrad_of[1] == k_ch and dgrad_of[2] == cout:       # no channel padding on either side
-            _timed(R, "k_wino4_weight_dgrad", 4.0 * (9 + 18) * cout * k_ch, lambda: check(
-                lib.cvk_wino4_weight_transform_dgrad(dgrad_of[0].data_ptr(), U.data_ptr(), dgrad_of[1], dgrad_of[2], s),
-                "cvk_wino4_weight_transform_dgrad"), "byte")
-        else:
-            w = w() if callable(w) else w
-            _timed(R, "k_wino4_weight", 4.0 * (9 + 18) * cout * k_ch, lambda: check(
-                lib.cvk_wino4_weight_transform(w.data_ptr(), U.data_ptr(), cout, k_ch, s), "cvk_wino4_weight_transform"), "byte")
+        def build_u4():
+            u = _empty(6 * cout * 3 * k_ch, x.device)
+            if dgrad_of is not None and dgrad_of[1] == k_ch and dgrad_of[2] == cout:       # no channel padding on either side
+                _timed(R, "k_wino4_weight_dgrad", 4.0 * (9 + 18) * cout * k_ch, lambda: check(
+                    lib.cvk_wino4_weight_transform_dgrad(dgrad_of[0].data_ptr(), u.data_ptr(), dgrad_of[1], dgrad_of[2], s),
+                    "cvk_wino4_weight_transform_dgrad"), "byte")
+            else:
+                wt = w() if callable(w) else w
+                _timed(R, "k_wino4_weight", 4.0 * (9 + 18) * cout * k_ch, lambda: check(
+                    lib.cvk_wino4_weight_transform(wt.data_ptr(), u.data_ptr(), cout, k_ch, s), "cvk_wino4_weight_transform"), "byte")
+            return u
+        U = cached("w4", build_u4)
         ws = R.workspace(lib.cvk_conv3x3_wino4_workspace_bytes(N, H, W, k_ch, ldy), x.device)
         ksplit = lib.cvk_conv3x3_wino4_ksplit(N, H, W, k_ch, ldy)
         _timed(R, conv_kernel_name("wino4", ldy), flops, lambda: check(
@@ -223,10 +236,13 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
         _timed(R, "k_wino4_output", (4.0 + 6.0 * ksplit) * M * ldy, lambda: check(
             lib.cvk_wino4_output(ws.data_ptr(), bias, y.data_ptr(), sp, N, H, W, cout, ldy, ksplit, s), "cvk_wino4_output"), "byte")
     else:
-        w = w() if callable(w) else w
-        U = _empty(4 * cout * 3 * k_ch, x.device)
-        _timed(R, "k_wino_weight", 4.0 * (9 + 12) * cout * k_ch, lambda: check(
-            lib.cvk_wino_weight_transform(w.data_ptr(), U.data_ptr(), cout, k_ch, s), "cvk_wino_weight_transform"), "byte")
+        def build_u():
+            wt = w() if callable(w) else w
+            u = _empty(4 * cout * 3 * k_ch, x.device)
+            _timed(R, "k_wino_weight", 4.0 * (9 + 12) * cout * k_ch, lambda: check(
+                lib.cvk_wino_weight_transform(wt.data_ptr(), u.data_ptr(), cout, k_ch, s), "cvk_wino_weight_transform"), "byte")
+            return u
+        U = cached("w", build_u)
         ws = R.workspace(lib.cvk_conv3x3_wino_workspace_bytes(N, H, W, ldy), x.device)
         _timed(R, conv_kernel_name("wino", ldy), flops, lambda: check(
             lib.cvk_conv3x3_wino_gemm(x.data_ptr(), U.data_ptr(), ws.data_ptr(), N, H, W, k_ch, cout, ldy, s), "cvk_conv3x3_wino_gemm" + what))
@@ -251,6 +267,38 @@ def conv_kernel_name(kind, n_cols, k_ch=32):
         return f"k_conv3x3_wgrad<{t}>"
     t = "128, 128, 2, 2" if n_cols > 64 else ("128, 64, 2, 2" if n_cols > 32 else "256, 32, 4, 1")
     return f"k_conv3x3_igemm<{t}, {'true' if kind == 'fwd' else 'false'}, {'true' if k_ch % 32 == 0 else 'false'}>"
+
+
+# ---- derived-weight cache ---------------------------------------------------------------------------------------------
+# Winograd-domain filters, data-grad packs and bf16 copies are functions of the conv weights only; a step used to rebuild
+# all of them (~55 launches, 0.5 ms, also in eval mode).  They are now kept per layer and rebuilt when the weights may have
+# changed.  A raw-pointer optimizer or a `p.data` write does not touch the parameter's version counter, so validity is
+# explicit: an entry is valid while (global optimizer epoch, runner epoch, storage pointer, tensor version) are unchanged.
+#   * any torch.optim optimizer step      -> global epoch (torch.optim.optimizer.register_optimizer_step_post_hook)
+#   * FlatAdamW.step, load_state_dict, ddp.DataParallel's broadcast, mark_weights_dirty(net) -> runner epoch
+#   * .to() / .cuda() / in-place autograd-visible ops -> storage pointer / version counter
+# In-place writes nobody can see (`p.data.add_()`, a foreign kernel) need `mark_weights_dirty(net)`.
+# Never used while a stream capture is running: a replayed graph must recompute the derived tensors from the live weights.
+WEIGHT_EPOCH = [0]
+WCACHE_DEFAULT = os.environ.get("CVK_WEIGHT_CACHE", "1") != "0"
+
+
+def _bump_epoch(*_a, **_k):
+    WEIGHT_EPOCH[0] += 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_opt_hook
+    _reg_opt_hook(_bump_epoch)
+except ImportError:                      # very old torch: no global hook, the cache stays off
+    WCACHE_DEFAULT = False
+
+
+def mark_weights_dirty(module):
+    """Tell the executor that the parameters of `module` were changed behind its back (p.data writes, custom kernels):
+    every derived weight tensor (Winograd-domain filters, data-grad packs, bf16 copies) is rebuilt on next use."""
+    from .modules import runner_of
+    runner_of(module).wepoch += 1
 
 
 PROF = None     # bench.py sets this to a list: every _timed call then appends (kernel name, work, start event, end event, unit, executed)
@@ -297,9 +345,11 @@ class ConvBnRelu(Op):
         if ldx == self.cin and w.is_contiguous(memory_format=torch.channels_last):
             return w
         wc = w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last)
-        out = _empty(self.cout * 9 * ldx, w.device)
-        check(R.lib.cvk_pack_weight_fwd(wc.data_ptr(), out.data_ptr(), self.cout, self.cin, ldx, st.stream), "cvk_pack_weight_fwd")
-        return out
+        def build():
+            out = _empty(self.cout * 9 * ldx, w.device)
+            check(R.lib.cvk_pack_weight_fwd(wc.data_ptr(), out.data_ptr(), self.cout, self.cin, ldx, st.stream), "cvk_pack_weight_fwd")
+            return out
+        return R.derived(((self.pslot, "f"), "pack"), w, build)
 
     def _wgrad2d(self, R):
         """Does this layer's weight-grad run through the transposed 2-D F(4x4,3x3) (csrc/wino2d.hip)?  Channel-heavy layers:
@@ -320,7 +370,8 @@ class ConvBnRelu(Op):
         N, H, W, M, C, ldy = src.N, src.H, src.W, src.M, self.cout, pad4(self.cout)
         sp = stats.data_ptr() if stats is not None else None
         if wino_ok(R, src.ld, ldy):
-            return wino_conv(R, lib, s, X, wk, b.data_ptr(), y, sp, N, H, W, src.ld, C, ldy, 18.0 * M * C * self.cin, keep_v=keep_v)
+            return wino_conv(R, lib, s, X, wk, b.data_ptr(), y, sp, N, H, W, src.ld, C, ldy, 18.0 * M * C * self.cin, keep_v=keep_v,
+                             wsrc=st.params[4 * self.pslot], ck=(self.pslot, "f"))
         else:
             _timed(R, conv_kernel_name("fwd", ldy, src.ld), 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy, s),
@@ -428,9 +479,9 @@ class ConvBnRelu(Op):
             dX = _empty(M * src.ld, dev).view(N, H, W, src.ld)
             if wino_ok(R, ldy, src.ld):
                 wino_conv(R, lib, s, dy, packed, None, dX, None, N, H, W, ldy, src.ld, src.ld, 18.0 * M * C * self.cin, "(dgrad)",
-                          dgrad_of=(wc, C, self.cin))
+                          dgrad_of=(wc, C, self.cin), wsrc=w, ck=(self.pslot, "d"))
             else:
-                wd = packed()
+                wd = R.derived(((self.pslot, "d"), "pack"), w, packed)
                 _timed(R, conv_kernel_name("dgrad", src.ld, ldy), 18.0 * M * C * self.cin, lambda: check(
                     lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
                     "cvk_conv3x3_fwd(dgrad)"))
@@ -489,8 +540,11 @@ class ConvBnRelu(Op):
         if C % 4:
             raise NotImplementedError("bf16 mode needs output channel counts that are multiples of 4")
         wc = w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last)
-        wb = torch.empty(lib.cvk_bf16s_rows_pad(C) * 9 * src.ld, device=dev, dtype=_BF16)
-        check(lib.cvk_pack_weight_fwd_bf16(wc.data_ptr(), wb.data_ptr(), C, self.cin, src.ld, s), "cvk_pack_weight_fwd_bf16")
+        def build_wb():
+            t = torch.empty(lib.cvk_bf16s_rows_pad(C) * 9 * src.ld, device=dev, dtype=_BF16)
+            check(lib.cvk_pack_weight_fwd_bf16(wc.data_ptr(), t.data_ptr(), C, self.cin, src.ld, s), "cvk_pack_weight_fwd_bf16")
+            return t
+        wb = R.derived(((self.pslot, "f"), "bf16"), w, build_wb)
         y = torch.empty(M * C, device=dev, dtype=_BF16)
         bnp = _empty(4 * C, dev)
         pm, pr, psc, psh = (bnp.data_ptr() + 4 * C * i for i in range(4))
@@ -564,8 +618,11 @@ class ConvBnRelu(Op):
         if self.src_needs_grad:
             if src.id in st.grad:
                 raise NotImplementedError("conv data-grad must be the first writer of its input's gradient buffer")
-            wd = torch.empty(lib.cvk_bf16s_rows_pad(self.cin) * 9 * ld_dy, device=dev, dtype=_BF16)
-            check(lib.cvk_pack_weight_dgrad_bf16(wc.data_ptr(), wd.data_ptr(), C, self.cin, ld_dy, s), "cvk_pack_weight_dgrad_bf16")
+            def build_wd():
+                t = torch.empty(lib.cvk_bf16s_rows_pad(self.cin) * 9 * ld_dy, device=dev, dtype=_BF16)
+                check(lib.cvk_pack_weight_dgrad_bf16(wc.data_ptr(), t.data_ptr(), C, self.cin, ld_dy, s), "cvk_pack_weight_dgrad_bf16")
+                return t
+            wd = R.derived(((self.pslot, "d"), "bf16"), w, build_wd)
             dX = torch.empty((N, H, W, src.ld), device=dev, dtype=_BF16)
             _timed(R, conv_kernel_name("bf16_dgrad", self.cin), flops, lambda: check(
                 lib.cvk_conv3x3_bf16s(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, None, N, H, W, ld_dy, self.cin, src.ld, s),
@@ -642,16 +699,18 @@ class Unpool(Op):
         code = st.saved[self.pool.idx]
         d = self.dst
         out = R.alloc_act(st, d, V.device)
-        check(R.lib.cvk_maxunpool2x2_fwd(V.data_ptr(), code.data_ptr(), out.data_ptr(), d.N, d.H, d.W, d.ld, st.stream),
-              "cvk_maxunpool2x2_fwd")
+        _timed(R, "k_unpool_fwd", 5.25 * d.M * d.ld, lambda: check(        # reads pooled values + 1-byte codes, writes the full frame
+            R.lib.cvk_maxunpool2x2_fwd(V.data_ptr(), code.data_ptr(), out.data_ptr(), d.N, d.H, d.W, d.ld, st.stream),
+            "cvk_maxunpool2x2_fwd"), "byte")
 
     def bwd(self, R, st):
         d = self.dst
         g = st.grad.pop(d.id)
         code = st.saved[self.pool.idx]
         dv = torch.empty_like(st.act[self.src.id])
-        check(R.lib.cvk_maxunpool2x2_bwd(g.data_ptr(), code.data_ptr(), dv.data_ptr(), d.N, d.H, d.W, d.ld, st.stream),
-              "cvk_maxunpool2x2_bwd")
+        _timed(R, "k_unpool_bwd", 5.25 * d.M * d.ld, lambda: check(
+            R.lib.cvk_maxunpool2x2_bwd(g.data_ptr(), code.data_ptr(), dv.data_ptr(), d.N, d.H, d.W, d.ld, st.stream),
+            "cvk_maxunpool2x2_bwd"), "byte")
         assert self.src.id not in st.grad
         st.grad[self.src.id] = dv
 
@@ -788,6 +847,24 @@ class Runner:
         self.wino4f = WINO4F_DEFAULT
         self.wino2d = WINO2D_DEFAULT
         self.bf16 = False           # opt-in: bf16-storage mode (modules.set_conv_precision; BASELINE.json configs[3])
+        self.wcache = WCACHE_DEFAULT
+        self.wepoch = 0             # bumped by mark_weights_dirty / FlatAdamW.step / load_state_dict
+        self._wc = {}               # (layer slot, kind) -> (signature, tensor)
+        self.wcache_builds = 0      # derived tensors built since creation (tests / diagnostics)
+
+    def derived(self, key, src, build):
+        """The derived weight tensor `key` of parameter `src`: cached while the weights are provably unchanged."""
+        if not self.wcache or key is None or torch.cuda.is_current_stream_capturing():
+            self.wcache_builds += 1
+            return build()
+        sig = (WEIGHT_EPOCH[0], self.wepoch, src.data_ptr(), src._version)
+        ent = self._wc.get(key)
+        if ent is not None and ent[0] == sig:
+            return ent[1]
+        t = build()
+        self.wcache_builds += 1
+        self._wc[key] = (sig, t)
+        return t
 
     def workspace(self, nbytes, dev):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:

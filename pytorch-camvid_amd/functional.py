@@ -56,7 +56,7 @@ class _CrossEntropy(torch.autograd.Function):
         ctx.save_for_backward(lg, tg, loss3)
         ctx.meta = (N, C, H, W, ld, grad_scale, int(ignore_index))
         _CrossEntropy.last_status = loss3
-        return loss3[0]
+        return loss3[0].clone()     # not a view: loss3 is saved for backward (its divisor) and published as the status
 
     @staticmethod
     def backward(ctx, gout):

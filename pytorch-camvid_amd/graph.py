@@ -1,0 +1,65 @@
+"""The training step as ONE captured HIP graph.
+
+A step of the path is ~500 kernel launches enqueued from Python through ctypes (11-15 ms of host time per step: hidden while
+the GPU needs 38 ms for the fp32 headline, the next wall for the bf16 configuration and a jitter source for 8 single-threaded
+ranks).  The executor's plan is static per input geometry, every launch goes to the current HIP stream and nothing in the step
+synchronises with the host, so `zero_grad -> net(x) -> loss -> backward` (reference train.py:124-131) can be captured once
+with torch.cuda.CUDAGraph and replayed with a single launch: activations, saved tensors, the flat gradient buffer and the
+workspace come from the graph's private pool, i.e. their addresses are the same in every replay.
+
+    step = GraphedStep(net, lossf, x, t)       # x, t: example batch of the geometry (copied into static buffers)
+    for xb, tb in loader:
+        loss = step.replay(xb, tb)             # p.grad of every parameter now holds this batch's gradients
+        optimizer.step()
+
+BatchNorm running statistics and num_batches_tracked are updated by the kernels on the device, exactly as in eager mode.
+Single process only: under ddp.DataParallel the bucketed all-reduces stay outside a graph (eager mode).
+"""
+import torch
+
+
+class GraphedStep:
+    def __init__(self, net, lossf, x, t, warmup=2):
+        from .modules import runner_of
+        R = runner_of(net)
+        if R.grad_sync is not None:
+            raise RuntimeError("GraphedStep: data-parallel gradient synchronisation runs in eager mode only")
+        if not (x.is_cuda and t.is_cuda):
+            raise RuntimeError("GraphedStep needs the example batch on the GPU")
+        self.net, self.lossf = net, lossf
+        self.x, self.t = x.clone(), t.clone()
+        self.params = [p for p in net.parameters() if p.requires_grad]
+        cur = torch.cuda.current_stream(x.device)
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):               # warm-up off the capture: plans, workspace, allocator pools
+            for _ in range(max(1, warmup)):
+                self._zero()
+                lossf(net(self.x), self.t).backward()
+        cur.wait_stream(side)
+        torch.cuda.synchronize(x.device)
+        self._zero()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = lossf(net(self.x), self.t)
+            self.loss.backward()
+        # every tensor a replay writes must stay alive as long as the graph: the gradients (views of the flat buffer the
+        # capture allocated) and the runner's workspace (a later, larger eager call would otherwise release it)
+        self.grads = [p.grad for p in self.params]
+        self._keep = R._ws
+
+    def _zero(self):
+        for p in self.params:
+            p.grad = None
+
+    def replay(self, x=None, t=None):
+        """Copy a new batch into the static input buffers (optional) and replay the step.  Returns the (static) loss tensor."""
+        if x is not None:
+            self.x.copy_(x, non_blocking=True)
+        if t is not None:
+            self.t.copy_(t, non_blocking=True)
+        for p, g in zip(self.params, self.grads):   # zero_grad(set_to_none=True) between steps keeps working
+            if p.grad is not g:
+                p.grad = g
+        self.graph.replay()
+        return self.loss

@@ -214,6 +214,11 @@ def _state_of(module):
     st = _STATE.get(module)
     if st is None:
         st = _STATE[module] = {"runner": engine.Runner(), "plans": {}}
+        runner = st["runner"]
+
+        def _loaded(_module, _incompatible):          # load_state_dict copies into the parameters: derived weights are stale
+            runner.wepoch += 1
+        module.register_load_state_dict_post_hook(_loaded)
     return st
 
 

@@ -104,4 +104,5 @@ class FlatAdamW(torch.optim.Optimizer):
         check(lib.cvk_adamw_step(self._flat.data_ptr(), grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), self._flat.numel(),
                                  float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
                                  self._step, torch.cuda.current_stream(self._flat.device).cuda_stream), "cvk_adamw_step")
+        engine._bump_epoch()          # the kernel wrote the parameters through raw pointers: derived weight tensors are stale
         return loss

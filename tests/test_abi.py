@@ -33,6 +33,24 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert sorted(_lib.SIGNATURES) == header_symbols(), "Python binding table out of sync with include/cvk.h"
 
 
+def test_integration_doc_matches_the_header():
+    """INTEGRATION.md is the binding guide a maintainer reads: every cvk_* name it mentions must exist in include/cvk.h, every
+    entry point of the header must be mentioned, and the stated counts (entry points, .hip files) must be the real ones."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    syms = set(header_symbols())
+    mentioned = set(re.findall(r"\b(cvk_[a-z0-9_]+)\b", doc)) - {"cvk_view"}          # cvk_view is the struct type
+    assert not (mentioned - syms), f"INTEGRATION.md names entry points that do not exist: {sorted(mentioned - syms)}"
+    assert not (syms - mentioned), f"entry points missing from INTEGRATION.md: {sorted(syms - mentioned)}"
+    m = re.search(r"declares (\d+) `extern \"C\"` entry points", doc)
+    assert m and int(m.group(1)) == len(syms), (m and m.group(1), len(syms))
+    words = {8: "eight", 9: "nine", 10: "ten", 11: "eleven", 12: "twelve", 13: "thirteen"}
+    nhip = len([f for f in os.listdir(os.path.join(ROOT, "pytorch-camvid_amd", "csrc")) if f.endswith(".hip")])
+    assert f"{words[nhip]} `.hip` files" in doc, nhip
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    m = re.search(r"`include/cvk.h` \((\d+) entry points\)", design)
+    assert m and int(m.group(1)) == len(syms), (m and m.group(1), len(syms))
+
+
 def test_argument_validation_without_gpu():
     """Argument errors are detected before any launch, return CVK_EINVAL and set the error string."""
     from pytorch_camvid_amd import _lib

@@ -147,6 +147,29 @@ def test_pool_unpool_bilinear_ce_raw_abi():
         close(nchw(dx), u["dx_up_only"], 1e-5, 1e-5)
 
 
+@pytest.mark.parametrize("C", [40, 63, 64, 130])
+def test_ce_any_class_count_and_loss_is_not_a_view(C):
+    """nn.CrossEntropyLoss (reference train.py:105) puts no bound on class_num: up to 63 classes go through the LDS-staged
+    kernels, wider rows through the row-walking ones (64..128 was an untested >64 KiB dynamic-LDS launch, > 128 an
+    error).  The returned loss must not alias the tensor saved for backward: an in-place op on it left the divisor corrupt."""
+    import pytorch_camvid_amd as A
+    g = torch.Generator().manual_seed(C)
+    lg = torch.randn(2, C, 9, 11, generator=g) * 3
+    tg = torch.randint(0, C, (2, 9, 11), generator=g)
+    tg[0, 0, :3] = -100
+    lref = lg.clone().double().requires_grad_(True)
+    want = torch.nn.functional.cross_entropy(lref, tg)
+    want.backward()
+    l = lg.to(dev()).requires_grad_(True)
+    loss = A.CrossEntropyLoss()(l, tg.to(dev()))
+    assert abs(loss.item() - want.item()) < 2e-6 * max(1.0, abs(want.item()))
+    loss2 = loss * 1.0
+    with torch.no_grad():
+        loss.mul_(0.0)                      # must not touch what backward needs
+    loss2.backward()
+    assert torch.allclose(l.grad.cpu().double(), lref.grad, rtol=1e-4, atol=1e-8)
+
+
 def test_ce_module_and_eval_ops():
     import pytorch_camvid_amd as A
     from oracle import np_ops as O

@@ -83,14 +83,23 @@ def test_bench_rehearsal_self_launch(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, CVK_REHEARSAL="1")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    # --with-input-pipeline / --with-optimizer: the extra loops run on EVERY rank (their backward passes issue all-reduces that
+    # all ranks must post: with rank 0 alone the N > 1 bench hung — ADVICE r2)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
-                        "--height", "96", "--width", "128", "--no-cpu-baseline", "--no-kernel-profile"],
+                        "--height", "96", "--width", "128", "--no-cpu-baseline", "--no-kernel-profile", "--with-input-pipeline", "--with-optimizer"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["value"] > 0 and "REHEARSAL" in rec["data"]
+    # the N > 1 record says what took part and how much of the exchange was exposed
+    dp = rec["dp"]
+    assert len(dp["ranks_seen"]) == 2 and {r["rank"] for r in dp["ranks_seen"]} == {0, 1} and dp["rehearsal"] is True
+    assert dp["distinct_gpus"] == 1                                     # rehearsal: both ranks on this box's one GPU, and the line says so
+    assert len(dp["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in dp["per_rank_ms_per_step"])
+    assert dp["allreduce_exposed_ms"] >= 0 and len(dp["buckets"]) >= 1 and sum(b["floats"] for b in dp["buckets"]) >= 34533924
+    assert rec["ms_per_step"] >= max(dp["per_rank_ms_per_step"]) - 1e-6  # MAX over ranks
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     with open(os.path.join(root, "gpurun_out", "rehearsal_n2.json"), "w") as f:
         f.write(lines[0] + "\n")

@@ -340,15 +340,19 @@ def test_segnet_fullsize_batch8_golden():
     assert dev_.max() <= max(3e-4, 2.0 * own.max()) and np.median(dev_) <= max(3e-4, 4.0 * np.median(own))
     names = list(d["param_names"])
     assert [k for k, _ in net.named_parameters()] == names
-    worst = 0.0
+    rel, own = [], []
     for i, (k, p) in enumerate(net.named_parameters()):
         if k.endswith(".conv.bias"):      # conv bias under train-mode BN: mathematically zero, numerically noise
             continue
-        g = float(p.grad.double().norm())
-        own_rel = abs(float(q["grad_l2"][i]) - float(d["grad_l2"][i])) / float(d["grad_l2"][i])
-        rel = abs(g - float(d["grad_l2"][i])) / float(d["grad_l2"][i])
-        assert rel < max(0.03, 4.0 * own_rel), (k, rel, own_rel)
-        worst = max(worst, rel)
+        ref = float(d["grad_l2"][i])
+        rel.append(abs(float(p.grad.double().norm()) - ref) / ref)
+        own.append(abs(float(q["grad_l2"][i]) - ref) / ref)
+    rel, own = np.array(rel), np.array(own)
+    # Which tensor an arg-max flip hits is chance (the reference's perturbed twin: median 0.19 %, 90th percentile 1.0 %, worst
+    # tensor 4.3 %), so the comparison is between the two DISTRIBUTIONS of per-tensor gradient-norm deviations, not tensor by tensor
+    assert np.median(rel) <= max(1e-3, 4.0 * np.median(own)), (np.median(rel), np.median(own))
+    assert np.percentile(rel, 90) <= max(1e-2, 4.0 * np.percentile(own, 90)), (np.percentile(rel, 90), np.percentile(own, 90))
+    assert rel.max() <= max(0.03, 2.0 * own.max()), (rel.max(), own.max())
     bm = np.array([float(v.double().norm()) for k, v in net.state_dict().items() if k.endswith("running_mean")])
     bv = np.array([float(v.double().norm()) for k, v in net.state_dict().items() if k.endswith("running_var")])
     np.testing.assert_allclose(bm, d["bn_mean_l2"], rtol=max(1e-4, 4.0 * float(np.max(np.abs(q["bn_mean_l2"] - d["bn_mean_l2"]) / d["bn_mean_l2"]))))

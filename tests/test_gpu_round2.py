@@ -182,3 +182,13 @@ def test_bench_json_contract_single_gpu():
     hk = d["hbm_kernels"]
     for name in ("k_bn_relu_apply", "k_w2d_input", "k_w2d_output", "k_w2d_weight", "k_ce_fwd", "k_ce_bwd", "k_bilinear_fwd"):
         assert name in hk and 0 < hk[name]["frac_of_8TBps"] <= 1.0, name
+    assert "k_conv3x3_wino4f" in d["conv_kernels"]          # the fused F(4,3) kernel carries the 64/128-channel levels
+    assert "configs[1]" in d["config"]["workload"]
+    # the other single-GPU configurations of BASELINE.json ride on the same line
+    ex = d["extra_configs"]
+    assert len(ex) == 2 and "configs[3]" in ex[0]["workload"] and "configs[4]" in ex[1]["workload"]
+    assert ex[0]["dtype"] == "bf16" and ex[0]["peak_tflops"] == 2500.0 and ex[1]["dtype"] == "f32" and ex[1]["peak_tflops"] == 157.3
+    for e in ex:
+        for k in ("workload", "dtype", "images_per_s", "ms_per_step", "dominant_kernel", "executed_frac_of_peak", "loss"):
+            assert k in e, k
+        assert e["images_per_s"] > 0 and 0 < e["executed_frac_of_peak"] <= 1.0 and 2.0 < e["loss"] < 3.0
