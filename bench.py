@@ -389,7 +389,9 @@ def main():
                           "images_per_s": round(e["value"], 3), "ms_per_step": round(e["ms"], 3), "steps": es, "warmup": ew,
                           "loss": round(e["loss"], 6), "dominant_kernel": r["kernel"], "executed_frac_of_peak": r["frac"],
                           "peak_tflops": r["peak"], "dominant_kernel_ms_per_step": round(r["avg_launch_us"] * r["launches_per_step"] / 1e3, 3),
-                          "all_conv_kernels": r["all_conv_kernels"], "hbm_bound_kernels_ms_per_step": r["hbm_bound_kernels_ms_per_step"]})
+                          "all_conv_kernels": r["all_conv_kernels"], "hbm_bound_kernels_ms_per_step": r["hbm_bound_kernels_ms_per_step"],
+                          "top_kernels_ms_per_step": dict(sorted([(k, v["ms_per_step"]) for k, v in list(e["kernels"].items()) + list(e["hbm_kernels"].items())],
+                                                                 key=lambda kv: -kv[1])[:8])})
 
     if rank == 0:
         line = {
