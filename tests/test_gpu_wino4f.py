@@ -100,3 +100,4 @@ def test_fused_is_deterministic_and_tile_walk_independent():
     for n in range(4):
         yn, _, _ = _fused_conv(x[n:n + 1].contiguous(), w, b)
         assert torch.equal(yn[0], y1[n])
+
