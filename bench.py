@@ -265,11 +265,13 @@ def dp_identity(dev, world, rehearsal):
     return {"ranks_seen": ranks, "distinct_gpus": len(ids), "rehearsal": rehearsal,
             "backend": dist.get_backend(),
             "rccl_env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_NCHANNELS_PER_PEER", "RCCL_MSCCL_ENABLE",
-                                                        "NCCL_ALGO", "NCCL_PROTO", "HSA_ENABLE_IPC_MODE_LEGACY", "CVK_DDP_BUCKET_MB", "CVK_W2D_NO_STAGGER")
+                                                        "NCCL_ALGO", "NCCL_PROTO", "HSA_ENABLE_IPC_MODE_LEGACY", "CVK_DDP_BUCKET_MB", "CVK_DP_RESERVE_CUS", "CVK_W2D_NO_STAGGER")
                          if os.environ.get(k) is not None},
             "note": "the conv grids assume an undisturbed chip (whole rounds of 256 CUs, csrc/wino2d.hip staggered start): RCCL's "
                     "all-reduce kernels occupy NCCL_MAX_NCHANNELS workgroups while backward runs; lower it (e.g. 8-16) if "
-                    "allreduce_exposed_ms is small but ms_per_step grows with N, and set CVK_W2D_NO_STAGGER=1 to A/B the stagger."}
+                    "allreduce_exposed_ms is small but ms_per_step grows with N, and set CVK_W2D_NO_STAGGER=1 to A/B the stagger.  The persistent "
+                    "fused F(4,3) kernel (one workgroup per CU) runs on CUs - CVK_DP_RESERVE_CUS (default 16) workgroups under data parallel, "
+                    "NCCL_MAX_NCHANNELS defaults to 16 here to match."}
 
 
 def main():
@@ -293,6 +295,9 @@ def main():
     import pytorch_camvid_amd as A
 
     if world > 1:
+        # RCCL's all-reduce kernels run beside backward and hold one CU per channel; the exchange needs ~7 GB/s (138 MB per
+        # 38 ms step), so a few channels suffice — the executor leaves CVK_DP_RESERVE_CUS (default 16) CUs free for them
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
         if rehearsal:
             dist.init_process_group("gloo")
         else:

@@ -153,12 +153,13 @@ int cvk_w2d_wgrad_output(const float* P, float* dw, int T, int Cin, int Cin_pad,
  * K-sliced LDS image of (G g); dgrad != 0 builds the data-grad filter (180-degree rotation, channels exchanged) straight
  * from the forward weights w [Ck][3][3][Cn].  Cin % 32 == 0.  stats/counts (both or neither): P =
  * cvk_wino4f_stat_partials(N,H,W) partials [sum | M2 about the partial mean] [2][P][Cout] + the P pixel counts, to be
- * reduced by cvk_bn_finalize_counts. */
+ * reduced by cvk_bn_finalize_counts.  The kernel is persistent (one workgroup per CU walks a list of tiles);
+ * max_workgroups > 0 caps its grid (data-parallel runs leave CUs to RCCL's kernels), 0 = one per CU. */
 size_t cvk_wino4f_weight_floats(int Cn, int Ck);
 int cvk_wino4f_weight_transform(const float* w, float* Uf, int Cn, int Ck, int dgrad, void* stream);
 int cvk_wino4f_stat_partials(int N, int H, int W);
 int cvk_conv3x3_wino4f(const float* x, const float* Uf, const float* bias, float* y, float* stats, float* counts, int N, int H,
-                       int W, int Cin, int Cout, int ldy, void* stream);
+                       int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream);
 
 /* weight-grad through the transposed F(4,3) (contract of cvk_conv3x3_wgrad; the workspace also holds the transformed
  * output-gradient planes E1..E4, float[4][N*H*ceil(W/4)][ld_dy], hence the extra ld_dy argument of the size query) */

@@ -54,7 +54,7 @@ SIGNATURES = {
     "cvk_wino4f_weight_floats": (c_size, [c_int, c_int]),
     "cvk_wino4f_weight_transform": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "cvk_wino4f_stat_partials": (c_int, [c_int, c_int, c_int]),
-    "cvk_conv3x3_wino4f": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_conv3x3_wino4f": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_w2d_tiles": (c_int, [c_int, c_int, c_int]),
     "cvk_w2d_stat_partials": (c_int, [c_int, c_int, c_int]),
     "cvk_conv3x3_w2d_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),

@@ -454,7 +454,7 @@ extern "C" int cvk_wino4f_stat_partials(int N, int H, int W) {
 }
 
 extern "C" int cvk_conv3x3_wino4f(const float* x, const float* Uf, const float* bias, float* y, float* stats, float* counts, int N,
-                                  int H, int W, int Cin, int Cout, int ldy, void* stream) {
+                                  int H, int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream) {
     CVK_CHECK_ARG(x && Uf && y, "cvk_conv3x3_wino4f: null pointer");
     CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout, "cvk_conv3x3_wino4f: bad shape");
     CVK_CHECK_ARG(Cin >= 32 && Cin % 32 == 0, "cvk_conv3x3_wino4f: Cin=%d must be a multiple of 32", Cin);
@@ -471,7 +471,11 @@ extern "C" int cvk_conv3x3_wino4f(const float* x, const float* Uf, const float* 
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
         else cus = 256;
     }
-    const int grid = ntiles < cus ? ntiles : cus;
+    // max_workgroups > 0 caps the persistent grid below one workgroup per CU: under data-parallel training RCCL's all-reduce
+    // kernels hold some CUs while backward runs, and a workgroup of this kernel needs a whole CU (144 KiB of LDS, all of its
+    // registers) — with a static tile assignment the workgroups that find no free CU would start only when others finish
+    const int wgs = (max_workgroups > 0 && max_workgroups < cus) ? max_workgroups : cus;
+    const int grid = ntiles < wgs ? ntiles : wgs;
     CVK_CHECK_ARG((F_BM * 4 + 3L * W + 8) * Cin * 4 < (1L << 31), "cvk_conv3x3_wino4f: a tile's input window exceeds the 2 GiB buffer-addressing limit");
     hipStream_t s = (hipStream_t)stream;
     if (stats)

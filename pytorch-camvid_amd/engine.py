@@ -213,7 +213,7 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
         Pf = lib.cvk_wino4f_stat_partials(N, H, W)
         cnt = sp + 4 * 2 * Pf * cout if sp is not None else None
         _timed(R, "k_conv3x3_wino4f", flops, lambda: check(
-            lib.cvk_conv3x3_wino4f(x.data_ptr(), Uf.data_ptr(), bias, y.data_ptr(), sp, cnt, N, H, W, k_ch, cout, ldy, s),
+            lib.cvk_conv3x3_wino4f(x.data_ptr(), Uf.data_ptr(), bias, y.data_ptr(), sp, cnt, N, H, W, k_ch, cout, ldy, R.persistent_wgs(), s),
             "cvk_conv3x3_wino4f" + what), executed=0.5 * flops)
         return (Pf, cnt) if sp is not None else None
     if use4:
@@ -841,6 +841,7 @@ class Runner:
     def __init__(self):
         self.lib = _lib.load()
         self._ws = None
+        self._dp_wgs = None
         self.grad_sync = None       # set by ddp.DataParallel
         self.wino = WINO_DEFAULT
         self.wino4 = WINO4_DEFAULT
@@ -851,6 +852,16 @@ class Runner:
         self.wepoch = 0             # bumped by mark_weights_dirty / FlatAdamW.step / load_state_dict
         self._wc = {}               # (layer slot, kind) -> (signature, tensor)
         self.wcache_builds = 0      # derived tensors built since creation (tests / diagnostics)
+
+    def persistent_wgs(self):
+        """Workgroup cap of the persistent (one-workgroup-per-CU) kernels: 0 = every CU.  Under data-parallel training
+        CVK_DP_RESERVE_CUS (default 16) CUs are left to RCCL's all-reduce kernels, which run beside backward."""
+        if self.grad_sync is None or getattr(self.grad_sync, "world", 1) <= 1:
+            return 0
+        if self._dp_wgs is None:
+            cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+            self._dp_wgs = max(8, cus - int(os.environ.get("CVK_DP_RESERVE_CUS", "16")))
+        return self._dp_wgs
 
     def derived(self, key, src, build):
         """The derived weight tensor `key` of parameter `src`: cached while the weights are provably unchanged."""

@@ -56,7 +56,7 @@ def main():
         stats = torch.empty(2 * P * co, device=dev)
         row = f"{name:10s} {ci:5d}->{co:5d} {H:3d}x{W:3d} "
         if "fwd" in which:
-            t = timeit(lambda: check(lib.cvk_conv3x3_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, ci, co, ldy, s)))
+            t = timeit(lambda: check(lib.cvk_conv3x3_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, ci, co, ldy, 0, s)))
             row += f" fwd {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF"; tot["fwd"][0] += flops; tot["fwd"][1] += t
         if "wino" in which and ci % 64 == 0:
             U = torch.empty(4 * co * 3 * ci, device=dev)
@@ -69,7 +69,7 @@ def main():
             U4 = torch.empty(6 * co * 3 * ci, device=dev)
             check(lib.cvk_wino4_weight_transform(w.data_ptr(), U4.data_ptr(), co, ci, s))
             wsb = lib.cvk_conv3x3_wino4_workspace_bytes(N, H, W, ci, ldy); ws4 = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            tg = timeit(lambda: check(lib.cvk_conv3x3_wino4_gemm(x.data_ptr(), U4.data_ptr(), ws4.data_ptr(), N, H, W, ci, co, ldy, s)))
+            tg = timeit(lambda: check(lib.cvk_conv3x3_wino4_gemm(x.data_ptr(), U4.data_ptr(), ws4.data_ptr(), N, H, W, ci, co, ldy, 0, s)))
             to = timeit(lambda: check(lib.cvk_wino4_output(ws4.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, W, co, ldy, lib.cvk_conv3x3_wino4_ksplit(N, H, W, ci, ldy), s)))
             t = tg + to
             err = (y - yref).abs().max().item() / yref.abs().max().item() if "wino" in which else float("nan")
@@ -82,7 +82,7 @@ def main():
             Pf = lib.cvk_wino4f_stat_partials(N, H, W); stf = torch.zeros(2 * Pf * co + Pf, device=dev)
             y.zero_()
             t = timeit(lambda: check(lib.cvk_conv3x3_wino4f(x.data_ptr(), Uf.data_ptr(), b.data_ptr(), y.data_ptr(), stf.data_ptr(), stf.data_ptr() + 8 * Pf * co,
-                                                            N, H, W, ci, co, ldy, s)))
+                                                            N, H, W, ci, co, ldy, 0, s)))
             err = (y - yref).abs().max().item() / max(yref.abs().max().item(), 1e-30) if "wino4" in which else float("nan")
             row += f" wino4f {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF err {err:.1e}"; tot["wino4f"][0] += flops; tot["wino4f"][1] += t
         if "w2d" in which and ci % 32 == 0 and co >= 64 and co % 4 == 0:

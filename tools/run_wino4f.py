@@ -16,6 +16,6 @@ Uf = torch.empty(lib.cvk_wino4f_weight_floats(co, ci), device="cuda")
 check(lib.cvk_wino4f_weight_transform(w.data_ptr(), Uf.data_ptr(), co, ci, 0, s))
 P = lib.cvk_wino4f_stat_partials(N, H, W); st = torch.zeros(2 * P * co + P, device="cuda")
 for _ in range(reps):
-    check(lib.cvk_conv3x3_wino4f(x.data_ptr(), Uf.data_ptr(), b.data_ptr(), y.data_ptr(), st.data_ptr(), st.data_ptr() + 8 * P * co, N, H, W, ci, co, co, s))
+    check(lib.cvk_conv3x3_wino4f(x.data_ptr(), Uf.data_ptr(), b.data_ptr(), y.data_ptr(), st.data_ptr(), st.data_ptr() + 8 * P * co, N, H, W, ci, co, co, 0, s))
 torch.cuda.synchronize()
 print("done", float(y[0, 0]))
