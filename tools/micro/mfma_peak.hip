@@ -3,6 +3,7 @@
 // piece by piece?   hipcc --offload-arch=gfx950 -O3 -o mfma_peak tools/micro/mfma_peak.hip && ./mfma_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <stdint.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -11,7 +12,8 @@ constexpr int LDT = 36;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s\n", hipGetErrorString(e_)); return; } } while (0)
 
 // MODE bits: 1 = operands re-read from LDS (ds_read_b128 per 16 MFMAs), 2 = barrier per step, 4 = NV VALU fma per step,
-//            8 = NL 16-byte buffer loads per step (L2-resident), 16 = 8 ds_write_b128 per step
+//            8 = NL 16-byte buffer loads per step (L2-resident), 16 = 8 ds_write_b128 per step,
+//            256 = NL LDS-DMA pieces (global_load_lds_dwordx4, 1 KiB each) per step, all at the top (512: one per 8 MFMAs)
 template <int MODE, int NV, int NL>
 __global__ __launch_bounds__(256, 2) void k(float* out, const float* src, int iters) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 256 * LDT];
@@ -32,9 +34,26 @@ __global__ __launch_bounds__(256, 2) void k(float* out, const float* src, int it
     for (int q = 0; q < 8; ++q) pv[q] = f32x2{(float)q, (float)q + 0.5f};
     const f32x2 pc = {1.0001f, 0.9999f}, pd = {0.5f, 0.25f};
     unsigned off = (unsigned)(blockIdx.x * 256 + tid) * 16u;
+    const unsigned lds_dma_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(smem + 256 * LDT) + wave * 2048);
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
+            if ((MODE & 256) && kk == 0) {
+#pragma unroll
+                for (int q = 0; q < NL; ++q) {
+                    const char* g = (const char*)src + ((off + q * 65536u) & 0xFFFFF0u);
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_dma_base + (q & 1) * 1024) : "memory");
+                }
+                off += 4096u;
+            }
+            if ((MODE & 512)) {
+#pragma unroll
+                for (int q = kk * (NL / 4); q < (kk + 1) * (NL / 4); ++q) {
+                    const char* g = (const char*)src + ((off + q * 65536u) & 0xFFFFF0u);
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_dma_base + (q & 1) * 1024) : "memory");
+                }
+                if (kk == 3) off += 4096u;
+            }
             if (MODE & 1) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) { a[t] = *(const f32x4*)(ar + t * 32 * LDT + kk * 8); b[t] = *(const f32x4*)(br + t * 32 * LDT + kk * 8); }
@@ -81,6 +100,7 @@ __global__ __launch_bounds__(256, 2) void k(float* out, const float* src, int it
                 }
             }
         }
+        if (MODE & (256 | 512)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (MODE & 2) __syncthreads();
     }
     float s = 0.f;
@@ -122,5 +142,9 @@ int main() {
     run<27, 0, 20>("+ 20 loads + 8 ds_write_b128 per step", out, src);
     run<31, 128, 20>("+ 20 loads + 8 ds_write + 128 VALU per step", out, src);
     run<31, 256, 20>("+ 20 loads + 8 ds_write + 256 VALU per step", out, src);
+    run<27, 0, 8>("+ 8 loads + 8 ds_write_b128 per step", out, src);
+    run<3 + 256, 0, 8>("+ 8 LDS-DMA pieces per step (all at the top)", out, src);
+    run<3 + 512, 0, 8>("+ 8 LDS-DMA pieces per step (2 per 16 MFMAs)", out, src);
+    run<3 + 256, 0, 4>("+ 4 LDS-DMA pieces per step (all at the top)", out, src);
     return 0;
 }
