@@ -161,6 +161,27 @@ int cvk_wino4f_stat_partials(int N, int H, int W);
 int cvk_conv3x3_wino4f(const float* x, const float* Uf, const float* bias, float* y, float* stats, float* counts, int N, int H,
                        int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream);
 
+/* Transposed F(4,3) weight-grad with both transforms outside the GEMM (csrc/wgradp.hip; the weight gradient of
+ * nn.Conv2d(cin,cout,3,padding=1), /root/reference/models/unet.py:11, backward of train.py:131): x and dy are written once as
+ * transform-domain planes (1.5x each, zero rows at every image border), the GEMM is one wave per workgroup with no vector
+ * arithmetic and no barrier.  Contract of cvk_conv3x3_wgrad; Cin_pad % 64 == 0 and Cout % 64 == 0. */
+size_t cvk_conv3x3_wgradp_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout);
+int cvk_conv3x3_wgradp(const float* x, const float* dy, const float* E6_pre, float* dw, int N, int H, int W, int Cin, int Cin_pad,
+                       int Cout, int ld_dy, void* workspace, size_t workspace_bytes, void* stream);
+/* E6_pre: NULL (the E planes are built from dy inside the call) or six planes float[6][cvk_wgradp_plane_rows(N,H,W)][Cout] that
+ * the BatchNorm/ReLU-backward pass wrote on its way: cvk_wgradp_zero_pads (pad rows) then cvk_bn_bwd_dx_e6 (contract of
+ * cvk_bn_bwd_dx_e with six planes E0..E5 in the padded plane layout; ld_dy == C). */
+long cvk_wgradp_plane_rows(int N, int H, int W);
+/* the steps of cvk_conv3x3_wgradp, separately callable: planes of x (is_dy == 0) or dy (is_dy != 0), then GEMM + reduction */
+int cvk_wgradp_planes(const float* t, int ld, float* planes, int N, int H, int W, int C, int is_dy, void* stream);
+size_t cvk_wgradp_gemm_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout);
+int cvk_wgradp_gemm(const float* E6, const float* V6, float* dw, int N, int H, int W, int Cin, int Cin_pad, int Cout, void* workspace,
+                    size_t workspace_bytes, void* stream);
+int cvk_wgradp_zero_pads(float* planes, int N, int H, int W, int C, void* stream);
+int cvk_bn_bwd_dx_e6(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
+                     const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* E6, float* part,
+                     int N, int H, int W, int C, int use_batch_stats, void* stream);
+
 /* weight-grad through the transposed F(4,3) (contract of cvk_conv3x3_wgrad; the workspace also holds the transformed
  * output-gradient planes E1..E4, float[4][N*H*ceil(W/4)][ld_dy], hence the extra ld_dy argument of the size query) */
 size_t cvk_conv3x3_wgrad_wino4_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout, int ld_dy);

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dx_e(const float* __restrict__ d
                                                     const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                     float* __restrict__ dy, int ld_dy, float* __restrict__ E,
                                                     float* __restrict__ part, int M, int C, int W, int Wt, int Mt, int tiles,
-                                                    int cchunk, int use_batch_stats) {
+                                                    int cchunk, int use_batch_stats, int six_H, int six_Wtp, long six_rows) {
     __shared__ float red[256 * 4];
     const int c0 = blockIdx.y * cchunk;
     const int cw = min(cchunk, C - c0);
@@ -329,12 +329,25 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dx_e(const float* __restrict__ d
                     *reinterpret_cast<f32x4*>(dy + (size_t)m * ld_dy + c) = r[i];
                 }
             }
-            float* o = E + (size_t)tl * ld_dy + c;
             const f32x4 a = r[0] + r[2], b = r[1] + r[3], cc = r[0] + 4.f * r[2], dd = 2.f * r[1] + 8.f * r[3];
-            *reinterpret_cast<f32x4*>(o) = a + b;
-            *reinterpret_cast<f32x4*>(o + plane) = a - b;
-            *reinterpret_cast<f32x4*>(o + 2 * plane) = cc + dd;
-            *reinterpret_cast<f32x4*>(o + 3 * plane) = cc - dd;
+            if (six_H == 0) {               // E1..E4 [4][Mt][ld_dy] for k_wgrad_wino4 (E0 / E5 are columns of dy itself)
+                float* o = E + (size_t)tl * ld_dy + c;
+                *reinterpret_cast<f32x4*>(o) = a + b;
+                *reinterpret_cast<f32x4*>(o + plane) = a - b;
+                *reinterpret_cast<f32x4*>(o + 2 * plane) = cc + dd;
+                *reinterpret_cast<f32x4*>(o + 3 * plane) = cc - dd;
+            } else {                        // E0..E5 in the padded plane layout of csrc/wgradp.hip (rows of C floats)
+                const int n = row / six_H, yy = row - n * six_H;
+                const size_t prow = (size_t)six_Wtp + ((size_t)n * (six_H + 2) + yy + 1) * six_Wtp + xt;
+                const size_t ps = (size_t)six_rows * C;
+                float* o = E + prow * C + c;
+                *reinterpret_cast<f32x4*>(o) = r[0];
+                *reinterpret_cast<f32x4*>(o + ps) = a + b;
+                *reinterpret_cast<f32x4*>(o + 2 * ps) = a - b;
+                *reinterpret_cast<f32x4*>(o + 3 * ps) = cc + dd;
+                *reinterpret_cast<f32x4*>(o + 4 * ps) = cc - dd;
+                *reinterpret_cast<f32x4*>(o + 5 * ps) = r[3];
+            }
         }
     }
     if (part == nullptr) return;
@@ -541,8 +554,31 @@ extern "C" int cvk_bn_bwd_dx_e(cvk_view dout, const float* y, int ldy, const flo
     const int cchunk = 1024;
     dim3 grid(nb, cvk_cdiv(C, cchunk));
     hipLaunchKernelGGL(k_bn_bwd_dx_e, grid, dim3(256), 0, (hipStream_t)stream, dout.ptr, dm, y, ldy, scale, shift, mean, rstd,
-                       dgamma, dbeta, dy, ld_dy, E, part, M, C, W, Wt, Mt, tiles, cchunk, use_batch_stats);
+                       dgamma, dbeta, dy, ld_dy, E, part, M, C, W, Wt, Mt, tiles, cchunk, use_batch_stats, 0, 0, 0L);
     CVK_LAUNCH_RETURN("cvk_bn_bwd_dx_e");
+}
+
+// The same pass writing the SIX planes E0..E5 = A dy in the padded plane layout of csrc/wgradp.hip (cvk_wgradp_plane_rows rows of
+// C floats per plane; the pad rows are zeroed by cvk_wgradp_zero_pads, not here).  ld_dy == C required.
+extern "C" int cvk_bn_bwd_dx_e6(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
+                                const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* E6,
+                                float* part, int N, int H, int W, int C, int use_batch_stats, void* stream) {
+    CVK_CHECK_ARG(dout.ptr && y && scale && shift && mean && rstd && dy && E6 && dgamma && dbeta, "cvk_bn_bwd_dx_e6: null pointer");
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && ldy >= C && ld_dy == C && (long)N * H * W < (1L << 31), "cvk_bn_bwd_dx_e6: bad shape (ld_dy must equal C)");
+    const PixMap dm = make_map(dout, H, W);
+    const bool v4 = vec_ok(y, dout.ptr, scale, ldy, ld_dy, C, &dm) && cvk_aligned16(shift) && cvk_aligned16(mean) &&
+                    cvk_aligned16(rstd) && cvk_aligned16(dy) && cvk_aligned16(E6);
+    CVK_CHECK_ARG(v4, "cvk_bn_bwd_dx_e6: needs the 4-channel vector layout (use cvk_bn_bwd_dx)");
+    const int M = N * H * W, Wt = (W + 3) / 4, Mt = N * H * Wt;
+    const int Wtp = (Wt + 7) / 8 * 8;
+    const long rows = (long)N * (H + 2) * Wtp + 2L * Wtp;
+    const int pb = cvk_bn_bwd_blocks(M);
+    const int tiles = cvk_cdiv(Mt, pb), nb = cvk_cdiv(Mt, tiles);
+    const int cchunk = 1024;
+    dim3 grid(nb, cvk_cdiv(C, cchunk));
+    hipLaunchKernelGGL(k_bn_bwd_dx_e, grid, dim3(256), 0, (hipStream_t)stream, dout.ptr, dm, y, ldy, scale, shift, mean, rstd,
+                       dgamma, dbeta, dy, ld_dy, E6, part, M, C, W, Wt, Mt, tiles, cchunk, use_batch_stats, H, Wtp, rows);
+    CVK_LAUNCH_RETURN("cvk_bn_bwd_dx_e6");
 }
 
 extern "C" int cvk_colsum_finalize(const float* part, int PB, int C, float* out0, float* out1, void* stream) {

@@ -154,6 +154,18 @@ def wino4f_ok(k_ch, cout):
     return k_ch % 32 == 0 and cout % 4 == 0 and cout >= 32
 
 
+# transposed F(4,3) weight-grad through transform-domain planes (csrc/wgradp.hip): "0" off, "1" where it pays, "always" (tests)
+WGRADP_DEFAULT = {"0": False, "1": True, "always": "always"}[os.environ.get("CVK_WGRADP", "1")]
+
+
+def wgradp_ok(cin_ld, cout, ldy):
+    return cin_ld % 64 == 0 and cout % 64 == 0 and ldy == cout
+
+
+def wgradp_pays(N, H, W, cin_ld, cout):
+    return cin_ld == 64 and N * H * ((W + 3) // 4) >= 4096
+
+
 def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what="", dgrad_of=None, keep_v=None, wsrc=None, ck=None):
     """y[N,H,W,ldy] = conv3x3(x[N,H,W,k_ch], w[cout][3][3][k_ch]) (+bias, +BN statistics partials at sp) through the
     Winograd kernels: weight transform -> (input transform ->) GEMMs M_xi -> output transform.  2-D F(4x4,3x3) for the
@@ -449,8 +461,25 @@ class ConvBnRelu(Op):
         # F(4,3) from 256x256 channels up: tools/bench_conv.py ww2d); it transforms dy itself, so no E planes are needed
         wgrad2d = self._wgrad2d(R)
         wgrad4 = wgrad4 and not wgrad2d
+        # 64-input-channel layers: both transforms outside the GEMM (csrc/wgradp.hip) — the E planes come from this pass, the V
+        # planes cost one pass over x; pays while that pass is cheap (measured: 64 -> 64 @360x480 0.74x, 64 -> 128 @180x240 0.7x
+        # the time of the transposed F(4,3) kernel; 128 input channels: the V pass eats the gain)
+        wgradp = wgrad4 and R.wgradp and wgradp_ok(src.ld, C, ldy) and (R.wgradp == "always" or wgradp_pays(N, H, W, src.ld, C))
         E = None
-        if wgrad4 and ldy == C and C % 4 == 0:
+        E6 = None
+        if wgradp:
+            rows6 = lib.cvk_wgradp_plane_rows(N, H, W)
+            E6 = _empty(6 * rows6 * C, dev)
+            check(lib.cvk_wgradp_zero_pads(E6.data_ptr(), N, H, W, C, s), "cvk_wgradp_zero_pads")
+            PBe = lib.cvk_bn_bwd_e_blocks(N, H, W)
+            rc = _timed(R, "k_bn_bwd<dx+E6>", (12.0 * M + 24.0 * N * H * ((W + 3) // 4)) * C, lambda: lib.cvk_bn_bwd_dx_e6(
+                dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, E6.data_ptr(), part.data_ptr(),
+                N, H, W, C, 1 if st.training else 0, s), "byte")
+            if rc == 0:
+                check(lib.cvk_colsum_finalize(part.data_ptr(), PBe, C, gb, None, s), "cvk_colsum_finalize")  # conv bias grad
+            else:
+                E6 = None           # layout not vectorisable (strided view): plain pass below, the weight-grad transforms dy itself
+        if E6 is None and wgrad4 and not wgradp and ldy == C and C % 4 == 0:
             E = _empty(4 * N * H * ((W + 3) // 4) * ldy, dev)
             PBe = lib.cvk_bn_bwd_e_blocks(N, H, W)
             rc = _timed(R, "k_bn_bwd<dx+E>", (12.0 * M + 16.0 * N * H * ((W + 3) // 4)) * C, lambda: lib.cvk_bn_bwd_dx_e(
@@ -460,7 +489,7 @@ class ConvBnRelu(Op):
                 check(lib.cvk_colsum_finalize(part.data_ptr(), PBe, C, gb, None, s), "cvk_colsum_finalize")  # conv bias grad
             else:
                 E = None            # layout not vectorisable (strided view): plain pass below, wgrad transforms dy itself
-        if E is None:
+        if E is None and E6 is None:
             _timed(R, "k_bn_bwd<dx>", 12.0 * M * C, lambda: check(
                 lib.cvk_bn_bwd_dx(dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, part.data_ptr(),
                                   N, H, W, C, 1 if st.training else 0, s), "cvk_bn_bwd_dx"), "byte")
@@ -504,6 +533,22 @@ class ConvBnRelu(Op):
             _timed(R, "k_w2d_wgrad_out", 4.0 * (36 * f + 9) * C * self.cin, lambda: check(
                 lib.cvk_w2d_wgrad_output(Pp, gw, T, self.cin, src.ld, C, s), "cvk_w2d_wgrad_output"), "byte")
             del Vkept
+        elif wgradp:
+            rows6 = lib.cvk_wgradp_plane_rows(N, H, W)
+            wsb = lib.cvk_wgradp_gemm_workspace_bytes(N, H, W, src.ld, C)
+            nE = 0 if E6 is not None else 6 * rows6 * C
+            ws = R.workspace(4 * (6 * rows6 * src.ld + nE) + wsb, dev)
+            V6p = ws.data_ptr()
+            E6p = E6.data_ptr() if E6 is not None else V6p + 4 * 6 * rows6 * src.ld
+            slabp = V6p + 4 * (6 * rows6 * src.ld + nE)
+            _timed(R, "k_wgradp_planes", 4.0 * (M + 6.0 * rows6) * src.ld, lambda: check(
+                lib.cvk_wgradp_planes(X.data_ptr(), src.ld, V6p, N, H, W, src.ld, 0, s), "cvk_wgradp_planes(x)"), "byte")
+            if E6 is None:
+                _timed(R, "k_wgradp_planes", 4.0 * (M + 6.0 * rows6) * C, lambda: check(
+                    lib.cvk_wgradp_planes(dy.data_ptr(), ldy, E6p, N, H, W, C, 1, s), "cvk_wgradp_planes(dy)"), "byte")
+            _timed(R, "k_wgradp_gemm", 18.0 * M * C * self.cin, lambda: check(
+                lib.cvk_wgradp_gemm(E6p, V6p, gw, N, H, W, self.cin, src.ld, C, slabp, wsb, s), "cvk_wgradp_gemm"),
+                executed=9.0 * M * C * self.cin)
         elif wgrad4:
             # transposed F(4,3): fastest weight-grad on every layer with >= 64 input channels (tools/bench_conv.py wgrad wwino wwino4)
             wsb = lib.cvk_conv3x3_wgrad_wino4_workspace_bytes(N, H, W, src.ld, C, ldy)
@@ -846,6 +891,7 @@ class Runner:
         self.wino = WINO_DEFAULT
         self.wino4 = WINO4_DEFAULT
         self.wino4f = WINO4F_DEFAULT
+        self.wgradp = WGRADP_DEFAULT
         self.wino2d = WINO2D_DEFAULT
         self.bf16 = False           # opt-in: bf16-storage mode (modules.set_conv_precision; BASELINE.json configs[3])
         self.wcache = WCACHE_DEFAULT

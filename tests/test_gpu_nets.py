@@ -58,6 +58,7 @@ def test_net_forward_loss_grads_golden(tag, conv):
     net = net.to(dev()).train()
     if conv == "f43_always":
         runner_of(net).wino4 = "always"
+        runner_of(net).wgradp = "always"      # ... and every eligible weight-grad through the transform-domain planes (csrc/wgradp.hip)
     if conv == "w2d_always":
         runner_of(net).wino2d = "always"
     n, _, h, w = meta["shape"]

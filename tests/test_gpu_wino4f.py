@@ -105,3 +105,43 @@ def test_fused_is_deterministic_and_tile_walk_independent():
         yc, sc, _ = _fused_conv(x, w, b, max_wg=cap)
         assert torch.equal(yc, y1) and torch.equal(sc, s1), cap
 
+
+# ------------------------------------------------------------------------- weight-grad through transform-domain planes (csrc/wgradp.hip)
+def _planes_wgrad(x_nhwc, dy_nhwc):
+    lib, check = _lib()
+    s = torch.cuda.current_stream().cuda_stream
+    N, H, W, Cin = x_nhwc.shape
+    Cout = dy_nhwc.shape[3]
+    dw = torch.full((Cout, 3, 3, Cin), float("nan"), device="cuda")
+    wsb = lib.cvk_conv3x3_wgradp_workspace_bytes(N, H, W, Cin, Cout)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    check(lib.cvk_conv3x3_wgradp(x_nhwc.data_ptr(), dy_nhwc.data_ptr(), None, dw.data_ptr(), N, H, W, Cin, Cin, Cout, Cout, ws.data_ptr(), wsb, s),
+          "wgradp")
+    torch.cuda.synchronize()
+    return dw
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(1, 5, 7, 64, 64), (2, 9, 13, 64, 128), (2, 33, 50, 128, 64), (1, 16, 36, 128, 128),
+                                             (3, 64, 96, 64, 64), (2, 3, 4, 256, 64), (2, 1, 40, 64, 64), (8, 90, 120, 64, 64)])
+def test_planes_weight_grad_vs_fp64(N, H, W, Cin, Cout):
+    """dW of conv2d(x, w, padding=1) for an upstream gradient dy — fp64 reference by autograd.  Ragged widths (W % 4, column
+    groups not a multiple of 8), single-row images (every step starts a new strip), runs that cross strips and images."""
+    g = torch.Generator().manual_seed(N + 7 * H + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, padding=1).backward(dy.double())
+    ref = w.grad                                                                      # [Cout][Cin][3][3]
+    dw = _planes_wgrad(x.permute(0, 2, 3, 1).contiguous().cuda(), dy.permute(0, 2, 3, 1).contiguous().cuda())
+    got = dw.permute(0, 3, 1, 2).double().cpu()                                       # [Cout][3][3][Cin] -> OIHW
+    assert torch.isfinite(got).all()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel < 5e-6, rel                      # F(4,3) transform constants + an fp32 sum over N*H*W/4 products per element
+
+
+def test_planes_weight_grad_is_deterministic():
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 40, 72, 64, generator=g).cuda()
+    dy = torch.randn(2, 40, 72, 128, generator=g).cuda()
+    a, b = _planes_wgrad(x, dy), _planes_wgrad(x, dy)
+    assert torch.equal(a, b)

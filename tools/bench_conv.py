@@ -116,6 +116,15 @@ def main():
             check(lib.cvk_conv3x3_wgrad_wino(x.data_ptr(), dy.data_ptr(), dwr.data_ptr(), N, H, W, ci, ci, co, ldy, ws2.data_ptr(), wsb2, s))
             err = (dw4 - dwr).abs().max().item() / dwr.abs().max().item()
             row += f" wwino4 {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF err {err:.1e}"; tot["wwino4"][0] += flops; tot["wwino4"][1] += t
+        if "wgradp" in which and ci % 64 == 0 and co % 64 == 0 and ci <= 256 and co <= 256:
+            dy = torch.randn(M, ldy, device=dev); dwf = torch.empty(co, 9 * ci, device=dev)
+            wsb = lib.cvk_conv3x3_wgradp_workspace_bytes(N, H, W, ci, co); wsf = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            t = timeit(lambda: check(lib.cvk_conv3x3_wgradp(x.data_ptr(), dy.data_ptr(), None, dwf.data_ptr(), N, H, W, ci, ci, co, ldy, wsf.data_ptr(), wsb, s)))
+            dwr = torch.empty(co, 9 * ci, device=dev)
+            wsb2 = lib.cvk_conv3x3_wgrad_wino4_workspace_bytes(N, H, W, ci, co, ldy); ws2 = torch.empty(wsb2, dtype=torch.uint8, device=dev)
+            t4 = timeit(lambda: check(lib.cvk_conv3x3_wgrad_wino4(x.data_ptr(), dy.data_ptr(), None, dwr.data_ptr(), N, H, W, ci, ci, co, ldy, ws2.data_ptr(), wsb2, s)))
+            err = (dwf - dwr).norm().item() / dwr.norm().item()
+            row += f" wgradp {t*1e6:8.1f}us {flops/t/1e12:6.1f}TF (wwino4 {t4*1e6:8.1f}us, ratio {t/t4:.2f}) relL2 {err:.1e}"; tot["wgradp"][0] += flops; tot["wgradp"][1] += t
         if "ww2d" in which and ci % 4 == 0 and co % 4 == 0 and ci >= 32 and co > 32:
             dy = torch.randn(M, ldy, device=dev); dw2 = torch.empty(co, 9 * ci, device=dev)
             wsb = lib.cvk_conv3x3_wgrad_w2d_workspace_bytes(N, H, W, ci, co); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
