@@ -215,6 +215,10 @@ int cvk_bn_eval_params(const float* gamma, const float* beta, const float* runni
 /* out = max(0, y*scale + shift), y dense (ldy), out a view. */
 int cvk_bn_relu_apply(const float* y, int ldy, const float* scale, const float* shift, cvk_view out,
                       int N, int H, int W, int C, void* stream);
+/* the same with nn.MaxPool2d(2,2) of the result fused in (/root/reference/models/unet.py:100-109, models/segnet.py:79): pool
+ * float[N][H/2][W/2][C] dense, code (optional) uint8 arg-max codes as cvk_maxpool2x2_fwd; 4-channel vector layout only */
+int cvk_bn_relu_apply_pool(const float* y, int ldy, const float* scale, const float* shift, cvk_view out, float* pool,
+                           unsigned char* code, int N, int H, int W, int C, void* stream);
 /* backward, pass 1: g = dout * [y*scale+shift > 0]; partial sums of g and g*xhat per row block:
  *   part float[2][PB][C], PB = cvk_bn_bwd_blocks(M). */
 int cvk_bn_bwd_blocks(int M);

@@ -92,6 +92,7 @@ SIGNATURES = {
                                 c_float, c_float, c_vp, c_size, c_vp]),
     "cvk_bn_eval_params": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_float, c_vp]),
     "cvk_bn_relu_apply": (c_int, [c_vp, c_int, c_vp, c_vp, View, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_bn_relu_apply_pool": (c_int, [c_vp, c_int, c_vp, c_vp, View, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_bn_bwd_blocks": (c_int, [c_int]),
     "cvk_bn_bwd_reduce": (c_int, [View, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_colsum_finalize": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),

@@ -189,6 +189,57 @@ __global__ __launch_bounds__(256) void k_bn_relu_apply(const float* __restrict__
     }
 }
 
+// BN-apply + ReLU with the 2x2 max pool of the result fused in (nn.MaxPool2d(2,2) directly behind a conv block:
+// /root/reference/models/unet.py:100-109, models/segnet.py:79): one thread = one 2x2 cell x 4 channels; writes the four
+// activations through the (concat) view and, for whole windows, the pooled value (+ the arg-max code 0..3 in window scan order,
+// first maximum, NaN propagating — exactly k_maxpool_fwd of pointwise.hip).  Saves the pool pass's re-read of the activation.
+__global__ __launch_bounds__(256) void k_bn_relu_apply_pool(const float* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, float* __restrict__ out, PixMap om,
+                                                           float* __restrict__ pool, unsigned char* __restrict__ code, int N, int H,
+                                                           int W, int C) {
+    const int cvn = C >> 2, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Hc * Wc * cvn;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cvn);
+        long t = i / cvn;
+        const int xc = (int)(t % Wc);
+        t /= Wc;
+        const int yc = (int)(t % Hc), n = (int)(t / Hc);
+        const int c = cv * 4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int yy = 2 * yc + (k >> 1), xx = 2 * xc + (k & 1);
+            if (yy < H && xx < W) {
+                const int m = (n * H + yy) * W + xx;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(y + (size_t)m * ldy + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[k][j] = fmaxf(a[j] * sc[j] + sh[j], 0.f);
+                *reinterpret_cast<f32x4*>(out + om.off(m) + c) = v[k];
+            }
+        }
+        if (yc < Ho && xc < Wo) {
+            f32x4 best = v[0];
+            unsigned char cd[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = v[k][j], b = best[j];
+                    if (a > b || a != a) { best[j] = a; cd[j] = (unsigned char)k; }
+                }
+            const long o = (((long)n * Ho + yc) * Wo + xc) * C + c;
+            *reinterpret_cast<f32x4*>(pool + o) = best;
+            if (code != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) code[o + j] = cd[j];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- backward
 // Shared walker: block b owns pixel rows [b*rows, (b+1)*rows); thread t owns channel vector (t % cvn) and walks
 // pixels t/cvn, t/cvn + 256/cvn, ...  MODE 0: partial sums of g and g*xhat.  MODE 1: write dy, partial sums of dy.
@@ -478,6 +529,21 @@ extern "C" int cvk_bn_relu_apply(const float* y, int ldy, const float* scale, co
     else
         hipLaunchKernelGGL(k_bn_relu_apply<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, ldy, scale, shift, out.ptr, om, M, C);
     CVK_LAUNCH_RETURN("cvk_bn_relu_apply");
+}
+
+// BN-apply + ReLU + MaxPool2d(2,2) of the result (pool [N][H/2][W/2][C] dense, code optional: as cvk_maxpool2x2_fwd).  4-channel
+// vector layout only (CVK_EINVAL otherwise: the caller then runs cvk_bn_relu_apply + cvk_maxpool2x2_fwd).
+extern "C" int cvk_bn_relu_apply_pool(const float* y, int ldy, const float* scale, const float* shift, cvk_view out, float* pool,
+                                      unsigned char* code, int N, int H, int W, int C, void* stream) {
+    CVK_CHECK_ARG(y && scale && shift && out.ptr && pool, "cvk_bn_relu_apply_pool: null pointer");
+    CVK_CHECK_ARG(N > 0 && H >= 2 && W >= 2 && C > 0 && ldy >= C && (long)N * H * W < (1L << 31), "cvk_bn_relu_apply_pool: bad shape");
+    const PixMap om = make_map(out, H, W);
+    const bool v4 = vec_ok(y, out.ptr, scale, ldy, 0, C, &om) && cvk_aligned16(shift) && cvk_aligned16(pool);
+    CVK_CHECK_ARG(v4, "cvk_bn_relu_apply_pool: needs the 4-channel vector layout");
+    const long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(k_bn_relu_apply_pool, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, ldy, scale, shift, out.ptr, om, pool, code, N, H, W, C);
+    CVK_LAUNCH_RETURN("cvk_bn_relu_apply_pool");
 }
 
 extern "C" int cvk_bn_bwd_blocks(int M) {

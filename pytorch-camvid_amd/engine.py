@@ -89,6 +89,7 @@ class RunState:
         self.gflat = None
         self.stream = None
         self.sync = None   # optional gradient synchroniser (ddp.GradSync)
+        self.pooled_by_block = {}   # op index of a conv block -> True when its BN-apply pass also wrote the max pool behind it
 
 
 def _empty(n, dev, dtype=_F32):
@@ -348,7 +349,8 @@ class ConvBnRelu(Op):
     def __init__(self, src, dst, pslot, holder, cin, cout, src_needs_grad):
         self.src, self.dst, self.pslot, self.holder = src, dst, pslot, holder
         self.cin, self.cout, self.src_needs_grad = cin, cout, src_needs_grad
-        self.pool_dst = None        # bf16 plans: the ActBuf of a MaxPool2d(2,2) of this block's output, written by the BN-apply pass
+        self.pool_dst = None        # the ActBuf of a MaxPool2d(2,2) of this block's output, written by the BN-apply pass
+        self.pool_op = None
         assert src.C == cin and dst.C == cout and dst.H == src.H and dst.W == src.W
 
     def _weight_fwd(self, R, st, w):
@@ -430,8 +432,23 @@ class ConvBnRelu(Op):
             check(lib.cvk_bn_eval_params(gamma.data_ptr(), beta.data_ptr(), bn.running_mean.data_ptr(),
                                          bn.running_var.data_ptr(), pm, pr, psc, psh, C, float(bn.eps), s), "cvk_bn_eval_params")
         out = R.alloc_act(st, dst.buf, dev)
-        _timed(R, "k_bn_relu_apply", 8.0 * M * C, lambda: check(
-            lib.cvk_bn_relu_apply(y.data_ptr(), ldy, psc, psh, dst.cview(out), N, H, W, C, s), "cvk_bn_relu_apply"), "byte")
+        pooled = False
+        if self.pool_dst is not None and C % 4 == 0:
+            # the 2x2 max pool behind this block is written by the same pass (csrc/bn.hip k_bn_relu_apply_pool)
+            pool = R.alloc_act(st, self.pool_dst, dev)
+            code = None
+            if self.pool_op.keep_code:
+                code = torch.empty(self.pool_dst.M * self.pool_dst.ld, device=dev, dtype=torch.uint8)
+            rc = _timed(R, "k_bn_relu_apply<pool>", (8.0 + 1.0 + (0.25 if code is not None else 0.0)) * M * C, lambda: lib.cvk_bn_relu_apply_pool(
+                y.data_ptr(), ldy, psc, psh, dst.cview(out), pool.data_ptr(), code.data_ptr() if code is not None else None,
+                N, H, W, C, s), "byte")
+            pooled = rc == 0
+            if pooled and code is not None:
+                st.saved[self.pool_op.idx] = code
+        st.pooled_by_block[self.idx] = pooled
+        if not pooled:
+            _timed(R, "k_bn_relu_apply", 8.0 * M * C, lambda: check(
+                lib.cvk_bn_relu_apply(y.data_ptr(), ldy, psc, psh, dst.cview(out), N, H, W, C, s), "cvk_bn_relu_apply"), "byte")
         if st.need_grad:
             st.saved[self.idx] = (y, bnp, keep_v[0] if keep_v else None)
 
@@ -686,7 +703,8 @@ class MaxPool(Op):
 
     def __init__(self, src_view, dst_buf, keep_code):
         self.src, self.dst, self.keep_code = src_view, dst_buf, keep_code
-        self.fused = False          # bf16 plans: produced by the preceding block's BN-apply pass
+        self.fused = False          # produced by the preceding block's BN-apply pass
+        self.producer_idx = -1
         if src_view.H < 2 or src_view.W < 2:
             raise RuntimeError(f"max_pool2d: input {src_view.H}x{src_view.W} is too small for a 2x2 window")
 
@@ -697,6 +715,8 @@ class MaxPool(Op):
             if not self.fused:
                 raise NotImplementedError("bf16 mode: a max pool must directly follow a conv block (it is fused into its BN pass)")
             return                                      # the producing block's BN-apply pass already wrote st.act[d.id]
+        if self.fused and st.pooled_by_block.get(self.producer_idx, False):
+            return                                      # the producing block's BN-apply pass already wrote st.act[d.id] (and the code)
         out = R.alloc_act(st, d, X.device)
         code = None
         if self.keep_code:
@@ -850,9 +870,12 @@ class Plan:
         dst = self.new_buf(src_view.C, src_view.H // 2, src_view.W // 2, "pool")
         op = self.add(MaxPool(src_view, dst, keep_code))
         prod = self._producer.get((src_view.buf.id, src_view.c0))
-        if self.bf16 and not keep_code and prod is not None and prod.dst.C == src_view.C and prod.pool_dst is None:
-            prod.pool_dst = dst         # the block's BN-apply pass writes the pooled tensor too (csrc/elem_bf16.hip)
+        if (not keep_code or not self.bf16) and prod is not None and prod.dst.C == src_view.C and prod.pool_dst is None \
+                and prod.dst.H == src_view.H and prod.dst.W == src_view.W and prod.dst.y0 == src_view.y0 and prod.dst.x0 == src_view.x0:
+            prod.pool_dst = dst         # the block's BN-apply pass writes the pooled tensor too (csrc/elem_bf16.hip, csrc/bn.hip)
+            prod.pool_op = op
             op.fused = True
+            op.producer_idx = prod.idx
         return op
 
     def unpool(self, src_buf, pool_op):
