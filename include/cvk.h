@@ -160,6 +160,15 @@ int cvk_wino4f_weight_transform(const float* w, float* Uf, int Cn, int Ck, int d
 int cvk_wino4f_stat_partials(int N, int H, int W);
 int cvk_conv3x3_wino4f(const float* x, const float* Uf, const float* bias, float* y, float* stats, float* counts, int N, int H,
                        int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream);
+/* The data-grad launch whose result y is the COMPLETE dL/d(activation) of the block that produced this conv's input
+ * (nn.BatchNorm2d + ReLU backward of /root/reference/models/unet.py:12-13 starts with two column sums over exactly that
+ * tensor): the epilogue also leaves  sum g  and  sum g * xhat,  g = y masked by the producer's ReLU (yP*scale+shift > 0),
+ * xhat = (yP - mean) * rstd,  as part = float[2][cvk_wino4f_stat_partials(N,H,W)][Cout] for
+ * cvk_colsum_finalize(part, partials, Cout, dbeta, dgamma) — cvk_bn_bwd_reduce is then not launched for that block.
+ * yP: the producer's conv output [N*H*W][ldy] (same row stride as y); no bias, no forward statistics. */
+int cvk_conv3x3_wino4f_bnred(const float* x, const float* Uf, float* y, int N, int H, int W, int Cin, int Cout, int ldy,
+                             const float* yP, const float* scale, const float* shift, const float* mean, const float* rstd,
+                             float* part, int max_workgroups, void* stream);
 
 /* Transposed F(4,3) weight-grad with both transforms outside the GEMM (csrc/wgradp.hip; the weight gradient of
  * nn.Conv2d(cin,cout,3,padding=1), /root/reference/models/unet.py:11, backward of train.py:131): x and dy are written once as

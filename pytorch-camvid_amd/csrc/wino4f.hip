@@ -91,11 +91,26 @@ __device__ __forceinline__ void f_dma16(const void* sbase, unsigned voff, unsign
 // run on the vector lanes: tools/micro/mfma_xwave.hip, and the ablation of the 4-wave version of this kernel: the side work of a
 // K step cost the same with and without MFMAs in the stream), so the staging work of one wave has to sit under the MFMAs of
 // the OTHER wave on its SIMD — with one 4-wave workgroup per CU (144 KiB of LDS) there was no other wave.
-template <bool STATS, int ABL = 0>
+//
+// BNR (data-grad launches only): the tensor written is dL/d(activation) of the layer that PRODUCED this conv's input, and that
+// layer's BatchNorm backward starts with two column sums over exactly these values (csrc/bn.hip k_bn_bwd<MODE 0>):
+// sum g and sum g * xhat with g = dX masked by the ReLU, xhat = (yP - mean) * rstd.  The epilogue has dX in registers: it reads
+// yP (the producer's conv output, same geometry and row stride as Y) and leaves per-m-tile partial sums in `stats`
+// ([2][P][Cout], the layout cvk_colsum_finalize reads) — the producer's reduce pass over dX and yP is not launched at all.
+struct FBnRed {
+    const float* y;       // producer's conv output [N*H*W][ldy]
+    const float* scale;   // gamma * rstd, beta - mean * gamma * rstd  (the forward's apply constants: the ReLU mask)
+    const float* shift;
+    const float* mean;
+    const float* rstd;
+};
+
+template <bool STATS, int ABL = 0, bool BNR = false>
 __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
     const float* __restrict__ X, const float* __restrict__ Uf, const float* __restrict__ bias, float* __restrict__ Y,
     float* __restrict__ stats, float* __restrict__ counts, int Mt, int H, int W, int Wt, int Cin, int Cout, int ldy,
-    int tilesN, int ntiles, int Mpix, int P) {
+    int tilesN, int ntiles, int Mpix, int P, FBnRed bn) {
+    static_assert(!(STATS && BNR), "forward statistics and the BatchNorm-backward sums are different launches");
     __shared__ __attribute__((aligned(1024))) char smem[2 * F_STAGE + 2048];
     const unsigned smem_addr = cvk_lds_addr(smem);
     float* const red = reinterpret_cast<float*>(smem + 2 * F_STAGE);     // [2 sums][4 wave rows][64 channels]
@@ -283,6 +298,19 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
                                                                             (int)(ybytes < 0x7FFFFFFFu ? ybytes : 0x7FFFFFFFu), 0x00020000);
         const unsigned ls = (unsigned)ldy * 4u;
         float s1 = 0.f, s2 = 0.f;
+        __amdgpu_buffer_rsrc_t pr = null_rsrc;
+        float bsc = 0.f, bsh = 0.f, bmu = 0.f;
+        if (BNR) {
+            pr = __builtin_amdgcn_make_buffer_rsrc((void*)(bn.y + (size_t)pixb * ldy), 0,
+                                                   (int)(ybytes < 0x7FFFFFFFu ? ybytes : 0x7FFFFFFFu), 0x00020000);
+            if (cok) { bsc = bn.scale[col]; bsh = bn.shift[col]; bmu = bn.mean[col]; }
+        }
+        // g = dX where the producer's ReLU passed; accumulates sum g and sum g * (yP - mean)  (rstd multiplies once, at the end)
+        auto bnacc = [&](float q, float v) {
+            const float g = fmaf(q, bsc, bsh) > 0.f ? v : 0.f;
+            s1 += g;
+            s2 = fmaf(g, q - bmu, s2);
+        };
         if ((W & 3) == 0 && m0 + F_BM <= Mt && (tn + 1) * F_BN <= Cout) {
             // whole tile, no ragged column group: pixel(t) = 4 t, every output valid.  The vector ALU only does the transform,
             // the bias and the statistics (its instructions take matrix time on this part); a row's byte offset is uniform and
@@ -303,6 +331,16 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
                 if (STATS) {
                     s1 += (y0 + y1) + (y2 + y3);
                     s2 += fmaf(y0, y0, y1 * y1) + fmaf(y2, y2, y3 * y3);
+                }
+                if (BNR) {
+                    // (hipcc keeps 16 of these loads in flight; asking for 32 up front changed nothing — every workgroup reaches
+                    // its epilogue at about the same time and the burst is bandwidth-, not latency-bound: +10 % on the launch,
+                    // against the whole reduce pass it replaces)
+                    const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, ob, so, 0));
+                    const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, ob, so + ls, 0));
+                    const float q2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, ob, so + 2 * ls, 0));
+                    const float q3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, ob, so + 3 * ls, 0));
+                    bnacc(q0, y0 + bs); bnacc(q1, y1 + bs); bnacc(q2, y2 + bs); bnacc(q3, y3 + bs);
                 }
             }
         } else {
@@ -325,6 +363,32 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
                     const float z0 = nv > 0 ? y0 : 0.f, z1 = nv > 1 ? y1 : 0.f, z2 = nv > 2 ? y2 : 0.f, z3 = nv > 3 ? y3 : 0.f;
                     s1 += (z0 + z1) + (z2 + z3);
                     s2 += fmaf(z0, z0, z1 * z1) + fmaf(z2, z2, z3 * z3);
+                }
+                if (BNR) {      // an out-of-range load returns 0; the value beside it is masked by nv as well
+                    const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 0, o), 0, 0));
+                    const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 1, o), ls, 0));
+                    const float q2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 2, o), 2 * ls, 0));
+                    const float q3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 3, o), 3 * ls, 0));
+                    bnacc(q0, nv > 0 ? y0 + bs : 0.f); bnacc(q1, nv > 1 ? y1 + bs : 0.f);
+                    bnacc(q2, nv > 2 ? y2 + bs : 0.f); bnacc(q3, nv > 3 ? y3 + bs : 0.f);
+                }
+            }
+        }
+        if (BNR) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lh == 0) {
+                red[wm * 64 + wn * 32 + li] = s1;
+                red[256 + wm * 64 + wn * 32 + li] = s2;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const int c = tn * F_BN + tid;
+                if (c < Cout) {
+                    const float a = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+                    const float b = (red[256 + tid] + red[320 + tid]) + (red[384 + tid] + red[448 + tid]);
+                    stats[(size_t)mt * Cout + c] = a;
+                    stats[(size_t)(P + mt) * Cout + c] = b * bn.rstd[c];
                 }
             }
         }
@@ -453,16 +517,16 @@ extern "C" int cvk_wino4f_stat_partials(int N, int H, int W) {
     return cvk_cdiv((long)N * H * ((W + 3) / 4), F_BM);
 }
 
-extern "C" int cvk_conv3x3_wino4f(const float* x, const float* Uf, const float* bias, float* y, float* stats, float* counts, int N,
-                                  int H, int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream) {
-    CVK_CHECK_ARG(x && Uf && y, "cvk_conv3x3_wino4f: null pointer");
-    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout, "cvk_conv3x3_wino4f: bad shape");
-    CVK_CHECK_ARG(Cin >= 32 && Cin % 32 == 0, "cvk_conv3x3_wino4f: Cin=%d must be a multiple of 32", Cin);
-    CVK_CHECK_ARG((stats == nullptr) == (counts == nullptr), "cvk_conv3x3_wino4f: stats and counts go together");
-    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(Uf), "cvk_conv3x3_wino4f: x and Uf must be 16-byte aligned");
-    CVK_CHECK_ARG((long)N * H * W < (1L << 31) - 512, "cvk_conv3x3_wino4f: tensor too large for 32-bit pixel indices");
+static int wino4f_launch(const char* who, const float* x, const float* Uf, const float* bias, float* y, float* stats, float* counts,
+                         const FBnRed* bn, int N, int H, int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream) {
+    CVK_CHECK_ARG(x && Uf && y, "%s: null pointer", who);
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout, "%s: bad shape", who);
+    CVK_CHECK_ARG(Cin >= 32 && Cin % 32 == 0, "%s: Cin=%d must be a multiple of 32", who, Cin);
+    CVK_CHECK_ARG((stats == nullptr) == (counts == nullptr) || bn, "%s: stats and counts go together", who);
+    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(Uf), "%s: x and Uf must be 16-byte aligned", who);
+    CVK_CHECK_ARG((long)N * H * W < (1L << 31) - 512, "%s: tensor too large for 32-bit pixel indices", who);
     const int Wt = (W + 3) / 4, Mt = N * H * Wt, Mpix = N * H * W;
-    CVK_CHECK_ARG((long)Mt * Wt < (1L << 32) && (long)N * H * H < (1L << 32), "cvk_conv3x3_wino4f: frame too large for the multiply-high coordinate split");
+    CVK_CHECK_ARG((long)Mt * Wt < (1L << 32) && (long)N * H * H < (1L << 32), "%s: frame too large for the multiply-high coordinate split", who);
     const int tilesN = f_tiles_n(Cout), tilesM = cvk_cdiv(Mt, F_BM), ntiles = tilesM * tilesN;
     // persistent strips: one workgroup per CU (144 KiB of LDS), each walks ntiles / grid consecutive tiles
     static int cus = 0;          // queried once (a benign race: every thread stores the same value); not during a stream capture
@@ -476,15 +540,35 @@ extern "C" int cvk_conv3x3_wino4f(const float* x, const float* Uf, const float* 
     // registers) — with a static tile assignment the workgroups that find no free CU would start only when others finish
     const int wgs = (max_workgroups > 0 && max_workgroups < cus) ? max_workgroups : cus;
     const int grid = ntiles < wgs ? ntiles : wgs;
-    CVK_CHECK_ARG((F_BM * 4 + 3L * W + 8) * Cin * 4 < (1L << 31), "cvk_conv3x3_wino4f: a tile's input window exceeds the 2 GiB buffer-addressing limit");
+    CVK_CHECK_ARG((F_BM * 4 + 3L * W + 8) * Cin * 4 < (1L << 31), "%s: a tile's input window exceeds the 2 GiB buffer-addressing limit", who);
     hipStream_t s = (hipStream_t)stream;
-    if (stats)
+    const FBnRed none = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (bn)
+        hipLaunchKernelGGL((k_conv3x3_wino4f<false, 0, true>), dim3(grid), dim3(512), 0, s, x, Uf, bias, y, stats, counts, Mt, H, W, Wt, Cin,
+                           Cout, ldy, tilesN, ntiles, Mpix, tilesM, *bn);
+    else if (stats)
         hipLaunchKernelGGL(k_conv3x3_wino4f<true>, dim3(grid), dim3(512), 0, s, x, Uf, bias, y, stats, counts, Mt, H, W, Wt, Cin, Cout, ldy,
-                           tilesN, ntiles, Mpix, tilesM);
+                           tilesN, ntiles, Mpix, tilesM, none);
     else
         hipLaunchKernelGGL(k_conv3x3_wino4f<false>, dim3(grid), dim3(512), 0, s, x, Uf, bias, y, stats, counts, Mt, H, W, Wt, Cin, Cout, ldy,
-                           tilesN, ntiles, Mpix, tilesM);
-    CVK_LAUNCH_RETURN("cvk_conv3x3_wino4f");
+                           tilesN, ntiles, Mpix, tilesM, none);
+    CVK_LAUNCH_RETURN(who);
+}
+
+extern "C" int cvk_conv3x3_wino4f(const float* x, const float* Uf, const float* bias, float* y, float* stats, float* counts, int N,
+                                  int H, int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream) {
+    return wino4f_launch("cvk_conv3x3_wino4f", x, Uf, bias, y, stats, counts, nullptr, N, H, W, Cin, Cout, ldy, max_workgroups, stream);
+}
+
+// The data-grad launch that also leaves the producer layer's BatchNorm-backward column sums (see FBnRed): `part` is
+// float[2][cvk_wino4f_stat_partials(N,H,W)][Cout], read by cvk_colsum_finalize(part, partials, Cout, dbeta, dgamma).
+// yP has y's geometry and row stride ldy.
+extern "C" int cvk_conv3x3_wino4f_bnred(const float* x, const float* Uf, float* y, int N, int H, int W, int Cin, int Cout, int ldy,
+                                        const float* yP, const float* scale, const float* shift, const float* mean,
+                                        const float* rstd, float* part, int max_workgroups, void* stream) {
+    CVK_CHECK_ARG(yP && scale && shift && mean && rstd && part, "cvk_conv3x3_wino4f_bnred: null pointer");
+    const FBnRed bn = {yP, scale, shift, mean, rstd};
+    return wino4f_launch("cvk_conv3x3_wino4f_bnred", x, Uf, nullptr, y, part, nullptr, &bn, N, H, W, Cin, Cout, ldy, max_workgroups, stream);
 }
 
 #ifdef CVK_WINO4F_ABLATE
@@ -494,7 +578,7 @@ extern "C" int cvk_conv3x3_wino4f_ablate(const float* x, const float* Uf, const 
     const int tilesN = f_tiles_n(Cout), tilesM = cvk_cdiv(Mt, F_BM), ntiles = tilesM * tilesN;
     const int grid = ntiles < 256 ? ntiles : 256;
     hipStream_t s = (hipStream_t)stream;
-#define CVK_ABL(A) case A: hipLaunchKernelGGL((k_conv3x3_wino4f<false, A>), dim3(grid), dim3(512), 0, s, x, Uf, bias, y, nullptr, nullptr, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM); break;
+#define CVK_ABL(A) case A: hipLaunchKernelGGL((k_conv3x3_wino4f<false, A>), dim3(grid), dim3(512), 0, s, x, Uf, bias, y, nullptr, nullptr, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, FBnRed{nullptr, nullptr, nullptr, nullptr, nullptr}); break;
     switch (abl) {
         CVK_ABL(0) CVK_ABL(1) CVK_ABL(2) CVK_ABL(3) CVK_ABL(4) CVK_ABL(7) CVK_ABL(8) CVK_ABL(9) CVK_ABL(11) CVK_ABL(15) CVK_ABL(16) CVK_ABL(24) CVK_ABL(31)
         default: return -1;

@@ -90,6 +90,7 @@ class RunState:
         self.stream = None
         self.sync = None   # optional gradient synchroniser (ddp.GradSync)
         self.pooled_by_block = {}   # op index of a conv block -> True when its BN-apply pass also wrote the max pool behind it
+        self.bnred = {}             # op index of a conv block -> (partials, count): its BN-backward sums, left by the consumer's data-grad
 
 
 def _empty(n, dev, dtype=_F32):
@@ -167,7 +168,8 @@ def wgradp_pays(N, H, W, cin_ld, cout):
     return cin_ld == 64 and N * H * ((W + 3) // 4) >= 4096
 
 
-def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what="", dgrad_of=None, keep_v=None, wsrc=None, ck=None):
+def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what="", dgrad_of=None, keep_v=None, wsrc=None, ck=None,
+              bnred=None):
     """y[N,H,W,ldy] = conv3x3(x[N,H,W,k_ch], w[cout][3][3][k_ch]) (+bias, +BN statistics partials at sp) through the
     Winograd kernels: weight transform -> (input transform ->) GEMMs M_xi -> output transform.  2-D F(4x4,3x3) for the
     channel-heavy layers (R.wino2d, wino2d_pays), else 1-D F(4,3) when R.wino4, else F(2,3).
@@ -176,7 +178,10 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
     Returns None, or (P, counts pointer) when the statistics partials at sp carry explicit pixel counts (2-D path:
     P = cvk_w2d_stat_partials partials of [sum | M2] followed by the counts -> cvk_bn_finalize_counts).  keep_v: a list that
     receives the transformed input V when the 2-D path runs (the layer's weight-grad reuses it).  wsrc / ck: the parameter the
-    filter derives from and the layer's cache key — the transformed filter is then kept across calls (Runner.derived)."""
+    filter derives from and the layer's cache key — the transformed filter is then kept across calls (Runner.derived).
+    bnred (data-grad only): (yP, scale, shift, mean, rstd pointers, out list) of the block that produced this conv's input; when
+    the fused F(4,3) kernel runs and ldy == cout it also leaves that block's BatchNorm-backward sums and appends
+    (partials tensor, partial count) to the list."""
     M = N * H * W
 
     def cached(kind, build):
@@ -225,6 +230,13 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
         Uf = cached("w4f", build_uf)
         Pf = lib.cvk_wino4f_stat_partials(N, H, W)
         cnt = sp + 4 * 2 * Pf * cout if sp is not None else None
+        if bnred is not None and sp is None and bias is None and ldy == cout and R.bnred_fuse:
+            bpart = _empty(2 * Pf * cout, x.device)
+            _timed(R, "k_conv3x3_wino4f<bnred>", flops, lambda: check(
+                lib.cvk_conv3x3_wino4f_bnred(x.data_ptr(), Uf.data_ptr(), y.data_ptr(), N, H, W, k_ch, cout, ldy, *bnred[:5],
+                                             bpart.data_ptr(), R.persistent_wgs(), s), "cvk_conv3x3_wino4f_bnred"), executed=0.5 * flops)
+            bnred[5].append((bpart, Pf))
+            return None
         _timed(R, "k_conv3x3_wino4f", flops, lambda: check(
             lib.cvk_conv3x3_wino4f(x.data_ptr(), Uf.data_ptr(), bias, y.data_ptr(), sp, cnt, N, H, W, k_ch, cout, ldy, R.persistent_wgs(), s),
             "cvk_conv3x3_wino4f" + what), executed=0.5 * flops)
@@ -468,9 +480,14 @@ class ConvBnRelu(Op):
         dO = dst.cview(st.grad[dst.buf.id])
         PB = lib.cvk_bn_bwd_blocks(M)
         part = _empty(2 * PB * C, dev)
-        _timed(R, "k_bn_bwd<reduce>", 8.0 * M * C, lambda: check(
-            lib.cvk_bn_bwd_reduce(dO, y.data_ptr(), ldy, psc, psh, pm, pr, part.data_ptr(), N, H, W, C, s), "cvk_bn_bwd_reduce"), "byte")
-        check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, gbe, gg, s), "cvk_colsum_finalize")   # dbeta, dgamma
+        pre = st.bnred.pop(self.idx, None)
+        if pre is not None:     # the data-grad that wrote dO summed it already (csrc/wino4f.hip BNR epilogue)
+            check(lib.cvk_colsum_finalize(pre[0].data_ptr(), pre[1], C, gbe, gg, s), "cvk_colsum_finalize")
+        else:
+            _timed(R, "k_bn_bwd<reduce>", 8.0 * M * C, lambda: check(
+                lib.cvk_bn_bwd_reduce(dO, y.data_ptr(), ldy, psc, psh, pm, pr, part.data_ptr(), N, H, W, C, s), "cvk_bn_bwd_reduce"), "byte")
+            check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, gbe, gg, s), "cvk_colsum_finalize")   # dbeta, dgamma
+        del pre
         dy = torch.zeros(M * ldy, device=dev, dtype=_F32) if ldy != C else _empty(M * ldy, dev)
         # layers whose weight-grad runs through the transposed F(4,3) get its transformed dy planes E1..E4 from this pass
         wgrad4 = R.wino and src.ld >= 32 and C > 32 and (R.wino4 == "always" or (R.wino4 and src.ld >= 64))
@@ -524,8 +541,18 @@ class ConvBnRelu(Op):
                 return wd_
             dX = _empty(M * src.ld, dev).view(N, H, W, src.ld)
             if wino_ok(R, ldy, src.ld):
+                # dX is the whole gradient of the producing block's activation when this conv is its only reader: the fused
+                # kernel then sums it for that block's BatchNorm backward on the way out (training-mode statistics only)
+                prod = st.plan.sole_producer(src) if st.training else None
+                bnred = None
+                if prod is not None and prod.idx in st.saved and pad4(prod.cout) == prod.cout == src.ld:
+                    py, pbnp = st.saved[prod.idx][0], st.saved[prod.idx][1]
+                    bnred = (py.data_ptr(), pbnp.data_ptr() + 8 * src.ld, pbnp.data_ptr() + 12 * src.ld, pbnp.data_ptr(),
+                             pbnp.data_ptr() + 4 * src.ld, [])
                 wino_conv(R, lib, s, dy, packed, None, dX, None, N, H, W, ldy, src.ld, src.ld, 18.0 * M * C * self.cin, "(dgrad)",
-                          dgrad_of=(wc, C, self.cin), wsrc=w, ck=(self.pslot, "d"))
+                          dgrad_of=(wc, C, self.cin), wsrc=w, ck=(self.pslot, "d"), bnred=bnred)
+                if bnred is not None and bnred[5]:
+                    st.bnred[prod.idx] = bnred[5][0]
             else:
                 wd = R.derived(((self.pslot, "d"), "pack"), w, packed)
                 _timed(R, conv_kernel_name("dgrad", src.ld, ldy), 18.0 * M * C * self.cin, lambda: check(
@@ -837,6 +864,7 @@ class Plan:
         self.bf16 = bool(bf16)      # bf16-storage plan: activation buffers are bf16 (the logits buffer stays fp32)
         self.bufs, self.ops, self.holders = [], [], []
         self._producer = {}         # (buffer id, first channel) -> the ConvBnRelu op that writes that view
+        self._readers = {}          # buffer id -> number of ops that read the buffer (each one adds to its gradient)
         self.input = self.new_buf(cin, H, W, "input")
         self.output = None
         self.input_needs_grad = False
@@ -851,6 +879,18 @@ class Plan:
         self.ops.append(op)
         return op
 
+    def _reads(self, buf):
+        self._readers[buf.id] = self._readers.get(buf.id, 0) + 1
+
+    def sole_producer(self, buf):
+        """The ConvBnRelu block whose output is exactly `buf` when `buf` has ONE reader — that reader's data-grad is then
+        the complete dL/d(activation) of the block, and may carry the block's BatchNorm-backward sums (csrc/wino4f.hip BNR)."""
+        op = self._producer.get((buf.id, 0))
+        if op is None or not op.dst.is_full or op.dst.buf is not buf or self._readers.get(buf.id, 0) != 1 or self.output is None \
+                or self.output.buf is buf:
+            return None
+        return op
+
     # ---- builders used by the modules -----------------------------------------------------------------------
     def conv_bn_relu(self, src_buf, holder, dst_view=None):
         cin, cout = holder.in_channels, holder.out_channels
@@ -862,12 +902,14 @@ class Plan:
         pslot = len(self.holders)
         self.holders.append(holder)
         needs = src_buf is not self.input or self.input_needs_grad
+        self._reads(src_buf)
         op = self.add(ConvBnRelu(src_buf, dst_view, pslot, holder, cin, cout, needs))
         self._producer[(dst_view.buf.id, dst_view.c0)] = op
         return dst_view
 
     def maxpool(self, src_view, keep_code=False):
         dst = self.new_buf(src_view.C, src_view.H // 2, src_view.W // 2, "pool")
+        self._reads(src_view.buf)
         op = self.add(MaxPool(src_view, dst, keep_code))
         prod = self._producer.get((src_view.buf.id, src_view.c0))
         if (not keep_code or not self.bf16) and prod is not None and prod.dst.C == src_view.C and prod.pool_dst is None \
@@ -881,11 +923,13 @@ class Plan:
     def unpool(self, src_buf, pool_op):
         v = pool_op.src
         dst = self.new_buf(v.C, v.H, v.W, "unpool")
+        self._reads(src_buf)
         self.add(Unpool(src_buf, pool_op, dst))
         return dst
 
     def upsample(self, src_buf):
         dst = self.new_buf(src_buf.C, 2 * src_buf.H, 2 * src_buf.W, "up")
+        self._reads(src_buf)
         self.add(Upsample(src_buf, dst))
         return dst
 
@@ -915,6 +959,7 @@ class Runner:
         self.wino4 = WINO4_DEFAULT
         self.wino4f = WINO4F_DEFAULT
         self.wgradp = WGRADP_DEFAULT
+        self.bnred_fuse = os.environ.get("CVK_BNRED_FUSE", "1") != "0"   # BN-backward sums in the fused data-grad's epilogue
         self.wino2d = WINO2D_DEFAULT
         self.bf16 = False           # opt-in: bf16-storage mode (modules.set_conv_precision; BASELINE.json configs[3])
         self.wcache = WCACHE_DEFAULT

@@ -87,6 +87,48 @@ def test_fused_data_grad_vs_fp64(N, H, W, Cin, Cout):
     assert rel < 3e-6, rel
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 9, 13, 64, 64), (1, 16, 36, 64, 128), (2, 33, 50, 128, 64), (3, 64, 96, 64, 64),
+                                             (1, 2, 3, 64, 64)])
+def test_fused_data_grad_leaves_the_producers_batchnorm_backward_sums(N, H, W, Cin, Cout):
+    """cvk_conv3x3_wino4f_bnred: the data-grad dx is bitwise the plain launch's, and its epilogue leaves the two column sums
+    the producer block's BatchNorm+ReLU backward (reference models/unet.py:12-13) starts with: sum g and sum g * xhat,
+    g = dx where the producer's ReLU passed, xhat = (yP - mean) * rstd — checked against fp64 of the same dx (fp32 partial
+    sums over <= 512 values per tile and channel, fp64 across tiles: 2e-5 of the sums' scale)."""
+    lib, check = _lib()
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(11 + Cin + Cout + W)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    dy = torch.randn(N, H, W, Cout, generator=g).cuda()
+    yP = (torch.randn(N, H, W, Cin, generator=g) * 1.5 + 0.3).cuda()
+    gamma, beta = (torch.rand(Cin, generator=g) + 0.5).cuda(), (torch.randn(Cin, generator=g) * 0.3).cuda()
+    mean = yP.mean(dim=(0, 1, 2))
+    rstd = (yP.var(dim=(0, 1, 2), unbiased=False) + 1e-5).rsqrt()
+    scale = gamma * rstd
+    shift = beta - mean * scale
+    plain, _, _ = _fused_conv(dy, w.cuda(), None, stats=False, dgrad=True)
+    wcl = w.permute(0, 2, 3, 1).contiguous().cuda()
+    Uf = torch.empty(lib.cvk_wino4f_weight_floats(Cin, Cout), device="cuda")
+    check(lib.cvk_wino4f_weight_transform(wcl.data_ptr(), Uf.data_ptr(), Cin, Cout, 1, s), "weight")
+    P = lib.cvk_wino4f_stat_partials(N, H, W)
+    for cap in (0, 3):
+        dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+        part = torch.full((2 * P * Cin,), float("nan"), device="cuda")
+        check(lib.cvk_conv3x3_wino4f_bnred(dy.data_ptr(), Uf.data_ptr(), dx.data_ptr(), N, H, W, Cout, Cin, Cin, yP.data_ptr(),
+                                           scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), part.data_ptr(), cap, s),
+              "bnred")
+        dbeta, dgamma = torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda")
+        check(lib.cvk_colsum_finalize(part.data_ptr(), P, Cin, dbeta.data_ptr(), dgamma.data_ptr(), s), "finalize")
+        torch.cuda.synchronize()
+        assert torch.equal(dx, plain)
+        mask = (yP * scale + shift) > 0
+        gm = torch.where(mask, dx, torch.zeros_like(dx)).double()
+        xh = (yP.double() - mean.double()) * rstd.double()
+        want_b, want_g = gm.sum(dim=(0, 1, 2)), (gm * xh).sum(dim=(0, 1, 2))
+        sc = gm.abs().sum(dim=(0, 1, 2)).max().item()
+        assert (dbeta.double() - want_b).abs().max().item() < 2e-5 * sc, cap
+        assert (dgamma.double() - want_g).abs().max().item() < 2e-5 * max(sc, (gm * xh).abs().sum(dim=(0, 1, 2)).max().item()), cap
+
+
 def test_fused_is_deterministic_and_tile_walk_independent():
     """Bitwise reproducible, and every image of a batch equals the same image run alone (the persistent tile walk and the
     batch size must not change any value: the K order per output is fixed)."""
