@@ -170,6 +170,24 @@ int cvk_conv3x3_wino4f_bnred(const float* x, const float* Uf, float* y, int N, i
                              const float* yP, const float* scale, const float* shift, const float* mean, const float* rstd,
                              float* part, int max_workgroups, void* stream);
 
+/* THIN layers (csrc/thin.hip): the stem nn.Conv2d(3, 64, 3, padding=1) (/root/reference/models/unet.py:103,
+ * models/segnet.py first block) and the classifier head nn.Conv2d(64, class_num, 3, padding=1) (models/unet.py:127), forward,
+ * data-grad and weight-grad.  The thin channel dimension is one 16-row side (or the k = 4) of v_mfma_f32_16x16x4_f32; a wave
+ * walks down a 16-pixel (forward) / 4-pixel (weight-grad) column with the 3x3 window's rows in registers.
+ *   cvk_conv3x3_thin_fwd: y = conv3x3(x, w) + bias; w [Cout][9][Cin_ld].  stats/counts (both or neither):
+ *     P = cvk_thin_stat_partials(N,H,W,Cin_ld) partials [sum | M2 about the partial mean] [2][P][Cout] + P pixel counts for
+ *     cvk_bn_finalize_counts.  Supported shapes: cvk_thin_fwd_supported(Cin_ld, Cout, ldy) != 0.
+ *   cvk_conv3x3_thin_wgrad: dw [Cout][9][Cin] = sum_p dy[p][co] * x[p + tap][ci]; fixed-order reduction (bitwise
+ *     reproducible).  Supported shapes: cvk_thin_wgrad_supported(Cin, Cin_ld, Cout, ld_dy) != 0. */
+int cvk_thin_fwd_supported(int Cin_ld, int Cout, int ldy);
+int cvk_thin_stat_partials(int N, int H, int W, int Cin_ld);
+int cvk_conv3x3_thin_fwd(const float* x, const float* w, const float* bias, float* y, float* stats, float* counts, int N, int H,
+                         int W, int Cin_ld, int Cout, int ldy, void* stream);
+int cvk_thin_wgrad_supported(int Cin, int Cin_ld, int Cout, int ld_dy);
+size_t cvk_conv3x3_thin_wgrad_workspace_bytes(int N, int H, int W, int Cin_ld, int Cout);
+int cvk_conv3x3_thin_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cin_ld, int Cout,
+                           int ld_dy, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Transposed F(4,3) weight-grad with both transforms outside the GEMM (csrc/wgradp.hip; the weight gradient of
  * nn.Conv2d(cin,cout,3,padding=1), /root/reference/models/unet.py:11, backward of train.py:131): x and dy are written once as
  * transform-domain planes (1.5x each, zero rows at every image border), the GEMM is one wave per workgroup with no vector

@@ -56,6 +56,12 @@ SIGNATURES = {
     "cvk_wino4f_stat_partials": (c_int, [c_int, c_int, c_int]),
     "cvk_conv3x3_wino4f": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_wino4f_bnred": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "cvk_thin_fwd_supported": (c_int, [c_int, c_int, c_int]),
+    "cvk_thin_stat_partials": (c_int, [c_int, c_int, c_int, c_int]),
+    "cvk_conv3x3_thin_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_thin_wgrad_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "cvk_conv3x3_thin_wgrad_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
+    "cvk_conv3x3_thin_wgrad": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
     "cvk_conv3x3_wgradp_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
     "cvk_conv3x3_wgradp": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
     "cvk_wgradp_plane_rows": (ctypes.c_long, [c_int, c_int, c_int]),

@@ -395,6 +395,14 @@ class ConvBnRelu(Op):
         lib, s, src = R.lib, st.stream, self.src
         N, H, W, M, C, ldy = src.N, src.H, src.W, src.M, self.cout, pad4(self.cout)
         sp = stats.data_ptr() if stats is not None else None
+        if R.thin and lib.cvk_thin_fwd_supported(src.ld, C, ldy):
+            # the classifier head (64 -> 12): csrc/thin.hip, the thin side is the 16-row side of a 16x16x4 MFMA
+            Pt = lib.cvk_thin_stat_partials(N, H, W, src.ld)
+            cnt = sp + 4 * 2 * Pt * C if sp is not None else None
+            _timed(R, "k_thin_co_fwd", 18.0 * M * C * self.cin, lambda: check(
+                lib.cvk_conv3x3_thin_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, cnt, N, H, W, src.ld, C, ldy, s),
+                "cvk_conv3x3_thin_fwd"), executed=18.0 * M * 16 * self.cin)
+            return (Pt, cnt) if sp is not None else None
         if wino_ok(R, src.ld, ldy):
             return wino_conv(R, lib, s, X, wk, b.data_ptr(), y, sp, N, H, W, src.ld, C, ldy, 18.0 * M * C * self.cin, keep_v=keep_v,
                              wsrc=st.params[4 * self.pslot], ck=(self.pslot, "f"))
@@ -421,7 +429,7 @@ class ConvBnRelu(Op):
         keep_v = [] if (st.need_grad and self._wgrad2d(R)) else None      # transformed input, reused by the weight-grad
         if st.training:
             P = (M + _lib.CVK_STAT_ROWS - 1) // _lib.CVK_STAT_ROWS
-            Pm = max(P, lib.cvk_w2d_stat_partials(N, H, W))     # room for either partial layout (+ the 2-D path's counts)
+            Pm = max(P, lib.cvk_w2d_stat_partials(N, H, W), lib.cvk_thin_stat_partials(N, H, W, src.ld))   # room for any partial layout (+ counts)
             stats = _empty(2 * Pm * C + Pm, dev)
             if M <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {[N, C, H, W]}")
@@ -601,6 +609,12 @@ class ConvBnRelu(Op):
                 lib.cvk_conv3x3_wgrad_wino4(X.data_ptr(), dy.data_ptr(), E.data_ptr() if E is not None else None, gw, N, H, W,
                                             self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
                 "cvk_conv3x3_wgrad_wino4"))
+        elif R.thin and lib.cvk_thin_wgrad_supported(self.cin, src.ld, C, ldy):
+            wsb = lib.cvk_conv3x3_thin_wgrad_workspace_bytes(N, H, W, src.ld, C)
+            ws = R.workspace(wsb, dev)
+            _timed(R, "k_thin_co_wgrad", 18.0 * M * C * self.cin, lambda: check(
+                lib.cvk_conv3x3_thin_wgrad(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
+                "cvk_conv3x3_thin_wgrad"), executed=18.0 * M * 16 * self.cin)
         elif R.wino and src.ld >= 32 and C > 32 and (src.ld > 64 or C > 64):   # 64->64 layers: the direct kernel is faster
             wsb = lib.cvk_conv3x3_wgrad_wino_workspace_bytes(N, H, W, src.ld, C)
             ws = R.workspace(wsb, dev)
@@ -959,6 +973,7 @@ class Runner:
         self.wino4 = WINO4_DEFAULT
         self.wino4f = WINO4F_DEFAULT
         self.wgradp = WGRADP_DEFAULT
+        self.thin = os.environ.get("CVK_THIN", "1") != "0"    # csrc/thin.hip for the stem and the classifier head
         self.bnred_fuse = os.environ.get("CVK_BNRED_FUSE", "1") != "0"   # BN-backward sums in the fused data-grad's epilogue
         self.wino2d = WINO2D_DEFAULT
         self.bf16 = False           # opt-in: bf16-storage mode (modules.set_conv_precision; BASELINE.json configs[3])
