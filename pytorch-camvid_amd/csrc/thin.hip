@@ -301,6 +301,253 @@ __global__ __launch_bounds__(1024) void k_thin_co_reduce(const float* __restrict
     }
 }
 
+// ============================================================================ thin INPUT: Cin_ld = 4 NV <= 12 -> wide Cout
+// The stem (3 -> 64, Cin_ld = 4) and the head's data-grad (12 -> 64 on the rotated/transposed pack, Cin_ld = 12).  A tap's
+// channels are the k of ONE MFMA (NV = 1) or of NV of them: lane group q carries channels [q NV, q NV + NV).  D[co][px]: a
+// workgroup column (blockIdx.y) owns 64 output channels = 4 row blocks, the filter (36 NV values per lane) lives in registers.
+// Input-row stationary as k_thin_co_fwd; a row is only 3 NV registers, so four are kept in flight.
+template <int NV, bool STATS>
+__global__ __launch_bounds__(256, 2) void k_thin_ci_fwd(const float* __restrict__ X, const float* __restrict__ Wt,
+                                                        const float* __restrict__ bias, float* __restrict__ Y,
+                                                        float* __restrict__ stats, float* __restrict__ counts, int H, int W,
+                                                        int Cout, int ldy, int R, int RC, int XG, int P) {
+    constexpr int LD = 4 * NV;
+    constexpr int RING = NV == 1 ? 4 : 2;               // input rows in registers: loads run RING - 1 steps (of 36 NV MFMAs) ahead
+    constexpr int UN = RING == 4 ? 12 : 6;              // lcm(RING, 3 output-row slots): every index below is static
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int task = blockIdx.x * 4 + wave;
+    if (task >= P) return;
+    const int cb = blockIdx.y * 64;
+    const ThinTask t = thin_task(task, XG, RC, R, H);
+    const int px = t.xg * 16 + n;
+    const __amdgpu_buffer_rsrc_t xr = image_rsrc(X + (size_t)t.img * H * W * LD, (size_t)H * W * LD);
+    const __amdgpu_buffer_rsrc_t yr = image_rsrc(Y + (size_t)t.img * H * W * ldy, (size_t)H * W * ldy);
+
+    float wa[4][9][NV];                                 // Wt[cb + 16 nb + n][tap][q NV + r]
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int co = cb + nb * 16 + n;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+            for (int r = 0; r < NV; ++r) wa[nb][tp][r] = co < Cout ? Wt[((size_t)co * 9 + tp) * LD + q * NV + r] : 0.f;
+    }
+    float in[RING][3][NV];                              // [ring slot][dx][r]: x[row][px + dx - 1][q NV + r]
+    auto load_row = [&](int yy, float (&dst)[3][NV]) {
+        const bool rok = (unsigned)yy < (unsigned)H && yy <= t.y1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int xx = px + d - 1;
+            const unsigned off = oob_unless(rok && (unsigned)xx < (unsigned)W, (unsigned)((yy * W + xx) * LD + q * NV) * 4u);
+#pragma unroll
+            for (int r = 0; r < NV; ++r) dst[d][r] = buf_load4(xr, off + 4u * r);
+        }
+    };
+    f32x4 bs[4], s1[4], s2[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        bs[nb] = s1[nb] = s2[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (bias != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (cb + nb * 16 + 4 * q + i < Cout) bs[nb][i] = bias[cb + nb * 16 + 4 * q + i];
+        }
+    }
+    const bool pok = px < W;
+    const unsigned obase = (unsigned)(px * ldy + cb + 4 * q) * 4u;
+    f32x4 acc[3][4];                                    // [output row slot = (row - y0) mod 3][row block]
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[o][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // step `it` handles input row y0 - 1 + it (ring slot it mod RING), it = 0 .. rows + 1
+    const int steps = t.y1 - t.y0 + 2;
+#pragma unroll
+    for (int j = 0; j < RING - 1; ++j) load_row(t.y0 - 1 + j, in[j]);
+    for (int ib = 0; ib < steps; ib += UN) {
+        t_static_for<UN>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            const int it = ib + k;
+            if (it < steps) {
+                load_row(t.y0 + it + RING - 2, in[(k + RING - 1) % RING]);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int yo = t.y0 + it - dy;                  // output row fed through kernel row dy
+                    constexpr int slot_base = k + 3;
+                    if (yo >= t.y0 && yo < t.y1) {
+#pragma unroll
+                        for (int d = 0; d < 3; ++d)
+#pragma unroll
+                            for (int r = 0; r < NV; ++r)
+#pragma unroll
+                                for (int nb = 0; nb < 4; ++nb)
+                                    acc[(slot_base - dy) % 3][nb] = mfma4(wa[nb][dy * 3 + d][r], in[k % RING][d][r], acc[(slot_base - dy) % 3][nb]);
+                    }
+                }
+                const int yd = t.y0 + it - 2;                       // complete after its kernel row 2
+                if (yd >= t.y0) {
+                    constexpr int sd = (k + 1) % 3;                 // (it - 2) mod 3
+                    const unsigned orow = obase + (unsigned)(yd * W) * ldy * 4u;
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) {
+                        const f32x4 v = acc[sd][nb];
+                        acc[sd][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        const f32x4 o = v + bs[nb];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yr,
+                                                               oob_unless(pok && cb + nb * 16 + 4 * q < ldy, orow + 64u * nb), 0, 0);
+                        if (STATS) {
+                            const f32x4 z = pok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                            s1[nb] += z;
+                            s2[nb] += z * z;
+                        }
+                    }
+                }
+            }
+        });
+    }
+    if (STATS) {
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s1[nb][i] += __shfl_xor(s1[nb][i], m, 64);
+                    s2[nb][i] += __shfl_xor(s2[nb][i], m, 64);
+                }
+        }
+        if (n == 0) {
+            const float cnt = (float)((t.y1 - t.y0) * min(16, W - t.xg * 16));
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = cb + nb * 16 + 4 * q + i;
+                    if (c < Cout) {
+                        const float m2 = s2[nb][i] - s1[nb][i] * s1[nb][i] / cnt;      // sums exclude the bias (shift invariance)
+                        stats[(size_t)task * Cout + c] = s1[nb][i] + cnt * bs[nb][i];
+                        stats[(size_t)(P + task) * Cout + c] = m2 > 0.f ? m2 : 0.f;
+                    }
+                }
+            if (q == 0 && blockIdx.y == 0) counts[task] = cnt;
+        }
+    }
+}
+
+// ================================================================================= stem weight-grad: dW[Cout][9][Cin <= 4]
+// The pixels are k again (4-pixel column strips).  B = the dY quad: one dwordx4 per lane = [4 px][64 co], register r <-> output
+// channels 4 n + r.  A = the X quad for ONE kernel row, all three kernel columns at once: row 4 dx + c of the 16 <-> (kernel
+// column dx, input channel c) — x[px - 1 + dx][c] for lane group k = pixel sits 16 B x (pixel + dx) + 4 B x c from the strip's
+// left neighbour, i.e. 4 B x row: one dword per lane, rows 12..15 unused.  12 MFMAs per image row and 64 output channels; rows
+// are processed in blocks of four, the next block's 6 + 16 registers in flight under the current one.
+constexpr int TS_ROWS = 4;
+
+__global__ __launch_bounds__(256, 4) void k_thin_ci_wgrad(const float* __restrict__ X, const float* __restrict__ DY,
+                                                          float* __restrict__ part, int H, int W, int Cout, int ld_dy, int R,
+                                                          int RC, int XG, int P) {
+    __shared__ f32x4 red[12 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, n = lane & 15;
+    const int task = blockIdx.x * 4 + wave;
+    const int cb = blockIdx.y * 64;
+    f32x4 acc[3][4];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[dy][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (task < P) {
+        const ThinTask t = thin_task(task, XG, RC, R, H);
+        const int px = t.xg * 4 + q;
+        const __amdgpu_buffer_rsrc_t xr = image_rsrc(X + (size_t)t.img * H * W * 4, (size_t)H * W * 4);
+        const __amdgpu_buffer_rsrc_t gr = image_rsrc(DY + (size_t)t.img * H * W * ld_dy, (size_t)H * W * ld_dy);
+        const int xx = px - 1 + (n >> 2);
+        const bool xok = n < 12 && (unsigned)xx < (unsigned)W;
+        const bool gok = px < W && cb + 4 * n < Cout;
+        float xa[2][TS_ROWS + 2];                       // x rows yb-1 .. yb+4 of the block
+        f32x4 gb[2][TS_ROWS];                           // dY rows yb .. yb+3
+        auto load_block = [&](int yb, float (&xd)[TS_ROWS + 2], f32x4 (&gd)[TS_ROWS]) {
+#pragma unroll
+            for (int j = 0; j < TS_ROWS + 2; ++j) {
+                const int yy = yb - 1 + j;
+                xd[j] = buf_load4(xr, oob_unless(xok && (unsigned)yy < (unsigned)H && yy <= t.y1, (unsigned)((yy * W + xx) * 4 + (n & 3)) * 4u));
+            }
+#pragma unroll
+            for (int j = 0; j < TS_ROWS; ++j) {
+                const int yy = yb + j;
+                gd[j] = buf_load16(gr, oob_unless(gok && yy < t.y1, (unsigned)((yy * W + px) * ld_dy + cb + 4 * n) * 4u));
+            }
+        };
+        load_block(t.y0, xa[0], gb[0]);
+        for (int yb = t.y0; yb < t.y1; yb += 2 * TS_ROWS) {
+            t_static_for<2>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                const int y = yb + k * TS_ROWS;
+                if (y < t.y1) {
+                    load_block(y + TS_ROWS, xa[k ^ 1], gb[k ^ 1]);
+#pragma unroll
+                    for (int j = 0; j < TS_ROWS; ++j)
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[dy][r] = mfma4(xa[k][j + dy], gb[k][j][r], acc[dy][r]);
+                }
+            });
+        }
+    }
+#pragma unroll 1
+    for (int w = 1; w < 4; ++w) {                       // wave 0 adds waves 1, 2, 3 in that order
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < 12; ++a) red[a * 64 + lane] = acc[a >> 2][a & 3];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int a = 0; a < 12; ++a) acc[a >> 2][a & 3] += red[a * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        f32x4* dst = reinterpret_cast<f32x4*>(part) + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 12 * 64;
+#pragma unroll
+        for (int a = 0; a < 12; ++a) dst[a * 64 + lane] = acc[a >> 2][a & 3];
+    }
+}
+
+// dW[co][tap = 3 dy + dx][ci] = sum_s part[s][co >> 6][dy * 4 + (co & 3)][lane = dx * 16 + ((co & 63) >> 2)][ci]
+__global__ __launch_bounds__(1024) void k_thin_ci_reduce(const float* __restrict__ part, float* __restrict__ dw, int S, int CB, int Cout,
+                                                         int Cin) {
+    __shared__ float red[16][64];
+    const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + l;                  // output index (co * 9 + tap) * Cin + ci
+    const int total = Cout * 9 * Cin;
+    float s = 0.f;
+    if (e < total) {
+        const int ci = e % Cin, ct = e / Cin, tap = ct % 9, co = ct / 9;
+        const int dy = tap / 3, dx = tap - 3 * dy;
+        const size_t src = ((size_t)(co >> 6) * 12 + dy * 4 + (co & 3)) * 256 + (size_t)(dx * 16 + ((co & 63) >> 2)) * 4 + ci;
+        const size_t stride = (size_t)CB * 12 * 256;
+        float s0 = 0.f, s1 = 0.f;
+        int p = g;
+        for (; p + 16 < S; p += 32) {
+            s0 += part[(size_t)p * stride + src];
+            s1 += part[(size_t)(p + 16) * stride + src];
+        }
+        if (p < S) s0 += part[(size_t)p * stride + src];
+        s = s0 + s1;
+    }
+    red[g][l] = s;
+    __syncthreads();
+    if (g == 0 && e < total) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a += red[i][l];
+        dw[e] = a;
+    }
+}
+
 // rows per task: the fewest rounds of `slots` concurrent waves, then the fewest rows per wave (each task also loads two halo rows)
 int thin_rows_per_task(int N, int H, int groups, int slots) {
     long best = -1;
@@ -332,8 +579,11 @@ int thin_slots() {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------- C ABI
+static bool thin_co_shape(int Cin_ld, int Cout, int ldy) { return Cin_ld == 64 && Cout <= 16 && ldy % 4 == 0 && ldy <= 16; }
+static bool thin_ci_shape(int Cin_ld, int Cout, int ldy) { return Cin_ld >= 4 && Cin_ld <= 12 && Cin_ld % 4 == 0 && Cout >= 32 && ldy % 4 == 0; }
+
 extern "C" int cvk_thin_fwd_supported(int Cin_ld, int Cout, int ldy) {
-    return (Cin_ld == 64 && Cout <= 16 && ldy % 4 == 0 && ldy <= 16) ? 1 : 0;
+    return (thin_co_shape(Cin_ld, Cout, ldy) || thin_ci_shape(Cin_ld, Cout, ldy)) ? 1 : 0;
 }
 
 extern "C" int cvk_thin_stat_partials(int N, int H, int W, int Cin_ld) {
@@ -350,10 +600,23 @@ extern "C" int cvk_conv3x3_thin_fwd(const float* x, const float* w, const float*
     CVK_CHECK_ARG(cvk_thin_fwd_supported(Cin_ld, Cout, ldy), "cvk_conv3x3_thin_fwd: Cin_ld=%d Cout=%d ldy=%d is not a thin layer", Cin_ld, Cout, ldy);
     CVK_CHECK_ARG((stats == nullptr) == (counts == nullptr), "cvk_conv3x3_thin_fwd: stats and counts go together");
     CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(w) && cvk_aligned16(y), "cvk_conv3x3_thin_fwd: x, w and y must be 16-byte aligned");
-    CVK_CHECK_ARG((long)H * W * 64 * 4 < (1L << 31), "cvk_conv3x3_thin_fwd: one image exceeds the 2 GiB buffer-addressing limit");
+    CVK_CHECK_ARG((long)H * W * (Cin_ld > ldy ? Cin_ld : ldy) * 4 < (1L << 31), "cvk_conv3x3_thin_fwd: one image exceeds the 2 GiB buffer-addressing limit");
     const int XG = cvk_cdiv(W, 16);
     const int R = thin_rows_per_task(N, H, XG, thin_slots()), RC = cvk_cdiv(H, R), P = N * XG * RC;
     hipStream_t s = (hipStream_t)stream;
+    if (!thin_co_shape(Cin_ld, Cout, ldy)) {
+        const dim3 grid(cvk_cdiv(P, 4), cvk_cdiv(Cout, 64));
+        // (12 input channels with statistics would spill at two waves per SIMD; no layer of the reference needs it)
+        CVK_CHECK_ARG(!(stats && Cin_ld > 8), "cvk_conv3x3_thin_fwd: statistics are fused for Cin_ld <= 8 only");
+#define CVK_THIN_CI(NV_, ST_) hipLaunchKernelGGL((k_thin_ci_fwd<NV_, ST_>), grid, dim3(256), 0, s, x, w, bias, y, stats, counts, H, W, Cout, ldy, R, RC, XG, P)
+        if (Cin_ld == 4 && stats) CVK_THIN_CI(1, true);
+        else if (Cin_ld == 4) CVK_THIN_CI(1, false);
+        else if (Cin_ld == 8 && stats) CVK_THIN_CI(2, true);
+        else if (Cin_ld == 8) CVK_THIN_CI(2, false);
+        else CVK_THIN_CI(3, false);
+#undef CVK_THIN_CI
+        CVK_LAUNCH_RETURN("cvk_conv3x3_thin_fwd");
+    }
     if (stats)
         hipLaunchKernelGGL(k_thin_co_fwd<true>, dim3(cvk_cdiv(P, 4)), dim3(256), 0, s, x, w, bias, y, stats, counts, H, W, Cout, ldy, R, RC, XG, P);
     else
@@ -361,8 +624,11 @@ extern "C" int cvk_conv3x3_thin_fwd(const float* x, const float* w, const float*
     CVK_LAUNCH_RETURN("cvk_conv3x3_thin_fwd");
 }
 
+static bool thin_co_wshape(int Cin, int Cin_ld, int Cout, int ld_dy) { return Cin == 64 && Cin_ld == 64 && Cout <= 16 && ld_dy <= 16; }
+static bool thin_ci_wshape(int Cin, int Cin_ld, int Cout, int ld_dy) { return Cin <= 4 && Cin_ld == 4 && Cout >= 32 && ld_dy % 4 == 0; }
+
 extern "C" int cvk_thin_wgrad_supported(int Cin, int Cin_ld, int Cout, int ld_dy) {
-    return (Cin == 64 && Cin_ld == 64 && Cout <= 16 && ld_dy <= 16) ? 1 : 0;
+    return (thin_co_wshape(Cin, Cin_ld, Cout, ld_dy) || thin_ci_wshape(Cin, Cin_ld, Cout, ld_dy)) ? 1 : 0;
 }
 
 static void thin_wgrad_plan(int N, int H, int W, int* R, int* RC, int* XG, int* P) {
@@ -376,6 +642,7 @@ extern "C" size_t cvk_conv3x3_thin_wgrad_workspace_bytes(int N, int H, int W, in
     if (N <= 0 || H <= 0 || W <= 0) return 0;
     int R, RC, XG, P;
     thin_wgrad_plan(N, H, W, &R, &RC, &XG, &P);
+    if (Cin_ld == 4) return (size_t)cvk_cdiv(P, 4) * cvk_cdiv(Cout, 64) * 12 * 256 * sizeof(float);
     return (size_t)cvk_cdiv(P, 4) * 36 * 256 * sizeof(float);
 }
 
@@ -385,7 +652,7 @@ extern "C" int cvk_conv3x3_thin_wgrad(const float* x, const float* dy, float* dw
     CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ld_dy >= Cout, "cvk_conv3x3_thin_wgrad: bad shape");
     CVK_CHECK_ARG(cvk_thin_wgrad_supported(Cin, Cin_ld, Cout, ld_dy), "cvk_conv3x3_thin_wgrad: Cin=%d Cin_ld=%d Cout=%d ld_dy=%d is not a thin layer", Cin, Cin_ld, Cout, ld_dy);
     CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(workspace), "cvk_conv3x3_thin_wgrad: x and the workspace must be 16-byte aligned");
-    CVK_CHECK_ARG((long)H * W * 64 * 4 < (1L << 31), "cvk_conv3x3_thin_wgrad: one image exceeds the 2 GiB buffer-addressing limit");
+    CVK_CHECK_ARG((long)H * W * (Cin_ld > ld_dy ? Cin_ld : ld_dy) * 4 < (1L << 31), "cvk_conv3x3_thin_wgrad: one image exceeds the 2 GiB buffer-addressing limit");
     if (workspace_bytes < cvk_conv3x3_thin_wgrad_workspace_bytes(N, H, W, Cin_ld, Cout)) {
         cvk_set_error("cvk_conv3x3_thin_wgrad: workspace too small");
         return CVK_EWORKSPACE;
@@ -394,6 +661,13 @@ extern "C" int cvk_conv3x3_thin_wgrad(const float* x, const float* dy, float* dw
     thin_wgrad_plan(N, H, W, &R, &RC, &XG, &P);
     const int S = cvk_cdiv(P, 4);
     hipStream_t s = (hipStream_t)stream;
+    if (Cin_ld == 4) {
+        CVK_CHECK_ARG(cvk_aligned16(dy), "cvk_conv3x3_thin_wgrad: dy must be 16-byte aligned");
+        const int CB = cvk_cdiv(Cout, 64);
+        hipLaunchKernelGGL(k_thin_ci_wgrad, dim3(S, CB), dim3(256), 0, s, x, dy, (float*)workspace, H, W, Cout, ld_dy, R, RC, XG, P);
+        hipLaunchKernelGGL(k_thin_ci_reduce, dim3(cvk_cdiv(Cout * 9 * Cin, 64)), dim3(1024), 0, s, (const float*)workspace, dw, S, CB, Cout, Cin);
+        CVK_LAUNCH_RETURN("cvk_conv3x3_thin_wgrad");
+    }
     hipLaunchKernelGGL(k_thin_co_wgrad, dim3(S), dim3(256), 0, s, x, dy, (float*)workspace, H, W, Cout, ld_dy, R, RC, XG, P);
     hipLaunchKernelGGL(k_thin_co_reduce, dim3(cvk_cdiv(Cout * 9 * 64, 64)), dim3(1024), 0, s, (const float*)workspace, dw, S, Cout);
     CVK_LAUNCH_RETURN("cvk_conv3x3_thin_wgrad");

@@ -395,13 +395,14 @@ class ConvBnRelu(Op):
         lib, s, src = R.lib, st.stream, self.src
         N, H, W, M, C, ldy = src.N, src.H, src.W, src.M, self.cout, pad4(self.cout)
         sp = stats.data_ptr() if stats is not None else None
-        if R.thin and lib.cvk_thin_fwd_supported(src.ld, C, ldy):
-            # the classifier head (64 -> 12): csrc/thin.hip, the thin side is the 16-row side of a 16x16x4 MFMA
+        if R.thin and lib.cvk_thin_fwd_supported(src.ld, C, ldy) and (sp is None or src.ld <= 8 or src.ld == 64):
+            # the stem (3 -> 64) and the classifier head (64 -> 12): csrc/thin.hip, the thin side is one side of a 16x16x4 MFMA
             Pt = lib.cvk_thin_stat_partials(N, H, W, src.ld)
             cnt = sp + 4 * 2 * Pt * C if sp is not None else None
-            _timed(R, "k_thin_co_fwd", 18.0 * M * C * self.cin, lambda: check(
+            head = src.ld == 64
+            _timed(R, "k_thin_co_fwd" if head else "k_thin_ci_fwd", 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_thin_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, cnt, N, H, W, src.ld, C, ldy, s),
-                "cvk_conv3x3_thin_fwd"), executed=18.0 * M * 16 * self.cin)
+                "cvk_conv3x3_thin_fwd"), executed=18.0 * M * (16 * self.cin if head else C * src.ld))
             return (Pt, cnt) if sp is not None else None
         if wino_ok(R, src.ld, ldy):
             return wino_conv(R, lib, s, X, wk, b.data_ptr(), y, sp, N, H, W, src.ld, C, ldy, 18.0 * M * C * self.cin, keep_v=keep_v,
@@ -561,6 +562,11 @@ class ConvBnRelu(Op):
                           dgrad_of=(wc, C, self.cin), wsrc=w, ck=(self.pslot, "d"), bnred=bnred)
                 if bnred is not None and bnred[5]:
                     st.bnred[prod.idx] = bnred[5][0]
+            elif R.thin and lib.cvk_thin_fwd_supported(ldy, src.ld, src.ld):      # the head's data-grad: 12 -> 64 (csrc/thin.hip)
+                wd = R.derived(((self.pslot, "d"), "pack"), w, packed)
+                _timed(R, "k_thin_ci_fwd(dgrad)", 18.0 * M * C * self.cin, lambda: check(
+                    lib.cvk_conv3x3_thin_fwd(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, None, N, H, W, ldy, src.ld, src.ld, s),
+                    "cvk_conv3x3_thin_fwd(dgrad)"), executed=18.0 * M * ldy * src.ld)
             else:
                 wd = R.derived(((self.pslot, "d"), "pack"), w, packed)
                 _timed(R, conv_kernel_name("dgrad", src.ld, ldy), 18.0 * M * C * self.cin, lambda: check(
@@ -612,9 +618,10 @@ class ConvBnRelu(Op):
         elif R.thin and lib.cvk_thin_wgrad_supported(self.cin, src.ld, C, ldy):
             wsb = lib.cvk_conv3x3_thin_wgrad_workspace_bytes(N, H, W, src.ld, C)
             ws = R.workspace(wsb, dev)
-            _timed(R, "k_thin_co_wgrad", 18.0 * M * C * self.cin, lambda: check(
+            head = src.ld == 64
+            _timed(R, "k_thin_co_wgrad" if head else "k_thin_ci_wgrad", 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_thin_wgrad(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
-                "cvk_conv3x3_thin_wgrad"), executed=18.0 * M * 16 * self.cin)
+                "cvk_conv3x3_thin_wgrad"), executed=18.0 * M * (16 * self.cin if head else C * 16 / 3.0))
         elif R.wino and src.ld >= 32 and C > 32 and (src.ld > 64 or C > 64):   # 64->64 layers: the direct kernel is faster
             wsb = lib.cvk_conv3x3_wgrad_wino_workspace_bytes(N, H, W, src.ld, C)
             ws = R.workspace(wsb, dev)

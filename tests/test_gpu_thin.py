@@ -56,8 +56,8 @@ def _check_stats(st, P, C, ref):
     var = (m2.sum(0) + (cnt[:, None] * (sums / cnt[:, None] - mean) ** 2).sum(0)) / M
     rmean, rvar = ref.mean(dim=(0, 2, 3)), ref.var(dim=(0, 2, 3), unbiased=False)
     assert (mean - rmean).abs().max().item() < 2e-6 * max(1.0, rmean.abs().max().item())
-    if M > 1:
-        assert ((var - rvar).abs() / rvar.clamp_min(1e-12)).max().item() < 2e-5
+    # fp32 sums: the variance is exact to 2e-5 of itself plus the rounding of the squared values it is a difference of
+    assert ((var - rvar).abs() <= 2e-5 * rvar + 2e-7 * (ref ** 2).mean(dim=(0, 2, 3))).all()
 
 
 @pytest.mark.parametrize("N,H,W", GEOM)
@@ -106,6 +106,72 @@ def test_head_weight_grad_vs_fp64(N, H, W, Cout, ld_dy):
         torch.cuda.synchronize()
         outs.append(dw)
     assert torch.equal(outs[0], outs[1])                                  # fixed-order reduction
+    got = outs[0].double().cpu()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel < 2e-6, rel
+
+
+@pytest.mark.parametrize("N,H,W", GEOM)
+@pytest.mark.parametrize("Cin,ld,Cout", [(3, 4, 64), (3, 4, 128), (5, 8, 64), (3, 4, 36)])
+def test_stem_forward_and_statistics_vs_fp64(N, H, W, Cin, ld, Cout):
+    g = torch.Generator().manual_seed(N * 31 + H * 7 + W + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    xn = torch.zeros(N, H, W, ld, device="cuda")
+    xn[..., :Cin] = x.permute(0, 2, 3, 1).cuda()
+    y, st, P = _fwd(xn, w.cuda(), b.cuda(), Cout)
+    got = y.permute(0, 3, 1, 2).double().cpu()
+    assert torch.isfinite(got).all()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel < 1e-6, rel
+    _check_stats(st, P, Cout, ref)
+
+
+@pytest.mark.parametrize("N,H,W", GEOM)
+def test_head_data_grad_vs_fp64(N, H, W):
+    """dx = conv_transpose(dy, w): the same kernel on the rotated / transposed pack [Cin][9][Cout_ld = 12], no bias, no statistics."""
+    lib, check = _lib()
+    Cout, Cin = 12, 64
+    g = torch.Generator().manual_seed(N + H + W)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    ref = F.conv_transpose2d(dy.double(), w.double(), padding=1)
+    wd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9, Cout).contiguous().cuda()        # [ci][tap'][co] = w[co][ci][8 - tap']
+    dyn = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+    check(lib.cvk_conv3x3_thin_fwd(dyn.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), None, None, N, H, W, 12, Cin, Cin, _stream()), "thin dgrad")
+    torch.cuda.synchronize()
+    got = dx.permute(0, 3, 1, 2).double().cpu()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel < 1e-6, rel
+
+
+@pytest.mark.parametrize("N,H,W", GEOM)
+@pytest.mark.parametrize("Cin,Cout", [(3, 64), (3, 128), (4, 64), (1, 36)])
+def test_stem_weight_grad_vs_fp64(N, H, W, Cin, Cout):
+    lib, check = _lib()
+    g = torch.Generator().manual_seed(N * 5 + H + W + Cout + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    wref = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wref, padding=1).backward(dy.double())
+    ref = wref.grad.permute(0, 2, 3, 1)                                   # [Cout][3][3][Cin]
+    xn = torch.zeros(N, H, W, 4, device="cuda")
+    xn[..., :Cin] = x.permute(0, 2, 3, 1).cuda()
+    dyn = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    assert lib.cvk_thin_wgrad_supported(Cin, 4, Cout, Cout) == 1
+    wsb = lib.cvk_conv3x3_thin_wgrad_workspace_bytes(N, H, W, 4, Cout)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(2):
+        dw = torch.full((Cout, 3, 3, Cin), float("nan"), device="cuda")
+        check(lib.cvk_conv3x3_thin_wgrad(xn.data_ptr(), dyn.data_ptr(), dw.data_ptr(), N, H, W, Cin, 4, Cout, Cout, ws.data_ptr(), wsb, _stream()),
+              "thin wgrad")
+        torch.cuda.synchronize()
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
     got = outs[0].double().cpu()
     rel = ((got - ref).norm() / ref.norm()).item()
     assert rel < 2e-6, rel
