@@ -123,6 +123,9 @@ int cvk_w2d_tpad(int T);                      /* rows per transform plane: T rou
 int cvk_w2d_stat_partials(int N, int H, int W);
 size_t cvk_conv3x3_w2d_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int cvk_w2d_weight_transform(const float* w, float* U, int Cout, int Cin, void* stream);
+/* the data-grad filter float[36][Cin][Cout] straight from the FORWARD weights w [Cout][3][3][Cin] (rotation by 180 degrees and
+ * the channel exchange happen inside; equals cvk_w2d_weight_transform(cvk_pack_weight_dgrad(w)) bit for bit) */
+int cvk_w2d_weight_transform_dgrad(const float* w, float* U, int Cout, int Cin, void* stream);
 int cvk_conv3x3_w2d(const float* x, const float* U, const float* bias, float* y, float* stats, float* counts, int N, int H,
                     int W, int Cin, int Cout, int ldy, void* workspace, size_t workspace_bytes, void* stream);
 /* the three passes of cvk_conv3x3_w2d, callable (and timed) one by one.  V float[36][Tpad][Cin] + 512 bytes of slack,

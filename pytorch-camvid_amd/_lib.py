@@ -75,6 +75,7 @@ SIGNATURES = {
     "cvk_w2d_stat_partials": (c_int, [c_int, c_int, c_int]),
     "cvk_conv3x3_w2d_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
     "cvk_w2d_weight_transform": (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
+    "cvk_w2d_weight_transform_dgrad": (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
     "cvk_w2d_input_transform": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_w2d_gemm": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_wgrad_w2d_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),

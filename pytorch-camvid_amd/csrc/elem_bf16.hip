@@ -219,7 +219,9 @@ __global__ __launch_bounds__(256) void k_bnbwd_bf16(const void* __restrict__ dou
                 k2[j] = use_batch_stats ? dgamma[c + j] * invM : 0.f;
             }
         }
-        for (int m = mbeg + pr; m < mend; m += ppp) {
+#pragma unroll 4
+        for (int m = mbeg + pr; m < mend; m += ppp) {     // four iterations' loads in flight (the sums stay in order): 32 B per
+            // thread and iteration, 4 blocks per CU — one iteration in flight is half the ~64 KiB per CU that 8 TB/s x 2 us asks for
             const FV<V> d = load_any<V, DOUT_F32>(dout, dm.off(m) + c);
             const FV<V> yy = load_bf16<V>(y + (size_t)m * ldy + c);
             FV<V> o;

@@ -125,6 +125,49 @@ __global__ __launch_bounds__(256) void k_w2d_weight(const float* __restrict__ Wt
     }
 }
 
+// ---- data-grad filter straight from the forward weights: U [36][Ci][Co] = G w'[ci][.][.][co] G^T with w'[ci][r][s][co] =
+// w[co][2-r][2-s][ci] (rotated by 180 degrees, channels exchanged) — no packed copy in between.  A workgroup transposes a
+// 32 (co) x 32 (ci) tile of all nine taps through LDS: reads run along ci, writes along co.
+__global__ __launch_bounds__(256) void k_w2d_weight_dgrad(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci) {
+    __shared__ float t[9][32][33];
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    float ld[36];
+#pragma unroll
+    for (int j = 0; j < 36; ++j) {                       // all 36 loads of a thread in flight at once
+        const int e = threadIdx.x + 256 * j;
+        const int ci = e & 31, co = (e >> 5) & 31, tap = e >> 10;
+        ld[j] = (co0 + co < Co && ci0 + ci < Ci) ? Wt[((size_t)(co0 + co) * 9 + tap) * Ci + ci0 + ci] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 36; ++j) {
+        const int e = threadIdx.x + 256 * j;
+        t[e >> 10][(e >> 5) & 31][e & 31] = ld[j];
+    }
+    __syncthreads();
+    const size_t total = (size_t)Co * Ci;
+    for (int p = threadIdx.x; p < 1024; p += 256) {
+        const int co = p & 31, ci = p >> 5;
+        if (co0 + co >= Co || ci0 + ci >= Ci) continue;
+        float a[6][3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {                 // along ky (rotated: kernel row r reads tap row 2 - r)
+            const float col[3] = {t[8 - kx][co][ci], t[5 - kx][co][ci], t[2 - kx][co][ci]};
+            float u[6];
+            w2_g(col, u);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) a[q][kx] = u[q];
+        }
+        const size_t o = (size_t)(ci0 + ci) * Co + co0 + co;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {                    // along kx
+            float u[6];
+            w2_g(a[q], u);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) U[(size_t)(q * 6 + r) * total + o] = u[r];
+        }
+    }
+}
+
 // ---- batched GEMM  D_xi[T][ldd] = A_xi[T][K] * B_xi[Nn][K]^T,  xi = 0..35 ------------------------------------------------------
 // Workgroup: BM x 128 tile, BM/32 waves in a (BM/64) x 2 grid of 64 x 64 wave tiles (2 x 2 MFMA 32x32x2 blocks, 64
 // accumulator registers).  LDS: NSTG stages of (BM + 128) rows x 128 bytes; 16-byte chunk c of row r sits at position
@@ -559,6 +602,12 @@ extern "C" int cvk_w2d_weight_transform(const float* w, float* U, int Cout, int 
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(k_w2d_weight, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
     CVK_LAUNCH_RETURN("cvk_w2d_weight_transform");
+}
+
+extern "C" int cvk_w2d_weight_transform_dgrad(const float* w, float* U, int Cout, int Cin, void* stream) {
+    CVK_CHECK_ARG(w && U && Cout > 0 && Cin > 0, "cvk_w2d_weight_transform_dgrad: bad arguments");
+    hipLaunchKernelGGL(k_w2d_weight_dgrad, dim3(cvk_cdiv(Cin, 32), cvk_cdiv(Cout, 32)), dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
+    CVK_LAUNCH_RETURN("cvk_w2d_weight_transform_dgrad");
 }
 
 extern "C" int cvk_w2d_input_transform(const float* x, float* V, int N, int H, int W, int Cin, void* stream) {

@@ -188,8 +188,13 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
         return R.derived((ck, kind), wsrc, build) if (ck is not None and wsrc is not None) else build()
     if wino2d_ok(k_ch, cout, ldy) and (R.wino2d == "always" or (R.wino2d and wino2d_pays(N, H, W, k_ch, cout))):
         def build_u2():
-            wt = w() if callable(w) else w
             u = _empty(36 * cout * k_ch, x.device)
+            if dgrad_of is not None and dgrad_of[1] == k_ch and dgrad_of[2] == cout:       # no channel padding: straight from the forward weights
+                _timed(R, "k_w2d_weight_dgrad", 4.0 * (9 + 36) * cout * k_ch, lambda: check(
+                    lib.cvk_w2d_weight_transform_dgrad(dgrad_of[0].data_ptr(), u.data_ptr(), dgrad_of[1], dgrad_of[2], s),
+                    "cvk_w2d_weight_transform_dgrad"), "byte")
+                return u
+            wt = w() if callable(w) else w
             _timed(R, "k_w2d_weight", 4.0 * (9 + 36) * cout * k_ch, lambda: check(
                 lib.cvk_w2d_weight_transform(wt.data_ptr(), u.data_ptr(), cout, k_ch, s), "cvk_w2d_weight_transform"), "byte")
             return u

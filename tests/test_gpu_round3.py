@@ -144,3 +144,22 @@ def test_graphed_step_refuses_data_parallel():
     with pytest.raises(RuntimeError, match="eager mode only"):
         A.GraphedStep(net, A.CrossEntropyLoss(), x, t)
     runner_of(net).grad_sync = None
+
+
+@pytest.mark.parametrize("Co,Ci", [(64, 32), (128, 256), (96, 160), (40, 72)])
+def test_w2d_data_grad_filter_straight_from_the_forward_weights(Co, Ci):
+    """cvk_w2d_weight_transform_dgrad(w) == cvk_w2d_weight_transform(cvk_pack_weight_dgrad(w)) bit for bit: the data-grad
+    of nn.Conv2d (backward of train.py:131) uses the 180-degree rotated, channel-exchanged filter; the packed copy is gone."""
+    from pytorch_camvid_amd import _lib
+    lib, check = _lib.load(), _lib.check
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(Co + Ci)
+    w = torch.randn(Co, 3, 3, Ci, generator=g).to(dev())                 # channels_last physical layout of an OIHW parameter
+    packed = torch.empty(Ci, 9, Co, device=dev())
+    check(lib.cvk_pack_weight_dgrad(w.data_ptr(), packed.data_ptr(), Co, Ci, Ci, Co, s), "pack")
+    want = torch.empty(36, Ci, Co, device=dev())
+    check(lib.cvk_w2d_weight_transform(packed.data_ptr(), want.data_ptr(), Ci, Co, s), "transform")
+    got = torch.full((36, Ci, Co), float("nan"), device=dev())
+    check(lib.cvk_w2d_weight_transform_dgrad(w.data_ptr(), got.data_ptr(), Co, Ci, s), "direct")
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
