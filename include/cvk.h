@@ -149,6 +149,27 @@ int cvk_w2d_wgrad_ksplit(int T, int Cin_pad, int Cout);
 int cvk_w2d_dy_transform(const float* dy, int ld_dy, float* E, int N, int H, int W, int Cout, void* stream);
 int cvk_w2d_gemm_tn(const float* E, const float* V, float* P, int T, int Cin_pad, int Cout, void* stream);
 int cvk_w2d_wgrad_output(const float* P, float* dw, int T, int Cin, int Cin_pad, int Cout, void* stream);
+
+/* 2-D Winograd F(6x6,3x3) (csrc/wino2d.hip, the same kernels instantiated for 8x8 input tiles; points 0, +-1, +-2, +-1/2, inf):
+ * 64 batched GEMMs over T = cvk_w6_tiles(N,H,W) 6x6 output tiles — 1.78 multiplies per output and input channel instead of
+ * 2.25, and 1.78x instead of 2.25x the activation in transform-domain planes.  fp32 rounding about twice that of F(4x4,3x3)
+ * (5e-6 relative L2 at 256 input channels).  Every cvk_w6_* entry point has the contract of its cvk_w2d_* namesake with 36 -> 64
+ * planes: U float[64][Cout][Cin], V float[64][Tpad][Cin] (+ 512 bytes), Mo float[f][64][T][Cout], E float[64][Tpad][Cout],
+ * P float[f][64][Cout][Cin_pad]; Tpad = cvk_w2d_tpad(T). */
+int cvk_w6_tiles(int N, int H, int W);
+int cvk_w6_stat_partials(int N, int H, int W);
+size_t cvk_conv3x3_w6_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int cvk_w6_weight_transform(const float* w, float* U, int Cout, int Cin, void* stream);
+int cvk_w6_weight_transform_dgrad(const float* w, float* U, int Cout, int Cin, void* stream);
+int cvk_w6_ksplit(int T, int Cin, int Cout);
+int cvk_w6_input_transform(const float* x, float* V, int N, int H, int W, int Cin, void* stream);
+int cvk_w6_gemm(const float* V, const float* U, float* Mo, int T, int Cin, int Cout, void* stream);
+int cvk_w6_output(const float* Mo, const float* bias, float* y, float* stats, float* counts, int N, int H, int W, int Cin,
+                  int Cout, int ldy, void* stream);
+int cvk_w6_wgrad_ksplit(int T, int Cin_pad, int Cout);
+int cvk_w6_dy_transform(const float* dy, int ld_dy, float* E, int N, int H, int W, int Cout, void* stream);
+int cvk_w6_gemm_tn(const float* E, const float* V, float* P, int T, int Cin_pad, int Cout, void* stream);
+int cvk_w6_wgrad_output(const float* P, float* dw, int T, int Cin, int Cin_pad, int Cout, void* stream);
 /* FUSED 1-D Winograd F(4,3) (csrc/wino4f.hip; replaces nn.Conv2d(cin,cout,3,padding=1) fwd and its data-grad,
  * /root/reference/models/unet.py:11, models/segnet.py:8, for the 64/128-channel levels): one workgroup computes all six
  * transform indices of a 128 x 64 tile, the output transform, bias and BatchNorm statistics happen in registers — no

@@ -72,6 +72,19 @@ SIGNATURES = {
     "cvk_bn_bwd_dx_e6": (c_int, [View, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp,
                                  c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_w2d_tiles": (c_int, [c_int, c_int, c_int]),
+    "cvk_w6_tiles": (c_int, [c_int, c_int, c_int]),
+    "cvk_w6_stat_partials": (c_int, [c_int, c_int, c_int]),
+    "cvk_conv3x3_w6_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
+    "cvk_w6_weight_transform": (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
+    "cvk_w6_weight_transform_dgrad": (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
+    "cvk_w6_input_transform": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_w6_gemm": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "cvk_w6_wgrad_ksplit": (c_int, [c_int, c_int, c_int]),
+    "cvk_w6_dy_transform": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_w6_gemm_tn": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "cvk_w6_wgrad_output": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_w6_ksplit": (c_int, [c_int, c_int, c_int]),
+    "cvk_w6_output": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_w2d_stat_partials": (c_int, [c_int, c_int, c_int]),
     "cvk_conv3x3_w2d_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
     "cvk_w2d_weight_transform": (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),

@@ -55,80 +55,208 @@ __device__ __forceinline__ void w2_g(const float* g, float* u) {
     u[5] = g[2];
 }
 
-// ---- input transform: x [N,H,W,C] -> V [36][T][C], T = N * ceil(H/4) * ceil(W/4); one thread = one tile x 4 channels ----------
+// A (6 x 4) = transpose of A^T above: e0 = d0, e1 = d0+d1+d2+d3, e2 = d0-d1+d2-d3, e3 = d0+2d1+4d2+8d3, e4 = d0-2d1+4d2-8d3, e5 = d3
+template <typename T>
+__device__ __forceinline__ void w2_a(const T* d, T* e) {
+    const T s02 = d[0] + d[2], s13 = d[1] + d[3], t02 = d[0] + 4.f * d[2], t13 = 2.f * d[1] + 8.f * d[3];
+    e[0] = d[0];
+    e[1] = s02 + s13;
+    e[2] = s02 - s13;
+    e[3] = t02 + t13;
+    e[4] = t02 - t13;
+    e[5] = d[3];
+}
+
+// ---- F(6x6, 3x3): points 0, +-1, +-2, +-1/2, inf (Lavin & Gray) — 64 products per 36 outputs = 1.78 multiplies per output and
+// input channel (F(4x4): 2.25), and 1.78x instead of 2.25x the activation in transform-domain planes.  Rounding in fp32: ~2x
+// that of F(4x4,3x3) (2.7e-6 / 5.1e-6 relative L2 at 64 / 256 input channels against 1.4e-6 / 2.7e-6, numpy restatement).
+// B^T d (8 -> 8)
+template <typename T>
+__device__ __forceinline__ void w6_bt(const T* d, T* v) {
+    v[0] = d[0] - d[6] + 5.25f * (d[4] - d[2]);
+    v[7] = d[7] - d[1] + 5.25f * (d[3] - d[5]);
+    const T a1 = d[2] + d[6] - 4.25f * d[4], b1 = d[1] + d[5] - 4.25f * d[3];
+    v[1] = a1 + b1;
+    v[2] = a1 - b1;
+    const T a2 = d[6] + 0.25f * d[2] - 1.25f * d[4], b2 = 0.5f * d[1] - 2.5f * d[3] + 2.f * d[5];
+    v[3] = a2 + b2;
+    v[4] = a2 - b2;
+    const T a3 = d[6] + 4.f * d[2] - 5.f * d[4], b3 = 2.f * d[1] - 2.5f * d[3] + 0.5f * d[5];
+    v[5] = a3 + b3;
+    v[6] = a3 - b3;
+}
+// A^T m (8 -> 6)
+template <typename T>
+__device__ __forceinline__ void w6_at(const T* m, T* y) {
+    const T s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4], s56 = m[5] + m[6], d56 = m[5] - m[6];
+    y[0] = m[0] + s12 + s34 + s56;
+    y[1] = d12 + 2.f * d34 + 0.5f * d56;
+    y[2] = s12 + 4.f * s34 + 0.25f * s56;
+    y[3] = d12 + 8.f * d34 + 0.125f * d56;
+    y[4] = s12 + 16.f * s34 + 0.0625f * s56;
+    y[5] = d12 + 32.f * d34 + 0.03125f * d56 + m[7];
+}
+// G g (3 -> 8)
+__device__ __forceinline__ void w6_g(const float* g, float* u) {
+    const float t = g[0] + g[2];
+    u[0] = g[0];
+    u[1] = (-2.f / 9.f) * (t + g[1]);
+    u[2] = (-2.f / 9.f) * (t - g[1]);
+    const float q = (1.f / 90.f) * g[0] + (2.f / 45.f) * g[2];
+    u[3] = q + (1.f / 45.f) * g[1];
+    u[4] = q - (1.f / 45.f) * g[1];
+    const float r = (32.f / 45.f) * g[0] + (8.f / 45.f) * g[2];
+    u[5] = r + (16.f / 45.f) * g[1];
+    u[6] = r - (16.f / 45.f) * g[1];
+    u[7] = g[2];
+}
+// A d (6 -> 8): the transpose of the output transform (weight-grad: dy tiles)
+template <typename T>
+__device__ __forceinline__ void w6_a(const T* d, T* e) {
+    const T ev = d[0] + d[2] + d[4], od = d[1] + d[3] + d[5];
+    e[0] = d[0];
+    e[1] = ev + od;
+    e[2] = ev - od;
+    const T ev2 = d[0] + 4.f * d[2] + 16.f * d[4], od2 = 2.f * d[1] + 8.f * d[3] + 32.f * d[5];
+    e[3] = ev2 + od2;
+    e[4] = ev2 - od2;
+    const T ev3 = d[0] + 0.25f * d[2] + 0.0625f * d[4], od3 = 0.5f * d[1] + 0.125f * d[3] + 0.03125f * d[5];
+    e[5] = ev3 + od3;
+    e[6] = ev3 - od3;
+    e[7] = d[5];
+}
+// G^T p (8 -> 3)
+__device__ __forceinline__ void w6_gt(const float* p, float* w) {
+    const float s12 = p[1] + p[2], d12 = p[1] - p[2], s34 = p[3] + p[4], d34 = p[3] - p[4], s56 = p[5] + p[6], d56 = p[5] - p[6];
+    w[0] = p[0] - (2.f / 9.f) * s12 + (1.f / 90.f) * s34 + (32.f / 45.f) * s56;
+    w[1] = -(2.f / 9.f) * d12 + (1.f / 45.f) * d34 + (16.f / 45.f) * d56;
+    w[2] = -(2.f / 9.f) * s12 + (2.f / 45.f) * s34 + (8.f / 45.f) * s56 + p[7];
+}
+// G^T p (6 -> 3) of F(4,3)
+__device__ __forceinline__ void w2_gt(const float* m, float* w) {
+    const float s12 = m[1] + m[2], d12 = m[2] - m[1], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    w[0] = 0.25f * m[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+    w[1] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+    w[2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + m[5];
+}
+
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+// Tile traits: MT x MT outputs per tile, NT = MT + 2 points per dimension, NX = NT^2 transform indices (= batched GEMMs); VT = the
+// channel vector one thread of a transform kernel owns (a whole tile lives in its registers: 36 x 4 or 64 x 2 floats).
+template <int MT> struct W2T;
+template <> struct W2T<4> {
+    static constexpr int NT = 6, NX = 36, VW = 4;
+    typedef f32x4 VT;
+    template <typename T> static __device__ __forceinline__ void bt(const T* d, T* v) { w2_bt(d, v); }
+    template <typename T> static __device__ __forceinline__ void a(const T* d, T* e) { w2_a(d, e); }
+    static __device__ __forceinline__ void g(const float* x, float* u) { w2_g(x, u); }
+    static __device__ __forceinline__ void gt(const float* x, float* w) { w2_gt(x, w); }
+    // A^T[row][col]
+    static __device__ __forceinline__ constexpr float at(int r, int c) {
+        return c == 0 ? (r == 0 ? 1.f : 0.f) : c == 5 ? (r == 3 ? 1.f : 0.f)
+             : c == 1 ? 1.f : c == 2 ? ((r & 1) ? -1.f : 1.f)
+             : c == 3 ? (float)(1 << r) : ((r & 1) ? -(float)(1 << r) : (float)(1 << r));
+    }
+};
+template <> struct W2T<6> {
+    static constexpr int NT = 8, NX = 64, VW = 2;
+    typedef f32x2v VT;
+    template <typename T> static __device__ __forceinline__ void bt(const T* d, T* v) { w6_bt(d, v); }
+    template <typename T> static __device__ __forceinline__ void a(const T* d, T* e) { w6_a(d, e); }
+    static __device__ __forceinline__ void g(const float* x, float* u) { w6_g(x, u); }
+    static __device__ __forceinline__ void gt(const float* x, float* w) { w6_gt(x, w); }
+    static __device__ __forceinline__ constexpr float at(int r, int c) {
+        return c == 0 ? (r == 0 ? 1.f : 0.f) : c == 7 ? (r == 5 ? 1.f : 0.f)
+             : c == 1 ? 1.f : c == 2 ? ((r & 1) ? -1.f : 1.f)
+             : c == 3 ? (float)(1 << r) : c == 4 ? ((r & 1) ? -(float)(1 << r) : (float)(1 << r))
+             : c == 5 ? 1.f / (float)(1 << r) : ((r & 1) ? -1.f / (float)(1 << r) : 1.f / (float)(1 << r));
+    }
+};
+
+// ---- input transform: x [N,H,W,C] -> V [NX][T][C], T = N * ceil(H/MT) * ceil(W/MT); one thread = one tile x VW channels ------
 // Rows T <= t < Tpad (weight-grad: the tile index is the GEMM depth, padded to whole K slices) are written as zeros.
+template <int MT>
 __global__ __launch_bounds__(256) void k_w2d_input(const float* __restrict__ X, float* __restrict__ V, int H, int W, int C,
                                                   int th, int tw, int T, int Tpad) {
-    const int cvn = C >> 2;
+    typedef W2T<MT> TR;
+    typedef typename TR::VT VT;
+    constexpr int NT = TR::NT, NX = TR::NX, VW = TR::VW;
+    const int cvn = C / VW;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const int t = (int)(idx / cvn), c = (int)(idx % cvn) * 4;
+    const int t = (int)(idx / cvn), c = (int)(idx % cvn) * VW;
     if (t >= Tpad) return;
+    const VT zero = {};
     if (t >= T) {
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        for (int xi = 0; xi < 36; ++xi) *reinterpret_cast<f32x4*>(V + ((size_t)xi * Tpad + t) * C + c) = zero;
+        for (int xi = 0; xi < NX; ++xi) *reinterpret_cast<VT*>(V + ((size_t)xi * Tpad + t) * C + c) = zero;
         return;
     }
     const int n = t / (th * tw), r = t - n * th * tw, ty = r / tw, tx = r - ty * tw;
-    const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+    const int y0 = MT * ty - 1, x0 = MT * tx - 1;
     const float* const xb = X + (size_t)n * H * W * C + c;
-    f32x4 w[6][6];
+    VT w[NT][NT];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        f32x4 d[6], v[6];
+    for (int j = 0; j < NT; ++j) {
+        VT d[NT], v[NT];
         const int xx = x0 + j;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < NT; ++i) {
             const int yy = y0 + i;
             const bool ok = ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            d[i] = ok ? *reinterpret_cast<const f32x4*>(xb + ((size_t)yy * W + xx) * C) : zero;
+            d[i] = ok ? *reinterpret_cast<const VT*>(xb + ((size_t)yy * W + xx) * C) : zero;
         }
-        w2_bt(d, v);
+        TR::bt(d, v);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) w[i][j] = v[i];
+        for (int i = 0; i < NT; ++i) w[i][j] = v[i];
     }
     const size_t plane = (size_t)Tpad * C;
     float* const vb = V + (size_t)t * C + c;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        f32x4 v[6];
-        w2_bt(w[i], v);
+    for (int i = 0; i < NT; ++i) {
+        VT v[NT];
+        TR::bt(w[i], v);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(vb + (size_t)(i * 6 + j) * plane) = v[j];
+        for (int j = 0; j < NT; ++j) *reinterpret_cast<VT*>(vb + (size_t)(i * NT + j) * plane) = v[j];
     }
 }
 
-// ---- weight transform: w [Co][3][3][Ci] -> U [36][Co][Ci]; one thread = one (co, ci) --------------------------------------------
+// ---- weight transform: w [Co][3][3][Ci] -> U [NX][Co][Ci]; one thread = one (co, ci) --------------------------------------------
+template <int MT>
 __global__ __launch_bounds__(256) void k_w2d_weight(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci) {
+    typedef W2T<MT> TR;
+    constexpr int NT = TR::NT;
     const size_t total = (size_t)Co * Ci;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int ci = (int)(i % Ci);
         const size_t co = i / Ci;
-        float g[3][3], a[6][3];
+        float g[3][3], a[NT][3];
 #pragma unroll
         for (int k = 0; k < 9; ++k) g[k / 3][k % 3] = Wt[(co * 9 + k) * Ci + ci];
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {                 // along ky
             const float col[3] = {g[0][kx], g[1][kx], g[2][kx]};
-            float u[6];
-            w2_g(col, u);
+            float u[NT];
+            TR::g(col, u);
 #pragma unroll
-            for (int p = 0; p < 6; ++p) a[p][kx] = u[p];
+            for (int p = 0; p < NT; ++p) a[p][kx] = u[p];
         }
 #pragma unroll
-        for (int p = 0; p < 6; ++p) {                    // along kx
-            float u[6];
-            w2_g(a[p], u);
+        for (int p = 0; p < NT; ++p) {                   // along kx
+            float u[NT];
+            TR::g(a[p], u);
 #pragma unroll
-            for (int q = 0; q < 6; ++q) U[(size_t)(p * 6 + q) * total + i] = u[q];
+            for (int q = 0; q < NT; ++q) U[(size_t)(p * NT + q) * total + i] = u[q];
         }
     }
 }
 
-// ---- data-grad filter straight from the forward weights: U [36][Ci][Co] = G w'[ci][.][.][co] G^T with w'[ci][r][s][co] =
+// ---- data-grad filter straight from the forward weights: U [NX][Ci][Co] = G w'[ci][.][.][co] G^T with w'[ci][r][s][co] =
 // w[co][2-r][2-s][ci] (rotated by 180 degrees, channels exchanged) — no packed copy in between.  A workgroup transposes a
 // 32 (co) x 32 (ci) tile of all nine taps through LDS: reads run along ci, writes along co.
+template <int MT>
 __global__ __launch_bounds__(256) void k_w2d_weight_dgrad(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci) {
+    typedef W2T<MT> TR;
+    constexpr int NT = TR::NT;
     __shared__ float t[9][32][33];
     const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
     float ld[36];
@@ -148,22 +276,22 @@ __global__ __launch_bounds__(256) void k_w2d_weight_dgrad(const float* __restric
     for (int p = threadIdx.x; p < 1024; p += 256) {
         const int co = p & 31, ci = p >> 5;
         if (co0 + co >= Co || ci0 + ci >= Ci) continue;
-        float a[6][3];
+        float a[NT][3];
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {                 // along ky (rotated: kernel row r reads tap row 2 - r)
             const float col[3] = {t[8 - kx][co][ci], t[5 - kx][co][ci], t[2 - kx][co][ci]};
-            float u[6];
-            w2_g(col, u);
+            float u[NT];
+            TR::g(col, u);
 #pragma unroll
-            for (int q = 0; q < 6; ++q) a[q][kx] = u[q];
+            for (int q = 0; q < NT; ++q) a[q][kx] = u[q];
         }
         const size_t o = (size_t)(ci0 + ci) * Co + co0 + co;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {                    // along kx
-            float u[6];
-            w2_g(a[q], u);
+        for (int q = 0; q < NT; ++q) {                   // along kx
+            float u[NT];
+            TR::g(a[q], u);
 #pragma unroll
-            for (int r = 0; r < 6; ++r) U[(size_t)(q * 6 + r) * total + o] = u[r];
+            for (int r = 0; r < NT; ++r) U[(size_t)(q * NT + r) * total + o] = u[r];
         }
     }
 }
@@ -292,54 +420,46 @@ __global__ __launch_bounds__(BM * 2, WPS) void k_w2d_gemm(const float* __restric
 // ================================================================================================ weight-grad
 // dW = G^T [ sum_tiles (A dy A^T) (.) (B^T x B) ] G:  per transform index one GEMM  P_xi[Cout][Cin] = E_xi^T V_xi  whose depth
 // is the tile index (reference: the weight gradient of nn.Conv2d, bwd of train.py:131).
-// A (6 x 4) = transpose of A^T above: e0 = d0, e1 = d0+d1+d2+d3, e2 = d0-d1+d2-d3, e3 = d0+2d1+4d2+8d3, e4 = d0-2d1+4d2-8d3, e5 = d3
-template <typename T>
-__device__ __forceinline__ void w2_a(const T* d, T* e) {
-    const T s02 = d[0] + d[2], s13 = d[1] + d[3], t02 = d[0] + 4.f * d[2], t13 = 2.f * d[1] + 8.f * d[3];
-    e[0] = d[0];
-    e[1] = s02 + s13;
-    e[2] = s02 - s13;
-    e[3] = t02 + t13;
-    e[4] = t02 - t13;
-    e[5] = d[3];
-}
-
-// dy [N,H,W,ld] -> E [36][Tpad][C]; one thread = one 4 x 4 tile x 4 channels (pixels beyond the frame count as zero)
+// dy [N,H,W,ld] -> E [NX][Tpad][C]; one thread = one MT x MT tile x VW channels (pixels beyond the frame count as zero)
+template <int MT>
 __global__ __launch_bounds__(256) void k_w2d_dy(const float* __restrict__ DY, int ld, float* __restrict__ E, int H, int W, int C,
                                                int th, int tw, int T, int Tpad) {
-    const int cvn = C >> 2;
+    typedef W2T<MT> TR;
+    typedef typename TR::VT VT;
+    constexpr int NT = TR::NT, NX = TR::NX, VW = TR::VW;
+    const int cvn = C / VW;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const int t = (int)(idx / cvn), c = (int)(idx % cvn) * 4;
+    const int t = (int)(idx / cvn), c = (int)(idx % cvn) * VW;
     if (t >= Tpad) return;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const VT zero = {};
     const size_t plane = (size_t)Tpad * C;
     float* const eb = E + (size_t)t * C + c;
     if (t >= T) {
-        for (int xi = 0; xi < 36; ++xi) *reinterpret_cast<f32x4*>(eb + (size_t)xi * plane) = zero;
+        for (int xi = 0; xi < NX; ++xi) *reinterpret_cast<VT*>(eb + (size_t)xi * plane) = zero;
         return;
     }
     const int n = t / (th * tw), r = t - n * th * tw, ty = r / tw, tx = r - ty * tw;
     const float* const db = DY + (size_t)n * H * W * ld + c;
-    f32x4 w[6][4];
+    VT w[NT][MT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f32x4 d[4], e[6];
-        const int xx = 4 * tx + j;
+    for (int j = 0; j < MT; ++j) {
+        VT d[MT], e[NT];
+        const int xx = MT * tx + j;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int yy = 4 * ty + i;
-            d[i] = (yy < H && xx < W) ? *reinterpret_cast<const f32x4*>(db + ((size_t)yy * W + xx) * ld) : zero;
+        for (int i = 0; i < MT; ++i) {
+            const int yy = MT * ty + i;
+            d[i] = (yy < H && xx < W) ? *reinterpret_cast<const VT*>(db + ((size_t)yy * W + xx) * ld) : zero;
         }
-        w2_a(d, e);
+        TR::a(d, e);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) w[i][j] = e[i];
+        for (int i = 0; i < NT; ++i) w[i][j] = e[i];
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        f32x4 e[6];
-        w2_a(w[i], e);
+    for (int i = 0; i < NT; ++i) {
+        VT e[NT];
+        TR::a(w[i], e);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(eb + (size_t)(i * 6 + j) * plane) = e[j];
+        for (int j = 0; j < NT; ++j) *reinterpret_cast<VT*>(eb + (size_t)(i * NT + j) * plane) = e[j];
     }
 }
 
@@ -352,7 +472,7 @@ __global__ __launch_bounds__(256) void k_w2d_dy(const float* __restrict__ DY, in
 // 36 * tiles workgroups alone would not fill the chip; the planes are added by k_w2d_wgrad_out in a fixed order.
 __global__ __launch_bounds__(256, 2) void k_w2d_gemm_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                        float* __restrict__ D, int Kp, int Mm, int Nn, int tilesM, int tilesN,
-                                                       int f) {
+                                                       int f, int NX) {
     constexpr int STAGE = 32 * 256 * 4, PPW = 8;        // 32 KiB per stage: depth rows [k][A 128 | B 128]... kept as two 16 KiB halves
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
     const unsigned smem_addr = cvk_lds_addr(smem);
@@ -366,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void k_w2d_gemm_tn(const float* __restrict_
     const int nK = Kp / 32, kb = part * nK / f, ke = (part + 1) * nK / f;
     A += (size_t)xi * Kp * lda + tm * 128;
     B += (size_t)xi * Kp * ldb + tn * 128;
-    D += ((size_t)part * 36 + xi) * Mm * Nn;
+    D += ((size_t)part * NX + xi) * Mm * Nn;
 
     // DMA: piece p = wave*8 + q; pieces 0..15 = A depth rows 2p, 2p+1 (LDS bytes [0, 16 KiB)), 16..31 = B (LDS [16, 32 KiB));
     // lane = depth row lane/32 of the pair, floats 4*(lane%32) .. +3 of the 128.  Columns beyond the matrix read the
@@ -427,59 +547,62 @@ __global__ __launch_bounds__(256, 2) void k_w2d_gemm_tn(const float* __restrict_
         }
 }
 
-// dw [Co][3][3][Ci] = G^T (sum of the f planes of P [36][Co][Cip]) G; one thread = one (co, ci)
+// dw [Co][3][3][Ci] = G^T (sum of the f planes of P [NX][Co][Cip]) G; one thread = one (co, ci)
+template <int MT>
 __global__ __launch_bounds__(256) void k_w2d_wgrad_out(const float* __restrict__ P, float* __restrict__ dw, int Co, int Ci, int Cip, int f) {
+    typedef W2T<MT> TR;
+    constexpr int NT = TR::NT, NX = TR::NX;
     const size_t total = (size_t)Co * Ci, plane = (size_t)Co * Cip;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int ci = (int)(idx % Ci);
         const size_t co = idx / Ci;
         const float* const pp = P + co * Cip + ci;
-        // all 36 values of a plane are loaded before they are added to the running sums: 36 independent loads in flight per
+        // all NX values of a plane are loaded before they are added to the running sums: NX independent loads in flight per
         // plane (a per-element loop over the planes left one dependent load chain per thread: 0.28 of the HBM rate)
-        float m36[36];
+        float mx[NX];
 #pragma unroll
-        for (int q = 0; q < 36; ++q) m36[q] = pp[(size_t)q * plane];
+        for (int q = 0; q < NX; ++q) mx[q] = pp[(size_t)q * plane];
         for (int k = 1; k < f; ++k) {
-            float v[36];
+            float v[NX];
 #pragma unroll
-            for (int q = 0; q < 36; ++q) v[q] = pp[(size_t)(k * 36 + q) * plane];
+            for (int q = 0; q < NX; ++q) v[q] = pp[(size_t)(k * NX + q) * plane];
 #pragma unroll
-            for (int q = 0; q < 36; ++q) m36[q] += v[q];
+            for (int q = 0; q < NX; ++q) mx[q] += v[q];
         }
-        float t[6][3];          // rows a of P, transformed along b
+        float t[NT][3];         // rows a of P, transformed along b
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            const float* const m = m36 + a * 6;
-            const float s12 = m[1] + m[2], d12 = m[2] - m[1], s34 = m[3] + m[4], d34 = m[3] - m[4];
-            t[a][0] = 0.25f * m[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
-            t[a][1] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
-            t[a][2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + m[5];
-        }
+        for (int a = 0; a < NT; ++a) TR::gt(mx + a * NT, t[a]);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const float s12 = t[1][kx] + t[2][kx], d12 = t[2][kx] - t[1][kx], s34 = t[3][kx] + t[4][kx], d34 = t[3][kx] - t[4][kx];
-            dw[(co * 9 + 0 + kx) * Ci + ci] = 0.25f * t[0][kx] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
-            dw[(co * 9 + 3 + kx) * Ci + ci] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
-            dw[(co * 9 + 6 + kx) * Ci + ci] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + t[5][kx];
+            float col[NT], w3[3];
+#pragma unroll
+            for (int a = 0; a < NT; ++a) col[a] = t[a][kx];
+            TR::gt(col, w3);
+            dw[(co * 9 + 0 + kx) * Ci + ci] = w3[0];
+            dw[(co * 9 + 3 + kx) * Ci + ci] = w3[1];
+            dw[(co * 9 + 6 + kx) * Ci + ci] = w3[2];
         }
     }
 }
 
-// ---- output transform: M [36][T][ldm] -> y [N,H,W,ldy] (+bias, + BatchNorm statistics partials with pixel counts) ----------------
-// block = w2_tb(T) tiles x CH channels (CH = 4 * cvn <= 256); thread = one channel vector, tiles pl apart
-template <bool STATS>
+// ---- output transform: M [NX][T][ldm] -> y [N,H,W,ldy] (+bias, + BatchNorm statistics partials with pixel counts) ----------------
+// block = w2_tb(T) tiles x CH channels (CH = VW * cvn <= 256); thread = one channel vector, tiles pl apart
+template <int MT, bool STATS>
 __global__ __launch_bounds__(256) void k_w2d_output(const float* __restrict__ Mo, int ldm, const float* __restrict__ bias,
                                                    float* __restrict__ Y, int ldy, float* __restrict__ stats,
                                                    float* __restrict__ counts, int P, int H, int W, int th, int tw, int T,
                                                    int Cout, int cvn, int BM, int tmn, int tilesN, int split_start, int f) {
-    __shared__ float red[2][1024];
+    typedef W2T<MT> TR;
+    typedef typename TR::VT VT;
+    constexpr int NT = TR::NT, NX = TR::NX, VW = TR::VW;
+    __shared__ float red[2][256 * VW];
     const int t = threadIdx.x;
     const int pl = 256 / cvn, cv = t % cvn, lanep = t / cvn;
-    const int c = (blockIdx.y * cvn + cv) * 4;
+    const int c = (blockIdx.y * cvn + cv) * VW;
     const bool cok = c < Cout;                          // Cout % 4 == 0 (checked by the host)
-    f32x4 sh = {0.f, 0.f, 0.f, 0.f};
-    if (cok && bias != nullptr) sh = *reinterpret_cast<const f32x4*>(bias + c);
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    VT sh = {};
+    if (cok && bias != nullptr) sh = *reinterpret_cast<const VT*>(bias + c);
+    VT s1 = {}, s2 = {};
     const size_t plane = (size_t)T * ldm;
     const int TB = w2_tb(T);
     const int tile_end = min(T, (int)(blockIdx.x + 1) * TB);
@@ -487,38 +610,52 @@ __global__ __launch_bounds__(256) void k_w2d_output(const float* __restrict__ Mo
         const int n = tile / (th * tw), rr = tile - n * th * tw, ty = rr / tw, tx = rr - ty * tw;
         const float* const mp = Mo + (size_t)tile * ldm + c;
         // GEMM tile of plane xi: xi * tmn + (tile / BM) * tilesN + c / 128; ids >= split_start carry f K-range planes
-        const int xi0 = f > 1 ? (split_start - ((tile / BM) * tilesN + c / W2_BN) + tmn - 1) / tmn : 36;
-        // column j of the 6 x 6 product tile: A^T along the rows, then its contribution to the four output columns
-        // (A^T[.][j] = 1,0,0,0 | 1,1,1,1 | 1,-1,1,-1 | 1,2,4,8 | 1,-2,4,-8 | 0,0,0,1): 16 accumulators instead of a 4 x 6 array,
-        // (forcing <= 128 registers through launch bounds made hipcc spill: 4x slower; it hoists all 36 loads at 215-230)
-        f32x4 o[4][4];
+        const int xi0 = f > 1 ? (split_start - ((tile / BM) * tilesN + c / W2_BN) + tmn - 1) / tmn : NX;
+        // column j of the NT x NT product tile: A^T along the rows, then its contribution A^T[.][j] to the MT output columns:
+        // MT x MT accumulators instead of an MT x NT array
+        // (F(4x4) with float4: forcing <= 128 registers through launch bounds made hipcc spill: 4x slower; it hoists all loads at 215-230)
+        VT o[MT][MT];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            f32x4 m[6], z[4];
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                m[i] = *reinterpret_cast<const f32x4*>(mp + (size_t)(i * 6 + j) * plane);
-                if (i * 6 + j >= xi0)
-                    for (int k = 1; k < f; ++k) m[i] += *reinterpret_cast<const f32x4*>(mp + (size_t)(k * 36 + i * 6 + j) * plane);
+            for (int jj = 0; jj < MT; ++jj) o[i][jj] = VT{};
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            VT m[NT], z[MT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                m[i] = *reinterpret_cast<const VT*>(mp + (size_t)(i * NT + j) * plane);
+                if (i * NT + j >= xi0)
+                    for (int k = 1; k < f; ++k) m[i] += *reinterpret_cast<const VT*>(mp + (size_t)(k * NX + i * NT + j) * plane);
             }
-            w2_at(m, z);
+            if constexpr (MT == 4) {
+                w2_at(m, z);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (j == 0) { o[i][0] = z[i]; }
-                else if (j == 1) { o[i][0] += z[i]; o[i][1] = z[i]; o[i][2] = z[i]; o[i][3] = z[i]; }
-                else if (j == 2) { o[i][0] += z[i]; o[i][1] -= z[i]; o[i][2] += z[i]; o[i][3] -= z[i]; }
-                else if (j == 3) { o[i][0] += z[i]; o[i][1] += 2.f * z[i]; o[i][2] += 4.f * z[i]; o[i][3] += 8.f * z[i]; }
-                else if (j == 4) { o[i][0] += z[i]; o[i][1] -= 2.f * z[i]; o[i][2] += 4.f * z[i]; o[i][3] -= 8.f * z[i]; }
-                else { o[i][3] += z[i]; }
+                for (int i = 0; i < 4; ++i) {
+                    if (j == 0) { o[i][0] = z[i]; }
+                    else if (j == 1) { o[i][0] += z[i]; o[i][1] = z[i]; o[i][2] = z[i]; o[i][3] = z[i]; }
+                    else if (j == 2) { o[i][0] += z[i]; o[i][1] -= z[i]; o[i][2] += z[i]; o[i][3] -= z[i]; }
+                    else if (j == 3) { o[i][0] += z[i]; o[i][1] += 2.f * z[i]; o[i][2] += 4.f * z[i]; o[i][3] += 8.f * z[i]; }
+                    else if (j == 4) { o[i][0] += z[i]; o[i][1] -= 2.f * z[i]; o[i][2] += 4.f * z[i]; o[i][3] -= 8.f * z[i]; }
+                    else { o[i][3] += z[i]; }
+                }
+            } else {
+                w6_at(m, z);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < MT; ++jj) {
+                        if (TR::at(jj, j) != 0.f) o[i][jj] += TR::at(jj, j) * z[i];      // folds after unrolling
+                    }
             }
         }
-        const int yb = 4 * ty, xb = 4 * tx;
+        const int yb = MT * ty, xb = MT * tx;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MT; ++i) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < MT; ++j) {
                 if (yb + i < H && xb + j < W) {
-                    *reinterpret_cast<f32x4*>(Y + ((size_t)(n * H + yb + i) * W + xb + j) * ldy + c) = o[i][j] + sh;
+                    *reinterpret_cast<VT*>(Y + ((size_t)(n * H + yb + i) * W + xb + j) * ldy + c) = o[i][j] + sh;
                     if (STATS) { s1 += o[i][j]; s2 += o[i][j] * o[i][j]; }
                 }
             }
@@ -526,23 +663,23 @@ __global__ __launch_bounds__(256) void k_w2d_output(const float* __restrict__ Mo
     }
     if (!STATS) return;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        red[0][t * 4 + j] = s1[j];
-        red[1][t * 4 + j] = s2[j];
+    for (int j = 0; j < VW; ++j) {
+        red[0][t * VW + j] = s1[j];
+        red[1][t * VW + j] = s2[j];
     }
     __syncthreads();
     if (t < cvn && c < Cout) {
         int cnt = 0;
         for (int tile = blockIdx.x * TB; tile < tile_end; ++tile) {
             const int rr = tile % (th * tw), ty = rr / tw, tx = rr - ty * tw;
-            cnt += min(4, H - 4 * ty) * min(4, W - 4 * tx);
+            cnt += min(MT, H - MT * ty) * min(MT, W - MT * tx);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < VW; ++j) {
             float a = 0.f, b = 0.f;
             for (int p = 0; p < pl; ++p) {
-                a += red[0][(p * cvn + t) * 4 + j];
-                b += red[1][(p * cvn + t) * 4 + j];
+                a += red[0][(p * cvn + t) * VW + j];
+                b += red[1][(p * cvn + t) * VW + j];
             }
             const float m2 = b - a * a / (float)cnt;     // about the partial mean; sums exclude the bias (shift invariance)
             stats[(size_t)blockIdx.x * Cout + c + j] = a + (float)cnt * sh[j];
@@ -552,22 +689,19 @@ __global__ __launch_bounds__(256) void k_w2d_output(const float* __restrict__ Mo
     }
 }
 
-inline int w2_tiles(int N, int H, int W) { return N * ((H + 3) / 4) * ((W + 3) / 4); }
+inline int w2_tiles(int mt, int N, int H, int W) { return N * ((H + mt - 1) / mt) * ((W + mt - 1) / mt); }
+inline int w2_nx(int mt) { return (mt + 2) * (mt + 2); }
 
 }  // namespace
 
-extern "C" int cvk_w2d_tiles(int N, int H, int W) { return (N > 0 && H > 0 && W > 0) ? w2_tiles(N, H, W) : 0; }
-
-extern "C" int cvk_w2d_stat_partials(int N, int H, int W) { return (N > 0 && H > 0 && W > 0) ? cvk_cdiv(w2_tiles(N, H, W), w2_tb(w2_tiles(N, H, W))) : 0; }
-
-// How the 36 GEMMs are cut into workgroups: tile height, grid, and the K split of the last partial round.
+// How the NX GEMMs are cut into workgroups: tile height, grid, and the K split of the last partial round.
 struct W2Plan { int BM, tilesM, tilesN, NT, split_start, f; };
-static W2Plan plan_w2d(int T, int Cin, int Cout) {
+static W2Plan plan_w2d(int nx, int T, int Cin, int Cout) {
     W2Plan p;
     p.BM = 128;
     p.tilesM = cvk_cdiv(T, p.BM);
     p.tilesN = cvk_cdiv(Cout, W2_BN);
-    p.NT = 36 * p.tilesM * p.tilesN;
+    p.NT = nx * p.tilesM * p.tilesN;
     const int slots = 512;                                // resident workgroups: two per CU
     const int nK = Cin / 32;
     const int full = p.NT / slots * slots, R = p.NT - full;
@@ -581,52 +715,67 @@ static W2Plan plan_w2d(int T, int Cin, int Cout) {
     return p;
 }
 
-extern "C" int cvk_w2d_ksplit(int T, int Cin, int Cout) {
-    if (T <= 0 || Cin < 32 || Cout <= 0) return 0;
-    return plan_w2d(T, Cin, Cout).f;
-}
-
 static inline int w2_tpad(int T) { return cvk_cdiv(T, 32) * 32; }
 
 extern "C" int cvk_w2d_tpad(int T) { return T > 0 ? w2_tpad(T) : 0; }
 
-extern "C" size_t cvk_conv3x3_w2d_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
-    if (N <= 0 || H <= 0 || W <= 0 || Cin < 32 || Cout <= 0) return 0;
-    const int T = w2_tiles(N, H, W);
-    return ((size_t)36 * w2_tpad(T) * Cin + 128 + (size_t)36 * T * plan_w2d(T, Cin, Cout).f * Cout) * sizeof(float);
+// ---- implementations, mt = 4: F(4x4,3x3) (cvk_w2d_*), mt = 6: F(6x6,3x3) (cvk_w6_*) ------------------------------------------
+static int w2i_tiles(int mt, int N, int H, int W) { return (N > 0 && H > 0 && W > 0) ? w2_tiles(mt, N, H, W) : 0; }
+
+static int w2i_stat_partials(int mt, int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    const int T = w2_tiles(mt, N, H, W);
+    return cvk_cdiv(T, w2_tb(T));
 }
 
-extern "C" int cvk_w2d_weight_transform(const float* w, float* U, int Cout, int Cin, void* stream) {
-    CVK_CHECK_ARG(w && U && Cout > 0 && Cin > 0, "cvk_w2d_weight_transform: bad arguments");
+static int w2i_ksplit(int mt, int T, int Cin, int Cout) {
+    if (T <= 0 || Cin < 32 || Cout <= 0) return 0;
+    return plan_w2d(w2_nx(mt), T, Cin, Cout).f;
+}
+
+static size_t w2i_workspace_bytes(int mt, int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin < 32 || Cout <= 0) return 0;
+    const int T = w2_tiles(mt, N, H, W), nx = w2_nx(mt);
+    return ((size_t)nx * w2_tpad(T) * Cin + 128 + (size_t)nx * T * plan_w2d(nx, T, Cin, Cout).f * Cout) * sizeof(float);
+}
+
+static int w2i_weight_transform(int mt, const char* who, const float* w, float* U, int Cout, int Cin, void* stream) {
+    CVK_CHECK_ARG(w && U && Cout > 0 && Cin > 0, "%s: bad arguments", who);
     const size_t total = (size_t)Cout * Cin;
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(k_w2d_weight, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
-    CVK_LAUNCH_RETURN("cvk_w2d_weight_transform");
+    if (mt == 4) hipLaunchKernelGGL(k_w2d_weight<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
+    else hipLaunchKernelGGL(k_w2d_weight<6>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
+    CVK_LAUNCH_RETURN(who);
 }
 
-extern "C" int cvk_w2d_weight_transform_dgrad(const float* w, float* U, int Cout, int Cin, void* stream) {
-    CVK_CHECK_ARG(w && U && Cout > 0 && Cin > 0, "cvk_w2d_weight_transform_dgrad: bad arguments");
-    hipLaunchKernelGGL(k_w2d_weight_dgrad, dim3(cvk_cdiv(Cin, 32), cvk_cdiv(Cout, 32)), dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
-    CVK_LAUNCH_RETURN("cvk_w2d_weight_transform_dgrad");
+static int w2i_weight_transform_dgrad(int mt, const char* who, const float* w, float* U, int Cout, int Cin, void* stream) {
+    CVK_CHECK_ARG(w && U && Cout > 0 && Cin > 0, "%s: bad arguments", who);
+    const dim3 grid(cvk_cdiv(Cin, 32), cvk_cdiv(Cout, 32));
+    if (mt == 4) hipLaunchKernelGGL(k_w2d_weight_dgrad<4>, grid, dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
+    else hipLaunchKernelGGL(k_w2d_weight_dgrad<6>, grid, dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
+    CVK_LAUNCH_RETURN(who);
 }
 
-extern "C" int cvk_w2d_input_transform(const float* x, float* V, int N, int H, int W, int Cin, void* stream) {
-    CVK_CHECK_ARG(x && V && N > 0 && H > 0 && W > 0 && Cin >= 4 && Cin % 4 == 0, "cvk_w2d_input_transform: bad arguments");
-    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(V), "cvk_w2d_input_transform: pointers must be 16-byte aligned");
-    const int th = (H + 3) / 4, tw = (W + 3) / 4, T = N * th * tw, Tpad = w2_tpad(T);
-    const long threads = (long)Tpad * (Cin / 4);
-    hipLaunchKernelGGL(k_w2d_input, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, V, H, W, Cin, th, tw, T, Tpad);
-    CVK_LAUNCH_RETURN("cvk_w2d_input_transform");
+static int w2i_input_transform(int mt, const char* who, const float* x, float* V, int N, int H, int W, int Cin, void* stream) {
+    CVK_CHECK_ARG(x && V && N > 0 && H > 0 && W > 0 && Cin >= 4 && Cin % 4 == 0, "%s: bad arguments", who);
+    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(V), "%s: pointers must be 16-byte aligned", who);
+    const int th = (H + mt - 1) / mt, tw = (W + mt - 1) / mt, T = N * th * tw, Tpad = w2_tpad(T);
+    const long threads = (long)Tpad * (Cin / (mt == 4 ? 4 : 2));
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (mt == 4) hipLaunchKernelGGL(k_w2d_input<4>, grid, dim3(256), 0, (hipStream_t)stream, x, V, H, W, Cin, th, tw, T, Tpad);
+    else hipLaunchKernelGGL(k_w2d_input<6>, grid, dim3(256), 0, (hipStream_t)stream, x, V, H, W, Cin, th, tw, T, Tpad);
+    CVK_LAUNCH_RETURN(who);
 }
 
-extern "C" int cvk_w2d_gemm(const float* V, const float* U, float* Mo, int T, int Cin, int Cout, void* stream) {
-    CVK_CHECK_ARG(V && U && Mo && T > 0, "cvk_w2d_gemm: bad arguments");
-    CVK_CHECK_ARG(Cin >= 32 && Cin % 32 == 0 && Cout > 0, "cvk_w2d_gemm: Cin=%d must be a multiple of 32", Cin);
-    CVK_CHECK_ARG(cvk_aligned16(V) && cvk_aligned16(U) && cvk_aligned16(Mo), "cvk_w2d_gemm: pointers must be 16-byte aligned");
-    CVK_CHECK_ARG((long)T * 36 * (Cin > Cout ? Cin : Cout) < (1L << 40), "cvk_w2d_gemm: tensor too large");
-    const W2Plan p = plan_w2d(T, Cin, Cout);
+static int w2i_gemm(int mt, const char* who, const float* V, const float* U, float* Mo, int T, int Cin, int Cout, void* stream) {
+    CVK_CHECK_ARG(V && U && Mo && T > 0, "%s: bad arguments", who);
+    CVK_CHECK_ARG(Cin >= 32 && Cin % 32 == 0 && Cout > 0, "%s: Cin=%d must be a multiple of 32", who, Cin);
+    CVK_CHECK_ARG(cvk_aligned16(V) && cvk_aligned16(U) && cvk_aligned16(Mo), "%s: pointers must be 16-byte aligned", who);
+    const int nx = w2_nx(mt);
+    CVK_CHECK_ARG((long)T * nx * (Cin > Cout ? Cin : Cout) < (1L << 40), "%s: tensor too large", who);
+    const W2Plan p = plan_w2d(nx, T, Cin, Cout);
     const dim3 grid(p.split_start + (p.NT - p.split_start) * p.f);
-    const size_t part_stride = (size_t)36 * T * Cout;
+    const size_t part_stride = (size_t)nx * T * Cout;
     hipStream_t s = (hipStream_t)stream;
     static int cus = 0, no_stagger = -1;          // queried once (benign race: every thread stores the same values)
     if (cus == 0) {
@@ -638,54 +787,39 @@ extern "C" int cvk_w2d_gemm(const float* V, const float* U, float* Mo, int T, in
     const int stagger = (!no_stagger && (int)grid.x >= 2 * cus && p.split_start >= 2 * cus) ? cus : 0;
     hipLaunchKernelGGL((k_w2d_gemm<128, 32, 2, 2>), grid, dim3(256), 0, s, V, U, Mo, T, w2_tpad(T), Cout, Cin, Cout, p.tilesM, p.tilesN,
                        p.split_start, p.f, part_stride, stagger);
-    CVK_LAUNCH_RETURN("cvk_w2d_gemm");
+    CVK_LAUNCH_RETURN(who);
 }
 
-extern "C" int cvk_w2d_output(const float* Mo, const float* bias, float* y, float* stats, float* counts, int N, int H, int W,
-                              int Cin, int Cout, int ldy, void* stream) {
-    CVK_CHECK_ARG(Mo && y && N > 0 && H > 0 && W > 0, "cvk_w2d_output: bad arguments");
-    CVK_CHECK_ARG(Cout >= 64 && Cout % 4 == 0 && ldy >= Cout && ldy % 4 == 0, "cvk_w2d_output: needs Cout %% 4 == 0, Cout >= 64 (got %d)", Cout);
-    CVK_CHECK_ARG((stats == nullptr) == (counts == nullptr), "cvk_w2d_output: stats and counts go together");
-    CVK_CHECK_ARG(cvk_aligned16(Mo) && cvk_aligned16(y), "cvk_w2d_output: pointers must be 16-byte aligned");
-    CVK_CHECK_ARG(Cin >= 32 && Cin % 32 == 0, "cvk_w2d_output: Cin (the GEMM depth, which fixes the K split of the planes) must be a multiple of 32");
-    const int th = (H + 3) / 4, tw = (W + 3) / 4, T = N * th * tw;
-    const int cvn = Cout / 4 >= 64 ? 64 : (Cout / 4 >= 32 ? 32 : 16);
+static int w2i_output(int mt, const char* who, const float* Mo, const float* bias, float* y, float* stats, float* counts, int N, int H,
+                      int W, int Cin, int Cout, int ldy, void* stream) {
+    CVK_CHECK_ARG(Mo && y && N > 0 && H > 0 && W > 0, "%s: bad arguments", who);
+    CVK_CHECK_ARG(Cout >= 64 && Cout % 4 == 0 && ldy >= Cout && ldy % 4 == 0, "%s: needs Cout %% 4 == 0, Cout >= 64 (got %d)", who, Cout);
+    CVK_CHECK_ARG((stats == nullptr) == (counts == nullptr), "%s: stats and counts go together", who);
+    CVK_CHECK_ARG(cvk_aligned16(Mo) && cvk_aligned16(y), "%s: pointers must be 16-byte aligned", who);
+    CVK_CHECK_ARG(Cin >= 32 && Cin % 32 == 0, "%s: Cin (the GEMM depth, which fixes the K split of the planes) must be a multiple of 32", who);
+    const int th = (H + mt - 1) / mt, tw = (W + mt - 1) / mt, T = N * th * tw;
+    const int vw = mt == 4 ? 4 : 2, nv = Cout / vw;
+    const int cvn = nv >= 64 ? 64 : (nv >= 32 ? 32 : 16);
     const int P = cvk_cdiv(T, w2_tb(T));
-    const W2Plan p = plan_w2d(T, Cin, Cout);
-    dim3 grid(P, cvk_cdiv(Cout / 4, cvn));
+    const W2Plan p = plan_w2d(w2_nx(mt), T, Cin, Cout);
+    dim3 grid(P, cvk_cdiv(nv, cvn));
     hipStream_t s = (hipStream_t)stream;
-    if (stats)
-        hipLaunchKernelGGL(k_w2d_output<true>, grid, dim3(256), 0, s, Mo, Cout, bias, y, ldy, stats, counts, P, H, W, th, tw, T, Cout, cvn,
-                           p.BM, p.tilesM * p.tilesN, p.tilesN, p.split_start, p.f);
-    else
-        hipLaunchKernelGGL(k_w2d_output<false>, grid, dim3(256), 0, s, Mo, Cout, bias, y, ldy, stats, counts, P, H, W, th, tw, T, Cout, cvn,
-                           p.BM, p.tilesM * p.tilesN, p.tilesN, p.split_start, p.f);
-    CVK_LAUNCH_RETURN("cvk_w2d_output");
-}
-
-extern "C" int cvk_conv3x3_w2d(const float* x, const float* U, const float* bias, float* y, float* stats, float* counts,
-                               int N, int H, int W, int Cin, int Cout, int ldy, void* workspace, size_t workspace_bytes,
-                               void* stream) {
-    CVK_CHECK_ARG(workspace && N > 0 && H > 0 && W > 0, "cvk_conv3x3_w2d: bad arguments");
-    CVK_CHECK_ARG(cvk_aligned16(workspace) && workspace_bytes >= cvk_conv3x3_w2d_workspace_bytes(N, H, W, Cin, Cout),
-                  "cvk_conv3x3_w2d: workspace too small or misaligned");
-    const int T = w2_tiles(N, H, W);
-    float* const V = (float*)workspace;
-    float* const Mo = V + (size_t)36 * w2_tpad(T) * Cin + 128;
-    int rc = cvk_w2d_input_transform(x, V, N, H, W, Cin, stream);
-    if (rc == CVK_OK) rc = cvk_w2d_gemm(V, U, Mo, T, Cin, Cout, stream);
-    if (rc == CVK_OK) rc = cvk_w2d_output(Mo, bias, y, stats, counts, N, H, W, Cin, Cout, ldy, stream);
-    return rc;
+#define CVK_W2_OUT(MT_, ST_) hipLaunchKernelGGL((k_w2d_output<MT_, ST_>), grid, dim3(256), 0, s, Mo, Cout, bias, y, ldy, stats, counts, P, H, W, th, tw, T, Cout, cvn, \
+                                                p.BM, p.tilesM * p.tilesN, p.tilesN, p.split_start, p.f)
+    if (mt == 4) { if (stats) CVK_W2_OUT(4, true); else CVK_W2_OUT(4, false); }
+    else         { if (stats) CVK_W2_OUT(6, true); else CVK_W2_OUT(6, false); }
+#undef CVK_W2_OUT
+    CVK_LAUNCH_RETURN(who);
 }
 
 // ---- weight-grad ---------------------------------------------------------------------------------------------------------
 struct W2WPlan { int Tpad, tilesM, tilesN, f; };
-static W2WPlan plan_w2d_wgrad(int T, int Cin_pad, int Cout) {
+static W2WPlan plan_w2d_wgrad(int nx, int T, int Cin_pad, int Cout) {
     W2WPlan p;
     p.Tpad = w2_tpad(T);
     p.tilesM = cvk_cdiv(Cout, 128);
     p.tilesN = cvk_cdiv(Cin_pad, 128);
-    const int nt = 36 * p.tilesM * p.tilesN, nK = p.Tpad / 32;
+    const int nt = nx * p.tilesM * p.tilesN, nK = p.Tpad / 32;
     // depth split: fill the 512 resident workgroups at least twice over, keep >= 4 slices per range, at most 16 planes
     int f = cvk_cdiv(1024, nt);
     if (f > nK / 4) f = nK / 4;
@@ -695,43 +829,99 @@ static W2WPlan plan_w2d_wgrad(int T, int Cin_pad, int Cout) {
     return p;
 }
 
-extern "C" int cvk_w2d_wgrad_ksplit(int T, int Cin_pad, int Cout) {
+static int w2i_wgrad_ksplit(int mt, int T, int Cin_pad, int Cout) {
     if (T <= 0 || Cin_pad <= 0 || Cout <= 0) return 0;
-    return plan_w2d_wgrad(T, Cin_pad, Cout).f;
+    return plan_w2d_wgrad(w2_nx(mt), T, Cin_pad, Cout).f;
 }
 
-extern "C" int cvk_w2d_dy_transform(const float* dy, int ld_dy, float* E, int N, int H, int W, int Cout, void* stream) {
-    CVK_CHECK_ARG(dy && E && N > 0 && H > 0 && W > 0 && Cout >= 4 && Cout % 4 == 0 && ld_dy >= Cout && ld_dy % 4 == 0, "cvk_w2d_dy_transform: bad arguments");
-    CVK_CHECK_ARG(cvk_aligned16(dy) && cvk_aligned16(E), "cvk_w2d_dy_transform: pointers must be 16-byte aligned");
-    const int th = (H + 3) / 4, tw = (W + 3) / 4, T = N * th * tw, Tpad = w2_tpad(T);
-    const long threads = (long)Tpad * (Cout / 4);
-    hipLaunchKernelGGL(k_w2d_dy, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, ld_dy, E, H, W, Cout, th, tw, T, Tpad);
-    CVK_LAUNCH_RETURN("cvk_w2d_dy_transform");
+static int w2i_dy_transform(int mt, const char* who, const float* dy, int ld_dy, float* E, int N, int H, int W, int Cout, void* stream) {
+    CVK_CHECK_ARG(dy && E && N > 0 && H > 0 && W > 0 && Cout >= 4 && Cout % 4 == 0 && ld_dy >= Cout && ld_dy % 4 == 0, "%s: bad arguments", who);
+    CVK_CHECK_ARG(cvk_aligned16(dy) && cvk_aligned16(E), "%s: pointers must be 16-byte aligned", who);
+    const int th = (H + mt - 1) / mt, tw = (W + mt - 1) / mt, T = N * th * tw, Tpad = w2_tpad(T);
+    const long threads = (long)Tpad * (Cout / (mt == 4 ? 4 : 2));
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (mt == 4) hipLaunchKernelGGL(k_w2d_dy<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, ld_dy, E, H, W, Cout, th, tw, T, Tpad);
+    else hipLaunchKernelGGL(k_w2d_dy<6>, grid, dim3(256), 0, (hipStream_t)stream, dy, ld_dy, E, H, W, Cout, th, tw, T, Tpad);
+    CVK_LAUNCH_RETURN(who);
 }
 
-extern "C" int cvk_w2d_gemm_tn(const float* E, const float* V, float* P, int T, int Cin_pad, int Cout, void* stream) {
-    CVK_CHECK_ARG(E && V && P && T > 0 && Cin_pad > 0 && Cin_pad % 4 == 0 && Cout > 0 && Cout % 4 == 0, "cvk_w2d_gemm_tn: bad arguments");
-    CVK_CHECK_ARG(cvk_aligned16(E) && cvk_aligned16(V) && cvk_aligned16(P), "cvk_w2d_gemm_tn: pointers must be 16-byte aligned");
-    const W2WPlan p = plan_w2d_wgrad(T, Cin_pad, Cout);
-    hipLaunchKernelGGL(k_w2d_gemm_tn, dim3(36 * p.tilesM * p.tilesN * p.f), dim3(256), 0, (hipStream_t)stream, E, Cout, V, Cin_pad, P, p.Tpad,
-                       Cout, Cin_pad, p.tilesM, p.tilesN, p.f);
-    CVK_LAUNCH_RETURN("cvk_w2d_gemm_tn");
+static int w2i_gemm_tn(int mt, const char* who, const float* E, const float* V, float* P, int T, int Cin_pad, int Cout, void* stream) {
+    CVK_CHECK_ARG(E && V && P && T > 0 && Cin_pad > 0 && Cin_pad % 4 == 0 && Cout > 0 && Cout % 4 == 0, "%s: bad arguments", who);
+    CVK_CHECK_ARG(cvk_aligned16(E) && cvk_aligned16(V) && cvk_aligned16(P), "%s: pointers must be 16-byte aligned", who);
+    const int nx = w2_nx(mt);
+    const W2WPlan p = plan_w2d_wgrad(nx, T, Cin_pad, Cout);
+    hipLaunchKernelGGL(k_w2d_gemm_tn, dim3(nx * p.tilesM * p.tilesN * p.f), dim3(256), 0, (hipStream_t)stream, E, Cout, V, Cin_pad, P, p.Tpad,
+                       Cout, Cin_pad, p.tilesM, p.tilesN, p.f, nx);
+    CVK_LAUNCH_RETURN(who);
 }
 
-extern "C" int cvk_w2d_wgrad_output(const float* P, float* dw, int T, int Cin, int Cin_pad, int Cout, void* stream) {
-    CVK_CHECK_ARG(P && dw && T > 0 && Cin > 0 && Cin <= Cin_pad && Cout > 0, "cvk_w2d_wgrad_output: bad arguments");
-    const W2WPlan p = plan_w2d_wgrad(T, Cin_pad, Cout);
+static int w2i_wgrad_output(int mt, const char* who, const float* P, float* dw, int T, int Cin, int Cin_pad, int Cout, void* stream) {
+    CVK_CHECK_ARG(P && dw && T > 0 && Cin > 0 && Cin <= Cin_pad && Cout > 0, "%s: bad arguments", who);
+    const W2WPlan p = plan_w2d_wgrad(w2_nx(mt), T, Cin_pad, Cout);
     const size_t total = (size_t)Cout * Cin;
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(k_w2d_wgrad_out, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, dw, Cout, Cin, Cin_pad, p.f);
-    CVK_LAUNCH_RETURN("cvk_w2d_wgrad_output");
+    if (mt == 4) hipLaunchKernelGGL(k_w2d_wgrad_out<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, dw, Cout, Cin, Cin_pad, p.f);
+    else hipLaunchKernelGGL(k_w2d_wgrad_out<6>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, dw, Cout, Cin, Cin_pad, p.f);
+    CVK_LAUNCH_RETURN(who);
 }
 
-extern "C" size_t cvk_conv3x3_wgrad_w2d_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout) {
+static size_t w2i_wgrad_workspace_bytes(int mt, int N, int H, int W, int Cin_pad, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin_pad <= 0 || Cout <= 0) return 0;
-    const W2WPlan p = plan_w2d_wgrad(w2_tiles(N, H, W), Cin_pad, Cout);
+    const int nx = w2_nx(mt);
+    const W2WPlan p = plan_w2d_wgrad(nx, w2_tiles(mt, N, H, W), Cin_pad, Cout);
     // V and E planes (+ 512 bytes of slack each: partial column tiles read past the last row) and the f product planes
-    return ((size_t)36 * p.Tpad * ((size_t)Cin_pad + Cout) + 2 * 128 + (size_t)p.f * 36 * Cout * Cin_pad) * sizeof(float);
+    return ((size_t)nx * p.Tpad * ((size_t)Cin_pad + Cout) + 2 * 128 + (size_t)p.f * nx * Cout * Cin_pad) * sizeof(float);
+}
+
+// ---- C ABI: F(4x4,3x3) ----------------------------------------------------------------------------------------------------
+extern "C" int cvk_w2d_tiles(int N, int H, int W) { return w2i_tiles(4, N, H, W); }
+extern "C" int cvk_w2d_stat_partials(int N, int H, int W) { return w2i_stat_partials(4, N, H, W); }
+extern "C" int cvk_w2d_ksplit(int T, int Cin, int Cout) { return w2i_ksplit(4, T, Cin, Cout); }
+extern "C" size_t cvk_conv3x3_w2d_workspace_bytes(int N, int H, int W, int Cin, int Cout) { return w2i_workspace_bytes(4, N, H, W, Cin, Cout); }
+extern "C" int cvk_w2d_weight_transform(const float* w, float* U, int Cout, int Cin, void* stream) {
+    return w2i_weight_transform(4, "cvk_w2d_weight_transform", w, U, Cout, Cin, stream);
+}
+extern "C" int cvk_w2d_weight_transform_dgrad(const float* w, float* U, int Cout, int Cin, void* stream) {
+    return w2i_weight_transform_dgrad(4, "cvk_w2d_weight_transform_dgrad", w, U, Cout, Cin, stream);
+}
+extern "C" int cvk_w2d_input_transform(const float* x, float* V, int N, int H, int W, int Cin, void* stream) {
+    return w2i_input_transform(4, "cvk_w2d_input_transform", x, V, N, H, W, Cin, stream);
+}
+extern "C" int cvk_w2d_gemm(const float* V, const float* U, float* Mo, int T, int Cin, int Cout, void* stream) {
+    return w2i_gemm(4, "cvk_w2d_gemm", V, U, Mo, T, Cin, Cout, stream);
+}
+extern "C" int cvk_w2d_output(const float* Mo, const float* bias, float* y, float* stats, float* counts, int N, int H, int W,
+                              int Cin, int Cout, int ldy, void* stream) {
+    return w2i_output(4, "cvk_w2d_output", Mo, bias, y, stats, counts, N, H, W, Cin, Cout, ldy, stream);
+}
+
+extern "C" int cvk_conv3x3_w2d(const float* x, const float* U, const float* bias, float* y, float* stats, float* counts,
+                               int N, int H, int W, int Cin, int Cout, int ldy, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    CVK_CHECK_ARG(workspace && N > 0 && H > 0 && W > 0, "cvk_conv3x3_w2d: bad arguments");
+    CVK_CHECK_ARG(cvk_aligned16(workspace) && workspace_bytes >= cvk_conv3x3_w2d_workspace_bytes(N, H, W, Cin, Cout),
+                  "cvk_conv3x3_w2d: workspace too small or misaligned");
+    const int T = w2_tiles(4, N, H, W);
+    float* const V = (float*)workspace;
+    float* const Mo = V + (size_t)36 * w2_tpad(T) * Cin + 128;
+    int rc = cvk_w2d_input_transform(x, V, N, H, W, Cin, stream);
+    if (rc == CVK_OK) rc = cvk_w2d_gemm(V, U, Mo, T, Cin, Cout, stream);
+    if (rc == CVK_OK) rc = cvk_w2d_output(Mo, bias, y, stats, counts, N, H, W, Cin, Cout, ldy, stream);
+    return rc;
+}
+
+extern "C" int cvk_w2d_wgrad_ksplit(int T, int Cin_pad, int Cout) { return w2i_wgrad_ksplit(4, T, Cin_pad, Cout); }
+extern "C" int cvk_w2d_dy_transform(const float* dy, int ld_dy, float* E, int N, int H, int W, int Cout, void* stream) {
+    return w2i_dy_transform(4, "cvk_w2d_dy_transform", dy, ld_dy, E, N, H, W, Cout, stream);
+}
+extern "C" int cvk_w2d_gemm_tn(const float* E, const float* V, float* P, int T, int Cin_pad, int Cout, void* stream) {
+    return w2i_gemm_tn(4, "cvk_w2d_gemm_tn", E, V, P, T, Cin_pad, Cout, stream);
+}
+extern "C" int cvk_w2d_wgrad_output(const float* P, float* dw, int T, int Cin, int Cin_pad, int Cout, void* stream) {
+    return w2i_wgrad_output(4, "cvk_w2d_wgrad_output", P, dw, T, Cin, Cin_pad, Cout, stream);
+}
+extern "C" size_t cvk_conv3x3_wgrad_w2d_workspace_bytes(int N, int H, int W, int Cin_pad, int Cout) {
+    return w2i_wgrad_workspace_bytes(4, N, H, W, Cin_pad, Cout);
 }
 
 // x == NULL: the workspace already holds V (cvk_w2d_input_transform of x, e.g. kept from the forward pass) at its start
@@ -742,7 +932,7 @@ extern "C" int cvk_conv3x3_wgrad_w2d(const float* x, const float* dy, float* dw,
                   "cvk_conv3x3_wgrad_w2d: bad shape (channel counts must be multiples of 4)");
     CVK_CHECK_ARG(cvk_aligned16(workspace) && workspace_bytes >= cvk_conv3x3_wgrad_w2d_workspace_bytes(N, H, W, Cin_pad, Cout),
                   "cvk_conv3x3_wgrad_w2d: workspace too small or misaligned");
-    const int T = w2_tiles(N, H, W), Tpad = w2_tpad(T);
+    const int T = w2_tiles(4, N, H, W), Tpad = w2_tpad(T);
     float* const V = (float*)workspace;
     float* const E = V + (size_t)36 * Tpad * Cin_pad + 128;
     float* const P = E + (size_t)36 * Tpad * Cout + 128;
@@ -751,4 +941,36 @@ extern "C" int cvk_conv3x3_wgrad_w2d(const float* x, const float* dy, float* dw,
     if (rc == CVK_OK) rc = cvk_w2d_gemm_tn(E, V, P, T, Cin_pad, Cout, stream);
     if (rc == CVK_OK) rc = cvk_w2d_wgrad_output(P, dw, T, Cin, Cin_pad, Cout, stream);
     return rc;
+}
+
+// ---- C ABI: F(6x6,3x3) — the same pipeline with 64 transform indices on 8 x 8 input tiles ---------------------------------------
+extern "C" int cvk_w6_tiles(int N, int H, int W) { return w2i_tiles(6, N, H, W); }
+extern "C" int cvk_w6_stat_partials(int N, int H, int W) { return w2i_stat_partials(6, N, H, W); }
+extern "C" int cvk_w6_ksplit(int T, int Cin, int Cout) { return w2i_ksplit(6, T, Cin, Cout); }
+extern "C" size_t cvk_conv3x3_w6_workspace_bytes(int N, int H, int W, int Cin, int Cout) { return w2i_workspace_bytes(6, N, H, W, Cin, Cout); }
+extern "C" int cvk_w6_weight_transform(const float* w, float* U, int Cout, int Cin, void* stream) {
+    return w2i_weight_transform(6, "cvk_w6_weight_transform", w, U, Cout, Cin, stream);
+}
+extern "C" int cvk_w6_weight_transform_dgrad(const float* w, float* U, int Cout, int Cin, void* stream) {
+    return w2i_weight_transform_dgrad(6, "cvk_w6_weight_transform_dgrad", w, U, Cout, Cin, stream);
+}
+extern "C" int cvk_w6_input_transform(const float* x, float* V, int N, int H, int W, int Cin, void* stream) {
+    return w2i_input_transform(6, "cvk_w6_input_transform", x, V, N, H, W, Cin, stream);
+}
+extern "C" int cvk_w6_gemm(const float* V, const float* U, float* Mo, int T, int Cin, int Cout, void* stream) {
+    return w2i_gemm(6, "cvk_w6_gemm", V, U, Mo, T, Cin, Cout, stream);
+}
+extern "C" int cvk_w6_output(const float* Mo, const float* bias, float* y, float* stats, float* counts, int N, int H, int W, int Cin,
+                             int Cout, int ldy, void* stream) {
+    return w2i_output(6, "cvk_w6_output", Mo, bias, y, stats, counts, N, H, W, Cin, Cout, ldy, stream);
+}
+extern "C" int cvk_w6_wgrad_ksplit(int T, int Cin_pad, int Cout) { return w2i_wgrad_ksplit(6, T, Cin_pad, Cout); }
+extern "C" int cvk_w6_dy_transform(const float* dy, int ld_dy, float* E, int N, int H, int W, int Cout, void* stream) {
+    return w2i_dy_transform(6, "cvk_w6_dy_transform", dy, ld_dy, E, N, H, W, Cout, stream);
+}
+extern "C" int cvk_w6_gemm_tn(const float* E, const float* V, float* P, int T, int Cin_pad, int Cout, void* stream) {
+    return w2i_gemm_tn(6, "cvk_w6_gemm_tn", E, V, P, T, Cin_pad, Cout, stream);
+}
+extern "C" int cvk_w6_wgrad_output(const float* P, float* dw, int T, int Cin, int Cin_pad, int Cout, void* stream) {
+    return w2i_wgrad_output(6, "cvk_w6_wgrad_output", P, dw, T, Cin, Cin_pad, Cout, stream);
 }

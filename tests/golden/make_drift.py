@@ -3,12 +3,16 @@
 widened after red runs, not before").  Uses only the oracle (oracle/torch_ref.py = the reference graph in stock torch,
 pinned to the reference by tests/test_oracle_golden.py; oracle/bf16_emul.py) — no reference import needed.
 
-    python tests/golden/make_drift.py [small] [full] [bf16small] [bf16full]      -> tests/golden/drift.json
+    python tests/golden/make_drift.py [small] [full] [logits] [bf16small] [bf16full]      -> tests/golden/drift.json
 
 1. trajectory drift: AdamW + OneCycleLR loss curves (reference train.py:100-134) of the golden trajectories, fp32 vs
    fp64 and fp32 vs fp32-with-1e-6-relative-input-noise (four noise seeds).  Two correct fp32 implementations differ
    by one more sample of that distribution, so tolerance[i] = max(FLOOR[i], SAFETY * max over the five samples),
    made non-decreasing in the step index.
+1b. forward drift of the logits (one training-mode forward pass, batch statistics): max |difference| on the golden slice, fp32 vs
+   fp64 and fp32 vs fp32-with-1e-6-relative-input-noise.  BatchNorm divides by each channel's standard deviation and the net ends in
+   one, so rounding-level differences of any fp32 implementation show up at 1e-4 in the logits: the slice tolerance of the full-size
+   golden tests is max(3e-4, SAFETY * the largest drift).
 2. bf16 storage cost: oracle/bf16_emul.py vs the fp32 run of the same graph (loss, logits relative L2, per-parameter
    gradient-norm deviation): tolerance = 3 x measured for the GPU bf16 parity tests.
 tests/test_drift_cpu.py re-measures the small cases and checks the committed numbers and the derivation rule."""
@@ -60,6 +64,41 @@ def trajectory_drift(kind, seed, shape, data_seed, steps, noise_seeds=NOISE_SEED
     b = trajectory(kind, seed, shape, data_seed, steps, dtype=torch.float64, **kw)
     c = np.max([np.abs(a - trajectory(kind, seed, shape, data_seed, steps, noise=1e-6, noise_seed=ns, **kw)) for ns in noise_seeds], axis=0)
     return {"fp32": a.tolist(), "drift_fp64": np.abs(a - b).tolist(), "drift_noise": c.tolist(), "noise_seeds": list(noise_seeds)}
+
+
+def logits_drift(kind, seed, shape, data_seed, stride, noise_seeds=NOISE_SEEDS[:2]):
+    """One train-mode forward of the reference graph: how far do two correct evaluations of the logits differ?"""
+    n, h, w = shape
+
+    def fwd(dtype, noise=0.0, ns=7):
+        torch.manual_seed(seed)
+        net = R.build(kind, 3, 12).to(dtype).train()
+        x, _ = R.synthetic_batch(n, h, w, data_seed)
+        x = x.to(dtype)
+        if noise:
+            x = x * (1 + noise * torch.randn(x.shape, generator=torch.Generator().manual_seed(ns)).to(dtype))
+        with torch.no_grad():
+            return net(x).double()
+
+    a = fwd(torch.float32)
+    b = fwd(torch.float64)
+    sl = lambda t: t[:, :, ::stride[0], ::stride[1]]
+    out = {"fp64_max_abs": float((a - b).abs().max()), "fp64_slice_max_abs": float(sl(a - b).abs().max()),
+           "fp64_rel_l2": float((a - b).norm() / b.norm()), "noise_seeds": list(noise_seeds), "noise_max_abs": 0.0, "noise_slice_max_abs": 0.0,
+           "noise_rel_l2": 0.0, "stride": list(stride)}
+    for ns in noise_seeds:
+        c = fwd(torch.float32, 1e-6, ns)
+        out["noise_max_abs"] = max(out["noise_max_abs"], float((a - c).abs().max()))
+        out["noise_slice_max_abs"] = max(out["noise_slice_max_abs"], float(sl(a - c).abs().max()))
+        out["noise_rel_l2"] = max(out["noise_rel_l2"], float((a - c).norm() / a.norm()))
+    return out
+
+
+LOGITS_FLOOR = 3e-4
+
+
+def logits_tolerance(v):
+    return {"slice_abs": max(LOGITS_FLOOR, SAFETY * max(v["fp64_slice_max_abs"], v["noise_slice_max_abs"]))}
 
 
 def tolerance_from(d):
@@ -168,6 +207,12 @@ def main():
         d["trajectory"]["segnet_s0_2x64x96"] = trajectory_drift("segnet", 0, (2, 64, 96), 1234, 3, total_steps=30)
     if "full" in which:
         d["trajectory"]["unet_s0_2x360x480"] = trajectory_drift("unet", 0, (2, 360, 480), 1234, 3, noise_seeds=NOISE_SEEDS[:2], steps_per_epoch=300)
+    d.setdefault("logits", {}); d.setdefault("logits_tolerance", {})
+    if "logits" in which:
+        d["logits"]["unet_s0_2x360x480"] = logits_drift("unet", 0, (2, 360, 480), 1234, (40, 48))
+        d["logits"]["unet_s0_8x360x480"] = logits_drift("unet", 0, (8, 360, 480), 1234, (40, 48))
+    for k, v in d["logits"].items():
+        d["logits_tolerance"][k] = logits_tolerance(v)
     for k, v in d["trajectory"].items():
         d["trajectory_tolerance"][k] = tolerance_from(v)
     if "bf16small" in which:

@@ -31,6 +31,10 @@ def test_tolerances_follow_the_rule():
         assert d["bf16_tolerance"][k] == md.bf16_tolerance(v), k
     for k, v in d["bf16_emul_noise"].items():
         assert d["bf16_emul_tolerance"][k] == md.bf16_emul_tolerance(v), k
+    for k, v in d["logits"].items():
+        assert d["logits_tolerance"][k] == md.logits_tolerance(v), k
+        assert 1e-5 < v["fp64_slice_max_abs"] < 1e-3 and 1e-5 < v["noise_slice_max_abs"] < 1e-3     # rounding shows at 1e-4 in the logits
+    assert "unet_s0_2x360x480" in d["logits_tolerance"]
     # every fixture the GPU tests read is there
     for k in ("unet_s0_2x48x64", "segnet_s0_2x64x96", "unet_s0_2x360x480"):
         assert k in d["trajectory_tolerance"], k

@@ -1,0 +1,140 @@
+"""Raw C-ABI parity of the 2-D Winograd pipelines (csrc/wino2d.hip) — F(4x4,3x3) `cvk_w2d_*` and F(6x6,3x3) `cvk_w6_*` — pass by
+pass against the fp64 operator they replace: nn.Conv2d(cin, cout, 3, padding=1) of /root/reference/models/unet.py:11 (forward +
+the BatchNorm batch statistics of unet.py:12), its data-grad and its weight-grad (backward of train.py:131).
+Tolerances: fp32 rounding of the transforms, measured with a numpy restatement at 64 / 256 input channels: F(4x4) 1.4e-6 / 2.7e-6,
+F(6x6) 2.7e-6 / 5.1e-6 relative L2 (it grows ~sqrt(Cin)); bounds below are 3x those."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from pytorch_camvid_amd import _lib
+    return _lib.load(), _lib.check
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def fam(lib, mt):
+    pre = "cvk_w2d_" if mt == 4 else "cvk_w6_"
+    return lambda name: getattr(lib, pre + name)
+
+
+TOL = {4: 1.0e-5, 6: 1.8e-5}
+
+CASES = [  # N, H, W, Cin, Cout: ragged tiles (H, W not multiples of 4 / 6), one tile, K-split tails, >128 output channels
+    (1, 5, 7, 32, 64),
+    (2, 12, 18, 64, 64),
+    (1, 22, 30, 256, 256),
+    (2, 45, 60, 128, 192),
+    (1, 3, 4, 512, 128),
+    (8, 22, 30, 512, 256),
+    (2, 90, 120, 64, 128),
+]
+
+
+def _forward(mt, x_nhwc, w_oihw, bias, stats=True, dgrad=False):
+    lib, check = _lib()
+    f = fam(lib, mt)
+    N, H, W, Ck = x_nhwc.shape
+    wcl = w_oihw.permute(0, 2, 3, 1).contiguous()
+    Cn = w_oihw.shape[1] if dgrad else w_oihw.shape[0]
+    nx = (mt + 2) ** 2
+    U = torch.empty(nx, Cn, Ck, device="cuda")
+    if dgrad:
+        check(f("weight_transform_dgrad")(wcl.data_ptr(), U.data_ptr(), w_oihw.shape[0], w_oihw.shape[1], _s()), "weight(dgrad)")
+    else:
+        check(f("weight_transform")(wcl.data_ptr(), U.data_ptr(), Cn, Ck, _s()), "weight")
+    T = f("tiles")(N, H, W)
+    Tp = lib.cvk_w2d_tpad(T)
+    ks = f("ksplit")(T, Ck, Cn)
+    V = torch.full((nx * Tp * Ck + 128,), float("nan"), device="cuda")
+    Mo = torch.full((ks * nx * T * Cn,), float("nan"), device="cuda")
+    wsb = lib.cvk_conv3x3_w2d_workspace_bytes(N, H, W, Ck, Cn) if mt == 4 else lib.cvk_conv3x3_w6_workspace_bytes(N, H, W, Ck, Cn)
+    assert wsb == 4 * (nx * Tp * Ck + 128 + ks * nx * T * Cn)
+    y = torch.full((N, H, W, Cn), float("nan"), device="cuda")
+    P = f("stat_partials")(N, H, W)
+    st = torch.full((2 * P * Cn + P,), float("nan"), device="cuda") if stats else None
+    check(f("input_transform")(x_nhwc.data_ptr(), V.data_ptr(), N, H, W, Ck, _s()), "input")
+    check(f("gemm")(V.data_ptr(), U.data_ptr(), Mo.data_ptr(), T, Ck, Cn, _s()), "gemm")
+    check(f("output")(Mo.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(), st.data_ptr() if stats else None,
+                      st.data_ptr() + 8 * P * Cn if stats else None, N, H, W, Ck, Cn, Cn, _s()), "output")
+    torch.cuda.synchronize()
+    return y, st, P, V
+
+
+@pytest.mark.parametrize("mt", [4, 6])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", CASES)
+def test_forward_and_statistics_vs_fp64(mt, N, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + Cin + mt)
+    x = torch.relu(torch.randn(N, Cin, H, W, generator=g))                # activations of the net are post-ReLU
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    y, st, P, _ = _forward(mt, x.permute(0, 2, 3, 1).contiguous().cuda(), w.cuda(), b.cuda())
+    got = y.permute(0, 3, 1, 2).double().cpu()
+    assert torch.isfinite(got).all()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel < TOL[mt], rel
+    M = N * H * W
+    sums = st[:P * Cout].view(P, Cout).double().cpu()
+    m2 = st[P * Cout:2 * P * Cout].view(P, Cout).double().cpu()
+    cnt = st[2 * P * Cout:].double().cpu()
+    assert int(cnt.sum().item()) == M
+    mean = sums.sum(0) / M
+    var = (m2.sum(0) + (cnt[:, None] * (sums / cnt[:, None] - mean) ** 2).sum(0)) / M
+    rmean, rvar = ref.mean(dim=(0, 2, 3)), ref.var(dim=(0, 2, 3), unbiased=False)
+    assert (mean - rmean).abs().max().item() < 1e-5 * max(1.0, rmean.abs().max().item())
+    assert ((var - rvar).abs() <= 1e-4 * rvar + 1e-6 * (ref ** 2).mean(dim=(0, 2, 3))).all()
+
+
+@pytest.mark.parametrize("mt", [4, 6])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 12, 18, 64, 64), (1, 22, 30, 256, 128), (2, 45, 60, 128, 192)])
+def test_data_grad_vs_fp64(mt, N, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(7 + Cin + Cout + mt)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    ref = F.conv_transpose2d(dy.double(), w.double(), padding=1)
+    dx, _, _, _ = _forward(mt, dy.permute(0, 2, 3, 1).contiguous().cuda(), w.cuda(), None, stats=False, dgrad=True)
+    got = dx.permute(0, 3, 1, 2).double().cpu()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel < TOL[mt], rel
+
+
+@pytest.mark.parametrize("mt", [4, 6])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 12, 18, 64, 64), (1, 22, 30, 256, 128), (2, 45, 60, 128, 192), (8, 22, 30, 512, 256)])
+def test_weight_grad_vs_fp64(mt, N, H, W, Cin, Cout):
+    lib, check = _lib()
+    f = fam(lib, mt)
+    g = torch.Generator().manual_seed(11 + Cin + Cout + mt)
+    x = torch.relu(torch.randn(N, Cin, H, W, generator=g))
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    wref = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wref, padding=1).backward(dy.double())
+    ref = wref.grad.permute(0, 2, 3, 1)
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    dyn = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    nx = (mt + 2) ** 2
+    T = f("tiles")(N, H, W)
+    Tp = lib.cvk_w2d_tpad(T)
+    fs = f("wgrad_ksplit")(T, Cin, Cout)
+    V = torch.full((nx * Tp * Cin + 128,), float("nan"), device="cuda")
+    E = torch.full((nx * Tp * Cout + 128,), float("nan"), device="cuda")
+    Pp = torch.full((fs * nx * Cout * Cin,), float("nan"), device="cuda")
+    outs = []
+    for _ in range(2):
+        dw = torch.full((Cout, 3, 3, Cin), float("nan"), device="cuda")
+        check(f("input_transform")(xn.data_ptr(), V.data_ptr(), N, H, W, Cin, _s()), "input")
+        check(f("dy_transform")(dyn.data_ptr(), Cout, E.data_ptr(), N, H, W, Cout, _s()), "dy")
+        check(f("gemm_tn")(E.data_ptr(), V.data_ptr(), Pp.data_ptr(), T, Cin, Cout, _s()), "gemm_tn")
+        check(f("wgrad_output")(Pp.data_ptr(), dw.data_ptr(), T, Cin, Cin, Cout, _s()), "wgrad_out")
+        torch.cuda.synchronize()
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
+    got = outs[0].double().cpu()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel < 2 * TOL[mt], rel

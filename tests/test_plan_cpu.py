@@ -106,4 +106,9 @@ def test_winograd2d_choice_per_layer():
                   (8, 90, 120, 128, 256), (8, 360, 480, 64, 12)):
         assert not f(*shape) and not w(*shape), shape
     assert not f(2, 6, 8, 512, 512) and not w(2, 6, 8, 512, 512)                  # golden-sized layers: fewer than 256 tiles
+    # 6x6 tiles (UNet's default since round 3, tools/bench_w6.py): the same layer set (taking the 128-channel layers too gained
+    # nothing on the step and doubled the logits deviation: engine.wino2d_pays)
+    for shape in ((8, 90, 120, 256, 256), (8, 22, 30, 1024, 1024), (8, 180, 240, 256, 128), (8, 180, 240, 128, 128), (8, 90, 120, 128, 256),
+                  (8, 360, 480, 64, 64), (8, 180, 240, 64, 128), (2, 6, 8, 512, 512)):
+        assert engine.wino2d_pays(*shape, tile=6) == f(*shape), shape
     assert engine.wino2d_ok(256, 256, 256) and not engine.wino2d_ok(48, 256, 256) and not engine.wino2d_ok(256, 12, 12)
