@@ -138,13 +138,26 @@ WINO2D_DEFAULT = {"0": False, "1": True, "always": "always"}[os.environ.get("CVK
 W2TILE_DEFAULT = {"auto": None, "4": 4, "6": 6}[os.environ.get("CVK_W2D_TILE", "auto")]
 
 
-def w2fn(lib, R, name):
-    """Entry point `name` of the 2-D Winograd family the runner uses: cvk_w2d_<name> or cvk_w6_<name>."""
-    return getattr(lib, ("cvk_w6_" if R.w2tile == 6 else "cvk_w2d_") + name)
+def w2fn(lib, tile, name):
+    """Entry point `name` of the 2-D Winograd family for output tile `tile`: cvk_w2d_<name> (4) or cvk_w6_<name> (6)."""
+    return getattr(lib, ("cvk_w6_" if tile == 6 else "cvk_w2d_") + name)
 
 
-def w2ws(lib, R, N, H, W, k_ch, cout):
-    return (lib.cvk_conv3x3_w6_workspace_bytes if R.w2tile == 6 else lib.cvk_conv3x3_w2d_workspace_bytes)(N, H, W, k_ch, cout)
+def w2ws(lib, tile, N, H, W, k_ch, cout):
+    return (lib.cvk_conv3x3_w6_workspace_bytes if tile == 6 else lib.cvk_conv3x3_w2d_workspace_bytes)(N, H, W, k_ch, cout)
+
+
+def layer_tile(R, N, H, W):
+    """Output tile of the 2-D path for a layer geometry.  The batched GEMM works on 128-row tiles of the tile index: at the 22x30
+    bottleneck (batch 8) 6x6 tiles give 160 rows = two row tiles of which 37 % are padding (138 us, as long as F(4x4)'s three full
+    row tiles) and 1.78x the filter-transform bytes (50 vs 28 us at 1024 x 1024 channels) — such layers keep 4x4 tiles."""
+    if R.w2tile != 6:
+        return 4
+    t6 = N * ((H + 5) // 6) * ((W + 5) // 6)
+    t4 = N * ((H + 3) // 4) * ((W + 3) // 4)
+    u6 = t6 / (128.0 * ((t6 + 127) // 128))
+    u4 = t4 / (128.0 * ((t4 + 127) // 128))
+    return 4 if (u6 < 0.7 and u4 > u6 + 0.2) else 6
 
 
 def wino2d_ok(k_ch, cout, ldy):
@@ -210,37 +223,38 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
     def cached(kind, build):
         return R.derived((ck, kind), wsrc, build) if (ck is not None and wsrc is not None) else build()
     if wino2d_ok(k_ch, cout, ldy) and (R.wino2d == "always" or (R.wino2d and wino2d_pays(N, H, W, k_ch, cout, R.w2tile))):
-        NX = 64 if R.w2tile == 6 else 36
+        tile = layer_tile(R, N, H, W)
+        NX = 64 if tile == 6 else 36
         def build_u2():
             u = _empty(NX * cout * k_ch, x.device)
             if dgrad_of is not None and dgrad_of[1] == k_ch and dgrad_of[2] == cout:       # no channel padding: straight from the forward weights
                 _timed(R, "k_w2d_weight_dgrad", 4.0 * (9 + NX) * cout * k_ch, lambda: check(
-                    w2fn(lib, R, "weight_transform_dgrad")(dgrad_of[0].data_ptr(), u.data_ptr(), dgrad_of[1], dgrad_of[2], s),
+                    w2fn(lib, tile, "weight_transform_dgrad")(dgrad_of[0].data_ptr(), u.data_ptr(), dgrad_of[1], dgrad_of[2], s),
                     "cvk_w2d_weight_transform_dgrad"), "byte")
                 return u
             wt = w() if callable(w) else w
             _timed(R, "k_w2d_weight", 4.0 * (9 + NX) * cout * k_ch, lambda: check(
-                w2fn(lib, R, "weight_transform")(wt.data_ptr(), u.data_ptr(), cout, k_ch, s), "cvk_w2d_weight_transform"), "byte")
+                w2fn(lib, tile, "weight_transform")(wt.data_ptr(), u.data_ptr(), cout, k_ch, s), "cvk_w2d_weight_transform"), "byte")
             return u
-        U = cached("w2d%d" % R.w2tile, build_u2)
-        T = w2fn(lib, R, "tiles")(N, H, W)
+        U = cached("w2d%d" % tile, build_u2)
+        T = w2fn(lib, tile, "tiles")(N, H, W)
         vfl = NX * lib.cvk_w2d_tpad(T) * k_ch + 128          # V planes + 512 bytes of slack
         if keep_v is not None:      # the weight-grad of this layer reuses V: its own tensor instead of the shared workspace
             Vt = _empty(vfl, x.device)
             keep_v.append(Vt)
-            ws = R.workspace(w2ws(lib, R, N, H, W, k_ch, cout) - 4 * vfl, x.device)
+            ws = R.workspace(w2ws(lib, tile, N, H, W, k_ch, cout) - 4 * vfl, x.device)
             V, Mo = Vt.data_ptr(), ws.data_ptr()
         else:
-            ws = R.workspace(w2ws(lib, R, N, H, W, k_ch, cout), x.device)
+            ws = R.workspace(w2ws(lib, tile, N, H, W, k_ch, cout), x.device)
             V, Mo = ws.data_ptr(), ws.data_ptr() + 4 * vfl
-        P2 = w2fn(lib, R, "stat_partials")(N, H, W)
+        P2 = w2fn(lib, tile, "stat_partials")(N, H, W)
         cnt = sp + 4 * 2 * P2 * cout if sp is not None else None
         _timed(R, "k_w2d_input", 4.0 * (M + NX * T) * k_ch, lambda: check(
-            w2fn(lib, R, "input_transform")(x.data_ptr(), V, N, H, W, k_ch, s), "cvk_w2d_input_transform" + what), "byte")
-        _timed(R, "k_w2d_gemm<128, 32, 2, 2>", flops, lambda: check(w2fn(lib, R, "gemm")(V, U.data_ptr(), Mo, T, k_ch, cout, s), "cvk_w2d_gemm" + what),
+            w2fn(lib, tile, "input_transform")(x.data_ptr(), V, N, H, W, k_ch, s), "cvk_w2d_input_transform" + what), "byte")
+        _timed(R, "k_w2d_gemm<128, 32, 2, 2>", flops, lambda: check(w2fn(lib, tile, "gemm")(V, U.data_ptr(), Mo, T, k_ch, cout, s), "cvk_w2d_gemm" + what),
                executed=2.0 * NX * T * k_ch * cout)   # NX GEMMs of T x k_ch x cout really run on the matrix pipe
         _timed(R, "k_w2d_output", 4.0 * (NX * T + M) * cout, lambda: check(
-            w2fn(lib, R, "output")(Mo, bias, y.data_ptr(), sp, cnt, N, H, W, k_ch, cout, ldy, s), "cvk_w2d_output" + what), "byte")
+            w2fn(lib, tile, "output")(Mo, bias, y.data_ptr(), sp, cnt, N, H, W, k_ch, cout, ldy, s), "cvk_w2d_output" + what), "byte")
         return (P2, cnt) if sp is not None else None
     use4 = R.wino4 == "always" or (R.wino4 and wino4_pays(N, H, W, k_ch, ldy))
     if use4 and R.wino4f and wino4f_ok(k_ch, cout) and (dgrad_of is None or (dgrad_of[1] == k_ch and dgrad_of[2] == cout)):
@@ -603,25 +617,26 @@ class ConvBnRelu(Op):
                     "cvk_conv3x3_fwd(dgrad)"))
             st.grad[src.id] = dX
         if wgrad2d:
-            NX = 64 if R.w2tile == 6 else 36
-            T = w2fn(lib, R, "tiles")(N, H, W)
+            tile = layer_tile(R, N, H, W)
+            NX = 64 if tile == 6 else 36
+            T = w2fn(lib, tile, "tiles")(N, H, W)
             Tp = lib.cvk_w2d_tpad(T)
             vfl, efl = NX * Tp * src.ld + 128, NX * Tp * C + 128
-            f = w2fn(lib, R, "wgrad_ksplit")(T, src.ld, C)
+            f = w2fn(lib, tile, "wgrad_ksplit")(T, src.ld, C)
             if Vkept is not None and Vkept.numel() != vfl:
                 Vkept = None            # forward ran with another tile size (the knob changed in between)
             if Vkept is None:           # forward ran another kernel (e.g. the mode changed in between): transform x now
                 Vkept = _empty(vfl, dev)
                 _timed(R, "k_w2d_input", 4.0 * (M + NX * T) * src.ld, lambda: check(
-                    w2fn(lib, R, "input_transform")(X.data_ptr(), Vkept.data_ptr(), N, H, W, src.ld, s), "cvk_w2d_input_transform(wgrad)"), "byte")
+                    w2fn(lib, tile, "input_transform")(X.data_ptr(), Vkept.data_ptr(), N, H, W, src.ld, s), "cvk_w2d_input_transform(wgrad)"), "byte")
             ws = R.workspace(4 * (efl + f * NX * C * src.ld), dev)
             Ep, Pp = ws.data_ptr(), ws.data_ptr() + 4 * efl
             _timed(R, "k_w2d_dy", 4.0 * (M + NX * T) * C, lambda: check(
-                w2fn(lib, R, "dy_transform")(dy.data_ptr(), ldy, Ep, N, H, W, C, s), "cvk_w2d_dy_transform"), "byte")
+                w2fn(lib, tile, "dy_transform")(dy.data_ptr(), ldy, Ep, N, H, W, C, s), "cvk_w2d_dy_transform"), "byte")
             _timed(R, "k_w2d_gemm_tn", 18.0 * M * C * self.cin, lambda: check(
-                w2fn(lib, R, "gemm_tn")(Ep, Vkept.data_ptr(), Pp, T, src.ld, C, s), "cvk_w2d_gemm_tn"), executed=2.0 * NX * Tp * src.ld * C)
+                w2fn(lib, tile, "gemm_tn")(Ep, Vkept.data_ptr(), Pp, T, src.ld, C, s), "cvk_w2d_gemm_tn"), executed=2.0 * NX * Tp * src.ld * C)
             _timed(R, "k_w2d_wgrad_out", 4.0 * (NX * f + 9) * C * self.cin, lambda: check(
-                w2fn(lib, R, "wgrad_output")(Pp, gw, T, self.cin, src.ld, C, s), "cvk_w2d_wgrad_output"), "byte")
+                w2fn(lib, tile, "wgrad_output")(Pp, gw, T, self.cin, src.ld, C, s), "cvk_w2d_wgrad_output"), "byte")
             del Vkept
         elif wgradp:
             rows6 = lib.cvk_wgradp_plane_rows(N, H, W)
