@@ -303,11 +303,16 @@ __global__ __launch_bounds__(256) void k_bilinear_fwd_tiled(const float* __restr
 // reads, two blocks per CU, load and compute phases that do not overlap; the re-reads of this version are L2 hits.)
 template <int V>
 __global__ __launch_bounds__(256) void k_bilinear_bwd(const float* __restrict__ dout, float* __restrict__ dx, int H, int W, int C,
-                                                     float sy, float sx, RowDiv dcv) {
+                                                     float sy, float sx, RowDiv dcv, int gx, RowDiv dgx) {
     typedef typename VT_<V>::T VT;
     const int Ho = 2 * H, Wo = 2 * W, cvn = C / V;
-    const int yi = blockIdx.y, n = blockIdx.z;
-    const unsigned idx = blockIdx.x * 256 + threadIdx.x;
+    // 1-D grid of gx column blocks x (N * H) input rows, dealt to the XCDs in contiguous chunks of rows: neighbouring input rows
+    // share two of their ~four gradient rows, and with one row per workgroup in dispatch order those rows were fetched by every
+    // XCD's L2 (PMC: 2.5x the gradient tensor crossed the fabric per launch)
+    const unsigned lid = (unsigned)cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned row = dgx.div(lid), bx = lid - row * gx;
+    const int n = (int)(row / (unsigned)H), yi = (int)(row - (unsigned)n * H);
+    const unsigned idx = bx * 256 + threadIdx.x;
     if (idx >= (unsigned)(W * cvn)) return;
     const int xi = (int)dcv.div(idx), cv = (int)idx - xi * cvn;
     // x2 with align_corners: src = s * dst, s = (n-1)/(2n-1) in [1/3, 1/2) — every output row/column whose taps touch input
@@ -454,10 +459,14 @@ extern "C" int cvk_bilinear_up2_bwd(const float* dout, float* dx, int N, int H, 
     CVK_CHECK_ARG(dout && dx && N > 0 && H > 0 && W > 0 && C > 0, "cvk_bilinear_up2_bwd: bad arguments");
     const float sy = ac_scale(H, 2 * H), sx = ac_scale(W, 2 * W);
     hipStream_t s = (hipStream_t)stream;
-    CVK_CHECK_ARG(H <= 65535 && N <= 65535 && (long)2 * W * C < (1L << 31), "cvk_bilinear_up2_bwd: frame too large for the row grid");
-    if (v4ok(C, dout, dx))
-        hipLaunchKernelGGL(k_bilinear_bwd<4>, dim3(cvk_cdiv((long)W * (C / 4), 256), H, N), dim3(256), 0, s, dout, dx, H, W, C, sy, sx, RowDiv(C / 4));
+    CVK_CHECK_ARG((long)2 * W * C < (1L << 31), "cvk_bilinear_up2_bwd: frame too large for the row grid");
+    const bool v4 = v4ok(C, dout, dx);
+    const int gx = cvk_cdiv((long)W * (v4 ? C / 4 : C), 256);
+    CVK_CHECK_ARG((long)gx * H * N < (1L << 31) - 8, "cvk_bilinear_up2_bwd: too many workgroups");
+    const dim3 grid((unsigned)((long)gx * H * N));
+    if (v4)
+        hipLaunchKernelGGL(k_bilinear_bwd<4>, grid, dim3(256), 0, s, dout, dx, H, W, C, sy, sx, RowDiv(C / 4), gx, RowDiv(gx));
     else
-        hipLaunchKernelGGL(k_bilinear_bwd<1>, dim3(cvk_cdiv((long)W * C, 256), H, N), dim3(256), 0, s, dout, dx, H, W, C, sy, sx, RowDiv(C));
+        hipLaunchKernelGGL(k_bilinear_bwd<1>, grid, dim3(256), 0, s, dout, dx, H, W, C, sy, sx, RowDiv(C), gx, RowDiv(gx));
     CVK_LAUNCH_RETURN("cvk_bilinear_up2_bwd");
 }

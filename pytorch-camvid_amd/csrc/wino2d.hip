@@ -183,7 +183,9 @@ __global__ __launch_bounds__(256) void k_w2d_input(const float* __restrict__ X, 
     typedef typename TR::VT VT;
     constexpr int NT = TR::NT, NX = TR::NX, VW = TR::VW;
     const int cvn = C / VW;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    // workgroups are dealt to the XCDs in contiguous chunks of tiles: vertically neighbouring tiles share two input rows, and a
+    // tile row is tw tiles — many workgroups — away
+    const long idx = (long)cvk_xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     const int t = (int)(idx / cvn), c = (int)(idx % cvn) * VW;
     if (t >= Tpad) return;
     const VT zero = {};
