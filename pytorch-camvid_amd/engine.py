@@ -438,7 +438,8 @@ class ConvBnRelu(Op):
         lib, s, src = R.lib, st.stream, self.src
         N, H, W, M, C, ldy = src.N, src.H, src.W, src.M, self.cout, pad4(self.cout)
         sp = stats.data_ptr() if stats is not None else None
-        if R.thin and lib.cvk_thin_fwd_supported(src.ld, C, ldy) and (sp is None or src.ld <= 8 or src.ld == 64):
+        if (R.thin and lib.cvk_thin_fwd_supported(src.ld, C, ldy) and (sp is None or src.ld <= 8 or src.ld == 64)
+                and H * W * max(src.ld, ldy) * 4 < 2 ** 31):       # one image per buffer resource
             # the stem (3 -> 64) and the classifier head (64 -> 12): csrc/thin.hip, the thin side is one side of a 16x16x4 MFMA
             Pt = lib.cvk_thin_stat_partials(N, H, W, src.ld)
             cnt = sp + 4 * 2 * Pt * C if sp is not None else None
@@ -605,7 +606,7 @@ class ConvBnRelu(Op):
                           dgrad_of=(wc, C, self.cin), wsrc=w, ck=(self.pslot, "d"), bnred=bnred)
                 if bnred is not None and bnred[5]:
                     st.bnred[prod.idx] = bnred[5][0]
-            elif R.thin and lib.cvk_thin_fwd_supported(ldy, src.ld, src.ld):      # the head's data-grad: 12 -> 64 (csrc/thin.hip)
+            elif R.thin and lib.cvk_thin_fwd_supported(ldy, src.ld, src.ld) and H * W * max(src.ld, ldy) * 4 < 2 ** 31:      # the head's data-grad: 12 -> 64 (csrc/thin.hip)
                 wd = R.derived(((self.pslot, "d"), "pack"), w, packed)
                 _timed(R, "k_thin_ci_fwd(dgrad)", 18.0 * M * C * self.cin, lambda: check(
                     lib.cvk_conv3x3_thin_fwd(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, None, N, H, W, ldy, src.ld, src.ld, s),
@@ -662,7 +663,7 @@ class ConvBnRelu(Op):
                 lib.cvk_conv3x3_wgrad_wino4(X.data_ptr(), dy.data_ptr(), E.data_ptr() if E is not None else None, gw, N, H, W,
                                             self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
                 "cvk_conv3x3_wgrad_wino4"))
-        elif R.thin and lib.cvk_thin_wgrad_supported(self.cin, src.ld, C, ldy):
+        elif R.thin and lib.cvk_thin_wgrad_supported(self.cin, src.ld, C, ldy) and H * W * max(src.ld, ldy) * 4 < 2 ** 31:
             wsb = lib.cvk_conv3x3_thin_wgrad_workspace_bytes(N, H, W, src.ld, C)
             ws = R.workspace(wsb, dev)
             head = src.ld == 64
