@@ -147,11 +147,12 @@ def w2ws(lib, tile, N, H, W, k_ch, cout):
     return (lib.cvk_conv3x3_w6_workspace_bytes if tile == 6 else lib.cvk_conv3x3_w2d_workspace_bytes)(N, H, W, k_ch, cout)
 
 
-def layer_tile(R, N, H, W):
-    """Output tile of the 2-D path for a layer geometry.  The batched GEMM works on 128-row tiles of the tile index: at the 22x30
+def layer_tile(R, N, H, W, dgrad=False):
+    """Output tile of the 2-D path for a layer geometry (dgrad: of a data-grad launch — networks with MaxUnpool2d keep 4x4 tiles in the
+    forward pass, where coarser rounding flips pool arg-maxes, but their data-grads run after the indices are fixed: 6x6).  The batched GEMM works on 128-row tiles of the tile index: at the 22x30
     bottleneck (batch 8) 6x6 tiles give 160 rows = two row tiles of which 37 % are padding (138 us, as long as F(4x4)'s three full
     row tiles) and 1.78x the filter-transform bytes (50 vs 28 us at 1024 x 1024 channels) — such layers keep 4x4 tiles."""
-    if R.w2tile != 6:
+    if (R.w2tile_dgrad if dgrad else R.w2tile) != 6:
         return 4
     t6 = N * ((H + 5) // 6) * ((W + 5) // 6)
     t4 = N * ((H + 3) // 4) * ((W + 3) // 4)
@@ -223,7 +224,7 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
     def cached(kind, build):
         return R.derived((ck, kind), wsrc, build) if (ck is not None and wsrc is not None) else build()
     if wino2d_ok(k_ch, cout, ldy) and (R.wino2d == "always" or (R.wino2d and wino2d_pays(N, H, W, k_ch, cout, R.w2tile))):
-        tile = layer_tile(R, N, H, W)
+        tile = layer_tile(R, N, H, W, dgrad=dgrad_of is not None)
         NX = 64 if tile == 6 else 36
         def build_u2():
             u = _empty(NX * cout * k_ch, x.device)
@@ -1033,6 +1034,7 @@ class Runner:
         self.wino2d = WINO2D_DEFAULT
         self.w2tile_cfg = W2TILE_DEFAULT    # None = auto (see W2TILE_DEFAULT), 4 or 6 = forced
         self.w2tile = 6                     # the tile of the plan being executed (set by forward / backward)
+        self.w2tile_dgrad = 6               # ... of its data-grad launches
         self.bf16 = False           # opt-in: bf16-storage mode (modules.set_conv_precision; BASELINE.json configs[3])
         self.wcache = WCACHE_DEFAULT
         self.wepoch = 0             # bumped by mark_weights_dirty / FlatAdamW.step / load_state_dict
@@ -1090,13 +1092,14 @@ class Runner:
 
     # ---- forward / backward -------------------------------------------------------------------------------------
     def tile_for(self, plan):
+        """(forward / weight-grad tile, data-grad tile) of the 2-D path for a plan."""
         if self.w2tile_cfg in (4, 6):
-            return self.w2tile_cfg
-        return 4 if any(isinstance(op, Unpool) for op in plan.ops) else 6
+            return self.w2tile_cfg, self.w2tile_cfg
+        return (4, 6) if any(isinstance(op, Unpool) for op in plan.ops) else (6, 6)
 
     def forward(self, plan, x, params, training, need_grad):
         dev = x.device
-        self.w2tile = self.tile_for(plan)
+        self.w2tile, self.w2tile_dgrad = self.tile_for(plan)
         st = RunState(params, training, need_grad)
         st.device = dev
         st.plan = plan
@@ -1130,7 +1133,7 @@ class Runner:
 
     def backward(self, plan, st, gout):
         dev = gout.device
-        self.w2tile = self.tile_for(plan)
+        self.w2tile, self.w2tile_dgrad = self.tile_for(plan)
         st.stream = torch.cuda.current_stream(dev).cuda_stream
         params = st.params
         st.goffs, total = self.layout_grads(plan, params)
