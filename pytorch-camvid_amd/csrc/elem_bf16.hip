@@ -389,39 +389,53 @@ __global__ __launch_bounds__(256) void k_bilinear_fwd_bf16_tiled(const __bf16* _
     }
 }
 
+// backward = gather over the output pixels whose taps touch input pixel (yi, xi), as pointwise.hip k_bilinear_bwd: a fixed 6 x 6
+// candidate window with per-candidate weights (all contributing loads in flight together; the first version walked data-dependent
+// loop bounds with one load in flight), one workgroup row = one input row, rows dealt to the XCDs in contiguous chunks (neighbouring
+// input rows share two of their ~four gradient rows: they stay in one L2).
 template <int V>
-__global__ void k_bilinear_bwd_bf16(const __bf16* __restrict__ dout, __bf16* __restrict__ dx, int N, int H, int W, int C, float sy, float sx) {
+__global__ __launch_bounds__(256) void k_bilinear_bwd_bf16(const __bf16* __restrict__ dout, __bf16* __restrict__ dx, int N, int H, int W, int C,
+                                                          float sy, float sx, int gx) {
     const int Ho = 2 * H, Wo = 2 * W, cvn = C / V;
-    const long total = (long)N * H * W * cvn;
-    CVK_GRID_STRIDE(i, total) {
-        const int cv = (int)(i % cvn);
-        long t = i / cvn;
-        const int xi = (int)(t % W);
-        t /= W;
-        const int yi = (int)(t % H), n = (int)(t / H);
-        int ylo = 0, yhi = Ho - 1, xlo = 0, xhi = Wo - 1;
-        if (sy > 0.f) { ylo = max(0, (int)floorf((float)(yi - 1) / sy)); yhi = min(Ho - 1, (int)ceilf((float)(yi + 1) / sy)); }
-        if (sx > 0.f) { xlo = max(0, (int)floorf((float)(xi - 1) / sx)); xhi = min(Wo - 1, (int)ceilf((float)(xi + 1) / sx)); }
-        FV<V> acc;
+    const unsigned lid = (unsigned)cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned row = lid / (unsigned)gx, bx = lid - row * gx;
+    const int n = (int)(row / (unsigned)H), yi = (int)(row - (unsigned)n * H);
+    const unsigned idx = bx * 256 + threadIdx.x;
+    if (idx >= (unsigned)(W * cvn)) return;
+    const int xi = (int)(idx / (unsigned)cvn), cv = (int)idx - xi * cvn;
+    float wy[6], wx[6];
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc.v[j] = 0.f;
-        const __bf16* b = dout + ((size_t)n * Ho * Wo) * C + cv * V;
-        for (int yo = ylo; yo <= yhi; ++yo) {
-            const Tap ty = make_tap(yo, sy, H);
-            const float wy = (ty.i0 == yi ? ty.l0 : 0.f) + (ty.i1 == yi ? ty.l1 : 0.f);
-            if (wy == 0.f) continue;
-            for (int xo = xlo; xo <= xhi; ++xo) {
-                const Tap tx = make_tap(xo, sx, W);
-                const float wx = (tx.i0 == xi ? tx.l0 : 0.f) + (tx.i1 == xi ? tx.l1 : 0.f);
-                if (wx == 0.f) continue;
-                const FV<V> g = load_bf16<V>(b + ((size_t)yo * Wo + xo) * C);
-                const float w = wy * wx;
-#pragma unroll
-                for (int j = 0; j < V; ++j) acc.v[j] += w * g.v[j];
-            }
+    for (int k = 0; k < 6; ++k) {
+        const int yo = 2 * yi - 2 + k, xo = 2 * xi - 2 + k;
+        wy[k] = 0.f; wx[k] = 0.f;
+        if ((unsigned)yo < (unsigned)Ho) {
+            const Tap t = make_tap(yo, sy, H);
+            wy[k] = (t.i0 == yi ? t.l0 : 0.f) + (t.i1 == yi ? t.l1 : 0.f);
         }
-        store_bf16<V>(dx + i * V, acc);
+        if ((unsigned)xo < (unsigned)Wo) {
+            const Tap t = make_tap(xo, sx, W);
+            wx[k] = (t.i0 == xi ? t.l0 : 0.f) + (t.i1 == xi ? t.l1 : 0.f);
+        }
     }
+    FV<V> acc;
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc.v[j] = 0.f;
+    const __bf16* b = dout + ((size_t)n * Ho * Wo) * C + cv * V;
+#pragma unroll
+    for (int ky = 0; ky < 6; ++ky) {                             // block-uniform
+        if (wy[ky] == 0.f) continue;
+        const int yo = 2 * yi - 2 + ky;
+#pragma unroll
+        for (int kx = 0; kx < 6; ++kx) {
+            if (wx[kx] == 0.f) continue;
+            const int xo = 2 * xi - 2 + kx;
+            const FV<V> g = load_bf16<V>(b + ((size_t)yo * Wo + xo) * C);
+            const float w = wy[ky] * wx[kx];
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc.v[j] += w * g.v[j];
+        }
+    }
+    store_bf16<V>(dx + (((size_t)n * H + yi) * W) * C + (size_t)idx * V, acc);
 }
 
 __global__ void k_zero_frame_bf16(cvk_viewh b, int N, int H, int W, int C, int y0, int x0, int h, int w) {
@@ -558,8 +572,10 @@ extern "C" int cvk_bilinear_up2_fwd_bf16(const void* x, void* out, int N, int H,
 
 extern "C" int cvk_bilinear_up2_bwd_bf16(const void* dout, void* dx, int N, int H, int W, int C, void* stream) {
     CVK_CHECK_ARG(dout && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && cvk_aligned16(dout) && cvk_aligned16(dx), "cvk_bilinear_up2_bwd_bf16: bad arguments");
-    hipLaunchKernelGGL(k_bilinear_bwd_bf16<8>, dim3(grid_for((long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
-                       (const __bf16*)dout, (__bf16*)dx, N, H, W, C, ac_scale(H, 2 * H), ac_scale(W, 2 * W));
+    const int gx = cvk_cdiv((long)W * (C / 8), 256);
+    CVK_CHECK_ARG((long)gx * H * N < (1L << 31) - 8, "cvk_bilinear_up2_bwd_bf16: too many workgroups");
+    hipLaunchKernelGGL(k_bilinear_bwd_bf16<8>, dim3((unsigned)((long)gx * H * N)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)dout, (__bf16*)dx, N, H, W, C, ac_scale(H, 2 * H), ac_scale(W, 2 * W), gx);
     CVK_LAUNCH_RETURN("cvk_bilinear_up2_bwd_bf16");
 }
 
