@@ -112,3 +112,16 @@ def test_winograd2d_choice_per_layer():
                   (8, 360, 480, 64, 64), (8, 180, 240, 64, 128), (2, 6, 8, 512, 512)):
         assert engine.wino2d_pays(*shape, tile=6) == f(*shape), shape
     assert engine.wino2d_ok(256, 256, 256) and not engine.wino2d_ok(48, 256, 256) and not engine.wino2d_ok(256, 12, 12)
+
+
+def test_winograd2d_tile_choice():
+    """engine.layer_tile / Runner.tile_for: 6x6 output tiles (F(6x6,3x3)) unless the layer's tile count fills the GEMM's 128-row tiles
+    badly (the 22x30 bottleneck at batch 8: 160 tiles) or the network unpools (SegNet: 4x4 in the forward pass, 6x6 for data-grads)."""
+    class R:
+        w2tile, w2tile_dgrad = 6, 6
+    assert engine.layer_tile(R, 8, 22, 30) == 4 and engine.layer_tile(R, 8, 45, 60) == 6 and engine.layer_tile(R, 8, 90, 120) == 6
+    assert engine.layer_tile(R, 8, 180, 240) == 6 and engine.layer_tile(R, 2, 45, 60) == 4
+    R.w2tile = 4
+    assert engine.layer_tile(R, 8, 90, 120) == 4 and engine.layer_tile(R, 8, 90, 120, dgrad=True) == 6
+    R.w2tile_dgrad = 4
+    assert engine.layer_tile(R, 8, 90, 120, dgrad=True) == 4
