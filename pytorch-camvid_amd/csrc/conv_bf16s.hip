@@ -28,6 +28,9 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef CVK_BF16_RING
+#define CVK_BF16_RING 4
+#endif
 constexpr int CK = 32;                 // channels per K slice: 64-byte pixel rows in LDS
 constexpr int TH = 8, TW = 32;         // output tile: 8 rows x 32 columns = 256 pixels (eight 32-pixel MFMA blocks)
 constexpr int HP = TW + 4;             // halo row pitch in pixels (34 used; 36 keeps the row term of the swizzle uniform)
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16s(const __bf16* __restrict_
     constexpr int TPS = BN == 64 ? 3 : 1;  // taps per step (= per barrier): the 64-channel tile has only 8 MFMAs per wave and
                                            // tap, so it runs a whole kernel row between two barriers
     constexpr int SPC = 9 / TPS;           // steps per channel slice
-    constexpr int RING = TPS == 3 ? 2 : 3; // weight ring depth in steps (LDS budget: 2 workgroups per CU)
+    constexpr int RING = TPS == 3 ? 2 : CVK_BF16_RING; // weight ring depth in steps (LDS budget: 2 workgroups per CU; 4 = exactly 80 KiB each)
     constexpr int NBP = BN / 64;           // weight DMA pieces (16 rows x 64 B) per wave per tap
     constexpr int BTAP = BN * 64;          // bytes of one tap's weight tile
     constexpr int BSLOT = BTAP * TPS;      // bytes per weight ring slot (one step)
@@ -190,9 +193,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16s(const __bf16* __restrict_
 #pragma unroll
     for (int t = 0; t < 6; ++t) dma_slab_piece(t, 0, slab0);
     dma_weights(0, 0, ring0);
-    if (RING == 3) {
+    if (RING >= 3) {
         dma_weights(1, 0, ring0 + BSLOT);
-        wait_vm<NBP * TPS>();          // everything but the step-1 weights has landed
+        if (RING == 4) {
+            dma_weights(2, 0, ring0 + 2 * BSLOT);
+            wait_vm<2 * NBP * TPS>();  // everything but the weights of steps 1 and 2 has landed
+        } else {
+            wait_vm<NBP * TPS>();      // everything but the step-1 weights has landed
+        }
     } else {
         wait_vm<0>();
     }
@@ -245,7 +253,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf16s(const __bf16* __restrict_
             // (3) ring of 3: everything issued before this step's DMAs has landed (the step+1 weights, older slab pieces).
             //     ring of 2: this step's weight DMAs feed the NEXT step and must land; the slab pieces (issued after them)
             //     may stay in flight except at the end of the slice.
-            if (RING == 3) {
+            if (RING == 4) {
+                // ring of 4: the DMAs of this step and the previous one (weights of steps + 3 and + 2, their slab pieces) may stay in
+                // flight: a weight tile now has three steps (~0.6 us at the matrix peak) to arrive instead of two — the L2 round trip
+                // of an LDS-DMA under load is about that long, and with a ring of 3 every step waited for it
+                constexpr int W2 = 2 * NBP * TPS;
+                if (sidx >= 1 && sidx * SLABPS < 6) wait_vm<W2 + 2 * SLABPS>();
+                else if (sidx == 0 || (sidx - 1) * SLABPS < 6) wait_vm<W2 + SLABPS>();
+                else wait_vm<W2>();
+            } else if (RING == 3) {
                 if (sidx * SLABPS < 6) wait_vm<NBP * TPS + SLABPS>();
                 else wait_vm<NBP * TPS>();
             } else {
