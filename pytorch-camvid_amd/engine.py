@@ -841,7 +841,9 @@ class MaxPool(Op):
             st.grad.pop(d.id)
             return
         code = st.saved.get(self.idx)
-        _timed(R, "k_pool_scatter(bwd)", (13.0 if acc else 9.0) * v.buf.N * v.H * v.W * v.C, lambda: check(
+        # bytes per input element: the pooled gradient (1) + the arg-max source (the activations, 4, or the 1-byte codes, 0.25) + the
+        # gradient written (4) or accumulated (8)
+        _timed(R, "k_pool_scatter(bwd)", (1.0 + (0.25 if code is not None else 4.0) + (8.0 if acc else 4.0)) * v.buf.N * v.H * v.W * v.C, lambda: check(
             R.lib.cvk_maxpool2x2_bwd(st.grad[d.id].data_ptr(), v.cview(X), code.data_ptr() if code is not None else None,
                                      v.cview(st.grad[v.buf.id]), 1 if acc else 0, v.buf.N, v.H, v.W, v.C, st.stream),
             "cvk_maxpool2x2_bwd"), "byte")

@@ -137,7 +137,9 @@ class UNet(nn.Module):
             cat = plan.new_buf(2 * w, t.H, t.W, f"cat{k}")
             skip = stage._emit(plan, t, BufView(cat, w, w, 0, 0, t.H, t.W))
             cats.append((cat, skip))
-            t = plan.maxpool(skip).dst
+            # fp32: the BN-apply pass that writes the pooled tensor also leaves the 1-byte arg-max codes, so the pool's backward reads
+            # 0.25 B per input element instead of re-reading the 4-byte activations to recompute the arg-max
+            t = plan.maxpool(skip, keep_code=not plan.bf16).dst
         t = self.down5._emit(plan, t).buf
         for k in range(1, 5):
             cat, skip = cats[4 - k]
