@@ -147,6 +147,9 @@ int cvk_conv3x3_wgrad_w2d(const float* x, const float* dy, float* dw, int N, int
                           int ld_dy, void* workspace, size_t workspace_bytes, void* stream);
 int cvk_w2d_wgrad_ksplit(int T, int Cin_pad, int Cout);
 int cvk_w2d_dy_transform(const float* dy, int ld_dy, float* E, int N, int H, int W, int Cout, void* stream);
+/* both transforms of dy in one launch: Vp = cvk_w2d_input_transform(dy) (the data-grad's operand, dy dense with row stride ld_dy =
+ * Cout required by that GEMM) and E = cvk_w2d_dy_transform(dy) (the weight-grad's), bit for bit; dy crosses the fabric once */
+int cvk_w2d_dy_transform_both(const float* dy, int ld_dy, float* Vp, float* E, int N, int H, int W, int Cout, void* stream);
 int cvk_w2d_gemm_tn(const float* E, const float* V, float* P, int T, int Cin_pad, int Cout, void* stream);
 int cvk_w2d_wgrad_output(const float* P, float* dw, int T, int Cin, int Cin_pad, int Cout, void* stream);
 
@@ -168,6 +171,7 @@ int cvk_w6_output(const float* Mo, const float* bias, float* y, float* stats, fl
                   int Cout, int ldy, void* stream);
 int cvk_w6_wgrad_ksplit(int T, int Cin_pad, int Cout);
 int cvk_w6_dy_transform(const float* dy, int ld_dy, float* E, int N, int H, int W, int Cout, void* stream);
+int cvk_w6_dy_transform_both(const float* dy, int ld_dy, float* Vp, float* E, int N, int H, int W, int Cout, void* stream);
 int cvk_w6_gemm_tn(const float* E, const float* V, float* P, int T, int Cin_pad, int Cout, void* stream);
 int cvk_w6_wgrad_output(const float* P, float* dw, int T, int Cin, int Cin_pad, int Cout, void* stream);
 /* FUSED 1-D Winograd F(4,3) (csrc/wino4f.hip; replaces nn.Conv2d(cin,cout,3,padding=1) fwd and its data-grad,

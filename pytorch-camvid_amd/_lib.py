@@ -96,6 +96,8 @@ SIGNATURES = {
     "cvk_w2d_tpad": (c_int, [c_int]),
     "cvk_w2d_wgrad_ksplit": (c_int, [c_int, c_int, c_int]),
     "cvk_w2d_dy_transform": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_w2d_dy_transform_both": (c_int, [c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_w6_dy_transform_both": (c_int, [c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_w2d_gemm_tn": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "cvk_w2d_wgrad_output": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_w2d_ksplit": (c_int, [c_int, c_int, c_int]),

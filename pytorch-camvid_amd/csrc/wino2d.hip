@@ -465,6 +465,82 @@ __global__ __launch_bounds__(256) void k_w2d_dy(const float* __restrict__ DY, in
     }
 }
 
+// dy -> BOTH transforms of the backward pass in one launch: V' = B^T dy B (the data-grad's GEMM operand: the tile with its one-pixel
+// halo) and E = A dy A^T (the weight-grad's: the tile's own MT x MT pixels).  The thread that has just transformed a tile for V'
+// re-reads its inner pixels (L1 / L2 hits) for E: dy crosses the fabric once instead of twice, and one launch replaces two.
+template <int MT>
+__global__ __launch_bounds__(256) void k_w2d_dy_both(const float* __restrict__ DY, int ld, float* __restrict__ Vp, float* __restrict__ E, int H,
+                                                    int W, int C, int th, int tw, int T, int Tpad) {
+    typedef W2T<MT> TR;
+    typedef typename TR::VT VT;
+    constexpr int NT = TR::NT, NX = TR::NX, VW = TR::VW;
+    const int cvn = C / VW;
+    const long idx = (long)cvk_xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    const int t = (int)(idx / cvn), c = (int)(idx % cvn) * VW;
+    if (t >= Tpad) return;
+    const VT zero = {};
+    const size_t plane = (size_t)Tpad * C;
+    float* const vb = Vp + (size_t)t * C + c;
+    float* const eb = E + (size_t)t * C + c;
+    if (t >= T) {
+        for (int xi = 0; xi < NX; ++xi) {
+            *reinterpret_cast<VT*>(vb + (size_t)xi * plane) = zero;
+            *reinterpret_cast<VT*>(eb + (size_t)xi * plane) = zero;
+        }
+        return;
+    }
+    const int n = t / (th * tw), r = t - n * th * tw, ty = r / tw, tx = r - ty * tw;
+    const float* const db = DY + (size_t)n * H * W * ld + c;
+    {   // V' (as k_w2d_input)
+        const int y0 = MT * ty - 1, x0 = MT * tx - 1;
+        VT w[NT][NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            VT d[NT], v[NT];
+            const int xx = x0 + j;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int yy = y0 + i;
+                const bool ok = ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+                d[i] = ok ? *reinterpret_cast<const VT*>(db + ((size_t)yy * W + xx) * ld) : zero;
+            }
+            TR::bt(d, v);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) w[i][j] = v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            VT v[NT];
+            TR::bt(w[i], v);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) *reinterpret_cast<VT*>(vb + (size_t)(i * NT + j) * plane) = v[j];
+        }
+    }
+    {   // E (as k_w2d_dy)
+        VT w[NT][MT];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            VT d[MT], e[NT];
+            const int xx = MT * tx + j;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int yy = MT * ty + i;
+                d[i] = (yy < H && xx < W) ? *reinterpret_cast<const VT*>(db + ((size_t)yy * W + xx) * ld) : zero;
+            }
+            TR::a(d, e);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) w[i][j] = e[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            VT e[NT];
+            TR::a(w[i], e);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) *reinterpret_cast<VT*>(eb + (size_t)(i * NT + j) * plane) = e[j];
+        }
+    }
+}
+
 // batched GEMM over the tile index:  D_xi[Mm][Nn] (plane `part`) = sum_{k in part's range} A_xi[k][Mm]^T * B_xi[k][Nn]
 // Both operands are depth-major (a depth row = lda / ldb contiguous floats).  Workgroup: 128 x 128 tile, four waves of
 // 64 x 64; LDS: two stages of 32 depth rows x (128 + 128) floats, copied by LDS-DMA as they lie (1 KiB = two depth rows of one
@@ -875,6 +951,17 @@ static size_t w2i_wgrad_workspace_bytes(int mt, int N, int H, int W, int Cin_pad
     return ((size_t)nx * p.Tpad * ((size_t)Cin_pad + Cout) + 2 * 128 + (size_t)p.f * nx * Cout * Cin_pad) * sizeof(float);
 }
 
+static int w2i_dy_both(int mt, const char* who, const float* dy, int ld_dy, float* Vp, float* E, int N, int H, int W, int C, void* stream) {
+    CVK_CHECK_ARG(dy && Vp && E && N > 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0 && ld_dy >= C && ld_dy % 4 == 0, "%s: bad arguments", who);
+    CVK_CHECK_ARG(cvk_aligned16(dy) && cvk_aligned16(Vp) && cvk_aligned16(E), "%s: pointers must be 16-byte aligned", who);
+    const int th = (H + mt - 1) / mt, tw = (W + mt - 1) / mt, T = N * th * tw, Tpad = w2_tpad(T);
+    const long threads = (long)Tpad * (C / (mt == 4 ? 4 : 2));
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (mt == 4) hipLaunchKernelGGL(k_w2d_dy_both<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, ld_dy, Vp, E, H, W, C, th, tw, T, Tpad);
+    else hipLaunchKernelGGL(k_w2d_dy_both<6>, grid, dim3(256), 0, (hipStream_t)stream, dy, ld_dy, Vp, E, H, W, C, th, tw, T, Tpad);
+    CVK_LAUNCH_RETURN(who);
+}
+
 // ---- C ABI: F(4x4,3x3) ----------------------------------------------------------------------------------------------------
 extern "C" int cvk_w2d_tiles(int N, int H, int W) { return w2i_tiles(4, N, H, W); }
 extern "C" int cvk_w2d_stat_partials(int N, int H, int W) { return w2i_stat_partials(4, N, H, W); }
@@ -915,6 +1002,9 @@ extern "C" int cvk_conv3x3_w2d(const float* x, const float* U, const float* bias
 extern "C" int cvk_w2d_wgrad_ksplit(int T, int Cin_pad, int Cout) { return w2i_wgrad_ksplit(4, T, Cin_pad, Cout); }
 extern "C" int cvk_w2d_dy_transform(const float* dy, int ld_dy, float* E, int N, int H, int W, int Cout, void* stream) {
     return w2i_dy_transform(4, "cvk_w2d_dy_transform", dy, ld_dy, E, N, H, W, Cout, stream);
+}
+extern "C" int cvk_w2d_dy_transform_both(const float* dy, int ld_dy, float* Vp, float* E, int N, int H, int W, int Cout, void* stream) {
+    return w2i_dy_both(4, "cvk_w2d_dy_transform_both", dy, ld_dy, Vp, E, N, H, W, Cout, stream);
 }
 extern "C" int cvk_w2d_gemm_tn(const float* E, const float* V, float* P, int T, int Cin_pad, int Cout, void* stream) {
     return w2i_gemm_tn(4, "cvk_w2d_gemm_tn", E, V, P, T, Cin_pad, Cout, stream);
@@ -969,6 +1059,9 @@ extern "C" int cvk_w6_output(const float* Mo, const float* bias, float* y, float
 extern "C" int cvk_w6_wgrad_ksplit(int T, int Cin_pad, int Cout) { return w2i_wgrad_ksplit(6, T, Cin_pad, Cout); }
 extern "C" int cvk_w6_dy_transform(const float* dy, int ld_dy, float* E, int N, int H, int W, int Cout, void* stream) {
     return w2i_dy_transform(6, "cvk_w6_dy_transform", dy, ld_dy, E, N, H, W, Cout, stream);
+}
+extern "C" int cvk_w6_dy_transform_both(const float* dy, int ld_dy, float* Vp, float* E, int N, int H, int W, int Cout, void* stream) {
+    return w2i_dy_both(6, "cvk_w6_dy_transform_both", dy, ld_dy, Vp, E, N, H, W, Cout, stream);
 }
 extern "C" int cvk_w6_gemm_tn(const float* E, const float* V, float* P, int T, int Cin_pad, int Cout, void* stream) {
     return w2i_gemm_tn(6, "cvk_w6_gemm_tn", E, V, P, T, Cin_pad, Cout, stream);

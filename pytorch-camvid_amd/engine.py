@@ -206,7 +206,7 @@ def wgradp_pays(N, H, W, cin_ld, cout):
 
 
 def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what="", dgrad_of=None, keep_v=None, wsrc=None, ck=None,
-              bnred=None):
+              bnred=None, v_pre=None):
     """y[N,H,W,ldy] = conv3x3(x[N,H,W,k_ch], w[cout][3][3][k_ch]) (+bias, +BN statistics partials at sp) through the
     Winograd kernels: weight transform -> (input transform ->) GEMMs M_xi -> output transform.  2-D F(4x4,3x3) for the
     channel-heavy layers (R.wino2d, wino2d_pays), else 1-D F(4,3) when R.wino4, else F(2,3).
@@ -218,7 +218,8 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
     filter derives from and the layer's cache key — the transformed filter is then kept across calls (Runner.derived).
     bnred (data-grad only): (yP, scale, shift, mean, rstd pointers, out list) of the block that produced this conv's input; when
     the fused F(4,3) kernel runs and ldy == cout it also leaves that block's BatchNorm-backward sums and appends
-    (partials tensor, partial count) to the list."""
+    (partials tensor, partial count) to the list.  v_pre (tile, tensor): the transformed input V of the 2-D path, already computed
+    with that tile (cvk_w6_dy_transform_both: the backward pass transforms dy once for the data-grad and the weight-grad)."""
     M = N * H * W
 
     def cached(kind, build):
@@ -240,7 +241,10 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
         U = cached("w2d%d" % tile, build_u2)
         T = w2fn(lib, tile, "tiles")(N, H, W)
         vfl = NX * lib.cvk_w2d_tpad(T) * k_ch + 128          # V planes + 512 bytes of slack
-        if keep_v is not None:      # the weight-grad of this layer reuses V: its own tensor instead of the shared workspace
+        if v_pre is not None and v_pre[0] == tile:
+            ws = R.workspace(w2ws(lib, tile, N, H, W, k_ch, cout) - 4 * vfl, x.device)
+            V, Mo = v_pre[1].data_ptr(), ws.data_ptr()
+        elif keep_v is not None:    # the weight-grad of this layer reuses V: its own tensor instead of the shared workspace
             Vt = _empty(vfl, x.device)
             keep_v.append(Vt)
             ws = R.workspace(w2ws(lib, tile, N, H, W, k_ch, cout) - 4 * vfl, x.device)
@@ -250,8 +254,9 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
             V, Mo = ws.data_ptr(), ws.data_ptr() + 4 * vfl
         P2 = w2fn(lib, tile, "stat_partials")(N, H, W)
         cnt = sp + 4 * 2 * P2 * cout if sp is not None else None
-        _timed(R, "k_w2d_input", 4.0 * (M + NX * T) * k_ch, lambda: check(
-            w2fn(lib, tile, "input_transform")(x.data_ptr(), V, N, H, W, k_ch, s), "cvk_w2d_input_transform" + what), "byte")
+        if not (v_pre is not None and v_pre[0] == tile):
+            _timed(R, "k_w2d_input", 4.0 * (M + NX * T) * k_ch, lambda: check(
+                w2fn(lib, tile, "input_transform")(x.data_ptr(), V, N, H, W, k_ch, s), "cvk_w2d_input_transform" + what), "byte")
         _timed(R, "k_w2d_gemm<128, 32, 2, 2>", flops, lambda: check(w2fn(lib, tile, "gemm")(V, U.data_ptr(), Mo, T, k_ch, cout, s), "cvk_w2d_gemm" + what),
                executed=2.0 * NX * T * k_ch * cout)   # NX GEMMs of T x k_ch x cout really run on the matrix pipe
         _timed(R, "k_w2d_output", 4.0 * (NX * T + M) * cout, lambda: check(
@@ -583,6 +588,20 @@ class ConvBnRelu(Op):
                                   N, H, W, C, 1 if st.training else 0, s), "cvk_bn_bwd_dx"), "byte")
             check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, gb, None, s), "cvk_colsum_finalize")  # conv bias grad
         del y
+        # weight-grad AND data-grad on the 2-D path with the same tile: dy is transformed for both in ONE launch (csrc/wino2d.hip
+        # k_w2d_dy_both): E for the weight-grad, V' for the data-grad; dy crosses the fabric once
+        both2 = None
+        if (wgrad2d and self.src_needs_grad and R.w2both and ldy == C and wino_ok(R, ldy, src.ld) and wino2d_ok(ldy, src.ld, src.ld)
+                and (R.wino2d == "always" or (R.wino2d and wino2d_pays(N, H, W, ldy, src.ld, R.w2tile)))
+                and layer_tile(R, N, H, W) == layer_tile(R, N, H, W, dgrad=True)):
+            tile = layer_tile(R, N, H, W)
+            NX = 64 if tile == 6 else 36
+            T = w2fn(lib, tile, "tiles")(N, H, W)
+            Tp = lib.cvk_w2d_tpad(T)
+            Eb, Vb = _empty(NX * Tp * C + 128, dev), _empty(NX * Tp * C + 128, dev)
+            _timed(R, "k_w2d_dy<both>", 4.0 * (M + 2 * NX * T) * C, lambda: check(
+                w2fn(lib, tile, "dy_transform_both")(dy.data_ptr(), ldy, Vb.data_ptr(), Eb.data_ptr(), N, H, W, C, s), "cvk_w2d_dy_transform_both"), "byte")
+            both2 = (tile, Eb, Vb)
         if self.src_needs_grad:
             if src.id in st.grad:
                 raise NotImplementedError("conv data-grad must be the first writer of its input's gradient buffer")
@@ -604,7 +623,8 @@ class ConvBnRelu(Op):
                     bnred = (py.data_ptr(), pbnp.data_ptr() + 8 * src.ld, pbnp.data_ptr() + 12 * src.ld, pbnp.data_ptr(),
                              pbnp.data_ptr() + 4 * src.ld, [])
                 wino_conv(R, lib, s, dy, packed, None, dX, None, N, H, W, ldy, src.ld, src.ld, 18.0 * M * C * self.cin, "(dgrad)",
-                          dgrad_of=(wc, C, self.cin), wsrc=w, ck=(self.pslot, "d"), bnred=bnred)
+                          dgrad_of=(wc, C, self.cin), wsrc=w, ck=(self.pslot, "d"), bnred=bnred,
+                          v_pre=(both2[0], both2[2]) if both2 is not None else None)
                 if bnred is not None and bnred[5]:
                     st.bnred[prod.idx] = bnred[5][0]
             elif R.thin and lib.cvk_thin_fwd_supported(ldy, src.ld, src.ld) and H * W * max(src.ld, ldy) * 4 < 2 ** 31:      # the head's data-grad: 12 -> 64 (csrc/thin.hip)
@@ -631,10 +651,14 @@ class ConvBnRelu(Op):
                 Vkept = _empty(vfl, dev)
                 _timed(R, "k_w2d_input", 4.0 * (M + NX * T) * src.ld, lambda: check(
                     w2fn(lib, tile, "input_transform")(X.data_ptr(), Vkept.data_ptr(), N, H, W, src.ld, s), "cvk_w2d_input_transform(wgrad)"), "byte")
-            ws = R.workspace(4 * (efl + f * NX * C * src.ld), dev)
-            Ep, Pp = ws.data_ptr(), ws.data_ptr() + 4 * efl
-            _timed(R, "k_w2d_dy", 4.0 * (M + NX * T) * C, lambda: check(
-                w2fn(lib, tile, "dy_transform")(dy.data_ptr(), ldy, Ep, N, H, W, C, s), "cvk_w2d_dy_transform"), "byte")
+            if both2 is not None and both2[0] == tile:      # E came with the data-grad's V'
+                ws = R.workspace(4 * (f * NX * C * src.ld), dev)
+                Ep, Pp = both2[1].data_ptr(), ws.data_ptr()
+            else:
+                ws = R.workspace(4 * (efl + f * NX * C * src.ld), dev)
+                Ep, Pp = ws.data_ptr(), ws.data_ptr() + 4 * efl
+                _timed(R, "k_w2d_dy", 4.0 * (M + NX * T) * C, lambda: check(
+                    w2fn(lib, tile, "dy_transform")(dy.data_ptr(), ldy, Ep, N, H, W, C, s), "cvk_w2d_dy_transform"), "byte")
             _timed(R, "k_w2d_gemm_tn", 18.0 * M * C * self.cin, lambda: check(
                 w2fn(lib, tile, "gemm_tn")(Ep, Vkept.data_ptr(), Pp, T, src.ld, C, s), "cvk_w2d_gemm_tn"), executed=2.0 * NX * Tp * src.ld * C)
             _timed(R, "k_w2d_wgrad_out", 4.0 * (NX * f + 9) * C * self.cin, lambda: check(
@@ -1032,6 +1056,7 @@ class Runner:
         self.wino4f = WINO4F_DEFAULT
         self.wgradp = WGRADP_DEFAULT
         self.thin = os.environ.get("CVK_THIN", "1") != "0"    # csrc/thin.hip for the stem and the classifier head
+        self.w2both = os.environ.get("CVK_W2D_DY_BOTH", "1") != "0"   # one launch transforms dy for the data-grad and the weight-grad
         self.bnred_fuse = os.environ.get("CVK_BNRED_FUSE", "1") != "0"   # BN-backward sums in the fused data-grad's epilogue
         self.wino2d = WINO2D_DEFAULT
         self.w2tile_cfg = W2TILE_DEFAULT    # None = auto (see W2TILE_DEFAULT), 4 or 6 = forced

@@ -138,3 +138,24 @@ def test_weight_grad_vs_fp64(mt, N, H, W, Cin, Cout):
     got = outs[0].double().cpu()
     rel = ((got - ref).norm() / ref.norm()).item()
     assert rel < 2 * TOL[mt], rel
+
+
+@pytest.mark.parametrize("mt", [4, 6])
+@pytest.mark.parametrize("N,H,W,C", [(2, 12, 18, 64), (1, 22, 30, 256), (2, 45, 60, 128), (1, 5, 7, 96)])
+def test_both_transforms_of_dy_in_one_launch(mt, N, H, W, C):
+    """cvk_w*_dy_transform_both == (cvk_w*_input_transform(dy), cvk_w*_dy_transform(dy)) bit for bit: the backward pass of a block whose
+    data-grad and weight-grad both run the 2-D path (backward of nn.Conv2d, train.py:131) transforms dy once."""
+    lib, check = _lib()
+    f = fam(lib, mt)
+    g = torch.Generator().manual_seed(mt + H + W + C)
+    dy = torch.randn(N, H, W, C, generator=g).cuda()
+    nx = (mt + 2) ** 2
+    T = f("tiles")(N, H, W); Tp = lib.cvk_w2d_tpad(T)
+    n = nx * Tp * C
+    V0 = torch.full((n + 128,), float("nan"), device="cuda"); E0 = torch.full((n + 128,), float("nan"), device="cuda")
+    V1 = torch.full((n + 128,), float("nan"), device="cuda"); E1 = torch.full((n + 128,), float("nan"), device="cuda")
+    check(f("input_transform")(dy.data_ptr(), V0.data_ptr(), N, H, W, C, _s()), "input")
+    check(f("dy_transform")(dy.data_ptr(), C, E0.data_ptr(), N, H, W, C, _s()), "dy")
+    check(f("dy_transform_both")(dy.data_ptr(), C, V1.data_ptr(), E1.data_ptr(), N, H, W, C, _s()), "both")
+    torch.cuda.synchronize()
+    assert torch.equal(V1[:n], V0[:n]) and torch.equal(E1[:n], E0[:n])
