@@ -1,0 +1,417 @@
+// conv_bf16p.hip — 3x3 convolution on bf16 NHWC tensors, "ping-pong" kernel for the channel-heavy layers of
+// BASELINE.json configs[3] (forward of models/unet.py:11 nn.Conv2d(3x3, pad 1) and its data-grad; same arithmetic and
+// operand layout in HBM as conv_bf16s.hip: bf16 x bf16 on the matrix cores, fp32 accumulation, BatchNorm statistics partials
+// from the fp32 accumulators).
+//
+// Why a second kernel (round 4; PMC of k_conv_bf16s<128,*>, profiles/r04_a_pmc_mfma_bf16.json): the matrix pipe is busy 51 %
+// of the SIMD cycles.  There a wave does everything in turn — DMA issue (~100-180 cycles per 1 KiB piece), twelve fragment
+// reads, the counted vmcnt wait, 16 MFMAs, the barrier — and its SIMD partner is a wave of ANOTHER workgroup in a random phase:
+// the two collide on the pipe or leave it idle together.  Here the partner is chosen and the alternation is forced:
+//   * one workgroup = 8 waves = TWO groups of four (waves w and w+4 share a SIMD), one workgroup per CU;
+//   * an interval between two s_barriers is group A's MFMA phase (16 x v_mfma_f32_32x32x16_bf16 = 512 matrix cycles, nothing
+//     else in the stream, s_setprio 1) and group B's LOAD phase (its DMA pieces, the twelve ds_read_b128 of ITS next step, the
+//     waits), then the roles swap: the pipe of every SIMD always has exactly one wave's MFMAs queued;
+//   * both groups multiply the SAME weight tile (128 output channels x 32 input channels of one tap) with pixel rows of their own
+//     half of a 16 x 32 pixel tile: a tap's 8 KiB are staged once for 512 pixels (k_conv_bf16s: for 256), 1.6 DMA pieces per wave
+//     and step instead of 3;
+//   * the weight pack is TILE-MAJOR: the 8 KiB of (output-channel tile, slice, tap) are contiguous and already in LDS image order
+//     (swizzle applied by the pack kernel), so a tile's whole K loop streams one linear byte range — 1 KiB-contiguous DMA pieces
+//     instead of sixteen 64-byte row fragments, and the address of step s is base + 8192 s;
+//   * LDS: two halo slabs (18 x 34 pixels x 64 B, 40 KiB each: slice cs+1 lands during slice cs) + a ring of D+1 weight tiles
+//     (D = steps a tile is requested ahead of its first read); counted s_waitcnt vmcnt, raw s_barrier, DMA from inline asm.
+// Swizzles as in conv_bf16s.hip: 16-byte chunk c of halo pixel column hx at position c ^ ((hx>>2)&3) of its 64-byte row,
+// weights row n at c ^ ((n>>2)&3): every ds_read_b128 is bank-conflict free for all nine tap shifts (a halo row is 34 x 64 B =
+// 8.5 bank rows: all lanes of one read share the halo row, so the half-row phase is common to them).
+#include <stdlib.h>
+#include "cvk_common.h"
+#include "lds_dma.h"
+#include "conv_bf16p.h"
+
+namespace {
+using namespace cvk_bf16p;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HP = TW + 2;                      // halo row pitch in pixels
+constexpr int SLAB_ROWS = (TH + 2) * HP;        // 612 LDS rows (halo pixels) of 64 B
+constexpr int SLAB_PIECES = 40;                 // 16-row DMA pieces per slab: 5 per wave (rows 612..639 come from the zero page)
+constexpr int SLAB_BYTES = SLAB_PIECES * 1024;
+constexpr int BTAP = BN * 64;                   // 8 KiB: the weight tile of one tap and one channel slice
+static_assert(SLAB_PIECES * 16 >= SLAB_ROWS && SLAB_PIECES % 8 == 0, "slab pieces");
+
+
+__device__ __forceinline__ bf16x8 lds_read16(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+__device__ __forceinline__ void phase_barrier() {
+    // phase boundary: nothing moves across it (hipcc otherwise sinks MFMAs below a raw s_barrier and hoists fragment reads above it)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// LDS-DMA with the address arithmetic on the SCALAR unit (round-4 finding, tools/stamps_bf16p.py: with per-lane 64-bit addresses
+// the v_lshl_add_u64 + global_load_lds pair of a LOAD phase took ~550 cycles while the SIMD partner issued its 16 MFMAs —
+// the whole MFMA phase — against ~100 alone; the fragment reads beside it were not delayed).  Weights: 64-bit SGPR base + a
+// constant 32-bit lane offset.  Slab: buffer load with LDS destination, per-lane 32-bit byte offset (fixed per piece), the
+// channel slice in the scalar offset, out-of-frame lanes get an offset past the end of the image: the range check returns 0.
+__device__ __forceinline__ void dma16_saddr(unsigned voff, const void* sbase, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ void dma16_buf(unsigned voff, i32x4 rsrc, unsigned soff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_byte_addr) : "memory");
+}
+
+// Weights are requested D = 2 steps ahead of their first read into a ring of three tiles: 9 steps per slice, so the slot of a
+// step is a compile-time constant of the unrolled slice body and every fragment read is lane base + immediate.
+// STATS: BatchNorm statistics partials.  DBG (timing experiments only, wrong results): 1 = no DMA in the K loop, 2 = no MFMAs,
+// 4 = no fragment reads, 8 = s_memtime stamps of workgroup 0 -> `stats`.  VAR: 1 = no s_setprio.
+template <bool STATS, int DBG, int VAR = 0>
+__global__ __launch_bounds__(512, 2) void k_conv_bf16p(const __bf16* __restrict__ X, const char* __restrict__ Wp,
+                                                      const float* __restrict__ bias, __bf16* __restrict__ Y,
+                                                      float* __restrict__ stats, float* __restrict__ cnt, int H, int W, int Cin,
+                                                      int Cout, int ldy, int tilesX, int tilesY, int tilesN, int P) {
+    constexpr int D = 2, RING = 3;
+    constexpr int RING_BYTES = RING * BTAP;                       // [0, 24 KiB): weight ring; then the two slabs
+    constexpr int MAIN_BYTES = RING_BYTES + 2 * SLAB_BYTES;
+    constexpr int STAT_BYTES = BN * 128 * 2 * 4;      // epilogue: the staged output tile [512 px][256 B], then [channel][128 partials][sum, sumsq]
+    constexpr int STAMP_BYTES = (DBG & 8) ? 8 * 48 * 8 * 4 : 0;   // DBG 8: s_memtime stamps of the first 48 steps of workgroup 0 -> `stats`
+    constexpr int LDS_BYTES = (MAIN_BYTES > STAT_BYTES ? MAIN_BYTES : STAT_BYTES) + STAMP_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+    const unsigned smem_addr = cvk_lds_addr(smem);
+
+    unsigned long long ct0 = 0, ct1 = 0, ct2 = 0;   // DBG 16: s_memrealtime (100 MHz) at kernel start / after the prologue / after the K loop / at the end
+    if (DBG & 16) ct0 = __builtin_amdgcn_s_memrealtime();
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int grp = wave >> 2;                 // 0: tile rows 0..7, 1: rows 8..15; waves w and w + 4 share a SIMD
+    const int wc = wave & 1, wp = (wave >> 1) & 1;
+    const int row0 = grp * 8 + wp * 4;         // this wave's first tile row (four rows x 32 pixels x 64 output channels)
+
+    // ---- which tile: output-channel tiles innermost, XCD-contiguous chunks of the logical order ------------------------------
+    const int gid = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = gid % tilesN;
+    const int sp = gid / tilesN;                        // spatial tile = statistics partial index
+    const int tx = sp % tilesX;
+    const int ty = (sp / tilesX) % tilesY;
+    const int img = sp / (tilesX * tilesY);
+    const int x0 = tx * TW, y0 = ty * TH, n0 = nt * BN;
+    const int ncs = Cin / CK, nsteps = ncs * 9;
+
+    // ---- DMA sources ---------------------------------------------------------------------------------------------------------
+    // slab piece t (0..4) of this wave = piece 8t + wave: LDS rows 16 (8t + wave) + lane/4, 16-byte position lane % 4
+    unsigned aoff[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int row = (8 * t + wave) * 16 + (lane >> 2);
+        const int hy = row / HP, hx = row - hy * HP;
+        const int chunk = (lane & 3) ^ ((hx >> 2) & 3);
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = (row < SLAB_ROWS) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+        aoff[t] = ok ? (unsigned)((iy * W + ix) * Cin + chunk * 8) * 2u : 0x80000000u;     // bytes; past the end: reads 0
+    }
+    const uintptr_t xbase = (uintptr_t)(X + (size_t)img * H * W * Cin);      // raw buffer over this image: base, stride 0, bytes, flags
+    i32x4 xrsrc;
+    xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xbase);
+    xrsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xbase >> 32) & 0xFFFF);
+    xrsrc[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)(H * W * Cin) * 2u));
+    xrsrc[3] = 0x00020000;
+    // the tile's weight stream: step s (= 9 cs + tap) is the 8 KiB at s * BTAP; this wave moves piece `wave` of every step
+    const unsigned wvoff = wave * 1024 + lane * 16;
+    const char* wnext = Wp + (size_t)nt * nsteps * BTAP;          // scalar: the tile of the next step to request
+
+    auto dma_slab_piece = [&](int t, int cs, unsigned slab_addr) { dma16_buf(aoff[t], xrsrc, (unsigned)cs * (CK * 2), slab_addr + (8 * t + wave) * 1024); };
+    auto dma_weights_next = [&](int slot, int s) {      // request step s into ring slot `slot`; past the end the last step is re-loaded
+        dma16_saddr(wvoff, wnext, smem_addr + slot * BTAP + wave * 1024);
+        if (s < nsteps - 1) wnext += BTAP;
+    };
+
+    // ---- operand read addresses (LDS byte offsets) ---------------------------------------------------------------------------------
+    // weights (MFMA A operand): row n = wc*64 + tc*32 + r, k-chunk 2kk + h at position (2kk + h) ^ ((n>>2)&3); slot, tc: immediates
+    const int nrow = wc * 64 + r;
+    int wa[2];
+    wa[0] = nrow * 64 + ((h ^ ((nrow >> 2) & 3)) << 4);
+    wa[1] = wa[0] ^ 32;
+    // pixels (MFMA B operand): tile row row0 + tp, tap (dy, dx): halo row row0 + tp + dy, halo column r + dx; rows: immediates
+    int pb[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        pb[dx][0] = RING_BYTES + row0 * (HP * 64) + (r + dx) * 64 + ((h ^ (((r + dx) >> 2) & 3)) << 4);
+        pb[dx][1] = pb[dx][0] ^ 32;
+    }
+    int pb_flip = SLAB_BYTES;                 // added to pb[][] at the end of a slice (alternating sign): the other slab
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    // ---- prologue: slab of slice 0, weight tiles of steps 0 and 1 ----------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < 5; ++t) dma_slab_piece(t, 0, smem_addr + RING_BYTES);
+    dma_weights_next(0, 0);
+    dma_weights_next(1, 1);
+    cvk_wait_vm<D - 1>();                      // everything but the weights of step 1 has landed
+    phase_barrier();
+    if (DBG & 16) ct1 = __builtin_amdgcn_s_memrealtime();
+    if (grp == 1) phase_barrier();             // group B runs one interval behind group A
+
+    int step = 0;
+    for (int cs = 0; cs < ncs; ++cs) {
+        const unsigned slab_next = smem_addr + RING_BYTES + ((cs + 1) & 1) * SLAB_BYTES;
+        const int csn = min(cs + 1, ncs - 1);     // past the end the last slice is re-loaded into the buffer nobody reads
+#pragma unroll
+        for (int sidx = 0; sidx < 9; ++sidx, ++step) {
+            // ======== LOAD phase (the other group's MFMA phase): scalar instructions, DMA issue, fragment reads, waits =============
+            unsigned long long tm0 = 0, tm1 = 0, tm3 = 0, tm4 = 0, tm5 = 0, tm6 = 0;
+            if (DBG & 8) tm0 = __builtin_amdgcn_s_memtime();
+            if (!(DBG & 1)) {
+                dma_weights_next((sidx + D) % RING, step + D);
+                if (sidx < 5) dma_slab_piece(sidx, csn, slab_next);
+            }
+            if (DBG & 8) { tm1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+            const int dy = sidx / 3, dx = sidx % 3, slot = sidx % RING;
+            bf16x8 a[2][2], b[4][2];
+            if (!(DBG & 4)) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                    for (int tc = 0; tc < 2; ++tc) a[tc][kk] = lds_read16(smem + (wa[kk] + slot * BTAP + tc * 32 * 64));
+#pragma unroll
+                    for (int tp = 0; tp < 4; ++tp) b[tp][kk] = lds_read16(smem + (pb[dx][kk] + (tp + dy) * (HP * 64)));
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                    for (int tc = 0; tc < 2; ++tc) asm volatile("" : "=v"(a[tc][kk]));
+#pragma unroll
+                    for (int tp = 0; tp < 4; ++tp) asm volatile("" : "=v"(b[tp][kk]));
+                }
+            }
+            // the fragments are in registers (this step's ring slot and slab rows may be refilled from the next interval on), and
+            // everything this wave requested before this phase has landed (its piece of the weights of step + 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (DBG & 8) { __builtin_amdgcn_sched_barrier(0); tm3 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+            if (!(DBG & 1)) {
+                if (sidx < 5) cvk_wait_vm<2>(); else cvk_wait_vm<1>();
+            }
+            if (DBG & 8) { __builtin_amdgcn_sched_barrier(0); tm4 = __builtin_amdgcn_s_memtime(); }
+            phase_barrier();
+            if (DBG & 8) { tm5 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+            // ======== MFMA phase ====================================================================================================
+            if (!(VAR & 1)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+                    for (int tp = 0; tp < 4; ++tp) {
+                        if (!(DBG & 2)) acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tc][kk], b[tp][kk], acc[tc][tp], 0, 0, 0);
+                        else asm volatile("" :: "v"(a[tc][kk]), "v"(b[tp][kk]));
+                    }
+            if (sidx == 8) {                   // the next slice reads the other slab
+#pragma unroll
+                for (int dx2 = 0; dx2 < 3; ++dx2) { pb[dx2][0] += pb_flip; pb[dx2][1] += pb_flip; }
+                pb_flip = -pb_flip;
+            }
+            if (!(VAR & 1)) __builtin_amdgcn_s_setprio(0);
+            if (DBG & 8) {
+                __builtin_amdgcn_sched_barrier(0);
+                tm6 = __builtin_amdgcn_s_memtime();
+                if (blockIdx.x == 0 && step < 48 && lane == 0) {
+                    unsigned* p = reinterpret_cast<unsigned*>(smem + MAIN_BYTES) + (wave * 48 + step) * 8;
+                    p[0] = (unsigned)tm0; p[1] = (unsigned)tm1; p[2] = (unsigned)tm3; p[3] = (unsigned)tm4; p[4] = (unsigned)tm5; p[5] = (unsigned)tm6;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            phase_barrier();
+        }
+    }
+    if (grp == 0) phase_barrier();      // group A's last barrier pairs with group B's last MFMA phase
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // tail DMAs landed: LDS is reused below
+    phase_barrier();
+    if (DBG & 16) ct2 = __builtin_amdgcn_s_memrealtime();
+    if ((DBG & 8) && blockIdx.x == 0 && stats != nullptr) {
+        const unsigned* p = reinterpret_cast<const unsigned*>(smem + MAIN_BYTES);
+        for (int i = tid; i < 8 * 48 * 8; i += 512) reinterpret_cast<unsigned*>(stats)[i] = p[i];
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------------------------------------------
+    // acc[tc][tp][i]: output channel n0 + wc*64 + tc*32 + (i&3) + 8*(i>>2) + 4*h, pixel (y0 + row0 + tp, x0 + r).
+    // A lane holds 4 consecutive channels (8 bytes) of 32 pixels that lie 2 ldy bytes apart: stored from here, a wave instruction
+    // is 32 scattered 16-byte pieces and the epilogue is store-issue bound (measured: 15-19 us per tile with every CU in its epilogue,
+    // against 24 us for the whole K loop of a 128-channel layer, tools/coarse_bf16p.py).  So the tile is transposed through LDS (dead by
+    // now): [512 pixels][256 B], 16-byte chunk c of pixel p at position c ^ (p & 15) (conflict-free both ways), and leaves as
+    // 16 bytes per lane, 256 contiguous bytes per pixel, 1 KiB per wave instruction.
+    const int px = x0 + r;
+    const bool colok = px < W;
+    float s[2][16], q[2][16];
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = n0 + wc * 64 + tc * 32 + 8 * g + 4 * h;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (bias != nullptr && co < Cout) bv = *reinterpret_cast<const f32x4*>(bias + co);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[tc][4 * g + j] = 0.f; q[tc][4 * g + j] = 0.f; }
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) {
+                const bool ok = colok & (y0 + row0 + tp < H);
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[tc][tp][4 * g + j] + bv[j];
+                if (STATS) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float vm = ok ? v[j] : 0.f;
+                        s[tc][4 * g + j] += vm;
+                        q[tc][4 * g + j] += vm * vm;
+                    }
+                }
+                const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                const int p = (row0 + tp) * 32 + r, chunk = wc * 8 + tc * 4 + g;
+                *reinterpret_cast<bf16x4*>(smem + p * 256 + ((chunk ^ (p & 15)) << 4) + 8 * h) = o;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        // wave w stores tile rows 2w, 2w + 1: 16 instructions of 4 pixels x 256 B
+        const int chunk = lane & 15, co = n0 + chunk * 8;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int p = wave * 64 + it * 4 + (lane >> 4);
+            const int py = y0 + (p >> 5), pxx = x0 + (p & 31);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(smem + p * 256 + ((chunk ^ (p & 15)) << 4));
+            if ((py < H) & (pxx < W) & (co < ldy))
+                *reinterpret_cast<f32x4*>(Y + ((size_t)(img * H + py) * W + pxx) * ldy + co) = v;
+        }
+    }
+    if ((DBG & 16) && stats != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const unsigned long long ct3 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(stats) + (size_t)blockIdx.x * 4;
+            o[0] = ct0; o[1] = ct1; o[2] = ct2; o[3] = ct3;
+        }
+    }
+    if (!STATS) return;
+    __syncthreads();                    // the staged tile has been read: the statistics scratch overlays it
+    // per channel: 32 lanes x 4 waves (2 groups x 2 row halves) hold partial (sum, sum of squares) -> LDS [channel][128 partials][2]
+    float* const red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ch = wc * 64 + tc * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int part = (grp * 2 + wp) * 32 + r;
+            const float2 v2 = {s[tc][i], q[tc][i]};
+            *reinterpret_cast<float2*>(red + ((size_t)ch * 128 + part) * 2) = v2;
+        }
+    __syncthreads();
+    {
+        // 512 threads: 128 channels x 4 segments of 32 partials, fp64, fixed order; the segments of a channel sit in neighbouring lanes
+        const int chl = tid >> 2, sg = tid & 3;
+        const float2* p = reinterpret_cast<const float2*>(red) + (size_t)chl * 128 + sg * 32;
+        double S = 0.0, Q = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) { S += (double)p[i].x; Q += (double)p[i].y; }
+#pragma unroll
+        for (int o = 1; o < 4; o <<= 1) {
+            S += __shfl_xor(S, o, 64);
+            Q += __shfl_xor(Q, o, 64);
+        }
+        const int co = n0 + chl;
+        const int nvalid = min(TH, H - y0) * min(TW, W - x0);
+        if (sg == 0 && co < Cout) {
+            const double m2 = Q - S * S / (double)nvalid;
+            stats[(size_t)sp * Cout + co] = (float)S;
+            stats[(size_t)(P + sp) * Cout + co] = (float)(m2 > 0.0 ? m2 : 0.0);
+        }
+        if (nt == 0 && tid == 0) cnt[sp] = (float)nvalid;
+    }
+}
+
+// fp32 master weights, physical [Cout][3][3][Cin] -> tile-major bf16 pack [row tile][slice][tap][128 rows][4 chunks][8], chunk
+// position p of row n holds source chunk p ^ ((n>>2)&3) (the LDS image of one DMA'd tap tile, byte for byte); zero padded.
+// dgrad: rows are the INPUT channels of the layer, k runs over its output channels, taps rotated by 180 degrees.
+__global__ void k_pack_w_pp(const float* __restrict__ w, __bf16* __restrict__ out, int Cout, int Cin, int ntile, int ncs, int dgrad) {
+    const size_t total = (size_t)ntile * ncs * 9 * BN * CK;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7), p = (int)((i >> 3) & 3), n = (int)((i >> 5) & (BN - 1));
+        size_t rest = i >> 12;
+        const int tap = (int)(rest % 9); rest /= 9;
+        const int cs = (int)(rest % ncs);
+        const int ntl = (int)(rest / ncs);
+        const int row = ntl * BN + n;
+        const int k = cs * CK + ((p ^ ((n >> 2) & 3)) << 3) + e;
+        float v = 0.f;
+        if (!dgrad) { if (row < Cout && k < Cin) v = w[((size_t)row * 9 + tap) * Cin + k]; }
+        else        { if (row < Cin && k < Cout) v = w[((size_t)k * 9 + (8 - tap)) * Cin + row]; }
+        out[i] = (__bf16)v;
+    }
+}
+
+}  // namespace
+
+namespace cvk_bf16p {
+
+bool serves(int Cin, int Cout) {
+    static const int on = getenv("CVK_BF16P") ? atoi(getenv("CVK_BF16P")) : 1;
+    return on && Cout > 64 && Cin >= 128 && Cin % CK == 0;
+}
+
+int stat_partials(int N, int H, int W) { return N * cvk_cdiv(H, TH) * cvk_cdiv(W, TW); }
+
+void pack(const float* w, void* out, int Cout, int Cin, int Kpad, bool dgrad, hipStream_t s) {
+    const int rows = dgrad ? Cin : Cout;
+    const int ntile = cvk_cdiv(rows, BN), ncs = Kpad / CK;
+    const size_t total = (size_t)ntile * ncs * 9 * BN * CK;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_pack_w_pp, dim3(blocks), dim3(256), 0, s, w, (__bf16*)out, Cout, Cin, ntile, ncs, dgrad ? 1 : 0);
+}
+
+void launch(const void* x, const void* wpp, const float* bias, void* y, float* stats, float* counts, int N, int H, int W, int Cin,
+            int Cout, int ldy, hipStream_t s) {
+    const int tilesX = cvk_cdiv(W, TW), tilesY = cvk_cdiv(H, TH), tilesN = cvk_cdiv(Cout, BN);
+    const int P = N * tilesX * tilesY;
+    dim3 grid((unsigned)(P * tilesN)), block(512);
+    static const int dbg = getenv("CVK_BF16P_DBG") ? atoi(getenv("CVK_BF16P_DBG")) : 0;      // timing experiments only
+    static const int var = getenv("CVK_BF16P_VAR") ? atoi(getenv("CVK_BF16P_VAR")) : 0;
+#define CVK_PP(ST_, DBG_, V_)                                                                                                              \
+    hipLaunchKernelGGL((k_conv_bf16p<ST_, DBG_, V_>), grid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, \
+                       H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P)
+    if (dbg == 0 && var == 0) {
+        if (stats) CVK_PP(true, 0, 0); else CVK_PP(false, 0, 0);
+    } else if (dbg == 0) {
+        CVK_PP(false, 0, 1);
+    } else {
+        switch (dbg) {
+            case 1: CVK_PP(false, 1, 0); break;
+            case 2: CVK_PP(false, 2, 0); break;
+            case 3: CVK_PP(false, 3, 0); break;
+            case 4: CVK_PP(false, 4, 0); break;
+            case 5: CVK_PP(false, 5, 0); break;
+            case 6: CVK_PP(false, 6, 0); break;
+            case 8: CVK_PP(false, 8, 0); break;
+            case 9: CVK_PP(false, 9, 0); break;
+            case 12: CVK_PP(false, 12, 0); break;
+            case 16: CVK_PP(false, 16, 0); break;
+            default: CVK_PP(false, 7, 0); break;
+        }
+    }
+#undef CVK_PP
+}
+
+}  // namespace cvk_bf16p

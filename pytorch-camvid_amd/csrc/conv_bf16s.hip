@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "cvk_common.h"
+#include "conv_bf16p.h"
 
 namespace {
 
@@ -602,6 +603,7 @@ static int strip_len_for(int ntiles) {
 /* number of BatchNorm-statistics partials cvk_conv3x3_bf16s writes for this layer */
 extern "C" int cvk_bf16s_stat_partials_c(int N, int H, int W, int Cin, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    if (cvk_bf16p::serves(Cin, Cout)) return cvk_bf16p::stat_partials(N, H, W);      // one partial per 16 x 32 pixel tile
     const int ntiles = N * cvk_cdiv(H, TH) * cvk_cdiv(W, TW);
     if (!use_strip(Cin, Cout)) return ntiles;
     return cvk_cdiv(ntiles, strip_len_for(ntiles));
@@ -615,6 +617,10 @@ extern "C" int cvk_bf16s_stat_partials(int N, int H, int W) {       /* upper bou
 extern "C" int cvk_pack_weight_fwd_bf16(const float* w, void* out, int Cout, int Cin, int Cin_pad, void* stream) {
     CVK_CHECK_ARG(w && out && Cout > 0 && Cin > 0 && Cin_pad >= Cin && Cin_pad % CK == 0, "cvk_pack_weight_fwd_bf16: bad arguments");
     const int rows = cvk_bf16s_rows_pad(Cout);
+    if (cvk_bf16p::serves(Cin_pad, Cout)) {      // tile-major pack of the ping-pong kernel (same size)
+        cvk_bf16p::pack(w, out, Cout, Cin, Cin_pad, false, (hipStream_t)stream);
+        CVK_LAUNCH_RETURN("cvk_pack_weight_fwd_bf16");
+    }
     const size_t total = (size_t)rows * 9 * Cin_pad;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(k_pack_w_fwd_bf16, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)out, Cout, Cin, rows, Cin_pad);
@@ -624,6 +630,10 @@ extern "C" int cvk_pack_weight_fwd_bf16(const float* w, void* out, int Cout, int
 extern "C" int cvk_pack_weight_dgrad_bf16(const float* w, void* out, int Cout, int Cin, int Cout_pad, void* stream) {
     CVK_CHECK_ARG(w && out && Cout > 0 && Cin > 0 && Cout_pad >= Cout && Cout_pad % CK == 0, "cvk_pack_weight_dgrad_bf16: bad arguments");
     const int rows = cvk_bf16s_rows_pad(Cin);
+    if (cvk_bf16p::serves(Cout_pad, Cin)) {      // the data-grad is a convolution Cout_pad -> Cin channels
+        cvk_bf16p::pack(w, out, Cout, Cin, Cout_pad, true, (hipStream_t)stream);
+        CVK_LAUNCH_RETURN("cvk_pack_weight_dgrad_bf16");
+    }
     const size_t total = (size_t)rows * 9 * Cout_pad;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(k_pack_w_dgrad_bf16, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)out, Cout, Cin, rows, Cout_pad);
@@ -645,6 +655,14 @@ extern "C" int cvk_conv3x3_bf16s(const void* x, const void* w, const float* bias
     const long P = (long)N * tilesX * tilesY;
     CVK_CHECK_ARG(P * tilesN < (1L << 31), "cvk_conv3x3_bf16s: grid too large");
     hipStream_t s = (hipStream_t)stream;
+    if (cvk_bf16p::serves(Cin, Cout)) {
+        // the ping-pong kernel stores 16 bytes per lane and addresses one image through a raw buffer (32-bit byte offsets, an
+        // offset of 2^31 marks an out-of-frame pixel)
+        CVK_CHECK_ARG(cvk_aligned16(y) && ldy % 8 == 0, "cvk_conv3x3_bf16s: layers with > 64 output and >= 128 input channels need a 16-byte aligned y and ldy %% 8 == 0");
+        CVK_CHECK_ARG((long)H * W * Cin * 2 < (1L << 31), "cvk_conv3x3_bf16s: one image exceeds 2 GiB");
+        cvk_bf16p::launch(x, w, bias, y, stats, counts, N, H, W, Cin, Cout, ldy, s);
+        CVK_LAUNCH_RETURN("cvk_conv3x3_bf16s");
+    }
     dim3 grid((unsigned)(P * tilesN)), block(256);
 #define CVK_BS_LAUNCH(BN_, ST_)                                                                                              \
     hipLaunchKernelGGL((k_conv_bf16s<BN_, ST_>), grid, block, 0, s, (const __bf16*)x, (const __bf16*)w, bias, (__bf16*)y, stats, counts, \

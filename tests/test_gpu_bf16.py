@@ -32,6 +32,9 @@ def rb(t):
 CONV_CASES = [  # (N, H, W, Cin, Cout)  ragged tiles, one / many channel slices, both output tiles, stem- and head-like padding
     (2, 8, 32, 32, 64), (1, 13, 45, 64, 128), (2, 9, 70, 32, 12), (1, 24, 40, 128, 256), (3, 5, 7, 64, 64), (1, 17, 33, 96, 192),
     (2, 19, 37, 128, 64),      # its data-grad is 64 -> 128 channels: two passes of the 64 x 64 strip kernel
+    # the ping-pong kernel (csrc/conv_bf16p.hip: > 64 output and >= 128 input channels), forward and data-grad: ragged 16 x 32 pixel
+    # tiles, a ragged last output-channel tile, one / several image rows of tiles, an odd number of channel slices
+    (1, 35, 66, 160, 160), (2, 16, 32, 128, 128), (1, 50, 31, 256, 320), (3, 7, 9, 128, 192),
 ]
 
 
@@ -209,7 +212,8 @@ def test_unet_bf16_vs_emulation_2x96x128():
         assert torch.equal(a.grad, b.grad)
 
 
-@pytest.mark.parametrize("case", [(4, 360, 480, 64, 128), (4, 180, 240, 256, 256), (4, 45, 60, 1024, 1024), (4, 720, 960, 64, 64), (4, 360, 480, 128, 64)])
+@pytest.mark.parametrize("case", [(4, 360, 480, 64, 128), (4, 180, 240, 256, 256), (4, 45, 60, 1024, 1024), (4, 720, 960, 64, 64), (4, 360, 480, 128, 64),
+                                  (4, 360, 480, 128, 128), (4, 90, 120, 512, 512), (4, 360, 480, 256, 128)])
 def test_bf16_kernels_fullsize_exact_and_deterministic(case):
     """Every bf16-storage conv kernel at grids with two workgroups per CU (the configs[3] layer sizes), three times on the
     same operands: forward with and without the fused statistics epilogue, data-grad and weight-grad must be bitwise

@@ -1,10 +1,16 @@
 #!/bin/bash
 # HBM traffic of the conv kernels from PMC counters (separate passes, as MI355X_MICROARCH.md §HBM prescribes).
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run on the GPU box through gpurun)}"
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+BENCH_ARGS=${BENCH_ARGS:-}
 for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf gpurun_out/pmc_$c
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile $BENCH_ARGS > /dev/null 2> gpurun_out/pmc_$c.err
+  ls gpurun_out/pmc_$c/*/*counter_collection.csv > /dev/null
 done
-python - <<'PY'
+python3 - <<'PY'
 import csv, glob, collections, json
 res = collections.defaultdict(lambda: {"n": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "t": 0.0})
 for c in ("FETCH_SIZE", "WRITE_SIZE"):

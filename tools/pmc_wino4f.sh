@@ -3,13 +3,18 @@
 # usage: tools/pmc_wino4f.sh "64 64 360 480"
 ARGS=${1:-"64 64 360 480"}
 OUT=gpurun_out/pmc_w4f
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run on the GPU box through gpurun)}"
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+rm -rf $OUT          # passes of earlier ARGS must not be summed into this summary
 mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVE_CYCLES" \
          "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $c | cut -d' ' -f1)
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$tag -- python3 tools/run_wino4f.py $ARGS > /dev/null 2> $OUT/$tag.err
+  ls $OUT/$tag/*/*counter_collection.csv > /dev/null
 done
 python3 - <<'PY'
 import csv, glob, collections, json
