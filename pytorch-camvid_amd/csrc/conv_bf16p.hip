@@ -43,6 +43,18 @@ static_assert(SLAB_PIECES * 16 >= SLAB_ROWS && SLAB_PIECES % 8 == 0, "slab piece
 
 __device__ __forceinline__ bf16x8 lds_read16(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
+// sum over the 16 lanes of a DPP row, result in every lane of the row; fixed tree
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);     // row_half_mirror
+    v = dpp_add<0x140>(v);     // row_mirror
+    return v;
+}
+
 __device__ __forceinline__ void phase_barrier() {
     // phase boundary: nothing moves across it (hipcc otherwise sinks MFMAs below a raw s_barrier and hoists fragment reads above it)
     __builtin_amdgcn_sched_barrier(0);
@@ -307,34 +319,239 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16p(const __bf16* __restrict_
         }
     }
     if (!STATS) return;
-    __syncthreads();                    // the staged tile has been read: the statistics scratch overlays it
-    // per channel: 32 lanes x 4 waves (2 groups x 2 row halves) hold partial (sum, sum of squares) -> LDS [channel][128 partials][2]
-    float* const red = reinterpret_cast<float*>(smem);
+    // Statistics: a lane holds (sum, sum of squares) of 32 channels over its 4 tile rows; the 16 lanes of a DPP row hold the same
+    // channels for 16 pixel columns.  Four DPP adds per value (quad butterflies, half-row mirror, row mirror: a fixed tree) leave the
+    // row total in every lane of the row — 256 vector instructions instead of a 128 KiB round trip through LDS with fp64 adds
+    // (measured: 5.5 us of a 34 us tile).  8 partials per channel (2 rows x 4 waves) meet in LDS and are combined in fp64 in a fixed order.
+    __syncthreads();                    // the staged tile has been read: the partials overlay it
 #pragma unroll
     for (int tc = 0; tc < 2; ++tc)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int ch = wc * 64 + tc * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            const int part = (grp * 2 + wp) * 32 + r;
-            const float2 v2 = {s[tc][i], q[tc][i]};
-            *reinterpret_cast<float2*>(red + ((size_t)ch * 128 + part) * 2) = v2;
+            s[tc][i] = row_sum16(s[tc][i]);
+            q[tc][i] = row_sum16(q[tc][i]);
         }
+    float2* const red = reinterpret_cast<float2*>(smem);          // [channel 128][partial 8]
+    if ((lane & 15) == 0) {
+        const int part = (grp * 2 + wp) * 2 + ((lane >> 4) & 1);
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ch = wc * 64 + tc * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                red[ch * 8 + part] = float2{s[tc][i], q[tc][i]};
+            }
+    }
+    __syncthreads();
+    if (tid < BN) {
+        double S = 0.0, Q = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float2 v = red[tid * 8 + i]; S += (double)v.x; Q += (double)v.y; }
+        const int co = n0 + tid;
+        const int nvalid = min(TH, H - y0) * min(TW, W - x0);
+        if (co < Cout) {
+            const double m2 = Q - S * S / (double)nvalid;
+            stats[(size_t)sp * Cout + co] = (float)S;
+            stats[(size_t)(P + sp) * Cout + co] = (float)(m2 > 0.0 ? m2 : 0.0);
+        }
+        if (nt == 0 && tid == 0) cnt[sp] = (float)nvalid;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- the same on v_mfma_f32_16x16x32_bf16
+// MI355X_MICROARCH.md (DVFS give-back, item 7): in MFMA-bound bf16 loops on random data the chip holds a higher clock on the
+// 16x16x32 shape than on 32x32x16 at equal cycles per FLOP (measured there: 1.12-1.15x the FLOP/s).  Same phases, same LDS budget,
+// same DMA; what changes is the fragment geometry:
+//   * a fragment is 16 rows x 32 k = ONE ds_read_b128 per lane for the whole K slice (lane: row l15 = lane & 15, 16-byte chunk
+//     q4 = lane >> 4 of the 64-byte row): 4 weight + 8 pixel fragments and 32 MFMAs (16 cycles each) per step — the same 12 reads
+//     and 512 matrix cycles — and ONE lane address per operand and column shift (no k-half variants);
+//   * swizzle: chunk c of a row (weights: row n; pixels: halo column hx) at position c ^ (2 * ((row >> 2) & 1)) — conflict-free
+//     for the 16-row x 4-chunk read pattern at every column shift (brute-forced over the ds_read_b128 lane groups);
+//   * D: lane (l15, q4) holds channels 4 q4 .. 4 q4 + 3 of the 16-channel block for pixel column l15 of the 16-pixel block:
+//     32 accumulators of 4 registers; statistics: 16 (sum, sumsq) pairs per lane, the 16 lanes of a DPP row share their channels.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <bool STATS>
+__global__ __launch_bounds__(512, 2) void k_conv_bf16q(const __bf16* __restrict__ X, const char* __restrict__ Wp,
+                                                      const float* __restrict__ bias, __bf16* __restrict__ Y,
+                                                      float* __restrict__ stats, float* __restrict__ cnt, int H, int W, int Cin,
+                                                      int Cout, int ldy, int tilesX, int tilesY, int tilesN, int P) {
+    constexpr int D = 2, RING = 3;
+    constexpr int RING_BYTES = RING * BTAP;
+    constexpr int MAIN_BYTES = RING_BYTES + 2 * SLAB_BYTES;
+    constexpr int STAGE_BYTES = TH * TW * BN * 2;                 // the staged output tile [512 px][256 B]
+    constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+    const unsigned smem_addr = cvk_lds_addr(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int grp = wave >> 2;
+    const int wc = wave & 1, wp = (wave >> 1) & 1;
+    const int row0 = grp * 8 + wp * 4;
+
+    const int gid = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = gid % tilesN;
+    const int sp = gid / tilesN;
+    const int tx = sp % tilesX;
+    const int ty = (sp / tilesX) % tilesY;
+    const int img = sp / (tilesX * tilesY);
+    const int x0 = tx * TW, y0 = ty * TH, n0 = nt * BN;
+    const int ncs = Cin / CK, nsteps = ncs * 9;
+
+    unsigned aoff[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int row = (8 * t + wave) * 16 + (lane >> 2);
+        const int hy = row / HP, hx = row - hy * HP;
+        const int chunk = (lane & 3) ^ (((hx >> 2) & 1) << 1);
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = (row < SLAB_ROWS) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+        aoff[t] = ok ? (unsigned)((iy * W + ix) * Cin + chunk * 8) * 2u : 0x80000000u;
+    }
+    const uintptr_t xbase = (uintptr_t)(X + (size_t)img * H * W * Cin);
+    i32x4 xrsrc;
+    xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xbase);
+    xrsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xbase >> 32) & 0xFFFF);
+    xrsrc[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)(H * W * Cin) * 2u));
+    xrsrc[3] = 0x00020000;
+    const unsigned wvoff = wave * 1024 + lane * 16;
+    const char* wnext = Wp + (size_t)nt * nsteps * BTAP;
+
+    auto dma_slab_piece = [&](int t, int cs, unsigned slab_addr) { dma16_buf(aoff[t], xrsrc, (unsigned)cs * (CK * 2), slab_addr + (8 * t + wave) * 1024); };
+    auto dma_weights_next = [&](int slot, int s) {
+        dma16_saddr(wvoff, wnext, smem_addr + slot * BTAP + wave * 1024);
+        if (s < nsteps - 1) wnext += BTAP;
+    };
+
+    // weights: row wc*64 + rb*16 + l15, chunk q4; pixels: halo row row0 + tp + dy, halo column half*16 + l15 + dx, chunk q4
+    const int wa = (wc * 64 + l15) * 64 + ((q4 ^ (((l15 >> 2) & 1) << 1)) << 4);
+    int pb[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) pb[dx] = RING_BYTES + row0 * (HP * 64) + (l15 + dx) * 64 + ((q4 ^ ((((l15 + dx) >> 2) & 1) << 1)) << 4);
+    int pb_flip = SLAB_BYTES;
+
+    f32x4v acc[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int t = 0; t < 5; ++t) dma_slab_piece(t, 0, smem_addr + RING_BYTES);
+    dma_weights_next(0, 0);
+    dma_weights_next(1, 1);
+    cvk_wait_vm<D - 1>();
+    phase_barrier();
+    if (grp == 1) phase_barrier();
+
+    int step = 0;
+    for (int cs = 0; cs < ncs; ++cs) {
+        const unsigned slab_next = smem_addr + RING_BYTES + ((cs + 1) & 1) * SLAB_BYTES;
+        const int csn = min(cs + 1, ncs - 1);
+#pragma unroll
+        for (int sidx = 0; sidx < 9; ++sidx, ++step) {
+            // ======== LOAD phase
+            dma_weights_next((sidx + D) % RING, step + D);
+            if (sidx < 5) dma_slab_piece(sidx, csn, slab_next);
+            const int dy = sidx / 3, dx = sidx % 3, slot = sidx % RING;
+            bf16x8 a[4], b[8];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) a[rb] = lds_read16(smem + (wa + slot * BTAP + rb * 16 * 64));
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) b[cb] = lds_read16(smem + (pb[dx] + ((cb >> 1) + dy) * (HP * 64) + (cb & 1) * 16 * 64));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (sidx < 5) cvk_wait_vm<2>(); else cvk_wait_vm<1>();
+            phase_barrier();
+            // ======== MFMA phase
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb)
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb], b[cb], acc[rb][cb], 0, 0, 0);
+            if (sidx == 8) {
+#pragma unroll
+                for (int dx2 = 0; dx2 < 3; ++dx2) pb[dx2] += pb_flip;
+                pb_flip = -pb_flip;
+            }
+            __builtin_amdgcn_s_setprio(0);
+            phase_barrier();
+        }
+    }
+    if (grp == 0) phase_barrier();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    phase_barrier();
+
+    // ---- epilogue: bias, statistics, transpose through LDS (see k_conv_bf16p), 16-byte stores ------------------------------------
+    // acc[rb][cb][i]: channel n0 + wc*64 + rb*16 + 4*q4 + i, pixel (y0 + row0 + (cb >> 1), x0 + (cb & 1)*16 + l15)
+    float s[4][4], q[4][4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        const int co = n0 + wc * 64 + rb * 16 + 4 * q4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias != nullptr && co < Cout) bv = *reinterpret_cast<const f32x4*>(bias + co);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[rb][j] = 0.f; q[rb][j] = 0.f; }
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) {
+            const bool ok = (x0 + (cb & 1) * 16 + l15 < W) & (y0 + row0 + (cb >> 1) < H);
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[rb][cb][j] + bv[j];
+            if (STATS) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float vm = ok ? v[j] : 0.f;
+                    s[rb][j] += vm;
+                    q[rb][j] += vm * vm;
+                }
+            }
+            const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            const int p = (row0 + (cb >> 1)) * 32 + (cb & 1) * 16 + l15, chunk = wc * 8 + rb * 2 + (q4 >> 1);
+            *reinterpret_cast<bf16x4*>(smem + p * 256 + ((chunk ^ (p & 15)) << 4) + 8 * (q4 & 1)) = o;
+        }
+    }
     __syncthreads();
     {
-        // 512 threads: 128 channels x 4 segments of 32 partials, fp64, fixed order; the segments of a channel sit in neighbouring lanes
-        const int chl = tid >> 2, sg = tid & 3;
-        const float2* p = reinterpret_cast<const float2*>(red) + (size_t)chl * 128 + sg * 32;
-        double S = 0.0, Q = 0.0;
-#pragma unroll 8
-        for (int i = 0; i < 32; ++i) { S += (double)p[i].x; Q += (double)p[i].y; }
+        const int chunk = lane & 15, co = n0 + chunk * 8;
 #pragma unroll
-        for (int o = 1; o < 4; o <<= 1) {
-            S += __shfl_xor(S, o, 64);
-            Q += __shfl_xor(Q, o, 64);
+        for (int it = 0; it < 16; ++it) {
+            const int p = wave * 64 + it * 4 + (lane >> 4);
+            const int py = y0 + (p >> 5), pxx = x0 + (p & 31);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(smem + p * 256 + ((chunk ^ (p & 15)) << 4));
+            if ((py < H) & (pxx < W) & (co < ldy))
+                *reinterpret_cast<f32x4*>(Y + ((size_t)(img * H + py) * W + pxx) * ldy + co) = v;
         }
-        const int co = n0 + chl;
+    }
+    if (!STATS) return;
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[rb][j] = row_sum16(s[rb][j]);
+            q[rb][j] = row_sum16(q[rb][j]);
+        }
+    float2* const red = reinterpret_cast<float2*>(smem);          // [channel 128][partial 4]
+    if (l15 == 0) {
+        const int part = grp * 2 + wp;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[(wc * 64 + rb * 16 + 4 * q4 + j) * 4 + part] = float2{s[rb][j], q[rb][j]};
+    }
+    __syncthreads();
+    if (tid < BN) {
+        double S = 0.0, Q = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float2 v = red[tid * 4 + i]; S += (double)v.x; Q += (double)v.y; }
+        const int co = n0 + tid;
         const int nvalid = min(TH, H - y0) * min(TW, W - x0);
-        if (sg == 0 && co < Cout) {
+        if (co < Cout) {
             const double m2 = Q - S * S / (double)nvalid;
             stats[(size_t)sp * Cout + co] = (float)S;
             stats[(size_t)(P + sp) * Cout + co] = (float)(m2 > 0.0 ? m2 : 0.0);
@@ -346,7 +563,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16p(const __bf16* __restrict_
 // fp32 master weights, physical [Cout][3][3][Cin] -> tile-major bf16 pack [row tile][slice][tap][128 rows][4 chunks][8], chunk
 // position p of row n holds source chunk p ^ ((n>>2)&3) (the LDS image of one DMA'd tap tile, byte for byte); zero padded.
 // dgrad: rows are the INPUT channels of the layer, k runs over its output channels, taps rotated by 180 degrees.
-__global__ void k_pack_w_pp(const float* __restrict__ w, __bf16* __restrict__ out, int Cout, int Cin, int ntile, int ncs, int dgrad) {
+__global__ void k_pack_w_pp(const float* __restrict__ w, __bf16* __restrict__ out, int Cout, int Cin, int ntile, int ncs, int dgrad, int mf16) {
     const size_t total = (size_t)ntile * ncs * 9 * BN * CK;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int e = (int)(i & 7), p = (int)((i >> 3) & 3), n = (int)((i >> 5) & (BN - 1));
@@ -355,7 +572,7 @@ __global__ void k_pack_w_pp(const float* __restrict__ w, __bf16* __restrict__ ou
         const int cs = (int)(rest % ncs);
         const int ntl = (int)(rest / ncs);
         const int row = ntl * BN + n;
-        const int k = cs * CK + ((p ^ ((n >> 2) & 3)) << 3) + e;
+        const int k = cs * CK + ((p ^ (mf16 ? ((n >> 2) & 1) << 1 : (n >> 2) & 3)) << 3) + e;
         float v = 0.f;
         if (!dgrad) { if (row < Cout && k < Cin) v = w[((size_t)row * 9 + tap) * Cin + k]; }
         else        { if (row < Cin && k < Cout) v = w[((size_t)k * 9 + (8 - tap)) * Cin + row]; }
@@ -372,6 +589,11 @@ bool serves(int Cin, int Cout) {
     return on && Cout > 64 && Cin >= 128 && Cin % CK == 0;
 }
 
+static int mfma_shape() {          // 16: v_mfma_f32_16x16x32_bf16 (k_conv_bf16q), 32: v_mfma_f32_32x32x16_bf16 (k_conv_bf16p)
+    static const int mf = getenv("CVK_BF16P_MF") ? atoi(getenv("CVK_BF16P_MF")) : 16;
+    return mf == 32 ? 32 : 16;
+}
+
 int stat_partials(int N, int H, int W) { return N * cvk_cdiv(H, TH) * cvk_cdiv(W, TW); }
 
 void pack(const float* w, void* out, int Cout, int Cin, int Kpad, bool dgrad, hipStream_t s) {
@@ -379,7 +601,7 @@ void pack(const float* w, void* out, int Cout, int Cin, int Kpad, bool dgrad, hi
     const int ntile = cvk_cdiv(rows, BN), ncs = Kpad / CK;
     const size_t total = (size_t)ntile * ncs * 9 * BN * CK;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_pack_w_pp, dim3(blocks), dim3(256), 0, s, w, (__bf16*)out, Cout, Cin, ntile, ncs, dgrad ? 1 : 0);
+    hipLaunchKernelGGL(k_pack_w_pp, dim3(blocks), dim3(256), 0, s, w, (__bf16*)out, Cout, Cin, ntile, ncs, dgrad ? 1 : 0, mfma_shape() == 16 ? 1 : 0);
 }
 
 void launch(const void* x, const void* wpp, const float* bias, void* y, float* stats, float* counts, int N, int H, int W, int Cin,
@@ -392,7 +614,10 @@ void launch(const void* x, const void* wpp, const float* bias, void* y, float* s
 #define CVK_PP(ST_, DBG_, V_)                                                                                                              \
     hipLaunchKernelGGL((k_conv_bf16p<ST_, DBG_, V_>), grid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, \
                        H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P)
-    if (dbg == 0 && var == 0) {
+    if (mfma_shape() == 16) {
+        if (stats) hipLaunchKernelGGL((k_conv_bf16q<true>), grid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P);
+        else hipLaunchKernelGGL((k_conv_bf16q<false>), grid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P);
+    } else if (dbg == 0 && var == 0) {
         if (stats) CVK_PP(true, 0, 0); else CVK_PP(false, 0, 0);
     } else if (dbg == 0) {
         CVK_PP(false, 0, 1);

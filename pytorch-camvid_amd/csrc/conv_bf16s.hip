@@ -63,6 +63,23 @@ __device__ __forceinline__ void dma16_asm_m0(const void* g, unsigned lds_byte_ad
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_byte_addr) : "memory");
 }
 
+// LDS-DMA through a raw buffer: per-lane 32-bit byte offset, the 64-bit base lives in scalar registers, lanes whose offset is
+// past num_records read 0.  Round 4 (tools/stamps_bf16p.py): the v_lshl_add_u64 that forms a per-lane 64-bit address is held
+// back while the SIMD's other wave issues MFMAs (~550 cycles per LOAD phase against ~60 with scalar addressing).
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma16_buf_m0(unsigned voff, i32x4v rsrc, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(rsrc), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ i32x4v raw_rsrc_2g(const void* base) {        // raw buffer of 2 GiB at `base`: offsets >= 2^31 read 0
+    const uintptr_t b = (uintptr_t)base;
+    i32x4v r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32) & 0xFFFF);
+    r[2] = (int)0x80000000u;
+    r[3] = 0x00020000;
+    return r;
+}
+
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
@@ -756,41 +773,40 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_bf16s(const __bf16* __restrict
     const int cob = blk / nblk_ci, cib = blk % nblk_ci;
     const int t0 = split * tiles_per_split;
     const int t1 = min(ntiles, t0 + tiles_per_split);
-    const __bf16* const zero = reinterpret_cast<const __bf16*>(g_zero_page);
 
-    // ---- DMA source mapping: per piece a 32-bit element offset relative to the tile's first pixel and the packed halo
-    //      coordinates for the frame test; per tile only a 64-bit base and a few uniform bounds change -------------------
+    // ---- DMA source mapping: per piece a 32-bit BYTE offset relative to the pixel one row and one column before the tile's
+    //      first pixel (non-negative) and the packed halo coordinates for the frame test; per tile only the two raw-buffer
+    //      bases (scalar) and a few uniform bounds change; out-of-frame lanes get the offset 2^31 = past the buffer -> 0 ----------
     // x slab: piece q (0..5) of this wave covers LDS rows (wave*6 + q)*8 + lane/8, 16-byte position lane%8
-    int xs_off[6], xs_yx[6];
+    unsigned xs_off[6]; int xs_yx[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
         const int row = (wave * 6 + q) * 8 + (lane >> 3);
         const int hy = row / HP, hx = row - hy * HP;
         const int chunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
         const bool ok = (row < WG_XROWS) & (hx < TW + 2) & (cib * 64 + chunk * 8 < ldx);
-        xs_off[q] = ((hy - 1) * W + (hx - 1)) * ldx + cib * 64 + chunk * 8;
+        xs_off[q] = (unsigned)((hy * W + hx) * ldx + cib * 64 + chunk * 8) * 2u;
         xs_yx[q] = ok ? (hy << 8) | hx : 0x7F7F;               // static rejects fail every frame test
     }
-    int ds_off[4], ds_yx[4];
+    unsigned ds_off[4]; int ds_yx[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = (wave * 4 + q) * 8 + (lane >> 3);      // tile pixel index: py*32 + px
         const int chunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
         const bool ok = cob * 64 + chunk * 8 < ld_dy;
-        ds_off[q] = ((row >> 5) * W + (row & 31)) * ld_dy + cob * 64 + chunk * 8;
+        ds_off[q] = (unsigned)(((row >> 5) * W + (row & 31)) * ld_dy + cob * 64 + chunk * 8) * 2u;
         ds_yx[q] = ok ? ((row >> 5) << 8) | (row & 31) : 0x7F7F;
     }
     const unsigned smem_addr = lds_addr_of(smem);
-    const __bf16* sx_base = X;
-    const __bf16* sd_base = DY;
+    i32x4v sx_rsrc = raw_rsrc_2g(X), sd_rsrc = raw_rsrc_2g(DY);
     int s_ylo = 0, s_yn = 0, s_xlo = 0, s_xn = 0, s_dyn = 0, s_dxn = 0;
     unsigned s_buf = 0;
     auto stage_begin = [&](int t, int which) {
         const int tx = t % tilesX, ty = (t / tilesX) % tilesY, img = t / (tilesX * tilesY);
         const int x0 = tx * TW, y0 = ty * TH;
         const long pix = ((long)img * H + y0) * W + x0;
-        sx_base = X + pix * ldx;
-        sd_base = DY + pix * ld_dy;
+        sx_rsrc = raw_rsrc_2g(X + (pix - W - 1) * ldx);       // lanes that would read in front of the tensor are out of frame
+        sd_rsrc = raw_rsrc_2g(DY + pix * ld_dy);
         // halo pixel (hy,hx) is inside the frame iff ylo <= hy < ylo + yn and xlo <= hx < xlo + xn
         s_ylo = y0 == 0 ? 1 : 0;  s_yn = min(TH + 2, H - y0 + 1) - s_ylo;
         s_xlo = x0 == 0 ? 1 : 0;  s_xn = min(TW + 2, W - x0 + 1) - s_xlo;
@@ -800,14 +816,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_bf16s(const __bf16* __restrict
     auto stage_x = [&](int q) {
         if (DBG & 1) return;
         const bool ok = ((unsigned)((xs_yx[q] >> 8) - s_ylo) < (unsigned)s_yn) & ((unsigned)((xs_yx[q] & 255) - s_xlo) < (unsigned)s_xn);
-        const __bf16* p = sx_base + xs_off[q];
-        dma16_asm_m0(ok ? (const void*)p : (const void*)zero, s_buf + (wave * 6 + q) * 1024);
+        dma16_buf_m0(ok ? xs_off[q] : 0x80000000u, sx_rsrc, s_buf + (wave * 6 + q) * 1024);
     };
     auto stage_d = [&](int q) {
         if (DBG & 1) return;
         const bool ok = ((ds_yx[q] >> 8) < s_dyn) & ((ds_yx[q] & 255) < s_dxn);
-        const __bf16* p = sd_base + ds_off[q];
-        dma16_asm_m0(ok ? (const void*)p : (const void*)zero, s_buf + WG_XBYTES + (wave * 4 + q) * 1024);
+        dma16_buf_m0(ok ? ds_off[q] : 0x80000000u, sd_rsrc, s_buf + WG_XBYTES + (wave * 4 + q) * 1024);
     };
 
     // ---- transposed-read lane addresses -----------------------------------------------------------------------------------
@@ -956,6 +970,7 @@ extern "C" int cvk_conv3x3_wgrad_bf16s(const void* x, const void* dy, float* dw,
     CVK_CHECK_ARG(x && dy && dw && workspace, "cvk_conv3x3_wgrad_bf16s: null pointer");
     CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ldx >= Cin && ld_dy >= Cout, "cvk_conv3x3_wgrad_bf16s: bad shape");
     CVK_CHECK_ARG(ldx % 8 == 0 && ld_dy % 8 == 0, "cvk_conv3x3_wgrad_bf16s: ldx and ld_dy must be multiples of 8");
+    CVK_CHECK_ARG((long)(10 * (long)W + 40) * (ldx > ld_dy ? ldx : ld_dy) * 2 < (1L << 31), "cvk_conv3x3_wgrad_bf16s: ten image rows exceed 2 GiB");
     CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(dy) && cvk_aligned16(workspace), "cvk_conv3x3_wgrad_bf16s: pointers must be 16-byte aligned");
     const WgPlan p = plan_wgrad_bf16s(N, H, W, Cin, Cout);
     const size_t n = (size_t)Cout * 9 * Cin;
