@@ -23,6 +23,7 @@
 // weights row n at c ^ ((n>>2)&3): every ds_read_b128 is bank-conflict free for all nine tap shifts (a halo row is 34 x 64 B =
 // 8.5 bank rows: all lanes of one read share the halo row, so the half-row phase is common to them).
 #include <stdlib.h>
+#include <type_traits>
 #include "cvk_common.h"
 #include "lds_dma.h"
 #include "conv_bf16p.h"
@@ -74,6 +75,15 @@ __device__ __forceinline__ void dma16_saddr(unsigned voff, const void* sbase, un
 }
 __device__ __forceinline__ void dma16_buf(unsigned voff, i32x4 rsrc, unsigned soff, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_byte_addr) : "memory");
+}
+
+// the same with the LDS destination = scalar base + compile-time offset (one s_add into M0: the dozen destinations of a slice body
+// do not each occupy a scalar register)
+template <int IMM> __device__ __forceinline__ void dma16_saddr_i(unsigned voff, const void* sbase, unsigned lds_base) {
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_base), "n"(IMM) : "memory", "scc");
+}
+template <int IMM> __device__ __forceinline__ void dma16_buf_i(unsigned voff, i32x4 rsrc, unsigned soff, unsigned lds_base) {
+    asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base), "n"(IMM) : "memory", "scc");
 }
 
 // Weights are requested D = 2 steps ahead of their first read into a ring of three tiles: 9 steps per slice, so the slot of a
@@ -370,18 +380,28 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16p(const __bf16* __restrict_
 //   * D: lane (l15, q4) holds channels 4 q4 .. 4 q4 + 3 of the 16-channel block for pixel column l15 of the 16-pixel block:
 //     32 accumulators of 4 registers; statistics: 16 (sum, sumsq) pairs per lane, the 16 lanes of a DPP row share their channels.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
+// PERSISTENT (round 4): a workgroup walks the tiles g, g + G, g + 2G, ... (G = grid size = CUs; the XCD remap keeps the tiles that
+// run together neighbours).  With one workgroup per CU nothing else covers a tile's prologue (2-4.5 us: the first slab comes from
+// HBM) and the launch gap between two workgroups (~1.5 us), against 24 us for the K loop of a 128-channel layer — so the NEXT tile's
+// prologue DMAs (slab of slice 0 -> slab buffer A, weights of steps 0 and 1) are issued right after the K loop and land under the
+// epilogue.  For that the epilogue keeps out of [0, 64 KiB) (ring + slab A): the output is transposed through a 64 KiB stage at
+// [64 KiB, 128 KiB) in TWO passes (group A's 256 pixels x 256 B, then group B's).  Results leave as always-issued buffer stores
+// (16 per lane and tile; out-of-frame lanes get an offset past the buffer), so the counted vmcnt of the next tile can step over them.
 template <bool STATS>
 __global__ __launch_bounds__(512, 2) void k_conv_bf16q(const __bf16* __restrict__ X, const char* __restrict__ Wp,
                                                       const float* __restrict__ bias, __bf16* __restrict__ Y,
                                                       float* __restrict__ stats, float* __restrict__ cnt, int H, int W, int Cin,
-                                                      int Cout, int ldy, int tilesX, int tilesY, int tilesN, int P) {
+                                                      int Cout, int ldy, int tilesX, int tilesY, int tilesN, int P, int ntiles) {
     constexpr int D = 2, RING = 3;
-    constexpr int RING_BYTES = RING * BTAP;
-    constexpr int MAIN_BYTES = RING_BYTES + 2 * SLAB_BYTES;
-    constexpr int STAGE_BYTES = TH * TW * BN * 2;                 // the staged output tile [512 px][256 B]
-    constexpr int LDS_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    constexpr int RING_BYTES = RING * BTAP;                       // [0, 24 KiB) weight ring, [24, 64) slab A, [64, 104) slab B
+    constexpr int STAGE_OFF = RING_BYTES + SLAB_BYTES;            // epilogue stage [64 KiB, 128 KiB): 256 pixels x 256 B per pass
+    constexpr int STAGE_BYTES = (TH / 2) * TW * BN * 2;
+    constexpr int RED_OFF = STAGE_OFF + STAGE_BYTES;              // statistics partials [channel 128][partial 4] (sum, sumsq): 4 KiB
+    constexpr int LDS_BYTES = RED_OFF + (STATS ? BN * 4 * 8 : 0);
+    constexpr int NSTORE = 16;                                    // buffer stores per lane and tile
+    static_assert(STAGE_OFF >= RING_BYTES + SLAB_BYTES && LDS_BYTES >= RING_BYTES + 2 * SLAB_BYTES && LDS_BYTES <= 160 * 1024, "LDS plan");
     __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
     const unsigned smem_addr = cvk_lds_addr(smem);
 
@@ -392,171 +412,266 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16q(const __bf16* __restrict_
     const int grp = wave >> 2;
     const int wc = wave & 1, wp = (wave >> 1) & 1;
     const int row0 = grp * 8 + wp * 4;
-
-    const int gid = cvk_xcd_remap(blockIdx.x, gridDim.x);
-    const int nt = gid % tilesN;
-    const int sp = gid / tilesN;
-    const int tx = sp % tilesX;
-    const int ty = (sp / tilesX) % tilesY;
-    const int img = sp / (tilesX * tilesY);
-    const int x0 = tx * TW, y0 = ty * TH, n0 = nt * BN;
     const int ncs = Cin / CK, nsteps = ncs * 9;
+    const int G = gridDim.x;
 
+    // ---- per-tile state: the tile being multiplied (cur_*) and the DMA sources of the tile being requested ------------------------
+    struct Geo { int nt, sp, x0, y0, img; };
+    auto geo_of = [&](int t) {
+        Geo g;
+        g.nt = t % tilesN;
+        g.sp = t / tilesN;
+        const int tx = g.sp % tilesX, ty = (g.sp / tilesX) % tilesY;
+        g.img = g.sp / (tilesX * tilesY);
+        g.x0 = tx * TW; g.y0 = ty * TH;
+        return g;
+    };
     unsigned aoff[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-        const int row = (8 * t + wave) * 16 + (lane >> 2);
-        const int hy = row / HP, hx = row - hy * HP;
-        const int chunk = (lane & 3) ^ (((hx >> 2) & 1) << 1);
-        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-        const bool ok = (row < SLAB_ROWS) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
-        aoff[t] = ok ? (unsigned)((iy * W + ix) * Cin + chunk * 8) * 2u : 0x80000000u;
-    }
-    const uintptr_t xbase = (uintptr_t)(X + (size_t)img * H * W * Cin);
     i32x4 xrsrc;
-    xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xbase);
-    xrsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xbase >> 32) & 0xFFFF);
     xrsrc[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)(H * W * Cin) * 2u));
     xrsrc[3] = 0x00020000;
     const unsigned wvoff = wave * 1024 + lane * 16;
-    const char* wnext = Wp + (size_t)nt * nsteps * BTAP;
-
-    auto dma_slab_piece = [&](int t, int cs, unsigned slab_addr) { dma16_buf(aoff[t], xrsrc, (unsigned)cs * (CK * 2), slab_addr + (8 * t + wave) * 1024); };
-    auto dma_weights_next = [&](int slot, int s) {
-        dma16_saddr(wvoff, wnext, smem_addr + slot * BTAP + wave * 1024);
+    const unsigned wave_lds = smem_addr + wave * 1024;         // LDS destination of this wave's piece of a weight tile / slab group
+    const char* wnext = Wp;
+    int slab_yx[5];                                           // halo coordinates of the LDS row a lane fills in slab piece 8t + wave
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int row = (8 * t + wave) * 16 + (lane >> 2);
+        const int hy = row / HP;
+        slab_yx[t] = row < SLAB_ROWS ? (hy << 8) | (row - hy * HP) : 0x4000;       // rows past the slab: far outside every frame
+    }
+    auto setup_dma = [&](const Geo& g) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int hy = slab_yx[t] >> 8, hx = slab_yx[t] & 255;
+            const int chunk = (lane & 3) ^ (((hx >> 2) & 1) << 1);
+            const int iy = g.y0 - 1 + hy, ix = g.x0 - 1 + hx;
+            const bool ok = ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+            aoff[t] = ok ? (unsigned)((iy * W + ix) * Cin + chunk * 8) * 2u : 0x80000000u;
+        }
+        const uintptr_t xbase = (uintptr_t)(X + (size_t)g.img * H * W * Cin);
+        xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xbase);
+        xrsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xbase >> 32) & 0xFFFF);
+        wnext = Wp + (size_t)g.nt * nsteps * BTAP;
+    };
+    // slab piece t of this wave into the slab whose first byte (+ this wave's 1 KiB) is slab_lds; weights of the next step into ring slot SLOT
+    auto dma_slab_piece = [&](auto t_tag, int cs, unsigned slab_lds) {
+        constexpr int T = decltype(t_tag)::value;
+        dma16_buf_i<T * 8192>(aoff[T], xrsrc, (unsigned)cs * (CK * 2), slab_lds);
+    };
+    auto dma_weights_next = [&](auto slot_tag, int s) {
+        dma16_saddr_i<decltype(slot_tag)::value * BTAP>(wvoff, wnext, wave_lds);
         if (s < nsteps - 1) wnext += BTAP;
+    };
+    auto issue_prologue = [&]() {
+        dma_slab_piece(std::integral_constant<int, 0>{}, 0, wave_lds + RING_BYTES);
+        dma_slab_piece(std::integral_constant<int, 1>{}, 0, wave_lds + RING_BYTES);
+        dma_slab_piece(std::integral_constant<int, 2>{}, 0, wave_lds + RING_BYTES);
+        dma_slab_piece(std::integral_constant<int, 3>{}, 0, wave_lds + RING_BYTES);
+        dma_slab_piece(std::integral_constant<int, 4>{}, 0, wave_lds + RING_BYTES);
+        dma_weights_next(std::integral_constant<int, 0>{}, 0);
+        dma_weights_next(std::integral_constant<int, 1>{}, 1);
     };
 
     // weights: row wc*64 + rb*16 + l15, chunk q4; pixels: halo row row0 + tp + dy, halo column half*16 + l15 + dx, chunk q4
     const int wa = (wc * 64 + l15) * 64 + ((q4 ^ (((l15 >> 2) & 1) << 1)) << 4);
-    int pb[3];
+    int pb0[3];
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) pb[dx] = RING_BYTES + row0 * (HP * 64) + (l15 + dx) * 64 + ((q4 ^ ((((l15 + dx) >> 2) & 1) << 1)) << 4);
-    int pb_flip = SLAB_BYTES;
+    for (int dx = 0; dx < 3; ++dx) pb0[dx] = RING_BYTES + row0 * (HP * 64) + (l15 + dx) * 64 + ((q4 ^ ((((l15 + dx) >> 2) & 1) << 1)) << 4);
 
-    f32x4v acc[4][8];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    // round k runs the tiles [k G, k G + n_k), n_k = min(G, tiles left), on the first n_k workgroups; the XCD remap is applied per
+    // round, so a partial last round is still spread over all eight XCDs (with one remap of the whole grid it ran on half of them:
+    // the 384-tile layers lost 6 %)
+    int base = 0;
+    int tile = cvk_xcd_remap(blockIdx.x, min(G, ntiles));
+    Geo cur = geo_of(tile);
+    setup_dma(cur);
+    issue_prologue();
+    bool stores_in_flight = false;
 
-#pragma unroll
-    for (int t = 0; t < 5; ++t) dma_slab_piece(t, 0, smem_addr + RING_BYTES);
-    dma_weights_next(0, 0);
-    dma_weights_next(1, 1);
-    cvk_wait_vm<D - 1>();
-    phase_barrier();
-    if (grp == 1) phase_barrier();
+    while (true) {
+        // slab of slice 0 and the weights of step 0 have landed; behind them in the queue: the weights of step 1 and, after the
+        // first tile, the previous tile's NSTORE stores
+        if (stores_in_flight) cvk_wait_vm<1 + NSTORE>(); else cvk_wait_vm<1>();
+        phase_barrier();
+        if (grp == 1) phase_barrier();
 
-    int step = 0;
-    for (int cs = 0; cs < ncs; ++cs) {
-        const unsigned slab_next = smem_addr + RING_BYTES + ((cs + 1) & 1) * SLAB_BYTES;
-        const int csn = min(cs + 1, ncs - 1);
+        f32x4v acc[4][8];
 #pragma unroll
-        for (int sidx = 0; sidx < 9; ++sidx, ++step) {
-            // ======== LOAD phase
-            dma_weights_next((sidx + D) % RING, step + D);
-            if (sidx < 5) dma_slab_piece(sidx, csn, slab_next);
-            const int dy = sidx / 3, dx = sidx % 3, slot = sidx % RING;
-            bf16x8 a[4], b[8];
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) a[rb] = lds_read16(smem + (wa + slot * BTAP + rb * 16 * 64));
+            for (int b = 0; b < 8; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        int pb[3] = {pb0[0], pb0[1], pb0[2]};
+        int pb_flip = SLAB_BYTES;
+
+        int step = 0;
+        for (int cs = 0; cs < ncs; ++cs) {
+            const unsigned slab_next = wave_lds + RING_BYTES + ((cs + 1) & 1) * SLAB_BYTES;
+            const int csn = min(cs + 1, ncs - 1);
+            auto step_body = [&](auto sidx_tag) {
+                constexpr int sidx = decltype(sidx_tag)::value;
+                // ======== LOAD phase
+                dma_weights_next(std::integral_constant<int, (sidx + D) % RING>{}, step + D);
+                if (sidx < 5) dma_slab_piece(std::integral_constant<int, sidx < 5 ? sidx : 0>{}, csn, slab_next);
+                constexpr int dy = sidx / 3, dx = sidx % 3, slot = sidx % RING;
+                bf16x8 a[4], b[8];
 #pragma unroll
-            for (int cb = 0; cb < 8; ++cb) b[cb] = lds_read16(smem + (pb[dx] + ((cb >> 1) + dy) * (HP * 64) + (cb & 1) * 16 * 64));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (sidx < 5) cvk_wait_vm<2>(); else cvk_wait_vm<1>();
-            phase_barrier();
-            // ======== MFMA phase
-            __builtin_amdgcn_s_setprio(1);
+                for (int rb = 0; rb < 4; ++rb) a[rb] = lds_read16(smem + (wa + slot * BTAP + rb * 16 * 64));
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) b[cb] = lds_read16(smem + (pb[dx] + ((cb >> 1) + dy) * (HP * 64) + (cb & 1) * 16 * 64));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // this wave's piece of the weights of step + 1 has landed: everything requested before this phase's DMAs — except in
+                // the first phase of a later tile, whose step-1 weights sit in front of the previous tile's stores
+                if (sidx == 0) {
+                    if (step == 0 && stores_in_flight) cvk_wait_vm<2 + NSTORE>(); else cvk_wait_vm<2>();
+                } else if (sidx < 5) cvk_wait_vm<2>();
+                else cvk_wait_vm<1>();
+                phase_barrier();
+                // ======== MFMA phase
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < 8; ++cb)
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb], b[cb], acc[rb][cb], 0, 0, 0);
+                if (sidx == 8) {
+#pragma unroll
+                    for (int dx2 = 0; dx2 < 3; ++dx2) pb[dx2] += pb_flip;
+                    pb_flip = -pb_flip;
+                }
+                __builtin_amdgcn_s_setprio(0);
+                phase_barrier();
+                ++step;
+            };
+            step_body(std::integral_constant<int, 0>{}); step_body(std::integral_constant<int, 1>{}); step_body(std::integral_constant<int, 2>{});
+            step_body(std::integral_constant<int, 3>{}); step_body(std::integral_constant<int, 4>{}); step_body(std::integral_constant<int, 5>{});
+            step_body(std::integral_constant<int, 6>{}); step_body(std::integral_constant<int, 7>{}); step_body(std::integral_constant<int, 8>{});
+        }
+        if (grp == 0) phase_barrier();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the tail re-loads have landed: ring and slabs are free
+        phase_barrier();
+
+        // ---- the next tile's prologue goes out before this tile's epilogue ---------------------------------------------------------
+        base += G;
+        const int n_k = min(G, ntiles - base);
+        const bool has_next = (int)blockIdx.x < n_k;
+        const int next = has_next ? base + cvk_xcd_remap(blockIdx.x, n_k) : 0;
+        if (has_next) {
+            const Geo g = geo_of(next);
+            setup_dma(g);
+            issue_prologue();
+        }
+
+        // ---- epilogue: bias, statistics, pack; transposed through the stage in two passes; 16-byte buffer stores -------------------
+        // acc[rb][cb][i]: channel n0 + wc*64 + rb*16 + 4*q4 + i, pixel (y0 + row0 + (cb >> 1), x0 + (cb & 1)*16 + l15)
+        const int n0 = cur.nt * BN;
+        // the epilogue's lane terms are recomputed per tile from a laundered lane id: hoisted out of the tile loop (they are loop
+        // invariant) the ~60 stage / store addresses would live in registers through the K loop and spill
+        int elane = lane;
+        asm volatile("" : "+v"(elane));
+        const int l15 = elane & 15, q4 = elane >> 4, lane = elane;
+
+        const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(Y + ((size_t)(cur.img * H + cur.y0) * W + cur.x0) * ldy + n0), 0, 0x7FFFFFFF, 0x00020000);
+        // Every wave: bias, statistics, pack to bf16 IN PLACE (the packed pair of a block replaces the first two of its four
+        // accumulator registers: no second register array beside the 128 accumulators).
+        // Statistics: a lane holds (sum, sum of squares) of 16 channels over its 8 pixel blocks; the 16 lanes of a DPP row hold the
+        // same channels for 16 pixel columns: four DPP adds per value leave the row total in every lane; 4 partials per channel
+        // (2 groups x 2 row halves) meet in LDS and are combined in fp64 in a fixed order.
+        {
+            float s[4][4], q[4][4];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const int co = n0 + wc * 64 + rb * 16 + 4 * q4;
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (bias != nullptr && co < Cout) bv = *reinterpret_cast<const f32x4*>(bias + co);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s[rb][j] = 0.f; q[rb][j] = 0.f; }
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) {
+                    const bool ok = (cur.x0 + (cb & 1) * 16 + l15 < W) & (cur.y0 + row0 + (cb >> 1) < H);
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[rb][cb][j] + bv[j];
+                    if (STATS) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float vm = ok ? v[j] : 0.f;
+                            s[rb][j] += vm;
+                            q[rb][j] += vm * vm;
+                        }
+                    }
+                    const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    const float2 of = __builtin_bit_cast(float2, o);
+                    acc[rb][cb][0] = of.x;
+                    acc[rb][cb][1] = of.y;
+                    __builtin_amdgcn_sched_barrier(0);      // one block at a time
+                }
+            }
+            if (STATS) {
+                float2* const red = reinterpret_cast<float2*>(smem + RED_OFF);
+                const int part = grp * 2 + wp;
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float ss = row_sum16(s[rb][j]), qq = row_sum16(q[rb][j]);
+                        if (l15 == 0) red[(wc * 64 + rb * 16 + 4 * q4 + j) * 4 + part] = float2{ss, qq};
+                    }
+            }
+        }
+        auto stage_mine = [&]() {
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-                for (int cb = 0; cb < 8; ++cb)
-                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb], b[cb], acc[rb][cb], 0, 0, 0);
-            if (sidx == 8) {
-#pragma unroll
-                for (int dx2 = 0; dx2 < 3; ++dx2) pb[dx2] += pb_flip;
-                pb_flip = -pb_flip;
-            }
-            __builtin_amdgcn_s_setprio(0);
-            phase_barrier();
-        }
-    }
-    if (grp == 0) phase_barrier();
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    phase_barrier();
-
-    // ---- epilogue: bias, statistics, transpose through LDS (see k_conv_bf16p), 16-byte stores ------------------------------------
-    // acc[rb][cb][i]: channel n0 + wc*64 + rb*16 + 4*q4 + i, pixel (y0 + row0 + (cb >> 1), x0 + (cb & 1)*16 + l15)
-    float s[4][4], q[4][4];
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-        const int co = n0 + wc * 64 + rb * 16 + 4 * q4;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (bias != nullptr && co < Cout) bv = *reinterpret_cast<const f32x4*>(bias + co);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { s[rb][j] = 0.f; q[rb][j] = 0.f; }
-#pragma unroll
-        for (int cb = 0; cb < 8; ++cb) {
-            const bool ok = (x0 + (cb & 1) * 16 + l15 < W) & (y0 + row0 + (cb >> 1) < H);
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[rb][cb][j] + bv[j];
-            if (STATS) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float vm = ok ? v[j] : 0.f;
-                    s[rb][j] += vm;
-                    q[rb][j] += vm * vm;
+                for (int cb = 0; cb < 8; ++cb) {
+                    const int p = (wp * 4 + (cb >> 1)) * 32 + (cb & 1) * 16 + l15, chunk = wc * 8 + rb * 2 + (q4 >> 1);
+                    *reinterpret_cast<float2*>(smem + STAGE_OFF + p * 256 + ((chunk ^ (p & 15)) << 4) + 8 * (q4 & 1)) = float2{acc[rb][cb][0], acc[rb][cb][1]};
                 }
+        };
+        auto store_pass = [&](int pass) {
+            // wave w stores stage rows 32w .. 32w + 31 (= tile row 8*pass + w): 8 instructions of 4 pixels x 256 B
+            const int chunk = lane & 15;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int p = wave * 32 + it * 4 + (lane >> 4);
+                const int prow = pass * 8 + (p >> 5), pcol = p & 31;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(smem + STAGE_OFF + p * 256 + ((chunk ^ (p & 15)) << 4));
+                const bool ok = (cur.y0 + prow < H) & (cur.x0 + pcol < W) & (n0 + chunk * 8 < ldy);
+                const unsigned off = (unsigned)((prow * W + pcol) * ldy + chunk * 8) * 2u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), yrsrc, ok ? off : 0x80000000u, 0, 0);
             }
-            const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-            const int p = (row0 + (cb >> 1)) * 32 + (cb & 1) * 16 + l15, chunk = wc * 8 + rb * 2 + (q4 >> 1);
-            *reinterpret_cast<bf16x4*>(smem + p * 256 + ((chunk ^ (p & 15)) << 4) + 8 * (q4 & 1)) = o;
+        };
+        if (grp == 0) stage_mine();
+        __syncthreads();
+        store_pass(0);
+        __syncthreads();
+        if (grp == 1) stage_mine();
+        __syncthreads();
+        store_pass(1);
+        __syncthreads();
+        if (STATS) {
+            // every partial was written before the last barrier above
+            if (tid < BN) {
+                const float2* const red = reinterpret_cast<const float2*>(smem + RED_OFF);
+                double S = 0.0, Q = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const float2 v = red[tid * 4 + i]; S += (double)v.x; Q += (double)v.y; }
+                const int co = n0 + tid;
+                const int nvalid = min(TH, H - cur.y0) * min(TW, W - cur.x0);
+                if (co < Cout) {
+                    const double m2 = Q - S * S / (double)nvalid;
+                    stats[(size_t)cur.sp * Cout + co] = (float)S;
+                    stats[(size_t)(P + cur.sp) * Cout + co] = (float)(m2 > 0.0 ? m2 : 0.0);
+                }
+                if (cur.nt == 0 && tid == 0) cnt[cur.sp] = (float)nvalid;
+            }
+            // the partials are rewritten in the next tile's epilogue, at least four barriers from here
         }
-    }
-    __syncthreads();
-    {
-        const int chunk = lane & 15, co = n0 + chunk * 8;
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int p = wave * 64 + it * 4 + (lane >> 4);
-            const int py = y0 + (p >> 5), pxx = x0 + (p & 31);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(smem + p * 256 + ((chunk ^ (p & 15)) << 4));
-            if ((py < H) & (pxx < W) & (co < ldy))
-                *reinterpret_cast<f32x4*>(Y + ((size_t)(img * H + py) * W + pxx) * ldy + co) = v;
-        }
-    }
-    if (!STATS) return;
-    __syncthreads();
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[rb][j] = row_sum16(s[rb][j]);
-            q[rb][j] = row_sum16(q[rb][j]);
-        }
-    float2* const red = reinterpret_cast<float2*>(smem);          // [channel 128][partial 4]
-    if (l15 == 0) {
-        const int part = grp * 2 + wp;
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) red[(wc * 64 + rb * 16 + 4 * q4 + j) * 4 + part] = float2{s[rb][j], q[rb][j]};
-    }
-    __syncthreads();
-    if (tid < BN) {
-        double S = 0.0, Q = 0.0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { const float2 v = red[tid * 4 + i]; S += (double)v.x; Q += (double)v.y; }
-        const int co = n0 + tid;
-        const int nvalid = min(TH, H - y0) * min(TW, W - x0);
-        if (co < Cout) {
-            const double m2 = Q - S * S / (double)nvalid;
-            stats[(size_t)sp * Cout + co] = (float)S;
-            stats[(size_t)(P + sp) * Cout + co] = (float)(m2 > 0.0 ? m2 : 0.0);
-        }
-        if (nt == 0 && tid == 0) cnt[sp] = (float)nvalid;
+        if (!has_next) break;
+        tile = next;
+        cur = geo_of(tile);
+        stores_in_flight = true;
     }
 }
 
@@ -586,7 +701,8 @@ namespace cvk_bf16p {
 
 bool serves(int Cin, int Cout) {
     static const int on = getenv("CVK_BF16P") ? atoi(getenv("CVK_BF16P")) : 1;
-    return on && Cout > 64 && Cin >= 128 && Cin % CK == 0;
+    static const int minci = getenv("CVK_BF16P_MINCI") ? atoi(getenv("CVK_BF16P_MINCI")) : 64;
+    return on && Cout > 64 && Cin >= minci && Cin % CK == 0;
 }
 
 static int mfma_shape() {          // 16: v_mfma_f32_16x16x32_bf16 (k_conv_bf16q), 32: v_mfma_f32_32x32x16_bf16 (k_conv_bf16p)
@@ -615,8 +731,14 @@ void launch(const void* x, const void* wpp, const float* bias, void* y, float* s
     hipLaunchKernelGGL((k_conv_bf16p<ST_, DBG_, V_>), grid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, \
                        H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P)
     if (mfma_shape() == 16) {
-        if (stats) hipLaunchKernelGGL((k_conv_bf16q<true>), grid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P);
-        else hipLaunchKernelGGL((k_conv_bf16q<false>), grid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P);
+        const int ntiles = P * tilesN;
+        static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 0 ? n : 256; }();
+        static const int cap = getenv("CVK_BF16P_GRID") ? atoi(getenv("CVK_BF16P_GRID")) : 0;      // timing experiments only
+        int g = cap > 0 ? cap : cus;
+        if (g > ntiles) g = ntiles;
+        dim3 pgrid((unsigned)g);
+        if (stats) hipLaunchKernelGGL((k_conv_bf16q<true>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);
+        else hipLaunchKernelGGL((k_conv_bf16q<false>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);
     } else if (dbg == 0 && var == 0) {
         if (stats) CVK_PP(true, 0, 0); else CVK_PP(false, 0, 0);
     } else if (dbg == 0) {
