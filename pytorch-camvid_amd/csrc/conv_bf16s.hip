@@ -922,6 +922,186 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_bf16s(const __bf16* __restrict
     else run(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
 }
 
+// ---- row-stationary version (round 4) ----------------------------------------------------------------------------------------------
+// k_wgrad_bf16s is bound by LDS bytes: every MFMA of a tap reads its own x fragment (1.2 KiB of transposed reads per MFMA; two waves
+// per SIMD at the matrix peak would need 307 B/clk of the 256 the LDS delivers; PMC: matrix pipe 55 % busy, and a ping-pong split of its
+// phases measured SLOWER — one wave per SIMD cannot even issue the 2.4 ds_read_b64_tr per MFMA in time).  But the x fragment of halo row
+// y' and column shift dx is the operand of THREE taps: kernel row dy pairs it with the dy fragment of output row y' - dy.  So a wave now
+// owns ALL NINE taps of its 32 x 32 (co, ci) quadrant (144 accumulator registers) for ONE 16-column half of the tile and walks the ten
+// halo rows: per halo row 3 x fragments (dx = 0, 1, 2) + 1 new dy fragment feed up to 9 MFMAs — 0.44 KiB of LDS reads per MFMA, 2.7x
+// less, 1.05 read instructions per MFMA instead of 2.4.  The two waves of a SIMD take the two column halves and their accumulators meet
+// through LDS once, after the workgroup's last tile (fixed order: deterministic).  Staging, LDS images, DMA, slabs: as k_wgrad_bf16s.
+__global__ __launch_bounds__(512, 2) void k_wgrad_bf16r(const __bf16* __restrict__ X, const __bf16* __restrict__ DY,
+                                                       float* __restrict__ slab, int H, int W, int ldx, int ld_dy, int Cout,
+                                                       int Cin, int tilesX, int tilesY, int ntiles, int tiles_per_split,
+                                                       int nblk_ci, int nblk) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * WG_STAGE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // 0..7
+    const int h = lane >> 5;
+    const int quad = wave & 3, half = wave >> 2;           // column half of the tile: pixels 16*half .. +15 of every tile row
+    const int wco = quad >> 1, wci = quad & 1;
+
+    const int gid = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int blk = gid % nblk, split = gid / nblk;
+    const int cob = blk / nblk_ci, cib = blk % nblk_ci;
+    const int t0 = split * tiles_per_split;
+    const int t1 = min(ntiles, t0 + tiles_per_split);
+
+    // ---- DMA source mapping: per piece ONE register, the 32-bit byte offset with the static rejects baked in (2^31 = past the raw
+    //      buffer -> 0).  Tiles whose halo lies inside the frame need nothing else; border tiles recompute the halo coordinates of a
+    //      piece for the frame test (wave-uniform branch).  With coordinates AND offsets resident (30 registers) beside 144
+    //      accumulators hipcc spilled them, and a spill reload next to a DMA makes it wait vmcnt(0). ------------------------------------
+    unsigned xs_off[6], ds_off[4];
+    auto x_yx = [&](int q) {
+        const int row = (wave * 6 + q) * 8 + (lane >> 3);
+        const int hy = row / HP;
+        return (hy << 8) | (row - hy * HP);
+    };
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int row = (wave * 6 + q) * 8 + (lane >> 3);
+        const int hy = row / HP, hx = row - hy * HP;
+        const int chunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
+        const bool ok = (row < WG_XROWS) & (hx < TW + 2) & (cib * 64 + chunk * 8 < ldx);
+        xs_off[q] = ok ? (unsigned)((hy * W + hx) * ldx + cib * 64 + chunk * 8) * 2u : 0x80000000u;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (wave * 4 + q) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
+        const bool ok = cob * 64 + chunk * 8 < ld_dy;
+        ds_off[q] = ok ? (unsigned)(((row >> 5) * W + (row & 31)) * ld_dy + cob * 64 + chunk * 8) * 2u : 0x80000000u;
+    }
+    const unsigned smem_addr = lds_addr_of(smem);
+    i32x4v sx_rsrc = raw_rsrc_2g(X), sd_rsrc = raw_rsrc_2g(DY);
+    int s_ylo = 0, s_yn = 0, s_xlo = 0, s_xn = 0, s_dyn = 0, s_dxn = 0;
+    bool s_interior = false;
+    unsigned s_buf = 0;
+    auto stage_begin = [&](int t, int which) {
+        const int tx = t % tilesX, ty = (t / tilesX) % tilesY, img = t / (tilesX * tilesY);
+        const int x0 = tx * TW, y0 = ty * TH;
+        const long pix = ((long)img * H + y0) * W + x0;
+        sx_rsrc = raw_rsrc_2g(X + (pix - W - 1) * ldx);
+        sd_rsrc = raw_rsrc_2g(DY + pix * ld_dy);
+        s_ylo = y0 == 0 ? 1 : 0;  s_yn = min(TH + 2, H - y0 + 1) - s_ylo;
+        s_xlo = x0 == 0 ? 1 : 0;  s_xn = min(TW + 2, W - x0 + 1) - s_xlo;
+        s_dyn = min(TH, H - y0);  s_dxn = min(TW, W - x0);
+        s_interior = (y0 > 0) & (y0 + TH < H) & (x0 > 0) & (x0 + TW < W);
+        s_buf = smem_addr + which * WG_STAGE;
+    };
+    auto stage_x = [&](int q) {
+        unsigned off = xs_off[q];
+        if (!s_interior) {
+            const int yx = x_yx(q);
+            const bool ok = ((unsigned)((yx >> 8) - s_ylo) < (unsigned)s_yn) & ((unsigned)((yx & 255) - s_xlo) < (unsigned)s_xn);
+            off = ok ? off : 0x80000000u;
+        }
+        dma16_buf_m0(off, sx_rsrc, s_buf + (wave * 6 + q) * 1024);
+    };
+    auto stage_d = [&](int q) {
+        unsigned off = ds_off[q];
+        if (!s_interior) {
+            const int row = (wave * 4 + q) * 8 + (lane >> 3);
+            const bool ok = ((row >> 5) < s_dyn) & ((row & 31) < s_dxn);
+            off = ok ? off : 0x80000000u;
+        }
+        dma16_buf_m0(off, sd_rsrc, s_buf + WG_XBYTES + (wave * 4 + q) * 1024);
+    };
+
+    // ---- transposed-read lane addresses (as k_wgrad_bf16s; the k-step of a row is this wave's column half) ---------------------------
+    const int tq = (lane & 15) >> 2, tp = lane & 3, g1 = (lane >> 4) & 1;
+    auto lane_addr = [&](int row_lane, int col_local) {
+        const int chunk = col_local >> 3;
+        return row_lane * 128 + ((chunk ^ (((row_lane >> 1) & 1) << 2)) << 4) + (col_local & 7) * 2;
+    };
+    const int rl = 8 * h + tq;
+    const int a_base = WG_XBYTES + lane_addr(rl, wco * 32 + 16 * g1 + 4 * tp) + half * 16 * 128;      // dy tile, row y: + y * 32 * 128
+    int b_base[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) b_base[dx] = lane_addr(rl + dx, wci * 32 + 16 * g1 + 4 * tp) + half * 16 * 128;      // halo row y': + y' * HP * 128
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    // One tile: ten halo rows.  fa[y % 4] = dy fragment of output row y (live for three halo rows, requested one row ahead), fb = the three x fragments of the
+    // current halo row; the fragments of halo row y' + 1 are requested before the MFMAs of row y' (order pinned with sched_barrier):
+    // fb[dx] is refilled in place right after its last MFMA of the row has been issued (the MFMA has latched its operands).
+    auto tile_body = [&](char* buf, const bool MORE) {     // ONE copy of the MFMA stream (two copies behind a branch: hipcc no longer ties the
+                                                           // accumulators in place across the tile loop and spills them); MORE is wave-uniform
+        bf16x8 fa[4], fb[3];
+        fa[0] = tr_read8(buf + a_base);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) fb[dx] = tr_read8(buf + b_base[dx]);
+#pragma unroll
+        for (int yp = 0; yp < TH + 2; ++yp) {
+            if (MORE && yp < 5) {      // this wave's 10 DMA pieces of the next tile: two per halo row in rows 0-4 (all ten at the start
+                                       // stall both waves of a SIMD together; the late rows leave them half a tile to land)
+                if (yp < 3) { stage_x(2 * yp); stage_x(2 * yp + 1); }
+                else { stage_d(2 * (yp - 3)); stage_d(2 * (yp - 3) + 1); }
+            }
+            if (yp + 1 < TH) fa[(yp + 1) % 4] = tr_read8(buf + a_base + (yp + 1) * 32 * 128);      // four slots: rows yp - 2 .. yp are still read below
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int y = yp - dy;
+                    if (y >= 0 && y < TH)
+                        acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[y % 4], fb[dx], acc[dy * 3 + dx], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (yp + 1 < TH + 2) fb[dx] = tr_read8(buf + b_base[dx] + (yp + 1) * HP * 128);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    if (t0 < t1) {
+        stage_begin(t0, 0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) stage_x(q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stage_d(q);
+    }
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int t = t0; t < t1; ++t) {
+        char* const buf = smem + cur * WG_STAGE;
+        const bool more = t + 1 < t1;
+        if (more) stage_begin(t + 1, cur ^ 1);
+        tile_body(buf, more);
+        wait_vm<0>();
+        lds_retire_barrier();
+        cur ^= 1;
+    }
+    // ---- the two column halves meet: waves 4-7 hand their accumulators to waves 0-3 through LDS (the stages are dead) -----------------
+    float* const xch = reinterpret_cast<float*>(smem);          // [quad][tap][register 16][lane 64]
+    if (half == 1) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xch[((quad * 9 + t) * 16 + i) * 64 + lane] = acc[t][i];
+    }
+    __syncthreads();
+    if (half == 1) return;
+    float* out = slab + (size_t)split * Cout * 9 * Cin;
+    const int ci = cib * 64 + wci * 32 + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int co = cob * 64 + wco * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const float v = acc[t][i] + xch[((quad * 9 + t) * 16 + i) * 64 + lane];
+            if (co < Cout && ci < Cin) out[((size_t)co * 9 + t) * Cin + ci] = v;
+        }
+}
+
 __global__ void k_wgrad_reduce_bf16s(const float* __restrict__ slab, float* __restrict__ dw, int splits, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -971,6 +1151,7 @@ extern "C" int cvk_conv3x3_wgrad_bf16s(const void* x, const void* dy, float* dw,
     CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ldx >= Cin && ld_dy >= Cout, "cvk_conv3x3_wgrad_bf16s: bad shape");
     CVK_CHECK_ARG(ldx % 8 == 0 && ld_dy % 8 == 0, "cvk_conv3x3_wgrad_bf16s: ldx and ld_dy must be multiples of 8");
     CVK_CHECK_ARG((long)(10 * (long)W + 40) * (ldx > ld_dy ? ldx : ld_dy) * 2 < (1L << 31), "cvk_conv3x3_wgrad_bf16s: ten image rows exceed 2 GiB");
+    CVK_CHECK_ARG(10L * W + 40 < (1L << 24) && 2L * ldx < (1L << 24) && 2L * ld_dy < (1L << 24), "cvk_conv3x3_wgrad_bf16s: W or a pixel pitch exceeds 2^24");
     CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(dy) && cvk_aligned16(workspace), "cvk_conv3x3_wgrad_bf16s: pointers must be 16-byte aligned");
     const WgPlan p = plan_wgrad_bf16s(N, H, W, Cin, Cout);
     const size_t n = (size_t)Cout * 9 * Cin;
@@ -982,6 +1163,11 @@ extern "C" int cvk_conv3x3_wgrad_bf16s(const void* x, const void* dy, float* dw,
     hipStream_t s = (hipStream_t)stream;
     const int nblk = p.nblk_co * p.nblk_ci;
     static const int dbg = getenv("CVK_WGRAD_DBG") ? atoi(getenv("CVK_WGRAD_DBG")) : 0;      // timing experiments only
+    static const int rowst = getenv("CVK_WGRAD_ROW") ? atoi(getenv("CVK_WGRAD_ROW")) : 1;
+    if (rowst && dbg == 0) {
+        hipLaunchKernelGGL(k_wgrad_bf16r, dim3(nblk * p.splits), dim3(512), 0, s, (const __bf16*)x, (const __bf16*)dy, (float*)workspace, H, W,
+                           ldx, ld_dy, Cout, Cin, cvk_cdiv(W, TW), cvk_cdiv(H, TH), p.ntiles, p.tps, p.nblk_ci, nblk);
+    } else
 #define CVK_WG_LAUNCH(D_) hipLaunchKernelGGL((k_wgrad_bf16s<D_>), dim3(nblk * p.splits), dim3(512), 0, s, (const __bf16*)x, (const __bf16*)dy, (float*)workspace, H, W, \
                            ldx, ld_dy, Cout, Cin, cvk_cdiv(W, TW), cvk_cdiv(H, TH), p.ntiles, p.tps, p.nblk_ci, nblk)
     if (dbg == 1) CVK_WG_LAUNCH(1);
