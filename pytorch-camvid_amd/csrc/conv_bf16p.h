@@ -12,6 +12,7 @@ constexpr int CK = 32;              // input channels per K slice
 // (a full 128-row weight tile) and at least 128 input channels (>= 4 slices: the K loop amortises prologue and epilogue).
 // A function of the channel counts only — the pack functions have no geometry.  CVK_BF16P=0 switches it off (A/B timing).
 bool serves(int Cin, int Cout);
+int kind(int Cin, int Cout);        // 0: not served, 1: 128 output channels per workgroup, 2: 64
 
 int stat_partials(int N, int H, int W);
 

@@ -551,6 +551,21 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16q(const __bf16* __restrict_
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the tail re-loads have landed: ring and slabs are free
         phase_barrier();
 
+        // this tile's bias values BEFORE the next tile's DMAs go out: hipcc waits vmcnt(0) for a register load, i.e. for every DMA
+        // issued in front of its use as well (tools/tile_stamps_h.py: 2.3 us per tile = the next slab's HBM latency, the very thing the
+        // early prologue is there to hide)
+        const int n0 = cur.nt * BN;
+        f32x4 bvals[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const int co = n0 + wc * 64 + rb * 16 + 4 * q4;
+            bvals[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (bias != nullptr && co < Cout) bvals[rb] = *reinterpret_cast<const f32x4*>(bias + co);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) asm volatile("" : "+v"(bvals[rb]));
+
         // ---- the next tile's prologue goes out before this tile's epilogue ---------------------------------------------------------
         base += G;
         const int n_k = min(G, ntiles - base);
@@ -564,7 +579,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16q(const __bf16* __restrict_
 
         // ---- epilogue: bias, statistics, pack; transposed through the stage in two passes; 16-byte buffer stores -------------------
         // acc[rb][cb][i]: channel n0 + wc*64 + rb*16 + 4*q4 + i, pixel (y0 + row0 + (cb >> 1), x0 + (cb & 1)*16 + l15)
-        const int n0 = cur.nt * BN;
         // the epilogue's lane terms are recomputed per tile from a laundered lane id: hoisted out of the tile loop (they are loop
         // invariant) the ~60 stage / store addresses would live in registers through the K loop and spill
         int elane = lane;
@@ -582,9 +596,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16q(const __bf16* __restrict_
             float s[4][4], q[4][4];
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) {
-                const int co = n0 + wc * 64 + rb * 16 + 4 * q4;
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (bias != nullptr && co < Cout) bv = *reinterpret_cast<const f32x4*>(bias + co);
+                const f32x4 bv = bvals[rb];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { s[rb][j] = 0.f; q[rb][j] = 0.f; }
 #pragma unroll
@@ -675,18 +687,325 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16q(const __bf16* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------- 64 output channels per workgroup
+// Layers with <= 64 output channels and >= 64 input channels (ups4 / up4.0: 128 -> 64 at full resolution, 64 -> 64, and the data-grad
+// of down2.0), which k_conv_bf16s<64> ran at 0.25-0.29 of the bf16 peak.  Same machine as k_conv_bf16q — persistent, two groups of four
+// waves alternating LOAD and MFMA phases, 16 x 32 pixel tile, 16x16x32 MFMA, scalar-addressed DMA, transposed epilogue — with half
+// the output channels per workgroup: a wave owns 64 channels x 64 pixels (2 tile rows), 64 accumulator registers.  One tap would be
+// only 16 MFMAs (256 cycles) against a barrier per phase and 8 fragment reads, so a phase is a KERNEL ROW: the three taps dx = 0, 1, 2 of
+// one dy — 48 MFMAs (768 cycles), 24 fragment reads (96 registers, affordable beside 64 accumulators), three phases per channel slice.
+// A ring slot holds the three 4 KiB weight tiles of a kernel row (12 KiB, contiguous in the tile-major pack); slot = dy.  DMA per wave and
+// phase: 1 weight piece (waves 0-3: 2) + 3 / 2 / 0 slab pieces (the next slice's slab must have landed before its first phase reads it).
+// LDS: ring 36 KiB | slab A 40 | slab B 40 | (epilogue) stage 64 KiB over slab B and beyond: the next tile's prologue (slab A, ring slots
+// 0 and 1) is issued before the epilogue, as in k_conv_bf16q, and the whole tile is staged in ONE pass (512 pixels x 128 B).
+constexpr int HBN = 64;                          // output channels per workgroup
+constexpr int HROW = 3 * HBN * 64;               // 12 KiB: the weight tiles of one kernel row of one channel slice
+
+template <bool STATS, int DBG = 0>     // DBG 1: s_memrealtime stamps of workgroup 0's first 16 tiles -> `stats` (timing experiments only)
+__global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict__ X, const char* __restrict__ Wp,
+                                                      const float* __restrict__ bias, __bf16* __restrict__ Y,
+                                                      float* __restrict__ stats, float* __restrict__ cnt, int H, int W, int Cin,
+                                                      int Cout, int ldy, int tilesX, int tilesY, int tilesN, int P, int ntiles) {
+    constexpr int RING_BYTES = 3 * HROW;                          // [0, 36 KiB) ring of three kernel rows; then slab A, slab B
+    constexpr int STAGE_OFF = RING_BYTES + SLAB_BYTES;            // epilogue stage: 512 pixels x 128 B
+    constexpr int STAGE_BYTES = TH * TW * HBN * 2;
+    constexpr int RED_OFF = STAGE_OFF + STAGE_BYTES;              // statistics partials [channel 64][partial 8] (sum, sumsq)
+    constexpr int LDS_BYTES = RED_OFF + (STATS ? HBN * 8 * 8 : 0);
+    constexpr int NSTORE = 8;
+    static_assert(LDS_BYTES >= RING_BYTES + 2 * SLAB_BYTES && LDS_BYTES <= 160 * 1024, "LDS plan");
+    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+    const unsigned smem_addr = cvk_lds_addr(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int grp = wave >> 2, wp = wave & 3;
+    const int row0 = grp * 8 + wp * 2;         // this wave's two tile rows
+    const bool lo = wave < 4;                  // waves 0-3 move two weight pieces per phase, waves 4-7 one
+    const int ncs = Cin / CK, nph = ncs * 3;
+    const int G = gridDim.x;
+
+    struct Geo { int nt, sp, x0, y0, img; };
+    auto geo_of = [&](int t) {
+        Geo g;
+        g.nt = t % tilesN;
+        g.sp = t / tilesN;
+        const int tx = g.sp % tilesX, ty = (g.sp / tilesX) % tilesY;
+        g.img = g.sp / (tilesX * tilesY);
+        g.x0 = tx * TW; g.y0 = ty * TH;
+        return g;
+    };
+    unsigned aoff[5];
+    i32x4 xrsrc;
+    xrsrc[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)(H * W * Cin) * 2u));
+    xrsrc[3] = 0x00020000;
+    const unsigned wvoff = wave * 1024 + lane * 16;
+    const unsigned wave_lds = smem_addr + wave * 1024;
+    const char* wnext = Wp;
+    int slab_yx[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int row = (8 * t + wave) * 16 + (lane >> 2);
+        const int hy = row / HP;
+        slab_yx[t] = row < SLAB_ROWS ? (hy << 8) | (row - hy * HP) : 0x4000;
+    }
+    auto setup_dma = [&](const Geo& g) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int hy = slab_yx[t] >> 8, hx = slab_yx[t] & 255;
+            const int chunk = (lane & 3) ^ (((hx >> 2) & 1) << 1);
+            const int iy = g.y0 - 1 + hy, ix = g.x0 - 1 + hx;
+            const bool ok = ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+            aoff[t] = ok ? (unsigned)((iy * W + ix) * Cin + chunk * 8) * 2u : 0x80000000u;
+        }
+        const uintptr_t xbase = (uintptr_t)(X + (size_t)g.img * H * W * Cin);
+        xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xbase);
+        xrsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xbase >> 32) & 0xFFFF);
+        wnext = Wp + (size_t)g.nt * nph * HROW;
+    };
+    auto dma_slab_piece = [&](auto t_tag, int cs, unsigned slab_lds) {
+        constexpr int T = decltype(t_tag)::value;
+        dma16_buf_i<T * 8192>(aoff[T], xrsrc, (unsigned)cs * (CK * 2), slab_lds);
+    };
+    // the weights of the next kernel row (12 pieces) into ring slot SLOT: piece `wave` by every wave, piece 8 + wave by waves 0-3
+    auto dma_row_next = [&](auto slot_tag, int ph) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        dma16_saddr_i<SLOT * HROW>(wvoff, wnext, wave_lds);
+        if (lo) dma16_saddr_i<SLOT * HROW + 8192>(wvoff, wnext + 8192, wave_lds);
+        if (ph < nph - 1) wnext += HROW;
+    };
+    auto issue_prologue = [&]() {
+        dma_slab_piece(std::integral_constant<int, 0>{}, 0, wave_lds + RING_BYTES);
+        dma_slab_piece(std::integral_constant<int, 1>{}, 0, wave_lds + RING_BYTES);
+        dma_slab_piece(std::integral_constant<int, 2>{}, 0, wave_lds + RING_BYTES);
+        dma_slab_piece(std::integral_constant<int, 3>{}, 0, wave_lds + RING_BYTES);
+        dma_slab_piece(std::integral_constant<int, 4>{}, 0, wave_lds + RING_BYTES);
+        dma_row_next(std::integral_constant<int, 0>{}, 0);
+        dma_row_next(std::integral_constant<int, 1>{}, 1);
+    };
+
+    // weights: tap dx of the slot's kernel row at dx * 4 KiB, row rb*16 + l15, chunk q4; pixels: halo row row0 + tp + dy, halo column
+    // half*16 + l15 + dx, chunk q4
+    const int wa = l15 * 64 + ((q4 ^ (((l15 >> 2) & 1) << 1)) << 4);
+    int pb0[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) pb0[dx] = RING_BYTES + row0 * (HP * 64) + (l15 + dx) * 64 + ((q4 ^ ((((l15 + dx) >> 2) & 1) << 1)) << 4);
+
+    int base = 0;
+    int tile = cvk_xcd_remap(blockIdx.x, min(G, ntiles));
+    Geo cur = geo_of(tile);
+    setup_dma(cur);
+    issue_prologue();
+    bool stores_in_flight = false;
+    int tcount = 0;
+    auto stamp = [&](int which) {
+        if (DBG && blockIdx.x == 0 && tcount < 16) {
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            if (tid == 0) reinterpret_cast<unsigned long long*>(stats)[tcount * 8 + which] = t;
+        }
+    };
+
+    while (true) {
+        stamp(0);
+        // slab of slice 0 and the weights of kernel row 0 have landed; behind them: the weights of row 1 (2 / 1 pieces) and, after the
+        // first tile, the previous tile's NSTORE stores
+        if (lo) { if (stores_in_flight) cvk_wait_vm<2 + NSTORE>(); else cvk_wait_vm<2>(); }
+        else    { if (stores_in_flight) cvk_wait_vm<1 + NSTORE>(); else cvk_wait_vm<1>(); }
+        phase_barrier();
+        stamp(1);
+        if (grp == 1) phase_barrier();
+
+        f32x4v acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        int pb[3] = {pb0[0], pb0[1], pb0[2]};
+        int pb_flip = SLAB_BYTES;
+
+        int ph = 0;
+        for (int cs = 0; cs < ncs; ++cs) {
+            const unsigned slab_next = wave_lds + RING_BYTES + ((cs + 1) & 1) * SLAB_BYTES;
+            const int csn = min(cs + 1, ncs - 1);
+            auto row_body = [&](auto dy_tag) {
+                constexpr int dy = decltype(dy_tag)::value;
+                // ======== LOAD phase: weights of kernel row ph + 2, the next slice's slab (3 + 2 pieces), this row's 24 fragments
+                dma_row_next(std::integral_constant<int, (dy + 2) % 3>{}, ph + 2);
+                if (dy == 0) {
+                    dma_slab_piece(std::integral_constant<int, 0>{}, csn, slab_next);
+                    dma_slab_piece(std::integral_constant<int, 1>{}, csn, slab_next);
+                    dma_slab_piece(std::integral_constant<int, 2>{}, csn, slab_next);
+                } else if (dy == 1) {
+                    dma_slab_piece(std::integral_constant<int, 3>{}, csn, slab_next);
+                    dma_slab_piece(std::integral_constant<int, 4>{}, csn, slab_next);
+                }
+                bf16x8 a[3][4], b[3][4];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) a[dx][rb] = lds_read16(smem + (wa + dy * HROW + dx * (HBN * 64) + rb * 16 * 64));
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) b[dx][cb] = lds_read16(smem + (pb[dx] + ((cb >> 1) + dy) * (HP * 64) + (cb & 1) * 16 * 64));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // the weights of kernel row ph + 1 have landed: everything requested before this phase's DMAs (2 or 1 weight pieces + 3 / 2 / 0
+                // slab pieces) — except in the first phase of a later tile, whose row-1 weights sit in front of the previous tile's stores
+                {
+                    constexpr int NS = dy == 0 ? 3 : (dy == 1 ? 2 : 0);
+                    const bool first = (dy == 0) && (ph == 0) && stores_in_flight;
+                    if (lo) { if (first) cvk_wait_vm<2 + NS + NSTORE>(); else cvk_wait_vm<2 + NS>(); }
+                    else    { if (first) cvk_wait_vm<1 + NS + NSTORE>(); else cvk_wait_vm<1 + NS>(); }
+                }
+                phase_barrier();
+                // ======== MFMA phase: 48 MFMAs
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                        for (int cb = 0; cb < 4; ++cb)
+                            acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[dx][rb], b[dx][cb], acc[rb][cb], 0, 0, 0);
+                if (dy == 2) {
+#pragma unroll
+                    for (int dx2 = 0; dx2 < 3; ++dx2) pb[dx2] += pb_flip;
+                    pb_flip = -pb_flip;
+                }
+                __builtin_amdgcn_s_setprio(0);
+                phase_barrier();
+                ++ph;
+            };
+            row_body(std::integral_constant<int, 0>{}); row_body(std::integral_constant<int, 1>{}); row_body(std::integral_constant<int, 2>{});
+        }
+        if (grp == 0) phase_barrier();
+        stamp(2);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        phase_barrier();
+        stamp(3);
+
+        // this tile's bias values BEFORE the next tile's DMAs go out: hipcc waits vmcnt(0) for a register load, i.e. for every DMA
+        // issued in front of its use as well (measured: 2.3 us per tile with the loads inside the epilogue = the slab's HBM latency)
+        const int n0 = cur.nt * HBN;
+        f32x4 bvals[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const int co = n0 + rb * 16 + 4 * q4;
+            bvals[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (bias != nullptr && co < Cout) bvals[rb] = *reinterpret_cast<const f32x4*>(bias + co);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) asm volatile("" : "+v"(bvals[rb]));      // the loads stay in front of the DMAs below
+
+        base += G;
+        const int n_k = min(G, ntiles - base);
+        const bool has_next = (int)blockIdx.x < n_k;
+        const int next = has_next ? base + cvk_xcd_remap(blockIdx.x, n_k) : 0;
+        if (has_next) {
+            const Geo g = geo_of(next);
+            setup_dma(g);
+            issue_prologue();
+        }
+        stamp(4);
+
+        // ---- epilogue: acc[rb][cb][i] = channel n0 + rb*16 + 4*q4 + i, pixel (y0 + row0 + (cb >> 1), x0 + (cb & 1)*16 + l15) ---------------
+        int elane = lane;
+        asm volatile("" : "+v"(elane));
+        const int l15 = elane & 15, q4 = elane >> 4, lane = elane;
+        const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(Y + ((size_t)(cur.img * H + cur.y0) * W + cur.x0) * ldy + n0), 0, 0x7FFFFFFF, 0x00020000);
+        {
+            float s[4][4], q[4][4];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const f32x4 bv = bvals[rb];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s[rb][j] = 0.f; q[rb][j] = 0.f; }
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    const bool ok = (cur.x0 + (cb & 1) * 16 + l15 < W) & (cur.y0 + row0 + (cb >> 1) < H);
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[rb][cb][j] + bv[j];
+                    if (STATS) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float vm = ok ? v[j] : 0.f;
+                            s[rb][j] += vm;
+                            q[rb][j] += vm * vm;
+                        }
+                    }
+                    const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    // stage: [512 pixels][128 B], 16-byte chunk c of pixel p at position c ^ ((p >> 1) & 7)
+                    const int p = (row0 + (cb >> 1)) * 32 + (cb & 1) * 16 + l15, chunk = rb * 2 + (q4 >> 1);
+                    *reinterpret_cast<bf16x4*>(smem + STAGE_OFF + p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4) + 8 * (q4 & 1)) = o;
+                }
+            }
+            if (STATS) {
+                float2* const red = reinterpret_cast<float2*>(smem + RED_OFF);
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float ss = row_sum16(s[rb][j]), qq = row_sum16(q[rb][j]);
+                        if (l15 == 0) red[(rb * 16 + 4 * q4 + j) * 8 + wave] = float2{ss, qq};
+                    }
+            }
+        }
+        __syncthreads();
+        stamp(5);
+        {
+            // wave w stores tile rows 2w, 2w + 1: 8 instructions of 8 pixels x 128 B
+            const int chunk = lane & 7;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int p = wave * 64 + it * 8 + (lane >> 3);
+                const int prow = p >> 5, pcol = p & 31;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(smem + STAGE_OFF + p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4));
+                const bool ok = (cur.y0 + prow < H) & (cur.x0 + pcol < W) & (n0 + chunk * 8 < ldy);
+                const unsigned off = (unsigned)((prow * W + pcol) * ldy + chunk * 8) * 2u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), yrsrc, ok ? off : 0x80000000u, 0, 0);
+            }
+        }
+        if (STATS) {
+            if (tid < HBN) {
+                const float2* const red = reinterpret_cast<const float2*>(smem + RED_OFF);
+                double S = 0.0, Q = 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float2 v = red[tid * 8 + i]; S += (double)v.x; Q += (double)v.y; }
+                const int co = n0 + tid;
+                const int nvalid = min(TH, H - cur.y0) * min(TW, W - cur.x0);
+                if (co < Cout) {
+                    const double m2 = Q - S * S / (double)nvalid;
+                    stats[(size_t)cur.sp * Cout + co] = (float)S;
+                    stats[(size_t)(P + cur.sp) * Cout + co] = (float)(m2 > 0.0 ? m2 : 0.0);
+                }
+                if (cur.nt == 0 && tid == 0) cnt[cur.sp] = (float)nvalid;
+            }
+        }
+        __syncthreads();            // stage and partials are read: the next tile's K loop may overwrite slab B
+        stamp(6);
+        ++tcount;
+        if (!has_next) break;
+        tile = next;
+        cur = geo_of(tile);
+        stores_in_flight = true;
+    }
+}
+
 // fp32 master weights, physical [Cout][3][3][Cin] -> tile-major bf16 pack [row tile][slice][tap][128 rows][4 chunks][8], chunk
 // position p of row n holds source chunk p ^ ((n>>2)&3) (the LDS image of one DMA'd tap tile, byte for byte); zero padded.
 // dgrad: rows are the INPUT channels of the layer, k runs over its output channels, taps rotated by 180 degrees.
-__global__ void k_pack_w_pp(const float* __restrict__ w, __bf16* __restrict__ out, int Cout, int Cin, int ntile, int ncs, int dgrad, int mf16) {
-    const size_t total = (size_t)ntile * ncs * 9 * BN * CK;
+__global__ void k_pack_w_pp(const float* __restrict__ w, __bf16* __restrict__ out, int Cout, int Cin, int ntile, int ncs, int dgrad, int mf16, int bn) {
+    const size_t total = (size_t)ntile * ncs * 9 * bn * CK;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int e = (int)(i & 7), p = (int)((i >> 3) & 3), n = (int)((i >> 5) & (BN - 1));
-        size_t rest = i >> 12;
+        const int e = (int)(i & 7), p = (int)((i >> 3) & 3), n = (int)((i >> 5) & (bn - 1));
+        size_t rest = (i >> 5) / bn;
         const int tap = (int)(rest % 9); rest /= 9;
         const int cs = (int)(rest % ncs);
         const int ntl = (int)(rest / ncs);
-        const int row = ntl * BN + n;
+        const int row = ntl * bn + n;
         const int k = cs * CK + ((p ^ (mf16 ? ((n >> 2) & 1) << 1 : (n >> 2) & 3)) << 3) + e;
         float v = 0.f;
         if (!dgrad) { if (row < Cout && k < Cin) v = w[((size_t)row * 9 + tap) * Cin + k]; }
@@ -699,11 +1018,16 @@ __global__ void k_pack_w_pp(const float* __restrict__ w, __bf16* __restrict__ ou
 
 namespace cvk_bf16p {
 
-bool serves(int Cin, int Cout) {
+int kind(int Cin, int Cout) {
     static const int on = getenv("CVK_BF16P") ? atoi(getenv("CVK_BF16P")) : 1;
     static const int minci = getenv("CVK_BF16P_MINCI") ? atoi(getenv("CVK_BF16P_MINCI")) : 64;
-    return on && Cout > 64 && Cin >= minci && Cin % CK == 0;
+    static const int h64 = getenv("CVK_BF16P_H64") ? atoi(getenv("CVK_BF16P_H64")) : 1;
+    if (!on || Cin < minci || Cin % CK != 0) return 0;
+    if (Cout > 64) return 1;
+    return (h64 && Cout > 32) ? 2 : 0;
 }
+
+bool serves(int Cin, int Cout) { return kind(Cin, Cout) != 0; }
 
 static int mfma_shape() {          // 16: v_mfma_f32_16x16x32_bf16 (k_conv_bf16q), 32: v_mfma_f32_32x32x16_bf16 (k_conv_bf16p)
     static const int mf = getenv("CVK_BF16P_MF") ? atoi(getenv("CVK_BF16P_MF")) : 16;
@@ -714,17 +1038,30 @@ int stat_partials(int N, int H, int W) { return N * cvk_cdiv(H, TH) * cvk_cdiv(W
 
 void pack(const float* w, void* out, int Cout, int Cin, int Kpad, bool dgrad, hipStream_t s) {
     const int rows = dgrad ? Cin : Cout;
-    const int ntile = cvk_cdiv(rows, BN), ncs = Kpad / CK;
-    const size_t total = (size_t)ntile * ncs * 9 * BN * CK;
+    const int k = kind(Kpad, rows);
+    const int bn = k == 2 ? HBN : BN;
+    const int ntile = cvk_cdiv(rows, bn), ncs = Kpad / CK;
+    const size_t total = (size_t)ntile * ncs * 9 * bn * CK;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_pack_w_pp, dim3(blocks), dim3(256), 0, s, w, (__bf16*)out, Cout, Cin, ntile, ncs, dgrad ? 1 : 0, mfma_shape() == 16 ? 1 : 0);
+    hipLaunchKernelGGL(k_pack_w_pp, dim3(blocks), dim3(256), 0, s, w, (__bf16*)out, Cout, Cin, ntile, ncs, dgrad ? 1 : 0, (k == 2 || mfma_shape() == 16) ? 1 : 0, bn);
 }
 
 void launch(const void* x, const void* wpp, const float* bias, void* y, float* stats, float* counts, int N, int H, int W, int Cin,
             int Cout, int ldy, hipStream_t s) {
-    const int tilesX = cvk_cdiv(W, TW), tilesY = cvk_cdiv(H, TH), tilesN = cvk_cdiv(Cout, BN);
+    const int knd = kind(Cin, Cout);
+    const int tilesX = cvk_cdiv(W, TW), tilesY = cvk_cdiv(H, TH), tilesN = cvk_cdiv(Cout, knd == 2 ? HBN : BN);
     const int P = N * tilesX * tilesY;
     dim3 grid((unsigned)(P * tilesN)), block(512);
+    static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 0 ? n : 256; }();
+    if (knd == 2) {
+        const int ntiles = P * tilesN;
+        dim3 pgrid((unsigned)(cus < ntiles ? cus : ntiles));
+        static const int hdbg = getenv("CVK_BF16H_DBG") ? atoi(getenv("CVK_BF16H_DBG")) : 0;
+        if (hdbg) hipLaunchKernelGGL((k_conv_bf16h<false, 1>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);
+        else if (stats) hipLaunchKernelGGL((k_conv_bf16h<true>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);
+        else hipLaunchKernelGGL((k_conv_bf16h<false>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);
+        return;
+    }
     static const int dbg = getenv("CVK_BF16P_DBG") ? atoi(getenv("CVK_BF16P_DBG")) : 0;      // timing experiments only
     static const int var = getenv("CVK_BF16P_VAR") ? atoi(getenv("CVK_BF16P_VAR")) : 0;
 #define CVK_PP(ST_, DBG_, V_)                                                                                                              \
@@ -732,7 +1069,6 @@ void launch(const void* x, const void* wpp, const float* bias, void* y, float* s
                        H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P)
     if (mfma_shape() == 16) {
         const int ntiles = P * tilesN;
-        static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 0 ? n : 256; }();
         static const int cap = getenv("CVK_BF16P_GRID") ? atoi(getenv("CVK_BF16P_GRID")) : 0;      // timing experiments only
         int g = cap > 0 ? cap : cus;
         if (g > ntiles) g = ntiles;
