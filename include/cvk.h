@@ -281,6 +281,12 @@ int cvk_bn_bwd_reduce(cvk_view dout, const float* y, int ldy, const float* scale
                       const float* mean, const float* rstd, float* part, int N, int H, int W, int C, void* stream);
 /* sums PB partial rows in fp64: out0[c] = sum part[0][:,c], out1[c] = sum part[1][:,c] (out1/part1 nullable) */
 int cvk_colsum_finalize(const float* part, int PB, int C, float* out0, float* out1, void* stream);
+/* n (<= CVK_COLSUM_BATCH_MAX) such finalisations, one output each, in ONE launch; `jobs` is a HOST array (copied into the
+ * kernel arguments).  The executor collects the conv-bias gradients of a backward pass and finalises them at its end
+ * (or when a data-parallel gradient bucket is handed to the all-reduce). */
+#define CVK_COLSUM_BATCH_MAX 64
+typedef struct cvk_colsum_job { const float* part; float* out; int PB, C; } cvk_colsum_job;
+int cvk_colsum_finalize_batch(const cvk_colsum_job* jobs, int n, void* stream);
 /* backward, pass 2: dy = scale*(g - dbeta/M - xhat*dgamma/M) (training) or dy = scale*g (eval: use_batch_stats=0);
  *   also emits column-sum partials of dy (conv bias gradient) into dbias_part float[PB][C] when non-NULL. */
 int cvk_bn_bwd_dx(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift,
@@ -350,6 +356,12 @@ int cvk_bf16s_stat_partials_c(int N, int H, int W, int Cin, int Cout);
  * data-grad filter bf16 [rows_pad(Cin)][9][Cout_pad]; zero padded */
 int cvk_pack_weight_fwd_bf16(const float* w, void* out, int Cout, int Cin, int Cin_pad, void* stream);
 int cvk_pack_weight_dgrad_bf16(const float* w, void* out, int Cout, int Cin, int Cout_pad, void* stream);
+/* n (<= CVK_PACK_BATCH_MAX) such packs in ONE launch: job i = cvk_pack_weight_fwd_bf16(w, out, Cout, Cin, Kpad) (dgrad = 0) or
+ * cvk_pack_weight_dgrad_bf16(w, out, Cout, Cin, Kpad) (dgrad = 1); `jobs` is a HOST array (copied into the kernel arguments).
+ * The executor packs every layer of a step up front when the weights have changed (models/unet.py:35-92: 23 conv layers). */
+#define CVK_PACK_BATCH_MAX 48
+typedef struct cvk_pack_job { const float* w; void* out; int Cout, Cin, Kpad, dgrad; } cvk_pack_job;
+int cvk_pack_weights_bf16_batch(const cvk_pack_job* jobs, int n, void* stream);
 /* y[N,H,W,ldy] (bf16) = conv3x3(x[N,H,W,Cin] bf16, w bf16 [rows_pad][9][Cin]) + bias; Cin % 32 == 0.  With stats != NULL:
  * stats[2][P][Cout] = per-tile (sum, M2 about the tile mean) of the fp32 results, counts[P] = pixels per tile,
  * P = cvk_bf16s_stat_partials_c(N,H,W,Cin,Cout) -> cvk_bn_finalize_counts.  Data-grad: the same call on dy and the dgrad pack. */

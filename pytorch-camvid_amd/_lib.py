@@ -119,6 +119,7 @@ SIGNATURES = {
     "cvk_bn_bwd_blocks": (c_int, [c_int]),
     "cvk_bn_bwd_reduce": (c_int, [View, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_colsum_finalize": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "cvk_colsum_finalize_batch": (c_int, [c_vp, c_int, c_vp]),            # jobs: host array of ColsumJob
     "cvk_bn_bwd_dx": (c_int, [View, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp,
                               c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_maxpool2x2_fwd": (c_int, [View, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
@@ -139,6 +140,7 @@ SIGNATURES = {
     "cvk_bf16s_stat_partials_c": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "cvk_pack_weight_fwd_bf16": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "cvk_pack_weight_dgrad_bf16": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "cvk_pack_weights_bf16_batch": (c_int, [c_vp, c_int, c_vp]),          # jobs: host array of PackJob
     "cvk_conv3x3_bf16s": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_bn_finalize_counts": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                        c_float, c_float, c_vp, c_size, c_vp]),
@@ -159,6 +161,19 @@ SIGNATURES = {
 
 _lib = None
 _lock = threading.Lock()
+
+
+class PackJob(ctypes.Structure):        # include/cvk.h cvk_pack_job
+    _fields_ = [("w", ctypes.c_void_p), ("out", ctypes.c_void_p), ("Cout", ctypes.c_int), ("Cin", ctypes.c_int),
+                ("Kpad", ctypes.c_int), ("dgrad", ctypes.c_int)]
+
+
+class ColsumJob(ctypes.Structure):      # include/cvk.h cvk_colsum_job
+    _fields_ = [("part", ctypes.c_void_p), ("out", ctypes.c_void_p), ("PB", ctypes.c_int), ("C", ctypes.c_int)]
+
+
+PACK_BATCH_MAX = 48
+COLSUM_BATCH_MAX = 64
 
 
 class CvkError(RuntimeError):

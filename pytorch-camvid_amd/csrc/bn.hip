@@ -445,6 +445,40 @@ __global__ __launch_bounds__(1024) void k_colsum_finalize(const float* __restric
     }
 }
 
+// several column-sum finalisations in one launch (the conv-bias gradients of a backward pass are not needed before its end: 23
+// launches of ~8 us -> 1); jobs by value, blockIdx.y = job
+struct ColsumJobsDev { cvk_colsum_job j[CVK_COLSUM_BATCH_MAX]; };
+__global__ __launch_bounds__(1024) void k_colsum_finalize_batch(const ColsumJobsDev jobs) {
+    __shared__ double red[16][64];
+    const cvk_colsum_job& J = jobs.j[blockIdx.y];
+    const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l;
+    if (blockIdx.x * 64 >= J.C) return;                 // uniform per workgroup
+    const float* src = J.part;
+    const int PB = J.PB, C = J.C;
+    double a = 0.0;
+    if (c < C) {
+        double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int p = g;
+        for (; p + 48 < PB; p += 64) {
+            a += (double)src[(size_t)p * C + c];
+            a1 += (double)src[(size_t)(p + 16) * C + c];
+            a2 += (double)src[(size_t)(p + 32) * C + c];
+            a3 += (double)src[(size_t)(p + 48) * C + c];
+        }
+        for (; p < PB; p += 16) a += (double)src[(size_t)p * C + c];
+        a = (a + a1) + (a2 + a3);
+    }
+    red[g][l] = a;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += red[i][l];
+        J.out[c] = (float)s;
+    }
+}
+
 int bwd_rows(int M) {
     const int pb = cvk_bn_bwd_blocks(M);
     return cvk_cdiv(M, pb);
@@ -645,6 +679,19 @@ extern "C" int cvk_bn_bwd_dx_e6(cvk_view dout, const float* y, int ldy, const fl
     hipLaunchKernelGGL(k_bn_bwd_dx_e, grid, dim3(256), 0, (hipStream_t)stream, dout.ptr, dm, y, ldy, scale, shift, mean, rstd,
                        dgamma, dbeta, dy, ld_dy, E6, part, M, C, W, Wt, Mt, tiles, cchunk, use_batch_stats, H, Wtp, rows);
     CVK_LAUNCH_RETURN("cvk_bn_bwd_dx_e6");
+}
+
+extern "C" int cvk_colsum_finalize_batch(const cvk_colsum_job* jobs, int n, void* stream) {
+    CVK_CHECK_ARG(jobs && n > 0 && n <= CVK_COLSUM_BATCH_MAX, "cvk_colsum_finalize_batch: 1 <= n <= %d jobs", CVK_COLSUM_BATCH_MAX);
+    ColsumJobsDev d;
+    int cmax = 0;
+    for (int i = 0; i < n; ++i) {
+        CVK_CHECK_ARG(jobs[i].part && jobs[i].out && jobs[i].PB > 0 && jobs[i].C > 0, "cvk_colsum_finalize_batch: bad job %d", i);
+        d.j[i] = jobs[i];
+        if (jobs[i].C > cmax) cmax = jobs[i].C;
+    }
+    hipLaunchKernelGGL(k_colsum_finalize_batch, dim3(cvk_cdiv(cmax, 64), n), dim3(1024), 0, (hipStream_t)stream, d);
+    CVK_LAUNCH_RETURN("cvk_colsum_finalize_batch");
 }
 
 extern "C" int cvk_colsum_finalize(const float* part, int PB, int C, float* out0, float* out1, void* stream) {

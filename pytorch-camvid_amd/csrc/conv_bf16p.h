@@ -1,6 +1,7 @@
 // Internal interface between conv_bf16s.hip (C-ABI entry points, layer dispatch) and conv_bf16p.hip (the ping-pong kernel).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "../../include/cvk.h"
 
 namespace cvk_bf16p {
 
@@ -22,5 +23,8 @@ void launch(const void* x, const void* wpp, const float* bias, void* y, float* s
 
 // fp32 master [Cout][3][3][Cin] -> tile-major bf16 pack; dgrad = rotated by 180 degrees, channels exchanged
 void pack(const float* w, void* out, int Cout, int Cin, int Kpad, bool dgrad, hipStream_t s);
+
+// every pack of a step in one launch (n <= CVK_PACK_BATCH_MAX); layouts as pack() / cvk_pack_weight_{fwd,dgrad}_bf16 choose them
+void pack_batch(const cvk_pack_job* jobs, int n, hipStream_t s);
 
 }  // namespace cvk_bf16p

@@ -657,6 +657,17 @@ extern "C" int cvk_pack_weight_dgrad_bf16(const float* w, void* out, int Cout, i
     CVK_LAUNCH_RETURN("cvk_pack_weight_dgrad_bf16");
 }
 
+extern "C" int cvk_pack_weights_bf16_batch(const cvk_pack_job* jobs, int n, void* stream) {
+    CVK_CHECK_ARG(jobs && n > 0 && n <= CVK_PACK_BATCH_MAX, "cvk_pack_weights_bf16_batch: 1 <= n <= %d jobs", CVK_PACK_BATCH_MAX);
+    for (int i = 0; i < n; ++i) {
+        const cvk_pack_job& q = jobs[i];
+        CVK_CHECK_ARG(q.w && q.out && q.Cout > 0 && q.Cin > 0 && q.Kpad % CK == 0 && q.Kpad >= (q.dgrad ? q.Cout : q.Cin),
+                      "cvk_pack_weights_bf16_batch: bad job %d", i);
+    }
+    cvk_bf16p::pack_batch(jobs, n, (hipStream_t)stream);
+    CVK_LAUNCH_RETURN("cvk_pack_weights_bf16_batch");
+}
+
 extern "C" int cvk_conv3x3_bf16s(const void* x, const void* w, const float* bias, void* y, float* stats, float* counts, int N, int H,
                                  int W, int Cin, int Cout, int ldy, void* stream) {
     CVK_CHECK_ARG(x && w && y, "cvk_conv3x3_bf16s: null pointer");

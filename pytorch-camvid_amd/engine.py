@@ -90,6 +90,7 @@ class RunState:
         self.stream = None
         self.sync = None   # optional gradient synchroniser (ddp.GradSync)
         self.pooled_by_block = {}   # op index of a conv block -> True when its BN-apply pass also wrote the max pool behind it
+        self.colsums = []           # queued column-sum finalisations (Runner.defer_colsum)
         self.bnred = {}             # op index of a conv block -> (partials, count): its BN-backward sums, left by the consumer's data-grad
 
 
@@ -569,7 +570,7 @@ class ConvBnRelu(Op):
                 dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, E6.data_ptr(), part.data_ptr(),
                 N, H, W, C, 1 if st.training else 0, s), "byte")
             if rc == 0:
-                check(lib.cvk_colsum_finalize(part.data_ptr(), PBe, C, gb, None, s), "cvk_colsum_finalize")  # conv bias grad
+                R.defer_colsum(st, part, PBe, C, gb)           # conv bias grad: finalised with the others, in one launch
             else:
                 E6 = None           # layout not vectorisable (strided view): plain pass below, the weight-grad transforms dy itself
         if E6 is None and wgrad4 and not wgradp and ldy == C and C % 4 == 0:
@@ -579,14 +580,14 @@ class ConvBnRelu(Op):
                 dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, E.data_ptr(), part.data_ptr(),
                 N, H, W, C, 1 if st.training else 0, s), "byte")
             if rc == 0:
-                check(lib.cvk_colsum_finalize(part.data_ptr(), PBe, C, gb, None, s), "cvk_colsum_finalize")  # conv bias grad
+                R.defer_colsum(st, part, PBe, C, gb)           # conv bias grad: finalised with the others, in one launch
             else:
                 E = None            # layout not vectorisable (strided view): plain pass below, wgrad transforms dy itself
         if E is None and E6 is None:
             _timed(R, "k_bn_bwd<dx>", 12.0 * M * C, lambda: check(
                 lib.cvk_bn_bwd_dx(dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, part.data_ptr(),
                                   N, H, W, C, 1 if st.training else 0, s), "cvk_bn_bwd_dx"), "byte")
-            check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, gb, None, s), "cvk_colsum_finalize")  # conv bias grad
+            R.defer_colsum(st, part, PB, C, gb)             # conv bias grad: finalised with the others, in one launch
         del y
         # weight-grad AND data-grad on the 2-D path with the same tile: dy is transformed for both in ONE launch (csrc/wino2d.hip
         # k_w2d_dy_both): E for the weight-grad, V' for the data-grad; dy crosses the fabric once
@@ -794,7 +795,7 @@ class ConvBnRelu(Op):
         _timed(R, "k_bnbwd_bf16<dx>", (esz + 4.0) * M * C, lambda: check(
             lib.cvk_bn_bwd_dx_bf16(dO, do_f32, y.data_ptr(), C, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ld_dy, part.data_ptr(),
                                    N, H, W, C, 1 if st.training else 0, s), "cvk_bn_bwd_dx_bf16"), "byte")
-        check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, gb, None, s), "cvk_colsum_finalize")  # conv bias grad
+        R.defer_colsum(st, part, PB, C, gb)             # conv bias grad: finalised with the others, in one launch
         del y
         wc = w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last)
         flops = 18.0 * M * C * self.cin
@@ -1092,6 +1093,35 @@ class Runner:
         self._wc[key] = (sig, t)
         return t
 
+    def prepack_bf16(self, plan, st, need_grad):
+        """bf16 plans: every weight pack the step will ask for and the cache does not hold (forward packs; data-grad packs when a
+        backward pass follows) in ONE launch (cvk_pack_weights_bf16_batch) instead of one ~9 us launch per layer and direction."""
+        if not self.wcache or torch.cuda.is_current_stream_capturing():
+            return
+        lib, jobs, keep = self.lib, [], []
+        for op in plan.ops:
+            if not isinstance(op, ConvBnRelu):
+                continue
+            w = st.params[4 * op.pslot]
+            sig = (WEIGHT_EPOCH[0], self.wepoch, w.data_ptr(), w._version)
+            want = [(((op.pslot, "f"), "bf16"), 0, op.cout, op.src.ld)]
+            if need_grad and op.src_needs_grad:
+                want.append((((op.pslot, "d"), "bf16"), 1, op.cin, max(32, op.cout)))
+            for key, dgrad, rows, kpad in want:
+                ent = self._wc.get(key)
+                if ent is not None and ent[0] == sig:
+                    continue
+                wc = w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last)
+                t = torch.empty(lib.cvk_bf16s_rows_pad(rows) * 9 * kpad, device=w.device, dtype=_BF16)
+                jobs.append(_lib.PackJob(wc.data_ptr(), t.data_ptr(), op.cout, op.cin, kpad, dgrad))
+                keep.append(wc)
+                self._wc[key] = (sig, t)
+                self.wcache_builds += 1
+        for i in range(0, len(jobs), _lib.PACK_BATCH_MAX):
+            chunk = jobs[i:i + _lib.PACK_BATCH_MAX]
+            arr = (_lib.PackJob * len(chunk))(*chunk)
+            check(lib.cvk_pack_weights_bf16_batch(ctypes.addressof(arr), len(chunk), st.stream), "cvk_pack_weights_bf16_batch")
+
     def workspace(self, nbytes, dev):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
             self._ws = torch.empty(max(nbytes, 1 << 20), device=dev, dtype=torch.uint8)
@@ -1113,8 +1143,23 @@ class Runner:
         base = st.gflat.data_ptr()
         return tuple(base + 4 * st.goffs[4 * slot + j] for j in range(4))
 
+    def defer_colsum(self, st, part, PB, C, out_ptr):
+        """Queue a column-sum finalisation whose result nobody reads before the end of backward (or the all-reduce of its
+        gradient bucket): flushed in ONE launch by flush_colsums."""
+        st.colsums.append((part, PB, C, out_ptr))
+        if len(st.colsums) >= _lib.COLSUM_BATCH_MAX:
+            self.flush_colsums(st)
+
+    def flush_colsums(self, st):
+        if not st.colsums:
+            return
+        arr = (_lib.ColsumJob * len(st.colsums))(*[_lib.ColsumJob(p.data_ptr(), o, pb, c) for p, pb, c, o in st.colsums])
+        check(self.lib.cvk_colsum_finalize_batch(ctypes.addressof(arr), len(st.colsums), st.stream), "cvk_colsum_finalize_batch")
+        st.colsums.clear()
+
     def grads_ready(self, st, slot):
         if st.sync is not None:
+            self.flush_colsums(st)          # a bucket may be handed to the all-reduce: its bias gradients must be final
             st.sync.layer_done(st, slot)
 
     # ---- forward / backward -------------------------------------------------------------------------------------
@@ -1149,6 +1194,8 @@ class Runner:
             check(self.lib.cvk_import_nchw(x.data_ptr(), sN, sC, sH, sW, t.data_ptr(), inb.ld, inb.N, inb.C, inb.H, inb.W,
                                            st.stream), "cvk_import_nchw")
             st.act[inb.id] = t
+        if plan.bf16:
+            self.prepack_bf16(plan, st, need_grad)
         for op in plan.ops:
             op.fwd(self, st)
         ov = plan.output
@@ -1183,6 +1230,7 @@ class Runner:
             st.grad[ob.id] = g
         for op in reversed(plan.ops):
             op.bwd(self, st)
+        self.flush_colsums(st)
         dx = None
         if plan.input_needs_grad:
             gi = st.grad[plan.input.id]
