@@ -131,3 +131,70 @@ def test_winograd2d_rounding():
         e_direct = np.linalg.norm(direct(x.astype(np.float32), w.astype(np.float32)) - ref) / n
         e_w2d = np.linalg.norm(w2d(x, w) - ref) / n
         assert e_direct < 5e-7 and 1e-6 < e_w2d < 3e-6, (ci, co, e_direct, e_w2d)      # GPU tolerance: 9e-6 = 3 x 3e-6
+
+
+def test_logits_tolerance_is_frozen():
+    """the full-size logits tolerance is derived from the reference graph's own drift (make_drift.py logits) — and may
+    not grow with the kernels.  6.8e-4 is the ceiling: a fixture regenerated with a larger tolerance fails here."""
+    import json, os
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "drift.json")))
+    for tag, v in d["logits_tolerance"].items():
+        assert 0 < v["slice_abs"] <= 6.8e-4, (tag, v)
+
+
+def test_w6_point_sets_and_exact_transforms():
+    """can F(6x6,3x3) be made as accurate as F(4x4,3x3) by other interpolation points or more careful transforms?
+    A numpy model of the 2-D path (Cook-Toom matrices for a point set, fp32 storage of U and V, fp32 GEMM accumulation) against an
+    fp64 direct convolution at 256 input channels: (1) the standard points {0, +-1, +-2, +-1/2, inf} are within 10 % of the best
+    symmetric set of simple rationals; (2) with all three transforms evaluated in fp64 and rounded ONCE the error only drops from
+    3.0e-6 to 2.7e-6 — it is the fp32 rounding of the transform-domain operands and products themselves, so no transform
+    arithmetic recovers the factor of two to F(4x4) (1.5e-6).  The accuracy trade of the 6x6 tile is inherent."""
+    from fractions import Fraction as Fr
+
+    def matrices(pts, m):
+        n = m + 2
+        a = [float(p) for p in pts]
+        AT = np.zeros((m, n)); G = np.zeros((n, 3))
+        for j in range(n - 1):
+            Nj = np.prod([a[j] - a[k] for k in range(n - 1) if k != j])
+            for i in range(m): AT[i, j] = a[j] ** i
+            for k in range(3): G[j, k] = a[j] ** k / Nj
+        AT[m - 1, n - 1] = 1.0; G[n - 1, 2] = 1.0
+        BT = np.zeros((n, n))
+        for l in range(n):
+            rows = [AT[i, :] * G[:, k] for i in range(m) for k in range(3)]
+            rhs = [1.0 if l == i + k else 0.0 for i in range(m) for k in range(3)]
+            BT[:, l] = np.linalg.lstsq(np.array(rows), np.array(rhs), rcond=None)[0]
+        return AT, G, BT
+
+    def err(pts, m, exact=False, ci=256, co=32):
+        AT, G, BT = matrices(pts, m)
+        rng = np.random.default_rng(0)
+        H = W = 12
+        x = np.maximum(rng.standard_normal((H + 2, W + 2, ci)), 0)
+        b = 1 / np.sqrt(9 * ci)
+        w = rng.uniform(-b, b, (co, 3, 3, ci))
+        ref = np.zeros((H, W, co))
+        for dy in range(3):
+            for dx in range(3):
+                ref += x[dy:dy + H, dx:dx + W, :] @ w[:, dy, dx, :].T
+        f = np.float32
+        T = np.float64 if exact else f
+        U = np.einsum('ij,ojkc,lk->iloc', G.astype(T), w.astype(f).astype(T), G.astype(T)).astype(f)
+        y = np.zeros((H, W, co))
+        for ty in range(0, H, m):
+            for tx in range(0, W, m):
+                d = x[ty:ty + m + 2, tx:tx + m + 2, :].astype(f).astype(T)
+                V = np.einsum('ikc,lk->ilc', np.einsum('ij,jkc->ikc', BT.astype(T), d), BT.astype(T)).astype(f)
+                M = np.einsum('ilc,iloc->ilo', V, U)                                      # fp32 accumulation
+                y[ty:ty + m, tx:tx + m, :] = np.einsum('jlo,kl->jko', np.einsum('ji,ilo->jlo', AT.astype(T), M.astype(T)), AT.astype(T))
+        return np.linalg.norm(y - ref) / np.linalg.norm(ref)
+
+    std6 = [0, 1, -1, 2, -2, Fr(1, 2), Fr(-1, 2)]
+    e6, e6x = err(std6, 6), err(std6, 6, exact=True)
+    e4 = err([0, 1, -1, 2, -2], 4)
+    others = [err([0, 1, -1, b, -b, c, -c], 6) for b, c in ((Fr(1, 2), Fr(7, 4)), (2, Fr(4, 7)), (Fr(7, 4), Fr(4, 7)), (Fr(1, 2), Fr(5, 3)),
+                                                            (2, Fr(3, 5)), (Fr(3, 4), Fr(4, 3)), (Fr(1, 2), 3), (Fr(3, 2), Fr(2, 3)))]
+    print("F(6x6) standard", e6, "exact transforms", e6x, "F(4x4)", e4, "best alternative", min(others))
+    assert min(others) > 0.9 * e6, (e6, others)                  # no alternative point set is meaningfully better
+    assert e6x > 0.8 * e6 and e6 > 1.7 * e4, (e6, e6x, e4)      # exact transforms do not close the gap to F(4x4)

@@ -23,11 +23,73 @@ def batch(n, h, w, seed):
     return x.to(dev()), t.to(dev())
 
 
-# SegNet fixture that the forced-F(4,3) mode skips: its rounding flips a max-pool arg-max there (see the docstring)
-F43_FLIPS = "segnet_s4_2x96x128"
+def _acts(net, x):
+    """Every activation buffer of one training-mode forward pass of `net`, by buffer id (engine.RunState.act), + the plan."""
+    from pytorch_camvid_amd import engine
+    from pytorch_camvid_amd.modules import _state_of
+    with torch.no_grad():
+        net(x)                                            # records the plan for this geometry
+    state = _state_of(net)
+    plan = [p for k, p in state["plans"].items() if k[:4] == tuple(x.shape)][0]
+    params = []
+    for h in plan.holders:
+        params.extend(h.block_params())
+    _, st = state["runner"].forward(plan, x, params, True, True)
+    torch.cuda.synchronize()
+    return plan, st
 
 
-@pytest.mark.parametrize("tag,conv", [(t, c) for t in NETS for c in ("default", "f43_always") if not (c == "f43_always" and t == F43_FLIPS)] +
+def _assert_deviation_is_an_argmax_tie(tag, meta, conv_setup, x):
+    """ADVICE r3 / VERDICT r3 2d: a forced kernel mode that moves a SegNet golden by more than the tolerance must be EXPLAINED, not
+    skipped.  Run the default mode and the forced mode on identical weights and input and walk the activation buffers in execution
+    order.  Claim checked: up to the first MaxUnpool2d (models/segnet.py:104-116) whose output differs, the two modes agree to
+    rounding; at that unpool the outputs differ because max-pool arg-max indices differ (models/segnet.py:79), and in EVERY window
+    whose index differs the two largest inputs lie closer together than the modes' own rounding-level difference on that tensor —
+    a tie that either summation order may break.  A defect in the forced kernels (wrong tile walk, wrong fused pool code, wrong
+    BN sums) would show as a difference that is NOT born at such a tie and fails here."""
+    import pytorch_camvid_amd as A
+    from pytorch_camvid_amd import engine
+    nets = []
+    for forced in (False, True):
+        torch.manual_seed(meta["seed"])
+        net = A.get_model(meta["kind"], 3, 12).to(dev()).train()
+        if forced:
+            conv_setup(net)
+        nets.append(net)
+    (plan, sa), (plan_b, sb) = _acts(nets[0], x), _acts(nets[1], x)
+    assert len(plan.ops) == len(plan_b.ops)
+    first = None
+    for op in plan.ops:
+        if isinstance(op, engine.MaxPool) and op.keep_code:
+            ca, cb = sa.saved[op.idx], sb.saved[op.idx]                     # 1-byte arg-max codes of every window
+            if not torch.equal(ca, cb):
+                first = op
+                break
+        elif isinstance(op, engine.ConvBnRelu):
+            a, b = sa.act[op.dst.buf.id].float(), sb.act[op.dst.buf.id].float()
+            scale = max(a.abs().max().item(), 1e-6)
+            # before the first flip the modes agree to accumulated rounding (BatchNorm over as few as 6-24 samples amplifies it)
+            assert (a - b).abs().max().item() <= 2e-3 * scale, (tag, "conv block output differs before any pool index differs", op.idx,
+                                                               (a - b).abs().max().item(), scale)
+    assert first is not None, (tag, "logits differ although every max-pool index agrees")
+    pool = first
+    pre_a, pre_b = sa.act[pool.src.buf.id].float(), sb.act[pool.src.buf.id].float()          # the max pool's input, both modes
+    rounding = (pre_a - pre_b).abs().max().item()
+    d = pool.dst
+    N, H, W, C = pre_a.shape[0], d.H * 2, d.W * 2, pool.src.C
+    win = pre_a[:, :H, :W, :C].reshape(N, d.H, 2, d.W, 2, C).permute(0, 1, 3, 5, 2, 4).reshape(N, d.H, d.W, C, 4)
+    top2 = win.topk(2, dim=-1).values
+    gap = (top2[..., 0] - top2[..., 1])                                                        # [N, H/2, W/2, C]
+    moved = (sa.saved[pool.idx] != sb.saved[pool.idx]).view(N, d.H, d.W, d.ld)[..., :C]
+    nmoved = int(moved.sum().item())
+    assert 0 < nmoved <= max(4, int(2e-3 * moved.numel())), (tag, "windows with a different arg-max", nmoved, moved.numel())
+    worst = gap[moved].max().item()
+    print(f"{tag}: {nmoved} of {moved.numel()} windows of the max pool at op {pool.idx} flipped; largest top-2 gap there {worst:.3e}, "
+          f"mode-to-mode rounding on that tensor {rounding:.3e}")
+    assert worst <= 4.0 * rounding + 1e-7, (tag, "an arg-max moved although its window was not a tie", worst, rounding)
+
+
+@pytest.mark.parametrize("tag,conv", [(t, c) for t in NETS for c in ("default", "f43_always")] +
                          [(t, c) for t in NETS if t.startswith("unet") for c in ("w2d_always", "w2d4_always")])
 def test_net_forward_loss_grads_golden(tag, conv):
     """conv = "default": the engine's per-layer choice (direct / F(2,3) / F(4,3) by grid size; at these small goldens
@@ -38,10 +100,13 @@ def test_net_forward_loss_grads_golden(tag, conv):
     F(4,3) 5e-4 max logits deviation.  SegNet's pool/unpool pairs are discontinuous in the arg-max: F(4,3) rounding flips one on
     exactly one of the three small fixtures, and WHICH one depends on the kernel's summation order — round 2's per-index F(4,3)
     kernels flipped segnet_s0 (31 % of the logits move, the other two within 4.8e-4), round 3's fused kernel (csrc/wino4f.hip)
-    passes s0 and s3 within 4.8e-4 and flips segnet_s4 (44 % move; the per-index kernels pass it) — the reference does the same
-    under 1e-6 input noise (fixture pair segnet_s0_8x360x480 / _perturbed: 11 % of the sampled logits move by > 1e-3).  The
-    forced mode therefore runs SegNet on s0 and s3; the raw kernels are pinned against fp64 at the bottleneck geometries in
-    tests/test_gpu_wino4f.py.
+    passes s0 and s3 within 4.8e-4 and flips segnet_s4 (44 % move; the per-index kernels pass it).  Round 4: no fixture is skipped any
+    more.  A SegNet case in a forced mode that exceeds the logits tolerance must pass _assert_deviation_is_an_argmax_tie (the
+    deviation is born at a max-pool window whose two largest inputs are closer than the modes' rounding difference, and nowhere
+    before); the loss / gradient / running-statistics checks below then do not apply to it (everything downstream of the unpool
+    differs).  The reference's own 1e-6 input perturbation does NOT flip these three small fixtures (tests/golden/*_perturbed.npz,
+    max 4.3e-4), so they stay pinned at 5e-4 in the default mode.  The raw kernels are pinned against fp64 at the bottleneck
+    geometries in tests/test_gpu_wino4f.py.
     "w2d_always" / "w2d4_always": every eligible layer (>= 32 input, >= 64 output channels) through the 2-D F(6x6,3x3) (the default
     tile for UNet since round 3; about twice the rounding of F(4x4), held to the same tolerance) / F(4x4,3x3) kernels, which the
     engine itself only uses from 256 tiles up; they round 3.5x coarser again (2.8e-6 vs 8e-7 relative L2 per layer,
@@ -69,7 +134,20 @@ def test_net_forward_loss_grads_golden(tag, conv):
     assert tuple(out.shape) == (n, 12, h, w)
     # forward tolerance (fp32, 23-26 conv+BN layers, BN over as few as 6-12 samples at the bottleneck of these
     # small goldens): 5e-4 absolute on logits in [0, ~5]; the reference itself moves ~5e-5 between fp32 and fp64
-    np.testing.assert_allclose(out.detach().cpu().numpy(), d["logits"], rtol=1e-3, atol={"default": 5e-4, "f43_always": 1e-3, "w2d_always": 3.5e-3, "w2d4_always": 3.5e-3}[conv])
+    atol = {"default": 5e-4, "f43_always": 1e-3, "w2d_always": 3.5e-3, "w2d4_always": 3.5e-3}[conv]
+    got = out.detach().cpu().numpy()
+    if meta["kind"] == "segnet" and conv != "default" and not np.allclose(got, d["logits"], rtol=1e-3, atol=atol):
+        def setup(m):
+            runner_of(m).wino4 = "always"
+            runner_of(m).wgradp = "always"
+        _assert_deviation_is_an_argmax_tie(tag, meta, setup, x)
+        return
+    np.testing.assert_allclose(got, d["logits"], rtol=1e-3, atol=atol)
+    if meta["kind"] == "segnet" and os.path.exists(os.path.join(G, tag + "_perturbed.npz")):
+        # the reference's own twin (1e-6 relative input noise): the device may not be further from the golden than 2 x that + 2e-4
+        tw = np.load(os.path.join(G, tag + "_perturbed.npz"))
+        ref_move = float(np.abs(tw["logits"] - d["logits"]).max())
+        assert float(np.abs(got - d["logits"]).max()) <= 2.0 * ref_move + (2e-4 if conv == "default" else 6e-4), (tag, conv, ref_move)
     loss = A.CrossEntropyLoss()(out, t)
     loss.backward()
     assert abs(loss.item() - float(d["loss"])) < 2e-5
@@ -128,6 +206,82 @@ def test_adamw_trajectory_golden(tag):
         assert abs(a - b) < tol[i], (i, a, b)
 
 
+# Regression sentinels for the full-size logits: measured device deviations from the reference on the DENSE fixtures
+# (every 8th pixel: 30x the points of the slice), per 2-D Winograd tile.  The hard bound stays the derived tolerance of drift.json
+# (4 x the reference graph's own drift, frozen by tests/test_drift_cpu.py); these sit ~1.3x above what the kernels measure today, so
+# a coarser kernel trips here long before it reaches the bound.  (max |dev|, share of points beyond 3e-4, relative L2)
+DENSE_SENTINEL = {6: (6.6e-4, 4e-3, 1.3e-4), 4: (4.3e-4, 2e-4, 8.5e-5)}       # measured r4: 6 -> 5.3e-4 / 1.7e-3 / 9.6e-5, 4 -> 3.3e-4 / 2.3e-5 / 6.3e-5
+
+
+def _dense_check(out, dense_tag, tile):
+    dd = np.load(os.path.join(G, dense_tag + ".npz"))
+    ref = dd["logits_dense"]
+    got = out[:, :, ::8, ::8].detach().cpu().numpy()
+    dv = np.abs(got - ref)
+    mx, frac, rel = float(dv.max()), float((dv > 3e-4).mean()), float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    npix = out.shape[0] * out.shape[2] * out.shape[3]
+    o64 = out.detach().double()
+    dmean = float(np.abs(o64.sum(dim=(0, 2, 3)).cpu().numpy() - dd["class_sum"]).max() / npix)
+    dsq = float(np.abs((o64 ** 2).sum(dim=(0, 2, 3)).cpu().numpy() - dd["class_sq_sum"]).max() / npix)
+    edges = torch.tensor(dd["hist_edges"], device=out.device, dtype=torch.float32)
+    tv = 0.0
+    for c in range(out.shape[1]):
+        h = torch.histogram(out[:, c].detach().float().cpu().flatten(), bins=edges.cpu())[0].numpy()
+        tv = max(tv, float(np.abs(h - dd["class_hist"][c]).sum() / (2.0 * npix)))
+    print(f"{dense_tag} tile {tile}: max |dev| {mx:.3e}, share beyond 3e-4 {frac:.2e}, relative L2 {rel:.3e} over {ref.size} points; "
+          f"per-class mean shift {dmean:.2e}, mean-square shift {dsq:.2e}, histogram distance {tv:.2e}")
+    smx, sfrac, srel = DENSE_SENTINEL[tile]
+    assert mx <= smx and frac <= sfrac and rel <= srel, (dense_tag, tile, mx, frac, rel)
+    # a systematic shift of a class (which max-abs over samples cannot see) and its distribution
+    assert dmean <= 2e-5 and dsq <= 1e-4 and tv <= 2e-3, (dmean, dsq, tv)
+
+
+def test_segnet_forced_2d_mode_deviation_is_an_argmax_tie():
+    """The coarsest forced mode (every eligible layer through 2-D F(6x6,3x3), which the engine never picks at this size) on the
+    SegNet fixture it is known to disturb: either the logits still meet the forced-mode tolerance, or the deviation must be
+    explained as a max-pool tie by _assert_deviation_is_an_argmax_tie (keeps that analysis exercised)."""
+    import pytorch_camvid_amd as A
+    from pytorch_camvid_amd.modules import runner_of
+    tag = "segnet_s4_2x96x128"
+    d = dict(np.load(os.path.join(G, tag + ".npz")))
+    meta = json.loads(str(d["meta"]))
+
+    def setup(m):
+        runner_of(m).wino2d = "always"
+        runner_of(m).w2tile_cfg = 6
+    torch.manual_seed(meta["seed"])
+    net = A.get_model("segnet", 3, 12).to(dev()).train()
+    setup(net)
+    n, _, h, w = meta["shape"]
+    x, t = batch(n, h, w, meta["data_seed"])
+    with torch.no_grad():
+        got = net(x).cpu().numpy()
+    if np.allclose(got, d["logits"], rtol=1e-3, atol=3.5e-3):
+        return
+    _assert_deviation_is_an_argmax_tie(tag, meta, setup, x)
+
+
+@pytest.mark.parametrize("tile", [6, 4])
+def test_unet_fullsize_batch8_dense_logits(tile):
+    """Headline workload, train-mode logits against the dense reference fixture, for the default 2-D tile F(6x6,3x3) and for
+    F(4x4,3x3) (CVK_W2D_TILE=4 / runner.w2tile_cfg = 4: the finer-rounding mode; bound = the pre-round-3 3e-4 on the slice)."""
+    import pytorch_camvid_amd as A
+    from pytorch_camvid_amd.modules import runner_of
+    d = dict(np.load(os.path.join(G, "unet_s0_8x360x480.npz")))
+    meta = json.loads(str(d["meta"]))
+    torch.manual_seed(meta["seed"])
+    net = A.UNet(3, 12).to(dev()).train()
+    runner_of(net).w2tile_cfg = tile
+    x, t = batch(8, 360, 480, meta["data_seed"])
+    with torch.no_grad():
+        out = net(x)
+    _dense_check(out, "unet_s0_8x360x480_dense", tile)
+    sh, sw = meta["slice"]
+    sl = np.abs(out[:, :, ::sh, ::sw].cpu().numpy() - d["logits_slice"]).max()
+    if tile == 4:
+        assert sl <= 3e-4, sl          # the fixed slice bound of rounds 1-2, still met by the 4x4 tile
+
+
 def test_unet_fullsize_batch2_golden():
     """BASELINE.json configs[0] geometry (2x3x360x480): loss, logits checksum/slice, grad norms vs the reference."""
     import pytorch_camvid_amd as A
@@ -144,6 +298,7 @@ def test_unet_fullsize_batch2_golden():
     # fp64 / 1e-6 input noise (BatchNorm's division by the channel deviation turns rounding into 1e-4 on the logits): 6.7e-4
     atol = json.load(open(os.path.join(G, "drift.json")))["logits_tolerance"]["unet_s0_2x360x480"]["slice_abs"]
     np.testing.assert_allclose(out[:, :, ::40, ::48].detach().cpu().numpy(), d["logits_slice"], rtol=1e-3, atol=atol)
+    _dense_check(out, "unet_s0_2x360x480_dense", 6)
     names = list(d["param_names"])
     rel = []
     for i, (k, p) in enumerate(net.named_parameters()):
