@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs[3] / configs[4] legs after the headline")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (N=1; reported under `graph_replay`, never `value`)")
     ap.add_argument("--with-optimizer", action="store_true", help="also time AdamW steps (reported separately)")
+    ap.add_argument("--dp-overhead", action="store_true",
+                    help="(N=1) what data parallel costs BEFORE any link is involved: the same step under ddp.DataParallel on a world-size-1 "
+                         "RCCL group with always_issue=True (every bucket really goes through RCCL, the persistent kernels leave "
+                         "CVK_DP_RESERVE_CUS CUs free), eager and as one captured graph; reported under `dp_overhead`, never `value`")
     ap.add_argument("--with-input-pipeline", action="store_true",
                     help="also time the steps fed from HOST uint8 frames through DevicePrefetcher (pinned staging, 1-byte upload one "
                          "batch ahead, device-side normalisation): the PCIe-inclusive rate, reported separately, never `value`")
@@ -248,6 +252,68 @@ def run_leg(A, dev, model, batch, h, w, precision, steps, warmup, profile, world
     return out
 
 
+def dp_overhead_leg(A, dev, net, lossf, leg, a, plain_step):
+    """VERDICT r3 #5a: everything about data parallel that ONE GPU can show.  A world-size-1 RCCL group; the headline network under
+    ddp.DataParallel(always_issue=True): every gradient bucket goes through a real RCCL all-reduce (a copy kernel on RCCL's stream at
+    world 1), the executor's persistent kernels leave CVK_DP_RESERVE_CUS CUs free, GradSync.finish makes the compute stream wait.
+    Reported: the plain step and the DP step timed back to back in this process, the exposed wait, and the same DP step replayed from
+    ONE captured graph (collectives inside) with its host enqueue time."""
+    from pytorch_camvid_amd import ddp
+    from pytorch_camvid_amd.graph import GraphedStep
+    from pytorch_camvid_amd.modules import runner_of
+    import socket
+    if not dist.is_initialized():
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(port))
+        ddp.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    n = max(10, min(a.steps, 40))
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        th = time.perf_counter() - t0
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n * 1e3, th / n * 1e3
+
+    plain_ms, _ = timed(plain_step)
+    wrapped = ddp.DataParallel(net, always_issue=True)
+    x, t, params = leg["x"], leg["t"], leg["params"]
+
+    def dp_step():
+        for p in params:
+            p.grad = None
+        A.mark_weights_dirty(net)
+        lossf(wrapped(x), t).backward()
+
+    wrapped.sync.wait_events = []
+    dp_ms, dp_host = timed(dp_step)
+    ev = wrapped.sync.wait_events
+    wrapped.sync.wait_events = None
+    exposed = [e0.elapsed_time(e1) for e0, e1 in ev[3:]] if len(ev) > 3 else []
+    buckets = [{"floats": hi - lo, "MB": round((hi - lo) * 4 / 2 ** 20, 1)} for lo, hi in wrapped.sync.launched]
+    gs = GraphedStep(net, lossf, x, t, allow_grad_sync=True)
+    g_ms, g_host = timed(gs.replay)
+    out = {"plain_ms_per_step": round(plain_ms, 3), "dp_world1_ms_per_step": round(dp_ms, 3),
+           "overhead_pct": round((dp_ms / plain_ms - 1.0) * 100.0, 2),
+           "allreduce_exposed_ms": round(sum(exposed) / max(len(exposed), 1), 3), "buckets": buckets,
+           "persistent_workgroups": runner_of(net).persistent_wgs(), "host_enqueue_ms_per_step": round(dp_host, 3),
+           "graphed_dp_ms_per_step": round(g_ms, 3), "graphed_dp_host_enqueue_ms_per_step": round(g_host, 4),
+           "rccl_env": {k: v for k, v in ddp.rccl_env().items() if v is not None}, "steps": n,
+           "what": "same process, same box: plain step vs the step under ddp.DataParallel on a world-size-1 RCCL group with always_issue=True "
+                   "(bucketed all-reduces really issued, CU reservation active), eager and replayed from one captured HIP graph; says what "
+                   "data parallel costs before any xGMI link is involved — not a scaling measurement"}
+    del gs
+    runner_of(net).grad_sync = None
+    return out
+
+
 def dp_identity(dev, world, rehearsal):
     """Which device each rank really runs on (all-gathered): proves N distinct GPUs took part."""
     pr = torch.cuda.get_device_properties(dev)
@@ -264,14 +330,12 @@ def dp_identity(dev, world, rehearsal):
     ids = {(r["uuid"], r["pci_bus_id"]) for r in ranks}
     return {"ranks_seen": ranks, "distinct_gpus": len(ids), "rehearsal": rehearsal,
             "backend": dist.get_backend(),
-            "rccl_env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_NCHANNELS_PER_PEER", "RCCL_MSCCL_ENABLE",
-                                                        "NCCL_ALGO", "NCCL_PROTO", "HSA_ENABLE_IPC_MODE_LEGACY", "CVK_DDP_BUCKET_MB", "CVK_DP_RESERVE_CUS", "CVK_W2D_NO_STAGGER")
-                         if os.environ.get(k) is not None},
+            "rccl_env": {k: v for k, v in __import__("pytorch_camvid_amd").ddp.rccl_env().items() if v is not None},
             "note": "the conv grids assume an undisturbed chip (whole rounds of 256 CUs, csrc/wino2d.hip staggered start): RCCL's "
                     "all-reduce kernels occupy NCCL_MAX_NCHANNELS workgroups while backward runs; lower it (e.g. 8-16) if "
                     "allreduce_exposed_ms is small but ms_per_step grows with N, and set CVK_W2D_NO_STAGGER=1 to A/B the stagger.  The persistent "
-                    "fused F(4,3) kernel (one workgroup per CU) runs on CUs - CVK_DP_RESERVE_CUS (default 16) workgroups under data parallel, "
-                    "NCCL_MAX_NCHANNELS defaults to 16 here to match."}
+                    "fused F(4,3) kernel and the persistent bf16 kernels (one workgroup per CU) run on CUs - CVK_DP_RESERVE_CUS workgroups under data "
+                    "parallel; ddp.init_process_group sets NCCL_MAX_NCHANNELS (default 16) and CVK_DP_RESERVE_CUS together."}
 
 
 def main():
@@ -295,13 +359,12 @@ def main():
     import pytorch_camvid_amd as A
 
     if world > 1:
-        # RCCL's all-reduce kernels run beside backward and hold one CU per channel; the exchange needs ~7 GB/s (138 MB per
-        # 38 ms step), so a few channels suffice — the executor leaves CVK_DP_RESERVE_CUS (default 16) CUs free for them
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
+        # the RCCL channel count and the CUs the executor leaves to the collectives are set together by ddp.init_process_group
+        from pytorch_camvid_amd import ddp as _ddp
         if rehearsal:
-            dist.init_process_group("gloo")
+            _ddp.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)     # RCCL
+            _ddp.init_process_group("nccl", device_id=dev)     # RCCL
 
     headline = (a.model, a.batch, a.height, a.width, a.precision) == ("unet", PER_GPU_BATCH, H, W, "fp32")
     leg = run_leg(A, dev, a.model, a.batch, a.height, a.width, a.precision, a.steps, a.warmup, not a.no_kernel_profile,
@@ -368,6 +431,10 @@ def main():
                  "what": "zero_grad + forward + CE + backward replayed from ONE captured HIP graph (pytorch_camvid_amd.graph.GraphedStep)"}
         del gs
 
+    dp_over = None
+    if a.dp_overhead and world == 1:
+        dp_over = dp_overhead_leg(A, dev, net, lossf, leg, a, step)
+
     dp = None
     if world > 1:
         dp = dp_identity(dev, world, rehearsal)
@@ -426,8 +493,10 @@ def main():
             line["with_input_pipeline"] = pipe
         if graph is not None:
             line["graph_replay"] = graph
+        if dp_over is not None:
+            line["dp_overhead"] = dp_over
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -367,6 +367,12 @@ int cvk_pack_weights_bf16_batch(const cvk_pack_job* jobs, int n, void* stream);
  * P = cvk_bf16s_stat_partials_c(N,H,W,Cin,Cout) -> cvk_bn_finalize_counts.  Data-grad: the same call on dy and the dgrad pack. */
 int cvk_conv3x3_bf16s(const void* x, const void* w, const float* bias, void* y, float* stats, float* counts,
                       int N, int H, int W, int Cin, int Cout, int ldy, void* stream);
+/* the same with a cap on the workgroups of the persistent kernels (layers with >= 64 input and > 32 output channels run one
+ * workgroup per CU that walks the tiles): under data-parallel training the executor leaves CVK_DP_RESERVE_CUS CUs to the RCCL
+ * all-reduce kernels that run beside backward (legacy/train_tpu.py:115 hides the same exchange).  0 = every CU.  Results are
+ * bitwise independent of the cap. */
+int cvk_conv3x3_bf16s_wg(const void* x, const void* w, const float* bias, void* y, float* stats, float* counts,
+                      int N, int H, int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream);
 int cvk_bn_finalize_counts(const float* stats, const float* counts, int P, int M, int C, const float* gamma, const float* beta,
                            float* mean, float* rstd, float* scale, float* shift, float* running_mean, float* running_var,
                            int64_t* num_batches_tracked, float momentum, float eps, void* workspace, size_t workspace_bytes,

@@ -18,8 +18,9 @@ int kind(int Cin, int Cout);        // 0: not served, 1: 128 output channels per
 int stat_partials(int N, int H, int W);
 
 // y = conv3x3(x, wpp) (+ bias) (+ statistics partials): same contract as cvk_conv3x3_bf16s, weights in the tile-major pack
+// max_workgroups > 0 caps the grid of the persistent kernels (data parallel: CUs left to the collectives); results do not depend on it
 void launch(const void* x, const void* wpp, const float* bias, void* y, float* stats, float* counts, int N, int H, int W, int Cin,
-            int Cout, int ldy, hipStream_t s);
+            int Cout, int ldy, hipStream_t s, int max_workgroups = 0);
 
 // fp32 master [Cout][3][3][Cin] -> tile-major bf16 pack; dgrad = rotated by 180 degrees, channels exchanged
 void pack(const float* w, void* out, int Cout, int Cin, int Kpad, bool dgrad, hipStream_t s);

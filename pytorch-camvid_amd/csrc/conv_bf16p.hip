@@ -1102,15 +1102,16 @@ void pack_batch(const cvk_pack_job* jobs, int n, hipStream_t s) {
 }
 
 void launch(const void* x, const void* wpp, const float* bias, void* y, float* stats, float* counts, int N, int H, int W, int Cin,
-            int Cout, int ldy, hipStream_t s) {
+            int Cout, int ldy, hipStream_t s, int max_workgroups) {
     const int knd = kind(Cin, Cout);
     const int tilesX = cvk_cdiv(W, TW), tilesY = cvk_cdiv(H, TH), tilesN = cvk_cdiv(Cout, knd == 2 ? HBN : BN);
     const int P = N * tilesX * tilesY;
     dim3 grid((unsigned)(P * tilesN)), block(512);
     static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 0 ? n : 256; }();
+    const int wgcap = max_workgroups > 0 && max_workgroups < cus ? max_workgroups : cus;      // data parallel: CUs left to RCCL
     if (knd == 2) {
         const int ntiles = P * tilesN;
-        dim3 pgrid((unsigned)(cus < ntiles ? cus : ntiles));
+        dim3 pgrid((unsigned)(wgcap < ntiles ? wgcap : ntiles));
         static const int hdbg = getenv("CVK_BF16H_DBG") ? atoi(getenv("CVK_BF16H_DBG")) : 0;
         if (hdbg) hipLaunchKernelGGL((k_conv_bf16h<false, 1>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);
         else if (stats) hipLaunchKernelGGL((k_conv_bf16h<true>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);
@@ -1125,7 +1126,7 @@ void launch(const void* x, const void* wpp, const float* bias, void* y, float* s
     if (mfma_shape() == 16) {
         const int ntiles = P * tilesN;
         static const int cap = getenv("CVK_BF16P_GRID") ? atoi(getenv("CVK_BF16P_GRID")) : 0;      // timing experiments only
-        int g = cap > 0 ? cap : cus;
+        int g = cap > 0 ? cap : wgcap;
         if (g > ntiles) g = ntiles;
         dim3 pgrid((unsigned)g);
         if (stats) hipLaunchKernelGGL((k_conv_bf16q<true>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);

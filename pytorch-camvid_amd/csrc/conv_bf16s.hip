@@ -668,8 +668,22 @@ extern "C" int cvk_pack_weights_bf16_batch(const cvk_pack_job* jobs, int n, void
     CVK_LAUNCH_RETURN("cvk_pack_weights_bf16_batch");
 }
 
+static int conv3x3_bf16s_impl(const void* x, const void* w, const float* bias, void* y, float* stats, float* counts, int N, int H,
+                              int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream);
+
 extern "C" int cvk_conv3x3_bf16s(const void* x, const void* w, const float* bias, void* y, float* stats, float* counts, int N, int H,
                                  int W, int Cin, int Cout, int ldy, void* stream) {
+    return conv3x3_bf16s_impl(x, w, bias, y, stats, counts, N, H, W, Cin, Cout, ldy, 0, stream);
+}
+
+extern "C" int cvk_conv3x3_bf16s_wg(const void* x, const void* w, const float* bias, void* y, float* stats, float* counts, int N, int H,
+                                    int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream) {
+    CVK_CHECK_ARG(max_workgroups >= 0, "cvk_conv3x3_bf16s_wg: max_workgroups must be >= 0");
+    return conv3x3_bf16s_impl(x, w, bias, y, stats, counts, N, H, W, Cin, Cout, ldy, max_workgroups, stream);
+}
+
+static int conv3x3_bf16s_impl(const void* x, const void* w, const float* bias, void* y, float* stats, float* counts, int N, int H,
+                              int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream) {
     CVK_CHECK_ARG(x && w && y, "cvk_conv3x3_bf16s: null pointer");
     CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout && ldy % 4 == 0, "cvk_conv3x3_bf16s: bad shape (ldy must be a multiple of 4)");
     CVK_CHECK_ARG(Cin > 0 && Cin % CK == 0, "cvk_conv3x3_bf16s: Cin=%d must be a multiple of %d (pad the tensor)", Cin, CK);
@@ -688,7 +702,7 @@ extern "C" int cvk_conv3x3_bf16s(const void* x, const void* w, const float* bias
         // offset of 2^31 marks an out-of-frame pixel)
         CVK_CHECK_ARG(cvk_aligned16(y) && ldy % 8 == 0, "cvk_conv3x3_bf16s: layers with > 64 output and >= 128 input channels need a 16-byte aligned y and ldy %% 8 == 0");
         CVK_CHECK_ARG((long)H * W * Cin * 2 < (1L << 31), "cvk_conv3x3_bf16s: one image exceeds 2 GiB");
-        cvk_bf16p::launch(x, w, bias, y, stats, counts, N, H, W, Cin, Cout, ldy, s);
+        cvk_bf16p::launch(x, w, bias, y, stats, counts, N, H, W, Cin, Cout, ldy, s, max_workgroups);
         CVK_LAUNCH_RETURN("cvk_conv3x3_bf16s");
     }
     dim3 grid((unsigned)(P * tilesN)), block(256);

@@ -22,6 +22,37 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+# RCCL's all-reduce kernels run beside backward and hold one CU per channel; the exchange needs ~7 GB/s (138 MB per 34 ms
+# step), so a few channels suffice.  The executor leaves CVK_DP_RESERVE_CUS CUs (default 16) to them: its persistent
+# one-workgroup-per-CU kernels launch on CUs - CVK_DP_RESERVE_CUS workgroups under data parallel (engine.Runner.persistent_wgs).
+# The two numbers belong together, so they are set together — here, not in a benchmark script.
+DEFAULT_RCCL_CHANNELS = 16
+
+
+def init_process_group(backend="nccl", rccl_channels=None, **kwargs):
+    """torch.distributed.init_process_group with the RCCL settings this path is tuned for (VERDICT r3 #5b: users of
+    ddp.DataParallel get what bench.py measures).  Before the group is created (RCCL reads its environment at communicator creation):
+      * NCCL_MAX_NCHANNELS (unless the caller's environment already sets it) = rccl_channels (default 16);
+      * CVK_DP_RESERVE_CUS follows it (unless set): the CUs the executor's persistent kernels leave free for the collectives;
+      * HSA_ENABLE_IPC_MODE_LEGACY=0 (the host driver of this pool only supports dmabuf IPC).
+    Rendezvous arguments (init_method, rank, world_size, device_id, ...) pass through unchanged.  Returns rccl_env()."""
+    ch = DEFAULT_RCCL_CHANNELS if rccl_channels is None else int(rccl_channels)
+    if backend == "nccl":
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(ch))
+        os.environ.setdefault("CVK_DP_RESERVE_CUS", os.environ["NCCL_MAX_NCHANNELS"])
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not dist.is_initialized():
+        dist.init_process_group(backend, **kwargs)
+    return rccl_env()
+
+
+def rccl_env():
+    """The knobs in effect (for logs and bench lines)."""
+    return {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_NCHANNELS_PER_PEER", "RCCL_MSCCL_ENABLE",
+                                           "NCCL_ALGO", "NCCL_PROTO", "HSA_ENABLE_IPC_MODE_LEGACY", "CVK_DDP_BUCKET_MB",
+                                           "CVK_DP_RESERVE_CUS", "CVK_W2D_NO_STAGGER")}
+
+
 def make_buckets(layer_ranges, bucket_floats):
     """layer_ranges: [(begin, end)] float offsets of each layer's gradients in completion order (ascending offsets).
     Returns [(begin, end, n_layers)] contiguous buckets cut at layer boundaries, each >= bucket_floats except the last."""
@@ -122,7 +153,7 @@ class GradSync:
 class DataParallel(nn.Module):
     """Wraps a pytorch_camvid_amd network for process-per-GPU data parallel training.
 
-    >>> dist.init_process_group("nccl")            # RCCL
+    >>> ddp.init_process_group("nccl")             # RCCL, with the channel / CU-reservation settings of this path
     >>> net = DataParallel(UNet(3, 12).cuda())
     Each rank feeds its own minibatch shard; after loss.backward() every rank holds the gradient mean."""
 

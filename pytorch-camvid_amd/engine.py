@@ -741,8 +741,8 @@ class ConvBnRelu(Op):
             stats = _empty(2 * P * C + P, dev)
             cnt = stats.data_ptr() + 4 * 2 * P * C
             _timed(R, conv_kernel_name("bf16_fwd", C), flops, lambda: check(
-                lib.cvk_conv3x3_bf16s(X.data_ptr(), wb.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), cnt, N, H, W, src.ld, C, C, s),
-                "cvk_conv3x3_bf16s"))
+                lib.cvk_conv3x3_bf16s_wg(X.data_ptr(), wb.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), cnt, N, H, W, src.ld, C, C,
+                                         R.persistent_wgs(), s), "cvk_conv3x3_bf16s"))
             wsb = lib.cvk_bn_finalize_workspace_bytes(P, C)
             ws = R.workspace(wsb, dev)
             track = bn.track_running_stats and bn.running_mean is not None
@@ -809,8 +809,8 @@ class ConvBnRelu(Op):
             wd = R.derived(((self.pslot, "d"), "bf16"), w, build_wd)
             dX = torch.empty((N, H, W, src.ld), device=dev, dtype=_BF16)
             _timed(R, conv_kernel_name("bf16_dgrad", self.cin), flops, lambda: check(
-                lib.cvk_conv3x3_bf16s(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, None, N, H, W, ld_dy, self.cin, src.ld, s),
-                "cvk_conv3x3_bf16s(dgrad)"))
+                lib.cvk_conv3x3_bf16s_wg(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, None, N, H, W, ld_dy, self.cin, src.ld,
+                                         R.persistent_wgs(), s), "cvk_conv3x3_bf16s(dgrad)"))
             st.grad[src.id] = dX
         wsb = lib.cvk_conv3x3_wgrad_bf16s_workspace_bytes(N, H, W, self.cin, C)
         ws = R.workspace(wsb, dev)
@@ -1072,7 +1072,8 @@ class Runner:
     def persistent_wgs(self):
         """Workgroup cap of the persistent (one-workgroup-per-CU) kernels: 0 = every CU.  Under data-parallel training
         CVK_DP_RESERVE_CUS (default 16) CUs are left to RCCL's all-reduce kernels, which run beside backward."""
-        if self.grad_sync is None or getattr(self.grad_sync, "world", 1) <= 1:
+        gs = self.grad_sync
+        if gs is None or (getattr(gs, "world", 1) <= 1 and not getattr(gs, "always_issue", False)):
             return 0
         if self._dp_wgs is None:
             cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count

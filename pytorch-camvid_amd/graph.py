@@ -13,20 +13,30 @@ workspace come from the graph's private pool, i.e. their addresses are the same 
         optimizer.step()
 
 BatchNorm running statistics and num_batches_tracked are updated by the kernels on the device, exactly as in eager mode.
-Single process only: under ddp.DataParallel the bucketed all-reduces stay outside a graph (eager mode).
+Data parallel (round 4): RCCL collectives are stream-capturable, so a step of a ddp.DataParallel network is captured WITH its
+bucketed all-reduces (`GraphedStep(dp_net.module, ..., allow_grad_sync=True)`): every rank replays the same graph, the
+collectives run on RCCL's stream inside it, and 8 single-threaded ranks no longer sit on 11-15 ms of Python enqueue per step.
+gloo groups (CPU rehearsals) cannot be captured.
 """
 import torch
 
 
 class GraphedStep:
-    def __init__(self, net, lossf, x, t, warmup=2):
+    def __init__(self, net, lossf, x, t, warmup=2, allow_grad_sync=False):
         from .modules import runner_of
         R = runner_of(net)
         if R.grad_sync is not None:
-            raise RuntimeError("GraphedStep: data-parallel gradient synchronisation runs in eager mode only")
+            if not allow_grad_sync:
+                raise RuntimeError("GraphedStep: the network synchronises gradients (ddp.DataParallel); pass allow_grad_sync=True to "
+                                   "capture the bucketed all-reduces with the step (RCCL only)")
+            if not getattr(R.grad_sync, "_native_avg", False):
+                raise RuntimeError("GraphedStep: only RCCL ('nccl') collectives can be captured; gloo groups run in eager mode")
         if not (x.is_cuda and t.is_cuda):
             raise RuntimeError("GraphedStep needs the example batch on the GPU")
         self.net, self.lossf = net, lossf
+        self._runner = R
+        # what the captured graph bakes in: replay() refuses to run once any of it has changed (ADVICE r3)
+        self._sig = self._signature()
         self.x, self.t = x.clone(), t.clone()
         self.params = [p for p in net.parameters() if p.requires_grad]
         cur = torch.cuda.current_stream(x.device)
@@ -52,8 +62,17 @@ class GraphedStep:
         for p in self.params:
             p.grad = None
 
+    def _signature(self):
+        R = self._runner
+        return (id(R.grad_sync), bool(self.net.training), bool(R.bf16), R.wino, R.wino4, R.wino4f, R.wgradp, R.wino2d, R.w2tile_cfg,
+                R.thin, R.persistent_wgs())
+
     def replay(self, x=None, t=None):
         """Copy a new batch into the static input buffers (optional) and replay the step.  Returns the (static) loss tensor."""
+        if self._signature() != self._sig:
+            raise RuntimeError("GraphedStep.replay: the network changed since the capture (train/eval mode, conv precision, a kernel "
+                               "knob, or it was wrapped in / unwrapped from ddp.DataParallel): the captured graph would silently run the "
+                               "old configuration — build a new GraphedStep")
         if x is not None:
             self.x.copy_(x, non_blocking=True)
         if t is not None:

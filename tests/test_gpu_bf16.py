@@ -296,3 +296,62 @@ def test_unet_bf16_config3_workload():
     assert loss2 == loss and torch.equal(out, out2)
     for a, b in zip(net.parameters(), net2.parameters()):
         assert torch.equal(a.grad, b.grad)
+
+
+@pytest.mark.parametrize("case", [(4, 90, 120, 256, 256), (2, 100, 130, 128, 64)])
+def test_persistent_bf16_kernels_do_not_depend_on_the_workgroup_cap(case):
+    """cvk_conv3x3_bf16s_wg: under data parallel the persistent kernels run on fewer workgroups (CUs left to RCCL); output and
+    statistics partials are bitwise the same for any cap (a tile's result does not depend on which workgroup walks it)."""
+    from pytorch_camvid_amd import _lib
+    from pytorch_camvid_amd._lib import check
+    lib = _lib.load()
+    N, H, W, Ci, Co = case
+    g = torch.Generator(device="cuda").manual_seed(sum(case))
+    x = torch.randn(N, H, W, Ci, device=dev(), generator=g).to(BF)
+    wd = torch.randn(Co, 3, 3, Ci, device=dev(), generator=g) * (2.0 / (9 * Ci)) ** 0.5
+    b = torch.randn(Co, device=dev(), generator=g) * 0.1
+    wp = torch.zeros(lib.cvk_bf16s_rows_pad(Co) * 9 * Ci, device=dev(), dtype=BF)
+    check(lib.cvk_pack_weight_fwd_bf16(wd.data_ptr(), wp.data_ptr(), Co, Ci, Ci, stream()))
+    P = lib.cvk_bf16s_stat_partials_c(N, H, W, Ci, Co)
+    ref = None
+    for cap in (0, 240, 100, 7, 1):
+        y = torch.full((N, H, W, Co), float("nan"), device=dev(), dtype=BF)
+        st = torch.full((2 * P * Co + P,), float("nan"), device=dev())
+        check(lib.cvk_conv3x3_bf16s_wg(x.data_ptr(), wp.data_ptr(), b.data_ptr(), y.data_ptr(), st.data_ptr(), st.data_ptr() + 8 * P * Co,
+                                       N, H, W, Ci, Co, Co, cap, stream()))
+        cur = (y.view(torch.int16).clone(), st.view(torch.int32).clone())
+        if ref is None:
+            assert bool(torch.isfinite(y.float()).all()) and bool(torch.isfinite(st).all())
+            ref = cur
+        else:
+            assert torch.equal(ref[0], cur[0]) and torch.equal(ref[1], cur[1]), (case, cap)
+
+
+def test_batched_weight_pack_equals_the_single_packs():
+    """cvk_pack_weights_bf16_batch (all layers of a step in one launch) writes exactly what cvk_pack_weight_{fwd,dgrad}_bf16 write,
+    for every layout (row-major packs of the strip kernels, tile-major packs with 128 / 64 rows)."""
+    import ctypes
+    from pytorch_camvid_amd import _lib
+    from pytorch_camvid_amd._lib import check
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    jobs, want, outs, keep = [], [], [], []
+    for (Co, Ci) in ((64, 3), (64, 64), (128, 64), (128, 128), (64, 128), (12, 64), (320, 160)):
+        w = torch.randn(Co, 3, 3, Ci, device=dev(), generator=g)
+        keep.append(w)
+        kf = (max(Ci, 32) + 31) // 32 * 32
+        a = torch.full((lib.cvk_bf16s_rows_pad(Co) * 9 * kf,), float("nan"), device=dev(), dtype=BF)
+        check(lib.cvk_pack_weight_fwd_bf16(w.data_ptr(), a.data_ptr(), Co, Ci, kf, stream()))
+        o = torch.full_like(a, float("nan"))
+        jobs.append(_lib.PackJob(w.data_ptr(), o.data_ptr(), Co, Ci, kf, 0)); want.append(a); outs.append(o)
+        if Ci >= 32:
+            kd = max(32, (Co + 31) // 32 * 32)
+            a = torch.full((lib.cvk_bf16s_rows_pad(Ci) * 9 * kd,), float("nan"), device=dev(), dtype=BF)
+            check(lib.cvk_pack_weight_dgrad_bf16(w.data_ptr(), a.data_ptr(), Co, Ci, kd, stream()))
+            o = torch.full_like(a, float("nan"))
+            jobs.append(_lib.PackJob(w.data_ptr(), o.data_ptr(), Co, Ci, kd, 1)); want.append(a); outs.append(o)
+    arr = (_lib.PackJob * len(jobs))(*jobs)
+    check(lib.cvk_pack_weights_bf16_batch(ctypes.addressof(arr), len(jobs), stream()))
+    torch.cuda.synchronize()
+    for i, (a, o) in enumerate(zip(want, outs)):
+        assert torch.equal(a.view(torch.int16), o.view(torch.int16)), i

@@ -103,3 +103,85 @@ def test_bench_rehearsal_self_launch(tmp_path):
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     with open(os.path.join(root, "gpurun_out", "rehearsal_n2.json"), "w") as f:
         f.write(lines[0] + "\n")
+
+
+def _world1_worker(rank, port, out_path):
+    """One process, a world-size-1 RCCL group (runs in a child so that the group dies with it)."""
+    import json
+    import pytorch_camvid_amd as A
+    from pytorch_camvid_amd import ddp
+    from pytorch_camvid_amd.modules import runner_of
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    env = ddp.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    torch.manual_seed(3)
+    net = A.UNet(3, 12).to(dev).train()
+    ref = A.UNet(3, 12).to(dev).train()
+    ref.load_state_dict(net.state_dict())
+    lossf = A.CrossEntropyLoss()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 3, 48, 64, generator=g).to(dev); t = torch.randint(0, 12, (2, 48, 64), generator=g).to(dev)
+    wrapped = ddp.DataParallel(net, always_issue=True, bucket_mb=8.0)
+    res = {"env": env, "reserve": runner_of(net).persistent_wgs()}
+    lossf(ref(x), t).backward()
+    lossf(wrapped(x), t).backward()
+    res["buckets"] = len(wrapped.sync.launched)
+    res["eager_equal"] = all(torch.equal(p.grad, q.grad) for p, q in zip(net.parameters(), ref.parameters()))
+    # the same data-parallel step captured WITH its all-reduces
+    st0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    gs = A.GraphedStep(net, lossf, x, t, allow_grad_sync=True)
+    net.load_state_dict(st0); ref.load_state_dict(st0)
+    ok = True
+    for it in range(2):
+        gi = torch.Generator().manual_seed(20 + it)
+        xi = torch.randn(2, 3, 48, 64, generator=gi).to(dev); ti = torch.randint(0, 12, (2, 48, 64), generator=gi).to(dev)
+        la = gs.replay(xi, ti)
+        for p in ref.parameters():
+            p.grad = None
+        lb = lossf(ref(xi), ti); lb.backward()
+        ok = ok and la.item() == lb.item() and all(torch.equal(p.grad, q.grad) for p, q in zip(net.parameters(), ref.parameters()))
+    res["graph_equal"] = bool(ok)
+    torch.cuda.synchronize()
+    with open(out_path, "w") as f:
+        json.dump(res, f)
+    torch.distributed.destroy_process_group()
+
+
+def test_world1_rccl_group_eager_and_captured_step():
+    """what one GPU can show of the data-parallel path over REAL RCCL.  A world-size-1 'nccl' group created through
+    ddp.init_process_group (NCCL_MAX_NCHANNELS and CVK_DP_RESERVE_CUS set together); ddp.DataParallel(always_issue=True) issues every
+    gradient bucket as an RCCL all-reduce; the gradients equal the plain step bit for bit (AVG over one rank), the persistent kernels
+    run under the CU reservation, and the step captured as ONE graph with its collectives (GraphedStep(allow_grad_sync=True)) replays
+    to the same loss and gradients."""
+    import json
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "w1.json")
+        mp.spawn(_world1_worker, args=(free_port(), out), nprocs=1, join=True)
+        res = json.load(open(out))
+    assert res["env"]["NCCL_MAX_NCHANNELS"] is not None and res["env"]["CVK_DP_RESERVE_CUS"] == res["env"]["NCCL_MAX_NCHANNELS"]
+    assert res["reserve"] > 0 and res["buckets"] >= 4
+    assert res["eager_equal"] and res["graph_equal"], res
+
+
+def test_bench_dp_overhead_line():
+    """`bench.py --dp-overhead` (N=1): the plain step, the step under DataParallel on a world-1 RCCL group, the exposed all-reduce
+    wait and the graph-captured DP step ride on the line under `dp_overhead`."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "2", "--height", "96",
+                        "--width", "128", "--no-cpu-baseline", "--no-kernel-profile", "--no-extra-configs", "--dp-overhead"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    o = rec["dp_overhead"]
+    for k in ("plain_ms_per_step", "dp_world1_ms_per_step", "overhead_pct", "allreduce_exposed_ms", "graphed_dp_ms_per_step",
+              "graphed_dp_host_enqueue_ms_per_step", "persistent_workgroups", "buckets"):
+        assert k in o, k
+    assert o["plain_ms_per_step"] > 0 and o["dp_world1_ms_per_step"] > 0 and o["persistent_workgroups"] > 0 and len(o["buckets"]) >= 1
+    assert o["graphed_dp_host_enqueue_ms_per_step"] < o["host_enqueue_ms_per_step"]

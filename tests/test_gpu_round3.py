@@ -141,9 +141,36 @@ def test_graphed_step_refuses_data_parallel():
     net = A.UNet(3, 12).to(dev()).train()
     runner_of(net).grad_sync = object()
     x, t = batch(1, 32, 48, 1)
-    with pytest.raises(RuntimeError, match="eager mode only"):
+    with pytest.raises(RuntimeError, match="allow_grad_sync"):
         A.GraphedStep(net, A.CrossEntropyLoss(), x, t)
+    with pytest.raises(RuntimeError, match="RCCL"):                       # a synchroniser that is not an RCCL group cannot be captured
+        A.GraphedStep(net, A.CrossEntropyLoss(), x, t, allow_grad_sync=True)
     runner_of(net).grad_sync = None
+
+
+def test_graphed_step_replay_refuses_a_changed_network():
+    """a captured graph bakes in train mode, the conv precision, the kernel knobs and the gradient synchroniser; replay()
+    after any of them changed would silently run the OLD configuration (e.g. skip every all-reduce) — it raises instead."""
+    import pytorch_camvid_amd as A
+    from pytorch_camvid_amd.modules import runner_of
+    net = A.UNet(3, 12).to(dev()).train()
+    x, t = batch(1, 32, 48, 1)
+    gs = A.GraphedStep(net, A.CrossEntropyLoss(), x, t)
+    gs.replay()
+    net.eval()
+    with pytest.raises(RuntimeError, match="changed since the capture"):
+        gs.replay()
+    net.train()
+    gs.replay()
+    runner_of(net).grad_sync = object()                                   # e.g. wrapped in ddp.DataParallel afterwards
+    with pytest.raises(RuntimeError, match="changed since the capture"):
+        gs.replay()
+    runner_of(net).grad_sync = None
+    A.set_conv_precision(net, "bf16")
+    with pytest.raises(RuntimeError, match="changed since the capture"):
+        gs.replay()
+    A.set_conv_precision(net, "fp32")
+    gs.replay()
 
 
 @pytest.mark.parametrize("Co,Ci", [(64, 32), (128, 256), (96, 160), (40, 72)])
