@@ -278,9 +278,16 @@ def dp_overhead_leg(A, dev, net, lossf, leg, a, plain_step):
         t0 = time.perf_counter()
         for _ in range(n):
             fn()
-        th = time.perf_counter() - t0
         torch.cuda.synchronize(dev)
-        return (time.perf_counter() - t0) / n * 1e3, th / n * 1e3
+        ms = (time.perf_counter() - t0) / n * 1e3
+        th = 0.0                                             # host time to enqueue ONE step into an idle queue
+        for _ in range(5):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            fn()
+            th += time.perf_counter() - t1
+        torch.cuda.synchronize(dev)
+        return ms, th / 5 * 1e3
 
     plain_ms, _ = timed(plain_step)
     wrapped = ddp.DataParallel(net, always_issue=True)
@@ -338,6 +345,15 @@ def dp_identity(dev, world, rehearsal):
                     "parallel; ddp.init_process_group sets NCCL_MAX_NCHANNELS (default 16) and CVK_DP_RESERVE_CUS together."}
 
 
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner when its first
+    communicator is created), so file descriptor 1 is pointed at stderr for the whole run and the line goes out through a saved copy."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(saved, "w")
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -347,6 +363,7 @@ def main():
         # `python bench.py --gpus N` without a launcher: start one rank per GPU ourselves (torch.distributed.run as a
         # CHILD process, before anything here touches the GPU) and relay rank 0's JSON line.
         raise SystemExit(self_launch(a.gpus))
+    real_stdout = _claim_stdout()       # after the self-launch decision: the child ranks claim their own
     if world != a.gpus:
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {a.gpus}: pass --gpus equal to the number of ranks")
     # CVK_REHEARSAL=1: ranks share the visible GPUs and talk over gloo — a plumbing check of the N>1 path on a 1-GPU
@@ -495,7 +512,8 @@ def main():
             line["graph_replay"] = graph
         if dp_over is not None:
             line["dp_overhead"] = dp_over
-        print(json.dumps(line), flush=True)
+        real_stdout.write(json.dumps(line) + "\n")
+        real_stdout.flush()
     if dist.is_initialized():
         dist.destroy_process_group()
 
