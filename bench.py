@@ -144,19 +144,25 @@ def kernel_profile(step, dev, nprof=3):
         step()
     torch.cuda.synchronize(dev)
     agg, mem = {}, {}
-    for name, work, e0, e1, unit, executed in engine.PROF:
-        d = (agg if unit == "flop" else mem).setdefault(name, [0, 0.0, 0.0, 0.0])
+    for name, work, e0, e1, unit, executed, nbytes in engine.PROF:
+        d = (agg if unit == "flop" else mem).setdefault(name, [0, 0.0, 0.0, 0.0, 0.0])
         d[0] += 1; d[1] += work; d[2] += e0.elapsed_time(e1) * 1e-3
         d[3] += executed if executed is not None else work * executed_share(name)
+        d[4] += nbytes if nbytes is not None else 0.0
     engine.PROF = None
     kernels = {k: {"launches_per_step": v[0] // nprof, "avg_us": round(v[2] / v[0] * 1e6, 1),
                    "tflops": round(v[1] / v[2] / 1e12, 2), "ms_per_step": round(v[2] / nprof * 1e3, 3),
                    "executed_frac_of_peak": round(v[3] / v[2] / 1e12 / peak_of(k), 4)} for k, v in agg.items()}
+    for k, v in agg.items():
+        if v[4] > 0:        # the thin stem / head kernels sit on the HBM side of the ridge (AI 12.9 / 45): both fractions
+            kernels[k].update({"algorithmic_GBps": round(v[4] / v[2] / 1e9, 1), "frac_of_8TBps": round(v[4] / v[2] / PEAK_HBM_BPS, 3),
+                               "flop_per_byte": round(v[1] / v[4], 1),
+                               "bound": "hbm" if v[1] / v[4] < peak_of(k) * 1e12 / PEAK_HBM_BPS else "mfma"})
     hbm_kernels = {k: {"launches_per_step": v[0] // nprof, "ms_per_step": round(v[2] / nprof * 1e3, 3),
                        "algorithmic_GBps": round(v[1] / v[2] / 1e9, 1), "frac_of_8TBps": round(v[1] / v[2] / PEAK_HBM_BPS, 3)}
                    for k, v in mem.items()}
     dom = max(agg.items(), key=lambda kv: kv[1][2])
-    cnt, fl, sec, exe = dom[1]
+    cnt, fl, sec, exe = dom[1][:4]
     alg = fl / sec / 1e12                       # algorithmic TFLOP/s (SURVEY.md §8d numerator)
     peak = peak_of(dom[0])
     ach = exe / sec / 1e12                      # FLOPs the MFMA pipe really executes per second: a hardware fraction <= 1

@@ -379,18 +379,20 @@ def mark_weights_dirty(module):
 PROF = None     # bench.py sets this to a list: every _timed call then appends (kernel name, work, start event, end event, unit, executed)
 
 
-def _timed(R, name, work, fn, unit="flop", executed=None):
+def _timed(R, name, work, fn, unit="flop", executed=None, nbytes=None):
     """Run fn(); when a profile list is attached (bench.py sets engine.PROF), bracket it with HIP events on the launch
     stream.  `work` is the ALGORITHMIC work of the call: FLOPs for the conv kernels, HBM bytes (each input read once,
     each output written once, at the storage dtype) for the memory-bound kernels.  `executed`: FLOPs the kernel really
-    issues to the matrix pipe when that is not a fixed share of `work` (bench.py knows the fixed shares by kernel name)."""
+    issues to the matrix pipe when that is not a fixed share of `work` (bench.py knows the fixed shares by kernel name).
+    `nbytes`: for conv kernels that sit near the HBM side of the ridge (the 3-channel stem, the 12-class head: SURVEY §8d) their
+    algorithmic bytes as well — bench.py then reports BOTH roofline fractions for them."""
     if PROF is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = fn()
     e1.record()
-    PROF.append((name, work, e0, e1, unit, executed))
+    PROF.append((name, work, e0, e1, unit, executed, nbytes))
     return r
 
 
@@ -453,7 +455,7 @@ class ConvBnRelu(Op):
             head = src.ld == 64
             _timed(R, "k_thin_co_fwd" if head else "k_thin_ci_fwd", 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_thin_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, cnt, N, H, W, src.ld, C, ldy, s),
-                "cvk_conv3x3_thin_fwd"), executed=18.0 * M * (16 * self.cin if head else C * src.ld))
+                "cvk_conv3x3_thin_fwd"), executed=18.0 * M * (16 * self.cin if head else C * src.ld), nbytes=4.0 * M * (src.ld + ldy))
             return (Pt, cnt) if sp is not None else None
         if wino_ok(R, src.ld, ldy):
             return wino_conv(R, lib, s, X, wk, b.data_ptr(), y, sp, N, H, W, src.ld, C, ldy, 18.0 * M * C * self.cin, keep_v=keep_v,
@@ -632,7 +634,7 @@ class ConvBnRelu(Op):
                 wd = R.derived(((self.pslot, "d"), "pack"), w, packed)
                 _timed(R, "k_thin_ci_fwd(dgrad)", 18.0 * M * C * self.cin, lambda: check(
                     lib.cvk_conv3x3_thin_fwd(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, None, N, H, W, ldy, src.ld, src.ld, s),
-                    "cvk_conv3x3_thin_fwd(dgrad)"), executed=18.0 * M * ldy * src.ld)
+                    "cvk_conv3x3_thin_fwd(dgrad)"), executed=18.0 * M * ldy * src.ld, nbytes=4.0 * M * (src.ld + ldy))
             else:
                 wd = R.derived(((self.pslot, "d"), "pack"), w, packed)
                 _timed(R, conv_kernel_name("dgrad", src.ld, ldy), 18.0 * M * C * self.cin, lambda: check(
@@ -695,7 +697,7 @@ class ConvBnRelu(Op):
             head = src.ld == 64
             _timed(R, "k_thin_co_wgrad" if head else "k_thin_ci_wgrad", 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_thin_wgrad(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ldy, ws.data_ptr(), wsb, s),
-                "cvk_conv3x3_thin_wgrad"), executed=18.0 * M * (16 * self.cin if head else C * 16 / 3.0))
+                "cvk_conv3x3_thin_wgrad"), executed=18.0 * M * (16 * self.cin if head else C * 16 / 3.0), nbytes=4.0 * M * (src.ld + ldy))
         elif R.wino and src.ld >= 32 and C > 32 and (src.ld > 64 or C > 64):   # 64->64 layers: the direct kernel is faster
             wsb = lib.cvk_conv3x3_wgrad_wino_workspace_bytes(N, H, W, src.ld, C)
             ws = R.workspace(wsb, dev)
