@@ -91,6 +91,7 @@ class RunState:
         self.sync = None   # optional gradient synchroniser (ddp.GradSync)
         self.pooled_by_block = {}   # op index of a conv block -> True when its BN-apply pass also wrote the max pool behind it
         self.colsums = []           # queued column-sum finalisations (Runner.defer_colsum)
+        self.pass_token = 0         # derived-weight cache token of this pass (Runner.forward)
         self.bnred = {}             # op index of a conv block -> (partials, count): its BN-backward sums, left by the consumer's data-grad
 
 
@@ -352,7 +353,12 @@ def conv_kernel_name(kind, n_cols, k_ch=32):
 #   * any torch.optim optimizer step      -> global epoch (torch.optim.optimizer.register_optimizer_step_post_hook)
 #   * FlatAdamW.step, load_state_dict, ddp.DataParallel's broadcast, mark_weights_dirty(net) -> runner epoch
 #   * .to() / .cuda() / in-place autograd-visible ops -> storage pointer / version counter
-# In-place writes nobody can see (`p.data.add_()`, a foreign kernel) need `mark_weights_dirty(net)`.
+# FAIL-SAFE in training: a TRAINING pass (forward with a backward to follow) never trusts entries of earlier passes — its
+# signature carries a per-pass token, so the tensors are built once per pass (one batched launch in bf16 mode) and shared by that
+# pass's forward and backward only.  Writes nobody can see (`p.data.copy_()` of an EMA swap, manual re-initialisation, a foreign
+# kernel, a freed-and-reallocated parameter at the same address) are therefore always picked up in training, as stock torch
+# picks them up.  Only eval / no-grad passes reuse entries across calls; THERE an invisible in-place write needs
+# `mark_weights_dirty(net)`.
 # Never used while a stream capture is running: a replayed graph must recompute the derived tensors from the live weights.
 WEIGHT_EPOCH = [0]
 WCACHE_DEFAULT = os.environ.get("CVK_WEIGHT_CACHE", "1") != "0"
@@ -1069,6 +1075,8 @@ class Runner:
         self.wcache = WCACHE_DEFAULT
         self.wepoch = 0             # bumped by mark_weights_dirty / FlatAdamW.step / load_state_dict
         self._wc = {}               # (layer slot, kind) -> (signature, tensor)
+        self._pass_token = 0        # 0: eval / no-grad passes (entries shared across calls); > 0: the training pass being executed
+        self._passes = 0
         self.wcache_builds = 0      # derived tensors built since creation (tests / diagnostics)
 
     def persistent_wgs(self):
@@ -1087,7 +1095,7 @@ class Runner:
         if not self.wcache or key is None or torch.cuda.is_current_stream_capturing():
             self.wcache_builds += 1
             return build()
-        sig = (WEIGHT_EPOCH[0], self.wepoch, src.data_ptr(), src._version)
+        sig = (WEIGHT_EPOCH[0], self.wepoch, src.data_ptr(), src._version, self._pass_token)
         ent = self._wc.get(key)
         if ent is not None and ent[0] == sig:
             return ent[1]
@@ -1106,7 +1114,7 @@ class Runner:
             if not isinstance(op, ConvBnRelu):
                 continue
             w = st.params[4 * op.pslot]
-            sig = (WEIGHT_EPOCH[0], self.wepoch, w.data_ptr(), w._version)
+            sig = (WEIGHT_EPOCH[0], self.wepoch, w.data_ptr(), w._version, self._pass_token)
             want = [(((op.pslot, "f"), "bf16"), 0, op.cout, op.src.ld)]
             if need_grad and op.src_needs_grad:
                 want.append((((op.pslot, "d"), "bf16"), 1, op.cin, max(32, op.cout)))
@@ -1178,6 +1186,10 @@ class Runner:
         st = RunState(params, training, need_grad)
         st.device = dev
         st.plan = plan
+        if training and need_grad:          # a training pass: derived weights are rebuilt for it (fail-safe, see the cache notes above)
+            self._passes += 1
+            st.pass_token = self._passes
+        self._pass_token = st.pass_token
         st.stream = torch.cuda.current_stream(dev).cuda_stream
         inb = plan.input
         xp = x.permute(0, 2, 3, 1)
@@ -1212,6 +1224,7 @@ class Runner:
         dev = gout.device
         self.w2tile, self.w2tile_dgrad = self.tile_for(plan)
         st.stream = torch.cuda.current_stream(dev).cuda_stream
+        self._pass_token = st.pass_token
         params = st.params
         st.goffs, total = self.layout_grads(plan, params)
         # A FRESH flat buffer per backward call (caching allocator: the block freed by `p.grad = None` comes straight
