@@ -454,6 +454,15 @@ def main():
                  "what": "zero_grad + forward + CE + backward replayed from ONE captured HIP graph (pytorch_camvid_amd.graph.GraphedStep)"}
         del gs
 
+    w2d_tile = None
+    if a.precision == "fp32":
+        # the accuracy trade of the 2-D Winograd tile is part of the configuration (tests/test_gpu_nets.py dense fixtures)
+        from pytorch_camvid_amd.modules import runner_of as _runner_of
+        cfg = _runner_of(net).w2tile_cfg
+        tf, td = (cfg, cfg) if cfg in (4, 6) else ((4, 6) if a.model == "segnet" else (6, 6))
+        w2d_tile = (f"channel-heavy layers: 2-D Winograd F({tf}x{tf},3x3) forward / weight-grad, F({td}x{td},3x3) data-grad.  Headline logits vs the "
+                    "reference: max |dev| 5.3e-4 with F(6x6), 3.3e-4 with F(4x4) (CVK_W2D_TILE=4: about -8 % images/s); tolerance 6.6e-4 = 4 x the "
+                    "reference graph's own drift")
     dp_over = None
     if a.dp_overhead and world == 1:
         dp_over = dp_overhead_leg(A, dev, net, lossf, leg, a, step)
@@ -499,7 +508,8 @@ def main():
             "config": {"workload": config_label(a.model, a.batch, a.height, a.width, a.precision, world),
                        "global_batch": world * a.batch, "parallelism": f"dp{world}", "timed_region": "zero_grad+forward+CE+backward"
                                    + ("+allreduce" if world > 1 else ""), "loss": round(leg["loss"], 6),
-                       "derived_weights": "rebuilt in every timed step (executor cache invalidated per step, as after optimizer.step)"},
+                       "derived_weights": "rebuilt in every timed step (executor cache invalidated per step, as after optimizer.step)",
+                       **({"w2d_tile": w2d_tile} if w2d_tile else {})},
             "roofline": leg.get("roof"), "cpu_baseline": cpu,
         }
         if leg.get("kernels"):
