@@ -701,7 +701,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16q(const __bf16* __restrict_
 constexpr int HBN = 64;                          // output channels per workgroup
 constexpr int HROW = 3 * HBN * 64;               // 12 KiB: the weight tiles of one kernel row of one channel slice
 
-template <bool STATS, int DBG = 0>     // DBG 1: s_memrealtime stamps of workgroup 0's first 16 tiles -> `stats` (timing experiments only)
+// P128: the weights come in the 128-row tile-major pack of k_conv_bf16q (layers with > 64 output channels whose tile count fills the chip
+// badly with 128-channel tiles, e.g. 512 channels at 90x120: 384 tiles = 1.5 rounds of 256 CUs, 768 half-width tiles = 3): this workgroup's
+// 64 rows are one half of every 8 KiB tap tile — three 4 KiB pieces 8 KiB apart instead of 12 contiguous KiB, still scalar-addressed.
+template <bool STATS, int DBG = 0, bool P128 = false>     // DBG 1: s_memrealtime stamps of workgroup 0's first 16 tiles -> `stats` (timing experiments only)
 __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict__ X, const char* __restrict__ Wp,
                                                       const float* __restrict__ bias, __bf16* __restrict__ Y,
                                                       float* __restrict__ stats, float* __restrict__ cnt, int H, int W, int Cin,
@@ -740,7 +743,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
     i32x4 xrsrc;
     xrsrc[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)(H * W * Cin) * 2u));
     xrsrc[3] = 0x00020000;
-    const unsigned wvoff = wave * 1024 + lane * 16;
+    constexpr int WROW = P128 ? 3 * BTAP : HROW;                 // source bytes of one kernel row of one slice
+    // source offset of this wave's first piece inside a kernel row (piece p = tap p / 4, KiB p % 4 of the tap's 64 rows)
+    const unsigned wvoff = (P128 ? (wave >> 2) * BTAP + (wave & 3) * 1024 : wave * 1024) + lane * 16;
     const unsigned wave_lds = smem_addr + wave * 1024;
     const char* wnext = Wp;
     int slab_yx[5];
@@ -762,7 +767,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
         const uintptr_t xbase = (uintptr_t)(X + (size_t)g.img * H * W * Cin);
         xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xbase);
         xrsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xbase >> 32) & 0xFFFF);
-        wnext = Wp + (size_t)g.nt * nph * HROW;
+        wnext = P128 ? Wp + (size_t)(g.nt >> 1) * nph * WROW + (g.nt & 1) * (HBN * 64) : Wp + (size_t)g.nt * nph * WROW;
     };
     auto dma_slab_piece = [&](auto t_tag, int cs, unsigned slab_lds) {
         constexpr int T = decltype(t_tag)::value;
@@ -772,8 +777,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
     auto dma_row_next = [&](auto slot_tag, int ph) {
         constexpr int SLOT = decltype(slot_tag)::value;
         dma16_saddr_i<SLOT * HROW>(wvoff, wnext, wave_lds);
-        if (lo) dma16_saddr_i<SLOT * HROW + 8192>(wvoff, wnext + 8192, wave_lds);
-        if (ph < nph - 1) wnext += HROW;
+        if (lo) dma16_saddr_i<SLOT * HROW + 8192>(wvoff, wnext + (P128 ? 2 * BTAP : 8192), wave_lds);      // pieces 8..11 = the third tap
+        if (ph < nph - 1) wnext += WROW;
     };
     auto issue_prologue = [&]() {
         dma_slab_piece(std::integral_constant<int, 0>{}, 0, wave_lds + RING_BYTES);
@@ -1103,8 +1108,20 @@ void pack_batch(const cvk_pack_job* jobs, int n, hipStream_t s) {
 
 void launch(const void* x, const void* wpp, const float* bias, void* y, float* stats, float* counts, int N, int H, int W, int Cin,
             int Cout, int ldy, hipStream_t s, int max_workgroups) {
-    const int knd = kind(Cin, Cout);
-    const int tilesX = cvk_cdiv(W, TW), tilesY = cvk_cdiv(H, TH), tilesN = cvk_cdiv(Cout, knd == 2 ? HBN : BN);
+    int knd = kind(Cin, Cout);
+    const int tilesX = cvk_cdiv(W, TW), tilesY = cvk_cdiv(H, TH);
+    bool p128 = false;
+    if (knd == 1) {
+        // 128-channel tiles that fill the chip badly (e.g. 384 tiles = 1.5 rounds of 256 CUs): the 64-channel kernel on the same pack
+        // (twice the tiles; its K loop and its doubled weight traffic cost a few per cent: it must win 10 % in balance; measured: 1380 tiles -> 2760 is a wash, 384 -> 768 gains 8-9 %)
+        static const int h128 = getenv("CVK_BF16P_H128") ? atoi(getenv("CVK_BF16P_H128")) : 1;
+        static const int ncu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 0 ? n : 256; }();
+        const int wg = ncu;          // NOT the data-parallel cap: the choice (and with it the statistics' summation order) must not depend on it
+        const long t1 = (long)N * tilesX * tilesY * cvk_cdiv(Cout, BN), t2 = (long)N * tilesX * tilesY * cvk_cdiv(Cout, HBN);
+        const double e1 = (double)t1 / ((double)cvk_cdiv(t1, wg) * wg), e2 = (double)t2 / ((double)cvk_cdiv(t2, wg) * wg);
+        if (h128 == 2 || (h128 == 1 && mfma_shape() == 16 && Cout % HBN == 0 && e2 * 0.90 > e1)) { knd = 2; p128 = true; }
+    }
+    const int tilesN = cvk_cdiv(Cout, knd == 2 ? HBN : BN);
     const int P = N * tilesX * tilesY;
     dim3 grid((unsigned)(P * tilesN)), block(512);
     static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 0 ? n : 256; }();
@@ -1113,6 +1130,11 @@ void launch(const void* x, const void* wpp, const float* bias, void* y, float* s
         const int ntiles = P * tilesN;
         dim3 pgrid((unsigned)(wgcap < ntiles ? wgcap : ntiles));
         static const int hdbg = getenv("CVK_BF16H_DBG") ? atoi(getenv("CVK_BF16H_DBG")) : 0;
+        if (p128) {
+            if (stats) hipLaunchKernelGGL((k_conv_bf16h<true, 0, true>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);
+            else hipLaunchKernelGGL((k_conv_bf16h<false, 0, true>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);
+            return;
+        }
         if (hdbg) hipLaunchKernelGGL((k_conv_bf16h<false, 1>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);
         else if (stats) hipLaunchKernelGGL((k_conv_bf16h<true>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);
         else hipLaunchKernelGGL((k_conv_bf16h<false>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);
