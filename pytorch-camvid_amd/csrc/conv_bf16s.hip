@@ -67,6 +67,7 @@ __device__ __forceinline__ void dma16_asm_m0(const void* g, unsigned lds_byte_ad
 // past num_records read 0.  Round 4 (tools/stamps_bf16p.py): the v_lshl_add_u64 that forms a per-lane 64-bit address is held
 // back while the SIMD's other wave issues MFMAs (~550 cycles per LOAD phase against ~60 with scalar addressing).
 typedef int i32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void dma16_buf_m0(unsigned voff, i32x4v rsrc, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(rsrc), "s"(lds_byte_addr) : "memory");
 }
@@ -956,11 +957,18 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_bf16s(const __bf16* __restrict
 // halo rows: per halo row 3 x fragments (dx = 0, 1, 2) + 1 new dy fragment feed up to 9 MFMAs — 0.44 KiB of LDS reads per MFMA, 2.7x
 // less, 1.05 read instructions per MFMA instead of 2.4.  The two waves of a SIMD take the two column halves and their accumulators meet
 // through LDS once, after the workgroup's last tile (fixed order: deterministic).  Staging, LDS images, DMA, slabs: as k_wgrad_bf16s.
+// The two waves of a SIMD run the same program and the OLDER one wins every MFMA arbitration: it runs through its tile in ~3300 cycles,
+// its partner gets the leftovers and then runs alone.  PRIO alternates s_setprio per halo row between the column halves so that both
+// advance together (with all DMA pieces in the first rows this measured no gain; with the pieces spread over rows 0-5 it is worth 1.7 %:
+// 4.92 against 5.01 ms for the weight-grads of the UNet layer set, CVK_WGRAD_PRIO=0 switches it off).
+template <int DBG = 0, bool PRIO = true>      // DBG (timing experiments, see the launcher): s_memtime stamps of workgroup 0, waves 0 and 4 -> behind the slabs
 __global__ __launch_bounds__(512, 2) void k_wgrad_bf16r(const __bf16* __restrict__ X, const __bf16* __restrict__ DY,
                                                        float* __restrict__ slab, int H, int W, int ldx, int ld_dy, int Cout,
                                                        int Cin, int tilesX, int tilesY, int ntiles, int tiles_per_split,
                                                        int nblk_ci, int nblk) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * WG_STAGE];
+    unsigned long long k0 = 0, r0 = 0;
+    if (DBG) { k0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // 0..7
@@ -978,6 +986,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_bf16r(const __bf16* __restrict
     //      buffer -> 0).  Tiles whose halo lies inside the frame need nothing else; border tiles recompute the halo coordinates of a
     //      piece for the frame test (wave-uniform branch).  With coordinates AND offsets resident (30 registers) beside 144
     //      accumulators hipcc spilled them, and a spill reload next to a DMA makes it wait vmcnt(0). ------------------------------------
+    // An out-of-frame lane reads offset OOB: past the 2 GiB raw buffer even with the instruction's immediate (<= 3072) added or, as
+    // here, subtracted beforehand (the immediate also moves the LDS address: pieces that share M0 differ by it) -> the lane gets 0.
+    constexpr unsigned OOB = 0x90000000u;
+    constexpr int IMM_BIAS = 3072;          // the descriptors start this many bytes early, so no lane offset goes negative
     unsigned xs_off[6], ds_off[4];
     auto x_yx = [&](int q) {
         const int row = (wave * 6 + q) * 8 + (lane >> 3);
@@ -990,49 +1002,107 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_bf16r(const __bf16* __restrict
         const int hy = row / HP, hx = row - hy * HP;
         const int chunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
         const bool ok = (row < WG_XROWS) & (hx < TW + 2) & (cib * 64 + chunk * 8 < ldx);
-        xs_off[q] = ok ? (unsigned)((hy * W + hx) * ldx + cib * 64 + chunk * 8) * 2u : 0x80000000u;
+        xs_off[q] = ok ? (unsigned)((hy * W + hx) * ldx + cib * 64 + chunk * 8) * 2u + (unsigned)(IMM_BIAS - (q & 3) * 1024) : OOB;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = (wave * 4 + q) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
         const bool ok = cob * 64 + chunk * 8 < ld_dy;
-        ds_off[q] = ok ? (unsigned)(((row >> 5) * W + (row & 31)) * ld_dy + cob * 64 + chunk * 8) * 2u : 0x80000000u;
+        ds_off[q] = ok ? (unsigned)(((row >> 5) * W + (row & 31)) * ld_dy + cob * 64 + chunk * 8) * 2u + (unsigned)(IMM_BIAS - q * 1024) : OOB;
     }
     const unsigned smem_addr = lds_addr_of(smem);
     i32x4v sx_rsrc = raw_rsrc_2g(X), sd_rsrc = raw_rsrc_2g(DY);
     int s_ylo = 0, s_yn = 0, s_xlo = 0, s_xn = 0, s_dyn = 0, s_dxn = 0;
     bool s_interior = false;
     unsigned s_buf = 0;
-    auto stage_begin = [&](int t, int which) {
-        const int tx = t % tilesX, ty = (t / tilesX) % tilesY, img = t / (tilesX * tilesY);
-        const int x0 = tx * TW, y0 = ty * TH;
-        const long pix = ((long)img * H + y0) * W + x0;
-        sx_rsrc = raw_rsrc_2g(X + (pix - W - 1) * ldx);
-        sd_rsrc = raw_rsrc_2g(DY + pix * ld_dy);
+    // Tile coordinates of the tile being PREPARED (descriptors, frame limits, offsets), advanced by one tile per step: the div/mod
+    // form (t % tilesX, t / tilesX % tilesY, ...) compiled to ~120 dependent scalar instructions per tile, executed by all eight
+    // waves at the tile start with the matrix pipe idle behind them.
+    int p_tx = 0, p_ty = 0, p_img = 0;
+    auto coords_init = [&](int t) {
+        p_tx = __builtin_amdgcn_readfirstlane(t % tilesX);
+        p_ty = __builtin_amdgcn_readfirstlane((t / tilesX) % tilesY);
+        p_img = __builtin_amdgcn_readfirstlane(t / (tilesX * tilesY));
+    };
+    auto coords_next = [&]() {
+        p_tx += 1;
+        const bool wx = p_tx == tilesX;
+        p_tx = wx ? 0 : p_tx;
+        p_ty += wx ? 1 : 0;
+        const bool wy = p_ty == tilesY;
+        p_ty = wy ? 0 : p_ty;
+        p_img += wy ? 1 : 0;
+    };
+    auto stage_begin = [&](int which) {
+        const int x0 = p_tx * TW, y0 = p_ty * TH;
+        const long pix = (long)((p_img * H + y0) * W + x0);            // pixel index: N * H * W < 2^31 (checked by the launcher)
+        sx_rsrc = raw_rsrc_2g(X + (pix - W - 1) * ldx - IMM_BIAS / 2);
+        sd_rsrc = raw_rsrc_2g(DY + pix * ld_dy - IMM_BIAS / 2);
         s_ylo = y0 == 0 ? 1 : 0;  s_yn = min(TH + 2, H - y0 + 1) - s_ylo;
         s_xlo = x0 == 0 ? 1 : 0;  s_xn = min(TW + 2, W - x0 + 1) - s_xlo;
         s_dyn = min(TH, H - y0);  s_dxn = min(TW, W - x0);
         s_interior = (y0 > 0) & (y0 + TH < H) & (x0 > 0) & (x0 + TW < W);
         s_buf = smem_addr + which * WG_STAGE;
     };
-    auto stage_x = [&](int q) {
-        unsigned off = xs_off[q];
-        if (!s_interior) {
-            const int yx = x_yx(q);
-            const bool ok = ((unsigned)((yx >> 8) - s_ylo) < (unsigned)s_yn) & ((unsigned)((yx & 255) - s_xlo) < (unsigned)s_xn);
-            off = ok ? off : 0x80000000u;
+    // Offsets of the ten pieces of the prepared tile, computed in one place (prepare_next).  The DMA slots themselves hold no vector-ALU
+    // instruction and no branch: with the frame test (2 v_sub, 2 v_cmp, v_cndmask) or even just the v_mov of a select plus two scalar
+    // branches in every slot a tile took ~6500 cycles instead of ~5300 (tools/tile_stamps_wgrad.py) — a wave whose SIMD partner streams
+    // MFMAs waits long for each of them.
+    unsigned noff[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) noff[q] = OOB;
+    auto stage_offsets = [&]() {
+        if (s_interior) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) noff[q] = xs_off[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) noff[6 + q] = ds_off[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int yx = x_yx(q);
+                const bool ok = ((unsigned)((yx >> 8) - s_ylo) < (unsigned)s_yn) & ((unsigned)((yx & 255) - s_xlo) < (unsigned)s_xn);
+                noff[q] = ok ? xs_off[q] : OOB;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = (wave * 4 + q) * 8 + (lane >> 3);
+                const bool ok = ((row >> 5) < s_dyn) & ((row & 31) < s_dxn);
+                noff[6 + q] = ok ? ds_off[q] : OOB;
+            }
         }
-        dma16_buf_m0(off, sx_rsrc, s_buf + (wave * 6 + q) * 1024);
+        if (DBG & 8) {
+#pragma unroll
+            for (int q = 0; q < 10; ++q) noff[q] = OOB;
+        }
     };
-    auto stage_d = [&](int q) {
-        unsigned off = ds_off[q];
-        if (!s_interior) {
-            const int row = (wave * 4 + q) * 8 + (lane >> 3);
-            const bool ok = ((row >> 5) < s_dyn) & ((row & 31) < s_dxn);
-            off = ok ? off : 0x80000000u;
+    // Piece q of the prepared tile.  This wave's x pieces 0-3, x pieces 4-5 and dy pieces 0-3 are 1 KiB apart in LDS = the instruction's
+    // immediate offset (taken out of the lane offsets above), so M0 takes three values only.
+    auto stage_piece = [&](int q) {           // q is a constant after unrolling
+        if (DBG & 32) return;
+        const unsigned mx0 = s_buf + wave * 6 * 1024, mx1 = mx0 + 4096, md = s_buf + WG_XBYTES + wave * 4 * 1024;
+#define CVK_WGR_PIECE(Q_, RSRC_, M0_, IMM_)                                                                                            \
+        if (q == Q_) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen offset:" #IMM_ " lds"       \
+                                  : : "v"(noff[Q_]), "s"(RSRC_), "s"(M0_) : "memory")
+        CVK_WGR_PIECE(0, sx_rsrc, mx0, 0);    CVK_WGR_PIECE(1, sx_rsrc, mx0, 1024); CVK_WGR_PIECE(2, sx_rsrc, mx0, 2048); CVK_WGR_PIECE(3, sx_rsrc, mx0, 3072);
+        CVK_WGR_PIECE(4, sx_rsrc, mx1, 0);    CVK_WGR_PIECE(5, sx_rsrc, mx1, 1024);
+        CVK_WGR_PIECE(6, sd_rsrc, md, 0);     CVK_WGR_PIECE(7, sd_rsrc, md, 1024);  CVK_WGR_PIECE(8, sd_rsrc, md, 2048);  CVK_WGR_PIECE(9, sd_rsrc, md, 3072);
+#undef CVK_WGR_PIECE
+    };
+    // While tile t is multiplied, halo rows 0-5 issue the pieces of tile t + 1 from the prepared state (2, 2, 2, 2, 1, 1) and halo row 6
+    // prepares tile t + 2.  The LDS-DMA path of a CU takes ~64 B/clk: the 80 KiB of a tile are 1280 cycles of it, and a wave stands at its
+    // buffer_load until the queue takes it.  All ten pieces of all eight waves in rows 0-1 (or 0-3) kept every wave in that queue for the
+    // first quarter of the tile, MFMAs trickling (tile 5800 cycles; 5150 without DMA: tools/tile_stamps_wgrad.py, CVK_WGRAD_DBG=84).
+    // Past the last tile the lanes point out of range: the DMA then zero-fills the stage nobody reads any more — no predicate needed.
+    auto prepare_next = [&](int which, bool exists) {
+        coords_next();
+        stage_begin(which);
+        stage_offsets();
+        if (!exists) {
+#pragma unroll
+            for (int q = 0; q < 10; ++q) noff[q] = OOB;
         }
-        dma16_buf_m0(off, sd_rsrc, s_buf + WG_XBYTES + (wave * 4 + q) * 1024);
     };
 
     // ---- transposed-read lane addresses (as k_wgrad_bf16s; the k-step of a row is this wave's column half) ---------------------------
@@ -1053,78 +1123,164 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_bf16r(const __bf16* __restrict
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    // One tile: ten halo rows.  fa[y % 4] = dy fragment of output row y (live for three halo rows, requested one row ahead), fb = the three x fragments of the
-    // current halo row; the fragments of halo row y' + 1 are requested before the MFMAs of row y' (order pinned with sched_barrier):
-    // fb[dx] is refilled in place right after its last MFMA of the row has been issued (the MFMA has latched its operands).
-    auto tile_body = [&](char* buf, const bool MORE) {     // ONE copy of the MFMA stream (two copies behind a branch: hipcc no longer ties the
-                                                           // accumulators in place across the tile loop and spills them); MORE is wave-uniform
-        bf16x8 fa[4], fb[3];
-        fa[0] = tr_read8(buf + a_base);
+    // One tile: ten halo rows.  fa[y % 4] = dy fragment of output row y (live for three halo rows, requested one row ahead), fb = the three
+    // x fragments of the current halo row, refilled in place for the next row once their last MFMA of this row has been issued (the
+    // MFMA has latched its operands).  A fragment is two ds_read_b64_tr_b16; each costs its wave ~18 cycles of issue, and an MFMA
+    // leaves the in-order wave 28 cycles before the pipe wants the next one.  Reads in pairs behind groups of three MFMAs (first
+    // version: M M M R R) pushed every following MFMA out by the excess: a wave alone on its SIMD needed ~340 cycles per 9-MFMA row
+    // (tools/tile_stamps_wgrad.py, CVK_WGRAD_DBG=80).  Now ONE read instruction follows each MFMA: the eight reads of a row are queued
+    // (dy fragment halves first, then fb[0], fb[1], fb[2] as their groups finish) and each MFMA is followed by the next one that is ready.
+    unsigned long long rowst[TH + 3];
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) fb[dx] = tr_read8(buf + b_base[dx]);
+    for (int i = 0; i < TH + 3; ++i) rowst[i] = 0;
+    auto rd_half = [&](const char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p); };
+    auto frag = [&](s16x4 lo, s16x4 hi) { return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)); };
+    // Two barriers per tile, neither followed by a cold start.  X, before halo row 8: every wave's DMA pieces of tile t + 1 have landed
+    // (issued in rows 0-1, ~4000 cycles earlier).  Behind it rows 8 and 9 still run on fragments already in registers, and row 9 requests
+    // the row-0 fragments of tile t + 1 from the other stage.  Y, at the tile end: every wave is through with the LDS reads of tile t, the
+    // DMA of tile t + 2 may overwrite it — and tile t + 1 starts multiplying at once (with one barrier at the tile end the first
+    // fragment reads came after it: ~300 idle cycles per tile on every SIMD).
+    s16x4 fal[4], fah[4], fbl[3], fbh[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { fal[i] = s16x4{0, 0, 0, 0}; fah[i] = s16x4{0, 0, 0, 0}; }
+    auto first_reads = [&](char* b0) {
+        fal[0] = rd_half(b0 + a_base);
+        fah[0] = rd_half(b0 + a_base + 512);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) { fbl[dx] = rd_half(b0 + b_base[dx]); fbh[dx] = rd_half(b0 + b_base[dx] + 512); }
+    };
+    auto tile_body = [&](char* buf, char* nbuf, const bool MORE2, int which2) {     // ONE copy of the MFMA stream (two copies behind a branch: hipcc no longer ties the
+                                                           // accumulators in place across the tile loop and spills them)
 #pragma unroll
         for (int yp = 0; yp < TH + 2; ++yp) {
-            if (MORE && yp < 5) {      // this wave's 10 DMA pieces of the next tile: two per halo row in rows 0-4 (all ten at the start
-                                       // stall both waves of a SIMD together; the late rows leave them half a tile to land)
-                if (yp < 3) { stage_x(2 * yp); stage_x(2 * yp + 1); }
-                else { stage_d(2 * (yp - 3)); stage_d(2 * (yp - 3) + 1); }
-            }
-            if (yp + 1 < TH) fa[(yp + 1) % 4] = tr_read8(buf + a_base + (yp + 1) * 32 * 128);      // four slots: rows yp - 2 .. yp are still read below
+            if (DBG & 64) rowst[yp] = __builtin_amdgcn_s_memtime();
+            if (yp == TH) { wait_vm<0>(); __builtin_amdgcn_s_barrier(); }          // X
+            if (PRIO) { if (half == (yp & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+            if (yp == 6 && !(DBG & 4)) prepare_next(which2, MORE2);
             __builtin_amdgcn_sched_barrier(0);
+            const int dy_lo = yp - (TH - 1) > 0 ? yp - (TH - 1) : 0, dy_hi = yp < 2 ? yp : 2;       // valid kernel rows: 0 <= yp - dy < TH
+            const int nv = dy_hi - dy_lo + 1;                                                           // MFMAs per dx group
+            const bool wrap = yp == TH + 1;              // the "next row" of the last halo row is row 0 of the next tile (other stage)
+            const bool has_a = yp + 1 < TH || wrap, has_b = true;
+            const int nreads = (DBG & 2) ? 0 : (has_a ? 2 : 0) + (has_b ? 6 : 0);
+            const int nrow = wrap ? 0 : yp + 1;
+            char* const rbuf = wrap ? nbuf : buf;
+            int r = 0;                                   // reads of the next row issued so far (compile-time after unrolling)
+            auto issue_read = [&](int q) {               // q-th read of the queue
+                const int qb = has_a ? q - 2 : q;
+                if (has_a && q < 2) {
+                    const char* pa = rbuf + a_base + nrow * 32 * 128 + q * 512;
+                    if (q == 0) fal[nrow % 4] = rd_half(pa); else fah[nrow % 4] = rd_half(pa);
+                } else {
+                    const char* pb = rbuf + b_base[qb >> 1] + nrow * HP * 128 + (qb & 1) * 512;
+                    if (qb & 1) fbh[qb >> 1] = rd_half(pb); else fbl[qb >> 1] = rd_half(pb);
+                }
+            };
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
                     const int y = yp - dy;
-                    if (y >= 0 && y < TH)
-                        acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[y % 4], fb[dx], acc[dy * 3 + dx], 0, 0, 0);
+                    if (y < 0 || y >= TH) continue;
+                    acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fal[y % 4], fah[y % 4]), frag(fbl[dx], fbh[dx]), acc[dy * 3 + dx], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bool last_of_group = dy == dy_hi;
+                    // the next queued read, if its registers are free: dy halves always, fb[g] once group g is through
+                    const int qb = has_a ? r - 2 : r;
+                    const bool ready = r < nreads && ((has_a && r < 2) || (qb >> 1) < dx || ((qb >> 1) == dx && last_of_group));
+                    if (ready) { issue_read(r); ++r; }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if (yp + 1 < TH + 2) fb[dx] = tr_read8(buf + b_base[dx] + (yp + 1) * HP * 128);
-                __builtin_amdgcn_sched_barrier(0);
             }
+            // what did not fit behind an MFMA (light rows; fb[2]'s second half)
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q >= r && q < nreads) issue_read(q);
+            if (!(DBG & 4)) {
+                constexpr int first[7] = {0, 2, 4, 6, 8, 9, 10};                 // pieces of halo rows 0-5: 2, 2, 2, 2, 1, 1
+#pragma unroll
+                for (int q = 0; q < 10; ++q)
+                    if (yp < 6 && q >= first[yp] && q < first[yp + 1]) stage_piece(q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            (void)nv;
         }
     };
 
     if (t0 < t1) {
-        stage_begin(t0, 0);
+        coords_init(t0);
+        stage_begin(0);
+        stage_offsets();
 #pragma unroll
-        for (int q = 0; q < 6; ++q) stage_x(q);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) stage_d(q);
+        for (int q = 0; q < 10; ++q) stage_piece(q);
+        prepare_next(1, t0 + 1 < t1);
     }
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
+    first_reads(smem);
     int cur = 0;
+    // behind the last split's slab (the timing script allocates the room)
+    unsigned long long* const dbgp = reinterpret_cast<unsigned long long*>(slab + (size_t)(gridDim.x / nblk) * Cout * 9 * Cin) + (size_t)(wave >> 2) * 24 * 4;
     for (int t = t0; t < t1; ++t) {
         char* const buf = smem + cur * WG_STAGE;
-        const bool more = t + 1 < t1;
-        if (more) stage_begin(t + 1, cur ^ 1);
-        tile_body(buf, more);
-        wait_vm<0>();
-        lds_retire_barrier();
+        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        if (DBG) s0 = __builtin_amdgcn_s_memtime();
+        tile_body(buf, smem + (cur ^ 1) * WG_STAGE, t + 2 < t1, cur);
+        if (DBG) s1 = __builtin_amdgcn_s_memtime();
+        if ((DBG & 64) && blockIdx.x == 0 && (wave & 3) == 0 && t - t0 == 9 && lane == 0) {
+            unsigned long long* o = dbgp + 2 * 24 * 4 + (wave >> 2) * 8;       // behind both waves' tile records
+            for (int i = 0; i < TH + 2; ++i) o[i] = rowst[i] - s0;
+            o[TH + 2] = s1 - s0;
+        }
+        if (DBG) s2 = __builtin_amdgcn_s_memtime();
+        // Y: the reads of THIS tile are through (the eight requests of row 9 for the next tile are younger and may still be in flight)
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (DBG) {
+            s3 = __builtin_amdgcn_s_memtime();
+            if (blockIdx.x == 0 && (wave & 3) == 0 && t - t0 < 23 && lane == 0) {
+                unsigned long long* o = dbgp + (t - t0) * 4;
+                o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
+            }
+        }
         cur ^= 1;
     }
     // ---- the two column halves meet: waves 4-7 hand their accumulators to waves 0-3 through LDS (the stages are dead) -----------------
-    float* const xch = reinterpret_cast<float*>(smem);          // [quad][tap][register 16][lane 64]
-    if (half == 1) {
+    // Half 0 hands its taps 5-8 to half 1, half 1 its taps 0-4 to half 0 (16-byte LDS accesses, [quad][tap][i / 4][lane]); each adds what
+    // it received to its own and stores those taps: all eight waves share the slab stores.  (half 0) + (half 1) either way round: the
+    // sum is the same bit pattern, whichever wave forms it.
+    f32x4v* const xch = reinterpret_cast<f32x4v*>(smem);
+    const int give0 = half == 0 ? 5 : 0, give1 = half == 0 ? 9 : 5;          // taps handed over
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t)
+        if (t >= give0 && t < give1) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) xch[((quad * 9 + t) * 16 + i) * 64 + lane] = acc[t][i];
-    }
+            for (int g = 0; g < 4; ++g)
+                xch[((quad * 9 + t) * 4 + g) * 64 + lane] = f32x4v{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+        }
     __syncthreads();
-    if (half == 1) return;
     float* out = slab + (size_t)split * Cout * 9 * Cin;
     const int ci = cib * 64 + wci * 32 + (lane & 31);
 #pragma unroll
     for (int t = 0; t < 9; ++t)
+        if (!(t >= give0 && t < give1)) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int co = cob * 64 + wco * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            const float v = acc[t][i] + xch[((quad * 9 + t) * 16 + i) * 64 + lane];
-            if (co < Cout && ci < Cin) out[((size_t)co * 9 + t) * Cin + ci] = v;
+            for (int g = 0; g < 4; ++g) {
+                const f32x4v o = xch[((quad * 9 + t) * 4 + g) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * g + j;
+                    const int co = cob * 64 + wco * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    const float v = acc[t][i] + o[j];
+                    if (co < Cout && ci < Cin) out[((size_t)co * 9 + t) * Cin + ci] = v;
+                }
+            }
         }
+    if (DBG && blockIdx.x == 0 && wave == 0 && lane == 0) {          // whole kernel: shader cycles and the 100 MHz clock
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* o = dbgp + 23 * 4;
+        o[0] = k0; o[1] = __builtin_amdgcn_s_memtime(); o[2] = r0; o[3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 __global__ void k_wgrad_reduce_bf16s(const float* __restrict__ slab, float* __restrict__ dw, int splits, size_t n) {
@@ -1178,6 +1334,7 @@ extern "C" int cvk_conv3x3_wgrad_bf16s(const void* x, const void* dy, float* dw,
     CVK_CHECK_ARG((long)(10 * (long)W + 40) * (ldx > ld_dy ? ldx : ld_dy) * 2 < (1L << 31), "cvk_conv3x3_wgrad_bf16s: ten image rows exceed 2 GiB");
     CVK_CHECK_ARG(10L * W + 40 < (1L << 24) && 2L * ldx < (1L << 24) && 2L * ld_dy < (1L << 24), "cvk_conv3x3_wgrad_bf16s: W or a pixel pitch exceeds 2^24");
     CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(dy) && cvk_aligned16(workspace), "cvk_conv3x3_wgrad_bf16s: pointers must be 16-byte aligned");
+    CVK_CHECK_ARG(((long)N * H + 16) * ((long)W + 64) < (1L << 31), "cvk_conv3x3_wgrad_bf16s: more than 2^31 pixels");
     const WgPlan p = plan_wgrad_bf16s(N, H, W, Cin, Cout);
     const size_t n = (size_t)Cout * 9 * Cin;
     const size_t need = (size_t)p.splits * n * sizeof(float);
@@ -1189,10 +1346,33 @@ extern "C" int cvk_conv3x3_wgrad_bf16s(const void* x, const void* dy, float* dw,
     const int nblk = p.nblk_co * p.nblk_ci;
     static const int dbg = getenv("CVK_WGRAD_DBG") ? atoi(getenv("CVK_WGRAD_DBG")) : 0;      // timing experiments only
     static const int rowst = getenv("CVK_WGRAD_ROW") ? atoi(getenv("CVK_WGRAD_ROW")) : 1;
+    static const int wprio = getenv("CVK_WGRAD_PRIO") ? atoi(getenv("CVK_WGRAD_PRIO")) : 1;
+#define CVK_WGR_LAUNCH(D_, P_) hipLaunchKernelGGL((k_wgrad_bf16r<D_, P_>), dim3(nblk * p.splits), dim3(512), 0, s, (const __bf16*)x, (const __bf16*)dy, (float*)workspace, \
+                           H, W, ldx, ld_dy, Cout, Cin, cvk_cdiv(W, TW), cvk_cdiv(H, TH), p.ntiles, p.tps, p.nblk_ci, nblk)
+    if (rowst && dbg >= 16) {
+        // timing experiments (tools/tile_stamps_wgrad.py): 16 = stamps, + 2 no fragment reads, + 4 no DMA, + 8 DMA of zeros, + 32 DMA
+        // instruction dropped, + 64 per-row stamps, + 128 alternating wave priority.  No reduction: the slabs hold wrong numbers.
+        switch (dbg) {
+            case 16: CVK_WGR_LAUNCH(1, false); break;
+            case 18: CVK_WGR_LAUNCH(3, false); break;
+            case 20: CVK_WGR_LAUNCH(5, false); break;
+            case 22: CVK_WGR_LAUNCH(7, false); break;
+            case 24: CVK_WGR_LAUNCH(9, false); break;
+            case 48: CVK_WGR_LAUNCH(33, false); break;
+            case 80: CVK_WGR_LAUNCH(65, false); break;
+            case 82: CVK_WGR_LAUNCH(67, false); break;
+            case 84: CVK_WGR_LAUNCH(69, false); break;
+            case 86: CVK_WGR_LAUNCH(71, false); break;
+            case 144: CVK_WGR_LAUNCH(1, true); break;
+            case 208: CVK_WGR_LAUNCH(65, true); break;
+            default: cvk_set_error("cvk_conv3x3_wgrad_bf16s: unknown CVK_WGRAD_DBG %d", dbg); return CVK_EINVAL;
+        }
+        return CVK_OK;
+    }
     if (rowst && dbg == 0) {
-        hipLaunchKernelGGL(k_wgrad_bf16r, dim3(nblk * p.splits), dim3(512), 0, s, (const __bf16*)x, (const __bf16*)dy, (float*)workspace, H, W,
-                           ldx, ld_dy, Cout, Cin, cvk_cdiv(W, TW), cvk_cdiv(H, TH), p.ntiles, p.tps, p.nblk_ci, nblk);
+        if (wprio) CVK_WGR_LAUNCH(0, true); else CVK_WGR_LAUNCH(0, false);
     } else
+#undef CVK_WGR_LAUNCH_UNUSED
 #define CVK_WG_LAUNCH(D_) hipLaunchKernelGGL((k_wgrad_bf16s<D_>), dim3(nblk * p.splits), dim3(512), 0, s, (const __bf16*)x, (const __bf16*)dy, (float*)workspace, H, W, \
                            ldx, ld_dy, Cout, Cin, cvk_cdiv(W, TW), cvk_cdiv(H, TH), p.ntiles, p.tps, p.nblk_ci, nblk)
     if (dbg == 1) CVK_WG_LAUNCH(1);
