@@ -400,6 +400,12 @@ int cvk_bn_bwd_dx_bf16(cvk_viewh dout, int dout_f32, const void* y, int ldy, con
 /* MaxPool2d(2,2) backward: dout dense bf16 [N,H/2,W/2,C]; x = the pooled layer's stored input (view); dx (view) is
  * written, or added to when accumulate != 0 */
 int cvk_maxpool2x2_bwd_bf16(const void* dout, cvk_viewh x, cvk_viewh dx, int accumulate, int N, int H, int W, int C, void* stream);
+/* MaxUnpool2d(2) of bf16 plans (reference models/segnet.py:80,104-116: self.unpool(x, idx, output_size)).  No index tensor is kept:
+ * the arg-max of every 2x2 cell is recomputed from x, the stored input of the pooling layer ([N,H,W,C] view; first maximum in scan
+ * order, NaN wins — ATen's rule, as cvk_maxpool2x2_bwd_bf16).  FORWARD is cvk_maxpool2x2_bwd_bf16(v, x, out, 0, ...): the pooled
+ * values v [N,H/2,W/2,C] scattered to their arg-max pixels, every other pixel 0.  BACKWARD (this entry) gathers:
+ * dv[n,yc,xc,c] = dout[n, arg-max pixel of cell (yc,xc), c]; dout dense [N,H,W,C], dv dense [N,H/2,W/2,C].  C % 8 == 0. */
+int cvk_maxunpool2x2_bwd_bf16(const void* dout, cvk_viewh x, void* dv, int N, int H, int W, int C, void* stream);
 int cvk_bilinear_up2_fwd_bf16(const void* x, void* out, int N, int H, int W, int C, void* stream);
 int cvk_bilinear_up2_bwd_bf16(const void* dout, void* dx, int N, int H, int W, int C, void* stream);
 int cvk_zero_frame_bf16(cvk_viewh buf, int N, int H, int W, int C, int y0, int x0, int h, int w, void* stream);

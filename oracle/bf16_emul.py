@@ -1,8 +1,8 @@
 """ORACLE — TEST INFRASTRUCTURE ONLY.  Never imported by the product path.
 
 CPU emulation of WHERE the bf16-storage mode (set_conv_precision(net, "bf16"); csrc/conv_bf16s.hip, csrc/elem_bf16.hip)
-rounds, on top of the stock-torch rebuild of the reference graph (oracle/torch_ref.py; reference models/unet.py:5-32,
-94-156).  Arithmetic is fp32 as on the device (bf16 x bf16 products are exact in fp32, accumulation is fp32); every
+rounds, on top of the stock-torch rebuild of the reference graphs (oracle/torch_ref.py; reference models/unet.py:5-32,
+94-156 and models/segnet.py:5-119).  Arithmetic is fp32 as on the device (bf16 x bf16 products are exact in fp32, accumulation is fp32); every
 tensor the device keeps in HBM as bf16 is rounded to bf16 (round-to-nearest-even) at the point it is stored:
   forward : the imported input, conv weights (a bf16 copy of the fp32 masters), the pre-BN conv output y, the BN+ReLU
             activation a, the bilinear-upsampled tensor; pooled tensors are maxima of rounded values (exact);
@@ -76,15 +76,36 @@ def unet_forward(net, x):
     return _cbr(net.output.conv[0], net.output.conv[1], x, last=True)
 
 
+def segnet_forward(net, x):
+    """oracle.torch_ref.RefSegNet.forward with the device's rounding points (reference models/segnet.py:84-119).  Pooling and
+    unpooling move bf16 values without arithmetic (exact); the arg-max is taken on the stored (rounded) activations, as the
+    device recomputes it from them.  The gradient entering an unpooled tensor is a conv data-grad, stored as bf16: rounded."""
+    x = _r(x)
+    marks = []
+    for k in range(1, 6):
+        for blk in getattr(net, f"encoder{k}"):
+            x = _cbr(blk.conv, blk.bn, x)
+        shape = x.shape
+        x, idx = F.max_pool2d(x, 2, return_indices=True)
+        marks.append((idx, shape))
+    for k in range(5, 0, -1):
+        idx, shape = marks[k - 1]
+        x = _RoundBoth.apply(F.max_unpool2d(x, idx, 2, output_size=shape))
+        seq = getattr(net, f"decoder{k}")
+        for i, blk in enumerate(seq):
+            x = _cbr(blk.conv, blk.bn, x, last=(k == 1 and i == len(seq) - 1))
+    return x
+
+
 def basic_conv(block, x, last=False):
     """One conv+BN+ReLU block (oracle.torch_ref._CBR) in the emulation; x is rounded on entry like an imported input."""
     return _cbr(block.conv[0], block.conv[1], _r(x), last)
 
 
-def fwd_bwd_step(net, x, t):
+def fwd_bwd_step(net, x, t, model="unet"):
     for p in net.parameters():
         p.grad = None
-    out = unet_forward(net, x)
+    out = unet_forward(net, x) if model == "unet" else segnet_forward(net, x)
     loss = F.cross_entropy(out, t)
     loss.backward()
     return loss, out

@@ -319,6 +319,40 @@ __global__ void k_pool_bwd_bf16(const __bf16* __restrict__ dout, const __bf16* _
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ max unpool backward
+// MaxUnpool2d(2) backward = a gather at the pool's arg-max: dv[cell] = dout[arg-max pixel of the cell].  The arg-max is recomputed from
+// the pooled layer's stored input x exactly as in k_pool_bwd_bf16 (bf16 plans keep no index tensor: the forward unpool is that kernel
+// with accumulate = 0 — a scatter of the pooled values).  Cells = floor(H/2) x floor(W/2).
+template <int V>
+__global__ void k_unpool_bwd_bf16(const __bf16* __restrict__ dout, const __bf16* __restrict__ x, PixMapH xm, __bf16* __restrict__ dv,
+                                  int N, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2, cvn = C / V;
+    const long total = (long)N * Ho * Wo * cvn;
+    CVK_GRID_STRIDE(i, total) {
+        const int cv = (int)(i % cvn);
+        long t = i / cvn;
+        const int xc = (int)(t % Wo);
+        t /= Wo;
+        const int yc = (int)(t % Ho), n = (int)(t / Ho);
+        const int c = cv * V;
+        FV<V> best, g[4], o;
+        int cd[V];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = (n * H + 2 * yc + (k >> 1)) * W + 2 * xc + (k & 1);
+            const FV<V> v = load_bf16<V>(x + xm.off(m) + c);
+            g[k] = load_bf16<V>(dout + (size_t)m * C + c);
+#pragma unroll
+            for (int j = 0; j < V; ++j)
+                if (k == 0 || v.v[j] > best.v[j] || v.v[j] != v.v[j]) { best.v[j] = v.v[j]; cd[j] = k; }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) o.v[j] = cd[j] == 0 ? g[0].v[j] : (cd[j] == 1 ? g[1].v[j] : (cd[j] == 2 ? g[2].v[j] : g[3].v[j]));
+        store_bf16<V>(dv + (((size_t)n * Ho + yc) * Wo + xc) * C + c, o);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ bilinear x2
 struct Tap { int i0, i1; float l0, l1; };
 __device__ __forceinline__ Tap make_tap(int dst, float scale, int n_in) {   // ATen align_corners source index (pointwise.hip)
@@ -553,6 +587,16 @@ extern "C" int cvk_maxpool2x2_bwd_bf16(const void* dout, cvk_viewh x, cvk_viewh 
     hipLaunchKernelGGL(k_pool_bwd_bf16<8>, dim3(grid_for(cells * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dout,
                        (const __bf16*)x.ptr, make_map(x, H, W), (__bf16*)dx.ptr, make_map(dx, H, W), accumulate, N, H, W, C);
     CVK_LAUNCH_RETURN("cvk_maxpool2x2_bwd_bf16");
+}
+
+extern "C" int cvk_maxunpool2x2_bwd_bf16(const void* dout, cvk_viewh x, void* dv, int N, int H, int W, int C, void* stream) {
+    CVK_CHECK_ARG(dout && x.ptr && dv && N > 0 && H >= 2 && W >= 2 && C > 0 && C % 8 == 0, "cvk_maxunpool2x2_bwd_bf16: bad arguments (C % 8)");
+    CVK_CHECK_ARG(cvk_aligned16(dout) && cvk_aligned16(dv) && viewok(x, 8, false), "cvk_maxunpool2x2_bwd_bf16: misaligned pointer or view");
+    CVK_CHECK_ARG((long)N * H * W < (1L << 31), "cvk_maxunpool2x2_bwd_bf16: more than 2^31 pixels");
+    const long cells = (long)N * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(k_unpool_bwd_bf16<8>, dim3(grid_for(cells * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dout,
+                       (const __bf16*)x.ptr, make_map(x, H, W), (__bf16*)dv, N, H, W, C);
+    CVK_LAUNCH_RETURN("cvk_maxunpool2x2_bwd_bf16");
 }
 
 static inline float ac_scale(int n_in, int n_out) { return n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f; }

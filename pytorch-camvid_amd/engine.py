@@ -890,12 +890,20 @@ class Unpool(Op):
         self.src, self.pool, self.dst = src_buf, pool_op, dst_buf
 
     def fwd(self, R, st):
-        if st.plan.bf16:
-            raise NotImplementedError("bf16 mode covers the UNet operator set (BASELINE.json configs[3]); SegNet's unpooling runs in fp32 mode")
         V = st.act[self.src.id]
-        code = st.saved[self.pool.idx]
         d = self.dst
         out = R.alloc_act(st, d, V.device)
+        if st.plan.bf16:
+            # bf16 plans keep no index tensor: the arg-max is recomputed from the pooling layer's stored input, and the forward unpool
+            # is the pool's backward kernel without accumulation (a scatter of the pooled values; every other pixel 0)
+            pv = self.pool.src
+            X = st.act[pv.buf.id]
+            assert d.ld == d.C and self.src.ld == d.C, "bf16 unpool: dense tensors (C % 8 == 0, C >= 32)"
+            _timed(R, "k_unpool_fwd_bf16", (2.0 * 0.25 + 2.0 + 2.0) * d.M * d.ld, lambda: check(
+                R.lib.cvk_maxpool2x2_bwd_bf16(V.data_ptr(), pv.hview(X), d.full_view().hview(out), 0, d.N, d.H, d.W, d.C, st.stream),
+                "cvk_maxpool2x2_bwd_bf16(unpool)"), "byte")
+            return
+        code = st.saved[self.pool.idx]
         _timed(R, "k_unpool_fwd", 5.25 * d.M * d.ld, lambda: check(        # reads pooled values + 1-byte codes, writes the full frame
             R.lib.cvk_maxunpool2x2_fwd(V.data_ptr(), code.data_ptr(), out.data_ptr(), d.N, d.H, d.W, d.ld, st.stream),
             "cvk_maxunpool2x2_fwd"), "byte")
@@ -903,8 +911,17 @@ class Unpool(Op):
     def bwd(self, R, st):
         d = self.dst
         g = st.grad.pop(d.id)
-        code = st.saved[self.pool.idx]
         dv = torch.empty_like(st.act[self.src.id])
+        if st.plan.bf16:
+            pv = self.pool.src
+            X = st.act[pv.buf.id]
+            _timed(R, "k_unpool_bwd_bf16", (2.0 + 2.0 + 2.0 * 0.25) * d.M * d.ld, lambda: check(
+                R.lib.cvk_maxunpool2x2_bwd_bf16(g.data_ptr(), pv.hview(X), dv.data_ptr(), d.N, d.H, d.W, d.C, st.stream),
+                "cvk_maxunpool2x2_bwd_bf16"), "byte")
+            assert self.src.id not in st.grad
+            st.grad[self.src.id] = dv
+            return
+        code = st.saved[self.pool.idx]
         _timed(R, "k_unpool_bwd", 5.25 * d.M * d.ld, lambda: check(
             R.lib.cvk_maxunpool2x2_bwd(g.data_ptr(), code.data_ptr(), dv.data_ptr(), d.N, d.H, d.W, d.ld, st.stream),
             "cvk_maxunpool2x2_bwd"), "byte")
@@ -1017,7 +1034,7 @@ class Plan:
         self._reads(src_view.buf)
         op = self.add(MaxPool(src_view, dst, keep_code))
         prod = self._producer.get((src_view.buf.id, src_view.c0))
-        if (not keep_code or not self.bf16) and prod is not None and prod.dst.C == src_view.C and prod.pool_dst is None \
+        if prod is not None and prod.dst.C == src_view.C and prod.pool_dst is None \
                 and prod.dst.H == src_view.H and prod.dst.W == src_view.W and prod.dst.y0 == src_view.y0 and prod.dst.x0 == src_view.x0:
             prod.pool_dst = dst         # the block's BN-apply pass writes the pooled tensor too (csrc/elem_bf16.hip, csrc/bn.hip)
             prod.pool_op = op
@@ -1194,8 +1211,6 @@ class Runner:
         inb = plan.input
         xp = x.permute(0, 2, 3, 1)
         if plan.bf16:
-            if plan.input_needs_grad:
-                raise NotImplementedError("bf16 mode does not return a gradient for the network input")
             t = torch.empty((inb.N, inb.H, inb.W, inb.ld), device=dev, dtype=_BF16)
             sN, sC, sH, sW = x.stride()
             check(self.lib.cvk_import_nchw_bf16(x.data_ptr(), sN, sC, sH, sW, t.data_ptr(), inb.ld, inb.N, inb.C, inb.H, inb.W,
@@ -1251,6 +1266,8 @@ class Runner:
         if plan.input_needs_grad:
             gi = st.grad[plan.input.id]
             dx = gi[..., :plan.input.C].permute(0, 3, 1, 2)
+            if plan.bf16:                   # the stem's data-grad is stored as bf16 like every other dX; x.grad is fp32 like x
+                dx = dx.float()
         grads = []
         for i, p in enumerate(params):
             n = p.numel()

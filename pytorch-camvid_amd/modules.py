@@ -275,7 +275,7 @@ def _run_traced(root, x):
 
 def set_conv_precision(module, precision):
     """"fp32" (default): exact-fp32 MFMA convolutions (Winograd where eligible), fp32 tensors everywhere.
-    "bf16" (BASELINE.json configs[3], UNet operator set): activations and activation gradients are stored in HBM as
+    "bf16" (BASELINE.json configs[3]; UNet and SegNet, with or without a gradient for the input): activations and activation gradients are stored in HBM as
     bf16 NHWC, convolutions (forward, data-grad, weight-grad) multiply bf16 x bf16 on the matrix cores with fp32
     accumulation, BatchNorm statistics come from the fp32 accumulators; parameters, parameter gradients, BatchNorm
     parameters/buffers, logits and the loss stay fp32, so optimizers and checkpoints are unchanged.  Expect relative
