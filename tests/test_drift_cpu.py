@@ -89,6 +89,31 @@ def test_bf16_emulation_rounding_points():
         E._r = saved
 
 
+def test_bf16_emulation_segnet_and_input_gradient():
+    """The round-4 additions to oracle/bf16_emul.py: segnet_forward is RefSegNet.forward when the rounding is switched off, its logits
+    stay fp32, and the input's gradient flows through the rounded import (rounded to bf16 like the device's stored dX)."""
+    from oracle import torch_ref as R, bf16_emul as E
+    x, t = R.synthetic_batch(1, 32, 64, 3)
+    torch.manual_seed(0)
+    net = R.build("segnet", 3, 12).train()
+    xg = x.clone().requires_grad_(True)
+    out = E.segnet_forward(net, xg)
+    assert out.shape == (1, 12, 32, 64) and not torch.equal(out, E._r(out))
+    torch.nn.functional.cross_entropy(out, t).backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all() and torch.equal(xg.grad, E._r(xg.grad))
+    saved = E._r
+    try:
+        E._r = lambda v: v
+        torch.manual_seed(0)
+        n2 = R.build("segnet", 3, 12).train()
+        o2 = E.segnet_forward(n2, x)
+        torch.manual_seed(0)
+        n3 = R.build("segnet", 3, 12).train()
+        assert torch.allclose(o2, n3(x), rtol=1e-5, atol=1e-6)
+    finally:
+        E._r = saved
+
+
 def test_winograd2d_rounding():
     """Derives the tolerance of the 2-D Winograd F(4x4,3x3) path (csrc/wino2d.hip): a numpy fp32 restatement of exactly its
     transforms (points 0, +-1, +-2, inf; V = B^T d B, U = G g G^T, y = A^T M A) against an fp64 direct convolution at the
