@@ -381,6 +381,18 @@ int cvk_bn_finalize_counts(const float* stats, const float* counts, int P, int M
 size_t cvk_conv3x3_wgrad_bf16s_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int cvk_conv3x3_wgrad_bf16s(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int ldx, int Cout,
                             int ld_dy, void* workspace, size_t workspace_bytes, void* stream);
+/* The same in two steps, so that a backward pass can sum the partial results of ALL its layers in one launch at its end (the weight
+ * gradients are read by nobody before the optimizer step / the all-reduce of their bucket: loss.backward() of train.py:131).
+ * _slabs: the partial sums only — S = cvk_conv3x3_wgrad_bf16s_splits(...) slabs of Cout*9*Cin floats at `slabs`
+ * (cvk_conv3x3_wgrad_bf16s_workspace_bytes of room); with S == 1 the one slab IS dw and may be written in place.
+ * _reduce_batch: dw = slab 0 + slab 1 + ... (the order cvk_conv3x3_wgrad_bf16s uses: bitwise the same) for n <= CVK_WREDUCE_BATCH_MAX
+ * layers; `jobs` is a HOST array (copied into the kernel arguments). */
+int cvk_conv3x3_wgrad_bf16s_splits(int N, int H, int W, int Cin, int Cout);
+int cvk_conv3x3_wgrad_bf16s_slabs(const void* x, const void* dy, float* slabs, int N, int H, int W, int Cin, int ldx, int Cout,
+                                  int ld_dy, size_t slab_bytes, void* stream);
+#define CVK_WREDUCE_BATCH_MAX 48
+typedef struct cvk_wreduce_job { const float* slabs; float* dw; unsigned long long n; int splits, pad; } cvk_wreduce_job;
+int cvk_wgrad_reduce_bf16s_batch(const cvk_wreduce_job* jobs, int n, void* stream);
 /* logical NCHW fp32 (any strides) -> dense bf16 NHWC with ld % 8 == 0, pad channels zero */
 int cvk_import_nchw_bf16(const float* src, int64_t sN, int64_t sC, int64_t sH, int64_t sW, void* dst, int ld,
                          int N, int C, int H, int W, void* stream);

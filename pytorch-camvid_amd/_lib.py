@@ -147,6 +147,9 @@ SIGNATURES = {
                                        c_float, c_float, c_vp, c_size, c_vp]),
     "cvk_conv3x3_wgrad_bf16s_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
     "cvk_conv3x3_wgrad_bf16s": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
+    "cvk_conv3x3_wgrad_bf16s_splits": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "cvk_conv3x3_wgrad_bf16s_slabs": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_size, c_vp]),
+    "cvk_wgrad_reduce_bf16s_batch": (c_int, [c_vp, c_int, c_vp]),
     "cvk_import_nchw_bf16": (c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_bn_relu_apply_bf16": (c_int, [c_vp, c_int, c_vp, c_vp, ViewH, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_bn_bwd_blocks_bf16": (c_int, [c_int]),
@@ -174,8 +177,13 @@ class ColsumJob(ctypes.Structure):      # include/cvk.h cvk_colsum_job
     _fields_ = [("part", ctypes.c_void_p), ("out", ctypes.c_void_p), ("PB", ctypes.c_int), ("C", ctypes.c_int)]
 
 
+class WReduceJob(ctypes.Structure):     # include/cvk.h cvk_wreduce_job
+    _fields_ = [("slabs", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("n", ctypes.c_ulonglong), ("splits", ctypes.c_int), ("pad", ctypes.c_int)]
+
+
 PACK_BATCH_MAX = 48
 COLSUM_BATCH_MAX = 64
+WREDUCE_BATCH_MAX = 48
 
 
 class CvkError(RuntimeError):

@@ -1325,23 +1325,9 @@ extern "C" size_t cvk_conv3x3_wgrad_bf16s_workspace_bytes(int N, int H, int W, i
     return (size_t)p.splits * Cout * 9 * Cin * sizeof(float);
 }
 
-// x: bf16 [N,H,W,ldx] (channels Cin..ldx-1 are never read as valid), dy: bf16 [N,H,W,ld_dy]; dw: fp32 [Cout][9][Cin]
-extern "C" int cvk_conv3x3_wgrad_bf16s(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int ldx, int Cout,
-                                       int ld_dy, void* workspace, size_t workspace_bytes, void* stream) {
-    CVK_CHECK_ARG(x && dy && dw && workspace, "cvk_conv3x3_wgrad_bf16s: null pointer");
-    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ldx >= Cin && ld_dy >= Cout, "cvk_conv3x3_wgrad_bf16s: bad shape");
-    CVK_CHECK_ARG(ldx % 8 == 0 && ld_dy % 8 == 0, "cvk_conv3x3_wgrad_bf16s: ldx and ld_dy must be multiples of 8");
-    CVK_CHECK_ARG((long)(10 * (long)W + 40) * (ldx > ld_dy ? ldx : ld_dy) * 2 < (1L << 31), "cvk_conv3x3_wgrad_bf16s: ten image rows exceed 2 GiB");
-    CVK_CHECK_ARG(10L * W + 40 < (1L << 24) && 2L * ldx < (1L << 24) && 2L * ld_dy < (1L << 24), "cvk_conv3x3_wgrad_bf16s: W or a pixel pitch exceeds 2^24");
-    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(dy) && cvk_aligned16(workspace), "cvk_conv3x3_wgrad_bf16s: pointers must be 16-byte aligned");
-    CVK_CHECK_ARG(((long)N * H + 16) * ((long)W + 64) < (1L << 31), "cvk_conv3x3_wgrad_bf16s: more than 2^31 pixels");
-    const WgPlan p = plan_wgrad_bf16s(N, H, W, Cin, Cout);
-    const size_t n = (size_t)Cout * 9 * Cin;
-    const size_t need = (size_t)p.splits * n * sizeof(float);
-    if (workspace_bytes < need) {
-        cvk_set_error("cvk_conv3x3_wgrad_bf16s: workspace %zu < %zu bytes", workspace_bytes, need);
-        return CVK_EWORKSPACE;
-    }
+// the partial slabs of one layer: `workspace` = p.splits slabs (checked by the callers)
+static int wgrad_bf16s_launch_slabs(const void* x, const void* dy, void* workspace, int N, int H, int W, int Cin, int ldx, int Cout, int ld_dy,
+                                    const WgPlan& p, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int nblk = p.nblk_co * p.nblk_ci;
     static const int dbg = getenv("CVK_WGRAD_DBG") ? atoi(getenv("CVK_WGRAD_DBG")) : 0;      // timing experiments only
@@ -1367,7 +1353,7 @@ extern "C" int cvk_conv3x3_wgrad_bf16s(const void* x, const void* dy, float* dw,
             case 208: CVK_WGR_LAUNCH(65, true); break;
             default: cvk_set_error("cvk_conv3x3_wgrad_bf16s: unknown CVK_WGRAD_DBG %d", dbg); return CVK_EINVAL;
         }
-        return CVK_OK;
+        return 1;          // timing experiment: no reduction, the slabs hold wrong numbers
     }
     if (rowst && dbg == 0) {
         if (wprio) CVK_WGR_LAUNCH(0, true); else CVK_WGR_LAUNCH(0, false);
@@ -1387,7 +1373,89 @@ extern "C" int cvk_conv3x3_wgrad_bf16s(const void* x, const void* dy, float* dw,
         cvk_set_error("cvk_conv3x3_wgrad_bf16s: launch failed: %s", hipGetErrorString(e));
         return (int)e;
     }
+    return CVK_OK;
+}
+
+static int wgrad_bf16s_check(const char* who, const void* x, const void* dy, const void* out, const void* workspace, int N, int H, int W, int Cin,
+                             int ldx, int Cout, int ld_dy) {
+    CVK_CHECK_ARG(x && dy && out && workspace, "%s: null pointer", who);
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ldx >= Cin && ld_dy >= Cout, "%s: bad shape", who);
+    CVK_CHECK_ARG(ldx % 8 == 0 && ld_dy % 8 == 0, "%s: ldx and ld_dy must be multiples of 8", who);
+    CVK_CHECK_ARG((long)(10 * (long)W + 40) * (ldx > ld_dy ? ldx : ld_dy) * 2 < (1L << 31), "%s: ten image rows exceed 2 GiB", who);
+    CVK_CHECK_ARG(10L * W + 40 < (1L << 24) && 2L * ldx < (1L << 24) && 2L * ld_dy < (1L << 24), "%s: W or a pixel pitch exceeds 2^24", who);
+    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(dy) && cvk_aligned16(workspace), "%s: pointers must be 16-byte aligned", who);
+    CVK_CHECK_ARG(((long)N * H + 16) * ((long)W + 64) < (1L << 31), "%s: more than 2^31 pixels", who);
+    return CVK_OK;
+}
+
+extern "C" int cvk_conv3x3_wgrad_bf16s_splits(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    return plan_wgrad_bf16s(N, H, W, Cin, Cout).splits;
+}
+
+extern "C" int cvk_conv3x3_wgrad_bf16s_slabs(const void* x, const void* dy, float* slabs, int N, int H, int W, int Cin, int ldx, int Cout,
+                                             int ld_dy, size_t slab_bytes, void* stream) {
+    const int rc = wgrad_bf16s_check("cvk_conv3x3_wgrad_bf16s_slabs", x, dy, slabs, slabs, N, H, W, Cin, ldx, Cout, ld_dy);
+    if (rc != CVK_OK) return rc;
+    const WgPlan p = plan_wgrad_bf16s(N, H, W, Cin, Cout);
+    const size_t need = (size_t)p.splits * Cout * 9 * Cin * sizeof(float);
+    if (slab_bytes < need) {
+        cvk_set_error("cvk_conv3x3_wgrad_bf16s_slabs: %zu bytes for %d slabs, need %zu", slab_bytes, p.splits, need);
+        return CVK_EWORKSPACE;
+    }
+    const int rl = wgrad_bf16s_launch_slabs(x, dy, slabs, N, H, W, Cin, ldx, Cout, ld_dy, p, stream);
+    return rl == 1 ? CVK_OK : rl;
+}
+
+// x: bf16 [N,H,W,ldx] (channels Cin..ldx-1 are never read as valid), dy: bf16 [N,H,W,ld_dy]; dw: fp32 [Cout][9][Cin]
+extern "C" int cvk_conv3x3_wgrad_bf16s(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int ldx, int Cout,
+                                       int ld_dy, void* workspace, size_t workspace_bytes, void* stream) {
+    const int rc = wgrad_bf16s_check("cvk_conv3x3_wgrad_bf16s", x, dy, dw, workspace, N, H, W, Cin, ldx, Cout, ld_dy);
+    if (rc != CVK_OK) return rc;
+    const WgPlan p = plan_wgrad_bf16s(N, H, W, Cin, Cout);
+    const size_t n = (size_t)Cout * 9 * Cin;
+    const size_t need = (size_t)p.splits * n * sizeof(float);
+    if (workspace_bytes < need) {
+        cvk_set_error("cvk_conv3x3_wgrad_bf16s: workspace %zu < %zu bytes", workspace_bytes, need);
+        return CVK_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int rl = wgrad_bf16s_launch_slabs(x, dy, workspace, N, H, W, Cin, ldx, Cout, ld_dy, p, stream);
+    if (rl != CVK_OK) return rl == 1 ? CVK_OK : rl;
     const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
     hipLaunchKernelGGL(k_wgrad_reduce_bf16s, dim3(blocks), dim3(256), 0, s, (const float*)workspace, dw, p.splits, n);
     CVK_LAUNCH_RETURN("cvk_conv3x3_wgrad_bf16s");
+}
+
+struct WReduceJobsDev { cvk_wreduce_job j[CVK_WREDUCE_BATCH_MAX]; };
+__global__ void k_wgrad_reduce_bf16s_batch(const WReduceJobsDev jobs) {
+    const cvk_wreduce_job& J = jobs.j[blockIdx.y];
+    const float* __restrict__ slab = J.slabs;
+    const size_t n = J.n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // exactly k_wgrad_reduce_bf16s's order
+        int s = 0;
+        for (; s + 4 <= J.splits; s += 4) {
+            s0 += slab[(size_t)(s + 0) * n + i];
+            s1 += slab[(size_t)(s + 1) * n + i];
+            s2 += slab[(size_t)(s + 2) * n + i];
+            s3 += slab[(size_t)(s + 3) * n + i];
+        }
+        for (; s < J.splits; ++s) s0 += slab[(size_t)s * n + i];
+        J.dw[i] = (s0 + s1) + (s2 + s3);
+    }
+}
+
+extern "C" int cvk_wgrad_reduce_bf16s_batch(const cvk_wreduce_job* jobs, int n, void* stream) {
+    CVK_CHECK_ARG(jobs && n > 0 && n <= CVK_WREDUCE_BATCH_MAX, "cvk_wgrad_reduce_bf16s_batch: 1..%d jobs", CVK_WREDUCE_BATCH_MAX);
+    WReduceJobsDev d;
+    unsigned long long most = 0;
+    for (int i = 0; i < n; ++i) {
+        CVK_CHECK_ARG(jobs[i].slabs && jobs[i].dw && jobs[i].n > 0 && jobs[i].splits > 0, "cvk_wgrad_reduce_bf16s_batch: bad job %d", i);
+        d.j[i] = jobs[i];
+        if (jobs[i].n > most) most = jobs[i].n;
+    }
+    const int bx = (int)((most + 255) / 256 < 4096 ? (most + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_wgrad_reduce_bf16s_batch, dim3(bx, n), dim3(256), 0, (hipStream_t)stream, d);
+    CVK_LAUNCH_RETURN("cvk_wgrad_reduce_bf16s_batch");
 }

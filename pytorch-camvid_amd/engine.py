@@ -91,6 +91,7 @@ class RunState:
         self.sync = None   # optional gradient synchroniser (ddp.GradSync)
         self.pooled_by_block = {}   # op index of a conv block -> True when its BN-apply pass also wrote the max pool behind it
         self.colsums = []           # queued column-sum finalisations (Runner.defer_colsum)
+        self.wreduces = []          # queued weight-gradient slab reductions of the bf16 path (Runner.defer_wreduce)
         self.pass_token = 0         # derived-weight cache token of this pass (Runner.forward)
         self.bnred = {}             # op index of a conv block -> (partials, count): its BN-backward sums, left by the consumer's data-grad
 
@@ -820,11 +821,16 @@ class ConvBnRelu(Op):
                 lib.cvk_conv3x3_bf16s_wg(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, None, N, H, W, ld_dy, self.cin, src.ld,
                                          R.persistent_wgs(), s), "cvk_conv3x3_bf16s(dgrad)"))
             st.grad[src.id] = dX
-        wsb = lib.cvk_conv3x3_wgrad_bf16s_workspace_bytes(N, H, W, self.cin, C)
-        ws = R.workspace(wsb, dev)
+        # partial slabs now, the sum over the slabs with every other layer's in ONE launch (Runner.flush_wreduces): nobody reads a weight
+        # gradient before the end of backward (or the all-reduce of its bucket); 23 reductions of ~11 us were 0.26 ms of a 21 ms step
+        S = lib.cvk_conv3x3_wgrad_bf16s_splits(N, H, W, self.cin, C)
+        n = C * 9 * self.cin
+        slab = None if S == 1 else _empty(S * n, dev)           # one slab: it is the gradient itself, written in place
         _timed(R, "k_wgrad_bf16s", flops, lambda: check(
-            lib.cvk_conv3x3_wgrad_bf16s(X.data_ptr(), dy.data_ptr(), gw, N, H, W, self.cin, src.ld, C, ld_dy, ws.data_ptr(), wsb, s),
-            "cvk_conv3x3_wgrad_bf16s"))
+            lib.cvk_conv3x3_wgrad_bf16s_slabs(X.data_ptr(), dy.data_ptr(), gw if slab is None else slab.data_ptr(), N, H, W, self.cin, src.ld, C,
+                                              ld_dy, 4 * S * n, s), "cvk_conv3x3_wgrad_bf16s_slabs"))
+        if slab is not None:
+            R.defer_wreduce(st, slab, S, n, gw)
         R.grads_ready(st, self.pslot)
 
 
@@ -1178,6 +1184,18 @@ class Runner:
         if len(st.colsums) >= _lib.COLSUM_BATCH_MAX:
             self.flush_colsums(st)
 
+    def defer_wreduce(self, st, slab, splits, n, dw_ptr):
+        st.wreduces.append((slab, splits, n, dw_ptr))
+        if len(st.wreduces) >= _lib.WREDUCE_BATCH_MAX:
+            self.flush_wreduces(st)
+
+    def flush_wreduces(self, st):
+        if not st.wreduces:
+            return
+        arr = (_lib.WReduceJob * len(st.wreduces))(*[_lib.WReduceJob(sl.data_ptr(), dw, n, sp, 0) for sl, sp, n, dw in st.wreduces])
+        check(self.lib.cvk_wgrad_reduce_bf16s_batch(ctypes.addressof(arr), len(st.wreduces), st.stream), "cvk_wgrad_reduce_bf16s_batch")
+        st.wreduces.clear()
+
     def flush_colsums(self, st):
         if not st.colsums:
             return
@@ -1187,7 +1205,8 @@ class Runner:
 
     def grads_ready(self, st, slot):
         if st.sync is not None:
-            self.flush_colsums(st)          # a bucket may be handed to the all-reduce: its bias gradients must be final
+            self.flush_colsums(st)          # a bucket may be handed to the all-reduce: its bias and weight gradients must be final
+            self.flush_wreduces(st)
             st.sync.layer_done(st, slot)
 
     # ---- forward / backward -------------------------------------------------------------------------------------
@@ -1262,6 +1281,7 @@ class Runner:
         for op in reversed(plan.ops):
             op.bwd(self, st)
         self.flush_colsums(st)
+        self.flush_wreduces(st)
         dx = None
         if plan.input_needs_grad:
             gi = st.grad[plan.input.id]

@@ -448,3 +448,41 @@ def test_batched_weight_pack_equals_the_single_packs():
     torch.cuda.synchronize()
     for i, (a, o) in enumerate(zip(want, outs)):
         assert torch.equal(a.view(torch.int16), o.view(torch.int16)), i
+
+
+@pytest.mark.parametrize("case", [(2, 40, 70, 64, 64), (1, 24, 33, 1024, 512), (1, 9, 17, 1024, 1024), (2, 19, 45, 32, 12)])
+def test_wgrad_slabs_plus_batched_reduction_equals_the_one_call_form(case):
+    """cvk_conv3x3_wgrad_bf16s_slabs + cvk_wgrad_reduce_bf16s_batch (what a backward pass does since round 4: one reduction launch for
+    all layers) against cvk_conv3x3_wgrad_bf16s: the same kernels and the same summation order, so bitwise; a layer whose plan has
+    one slab (splits == 1) is written straight into dw and needs no reduction."""
+    from pytorch_camvid_amd import _lib
+    from pytorch_camvid_amd._lib import check
+    import ctypes
+    lib = _lib.load()
+    N, H, W, Ci, Co = case
+    g = torch.Generator(device="cuda").manual_seed(sum(case))
+    ldx, ld_dy = max(32, Ci), max(32, (Co + 7) // 8 * 8)
+    x = torch.zeros(N, H, W, ldx, device=dev(), dtype=BF); x[..., :Ci] = torch.randn(N, H, W, Ci, device=dev(), generator=g).to(BF)
+    dy = torch.zeros(N, H, W, ld_dy, device=dev(), dtype=BF); dy[..., :Co] = torch.randn(N, H, W, Co, device=dev(), generator=g).to(BF)
+    wsb = lib.cvk_conv3x3_wgrad_bf16s_workspace_bytes(N, H, W, Ci, Co)
+    ws = torch.empty(wsb, device=dev(), dtype=torch.uint8)
+    want = torch.full((Co, 3, 3, Ci), float("nan"), device=dev())
+    check(lib.cvk_conv3x3_wgrad_bf16s(x.data_ptr(), dy.data_ptr(), want.data_ptr(), N, H, W, Ci, ldx, Co, ld_dy, ws.data_ptr(), wsb, stream()))
+    S = lib.cvk_conv3x3_wgrad_bf16s_splits(N, H, W, Ci, Co)
+    n = Co * 9 * Ci
+    assert S >= 1 and wsb == 4 * S * n
+    got = torch.full((Co, 3, 3, Ci), float("nan"), device=dev())
+    if S == 1:
+        check(lib.cvk_conv3x3_wgrad_bf16s_slabs(x.data_ptr(), dy.data_ptr(), got.data_ptr(), N, H, W, Ci, ldx, Co, ld_dy, 4 * n, stream()))
+    else:
+        slabs = torch.full((S * n,), float("nan"), device=dev())
+        check(lib.cvk_conv3x3_wgrad_bf16s_slabs(x.data_ptr(), dy.data_ptr(), slabs.data_ptr(), N, H, W, Ci, ldx, Co, ld_dy, 4 * S * n, stream()))
+        other = torch.full((5,), float("nan"), device=dev())          # a second job in the same launch
+        src2 = torch.arange(15, device=dev(), dtype=torch.float32)
+        arr = (_lib.WReduceJob * 2)(_lib.WReduceJob(slabs.data_ptr(), got.data_ptr(), n, S, 0), _lib.WReduceJob(src2.data_ptr(), other.data_ptr(), 5, 3, 0))
+        check(lib.cvk_wgrad_reduce_bf16s_batch(ctypes.addressof(arr), 2, stream()))
+        assert other.tolist() == [15.0, 18.0, 21.0, 24.0, 27.0]
+        with pytest.raises(_lib.CvkError):
+            check(lib.cvk_conv3x3_wgrad_bf16s_slabs(x.data_ptr(), dy.data_ptr(), slabs.data_ptr(), N, H, W, Ci, ldx, Co, ld_dy, 4 * S * n - 4, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
