@@ -50,7 +50,13 @@ class GraphedStep:
         torch.cuda.synchronize(x.device)
         self._zero()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # With a process group alive, ProcessGroupNCCL's watchdog thread polls the events of earlier collectives (hipEventQuery) at any
+        # moment; under the default "global" capture mode such a call from ANOTHER thread fails with "operation not permitted when
+        # stream is capturing" and the watchdog takes the process down (seen once in three full test runs).  "thread_local" restricts
+        # the check to the capturing thread — what torch prescribes for capturing collectives.
+        import torch.distributed as dist
+        mode = "thread_local" if (R.grad_sync is not None or (dist.is_available() and dist.is_initialized())) else "global"
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.loss = lossf(net(self.x), self.t)
             self.loss.backward()
         # every tensor a replay writes must stay alive as long as the graph: the gradients (views of the flat buffer the
