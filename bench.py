@@ -169,8 +169,8 @@ def kernel_profile(step, dev, nprof=3):
     allf = sum(v[1] for v in agg.values()); alls = sum(v[2] for v in agg.values())
     alle = sum(v[3] for v in agg.values())
     traffic = None
-    pat = "r*_pmc_hbm_traffic_bf16.json" if "bf16" in dom[0] else "r*_pmc_hbm_traffic.json"
-    tp = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))[-1:]
+    pats = ["r*_pmc_hbm_traffic_bf16.json"] if "bf16" in dom[0] else ["r*_pmc_hbm_traffic.json", "r*_pmc_hbm_traffic_fp32.json"]
+    tp = sorted((f for pat in pats for f in glob.glob(os.path.join(ROOT, "profiles", pat))), key=os.path.basename)[-1:]
     tp = tp[0] if tp else ""
     if os.path.exists(tp):
         for k, v in json.load(open(tp)).items():

@@ -389,6 +389,21 @@ typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 // epilogue.  For that the epilogue keeps out of [0, 64 KiB) (ring + slab A): the output is transposed through a 64 KiB stage at
 // [64 KiB, 128 KiB) in TWO passes (group A's 256 pixels x 256 B, then group B's).  Results leave as always-issued buffer stores
 // (16 per lane and tile; out-of-frame lanes get an offset past the buffer), so the counted vmcnt of the next tile can step over them.
+
+// t / d for t * d < 2^32 (the launcher checks the tile counts): one multiply-high instead of the ~40 scalar instructions of a division
+// by a run-time divisor.  The persistent kernels decode a tile index three times per tile, on every wave, with the matrix pipe idle.
+struct TileDiv {
+    unsigned m, add_mask, d;
+    __device__ explicit TileDiv(int dd) {
+        d = (unsigned)dd;
+        const unsigned long long mm = 0x100000000ULL / d + 1ULL;
+        m = __builtin_amdgcn_readfirstlane((unsigned)mm);
+        add_mask = (mm >> 32) ? 0xFFFFFFFFu : 0u;
+    }
+    __device__ __forceinline__ int div(int t) const { return (int)(__umulhi((unsigned)t, m) + ((unsigned)t & add_mask)); }
+    __device__ __forceinline__ int mod(int t, int q) const { return t - q * (int)d; }
+};
+
 template <bool STATS>
 __global__ __launch_bounds__(512, 2) void k_conv_bf16q(const __bf16* __restrict__ X, const char* __restrict__ Wp,
                                                       const float* __restrict__ bias, __bf16* __restrict__ Y,
@@ -417,12 +432,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16q(const __bf16* __restrict_
 
     // ---- per-tile state: the tile being multiplied (cur_*) and the DMA sources of the tile being requested ------------------------
     struct Geo { int nt, sp, x0, y0, img; };
+    const TileDiv divN(tilesN), divX(tilesX), divXY(tilesX * tilesY);
     auto geo_of = [&](int t) {
         Geo g;
-        g.nt = t % tilesN;
-        g.sp = t / tilesN;
-        const int tx = g.sp % tilesX, ty = (g.sp / tilesX) % tilesY;
-        g.img = g.sp / (tilesX * tilesY);
+        g.sp = divN.div(t);
+        g.nt = divN.mod(t, g.sp);
+        g.img = divXY.div(g.sp);
+        const int rem = divXY.mod(g.sp, g.img);
+        const int ty = divX.div(rem), tx = divX.mod(rem, ty);
         g.x0 = tx * TW; g.y0 = ty * TH;
         return g;
     };
@@ -571,9 +588,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16q(const __bf16* __restrict_
         const int n_k = min(G, ntiles - base);
         const bool has_next = (int)blockIdx.x < n_k;
         const int next = has_next ? base + cvk_xcd_remap(blockIdx.x, n_k) : 0;
+        Geo nxt = cur;
         if (has_next) {
-            const Geo g = geo_of(next);
-            setup_dma(g);
+            nxt = geo_of(next);
+            setup_dma(nxt);
             issue_prologue();
         }
 
@@ -682,7 +700,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16q(const __bf16* __restrict_
         }
         if (!has_next) break;
         tile = next;
-        cur = geo_of(tile);
+        cur = nxt;
         stores_in_flight = true;
     }
 }
@@ -730,12 +748,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
     const int G = gridDim.x;
 
     struct Geo { int nt, sp, x0, y0, img; };
+    const TileDiv divN(tilesN), divX(tilesX), divXY(tilesX * tilesY);
     auto geo_of = [&](int t) {
         Geo g;
-        g.nt = t % tilesN;
-        g.sp = t / tilesN;
-        const int tx = g.sp % tilesX, ty = (g.sp / tilesX) % tilesY;
-        g.img = g.sp / (tilesX * tilesY);
+        g.sp = divN.div(t);
+        g.nt = divN.mod(t, g.sp);
+        g.img = divXY.div(g.sp);
+        const int rem = divXY.mod(g.sp, g.img);
+        const int ty = divX.div(rem), tx = divX.mod(rem, ty);
         g.x0 = tx * TW; g.y0 = ty * TH;
         return g;
     };
@@ -807,7 +827,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
     auto stamp = [&](int which) {
         if (DBG && blockIdx.x == 0 && tcount < 16) {
             const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-            if (tid == 0) reinterpret_cast<unsigned long long*>(stats)[tcount * 8 + which] = t;
+            // STATS builds keep their statistics: the stamps go behind the counts (the timing script allocates the room)
+            unsigned long long* const sb = STATS ? reinterpret_cast<unsigned long long*>(cnt + ((P + 1) & ~1)) : reinterpret_cast<unsigned long long*>(stats);
+            if (tid == 0) sb[tcount * 8 + which] = t;
         }
     };
 
@@ -907,12 +929,25 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
         const int n_k = min(G, ntiles - base);
         const bool has_next = (int)blockIdx.x < n_k;
         const int next = has_next ? base + cvk_xcd_remap(blockIdx.x, n_k) : 0;
+        Geo nxt = cur;
         if (has_next) {
-            const Geo g = geo_of(next);
-            setup_dma(g);
-            issue_prologue();
+            nxt = geo_of(next);
+            setup_dma(nxt);
         }
         stamp(4);
+        // The next tile's prologue (7-9 KiB per wave, 64 KiB per workgroup: ~1000 cycles of the CU's 64 B/clk LDS-DMA path) goes out one
+        // piece per block of the epilogue below instead of in one burst in front of it: the waves compute while the queue drains
+        // (tools/tile_stamps_h.py: "next prologue issue" 1.2-1.5 us of a 10-16 us tile).  All of it is still issued before the first store.
+        auto prologue_piece = [&](int k) {
+            if (!has_next) return;
+            if (k == 0) dma_slab_piece(std::integral_constant<int, 0>{}, 0, wave_lds + RING_BYTES);
+            if (k == 1) dma_slab_piece(std::integral_constant<int, 1>{}, 0, wave_lds + RING_BYTES);
+            if (k == 2) dma_slab_piece(std::integral_constant<int, 2>{}, 0, wave_lds + RING_BYTES);
+            if (k == 3) dma_slab_piece(std::integral_constant<int, 3>{}, 0, wave_lds + RING_BYTES);
+            if (k == 4) dma_slab_piece(std::integral_constant<int, 4>{}, 0, wave_lds + RING_BYTES);
+            if (k == 5) dma_row_next(std::integral_constant<int, 0>{}, 0);
+            if (k == 6) dma_row_next(std::integral_constant<int, 1>{}, 1);
+        };
 
         // ---- epilogue: acc[rb][cb][i] = channel n0 + rb*16 + 4*q4 + i, pixel (y0 + row0 + (cb >> 1), x0 + (cb & 1)*16 + l15) ---------------
         int elane = lane;
@@ -945,6 +980,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
                     // stage: [512 pixels][128 B], 16-byte chunk c of pixel p at position c ^ ((p >> 1) & 7)
                     const int p = (row0 + (cb >> 1)) * 32 + (cb & 1) * 16 + l15, chunk = rb * 2 + (q4 >> 1);
                     *reinterpret_cast<bf16x4*>(smem + STAGE_OFF + p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4) + 8 * (q4 & 1)) = o;
+                    if (rb * 4 + cb < 7) prologue_piece(rb * 4 + cb);
                 }
             }
             if (STATS) {
@@ -994,7 +1030,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
         ++tcount;
         if (!has_next) break;
         tile = next;
-        cur = geo_of(tile);
+        cur = nxt;
         stores_in_flight = true;
     }
 }
@@ -1163,7 +1199,8 @@ void launch(const void* x, const void* wpp, const float* bias, void* y, float* s
             else hipLaunchKernelGGL((k_conv_bf16h<false, 0, true>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);
             return;
         }
-        if (hdbg) hipLaunchKernelGGL((k_conv_bf16h<false, 1>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);
+        if (hdbg == 2 && stats) hipLaunchKernelGGL((k_conv_bf16h<true, 1>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);
+        else if (hdbg == 1) hipLaunchKernelGGL((k_conv_bf16h<false, 1>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);
         else if (stats) hipLaunchKernelGGL((k_conv_bf16h<true>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);
         else hipLaunchKernelGGL((k_conv_bf16h<false>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles);
         return;

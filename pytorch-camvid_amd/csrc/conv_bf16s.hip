@@ -703,6 +703,11 @@ static int conv3x3_bf16s_impl(const void* x, const void* w, const float* bias, v
         // offset of 2^31 marks an out-of-frame pixel)
         CVK_CHECK_ARG(cvk_aligned16(y) && ldy % 8 == 0, "cvk_conv3x3_bf16s: layers with > 64 output and >= 128 input channels need a 16-byte aligned y and ldy %% 8 == 0");
         CVK_CHECK_ARG((long)H * W * Cin * 2 < (1L << 31), "cvk_conv3x3_bf16s: one image exceeds 2 GiB");
+        {   // the persistent kernels decode tile indices with a multiply-high (conv_bf16p.hip TileDiv): exact while index * divisor < 2^32
+            const long pt = (long)N * cvk_cdiv(H, cvk_bf16p::TH) * cvk_cdiv(W, cvk_bf16p::TW), tn = cvk_cdiv(Cout, 64);
+            const long txy = (long)cvk_cdiv(H, cvk_bf16p::TH) * cvk_cdiv(W, cvk_bf16p::TW);
+            CVK_CHECK_ARG(pt * tn * tn < (1L << 32) && pt * txy < (1L << 32), "cvk_conv3x3_bf16s: too many tiles for the 32-bit tile decode");
+        }
         cvk_bf16p::launch(x, w, bias, y, stats, counts, N, H, W, Cin, Cout, ldy, s, max_workgroups);
         CVK_LAUNCH_RETURN("cvk_conv3x3_bf16s");
     }

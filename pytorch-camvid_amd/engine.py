@@ -826,7 +826,7 @@ class ConvBnRelu(Op):
         S = lib.cvk_conv3x3_wgrad_bf16s_splits(N, H, W, self.cin, C)
         n = C * 9 * self.cin
         slab = None if S == 1 else _empty(S * n, dev)           # one slab: it is the gradient itself, written in place
-        _timed(R, "k_wgrad_bf16s", flops, lambda: check(
+        _timed(R, "k_wgrad_bf16r<0, true>", flops, lambda: check(
             lib.cvk_conv3x3_wgrad_bf16s_slabs(X.data_ptr(), dy.data_ptr(), gw if slab is None else slab.data_ptr(), N, H, W, self.cin, src.ld, C,
                                               ld_dy, 4 * S * n, s), "cvk_conv3x3_wgrad_bf16s_slabs"))
         if slab is not None:

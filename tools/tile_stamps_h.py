@@ -14,10 +14,21 @@ wt = torch.randn(co, 3, 3, ci, device=dev) * 0.05
 wp = torch.empty(lib.cvk_bf16s_rows_pad(co) * 9 * ci, device=dev, dtype=BF)
 check(lib.cvk_pack_weight_fwd_bf16(wt.data_ptr(), wp.data_ptr(), co, ci, ci, s))
 y = torch.empty(N * h * w * co, device=dev, dtype=BF)
-st = torch.zeros(16 * 8 + 64, device=dev, dtype=torch.int64)
-for _ in range(3):
-    check(lib.cvk_conv3x3_bf16s(x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), st.data_ptr(), st.data_ptr(), N, h, w, ci, co, co, s))
-torch.cuda.synchronize()
+with_stats = os.environ.get("CVK_BF16H_DBG") == "2"          # 2: the statistics epilogue (stamps behind the counts), 1: without
+if with_stats:
+    P = lib.cvk_bf16s_stat_partials_c(N, h, w, ci, co)
+    buf = torch.zeros(2 * P * co + ((P + 1) & ~1) + 2 * (16 * 8 + 64), device=dev, dtype=torch.float32)
+    bias = torch.zeros(co, device=dev)
+    cntp = buf.data_ptr() + 4 * 2 * P * co
+    for _ in range(3):
+        check(lib.cvk_conv3x3_bf16s(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), y.data_ptr(), buf.data_ptr(), cntp, N, h, w, ci, co, co, s))
+    torch.cuda.synchronize()
+    st = buf[2 * P * co + ((P + 1) & ~1):].view(torch.int64)
+else:
+    st = torch.zeros(16 * 8 + 64, device=dev, dtype=torch.int64)
+    for _ in range(3):
+        check(lib.cvk_conv3x3_bf16s(x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), st.data_ptr(), st.data_ptr(), N, h, w, ci, co, co, s))
+    torch.cuda.synchronize()
 t = st[:128].cpu().view(16, 8).double() * 10e-3
 names = ["top wait+barrier", "K loop", "drain", "next prologue issue", "compute+stage", "store+stats"]
 for i in range(2, 10):

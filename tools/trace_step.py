@@ -2,7 +2,7 @@
 usage: python3 tools/trace_step.py <dir with *_kernel_trace.csv> [name substrings...]"""
 import csv, glob, sys
 f = (glob.glob(sys.argv[1] + "/*/*kernel_trace.csv") + glob.glob(sys.argv[1] + "/*kernel_trace.csv"))[0]
-subs = sys.argv[2:] or ["k_conv_bf16", "k_wgrad_bf16s"]
+subs = sys.argv[2:] or ["k_conv_bf16", "k_wgrad_bf16r"]
 rows = [r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "k_ce_fwd" in r["Kernel_Name"]]
