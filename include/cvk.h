@@ -185,6 +185,14 @@ int cvk_w6_wgrad_output(const float* P, float* dw, int T, int Cin, int Cin_pad, 
  * max_workgroups > 0 caps its grid (data-parallel runs leave CUs to RCCL's kernels), 0 = one per CU. */
 size_t cvk_wino4f_weight_floats(int Cn, int Ck);
 int cvk_wino4f_weight_transform(const float* w, float* Uf, int Cn, int Ck, int dgrad, void* stream);
+/* n (<= CVK_WT_BATCH_MAX) filter transforms in ONE launch; `jobs` is a HOST array (copied into the kernel arguments).  A training step
+ * rebuilds every Winograd-domain filter (the weights changed in optimizer.step(), train.py:134): 16 + 26 launches of 5-15 us each.
+ *   cvk_wino4f_weight_transform_batch: job = cvk_wino4f_weight_transform(w, out, rows = Cn, cols = Ck, dgrad)      (tile ignored)
+ *   cvk_w2d_weight_transform_batch:    job = cvk_w2d_ / cvk_w6_weight_transform[_dgrad](w, out, rows = Cout, cols = Cin), tile = 4 | 6 */
+#define CVK_WT_BATCH_MAX 48
+typedef struct cvk_wt_job { const float* w; float* out; int rows, cols, tile, dgrad; } cvk_wt_job;
+int cvk_wino4f_weight_transform_batch(const cvk_wt_job* jobs, int n, void* stream);
+int cvk_w2d_weight_transform_batch(const cvk_wt_job* jobs, int n, void* stream);
 int cvk_wino4f_stat_partials(int N, int H, int W);
 int cvk_conv3x3_wino4f(const float* x, const float* Uf, const float* bias, float* y, float* stats, float* counts, int N, int H,
                        int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream);

@@ -53,6 +53,8 @@ SIGNATURES = {
     "cvk_wino4_output": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_wino4f_weight_floats": (c_size, [c_int, c_int]),
     "cvk_wino4f_weight_transform": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "cvk_wino4f_weight_transform_batch": (c_int, [c_vp, c_int, c_vp]),
+    "cvk_w2d_weight_transform_batch": (c_int, [c_vp, c_int, c_vp]),
     "cvk_wino4f_stat_partials": (c_int, [c_int, c_int, c_int]),
     "cvk_conv3x3_wino4f": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_wino4f_bnred": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
@@ -177,6 +179,11 @@ class ColsumJob(ctypes.Structure):      # include/cvk.h cvk_colsum_job
     _fields_ = [("part", ctypes.c_void_p), ("out", ctypes.c_void_p), ("PB", ctypes.c_int), ("C", ctypes.c_int)]
 
 
+class WtJob(ctypes.Structure):          # include/cvk.h cvk_wt_job
+    _fields_ = [("w", ctypes.c_void_p), ("out", ctypes.c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int), ("tile", ctypes.c_int),
+                ("dgrad", ctypes.c_int)]
+
+
 class WReduceJob(ctypes.Structure):     # include/cvk.h cvk_wreduce_job
     _fields_ = [("slabs", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("n", ctypes.c_ulonglong), ("splits", ctypes.c_int), ("pad", ctypes.c_int)]
 
@@ -184,6 +191,7 @@ class WReduceJob(ctypes.Structure):     # include/cvk.h cvk_wreduce_job
 PACK_BATCH_MAX = 48
 COLSUM_BATCH_MAX = 64
 WREDUCE_BATCH_MAX = 48
+WT_BATCH_MAX = 48
 
 
 class CvkError(RuntimeError):

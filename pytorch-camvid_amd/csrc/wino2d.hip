@@ -224,11 +224,11 @@ __global__ __launch_bounds__(256) void k_w2d_input(const float* __restrict__ X, 
 
 // ---- weight transform: w [Co][3][3][Ci] -> U [NX][Co][Ci]; one thread = one (co, ci) --------------------------------------------
 template <int MT>
-__global__ __launch_bounds__(256) void k_w2d_weight(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci) {
+__device__ __forceinline__ void w2d_weight_body(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci, unsigned vblock, unsigned nblocks) {
     typedef W2T<MT> TR;
     constexpr int NT = TR::NT;
     const size_t total = (size_t)Co * Ci;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    for (size_t i = (size_t)vblock * 256 + threadIdx.x; i < total; i += (size_t)nblocks * 256) {
         const int ci = (int)(i % Ci);
         const size_t co = i / Ci;
         float g[3][3], a[NT][3];
@@ -251,16 +251,19 @@ __global__ __launch_bounds__(256) void k_w2d_weight(const float* __restrict__ Wt
         }
     }
 }
+template <int MT>
+__global__ __launch_bounds__(256) void k_w2d_weight(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci) {
+    w2d_weight_body<MT>(Wt, U, Co, Ci, blockIdx.x, gridDim.x);
+}
 
 // ---- data-grad filter straight from the forward weights: U [NX][Ci][Co] = G w'[ci][.][.][co] G^T with w'[ci][r][s][co] =
 // w[co][2-r][2-s][ci] (rotated by 180 degrees, channels exchanged) — no packed copy in between.  A workgroup transposes a
 // 32 (co) x 32 (ci) tile of all nine taps through LDS: reads run along ci, writes along co.
 template <int MT>
-__global__ __launch_bounds__(256) void k_w2d_weight_dgrad(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci) {
+__device__ __forceinline__ void w2d_weight_dgrad_body(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci, int bx, int by, float (*t)[32][33]) {
     typedef W2T<MT> TR;
     constexpr int NT = TR::NT;
-    __shared__ float t[9][32][33];
-    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int ci0 = bx * 32, co0 = by * 32;
     float ld[36];
 #pragma unroll
     for (int j = 0; j < 36; ++j) {                       // all 36 loads of a thread in flight at once
@@ -295,6 +298,31 @@ __global__ __launch_bounds__(256) void k_w2d_weight_dgrad(const float* __restric
 #pragma unroll
             for (int r = 0; r < NT; ++r) U[(size_t)(q * NT + r) * total + o] = u[r];
         }
+    }
+}
+template <int MT>
+__global__ __launch_bounds__(256) void k_w2d_weight_dgrad(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci) {
+    __shared__ float t[9][32][33];
+    w2d_weight_dgrad_body<MT>(Wt, U, Co, Ci, blockIdx.x, blockIdx.y, t);
+}
+
+// All 2-D Winograd filter transforms of a step (forward and data-grad filters, both tile sizes) in ONE launch: job j owns the blocks
+// [first[j], first[j + 1]); the jobs travel by value in the kernel arguments.
+struct W2WJobsDev { const float* w[CVK_WT_BATCH_MAX]; float* out[CVK_WT_BATCH_MAX]; int Co[CVK_WT_BATCH_MAX], Ci[CVK_WT_BATCH_MAX], kind[CVK_WT_BATCH_MAX];
+                    unsigned first[CVK_WT_BATCH_MAX + 1]; int n; };      // kind = tile (4 | 6) + 16 * dgrad
+__global__ __launch_bounds__(256) void k_w2d_weight_batch(const W2WJobsDev jobs) {
+    __shared__ float t[9][32][33];
+    int j = 0;
+    while (j + 1 < jobs.n && blockIdx.x >= jobs.first[j + 1]) ++j;
+    const unsigned vb = blockIdx.x - jobs.first[j], nb = jobs.first[j + 1] - jobs.first[j];
+    const int Co = jobs.Co[j], Ci = jobs.Ci[j], kind = jobs.kind[j];
+    if (kind & 16) {
+        const int gx = (Ci + 31) / 32;
+        if ((kind & 15) == 4) w2d_weight_dgrad_body<4>(jobs.w[j], jobs.out[j], Co, Ci, (int)(vb % gx), (int)(vb / gx), t);
+        else w2d_weight_dgrad_body<6>(jobs.w[j], jobs.out[j], Co, Ci, (int)(vb % gx), (int)(vb / gx), t);
+    } else {
+        if ((kind & 15) == 4) w2d_weight_body<4>(jobs.w[j], jobs.out[j], Co, Ci, vb, nb);
+        else w2d_weight_body<6>(jobs.w[j], jobs.out[j], Co, Ci, vb, nb);
     }
 }
 
@@ -832,6 +860,23 @@ static int w2i_weight_transform_dgrad(int mt, const char* who, const float* w, f
     if (mt == 4) hipLaunchKernelGGL(k_w2d_weight_dgrad<4>, grid, dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
     else hipLaunchKernelGGL(k_w2d_weight_dgrad<6>, grid, dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
     CVK_LAUNCH_RETURN(who);
+}
+
+extern "C" int cvk_w2d_weight_transform_batch(const cvk_wt_job* jobs, int n, void* stream) {
+    CVK_CHECK_ARG(jobs && n > 0 && n <= CVK_WT_BATCH_MAX, "cvk_w2d_weight_transform_batch: 1..%d jobs", CVK_WT_BATCH_MAX);
+    W2WJobsDev d;
+    unsigned nb = 0;
+    for (int i = 0; i < n; ++i) {
+        const cvk_wt_job& q = jobs[i];
+        CVK_CHECK_ARG(q.w && q.out && q.rows > 0 && q.cols > 0 && (q.tile == 4 || q.tile == 6), "cvk_w2d_weight_transform_batch: bad job %d", i);
+        d.w[i] = q.w; d.out[i] = q.out; d.Co[i] = q.rows; d.Ci[i] = q.cols; d.kind[i] = q.tile + (q.dgrad ? 16 : 0);
+        d.first[i] = nb;
+        if (q.dgrad) nb += (unsigned)(cvk_cdiv(q.cols, 32) * cvk_cdiv(q.rows, 32));
+        else { const size_t total = (size_t)q.rows * q.cols; nb += (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096); }
+    }
+    d.first[n] = nb; d.n = n;
+    hipLaunchKernelGGL(k_w2d_weight_batch, dim3(nb), dim3(256), 0, (hipStream_t)stream, d);
+    CVK_LAUNCH_RETURN("cvk_w2d_weight_transform_batch");
 }
 
 static int w2i_input_transform(int mt, const char* who, const float* x, float* V, int N, int H, int W, int Cin, void* stream) {

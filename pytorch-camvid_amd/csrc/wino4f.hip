@@ -38,11 +38,11 @@ constexpr int F_STAGE = F_ABYTES + F_BBYTES;     // 73728
 // slice*16 .. +15 of (G g)_xi, K = kernel row * Ck + input channel; 16-byte chunk c of row r is stored at c ^ ((r >> 2) & 3)
 // (the LDS image: the sixteen rows of a ds_read_b128 phase then hit sixteen different bank groups).  Rows >= Cn are zero.
 // dgrad: w is the FORWARD filter [Ck][3][3][Cn] and g_s = w[k][2-r][2-s][n] (rotated by 180 degrees, channels exchanged).
-__global__ __launch_bounds__(256) void k_wino4f_weight(const float* __restrict__ w, float* __restrict__ Uf, int Cn, int Ck,
-                                                      int tilesN, int dgrad) {
+__device__ __forceinline__ void wino4f_weight_body(const float* __restrict__ w, float* __restrict__ Uf, int Cn, int Ck, int tilesN, int dgrad,
+                                                   unsigned vblock, unsigned nblocks) {
     const int Nn = tilesN * F_BN;
     const size_t total = (size_t)Nn * 3 * Ck;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)vblock * blockDim.x + threadIdx.x; i < total; i += (size_t)nblocks * blockDim.x) {
         int n, r, k;
         if (dgrad) {       // n fastest: coalesced reads along the forward filter's input channels
             n = (int)(i % Nn);
@@ -76,6 +76,22 @@ __global__ __launch_bounds__(256) void k_wino4f_weight(const float* __restrict__
         Uf[o + 4 * ps] = (float)(g0 / 24.0 - g1 / 12.0 + g2 / 6.0);
         Uf[o + 5 * ps] = (float)g2;
     }
+}
+
+__global__ __launch_bounds__(256) void k_wino4f_weight(const float* __restrict__ w, float* __restrict__ Uf, int Cn, int Ck,
+                                                      int tilesN, int dgrad) {
+    wino4f_weight_body(w, Uf, Cn, Ck, tilesN, dgrad, blockIdx.x, gridDim.x);
+}
+
+// All fused-F(4,3) filter transforms of a step in ONE launch (16 launches of ~5 us each in a UNet step): the jobs travel by value in the
+// kernel arguments, job j owns the blocks [first[j], first[j + 1]).
+struct F4WJobsDev { const float* w[CVK_WT_BATCH_MAX]; float* out[CVK_WT_BATCH_MAX]; int Cn[CVK_WT_BATCH_MAX], Ck[CVK_WT_BATCH_MAX], dgrad[CVK_WT_BATCH_MAX];
+                    unsigned first[CVK_WT_BATCH_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void k_wino4f_weight_batch(const F4WJobsDev jobs) {
+    int j = 0;
+    while (j + 1 < jobs.n && blockIdx.x >= jobs.first[j + 1]) ++j;
+    wino4f_weight_body(jobs.w[j], jobs.out[j], jobs.Cn[j], jobs.Ck[j], (jobs.Cn[j] + F_BN - 1) / F_BN, jobs.dgrad[j],
+                       blockIdx.x - jobs.first[j], jobs.first[j + 1] - jobs.first[j]);
 }
 
 // LDS-DMA with a scalar base: global address = sbase + voff (32-bit per-lane byte offset), LDS = m0 + 16 * lane.
@@ -510,6 +526,23 @@ extern "C" int cvk_wino4f_weight_transform(const float* w, float* Uf, int Cn, in
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(k_wino4f_weight, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Uf, Cn, Ck, f_tiles_n(Cn), dgrad ? 1 : 0);
     CVK_LAUNCH_RETURN("cvk_wino4f_weight_transform");
+}
+
+extern "C" int cvk_wino4f_weight_transform_batch(const cvk_wt_job* jobs, int n, void* stream) {
+    CVK_CHECK_ARG(jobs && n > 0 && n <= CVK_WT_BATCH_MAX, "cvk_wino4f_weight_transform_batch: 1..%d jobs", CVK_WT_BATCH_MAX);
+    F4WJobsDev d;
+    unsigned nb = 0;
+    for (int i = 0; i < n; ++i) {
+        const cvk_wt_job& q = jobs[i];
+        CVK_CHECK_ARG(q.w && q.out && q.rows > 0 && q.cols > 0 && q.cols % F_BK == 0 && cvk_aligned16(q.out), "cvk_wino4f_weight_transform_batch: bad job %d", i);
+        d.w[i] = q.w; d.out[i] = q.out; d.Cn[i] = q.rows; d.Ck[i] = q.cols; d.dgrad[i] = q.dgrad ? 1 : 0;
+        const size_t total = (size_t)f_tiles_n(q.rows) * F_BN * 3 * q.cols;
+        d.first[i] = nb;
+        nb += (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    }
+    d.first[n] = nb; d.n = n;
+    hipLaunchKernelGGL(k_wino4f_weight_batch, dim3(nb), dim3(256), 0, (hipStream_t)stream, d);
+    CVK_LAUNCH_RETURN("cvk_wino4f_weight_transform_batch");
 }
 
 extern "C" int cvk_wino4f_stat_partials(int N, int H, int W) {

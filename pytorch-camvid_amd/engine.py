@@ -225,8 +225,11 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
     with that tile (cvk_w6_dy_transform_both: the backward pass transforms dy once for the data-grad and the weight-grad)."""
     M = N * H * W
 
-    def cached(kind, build):
-        return R.derived((ck, kind), wsrc, build) if (ck is not None and wsrc is not None) else build()
+    def cached(kind, build, job=None):
+        return R.derived((ck, kind), wsrc, build, job) if (ck is not None and wsrc is not None) else build()
+
+    def straight(t):                        # is tensor t the parameter itself (no packed / padded copy in between)?
+        return wsrc is not None and t is not None and not callable(t) and t.data_ptr() == wsrc.data_ptr()
     if wino2d_ok(k_ch, cout, ldy) and (R.wino2d == "always" or (R.wino2d and wino2d_pays(N, H, W, k_ch, cout, R.w2tile))):
         tile = layer_tile(R, N, H, W, dgrad=dgrad_of is not None)
         NX = 64 if tile == 6 else 36
@@ -241,7 +244,12 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
             _timed(R, "k_w2d_weight", 4.0 * (9 + NX) * cout * k_ch, lambda: check(
                 w2fn(lib, tile, "weight_transform")(wt.data_ptr(), u.data_ptr(), cout, k_ch, s), "cvk_w2d_weight_transform"), "byte")
             return u
-        U = cached("w2d%d" % tile, build_u2)
+        job = None
+        if dgrad_of is not None and dgrad_of[1] == k_ch and dgrad_of[2] == cout and straight(dgrad_of[0]):
+            job = ("w2d", NX * cout * k_ch, dgrad_of[1], dgrad_of[2], tile, 1)
+        elif dgrad_of is None and straight(w):
+            job = ("w2d", NX * cout * k_ch, cout, k_ch, tile, 0)
+        U = cached("w2d%d" % tile, build_u2, job)
         T = w2fn(lib, tile, "tiles")(N, H, W)
         vfl = NX * lib.cvk_w2d_tpad(T) * k_ch + 128          # V planes + 512 bytes of slack
         if v_pre is not None and v_pre[0] == tile:
@@ -279,7 +287,12 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
                 _timed(R, "k_wino4f_weight", 4.0 * (9 + 18) * cout * k_ch, lambda: check(
                     lib.cvk_wino4f_weight_transform(wt.data_ptr(), uf.data_ptr(), cout, k_ch, 0, s), "cvk_wino4f_weight_transform"), "byte")
             return uf
-        Uf = cached("w4f", build_uf)
+        job = None
+        if dgrad_of is not None and straight(dgrad_of[0]):
+            job = ("w4f", lib.cvk_wino4f_weight_floats(cout, k_ch), cout, k_ch, 0, 1)
+        elif dgrad_of is None and straight(w):
+            job = ("w4f", lib.cvk_wino4f_weight_floats(cout, k_ch), cout, k_ch, 0, 0)
+        Uf = cached("w4f", build_uf, job)
         Pf = lib.cvk_wino4f_stat_partials(N, H, W)
         cnt = sp + 4 * 2 * Pf * cout if sp is not None else None
         if bnred is not None and sp is None and bias is None and ldy == cout and R.bnred_fuse:
@@ -1098,6 +1111,7 @@ class Runner:
         self.wcache = WCACHE_DEFAULT
         self.wepoch = 0             # bumped by mark_weights_dirty / FlatAdamW.step / load_state_dict
         self._wc = {}               # (layer slot, kind) -> (signature, tensor)
+        self._wjobs, self._wjobs_cfg = {}, None      # batchable builds recorded by the last pass (prebuild_fp32)
         self._pass_token = 0        # 0: eval / no-grad passes (entries shared across calls); > 0: the training pass being executed
         self._passes = 0
         self.wcache_builds = 0      # derived tensors built since creation (tests / diagnostics)
@@ -1113,11 +1127,15 @@ class Runner:
             self._dp_wgs = max(8, cus - int(os.environ.get("CVK_DP_RESERVE_CUS", "16")))
         return self._dp_wgs
 
-    def derived(self, key, src, build):
-        """The derived weight tensor `key` of parameter `src`: cached while the weights are provably unchanged."""
+    def derived(self, key, src, build, job=None):
+        """The derived weight tensor `key` of parameter `src`: cached while the weights are provably unchanged.
+        job = (family, floats, rows, cols, tile, dgrad): how a batched launch can build it straight from `src` (prebuild_fp32 then builds
+        it with every other recorded tensor of the network at the start of the next pass)."""
         if not self.wcache or key is None or torch.cuda.is_current_stream_capturing():
             self.wcache_builds += 1
             return build()
+        if job is not None:
+            self._wjobs[key] = (src, job)
         sig = (WEIGHT_EPOCH[0], self.wepoch, src.data_ptr(), src._version, self._pass_token)
         ent = self._wc.get(key)
         if ent is not None and ent[0] == sig:
@@ -1126,6 +1144,39 @@ class Runner:
         self.wcache_builds += 1
         self._wc[key] = (sig, t)
         return t
+
+    def prebuild_fp32(self, plan, st, need_grad):
+        """fp32 plans: the Winograd-domain filters the previous pass over this plan asked for (fused F(4,3): 16 per UNet step; 2-D forward
+        and data-grad filters: 26), rebuilt in TWO launches (cvk_wino4f_weight_transform_batch, cvk_w2d_weight_transform_batch) instead
+        of 42 of 5-15 us each.  Which filters a layer needs is decided where the layer runs (wino_conv); that code records a job with
+        every cached tensor it builds straight from a parameter, and this pass replays the record."""
+        if not self.wcache or torch.cuda.is_current_stream_capturing():
+            return
+        cfg = (id(plan), self.w2tile, self.w2tile_dgrad, self.wino, self.wino4, self.wino4f, self.wino2d, self.wgradp, self.thin)
+        if cfg != self._wjobs_cfg:          # another plan or other kernel knobs: the record starts over with this pass
+            self._wjobs, self._wjobs_cfg = {}, cfg
+            return
+        live = {p.data_ptr() for p in st.params}
+        lib, fam_jobs, nbytes = self.lib, {"w4f": [], "w2d": []}, 0.0
+        for key, (src, (fam, floats, rows, cols, tile, dgrad)) in self._wjobs.items():
+            if src.data_ptr() not in live or (dgrad and not need_grad):
+                continue
+            sig = (WEIGHT_EPOCH[0], self.wepoch, src.data_ptr(), src._version, self._pass_token)
+            ent = self._wc.get(key)
+            if ent is not None and ent[0] == sig:
+                continue
+            t = _empty(floats, src.device)
+            fam_jobs[fam].append(_lib.WtJob(src.data_ptr(), t.data_ptr(), rows, cols, tile, dgrad))
+            nbytes += 4.0 * (src.numel() + floats)
+            self._wc[key] = (sig, t)
+            self.wcache_builds += 1
+        for fam, fn in (("w4f", lib.cvk_wino4f_weight_transform_batch), ("w2d", lib.cvk_w2d_weight_transform_batch)):
+            jobs = fam_jobs[fam]
+            for i in range(0, len(jobs), _lib.WT_BATCH_MAX):
+                chunk = jobs[i:i + _lib.WT_BATCH_MAX]
+                arr = (_lib.WtJob * len(chunk))(*chunk)
+                _timed(self, "k_weight_transform_batch", nbytes / max(1, len(fam_jobs["w4f"]) + len(fam_jobs["w2d"])) * len(chunk),
+                       lambda: check(fn(ctypes.addressof(arr), len(chunk), st.stream), "cvk_%s_weight_transform_batch" % fam), "byte")
 
     def prepack_bf16(self, plan, st, need_grad):
         """bf16 plans: every weight pack the step will ask for and the cache does not hold (forward packs; data-grad packs when a
@@ -1245,6 +1296,8 @@ class Runner:
             st.act[inb.id] = t
         if plan.bf16:
             self.prepack_bf16(plan, st, need_grad)
+        else:
+            self.prebuild_fp32(plan, st, need_grad)
         for op in plan.ops:
             op.fwd(self, st)
         ov = plan.output

@@ -200,3 +200,73 @@ def test_w2d_data_grad_filter_straight_from_the_forward_weights(Co, Ci):
     check(lib.cvk_w2d_weight_transform_dgrad(w.data_ptr(), got.data_ptr(), Co, Ci, s), "direct")
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+
+
+def test_batched_filter_transforms_equal_the_single_launches():
+    """cvk_wino4f_weight_transform_batch / cvk_w2d_weight_transform_batch (round 4: the Winograd-domain filters of a whole step in two
+    launches) against the per-layer entry points: the same device functions, so bitwise — forward and data-grad filters, both 2-D tiles."""
+    import ctypes
+    from pytorch_camvid_amd import _lib
+    lib, check = _lib.load(), _lib.check
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(11)
+    shapes = [(64, 64), (128, 64), (96, 160), (256, 128)]
+    ws = [torch.randn(co, 3, 3, ci, generator=g).to(dev()) for co, ci in shapes]
+    # fused F(4,3)
+    jobs, want, got = [], [], []
+    for w, (co, ci) in zip(ws, shapes):
+        for dgrad in (0, 1):
+            cn, ck = (co, ci) if not dgrad else (ci, co)
+            n = lib.cvk_wino4f_weight_floats(cn, ck)
+            a = torch.full((n,), float("nan"), device=dev()); b = torch.full((n,), float("nan"), device=dev())
+            check(lib.cvk_wino4f_weight_transform(w.data_ptr(), a.data_ptr(), cn, ck, dgrad, s), "single")
+            jobs.append(_lib.WtJob(w.data_ptr(), b.data_ptr(), cn, ck, 0, dgrad)); want.append(a); got.append(b)
+    arr = (_lib.WtJob * len(jobs))(*jobs)
+    check(lib.cvk_wino4f_weight_transform_batch(ctypes.addressof(arr), len(jobs), s), "batch")
+    torch.cuda.synchronize()
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    # 2-D F(4x4) / F(6x6)
+    jobs, want, got = [], [], []
+    for w, (co, ci) in zip(ws, shapes):
+        for tile, nx in ((4, 36), (6, 64)):
+            for dgrad in (0, 1):
+                a = torch.full((nx * co * ci,), float("nan"), device=dev()); b = torch.full((nx * co * ci,), float("nan"), device=dev())
+                fn = getattr(lib, ("cvk_w2d_" if tile == 4 else "cvk_w6_") + ("weight_transform_dgrad" if dgrad else "weight_transform"))
+                check(fn(w.data_ptr(), a.data_ptr(), co, ci, s), "single")
+                jobs.append(_lib.WtJob(w.data_ptr(), b.data_ptr(), co, ci, tile, dgrad)); want.append(a); got.append(b)
+    arr = (_lib.WtJob * len(jobs))(*jobs)
+    check(lib.cvk_w2d_weight_transform_batch(ctypes.addressof(arr), len(jobs), s), "batch")
+    torch.cuda.synchronize()
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+
+
+def test_recorded_filter_builds_are_replayed_in_two_launches():
+    """The second training pass over a plan rebuilds its Winograd-domain filters through Runner.prebuild_fp32 (recorded by the first pass):
+    same losses and gradients as the uncached executor, and the per-layer transform entry points are no longer called."""
+    import pytorch_camvid_amd as A
+    from pytorch_camvid_amd import engine
+    from pytorch_camvid_amd.modules import runner_of
+    torch.manual_seed(0)
+    net = A.UNet(3, 12).to(dev()).train()
+    ref = A.UNet(3, 12).to(dev()).train()
+    ref.load_state_dict(net.state_dict())
+    runner_of(ref).wcache = False
+    lossf = A.CrossEntropyLoss()
+    x, t = batch(2, 96, 128, 3)
+    for it in range(3):
+        la, lb = _step(net, lossf, x, t), _step(ref, lossf, x, t)
+        assert la.item() == lb.item(), it
+        for (k, p), q in zip(net.named_parameters(), ref.parameters()):
+            assert torch.equal(p.grad, q.grad), (it, k)
+    R = runner_of(net)
+    assert len(R._wjobs) > 0
+    engine.PROF = []
+    try:
+        _step(net, lossf, x, t)
+        names = [r[0] for r in engine.PROF]
+    finally:
+        engine.PROF = None
+    assert "k_weight_transform_batch" in names
+    assert not any(n in ("k_wino4f_weight", "k_w2d_weight", "k_w2d_weight_dgrad") for n in names), sorted(set(names))
