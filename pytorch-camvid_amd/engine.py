@@ -1157,7 +1157,7 @@ class Runner:
             self._wjobs, self._wjobs_cfg = {}, cfg
             return
         live = {p.data_ptr() for p in st.params}
-        lib, fam_jobs, nbytes = self.lib, {"w4f": [], "w2d": []}, 0.0
+        lib, fam_jobs = self.lib, {"w4f": [], "w2d": []}
         for key, (src, (fam, floats, rows, cols, tile, dgrad)) in self._wjobs.items():
             if src.data_ptr() not in live or (dgrad and not need_grad):
                 continue
@@ -1166,16 +1166,15 @@ class Runner:
             if ent is not None and ent[0] == sig:
                 continue
             t = _empty(floats, src.device)
-            fam_jobs[fam].append(_lib.WtJob(src.data_ptr(), t.data_ptr(), rows, cols, tile, dgrad))
-            nbytes += 4.0 * (src.numel() + floats)
+            fam_jobs[fam].append((_lib.WtJob(src.data_ptr(), t.data_ptr(), rows, cols, tile, dgrad), 4.0 * (src.numel() + floats)))
             self._wc[key] = (sig, t)
             self.wcache_builds += 1
         for fam, fn in (("w4f", lib.cvk_wino4f_weight_transform_batch), ("w2d", lib.cvk_w2d_weight_transform_batch)):
             jobs = fam_jobs[fam]
             for i in range(0, len(jobs), _lib.WT_BATCH_MAX):
                 chunk = jobs[i:i + _lib.WT_BATCH_MAX]
-                arr = (_lib.WtJob * len(chunk))(*chunk)
-                _timed(self, "k_weight_transform_batch", nbytes / max(1, len(fam_jobs["w4f"]) + len(fam_jobs["w2d"])) * len(chunk),
+                arr = (_lib.WtJob * len(chunk))(*[j for j, _ in chunk])
+                _timed(self, "k_weight_transform_batch", sum(b for _, b in chunk),           # filter read + transformed filter written
                        lambda: check(fn(ctypes.addressof(arr), len(chunk), st.stream), "cvk_%s_weight_transform_batch" % fam), "byte")
 
     def prepack_bf16(self, plan, st, need_grad):

@@ -180,7 +180,7 @@ def test_bench_json_contract_single_gpu():
     assert rf["algorithmic_tflops"] >= rf["achieved"] and 0 < rf["executed_share_of_algorithmic_flops"] <= 1.0
     assert all(0 < v["executed_frac_of_peak"] <= 1.0 for v in d["conv_kernels"].values())
     hk = d["hbm_kernels"]
-    for name in ("k_bn_relu_apply", "k_w2d_input", "k_w2d_output", "k_w2d_weight", "k_ce_fwd", "k_ce_bwd", "k_bilinear_fwd"):
+    for name in ("k_bn_relu_apply", "k_w2d_input", "k_w2d_output", "k_weight_transform_batch", "k_ce_fwd", "k_ce_bwd", "k_bilinear_fwd"):
         assert name in hk and 0 < hk[name]["frac_of_8TBps"] <= 1.0, name
     assert "k_conv3x3_wino4f" in d["conv_kernels"]          # the fused F(4,3) kernel carries the 64/128-channel levels
     assert "configs[1]" in d["config"]["workload"]
