@@ -966,7 +966,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_bf16s(const __bf16* __restrict
 // its partner gets the leftovers and then runs alone.  PRIO alternates s_setprio per halo row between the column halves so that both
 // advance together (with all DMA pieces in the first rows this measured no gain; with the pieces spread over rows 0-5 it is worth 1.7 %:
 // 4.92 against 5.01 ms for the weight-grads of the UNet layer set, CVK_WGRAD_PRIO=0 switches it off).
-template <int DBG = 0, bool PRIO = true>      // DBG (timing experiments, see the launcher): s_memtime stamps of workgroup 0, waves 0 and 4 -> behind the slabs
+template <int DBG = 0, bool PRIO = true, bool NTS = false>      // DBG (timing experiments, see the launcher): s_memtime stamps of workgroup 0, waves 0 and 4 -> behind the slabs
 __global__ __launch_bounds__(512, 2) void k_wgrad_bf16r(const __bf16* __restrict__ X, const __bf16* __restrict__ DY,
                                                        float* __restrict__ slab, int H, int W, int ldx, int ld_dy, int Cout,
                                                        int Cin, int tilesX, int tilesY, int ntiles, int tiles_per_split,
@@ -1277,7 +1277,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_bf16r(const __bf16* __restrict
                     const int i = 4 * g + j;
                     const int co = cob * 64 + wco * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
                     const float v = acc[t][i] + o[j];
-                    if (co < Cout && ci < Cin) out[((size_t)co * 9 + t) * Cin + ci] = v;
+                    if (co < Cout && ci < Cin) { if (NTS) __builtin_nontemporal_store(v, &out[((size_t)co * 9 + t) * Cin + ci]); else out[((size_t)co * 9 + t) * Cin + ci] = v; }
                 }
             }
         }
@@ -1360,7 +1360,11 @@ static int wgrad_bf16s_launch_slabs(const void* x, const void* dy, void* workspa
         }
         return 1;          // timing experiment: no reduction, the slabs hold wrong numbers
     }
-    if (rowst && dbg == 0) {
+    static const int nts = getenv("CVK_STREAM_HINTS") ? atoi(getenv("CVK_STREAM_HINTS")) : 5;      // 0: no streaming hints (A/B timing)
+    if (rowst && dbg == 0 && nts >= 5 && wprio && p.splits > 1) {
+        hipLaunchKernelGGL((k_wgrad_bf16r<0, true, true>), dim3(nblk * p.splits), dim3(512), 0, s, (const __bf16*)x, (const __bf16*)dy, (float*)workspace,
+                           H, W, ldx, ld_dy, Cout, Cin, cvk_cdiv(W, TW), cvk_cdiv(H, TH), p.ntiles, p.tps, p.nblk_ci, nblk);
+    } else if (rowst && dbg == 0) {
         if (wprio) CVK_WGR_LAUNCH(0, true); else CVK_WGR_LAUNCH(0, false);
     } else
 #undef CVK_WGR_LAUNCH_UNUSED
