@@ -174,7 +174,8 @@ def kernel_profile(step, dev, nprof=3):
     tp = tp[0] if tp else ""
     if os.path.exists(tp):
         for k, v in json.load(open(tp)).items():
-            if k.replace(" ", "") == dom[0].replace(" ", ""):
+            kk, dd = k.replace(" ", ""), dom[0].replace(" ", "")
+            if kk == dd or (dd.endswith(">") and kk.startswith(dd[:-1] + ",")) or (not dd.endswith(">") and kk.startswith(dd + "<")):
                 traffic = {"bytes_per_launch": (v["read_MB_per_launch"] + v["write_MB_per_launch"]) * 1e6,
                            "source": "profiles/" + os.path.basename(tp) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                                      "FETCH doubled per MI355X_MICROARCH.md; recorded run, not this run)"}
