@@ -142,6 +142,14 @@ def _world1_worker(rank, port, out_path):
         lb = lossf(ref(xi), ti); lb.backward()
         ok = ok and la.item() == lb.item() and all(torch.equal(p.grad, q.grad) for p, q in zip(net.parameters(), ref.parameters()))
     res["graph_equal"] = bool(ok)
+    # bf16 mode under the same wrapper: the weight-gradient slab reductions and conv-bias sums of a bucket are deferred and must be
+    # flushed BEFORE the bucket's all-reduce is issued (Runner.grads_ready) — bitwise the plain step again
+    A.set_conv_precision(net, "bf16"); A.set_conv_precision(ref, "bf16")
+    for p in list(net.parameters()) + list(ref.parameters()):
+        p.grad = None
+    lossf(ref(x), t).backward()
+    lossf(wrapped(x), t).backward()
+    res["bf16_equal"] = all(torch.equal(p.grad, q.grad) for p, q in zip(net.parameters(), ref.parameters()))
     torch.cuda.synchronize()
     with open(out_path, "w") as f:
         json.dump(res, f)
@@ -161,7 +169,7 @@ def test_world1_rccl_group_eager_and_captured_step():
         res = json.load(open(out))
     assert res["env"]["NCCL_MAX_NCHANNELS"] is not None and res["env"]["CVK_DP_RESERVE_CUS"] == res["env"]["NCCL_MAX_NCHANNELS"]
     assert res["reserve"] > 0 and res["buckets"] >= 4
-    assert res["eager_equal"] and res["graph_equal"], res
+    assert res["eager_equal"] and res["graph_equal"] and res["bf16_equal"], res
 
 
 def test_bench_dp_overhead_line():
