@@ -494,8 +494,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv_bf16s_strip(const __bf
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
         // A B fragment (halo row hr, column shift dx, k-step ks) serves the up to three output rows hr - dy of this wave, so a
-        // wave reads (TP+2)*3*NK fragments for its 9*NK*TP MFMAs — LDS bandwidth (128 B/clk/CU: one fragment read per MFMA
-        // from all four SIMDs is exactly the MFMA rate) stops being the co-limiter.  hr is the inner index, so consecutive
+        // wave reads (TP+2)*3*NK fragments for its 9*NK*TP MFMAs — the fragment-read rate of one in-order wave per SIMD (~18 cycles of
+        // issue per ds_read_b128 beside its own MFMAs: about half the 256 B/clk/CU of the LDS array) stops being the co-limiter.  hr is the inner index, so consecutive
         // MFMAs rotate through the accumulators.  Nothing but the instruction order hides the LDS latency within a wave: the
         // read of fragment i+1 is pinned (sched_barrier) in front of the MFMAs of fragment i.
         constexpr int NF = 3 * NK * (TP + 2);
