@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_bf16r(const __bf16* __restrict
     auto rd_half = [&](const char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p); };
     auto frag = [&](s16x4 lo, s16x4 hi) { return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)); };
     // Two barriers per tile, neither followed by a cold start.  X, before halo row 8: every wave's DMA pieces of tile t + 1 have landed
-    // (issued in rows 0-1, ~4000 cycles earlier).  Behind it rows 8 and 9 still run on fragments already in registers, and row 9 requests
+    // (issued in rows 0-5).  Behind it rows 8 and 9 still run on fragments already in registers, and row 9 requests
     // the row-0 fragments of tile t + 1 from the other stage.  Y, at the tile end: every wave is through with the LDS reads of tile t, the
     // DMA of tile t + 2 may overwrite it — and tile t + 1 starts multiplying at once (with one barrier at the tile end the first
     // fragment reads came after it: ~300 idle cycles per tile on every SIMD).
