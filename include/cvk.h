@@ -381,6 +381,10 @@ int cvk_conv3x3_bf16s(const void* x, const void* w, const float* bias, void* y, 
  * bitwise independent of the cap. */
 int cvk_conv3x3_bf16s_wg(const void* x, const void* w, const float* bias, void* y, float* stats, float* counts,
                       int N, int H, int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream);
+/* which kernel the two calls above run for a layer geometry (a query of their dispatch, no launch; measurement tools label their
+ * timings with the name a kernel trace shows): 0 k_conv_bf16s (tile kernel), 1 k_conv_bf16q, 2 k_conv_bf16h, 3 k_conv_bf16h on the
+ * 128-row weight pack, 4 k_conv_bf16s_strip, 5 two k_conv_bf16s_strip passes (64 -> 128 channels without statistics); < 0: bad shape */
+int cvk_conv3x3_bf16s_kernel(int N, int H, int W, int Cin, int Cout, int with_stats);
 int cvk_bn_finalize_counts(const float* stats, const float* counts, int P, int M, int C, const float* gamma, const float* beta,
                            float* mean, float* rstd, float* scale, float* shift, float* running_mean, float* running_var,
                            int64_t* num_batches_tracked, float momentum, float eps, void* workspace, size_t workspace_bytes,

@@ -145,6 +145,7 @@ SIGNATURES = {
     "cvk_pack_weights_bf16_batch": (c_int, [c_vp, c_int, c_vp]),          # jobs: host array of PackJob
     "cvk_conv3x3_bf16s": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_bf16s_wg": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_conv3x3_bf16s_kernel": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "cvk_bn_finalize_counts": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                        c_float, c_float, c_vp, c_size, c_vp]),
     "cvk_conv3x3_wgrad_bf16s_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),

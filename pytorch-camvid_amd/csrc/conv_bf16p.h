@@ -11,9 +11,11 @@ constexpr int CK = 32;              // input channels per K slice
 
 // Layers the ping-pong kernel serves (the weight pack for them is tile-major, see k_pack_w_pp): more than 64 output channels
 // (a full 128-row weight tile) and at least 128 input channels (>= 4 slices: the K loop amortises prologue and epilogue).
-// A function of the channel counts only — the pack functions have no geometry.  CVK_BF16P=0 switches it off (A/B timing).
+// A function of the channel counts only — the pack functions have no geometry.
 bool serves(int Cin, int Cout);
 int kind(int Cin, int Cout);        // 0: not served, 1: 128 output channels per workgroup, 2: 64
+// the kernel launch() runs for a layer geometry: 0 not served, 1 k_conv_bf16q, 2 k_conv_bf16h, 3 k_conv_bf16h on the 128-row pack
+int choose(int N, int H, int W, int Cin, int Cout);
 
 int stat_partials(int N, int H, int W);
 

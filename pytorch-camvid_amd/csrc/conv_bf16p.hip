@@ -8,7 +8,7 @@
 // reads, the counted vmcnt wait, 16 MFMAs, the barrier — and its SIMD partner is a wave of ANOTHER workgroup in a random phase:
 // the two collide on the pipe or leave it idle together.  Here the partner is chosen and the alternation is forced:
 //   * one workgroup = 8 waves = TWO groups of four (waves w and w+4 share a SIMD), one workgroup per CU;
-//   * an interval between two s_barriers is group A's MFMA phase (16 x v_mfma_f32_32x32x16_bf16 = 512 matrix cycles, nothing
+//   * an interval between two s_barriers is group A's MFMA phase (32 x v_mfma_f32_16x16x32_bf16 = 512 matrix cycles, nothing
 //     else in the stream, s_setprio 1) and group B's LOAD phase (its DMA pieces, the twelve ds_read_b128 of ITS next step, the
 //     waits), then the roles swap: the pipe of every SIMD always has exactly one wave's MFMAs queued;
 //   * both groups multiply the SAME weight tile (128 output channels x 32 input channels of one tap) with pixel rows of their own
@@ -19,10 +19,8 @@
 //     instead of sixteen 64-byte row fragments, and the address of step s is base + 8192 s;
 //   * LDS: two halo slabs (18 x 34 pixels x 64 B, 40 KiB each: slice cs+1 lands during slice cs) + a ring of D+1 weight tiles
 //     (D = steps a tile is requested ahead of its first read); counted s_waitcnt vmcnt, raw s_barrier, DMA from inline asm.
-// Swizzles as in conv_bf16s.hip: 16-byte chunk c of halo pixel column hx at position c ^ ((hx>>2)&3) of its 64-byte row,
-// weights row n at c ^ ((n>>2)&3): every ds_read_b128 is bank-conflict free for all nine tap shifts (a halo row is 34 x 64 B =
-// 8.5 bank rows: all lanes of one read share the halo row, so the half-row phase is common to them).
-#include <stdlib.h>
+// Swizzle (weights: row n; pixels: halo column hx): 16-byte chunk c of a 64-byte row at position c ^ (2 * ((row >> 2) & 1)).
+// Environment switches and in-kernel time stamps exist only in the experiments build (cvk_common.h cvk_knob, `make experiments`).
 #include <type_traits>
 #include "cvk_common.h"
 #include "lds_dma.h"
@@ -86,292 +84,11 @@ template <int IMM> __device__ __forceinline__ void dma16_buf_i(unsigned voff, i3
     asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base), "n"(IMM) : "memory", "scc");
 }
 
-// Weights are requested D = 2 steps ahead of their first read into a ring of three tiles: 9 steps per slice, so the slot of a
-// step is a compile-time constant of the unrolled slice body and every fragment read is lane base + immediate.
-// STATS: BatchNorm statistics partials.  DBG (timing experiments only, wrong results): 1 = no DMA in the K loop, 2 = no MFMAs,
-// 4 = no fragment reads, 8 = s_memtime stamps of workgroup 0 -> `stats`.  VAR: 1 = no s_setprio.
-template <bool STATS, int DBG, int VAR = 0>
-__global__ __launch_bounds__(512, 2) void k_conv_bf16p(const __bf16* __restrict__ X, const char* __restrict__ Wp,
-                                                      const float* __restrict__ bias, __bf16* __restrict__ Y,
-                                                      float* __restrict__ stats, float* __restrict__ cnt, int H, int W, int Cin,
-                                                      int Cout, int ldy, int tilesX, int tilesY, int tilesN, int P) {
-    constexpr int D = 2, RING = 3;
-    constexpr int RING_BYTES = RING * BTAP;                       // [0, 24 KiB): weight ring; then the two slabs
-    constexpr int MAIN_BYTES = RING_BYTES + 2 * SLAB_BYTES;
-    constexpr int STAT_BYTES = BN * 128 * 2 * 4;      // epilogue: the staged output tile [512 px][256 B], then [channel][128 partials][sum, sumsq]
-    constexpr int STAMP_BYTES = (DBG & 8) ? 8 * 48 * 8 * 4 : 0;   // DBG 8: s_memtime stamps of the first 48 steps of workgroup 0 -> `stats`
-    constexpr int LDS_BYTES = (MAIN_BYTES > STAT_BYTES ? MAIN_BYTES : STAT_BYTES) + STAMP_BYTES;
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
-    const unsigned smem_addr = cvk_lds_addr(smem);
-
-    unsigned long long ct0 = 0, ct1 = 0, ct2 = 0;   // DBG 16: s_memrealtime (100 MHz) at kernel start / after the prologue / after the K loop / at the end
-    if (DBG & 16) ct0 = __builtin_amdgcn_s_memrealtime();
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int grp = wave >> 2;                 // 0: tile rows 0..7, 1: rows 8..15; waves w and w + 4 share a SIMD
-    const int wc = wave & 1, wp = (wave >> 1) & 1;
-    const int row0 = grp * 8 + wp * 4;         // this wave's first tile row (four rows x 32 pixels x 64 output channels)
-
-    // ---- which tile: output-channel tiles innermost, XCD-contiguous chunks of the logical order ------------------------------
-    const int gid = cvk_xcd_remap(blockIdx.x, gridDim.x);
-    const int nt = gid % tilesN;
-    const int sp = gid / tilesN;                        // spatial tile = statistics partial index
-    const int tx = sp % tilesX;
-    const int ty = (sp / tilesX) % tilesY;
-    const int img = sp / (tilesX * tilesY);
-    const int x0 = tx * TW, y0 = ty * TH, n0 = nt * BN;
-    const int ncs = Cin / CK, nsteps = ncs * 9;
-
-    // ---- DMA sources ---------------------------------------------------------------------------------------------------------
-    // slab piece t (0..4) of this wave = piece 8t + wave: LDS rows 16 (8t + wave) + lane/4, 16-byte position lane % 4
-    unsigned aoff[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-        const int row = (8 * t + wave) * 16 + (lane >> 2);
-        const int hy = row / HP, hx = row - hy * HP;
-        const int chunk = (lane & 3) ^ ((hx >> 2) & 3);
-        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-        const bool ok = (row < SLAB_ROWS) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
-        aoff[t] = ok ? (unsigned)((iy * W + ix) * Cin + chunk * 8) * 2u : 0x80000000u;     // bytes; past the end: reads 0
-    }
-    const uintptr_t xbase = (uintptr_t)(X + (size_t)img * H * W * Cin);      // raw buffer over this image: base, stride 0, bytes, flags
-    i32x4 xrsrc;
-    xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xbase);
-    xrsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xbase >> 32) & 0xFFFF);
-    xrsrc[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)(H * W * Cin) * 2u));
-    xrsrc[3] = 0x00020000;
-    // the tile's weight stream: step s (= 9 cs + tap) is the 8 KiB at s * BTAP; this wave moves piece `wave` of every step
-    const unsigned wvoff = wave * 1024 + lane * 16;
-    const char* wnext = Wp + (size_t)nt * nsteps * BTAP;          // scalar: the tile of the next step to request
-
-    auto dma_slab_piece = [&](int t, int cs, unsigned slab_addr) { dma16_buf(aoff[t], xrsrc, (unsigned)cs * (CK * 2), slab_addr + (8 * t + wave) * 1024); };
-    auto dma_weights_next = [&](int slot, int s) {      // request step s into ring slot `slot`; past the end the last step is re-loaded
-        dma16_saddr(wvoff, wnext, smem_addr + slot * BTAP + wave * 1024);
-        if (s < nsteps - 1) wnext += BTAP;
-    };
-
-    // ---- operand read addresses (LDS byte offsets) ---------------------------------------------------------------------------------
-    // weights (MFMA A operand): row n = wc*64 + tc*32 + r, k-chunk 2kk + h at position (2kk + h) ^ ((n>>2)&3); slot, tc: immediates
-    const int nrow = wc * 64 + r;
-    int wa[2];
-    wa[0] = nrow * 64 + ((h ^ ((nrow >> 2) & 3)) << 4);
-    wa[1] = wa[0] ^ 32;
-    // pixels (MFMA B operand): tile row row0 + tp, tap (dy, dx): halo row row0 + tp + dy, halo column r + dx; rows: immediates
-    int pb[3][2];
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-        pb[dx][0] = RING_BYTES + row0 * (HP * 64) + (r + dx) * 64 + ((h ^ (((r + dx) >> 2) & 3)) << 4);
-        pb[dx][1] = pb[dx][0] ^ 32;
-    }
-    int pb_flip = SLAB_BYTES;                 // added to pb[][] at the end of a slice (alternating sign): the other slab
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-
-    // ---- prologue: slab of slice 0, weight tiles of steps 0 and 1 ----------------------------------------------------------------
-#pragma unroll
-    for (int t = 0; t < 5; ++t) dma_slab_piece(t, 0, smem_addr + RING_BYTES);
-    dma_weights_next(0, 0);
-    dma_weights_next(1, 1);
-    cvk_wait_vm<D - 1>();                      // everything but the weights of step 1 has landed
-    phase_barrier();
-    if (DBG & 16) ct1 = __builtin_amdgcn_s_memrealtime();
-    if (grp == 1) phase_barrier();             // group B runs one interval behind group A
-
-    int step = 0;
-    for (int cs = 0; cs < ncs; ++cs) {
-        const unsigned slab_next = smem_addr + RING_BYTES + ((cs + 1) & 1) * SLAB_BYTES;
-        const int csn = min(cs + 1, ncs - 1);     // past the end the last slice is re-loaded into the buffer nobody reads
-#pragma unroll
-        for (int sidx = 0; sidx < 9; ++sidx, ++step) {
-            // ======== LOAD phase (the other group's MFMA phase): scalar instructions, DMA issue, fragment reads, waits =============
-            unsigned long long tm0 = 0, tm1 = 0, tm3 = 0, tm4 = 0, tm5 = 0, tm6 = 0;
-            if (DBG & 8) tm0 = __builtin_amdgcn_s_memtime();
-            if (!(DBG & 1)) {
-                dma_weights_next((sidx + D) % RING, step + D);
-                if (sidx < 5) dma_slab_piece(sidx, csn, slab_next);
-            }
-            if (DBG & 8) { tm1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-            const int dy = sidx / 3, dx = sidx % 3, slot = sidx % RING;
-            bf16x8 a[2][2], b[4][2];
-            if (!(DBG & 4)) {
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                    for (int tc = 0; tc < 2; ++tc) a[tc][kk] = lds_read16(smem + (wa[kk] + slot * BTAP + tc * 32 * 64));
-#pragma unroll
-                    for (int tp = 0; tp < 4; ++tp) b[tp][kk] = lds_read16(smem + (pb[dx][kk] + (tp + dy) * (HP * 64)));
-                }
-            } else {
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                    for (int tc = 0; tc < 2; ++tc) asm volatile("" : "=v"(a[tc][kk]));
-#pragma unroll
-                    for (int tp = 0; tp < 4; ++tp) asm volatile("" : "=v"(b[tp][kk]));
-                }
-            }
-            // the fragments are in registers (this step's ring slot and slab rows may be refilled from the next interval on), and
-            // everything this wave requested before this phase has landed (its piece of the weights of step + 1)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (DBG & 8) { __builtin_amdgcn_sched_barrier(0); tm3 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-            if (!(DBG & 1)) {
-                if (sidx < 5) cvk_wait_vm<2>(); else cvk_wait_vm<1>();
-            }
-            if (DBG & 8) { __builtin_amdgcn_sched_barrier(0); tm4 = __builtin_amdgcn_s_memtime(); }
-            phase_barrier();
-            if (DBG & 8) { tm5 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-            // ======== MFMA phase ====================================================================================================
-            if (!(VAR & 1)) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-                    for (int tp = 0; tp < 4; ++tp) {
-                        if (!(DBG & 2)) acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tc][kk], b[tp][kk], acc[tc][tp], 0, 0, 0);
-                        else asm volatile("" :: "v"(a[tc][kk]), "v"(b[tp][kk]));
-                    }
-            if (sidx == 8) {                   // the next slice reads the other slab
-#pragma unroll
-                for (int dx2 = 0; dx2 < 3; ++dx2) { pb[dx2][0] += pb_flip; pb[dx2][1] += pb_flip; }
-                pb_flip = -pb_flip;
-            }
-            if (!(VAR & 1)) __builtin_amdgcn_s_setprio(0);
-            if (DBG & 8) {
-                __builtin_amdgcn_sched_barrier(0);
-                tm6 = __builtin_amdgcn_s_memtime();
-                if (blockIdx.x == 0 && step < 48 && lane == 0) {
-                    unsigned* p = reinterpret_cast<unsigned*>(smem + MAIN_BYTES) + (wave * 48 + step) * 8;
-                    p[0] = (unsigned)tm0; p[1] = (unsigned)tm1; p[2] = (unsigned)tm3; p[3] = (unsigned)tm4; p[4] = (unsigned)tm5; p[5] = (unsigned)tm6;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            phase_barrier();
-        }
-    }
-    if (grp == 0) phase_barrier();      // group A's last barrier pairs with group B's last MFMA phase
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // tail DMAs landed: LDS is reused below
-    phase_barrier();
-    if (DBG & 16) ct2 = __builtin_amdgcn_s_memrealtime();
-    if ((DBG & 8) && blockIdx.x == 0 && stats != nullptr) {
-        const unsigned* p = reinterpret_cast<const unsigned*>(smem + MAIN_BYTES);
-        for (int i = tid; i < 8 * 48 * 8; i += 512) reinterpret_cast<unsigned*>(stats)[i] = p[i];
-    }
-
-    // ---- epilogue ----------------------------------------------------------------------------------------------------------------
-    // acc[tc][tp][i]: output channel n0 + wc*64 + tc*32 + (i&3) + 8*(i>>2) + 4*h, pixel (y0 + row0 + tp, x0 + r).
-    // A lane holds 4 consecutive channels (8 bytes) of 32 pixels that lie 2 ldy bytes apart: stored from here, a wave instruction
-    // is 32 scattered 16-byte pieces and the epilogue is store-issue bound (measured: 15-19 us per tile with every CU in its epilogue,
-    // against 24 us for the whole K loop of a 128-channel layer, tools/coarse_bf16p.py).  So the tile is transposed through LDS (dead by
-    // now): [512 pixels][256 B], 16-byte chunk c of pixel p at position c ^ (p & 15) (conflict-free both ways), and leaves as
-    // 16 bytes per lane, 256 contiguous bytes per pixel, 1 KiB per wave instruction.
-    const int px = x0 + r;
-    const bool colok = px < W;
-    float s[2][16], q[2][16];
-#pragma unroll
-    for (int tc = 0; tc < 2; ++tc) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int co = n0 + wc * 64 + tc * 32 + 8 * g + 4 * h;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (bias != nullptr && co < Cout) bv = *reinterpret_cast<const f32x4*>(bias + co);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { s[tc][4 * g + j] = 0.f; q[tc][4 * g + j] = 0.f; }
-#pragma unroll
-            for (int tp = 0; tp < 4; ++tp) {
-                const bool ok = colok & (y0 + row0 + tp < H);
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[tc][tp][4 * g + j] + bv[j];
-                if (STATS) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float vm = ok ? v[j] : 0.f;
-                        s[tc][4 * g + j] += vm;
-                        q[tc][4 * g + j] += vm * vm;
-                    }
-                }
-                const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                const int p = (row0 + tp) * 32 + r, chunk = wc * 8 + tc * 4 + g;
-                *reinterpret_cast<bf16x4*>(smem + p * 256 + ((chunk ^ (p & 15)) << 4) + 8 * h) = o;
-            }
-        }
-    }
-    __syncthreads();
-    {
-        // wave w stores tile rows 2w, 2w + 1: 16 instructions of 4 pixels x 256 B
-        const int chunk = lane & 15, co = n0 + chunk * 8;
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int p = wave * 64 + it * 4 + (lane >> 4);
-            const int py = y0 + (p >> 5), pxx = x0 + (p & 31);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(smem + p * 256 + ((chunk ^ (p & 15)) << 4));
-            if ((py < H) & (pxx < W) & (co < ldy))
-                *reinterpret_cast<f32x4*>(Y + ((size_t)(img * H + py) * W + pxx) * ldy + co) = v;
-        }
-    }
-    if ((DBG & 16) && stats != nullptr) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const unsigned long long ct3 = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0) {
-            unsigned long long* o = reinterpret_cast<unsigned long long*>(stats) + (size_t)blockIdx.x * 4;
-            o[0] = ct0; o[1] = ct1; o[2] = ct2; o[3] = ct3;
-        }
-    }
-    if (!STATS) return;
-    // Statistics: a lane holds (sum, sum of squares) of 32 channels over its 4 tile rows; the 16 lanes of a DPP row hold the same
-    // channels for 16 pixel columns.  Four DPP adds per value (quad butterflies, half-row mirror, row mirror: a fixed tree) leave the
-    // row total in every lane of the row — 256 vector instructions instead of a 128 KiB round trip through LDS with fp64 adds
-    // (measured: 5.5 us of a 34 us tile).  8 partials per channel (2 rows x 4 waves) meet in LDS and are combined in fp64 in a fixed order.
-    __syncthreads();                    // the staged tile has been read: the partials overlay it
-#pragma unroll
-    for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            s[tc][i] = row_sum16(s[tc][i]);
-            q[tc][i] = row_sum16(q[tc][i]);
-        }
-    float2* const red = reinterpret_cast<float2*>(smem);          // [channel 128][partial 8]
-    if ((lane & 15) == 0) {
-        const int part = (grp * 2 + wp) * 2 + ((lane >> 4) & 1);
-#pragma unroll
-        for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int ch = wc * 64 + tc * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                red[ch * 8 + part] = float2{s[tc][i], q[tc][i]};
-            }
-    }
-    __syncthreads();
-    if (tid < BN) {
-        double S = 0.0, Q = 0.0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { const float2 v = red[tid * 8 + i]; S += (double)v.x; Q += (double)v.y; }
-        const int co = n0 + tid;
-        const int nvalid = min(TH, H - y0) * min(TW, W - x0);
-        if (co < Cout) {
-            const double m2 = Q - S * S / (double)nvalid;
-            stats[(size_t)sp * Cout + co] = (float)S;
-            stats[(size_t)(P + sp) * Cout + co] = (float)(m2 > 0.0 ? m2 : 0.0);
-        }
-        if (nt == 0 && tid == 0) cnt[sp] = (float)nvalid;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------- the same on v_mfma_f32_16x16x32_bf16
-// MI355X_MICROARCH.md (DVFS give-back, item 7): in MFMA-bound bf16 loops on random data the chip holds a higher clock on the
-// 16x16x32 shape than on 32x32x16 at equal cycles per FLOP (measured there: 1.12-1.15x the FLOP/s).  Same phases, same LDS budget,
-// same DMA; what changes is the fragment geometry:
+// The kernels below run v_mfma_f32_16x16x32_bf16.  MI355X_MICROARCH.md (DVFS give-back, item 7): in MFMA-bound bf16 loops on random data
+// the chip holds a higher clock on the 16x16x32 shape than on 32x32x16 at equal cycles per FLOP (measured there: 1.12-1.15x the FLOP/s; here
+// +7-8 % wall on every layer against round 4's first ping-pong kernel on 32x32x16, which was removed in round 5 — git history: k_conv_bf16p).
+// Weights are requested D = 2 steps ahead of their first read into a ring of three tiles: 9 steps per slice, so the slot of a step is a
+// compile-time constant of the unrolled slice body and every fragment read is lane base + immediate.  Fragment geometry:
 //   * a fragment is 16 rows x 32 k = ONE ds_read_b128 per lane for the whole K slice (lane: row l15 = lane & 15, 16-byte chunk
 //     q4 = lane >> 4 of the 64-byte row): 4 weight + 8 pixel fragments and 32 MFMAs (16 cycles each) per step — the same 12 reads
 //     and 512 matrix cycles — and ONE lane address per operand and column shift (no k-half variants);
@@ -723,7 +440,7 @@ constexpr int HROW = 3 * HBN * 64;               // 12 KiB: the weight tiles of 
 // P128: the weights come in the 128-row tile-major pack of k_conv_bf16q (layers with > 64 output channels whose tile count fills the chip
 // badly with 128-channel tiles, e.g. 512 channels at 90x120: 384 tiles = 1.5 rounds of 256 CUs, 768 half-width tiles = 3): this workgroup's
 // 64 rows are one half of every 8 KiB tap tile — three 4 KiB pieces 8 KiB apart instead of 12 contiguous KiB, still scalar-addressed.
-template <bool STATS, int DBG = 0, bool P128 = false>     // DBG 1: s_memrealtime stamps of workgroup 0's first 16 tiles -> `stats` (timing experiments only)
+template <bool STATS, int DBG = 0, bool P128 = false>     // DBG 1 (instantiated in the experiments build only): s_memrealtime stamps of workgroup 0's first 16 tiles -> `stats`
 __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict__ X, const char* __restrict__ Wp,
                                                       const float* __restrict__ bias, __bf16* __restrict__ Y,
                                                       float* __restrict__ stats, float* __restrict__ cnt, int H, int W, int Cin,
@@ -1121,20 +838,15 @@ __global__ void k_pack_batch(const PackJobsDev jobs) {
 namespace cvk_bf16p {
 
 int kind(int Cin, int Cout) {
-    static const int on = getenv("CVK_BF16P") ? atoi(getenv("CVK_BF16P")) : 1;
-    static const int minci = getenv("CVK_BF16P_MINCI") ? atoi(getenv("CVK_BF16P_MINCI")) : 64;
-    static const int h64 = getenv("CVK_BF16P_H64") ? atoi(getenv("CVK_BF16P_H64")) : 1;
+    const int on = cvk_knob("CVK_BF16P", 1);             // experiments build: 0 = the round-2/3 tile kernels of conv_bf16s.hip for every layer
+    const int minci = cvk_knob("CVK_BF16P_MINCI", 64);
+    const int h64 = cvk_knob("CVK_BF16P_H64", 1);
     if (!on || Cin < minci || Cin % CK != 0) return 0;
     if (Cout > 64) return 1;
     return (h64 && Cout > 32) ? 2 : 0;
 }
 
 bool serves(int Cin, int Cout) { return kind(Cin, Cout) != 0; }
-
-static int mfma_shape() {          // 16: v_mfma_f32_16x16x32_bf16 (k_conv_bf16q), 32: v_mfma_f32_32x32x16_bf16 (k_conv_bf16p)
-    static const int mf = getenv("CVK_BF16P_MF") ? atoi(getenv("CVK_BF16P_MF")) : 16;
-    return mf == 32 ? 32 : 16;
-}
 
 int stat_partials(int N, int H, int W) { return N * cvk_cdiv(H, TH) * cvk_cdiv(W, TW); }
 
@@ -1145,7 +857,7 @@ void pack(const float* w, void* out, int Cout, int Cin, int Kpad, bool dgrad, hi
     const int ntile = cvk_cdiv(rows, bn), ncs = Kpad / CK;
     const size_t total = (size_t)ntile * ncs * 9 * bn * CK;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_pack_w_pp, dim3(blocks), dim3(256), 0, s, w, (__bf16*)out, Cout, Cin, ntile, ncs, dgrad ? 1 : 0, (k == 2 || mfma_shape() == 16) ? 1 : 0, bn);
+    hipLaunchKernelGGL(k_pack_w_pp, dim3(blocks), dim3(256), 0, s, w, (__bf16*)out, Cout, Cin, ntile, ncs, dgrad ? 1 : 0, 1, bn);
 }
 
 void pack_batch(const cvk_pack_job* jobs, int n, hipStream_t s) {
@@ -1159,7 +871,7 @@ void pack_batch(const cvk_pack_job* jobs, int n, hipStream_t s) {
         o.w = q.w; o.out = (__bf16*)q.out; o.Cout = q.Cout; o.Cin = q.Cin; o.Kpad = q.Kpad; o.dgrad = q.dgrad ? 1 : 0;
         o.ncs = q.Kpad / CK;
         if (k != 0) {
-            o.mode = 2; o.bn = k == 2 ? HBN : BN; o.mf16 = (k == 2 || mfma_shape() == 16) ? 1 : 0;
+            o.mode = 2; o.bn = k == 2 ? HBN : BN; o.mf16 = 1;
             o.total = (unsigned long long)cvk_cdiv(rows, o.bn) * o.ncs * 9 * o.bn * CK;
         } else {
             o.mode = q.dgrad ? 1 : 0; o.bn = 0; o.mf16 = 0;
@@ -1172,78 +884,65 @@ void pack_batch(const cvk_pack_job* jobs, int n, hipStream_t s) {
     hipLaunchKernelGGL(k_pack_batch, dim3(bx > 0 ? bx : 1, n), dim3(256), 0, s, d);
 }
 
+static int device_cus() {
+    static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 0 ? n : 256; }();
+    return cus;
+}
+
+int choose(int N, int H, int W, int Cin, int Cout) {
+    const int knd = kind(Cin, Cout);
+    if (knd != 1) return knd;
+    // 128-channel tiles that fill the chip badly (e.g. 384 tiles = 1.5 rounds of 256 CUs): the 64-channel kernel on the same pack
+    // (twice the tiles; its K loop and its doubled weight traffic cost a few per cent: it must win 10 % in balance; measured: 1380 tiles -> 2760 is a wash, 384 -> 768 gains 8-9 %)
+    const int h128 = cvk_knob("CVK_BF16P_H128", 1);
+    const int wg = device_cus();          // NOT the data-parallel cap: the choice (and with it the statistics' summation order) must not depend on it
+    const int tilesX = cvk_cdiv(W, TW), tilesY = cvk_cdiv(H, TH);
+    const long t1 = (long)N * tilesX * tilesY * cvk_cdiv(Cout, BN), t2 = (long)N * tilesX * tilesY * cvk_cdiv(Cout, HBN);
+    const double e1 = (double)t1 / ((double)cvk_cdiv(t1, wg) * wg), e2 = (double)t2 / ((double)cvk_cdiv(t2, wg) * wg);
+    return (h128 == 2 || (h128 == 1 && Cout % HBN == 0 && e2 * 0.90 > e1)) ? 3 : 1;
+}
+
 void launch(const void* x, const void* wpp, const float* bias, void* y, float* stats, float* counts, int N, int H, int W, int Cin,
             int Cout, int ldy, hipStream_t s, int max_workgroups) {
-    int knd = kind(Cin, Cout);
     // streaming hint on the result stores (csrc/elem_bf16.hip: the result is read once by the pass that follows and must not push the
     // input tiles and weights the neighbouring tiles still need out of L2): +0.9 % on configs[3] (190.9 -> 192.6 img/s, interleaved runs)
-    static const int nts_cfg = getenv("CVK_STREAM_HINTS") ? atoi(getenv("CVK_STREAM_HINTS")) : 5;
-    const int nts = nts_cfg >= 1 ? 1 : 0;
+    const int nts = cvk_knob("CVK_STREAM_HINTS", 5) >= 1 ? 1 : 0;
     const int tilesX = cvk_cdiv(W, TW), tilesY = cvk_cdiv(H, TH);
-    bool p128 = false;
-    if (knd == 1) {
-        // 128-channel tiles that fill the chip badly (e.g. 384 tiles = 1.5 rounds of 256 CUs): the 64-channel kernel on the same pack
-        // (twice the tiles; its K loop and its doubled weight traffic cost a few per cent: it must win 10 % in balance; measured: 1380 tiles -> 2760 is a wash, 384 -> 768 gains 8-9 %)
-        static const int h128 = getenv("CVK_BF16P_H128") ? atoi(getenv("CVK_BF16P_H128")) : 1;
-        static const int ncu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 0 ? n : 256; }();
-        const int wg = ncu;          // NOT the data-parallel cap: the choice (and with it the statistics' summation order) must not depend on it
-        const long t1 = (long)N * tilesX * tilesY * cvk_cdiv(Cout, BN), t2 = (long)N * tilesX * tilesY * cvk_cdiv(Cout, HBN);
-        const double e1 = (double)t1 / ((double)cvk_cdiv(t1, wg) * wg), e2 = (double)t2 / ((double)cvk_cdiv(t2, wg) * wg);
-        if (h128 == 2 || (h128 == 1 && mfma_shape() == 16 && Cout % HBN == 0 && e2 * 0.90 > e1)) { knd = 2; p128 = true; }
-    }
+    const int ch = choose(N, H, W, Cin, Cout);
+    const int knd = ch == 3 ? 2 : ch;
+    const bool p128 = ch == 3;
+    const int cus = device_cus();
     const int tilesN = cvk_cdiv(Cout, knd == 2 ? HBN : BN);
     const int P = N * tilesX * tilesY;
-    dim3 grid((unsigned)(P * tilesN)), block(512);
-    static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 0 ? n : 256; }();
+    const int ntiles = P * tilesN;
+    dim3 block(512);
     const int wgcap = max_workgroups > 0 && max_workgroups < cus ? max_workgroups : cus;      // data parallel: CUs left to RCCL
+    int g = wgcap;
+    {
+        const int cap = cvk_knob("CVK_BF16P_GRID", 0);      // experiments build: fewer workgroups (timing)
+        if (cap > 0) g = cap;
+    }
+    if (g > ntiles) g = ntiles;
+    dim3 pgrid((unsigned)g);
+#define CVK_PP_ARGS (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles, nts
     if (knd == 2) {
-        const int ntiles = P * tilesN;
-        dim3 pgrid((unsigned)(wgcap < ntiles ? wgcap : ntiles));
-        static const int hdbg = getenv("CVK_BF16H_DBG") ? atoi(getenv("CVK_BF16H_DBG")) : 0;
         if (p128) {
-            if (stats) hipLaunchKernelGGL((k_conv_bf16h<true, 0, true>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles, nts);
-            else hipLaunchKernelGGL((k_conv_bf16h<false, 0, true>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles, nts);
+            if (stats) hipLaunchKernelGGL((k_conv_bf16h<true, 0, true>), pgrid, block, 0, s, CVK_PP_ARGS);
+            else hipLaunchKernelGGL((k_conv_bf16h<false, 0, true>), pgrid, block, 0, s, CVK_PP_ARGS);
             return;
         }
-        if (hdbg == 2 && stats) hipLaunchKernelGGL((k_conv_bf16h<true, 1>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles, nts);
-        else if (hdbg == 1) hipLaunchKernelGGL((k_conv_bf16h<false, 1>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles, nts);
-        else if (stats) hipLaunchKernelGGL((k_conv_bf16h<true>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles, nts);
-        else hipLaunchKernelGGL((k_conv_bf16h<false>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles, nts);
+#ifdef CVK_EXPERIMENTS
+        const int hdbg = cvk_knob("CVK_BF16H_DBG", 0);      // per-tile time stamps (tools/tile_stamps_h.py)
+        if (hdbg == 2 && stats) { hipLaunchKernelGGL((k_conv_bf16h<true, 1>), pgrid, block, 0, s, CVK_PP_ARGS); return; }
+        if (hdbg == 1) { hipLaunchKernelGGL((k_conv_bf16h<false, 1>), pgrid, block, 0, s, CVK_PP_ARGS); return; }
+#endif
+        if (stats) hipLaunchKernelGGL((k_conv_bf16h<true>), pgrid, block, 0, s, CVK_PP_ARGS);
+        else hipLaunchKernelGGL((k_conv_bf16h<false>), pgrid, block, 0, s, CVK_PP_ARGS);
         return;
     }
-    static const int dbg = getenv("CVK_BF16P_DBG") ? atoi(getenv("CVK_BF16P_DBG")) : 0;      // timing experiments only
-    static const int var = getenv("CVK_BF16P_VAR") ? atoi(getenv("CVK_BF16P_VAR")) : 0;
-#define CVK_PP(ST_, DBG_, V_)                                                                                                              \
-    hipLaunchKernelGGL((k_conv_bf16p<ST_, DBG_, V_>), grid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, \
-                       H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P)
-    if (mfma_shape() == 16) {
-        const int ntiles = P * tilesN;
-        static const int cap = getenv("CVK_BF16P_GRID") ? atoi(getenv("CVK_BF16P_GRID")) : 0;      // timing experiments only
-        int g = cap > 0 ? cap : wgcap;
-        if (g > ntiles) g = ntiles;
-        dim3 pgrid((unsigned)g);
-        if (stats) hipLaunchKernelGGL((k_conv_bf16q<true>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles, nts);
-        else hipLaunchKernelGGL((k_conv_bf16q<false>), pgrid, block, 0, s, (const __bf16*)x, (const char*)wpp, bias, (__bf16*)y, stats, counts, H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, P, ntiles, nts);
-    } else if (dbg == 0 && var == 0) {
-        if (stats) CVK_PP(true, 0, 0); else CVK_PP(false, 0, 0);
-    } else if (dbg == 0) {
-        CVK_PP(false, 0, 1);
-    } else {
-        switch (dbg) {
-            case 1: CVK_PP(false, 1, 0); break;
-            case 2: CVK_PP(false, 2, 0); break;
-            case 3: CVK_PP(false, 3, 0); break;
-            case 4: CVK_PP(false, 4, 0); break;
-            case 5: CVK_PP(false, 5, 0); break;
-            case 6: CVK_PP(false, 6, 0); break;
-            case 8: CVK_PP(false, 8, 0); break;
-            case 9: CVK_PP(false, 9, 0); break;
-            case 12: CVK_PP(false, 12, 0); break;
-            case 16: CVK_PP(false, 16, 0); break;
-            default: CVK_PP(false, 7, 0); break;
-        }
-    }
-#undef CVK_PP
+    if (stats) hipLaunchKernelGGL((k_conv_bf16q<true>), pgrid, block, 0, s, CVK_PP_ARGS);
+    else hipLaunchKernelGGL((k_conv_bf16q<false>), pgrid, block, 0, s, CVK_PP_ARGS);
+#undef CVK_PP_ARGS
 }
 
 }  // namespace cvk_bf16p

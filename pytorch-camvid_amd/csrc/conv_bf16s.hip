@@ -19,7 +19,6 @@
 //   * MFMA orientation D[cout][pixel] = Wt-tile (A operand) x pixel-tile (B operand): a lane ends up with four
 //     consecutive output channels of one pixel per register quad -> 8-byte packed bf16 stores along NHWC rows.
 //   * out-of-frame halo pixels (conv zero padding, ragged tiles) are DMA'd from a zero page.
-#include <stdlib.h>
 #include <type_traits>
 #include "cvk_common.h"
 #include "conv_bf16p.h"
@@ -672,6 +671,18 @@ extern "C" int cvk_pack_weights_bf16_batch(const cvk_pack_job* jobs, int n, void
 static int conv3x3_bf16s_impl(const void* x, const void* w, const float* bias, void* y, float* stats, float* counts, int N, int H,
                               int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream);
 
+// Which kernel cvk_conv3x3_bf16s runs for a layer (the dispatch below, as a query: measurement tools label their timings with the
+// kernel a trace will show): 0 k_conv_bf16s<BN> (tile kernel), 1 k_conv_bf16q, 2 k_conv_bf16h, 3 k_conv_bf16h on the 128-row pack,
+// 4 k_conv_bf16s_strip, 5 two k_conv_bf16s_strip passes over the halves of a 64 -> 128 filter.  < 0: bad arguments.
+extern "C" int cvk_conv3x3_bf16s_kernel(int N, int H, int W, int Cin, int Cout, int with_stats) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % CK != 0) return CVK_EINVAL;
+    if (cvk_bf16p::serves(Cin, Cout)) return cvk_bf16p::choose(N, H, W, Cin, Cout);
+    const int no_strip = cvk_knob("CVK_BF16S_NO_STRIP", 0);
+    if (use_strip(Cin, Cout) && !no_strip) return 4;
+    if (!with_stats && Cin == 64 && Cout == 128 && !no_strip) return 5;
+    return 0;
+}
+
 extern "C" int cvk_conv3x3_bf16s(const void* x, const void* w, const float* bias, void* y, float* stats, float* counts, int N, int H,
                                  int W, int Cin, int Cout, int ldy, void* stream) {
     return conv3x3_bf16s_impl(x, w, bias, y, stats, counts, N, H, W, Cin, Cout, ldy, 0, stream);
@@ -715,12 +726,12 @@ static int conv3x3_bf16s_impl(const void* x, const void* w, const float* bias, v
 #define CVK_BS_LAUNCH(BN_, ST_)                                                                                              \
     hipLaunchKernelGGL((k_conv_bf16s<BN_, ST_>), grid, block, 0, s, (const __bf16*)x, (const __bf16*)w, bias, (__bf16*)y, stats, counts, \
                        H, W, Cin, Cout, ldy, tilesX, tilesY, tilesN, (int)P)
-    static const int no_strip = getenv("CVK_BF16S_NO_STRIP") ? atoi(getenv("CVK_BF16S_NO_STRIP")) : 0;     // A/B timing only
+    const int no_strip = cvk_knob("CVK_BF16S_NO_STRIP", 0);     // experiments build: A/B timing
     if (use_strip(Cin, Cout) && !no_strip) {
         const int ntiles = (int)P;
         const int slen = strip_len_for(ntiles);
         const int nstrips = cvk_cdiv(ntiles, slen);
-        static const int strip_nw = getenv("CVK_STRIP_NW") ? atoi(getenv("CVK_STRIP_NW")) : 0;
+        const int strip_nw = cvk_knob("CVK_STRIP_NW", 0);
 #define CVK_STRIP(NCS_, ST_, NW_) hipLaunchKernelGGL((k_conv_bf16s_strip<NCS_, ST_, NW_>), dim3(nstrips), dim3(64 * NW_), 0, s, (const __bf16*)x, \
                            (const __bf16*)w, bias, (__bf16*)y, stats, counts, H, W, Cout, ldy, tilesX, tilesY, ntiles, slen, nstrips)
         if (Cin == 64) {
@@ -781,187 +792,17 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* p) {
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-// 8 waves: wave w owns quadrant (w & 3) = (co half, ci half) of the 64 x 64 block; waves 0-3 accumulate taps 0..4, waves
-// 4-7 taps 5..8 (80 / 64 accumulator registers: two waves per SIMD fit the 512-entry register file without spills).  Measured ablation of the 4-wave version (one wave per SIMD; DMA off / MFMA
-// off / both off): the transposed LDS reads (320 per wave and tile, the LDS array's full 256 B/clk), the MFMAs and the DMA
-// each need 1.2-1.9 us per tile but ran almost back to back (3.5-4.8 us): one in-order wave cannot overlap them.  Two
-// waves per SIMD can.  DBG (timing experiments only, wrong results): 1 = no DMA after the first tile, 2 = no MFMAs.
-template <int DBG = 0>
-__global__ __launch_bounds__(512, 2) void k_wgrad_bf16s(const __bf16* __restrict__ X, const __bf16* __restrict__ DY,
-                                                       float* __restrict__ slab, int H, int W, int ldx, int ld_dy, int Cout,
-                                                       int Cin, int tilesX, int tilesY, int ntiles, int tiles_per_split,
-                                                       int nblk_ci, int nblk) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * WG_STAGE];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // 0..7
-    const int h = lane >> 5;
-    const int quad = wave & 3, tg = wave >> 2;             // tap group: 0 -> taps 0..4, 1 -> taps 5..8
-    const int wco = quad >> 1, wci = quad & 1;
-
-    const int gid = cvk_xcd_remap(blockIdx.x, gridDim.x);
-    const int blk = gid % nblk, split = gid / nblk;      // blocks of one pixel range are neighbours (one XCD's L2)
-    const int cob = blk / nblk_ci, cib = blk % nblk_ci;
-    const int t0 = split * tiles_per_split;
-    const int t1 = min(ntiles, t0 + tiles_per_split);
-
-    // ---- DMA source mapping: per piece a 32-bit BYTE offset relative to the pixel one row and one column before the tile's
-    //      first pixel (non-negative) and the packed halo coordinates for the frame test; per tile only the two raw-buffer
-    //      bases (scalar) and a few uniform bounds change; out-of-frame lanes get the offset 2^31 = past the buffer -> 0 ----------
-    // x slab: piece q (0..5) of this wave covers LDS rows (wave*6 + q)*8 + lane/8, 16-byte position lane%8
-    unsigned xs_off[6]; int xs_yx[6];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int row = (wave * 6 + q) * 8 + (lane >> 3);
-        const int hy = row / HP, hx = row - hy * HP;
-        const int chunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
-        const bool ok = (row < WG_XROWS) & (hx < TW + 2) & (cib * 64 + chunk * 8 < ldx);
-        xs_off[q] = (unsigned)((hy * W + hx) * ldx + cib * 64 + chunk * 8) * 2u;
-        xs_yx[q] = ok ? (hy << 8) | hx : 0x7F7F;               // static rejects fail every frame test
-    }
-    unsigned ds_off[4]; int ds_yx[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = (wave * 4 + q) * 8 + (lane >> 3);      // tile pixel index: py*32 + px
-        const int chunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
-        const bool ok = cob * 64 + chunk * 8 < ld_dy;
-        ds_off[q] = (unsigned)(((row >> 5) * W + (row & 31)) * ld_dy + cob * 64 + chunk * 8) * 2u;
-        ds_yx[q] = ok ? ((row >> 5) << 8) | (row & 31) : 0x7F7F;
-    }
-    const unsigned smem_addr = lds_addr_of(smem);
-    i32x4v sx_rsrc = raw_rsrc_2g(X), sd_rsrc = raw_rsrc_2g(DY);
-    int s_ylo = 0, s_yn = 0, s_xlo = 0, s_xn = 0, s_dyn = 0, s_dxn = 0;
-    unsigned s_buf = 0;
-    auto stage_begin = [&](int t, int which) {
-        const int tx = t % tilesX, ty = (t / tilesX) % tilesY, img = t / (tilesX * tilesY);
-        const int x0 = tx * TW, y0 = ty * TH;
-        const long pix = ((long)img * H + y0) * W + x0;
-        sx_rsrc = raw_rsrc_2g(X + (pix - W - 1) * ldx);       // lanes that would read in front of the tensor are out of frame
-        sd_rsrc = raw_rsrc_2g(DY + pix * ld_dy);
-        // halo pixel (hy,hx) is inside the frame iff ylo <= hy < ylo + yn and xlo <= hx < xlo + xn
-        s_ylo = y0 == 0 ? 1 : 0;  s_yn = min(TH + 2, H - y0 + 1) - s_ylo;
-        s_xlo = x0 == 0 ? 1 : 0;  s_xn = min(TW + 2, W - x0 + 1) - s_xlo;
-        s_dyn = min(TH, H - y0);  s_dxn = min(TW, W - x0);
-        s_buf = smem_addr + which * WG_STAGE;
-    };
-    auto stage_x = [&](int q) {
-        if (DBG & 1) return;
-        const bool ok = ((unsigned)((xs_yx[q] >> 8) - s_ylo) < (unsigned)s_yn) & ((unsigned)((xs_yx[q] & 255) - s_xlo) < (unsigned)s_xn);
-        dma16_buf_m0(ok ? xs_off[q] : 0x80000000u, sx_rsrc, s_buf + (wave * 6 + q) * 1024);
-    };
-    auto stage_d = [&](int q) {
-        if (DBG & 1) return;
-        const bool ok = ((ds_yx[q] >> 8) < s_dyn) & ((ds_yx[q] & 255) < s_dxn);
-        dma16_buf_m0(ok ? ds_off[q] : 0x80000000u, sd_rsrc, s_buf + WG_XBYTES + (wave * 4 + q) * 1024);
-    };
-
-    // ---- transposed-read lane addresses -----------------------------------------------------------------------------------
-    // 16-lane group g1 = (lane>>4)&1 covers matrix columns 16*g1 .. +15; inside it lane 4*tq + tp supplies LDS row tq
-    // (first read; +4 second), columns 4*tp .. 4*tp+3.  K half h: pixels 8h .. 8h+7 of the 16-pixel k-step.
-    const int tq = (lane & 15) >> 2, tp = lane & 3, g1 = (lane >> 4) & 1;
-    auto lane_addr = [&](int row_lane, int col_local) {      // byte offset in an image of 128-byte rows, row term = row_lane
-        const int chunk = col_local >> 3;
-        return row_lane * 128 + ((chunk ^ (((row_lane >> 1) & 1) << 2)) << 4) + (col_local & 7) * 2;
-    };
-    const int rl = 8 * h + tq;
-    const int a_base = WG_XBYTES + lane_addr(rl, wco * 32 + 16 * g1 + 4 * tp);           // dy tile
-    int b_base[3];
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) b_base[dx] = lane_addr(rl + dx, wci * 32 + 16 * g1 + 4 * tp);
-
-    // One tile for one wave: 16 k-steps (16 pixels each) x its NT taps.  Fragments: fa double-buffered, fb[j] reloaded in
-    // place right after its MFMA (the MFMA has latched its operands when the LDS data returns), order pinned with
-    // sched_barrier: every operand is requested a whole k-step before its use.  The tile body is one basic block
-    // (MORE is a template flag, not a branch).
-    auto run = [&](auto t0_tag, auto nt_tag) {
-        constexpr int TAP0 = decltype(t0_tag)::value, NT = decltype(nt_tag)::value;
-        f32x16 acc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-        auto tile_body = [&](char* buf, auto more_tag) {
-            constexpr bool MORE = decltype(more_tag)::value;
-            bf16x8 fa[2], fb[NT];
-            auto a_addr = [&](int ks) { return buf + a_base + ((ks >> 1) * 32 + (ks & 1) * 16) * 128; };
-            auto b_addr = [&](int ks, int j) {
-                const int tap = TAP0 + j;
-                return buf + b_base[tap % 3] + (((ks >> 1) + tap / 3) * HP + (ks & 1) * 16) * 128;
-            };
-            fa[0] = tr_read8(a_addr(0));
-#pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = tr_read8(b_addr(0, j));
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const int cs_ = ks & 1, ns_ = cs_ ^ 1;
-                if (MORE && ks < 2) {    // this wave's 10 DMA pieces of the next tile go out at the start of the tile: the whole
-                                         // tile (~2 us of MFMAs) covers their flight (issued late, HBM latency showed at the barrier)
-                    if (ks == 0) {
-#pragma unroll
-                        for (int q = 0; q < 6; ++q) stage_x(q);
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) stage_d(q);
-                    }
-                }
-                if (ks + 1 < 16) fa[ns_] = tr_read8(a_addr(ks + 1));
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    if (!(DBG & 2)) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cs_], fb[j], acc[j], 0, 0, 0);
-                    else asm volatile("" :: "v"(fb[j]), "v"(fa[cs_]));
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (ks + 1 < 16 && !((DBG & 4) && (j & 1))) fb[j] = tr_read8(b_addr(ks + 1, j));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        };
-        int cur = 0;
-        for (int t = t0; t < t1; ++t) {
-            char* const buf = smem + cur * WG_STAGE;
-            if (t + 1 < t1) {
-                stage_begin(t + 1, cur ^ 1);
-                tile_body(buf, std::true_type{});
-            } else {
-                tile_body(buf, std::false_type{});
-            }
-            wait_vm<0>();
-            lds_retire_barrier();
-            cur ^= 1;
-        }
-        // ---- partial slab: [split][co][tap][ci] fp32 -----------------------------------------------------------------------
-        float* out = slab + (size_t)split * Cout * 9 * Cin;
-        const int ci = cib * 64 + wci * 32 + (lane & 31);
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int co = cob * 64 + wco * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (co < Cout && ci < Cin) out[((size_t)co * 9 + TAP0 + j) * Cin + ci] = acc[j][i];
-            }
-    };
-
-    if (t0 < t1) {
-        stage_begin(t0, 0);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) stage_x(q);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) stage_d(q);
-    }
-    wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    if (tg == 0) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
-    else run(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
-}
-
-// ---- row-stationary version (round 4) ----------------------------------------------------------------------------------------------
-// k_wgrad_bf16s is bound by LDS bytes: every MFMA of a tap reads its own x fragment (1.2 KiB of transposed reads per MFMA; two waves
+// ---- row-stationary weight-grad (round 4) ---------------------------------------------------------------------------------------------
+// Rounds 2-3 ran k_wgrad_bf16s (removed in round 5; git history): 8 waves, wave w owning quadrant (w & 3) of the 64 x 64 (co, ci) block
+// for taps 0..4 (waves 0-3) or 5..8 (waves 4-7), same staging / LDS images / DMA / slabs as below.
+// It was bound by LDS bytes: every MFMA of a tap reads its own x fragment (1.2 KiB of transposed reads per MFMA; two waves
 // per SIMD at the matrix peak would need 307 B/clk of the 256 the LDS delivers; PMC: matrix pipe 55 % busy, and a ping-pong split of its
 // phases measured SLOWER — one wave per SIMD cannot even issue the 2.4 ds_read_b64_tr per MFMA in time).  But the x fragment of halo row
 // y' and column shift dx is the operand of THREE taps: kernel row dy pairs it with the dy fragment of output row y' - dy.  So a wave now
 // owns ALL NINE taps of its 32 x 32 (co, ci) quadrant (144 accumulator registers) for ONE 16-column half of the tile and walks the ten
 // halo rows: per halo row 3 x fragments (dx = 0, 1, 2) + 1 new dy fragment feed up to 9 MFMAs — 0.44 KiB of LDS reads per MFMA, 2.7x
 // less, 1.05 read instructions per MFMA instead of 2.4.  The two waves of a SIMD take the two column halves and their accumulators meet
-// through LDS once, after the workgroup's last tile (fixed order: deterministic).  Staging, LDS images, DMA, slabs: as k_wgrad_bf16s.
+// through LDS once, after the workgroup's last tile (fixed order: deterministic).
 // The two waves of a SIMD run the same program and the OLDER one wins every MFMA arbitration: it runs through its tile in ~3300 cycles,
 // its partner gets the leftovers and then runs alone.  PRIO alternates s_setprio per halo row between the column halves so that both
 // advance together (with all DMA pieces in the first rows this measured no gain; with the pieces spread over rows 0-5 it is worth 1.7 %:
@@ -1110,7 +951,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_bf16r(const __bf16* __restrict
         }
     };
 
-    // ---- transposed-read lane addresses (as k_wgrad_bf16s; the k-step of a row is this wave's column half) ---------------------------
+    // ---- transposed-read lane addresses (the k-step of a row is this wave's column half) ---------------------------
     const int tq = (lane & 15) >> 2, tp = lane & 3, g1 = (lane >> 4) & 1;
     auto lane_addr = [&](int row_lane, int col_local) {
         const int chunk = col_local >> 3;
@@ -1335,12 +1176,11 @@ static int wgrad_bf16s_launch_slabs(const void* x, const void* dy, void* workspa
                                     const WgPlan& p, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int nblk = p.nblk_co * p.nblk_ci;
-    static const int dbg = getenv("CVK_WGRAD_DBG") ? atoi(getenv("CVK_WGRAD_DBG")) : 0;      // timing experiments only
-    static const int rowst = getenv("CVK_WGRAD_ROW") ? atoi(getenv("CVK_WGRAD_ROW")) : 1;
-    static const int wprio = getenv("CVK_WGRAD_PRIO") ? atoi(getenv("CVK_WGRAD_PRIO")) : 1;
 #define CVK_WGR_LAUNCH(D_, P_) hipLaunchKernelGGL((k_wgrad_bf16r<D_, P_>), dim3(nblk * p.splits), dim3(512), 0, s, (const __bf16*)x, (const __bf16*)dy, (float*)workspace, \
                            H, W, ldx, ld_dy, Cout, Cin, cvk_cdiv(W, TW), cvk_cdiv(H, TH), p.ntiles, p.tps, p.nblk_ci, nblk)
-    if (rowst && dbg >= 16) {
+#ifdef CVK_EXPERIMENTS
+    const int dbg = cvk_knob("CVK_WGRAD_DBG", 0);
+    if (dbg >= 16) {
         // timing experiments (tools/tile_stamps_wgrad.py): 16 = stamps, + 2 no fragment reads, + 4 no DMA, + 8 DMA of zeros, + 32 DMA
         // instruction dropped, + 64 per-row stamps, + 128 alternating wave priority.  No reduction: the slabs hold wrong numbers.
         switch (dbg) {
@@ -1360,23 +1200,22 @@ static int wgrad_bf16s_launch_slabs(const void* x, const void* dy, void* workspa
         }
         return 1;          // timing experiment: no reduction, the slabs hold wrong numbers
     }
-    static const int nts = getenv("CVK_STREAM_HINTS") ? atoi(getenv("CVK_STREAM_HINTS")) : 5;      // 0: no streaming hints (A/B timing)
-    if (rowst && dbg == 0 && nts >= 5 && wprio && p.splits > 1) {
+#endif
+    const int nts = cvk_knob("CVK_STREAM_HINTS", 5);      // experiments build: 0 = no streaming hints (A/B timing)
+    const int wprio = cvk_knob("CVK_WGRAD_PRIO", 1);
+    if (nts >= 5 && wprio && p.splits > 1) {
         hipLaunchKernelGGL((k_wgrad_bf16r<0, true, true>), dim3(nblk * p.splits), dim3(512), 0, s, (const __bf16*)x, (const __bf16*)dy, (float*)workspace,
                            H, W, ldx, ld_dy, Cout, Cin, cvk_cdiv(W, TW), cvk_cdiv(H, TH), p.ntiles, p.tps, p.nblk_ci, nblk);
-    } else if (rowst && dbg == 0) {
-        if (wprio) CVK_WGR_LAUNCH(0, true); else CVK_WGR_LAUNCH(0, false);
-    } else
-#undef CVK_WGR_LAUNCH_UNUSED
-#define CVK_WG_LAUNCH(D_) hipLaunchKernelGGL((k_wgrad_bf16s<D_>), dim3(nblk * p.splits), dim3(512), 0, s, (const __bf16*)x, (const __bf16*)dy, (float*)workspace, H, W, \
-                           ldx, ld_dy, Cout, Cin, cvk_cdiv(W, TW), cvk_cdiv(H, TH), p.ntiles, p.tps, p.nblk_ci, nblk)
-    if (dbg == 1) CVK_WG_LAUNCH(1);
-    else if (dbg == 2) CVK_WG_LAUNCH(2);
-    else if (dbg == 3) CVK_WG_LAUNCH(3);
-    else if (dbg == 4) CVK_WG_LAUNCH(4);
-    else if (dbg == 5) CVK_WG_LAUNCH(5);
-    else CVK_WG_LAUNCH(0);
-#undef CVK_WG_LAUNCH
+    } else if (wprio) {
+        CVK_WGR_LAUNCH(0, true);
+    } else {
+#ifdef CVK_EXPERIMENTS
+        CVK_WGR_LAUNCH(0, false);
+#else
+        CVK_WGR_LAUNCH(0, true);
+#endif
+    }
+#undef CVK_WGR_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         cvk_set_error("cvk_conv3x3_wgrad_bf16s: launch failed: %s", hipGetErrorString(e));

@@ -29,6 +29,19 @@ void cvk_set_error(const char* fmt, ...);
         return CVK_OK;                                                           \
     } while (0)
 
+// Kernel-selection / timing switches read from the environment exist ONLY in the experiments build (`make experiments` ->
+// lib/libcvk_exp.so, compiled with -DCVK_EXPERIMENTS; the tools/ timing scripts load it through CVK_LIB_PATH).  In the product
+// library cvk_knob(name, default) is the constant `default`: libcvk.so never calls getenv and holds no CVK_* name, so a stray
+// variable in a user's environment cannot change a kernel, let alone select one of the wrong-result ablation variants
+// (tests/test_abi.py::test_product_library_reads_no_environment).
+#ifdef CVK_EXPERIMENTS
+#include <stdlib.h>
+static inline int cvk_knob_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#define cvk_knob(name, dflt) cvk_knob_env(name, dflt)
+#else
+#define cvk_knob(name, dflt) (dflt)
+#endif
+
 static inline bool cvk_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 static inline int cvk_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

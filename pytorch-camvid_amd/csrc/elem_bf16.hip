@@ -535,7 +535,7 @@ extern "C" int cvk_bn_relu_apply_bf16(const void* y, int ldy, const float* scale
     CVK_CHECK_ARG(v8 || viewok(out, 4, out_f32 != 0), "cvk_bn_relu_apply_bf16: misaligned output view");
     const long cells = pool ? (long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long)N * H * W;
 #define CVK_AP(V_, F_, P_) hipLaunchKernelGGL((k_apply_bf16<V_, F_, P_>), dim3(grid_for(cells * (C / V_))), dim3(256), 0, s, (const __bf16*)y, ldy, scale, shift, out.ptr, om, (__bf16*)pool, N, H, W, C)
-    static const int nt = getenv("CVK_STREAM_HINTS") ? atoi(getenv("CVK_STREAM_HINTS")) : 5;      // 0: no streaming hints (A/B timing)
+    const int nt = cvk_knob("CVK_STREAM_HINTS", 5);      // experiments build: 0 = no streaming hints (A/B timing)
     if (v8 && nt >= 2 && !out_f32) {
         if (pool) hipLaunchKernelGGL((k_apply_bf16<8, false, true, true>), dim3(grid_for(cells * (C / 8))), dim3(256), 0, s, (const __bf16*)y, ldy, scale, shift, out.ptr, om, (__bf16*)pool, N, H, W, C);
         else hipLaunchKernelGGL((k_apply_bf16<8, false, false, true>), dim3(grid_for(cells * (C / 8))), dim3(256), 0, s, (const __bf16*)y, ldy, scale, shift, out.ptr, om, (__bf16*)pool, N, H, W, C);
@@ -570,7 +570,7 @@ static int bnbwd_launch(int mode, cvk_viewh dout, int dout_f32, const void* y, i
     // every thread idle and the partial sums unwritten
     CVK_CHECK_ARG(C / (v8 ? 8 : 4) <= 256, "%s: C=%d needs more than 256 channel vectors of %d (C <= 1024 for 4-wide, 2048 for 8-wide access)", name, C, v8 ? 8 : 4);
 #define CVK_BB(V_, M_, F_) hipLaunchKernelGGL((k_bnbwd_bf16<V_, M_, F_>), dim3(PB), dim3(256), 0, s, dout.ptr, dm, (const __bf16*)y, ldy, scale, shift, mean, rstd, dgamma, dbeta, (__bf16*)dy, ld_dy, part, M, C, rows, PB, use_batch_stats)
-    static const int nt = getenv("CVK_STREAM_HINTS") ? atoi(getenv("CVK_STREAM_HINTS")) : 5;      // 0: no streaming hints (A/B timing)
+    const int nt = cvk_knob("CVK_STREAM_HINTS", 5);      // experiments build: 0 = no streaming hints (A/B timing)
     if (v8) {
         if (mode == 0 && nt >= 4 && !dout_f32 && (size_t)M * C * 2 >= ((size_t)128 << 20)) hipLaunchKernelGGL((k_bnbwd_bf16<8, 0, false, true>), dim3(PB), dim3(256), 0, s, dout.ptr, dm, (const __bf16*)y, ldy, scale, shift, mean, rstd, dgamma, dbeta, (__bf16*)dy, ld_dy, part, M, C, rows, PB, use_batch_stats);
         else if (mode == 0) { if (dout_f32) CVK_BB(8, 0, true); else CVK_BB(8, 0, false); }

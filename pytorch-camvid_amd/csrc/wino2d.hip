@@ -900,13 +900,12 @@ static int w2i_gemm(int mt, const char* who, const float* V, const float* U, flo
     const dim3 grid(p.split_start + (p.NT - p.split_start) * p.f);
     const size_t part_stride = (size_t)nx * T * Cout;
     hipStream_t s = (hipStream_t)stream;
-    static int cus = 0, no_stagger = -1;          // queried once (benign race: every thread stores the same values)
+    static int cus = 0;          // queried once (benign race: every thread stores the same value)
     if (cus == 0) {
         int dev = 0, v = 0;
         cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-        const char* e = getenv("CVK_W2D_NO_STAGGER");
-        no_stagger = (e != nullptr && e[0] == '1') ? 1 : 0;
     }
+    const int no_stagger = cvk_knob("CVK_W2D_NO_STAGGER", 0);          // experiments build: A/B of the staggered start
     const int stagger = (!no_stagger && (int)grid.x >= 2 * cus && p.split_start >= 2 * cus) ? cus : 0;
     hipLaunchKernelGGL((k_w2d_gemm<128, 32, 2, 2>), grid, dim3(256), 0, s, V, U, Mo, T, w2_tpad(T), Cout, Cin, Cout, p.tilesM, p.tilesN,
                        p.split_start, p.f, part_stride, stagger);

@@ -50,7 +50,7 @@ def rccl_env():
     """The knobs in effect (for logs and bench lines)."""
     return {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_NCHANNELS_PER_PEER", "RCCL_MSCCL_ENABLE",
                                            "NCCL_ALGO", "NCCL_PROTO", "HSA_ENABLE_IPC_MODE_LEGACY", "CVK_DDP_BUCKET_MB",
-                                           "CVK_DP_RESERVE_CUS", "CVK_W2D_NO_STAGGER")}
+                                           "CVK_DP_RESERVE_CUS")}
 
 
 def make_buckets(layer_ranges, bucket_floats):

@@ -342,8 +342,6 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
 
 def conv_kernel_name(kind, n_cols, k_ch=32):
     """Mirror of the tile dispatch in csrc/conv3x3.hip / wino.hip: the kernel-trace name."""
-    if kind in ("bf16_fwd", "bf16_dgrad"):       # csrc/conv_bf16s.hip: k_conv_bf16s<BN, STATS>
-        return f"k_conv_bf16s<{128 if n_cols > 64 else 64}, {'true' if kind == 'bf16_fwd' else 'false'}>"
     if kind == "wino4":
         return "k_conv3x3_wino4<128, 128, 2, 2>" if n_cols > 64 else ("k_conv3x3_wino4<128, 64, 2, 2>" if n_cols > 32 else "k_conv3x3_wino4<128, 32, 4, 1>")
     if kind == "wino":
@@ -357,6 +355,20 @@ def conv_kernel_name(kind, n_cols, k_ch=32):
         return f"k_conv3x3_wgrad<{t}>"
     t = "128, 128, 2, 2" if n_cols > 64 else ("128, 64, 2, 2" if n_cols > 32 else "256, 32, 4, 1")
     return f"k_conv3x3_igemm<{t}, {'true' if kind == 'fwd' else 'false'}, {'true' if k_ch % 32 == 0 else 'false'}>"
+
+
+def bf16_kernel_name(lib, N, H, W, cin_ld, cout, stats):
+    """The kernel cvk_conv3x3_bf16s(_wg) dispatches for this geometry, as a kernel trace names it (the library answers:
+    cvk_conv3x3_bf16s_kernel is a query of the same dispatch code; csrc/conv_bf16s.hip, csrc/conv_bf16p.hip)."""
+    k = lib.cvk_conv3x3_bf16s_kernel(N, H, W, cin_ld, cout, 1 if stats else 0)
+    st = "true" if stats else "false"
+    if k == 1:
+        return f"k_conv_bf16q<{st}>"
+    if k in (2, 3):
+        return f"k_conv_bf16h<{st}, 0, {'true' if k == 3 else 'false'}>"
+    if k in (4, 5):
+        return f"k_conv_bf16s_strip<{1 if cin_ld == 32 else 2}, {st}>" + (" x2" if k == 5 else "")
+    return f"k_conv_bf16s<{128 if cout > 64 else 64}, {st}>"
 
 
 # ---- derived-weight cache ---------------------------------------------------------------------------------------------
@@ -762,7 +774,7 @@ class ConvBnRelu(Op):
             P = lib.cvk_bf16s_stat_partials_c(N, H, W, src.ld, C)
             stats = _empty(2 * P * C + P, dev)
             cnt = stats.data_ptr() + 4 * 2 * P * C
-            _timed(R, conv_kernel_name("bf16_fwd", C), flops, lambda: check(
+            _timed(R, bf16_kernel_name(lib, N, H, W, src.ld, C, True), flops, lambda: check(
                 lib.cvk_conv3x3_bf16s_wg(X.data_ptr(), wb.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), cnt, N, H, W, src.ld, C, C,
                                          R.persistent_wgs(), s), "cvk_conv3x3_bf16s"))
             wsb = lib.cvk_bn_finalize_workspace_bytes(P, C)
@@ -775,7 +787,7 @@ class ConvBnRelu(Op):
                                              bn.num_batches_tracked.data_ptr() if track else None,
                                              mom, float(bn.eps), ws.data_ptr(), wsb, s), "cvk_bn_finalize_counts")
         else:
-            _timed(R, conv_kernel_name("bf16_dgrad", C), flops, lambda: check(
+            _timed(R, bf16_kernel_name(lib, N, H, W, src.ld, C, False), flops, lambda: check(
                 lib.cvk_conv3x3_bf16s(X.data_ptr(), wb.data_ptr(), b.data_ptr(), y.data_ptr(), None, None, N, H, W, src.ld, C, C, s),
                 "cvk_conv3x3_bf16s"))
             check(lib.cvk_bn_eval_params(gamma.data_ptr(), beta.data_ptr(), bn.running_mean.data_ptr(),
@@ -830,7 +842,7 @@ class ConvBnRelu(Op):
                 return t
             wd = R.derived(((self.pslot, "d"), "bf16"), w, build_wd)
             dX = torch.empty((N, H, W, src.ld), device=dev, dtype=_BF16)
-            _timed(R, conv_kernel_name("bf16_dgrad", self.cin), flops, lambda: check(
+            _timed(R, bf16_kernel_name(lib, N, H, W, ld_dy, self.cin, False), flops, lambda: check(
                 lib.cvk_conv3x3_bf16s_wg(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, None, N, H, W, ld_dy, self.cin, src.ld,
                                          R.persistent_wgs(), s), "cvk_conv3x3_bf16s(dgrad)"))
             st.grad[src.id] = dX
@@ -839,7 +851,7 @@ class ConvBnRelu(Op):
         S = lib.cvk_conv3x3_wgrad_bf16s_splits(N, H, W, self.cin, C)
         n = C * 9 * self.cin
         slab = None if S == 1 else _empty(S * n, dev)           # one slab: it is the gradient itself, written in place
-        _timed(R, "k_wgrad_bf16r<0, true>", flops, lambda: check(
+        _timed(R, "k_wgrad_bf16r", flops, lambda: check(
             lib.cvk_conv3x3_wgrad_bf16s_slabs(X.data_ptr(), dy.data_ptr(), gw if slab is None else slab.data_ptr(), N, H, W, self.cin, src.ld, C,
                                               ld_dy, 4 * S * n, s), "cvk_conv3x3_wgrad_bf16s_slabs"))
         if slab is not None:

@@ -209,6 +209,57 @@ def bf16_tolerance(c):
             "grad_rel_l2_median": max(1e-2, SAFETY * c["grad_rel_l2_median"]), "grad_rel_l2_max": max(5e-2, SAFETY * c["grad_rel_l2_max"])}
 
 
+def bf16_protocol(perturb=0):
+    """The configs[0] protocol (tests/golden/protocol_data.py: the reference's loop train.py:100-134 for one 300-step epoch at batch
+    2 x 3x360x480, then the validation pass train.py:169-206) run through oracle/bf16_emul.py — the reference graph with the DEVICE's
+    bf16 rounding points.  Its distance from the reference's own fp32 run (protocol_unet_2x360x480_run0.npz) is what bf16 storage costs
+    a whole training run by construction; the GPU bf16 path is held to SAFETY x that envelope on the loss curve and to the reference's
+    mIoU +-0.005 (tests/test_gpu_protocol.py).  perturb=1: the same run under a 1e-6 relative input perturbation (the emulation's own
+    reproducibility).  ~1 h of CPU each."""
+    import time
+    sys.path.insert(0, os.path.dirname(OUT))
+    from protocol_data import PROTO as P, proto_batch
+    torch.manual_seed(0)
+    net = R.build("unet", 3, 12).train()
+    opt = torch.optim.AdamW(net.parameters(), lr=P["lr"], weight_decay=0)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=P["lr"], steps_per_epoch=P["steps"], epochs=1)
+    losses, t0 = [], time.time()
+    for it in range(P["steps"]):
+        x, m = proto_batch(it)
+        if perturb:
+            x = x * (1 + 1e-6 * torch.randn(x.shape, generator=torch.Generator().manual_seed(7 + it)))
+        opt.zero_grad()
+        l = F.cross_entropy(E.unet_forward(net, x), m)
+        l.backward()
+        opt.step(); sched.step()
+        losses.append(float(l))
+        if it % 10 == 0:
+            print("bf16proto", perturb, it, float(l), f"{time.time() - t0:.0f}s", flush=True)
+    net.eval()
+    ti, tu, vloss = np.zeros(12), np.zeros(12), []
+    with torch.no_grad():
+        for i in range(P["val_batches"]):
+            x, m = proto_batch(i, val=True)
+            o = E.unet_forward(net, x)
+            vloss.append(float(F.cross_entropy(o, m)))
+            pr, g = o.argmax(dim=1).numpy().ravel(), m.numpy().ravel()
+            keep = g != 11                      # utils.intersect_and_union(pred, label, 12, ignore_index=11): void pixels leave both histograms
+            pr, g = pr[keep], g[keep]
+            for c in range(12):
+                ti[c] += np.sum((pr == c) & (g == c)); tu[c] += np.sum((pr == c) | (g == c))
+    iou = ti[:11] / np.maximum(tu[:11], 1)
+    ref = dict(np.load(os.path.join(os.path.dirname(OUT), "protocol_unet_2x360x480_run0.npz")))
+    dl = np.abs(np.array(losses) - ref["losses"])
+    np.savez_compressed(os.path.join(os.path.dirname(OUT), "protocol_bf16emu_unet_2x360x480_run%d.npz" % perturb),
+                        meta=json.dumps(dict(P, perturb=perturb, torch=torch.__version__)), losses=np.array(losses), val_loss=np.array(vloss),
+                        inter=ti, union=tu, miou=np.float64(iou.mean()))
+    print("bf16proto", perturb, "mIoU", iou.mean(), "reference", float(ref["miou"]), "max |loss - ref|", dl.max(), flush=True)
+    return {"perturb": perturb, "miou": float(iou.mean()), "miou_reference": float(ref["miou"]), "loss_max_abs_vs_reference": float(dl.max()),
+            "loss_final": losses[-1], "loss_final_reference": float(ref["losses"][-1]),
+            "loss_last20_mean_abs_vs_reference": float(abs(np.mean(losses[-20:]) - ref["losses"][-20:].mean())),
+            "val_loss": float(np.mean(vloss)), "val_loss_reference": float(np.mean(ref["val_loss"]))}
+
+
 def main():
     which = sys.argv[1:] or ["small", "full", "bf16small", "bf16full"]
     torch.set_num_threads(int(os.environ.get("GOLD_THREADS", "8")))
@@ -239,6 +290,11 @@ def main():
     if "bf16full" in which:
         d["bf16_cost"]["unet_4x720x960"] = bf16_cost((4, 720, 960))
         d["bf16_emul_noise"]["unet_4x720x960"] = bf16_fixture((4, 720, 960), "bf16emu_unet_s0_4x720x960", (80, 96))
+    d.setdefault("bf16_protocol", {})
+    if "bf16proto" in which:
+        d["bf16_protocol"]["run0"] = bf16_protocol(0)
+    if "bf16proto1" in which:
+        d["bf16_protocol"]["run1"] = bf16_protocol(1)
     for k, v in d["bf16_cost"].items():
         d["bf16_tolerance"][k] = bf16_tolerance(v)
     for k, v in d["bf16_emul_noise"].items():

@@ -82,3 +82,25 @@ def test_module_surface_matches_reference_and_fails_loudly_on_cpu():
     for (k, a), (_, b) in zip(net.state_dict().items(), ref.state_dict().items()):
         assert torch.equal(a, b), k
     ref.load_state_dict(net.state_dict())
+
+
+def test_product_library_reads_no_environment():
+    """a stray variable in a user's environment must not be able to change a kernel — least of all select one of the
+    wrong-result ablation variants the timing experiments use.  Those (and every CVK_* switch of the C side) are compiled only with
+    -DCVK_EXPERIMENTS into lib/libcvk_exp.so (`make experiments`, loaded by tools/ through CVK_LIB_PATH).  The product library must
+    not import getenv and must not contain a CVK_* name, a *_DBG name in particular."""
+    import subprocess
+    from pytorch_camvid_amd import _lib
+    path = os.path.join(ROOT, "pytorch-camvid_amd", "lib", "libcvk.so")
+    if not os.path.exists(path):
+        _lib.build()
+    data = open(path, "rb").read()
+    names = sorted(set(m.decode() for m in re.findall(rb"CVK_[A-Z0-9_]{3,}", data)))
+    assert not [n for n in names if n.endswith("_DBG")], names
+    assert not names, f"environment-style names inside the product library: {names}"
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined, "libcvk.so imports getenv"
+    # and the superseded kernel generations are gone from the default build (they live in git history)
+    assert b"k_conv_bf16p" not in data and b"k_wgrad_bf16sI" not in data
+    # the product never loads the experiments build by itself: only an explicit CVK_LIB_PATH does
+    assert _lib.LIB_PATH == (os.environ.get("CVK_LIB_PATH") or path)

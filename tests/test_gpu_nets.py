@@ -208,9 +208,9 @@ def test_adamw_trajectory_golden(tag):
 
 # Regression sentinels for the full-size logits: measured device deviations from the reference on the DENSE fixtures
 # (every 8th pixel: 30x the points of the slice), per 2-D Winograd tile.  The hard bound stays the derived tolerance of drift.json
-# (4 x the reference graph's own drift, frozen by tests/test_drift_cpu.py); these sit ~1.3x above what the kernels measure today, so
-# a coarser kernel trips here long before it reaches the bound.  (max |dev|, share of points beyond 3e-4, relative L2)
-DENSE_SENTINEL = {6: (6.6e-4, 4e-3, 1.3e-4), 4: (4.3e-4, 2e-4, 8.5e-5)}       # measured r4: 6 -> 5.3e-4 / 1.7e-3 / 9.6e-5, 4 -> 3.3e-4 / 2.3e-5 / 6.3e-5
+# (4 x the reference graph's own drift, frozen by tests/test_drift_cpu.py); these sit ~1.1-1.3x above what the kernels measure today and BELOW the
+# frozen bound (max-abs: 6.0e-4 against 6.6e-4 since round 5), so a coarser kernel trips here before it reaches the bound.  (max |dev|, share of points beyond 3e-4, relative L2)
+DENSE_SENTINEL = {6: (6.0e-4, 4e-3, 1.3e-4), 4: (4.3e-4, 2e-4, 8.5e-5)}       # measured r4: 6 -> 5.3e-4 / 1.7e-3 / 9.6e-5, 4 -> 3.3e-4 / 2.3e-5 / 6.3e-5
 
 
 def _dense_check(out, dense_tag, tile):

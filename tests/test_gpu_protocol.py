@@ -16,19 +16,14 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 sys.path.insert(0, G)
 
 
-def test_one_epoch_loss_curve_and_miou_match_the_reference_run():
+def _run_protocol(precision):
+    """The reference's loop (train.py:100-134) + validation pass (train.py:169-206) through the engine; returns (losses, report)."""
     import pytorch_camvid_amd as A
-    from protocol_data import PROTO, proto_batch
-    r0 = dict(np.load(os.path.join(G, "protocol_unet_2x360x480_run0.npz")))
-    r1 = dict(np.load(os.path.join(G, "protocol_unet_2x360x480_run1.npz")))
-    P = PROTO
-    spread = np.abs(r0["losses"] - r1["losses"])
-    assert spread[0] == 0.0 and spread.max() < 5e-3                   # the fixture pair itself: identical start, close curves
-    tol = np.maximum(4.0 * np.maximum.accumulate(spread), 2e-5)       # non-decreasing envelope; first step is a pure forward
-    tol[1:] = np.maximum(tol[1:], 4.0 * spread.max() * 0.1)           # early steps: at least a tenth of the curve's spread
+    from protocol_data import PROTO as P, proto_batch
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     net = A.UNet(3, 12).to(dev).train()
+    A.set_conv_precision(net, precision)
     opt = torch.optim.AdamW(net.parameters(), lr=P["lr"], weight_decay=0)                                   # train.py:100
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=P["lr"], steps_per_epoch=P["steps"], epochs=1)   # train.py:103-104
     lossf = A.CrossEntropyLoss()
@@ -40,13 +35,57 @@ def test_one_epoch_loss_curve_and_miou_match_the_reference_run():
         loss.backward()
         opt.step(); sched.step()
         losses.append(loss.detach())
-    losses = torch.stack(losses).cpu().numpy()
+    val = [tuple(t.to(dev) for t in proto_batch(i, val=True)) for i in range(P["val_batches"])]
+    return torch.stack(losses).cpu().numpy(), A.evaluate_report(net, val, num_classes=12, ignore_index=11)
+
+
+def test_bf16_mode_trains_to_the_reference_curve_and_miou():
+    """VERDICT r4 #1 — configs[3]'s arithmetic (bf16 storage + bf16 MFMA, set_conv_precision(net, "bf16")) is NARROWER than the
+    reference's fp32, so single-step agreement is not the parity statement that matters: the whole protocol is.  The same 300 AdamW +
+    OneCycleLR steps as the fp32 test above, in bf16 mode, against the REFERENCE's fp32 run (protocol_unet_2x360x480_run0.npz):
+      * validation mIoU within +-0.005 (BASELINE.json / README.md:39 tolerance) and per-class IoU within 0.01;
+      * loss curve within SAFETY x the envelope that bf16 storage costs BY CONSTRUCTION: oracle/bf16_emul.py (the reference graph
+        with the device's rounding points) run through the same protocol on CPU (tests/golden/make_drift.py bf16proto ->
+        protocol_bf16emu_unet_2x360x480_run0.npz) — the tolerance is derived from that run's distance to the reference, not chosen;
+      * final loss (mean of the last 20 steps) and validation loss within the same derived bound."""
+    r0 = dict(np.load(os.path.join(G, "protocol_unet_2x360x480_run0.npz")))
+    r1 = dict(np.load(os.path.join(G, "protocol_unet_2x360x480_run1.npz")))
+    emu = dict(np.load(os.path.join(G, "protocol_bf16emu_unet_2x360x480_run0.npz")))
+    ref = r0["losses"]
+    cost = np.abs(emu["losses"] - ref)                       # what bf16 storage costs the curve by construction (emulation vs reference)
+    spread = np.abs(ref - r1["losses"])                      # the reference's own reproducibility
+    assert cost[0] < 2e-3 and abs(float(emu["miou"]) - float(r0["miou"])) <= 0.005      # the emulation itself trains like the reference
+    tol = 4.0 * np.maximum.accumulate(np.maximum(cost, spread))
+    tol = np.maximum(tol, 4.0 * max(cost.max(), spread.max()) * 0.1)
+    losses, rep = _run_protocol("bf16")
+    d = np.abs(losses - ref)
+    worst = int(np.argmax(d / tol))
+    ref_miou = float(r0["miou"])
+    print(f"bf16 protocol: max |loss - reference| {d.max():.2e} at step {int(d.argmax())} (bf16 emulation vs reference {cost.max():.2e}, "
+          f"reference pair {spread.max():.2e}); last-20 mean {losses[-20:].mean():.5f} vs {ref[-20:].mean():.5f}; "
+          f"mIoU {rep['miou']:.5f} vs reference {ref_miou:.5f} (emulation {float(emu['miou']):.5f}); val loss {rep['loss']:.5f} vs "
+          f"{float(np.mean(r0['val_loss'])):.5f}")
+    assert (d <= tol).all(), (worst, float(d[worst]), float(tol[worst]), float(losses[worst]), float(ref[worst]))
+    assert abs(rep["miou"] - ref_miou) <= 0.005                         # BASELINE.json: mIoU +-0.005
+    end_tol = max(5e-3, 4.0 * abs(float(emu["losses"][-20:].mean()) - float(ref[-20:].mean())))
+    assert abs(float(losses[-20:].mean()) - float(ref[-20:].mean())) <= end_tol
+    assert abs(rep["loss"] - float(np.mean(r0["val_loss"]))) <= max(5e-3, 4.0 * abs(float(np.mean(emu["val_loss"])) - float(np.mean(r0["val_loss"]))))
+    iou_ref = np.asarray(r0["inter"][:11]) / np.asarray(r0["union"][:11])
+    assert np.abs(rep["iou"].numpy()[:11] - iou_ref).max() < 0.01
+
+
+def test_one_epoch_loss_curve_and_miou_match_the_reference_run():
+    r0 = dict(np.load(os.path.join(G, "protocol_unet_2x360x480_run0.npz")))
+    r1 = dict(np.load(os.path.join(G, "protocol_unet_2x360x480_run1.npz")))
+    spread = np.abs(r0["losses"] - r1["losses"])
+    assert spread[0] == 0.0 and spread.max() < 5e-3                   # the fixture pair itself: identical start, close curves
+    tol = np.maximum(4.0 * np.maximum.accumulate(spread), 2e-5)       # non-decreasing envelope; first step is a pure forward
+    tol[1:] = np.maximum(tol[1:], 4.0 * spread.max() * 0.1)           # early steps: at least a tenth of the curve's spread
+    losses, rep = _run_protocol("fp32")
     d = np.abs(losses - r0["losses"])
     worst = int(np.argmax(d / tol))
     print(f"protocol: max |loss - ref| {d.max():.2e} (reference pair {spread.max():.2e}); final {losses[-1]:.5f} vs {r0['losses'][-1]:.5f}")
     assert (d <= tol).all(), (worst, float(d[worst]), float(tol[worst]), float(losses[worst]), float(r0["losses"][worst]))
-    val = [tuple(t.to(dev) for t in proto_batch(i, val=True)) for i in range(P["val_batches"])]
-    rep = A.evaluate_report(net, val, num_classes=12, ignore_index=11)
     ref_miou = float(r0["miou"])
     print(f"protocol: mIoU {rep['miou']:.5f} vs reference {ref_miou:.5f} (reference pair differs by {abs(ref_miou - float(r1['miou'])):.1e})")
     assert abs(rep["miou"] - ref_miou) <= 0.005                         # BASELINE.json: mIoU +-0.005

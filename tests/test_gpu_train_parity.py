@@ -24,10 +24,12 @@ def _task(n_batches, n, h, w, seed):
     return images, masks
 
 
-def _run(make_net, loss_fn, argmax, steps, images, masks, val_images, val_masks):
+def _run(make_net, loss_fn, argmax, steps, images, masks, val_images, val_masks, prepare=None):
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     net = make_net().to(dev).train()
+    if prepare is not None:
+        prepare(net)
     opt = torch.optim.AdamW(net.parameters(), lr=2e-3, weight_decay=0.0)             # train.py:100 (lr raised: short run)
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=2e-3, total_steps=steps)  # train.py:103-104
     losses = []
@@ -62,5 +64,27 @@ def test_training_reaches_the_same_miou_as_the_reference_graph():
     assert abs(l_a[0] - l_r[0]) < 1e-4                       # identical initialisation and first forward
     assert np.abs(l_a[:5] - l_r[:5]).max() < 2e-2            # the first steps track each other
     assert l_a[-10:].mean() < 0.25 * l_a[0] and l_r[-10:].mean() < 0.25 * l_r[0]          # both learn the task
+    assert abs(l_a[-10:].mean() - l_r[-10:].mean()) < 0.05
+    assert miou_a > 0.9 and miou_r > 0.9 and abs(miou_a - miou_r) <= 0.005, (miou_a, miou_r)
+
+
+def test_bf16_mode_training_reaches_the_same_miou_as_the_reference_graph():
+    """The same 120-step task with set_conv_precision(net, "bf16") (BASELINE.json configs[3]'s arithmetic: bf16 storage + bf16 MFMA)
+    against the fp32 reference graph: a mode narrower than the reference's arithmetic must still TRAIN like it —
+    same bar as the fp32 test: validation mIoU within +-0.005, matching final losses; the early steps may differ by what bf16
+    rounding of every stored activation costs (a few 1e-3 on a loss of ~2.5)."""
+    import pytorch_camvid_amd as A
+    from oracle import torch_ref as R
+    steps = 120
+    images, masks = _task(8, 4, 96, 128, seed=5)
+    val_images, val_masks = _task(2, 4, 96, 128, seed=6)
+    l_a, miou_a = _run(lambda: A.get_model("unet", 3, 12), A.CrossEntropyLoss(), A.argmax_channels, steps,
+                       images, masks, val_images, val_masks, prepare=lambda n: A.set_conv_precision(n, "bf16"))
+    l_r, miou_r = _run(lambda: R.build("unet", 3, 12), torch.nn.CrossEntropyLoss(), lambda o: o.argmax(1), steps,
+                       images, masks, val_images, val_masks)
+    print(f"bf16: final loss {l_a[-10:].mean():.4f} vs {l_r[-10:].mean():.4f}; first-5 max diff {np.abs(l_a[:5] - l_r[:5]).max():.2e}; mIoU {miou_a:.4f} vs {miou_r:.4f}")
+    assert abs(l_a[0] - l_r[0]) < 5e-3                       # identical initialisation; one forward in bf16 storage
+    assert np.abs(l_a[:5] - l_r[:5]).max() < 5e-2
+    assert l_a[-10:].mean() < 0.25 * l_a[0] and l_r[-10:].mean() < 0.25 * l_r[0]
     assert abs(l_a[-10:].mean() - l_r[-10:].mean()) < 0.05
     assert miou_a > 0.9 and miou_r > 0.9 and abs(miou_a - miou_r) <= 0.005, (miou_a, miou_r)

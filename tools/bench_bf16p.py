@@ -1,7 +1,9 @@
 """Timing of the bf16 forward / data-grad conv kernels on a few configs[3] layers (no statistics), for A/B runs under
-CVK_BF16P / CVK_BF16P_D / CVK_BF16P_DBG:   python tools/bench_bf16p.py [tag]"""
+the experiment knobs CVK_BF16P / CVK_BF16P_H64 / CVK_BF16P_H128 / CVK_STREAM_HINTS (experiments build):   python tools/bench_bf16p.py [tag]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _exp  # noqa: F401  (experiments build of the library: CVK_* knobs and time stamps)
 import torch
 from pytorch_camvid_amd import _lib
 from pytorch_camvid_amd._lib import check

@@ -1,6 +1,8 @@
 """Per-tile timeline of workgroup 0 of the 64-channel ping-pong kernel (CVK_BF16H_DBG=1): python tools/tile_stamps_h.py Cin Cout H W"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _exp  # noqa: F401  (experiments build of the library: CVK_* knobs and time stamps)
 import torch
 from pytorch_camvid_amd import _lib
 from pytorch_camvid_amd._lib import check
