@@ -90,6 +90,16 @@ class _SyncCall:
         self.work = []
         self.launched = []
 
+    def closes_bucket(self):
+        """Will the NEXT layer_done() hand a bucket to the all-reduce?  (The executor finalises its queued gradient pieces first.)"""
+        if self.next_bucket >= len(self.buckets) or self.layers_done >= len(self.ranges):
+            return False
+        return self.buckets[self.next_bucket][1] <= self.ranges[self.layers_done][1]
+
+    def in_flight(self):
+        """Has an asynchronous collective been issued in this backward pass (it may still be running beside the next kernels)?"""
+        return len(self.work) > 0
+
     def layer_done(self, st, slot):
         self.layers_done += 1
         done_upto = self.ranges[self.layers_done - 1][1]

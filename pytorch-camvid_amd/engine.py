@@ -299,11 +299,11 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
             bpart = _empty(2 * Pf * cout, x.device)
             _timed(R, "k_conv3x3_wino4f<bnred>", flops, lambda: check(
                 lib.cvk_conv3x3_wino4f_bnred(x.data_ptr(), Uf.data_ptr(), y.data_ptr(), N, H, W, k_ch, cout, ldy, *bnred[:5],
-                                             bpart.data_ptr(), R.persistent_wgs(), s), "cvk_conv3x3_wino4f_bnred"), executed=0.5 * flops)
+                                             bpart.data_ptr(), R.launch_wgs(), s), "cvk_conv3x3_wino4f_bnred"), executed=0.5 * flops)
             bnred[5].append((bpart, Pf))
             return None
         _timed(R, "k_conv3x3_wino4f", flops, lambda: check(
-            lib.cvk_conv3x3_wino4f(x.data_ptr(), Uf.data_ptr(), bias, y.data_ptr(), sp, cnt, N, H, W, k_ch, cout, ldy, R.persistent_wgs(), s),
+            lib.cvk_conv3x3_wino4f(x.data_ptr(), Uf.data_ptr(), bias, y.data_ptr(), sp, cnt, N, H, W, k_ch, cout, ldy, R.launch_wgs(), s),
             "cvk_conv3x3_wino4f" + what), executed=0.5 * flops)
         return (Pf, cnt) if sp is not None else None
     if use4:
@@ -776,7 +776,7 @@ class ConvBnRelu(Op):
             cnt = stats.data_ptr() + 4 * 2 * P * C
             _timed(R, bf16_kernel_name(lib, N, H, W, src.ld, C, True), flops, lambda: check(
                 lib.cvk_conv3x3_bf16s_wg(X.data_ptr(), wb.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), cnt, N, H, W, src.ld, C, C,
-                                         R.persistent_wgs(), s), "cvk_conv3x3_bf16s"))
+                                         R.launch_wgs(), s), "cvk_conv3x3_bf16s"))
             wsb = lib.cvk_bn_finalize_workspace_bytes(P, C)
             ws = R.workspace(wsb, dev)
             track = bn.track_running_stats and bn.running_mean is not None
@@ -844,7 +844,7 @@ class ConvBnRelu(Op):
             dX = torch.empty((N, H, W, src.ld), device=dev, dtype=_BF16)
             _timed(R, bf16_kernel_name(lib, N, H, W, ld_dy, self.cin, False), flops, lambda: check(
                 lib.cvk_conv3x3_bf16s_wg(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, None, N, H, W, ld_dy, self.cin, src.ld,
-                                         R.persistent_wgs(), s), "cvk_conv3x3_bf16s(dgrad)"))
+                                         R.launch_wgs(), s), "cvk_conv3x3_bf16s(dgrad)"))
             st.grad[src.id] = dX
         # partial slabs now, the sum over the slabs with every other layer's in ONE launch (Runner.flush_wreduces): nobody reads a weight
         # gradient before the end of backward (or the all-reduce of its bucket); 23 reductions of ~11 us were 0.26 ms of a 21 ms step
@@ -1107,6 +1107,7 @@ class Runner:
         self.lib = _lib.load()
         self._ws = None
         self._dp_wgs = None
+        self._collectives_in_flight = False     # a gradient bucket's all-reduce has been issued and backward is still running
         self.grad_sync = None       # set by ddp.DataParallel
         self.wino = WINO_DEFAULT
         self.wino4 = WINO4_DEFAULT
@@ -1138,6 +1139,15 @@ class Runner:
             cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
             self._dp_wgs = max(8, cus - int(os.environ.get("CVK_DP_RESERVE_CUS", "16")))
         return self._dp_wgs
+
+    def launch_wgs(self):
+        """Workgroup cap for a persistent-kernel launch NOW: the data-parallel cap only while a collective can be in flight — from the
+        first gradient bucket's all-reduce to the end of backward (round 5).  The forward pass and the part of backward before the
+        first bucket run on every CU: a capped grid changes the tile rounds of the persistent walk (768 tiles = 3 rounds of 256
+        workgroups but 4 of 240: measured +7-8 % on the whole bf16 step at world 1 for ANY channel count between 2 and 16, so the cost
+        was the lost fit, not the CUs), and there is nothing to leave CUs to before the first bucket is issued.  Results are bitwise
+        independent of the cap (tests/test_gpu_wino4f.py, tests/test_gpu_bf16.py)."""
+        return self.persistent_wgs() if self._collectives_in_flight else 0
 
     def derived(self, key, src, build, job=None):
         """The derived weight tensor `key` of parameter `src`: cached while the weights are provably unchanged.
@@ -1267,9 +1277,11 @@ class Runner:
 
     def grads_ready(self, st, slot):
         if st.sync is not None:
-            self.flush_colsums(st)          # a bucket may be handed to the all-reduce: its bias and weight gradients must be final
-            self.flush_wreduces(st)
+            if st.sync.closes_bucket():     # this layer completes a bucket that is handed to the all-reduce now: its queued bias and
+                self.flush_colsums(st)      # weight gradient finalisations must have run (round 5: only then — flushing after every
+                self.flush_wreduces(st)     # layer turned the two batched launches of a backward pass into 23 + 23 under data parallel)
             st.sync.layer_done(st, slot)
+            self._collectives_in_flight = st.sync.in_flight()
 
     # ---- forward / backward -------------------------------------------------------------------------------------
     def tile_for(self, plan):
@@ -1281,6 +1293,7 @@ class Runner:
     def forward(self, plan, x, params, training, need_grad):
         dev = x.device
         self.w2tile, self.w2tile_dgrad = self.tile_for(plan)
+        self._collectives_in_flight = False     # finish() of the previous backward waited for every collective
         st = RunState(params, training, need_grad)
         st.device = dev
         st.plan = plan
@@ -1331,6 +1344,7 @@ class Runner:
         # accumulation across zero_grad(set_to_none=True)): no later backward ever writes into memory handed out here.
         st.gflat = torch.empty(total, device=dev, dtype=_F32)
         st.sync = self.grad_sync.begin(st, plan) if self.grad_sync is not None else None
+        self._collectives_in_flight = False
         ob = plan.output.buf
         gp = gout.permute(0, 2, 3, 1)
         if ob.ld == ob.C and gp.is_contiguous():
@@ -1364,6 +1378,7 @@ class Runner:
             grads.append(seg)
         if st.sync is not None:
             st.sync.finish(st)
+        self._collectives_in_flight = False
         st.act.clear(); st.saved.clear(); st.grad.clear()
         return dx, grads
 

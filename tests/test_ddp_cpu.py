@@ -71,3 +71,46 @@ def test_init_process_group_couples_channels_and_cu_reservation(monkeypatch):
     monkeypatch.delenv("NCCL_MAX_NCHANNELS"); monkeypatch.delenv("CVK_DP_RESERVE_CUS")
     ddp.init_process_group("gloo")
     assert "NCCL_MAX_NCHANNELS" not in seen["env"]                                                       # nothing RCCL-specific for gloo
+
+
+def test_closes_bucket_predicts_exactly_the_layers_that_issue():
+    """engine.Runner.grads_ready flushes its queued gradient finalisations only when _SyncCall.closes_bucket() says the layer that
+    just finished hands a bucket to the all-reduce (round 5; before: after every layer).  The prediction must be exact: a bucket issued
+    without the flush would all-reduce unfinished bias / weight gradients."""
+    from pytorch_camvid_amd.ddp import _SyncCall
+
+    class Owner:
+        bucket_floats = 25
+        wait_events = None
+
+        def __init__(self):
+            self.issued = []
+
+        def _issue(self, call, t):
+            self.issued.append(int(t.numel()))
+            call.work.append((None, None))
+
+    class St:
+        pass
+    sizes = [10, 20, 5, 65, 1]                  # per-layer gradient floats in completion order (multiples of nothing: offsets given below)
+    st = St()
+    st.params = [torch.zeros(1)] * (4 * len(sizes))
+    offs, o = [0] * (4 * len(sizes)), 0
+    for slot in range(len(sizes) - 1, -1, -1):  # last-executed block first in the buffer (engine.layout_grads)
+        offs[4 * slot] = o
+        offs[4 * slot + 1] = offs[4 * slot + 2] = o
+        offs[4 * slot + 3] = o + sizes[len(sizes) - 1 - slot] - 4
+        o += sizes[len(sizes) - 1 - slot]
+    st.goffs, st.gflat = offs, torch.zeros(o)
+    owner = Owner()
+    call = _SyncCall(owner, st)
+    assert not call.in_flight()
+    predicted, actual = [], []
+    for k, slot in enumerate(range(len(sizes) - 1, -1, -1)):
+        predicted.append(call.closes_bucket())
+        n0 = len(owner.issued)
+        call.layer_done(st, slot)
+        actual.append(len(owner.issued) > n0)
+    assert predicted == actual and any(actual) and not all(actual), (predicted, actual)
+    assert call.in_flight() and not call.closes_bucket()          # everything issued: nothing left to close
+    assert sum(owner.issued) == o

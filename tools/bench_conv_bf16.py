@@ -2,6 +2,9 @@
     python tools/bench_conv_bf16.py [N H W]        default 4 720 960 (BASELINE.json configs[3])"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("CVK_EXP"):          # CVK_EXP=1: the experiments build (CVK_* kernel knobs)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _exp  # noqa: F401
 import torch
 from pytorch_camvid_amd import _lib
 from pytorch_camvid_amd._lib import check
@@ -44,7 +47,11 @@ for name, ci, co, d in LAYERS:
     st = torch.empty(2 * P * co + P, device=dev)
     flops = 18.0 * M * ci * co
     t = timeit(lambda: check(lib.cvk_conv3x3_bf16s(x.data_ptr(), wp.data_ptr(), b.data_ptr(), y.data_ptr(), st.data_ptr(), st.data_ptr() + 8 * P * co, N, h, w, ldx, co, co, s)))
-    row = f"{name:8s} {ci:5d}->{co:5d} @{h:4d}x{w:4d}  fwd {t*1e6:8.1f}us {flops/t/1e12:7.1f}TF"
+    KN = {0: "s", 1: "q", 2: "h", 3: "hP", 4: "st", 5: "st2"}
+    tl = N * ((h + 15) // 16) * ((w + 31) // 32)
+    kf = lib.cvk_conv3x3_bf16s_kernel(N, h, w, ldx, co, 1)
+    nt = tl * ((co + 127) // 128 if kf == 1 else (co + 63) // 64)
+    row = f"{name:8s} {ci:5d}->{co:5d} @{h:4d}x{w:4d}  fwd[{KN[kf]:3s} {nt / 256.0:5.2f}r] {t*1e6:8.1f}us {flops/t/1e12:7.1f}TF"
     tot["fwd"][0] += flops; tot["fwd"][1] += t
     ld_dy = max(32, co)
     dy = torch.randn(N, h, w, ld_dy, device=dev).to(BF)
@@ -53,10 +60,12 @@ for name, ci, co, d in LAYERS:
         check(lib.cvk_pack_weight_dgrad_bf16(wt.data_ptr(), wd.data_ptr(), co, ci, ld_dy, s))
         dx = torch.empty(M * ldx, device=dev, dtype=BF)
         t = timeit(lambda: check(lib.cvk_conv3x3_bf16s(dy.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), None, None, N, h, w, ld_dy, ci, ldx, s)))
-        row += f"  dgrad {t*1e6:8.1f}us {flops/t/1e12:7.1f}TF"
+        kd = lib.cvk_conv3x3_bf16s_kernel(N, h, w, ld_dy, ci, 0)
+        ntd = tl * ((ci + 127) // 128 if kd == 1 else (ci + 63) // 64)
+        row += f"  dgrad[{KN[kd]:3s} {ntd / 256.0:5.2f}r] {t*1e6:8.1f}us {flops/t/1e12:7.1f}TF"
         tot["dgrad"][0] += flops; tot["dgrad"][1] += t
     else:
-        row += " " * 33
+        row += " " * 45
     dw = torch.empty(co * 9 * ci, device=dev)
     wsb = lib.cvk_conv3x3_wgrad_bf16s_workspace_bytes(N, h, w, ci, co)
     ws = torch.empty(wsb, device=dev, dtype=torch.uint8)

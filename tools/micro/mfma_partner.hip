@@ -28,7 +28,9 @@ __device__ __forceinline__ i32x4v raw_rsrc_2g(const void* base) {
     return r;
 }
 
-template <int MODE, int SLEEP, int OWN>     // OWN: the MFMA waves issue one zero-fill DMA per iteration themselves (partners idle when MODE 0)
+// round 5: PRIO = s_setprio of the partner waves (the MFMA waves stay at 0); OWNV = v_add_u32 per MFMA in the MFMA waves' OWN stream;
+// M16 = v_mfma_f32_16x16x32_bf16 (16 cycles) instead of 32x32x16 (32 cycles)
+template <int MODE, int SLEEP, int OWN, int PRIO = 0, int OWNV = 0, int M16 = 0>     // OWN: the MFMA waves issue one zero-fill DMA per iteration themselves (partners idle when MODE 0)
 __global__ __launch_bounds__(512, 2) void k(float* out, const float* src, unsigned long long* stamps, int iters, unsigned long long limit) {
     __shared__ __attribute__((aligned(1024))) char smem[64 * 1024];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -49,8 +51,18 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const float* src, unsign
                 const unsigned off = 0x80000000u;
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(off), "s"(rsrc), "s"(lds0 + 32768 + wave * 1024) : "memory");
             }
+            unsigned vv = lane;
 #pragma unroll
-            for (int j = 0; j < NM; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[j], 0, 0, 0);
+            for (int j = 0; j < NM; ++j) {
+                if (M16) {
+                    f32x4 c4 = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, c4, 0, 0, 0);
+                    acc[j][0] = c4[0]; acc[j][1] = c4[1]; acc[j][2] = c4[2]; acc[j][3] = c4[3];
+                } else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < OWNV; ++q) asm volatile("v_add_u32 %0, %0, %1" : "+v"(vv) : "v"(lane));
+            }
+            asm volatile("" :: "v"(vv));
         }
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
         float s = 0.f;
@@ -61,6 +73,7 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const float* src, unsign
         return;
     }
     if (MODE == 0) return;
+    if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     unsigned v = lane, n = 0;
     f32x4 sink = {0.f, 0.f, 0.f, 0.f};
@@ -158,12 +171,12 @@ int run2(const char* what, float* out, const float* src, unsigned long long* sta
     return 0;
 }
 
-template <int MODE, int SLEEP, int OWN>
+template <int MODE, int SLEEP, int OWN, int PRIO = 0, int OWNV = 0, int M16 = 0>
 int run(const char* what, float* out, const float* src, unsigned long long* stamps) {
     const int iters = 4000;
     const unsigned long long limit = (unsigned long long)iters * 8 * 34;
     CK(hipMemset(stamps, 0, 2048 * 8));
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<MODE, SLEEP, OWN>), dim3(256), dim3(512), 0, 0, out, src, stamps, iters, limit);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<MODE, SLEEP, OWN, PRIO, OWNV, M16>), dim3(256), dim3(512), 0, 0, out, src, stamps, iters, limit);
     CK(hipDeviceSynchronize());
     unsigned long long h[2048];
     CK(hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost));
@@ -198,6 +211,19 @@ int main() {
     run<5, 0, 0>("partner: 8 v_add_u32, back to back", out, src, stamps);
     run<0, 0, 1>("own stream: one zero-fill LDS-DMA per 8 MFMAs, partner idle", out, src, stamps);
     run<6, 2, 1>("own stream: one zero-fill LDS-DMA per 8 MFMAs, partner sleeps", out, src, stamps);
+    printf("# round 5: partner priority / vector work in the MFMA wave's own stream / 16x16x32 shape\n");
+    run<5, 0, 0, 3>("partner: 8 v_add_u32 back to back, partner s_setprio 3", out, src, stamps);
+    run<4, 0, 0, 3>("partner: ds_read_b128 back to back, partner s_setprio 3", out, src, stamps);
+    run<0, 0, 0, 0, 1>("own stream: 1 v_add_u32 per MFMA, partner idle", out, src, stamps);
+    run<0, 0, 0, 0, 2>("own stream: 2 v_add_u32 per MFMA, partner idle", out, src, stamps);
+    run<0, 0, 0, 0, 4>("own stream: 4 v_add_u32 per MFMA, partner idle", out, src, stamps);
+    run<0, 0, 0, 0, 6>("own stream: 6 v_add_u32 per MFMA, partner idle", out, src, stamps);
+    run<0, 0, 0, 0, 0, 1>("16x16x32: partner idle", out, src, stamps);
+    run<5, 0, 0, 0, 0, 1>("16x16x32: partner 8 v_add_u32 back to back", out, src, stamps);
+    run<5, 0, 0, 3, 0, 1>("16x16x32: partner 8 v_add_u32 back to back, partner s_setprio 3", out, src, stamps);
+    run<0, 0, 0, 0, 1, 1>("16x16x32: own stream 1 v_add_u32 per MFMA", out, src, stamps);
+    run<0, 0, 0, 0, 2, 1>("16x16x32: own stream 2 v_add_u32 per MFMA", out, src, stamps);
+    run<0, 0, 0, 0, 3, 1>("16x16x32: own stream 3 v_add_u32 per MFMA", out, src, stamps);
     run2<0, 3>("nothing between", out, src, stamps);
     run2<5, 3>("s_nop", out, src, stamps);
     run2<4, 3>("one v_mov_b32", out, src, stamps);
