@@ -373,7 +373,7 @@ def dp_identity(dev, world, rehearsal):
                     "all-reduce kernels occupy NCCL_MAX_NCHANNELS workgroups while backward runs; lower it (e.g. 8-16) if "
                     "allreduce_exposed_ms is small but ms_per_step grows with N, and A/B the 2-D GEMM's staggered start with the experiments build (CVK_W2D_NO_STAGGER=1).  The persistent "
                     "fused F(4,3) kernel and the persistent bf16 kernels (one workgroup per CU) run on CUs - CVK_DP_RESERVE_CUS workgroups under data "
-                    "parallel; ddp.init_process_group sets NCCL_MAX_NCHANNELS (default 16) and CVK_DP_RESERVE_CUS together."}
+                    "parallel; ddp.init_process_group sets NCCL_MAX_NCHANNELS (default 8) and CVK_DP_RESERVE_CUS together."}
 
 
 def _claim_stdout():

@@ -23,16 +23,18 @@ import torch.nn as nn
 
 
 # RCCL's all-reduce kernels run beside backward and hold one CU per channel; the exchange needs ~7 GB/s (138 MB per 34 ms
-# step), so a few channels suffice.  The executor leaves CVK_DP_RESERVE_CUS CUs (default 16) to them: its persistent
+# step), so a few channels suffice: 8 since round 5 (tools/dp_sweep.sh at world size 1: 2 / 4 / 8 / 16 channels cost the step the same
+# within 0.1 % — the exchange is never exposed — so the default is the value that leaves RCCL a comfortable 8 rings for the day the
+# links are real and reserves half the CUs of round 4's 16).  The executor leaves CVK_DP_RESERVE_CUS CUs (default 8) to them: its persistent
 # one-workgroup-per-CU kernels launch on CUs - CVK_DP_RESERVE_CUS workgroups under data parallel (engine.Runner.persistent_wgs).
 # The two numbers belong together, so they are set together — here, not in a benchmark script.
-DEFAULT_RCCL_CHANNELS = 16
+DEFAULT_RCCL_CHANNELS = 8
 
 
 def init_process_group(backend="nccl", rccl_channels=None, **kwargs):
     """torch.distributed.init_process_group with the RCCL settings this path is tuned for (VERDICT r3 #5b: users of
     ddp.DataParallel get what bench.py measures).  Before the group is created (RCCL reads its environment at communicator creation):
-      * NCCL_MAX_NCHANNELS (unless the caller's environment already sets it) = rccl_channels (default 16);
+      * NCCL_MAX_NCHANNELS (unless the caller's environment already sets it) = rccl_channels (default 8);
       * CVK_DP_RESERVE_CUS follows it (unless set): the CUs the executor's persistent kernels leave free for the collectives;
       * HSA_ENABLE_IPC_MODE_LEGACY=0 (the host driver of this pool only supports dmabuf IPC).
     Rendezvous arguments (init_method, rank, world_size, device_id, ...) pass through unchanged.  Returns rccl_env()."""

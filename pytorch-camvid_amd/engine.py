@@ -1131,13 +1131,13 @@ class Runner:
 
     def persistent_wgs(self):
         """Workgroup cap of the persistent (one-workgroup-per-CU) kernels: 0 = every CU.  Under data-parallel training
-        CVK_DP_RESERVE_CUS (default 16) CUs are left to RCCL's all-reduce kernels, which run beside backward."""
+        CVK_DP_RESERVE_CUS (default 8) CUs are left to RCCL's all-reduce kernels, which run beside backward."""
         gs = self.grad_sync
         if gs is None or (getattr(gs, "world", 1) <= 1 and not getattr(gs, "always_issue", False)):
             return 0
         if self._dp_wgs is None:
             cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-            self._dp_wgs = max(8, cus - int(os.environ.get("CVK_DP_RESERVE_CUS", "16")))
+            self._dp_wgs = max(8, cus - int(os.environ.get("CVK_DP_RESERVE_CUS", "8")))
         return self._dp_wgs
 
     def launch_wgs(self):

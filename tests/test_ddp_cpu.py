@@ -62,12 +62,12 @@ def test_init_process_group_couples_channels_and_cu_reservation(monkeypatch):
         monkeypatch.delenv(k, raising=False)
     env = ddp.init_process_group("nccl", rank=0, world_size=1)
     assert seen["backend"] == "nccl" and seen["kw"] == {"rank": 0, "world_size": 1}
-    assert seen["env"]["NCCL_MAX_NCHANNELS"] == "16" and seen["env"]["CVK_DP_RESERVE_CUS"] == "16" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
-    assert env["NCCL_MAX_NCHANNELS"] == "16"
-    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "8")
+    assert seen["env"]["NCCL_MAX_NCHANNELS"] == "8" and seen["env"]["CVK_DP_RESERVE_CUS"] == "8" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert env["NCCL_MAX_NCHANNELS"] == "8"
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "4")
     monkeypatch.delenv("CVK_DP_RESERVE_CUS")
     ddp.init_process_group("nccl", rccl_channels=32)
-    assert seen["env"]["NCCL_MAX_NCHANNELS"] == "8" and seen["env"]["CVK_DP_RESERVE_CUS"] == "8"      # the caller's environment wins, the pair stays coupled
+    assert seen["env"]["NCCL_MAX_NCHANNELS"] == "4" and seen["env"]["CVK_DP_RESERVE_CUS"] == "4"      # the caller's environment wins, the pair stays coupled
     monkeypatch.delenv("NCCL_MAX_NCHANNELS"); monkeypatch.delenv("CVK_DP_RESERVE_CUS")
     ddp.init_process_group("gloo")
     assert "NCCL_MAX_NCHANNELS" not in seen["env"]                                                       # nothing RCCL-specific for gloo
