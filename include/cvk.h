@@ -173,6 +173,14 @@ int cvk_w6_wgrad_ksplit(int T, int Cin_pad, int Cout);
 int cvk_w6_dy_transform(const float* dy, int ld_dy, float* E, int N, int H, int W, int Cout, void* stream);
 int cvk_w6_dy_transform_both(const float* dy, int ld_dy, float* Vp, float* E, int N, int H, int W, int Cout, void* stream);
 int cvk_w6_gemm_tn(const float* E, const float* V, float* P, int T, int Cin_pad, int Cout, void* stream);
+/* STUDY KERNELS (round 5; not used by the executor — its fp32 path is exact-fp32 MFMA): the GEMM stage above on the bf16 matrix pipe with
+ * 3-term split fp32 operands (x = x1 + x2 + x3 in bf16, the six largest cross-products accumulated in fp32: at least fp32-MFMA accuracy at
+ * 0.375 of its matrix time; csrc/split3.hip, tools/study/).  cvk_split3_planes: fp32 planes P[NX][R][C] -> split planes
+ * bf16 [NX][C/32][3][Rpad][32] (Rpad = cvk_split3_rows_pad(R, 256) for V, (R, 128) for U; C % 32 == 0).  cvk_w2d_gemm_split3:
+ * Mo fp32 [NX][T][Cout] = V * U^T per transform index, both operands as split planes. */
+int cvk_split3_rows_pad(int R, int mult);
+int cvk_split3_planes(const float* P, void* S, int NX, int R, int Rpad, int C, void* stream);
+int cvk_w2d_gemm_split3(const void* V3, const void* U3, float* Mo, int NX, int T, int Tpad, int Cin, int Cout, int Cpad, void* stream);
 int cvk_w6_wgrad_output(const float* P, float* dw, int T, int Cin, int Cin_pad, int Cout, void* stream);
 /* FUSED 1-D Winograd F(4,3) (csrc/wino4f.hip; replaces nn.Conv2d(cin,cout,3,padding=1) fwd and its data-grad,
  * /root/reference/models/unet.py:11, models/segnet.py:8, for the 64/128-channel levels): one workgroup computes all six

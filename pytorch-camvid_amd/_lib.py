@@ -96,6 +96,9 @@ SIGNATURES = {
     "cvk_conv3x3_wgrad_w2d_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
     "cvk_conv3x3_wgrad_w2d": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
     "cvk_w2d_tpad": (c_int, [c_int]),
+    "cvk_split3_rows_pad": (c_int, [c_int, c_int]),
+    "cvk_split3_planes": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_w2d_gemm_split3": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_w2d_wgrad_ksplit": (c_int, [c_int, c_int, c_int]),
     "cvk_w2d_dy_transform": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_w2d_dy_transform_both": (c_int, [c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),

@@ -1,0 +1,215 @@
+// split3.hip — STUDY KERNELS (not used by the executor, whose fp32 path is exact-fp32 MFMA): the batched GEMM stage of
+// the 2-D Winograd path, M_xi[T][Cout] = V_xi[T][Cin] * U_xi[Cout][Cin]^T (csrc/wino2d.hip k_w2d_gemm; reference op: the multiply-adds of
+// nn.Conv2d(3x3) in models/unet.py:11), on the bf16 matrix pipe with SPLIT fp32 operands.
+//
+// Every fp32 value x is written as three bf16 terms x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 8 + 8 + 8
+// mantissa bits) and a product x*w as its six largest cross-products x1w1 + x1w2 + x2w1 + x1w3 + x3w1 + x2w2 (the dropped ones are
+// below 2^-24 relative).  Each cross-product of two bf16 values is EXACT in fp32 and is accumulated in the fp32 accumulators of
+// v_mfma_f32_16x16x32_bf16 — 6 bf16 MFMAs replace 16 cycles-equivalents of fp32 MFMA: 0.375 of the matrix time.  Numerically at least as
+// good as the fp32 MFMA path (tools/study/split_bf16_model.py: 8e-7 / 1.8e-6 relative L2 for F(4x4) / F(6x6) at 256 channels against
+// 1.5e-6 / 3.0e-6 with fp32 products; on the device: tests/test_gpu_split3.py).
+//
+// Operand format ("split planes"): bf16 [xi][Cin/32][term 3][Rpad][32], rows padded with zeros to a multiple of 256 (V) / 128 (U), the
+// four 16-byte chunks of a 64-byte row stored at position c ^ (2 * ((row >> 2) & 1)) — byte for byte the LDS image of a (term, row tile,
+// channel slice) block, so a tile's K loop streams linear 8 KiB ranges by LDS-DMA (the tile-major idea of conv_bf16p.hip).
+// cvk_split3_planes converts fp32 planes [xi][R][C] into it (a stand-alone pass here; a production version would emit the terms from
+// the transform kernels' store loops instead).
+//
+// GEMM kernel: the ping-pong machine of conv_bf16p.hip.  One workgroup = 8 waves = two groups of four (waves w, w + 4 share a SIMD),
+// tile = 256 rows of V (128 per group) x 128 rows of U; a wave owns 64 (co) x 64 (t): 16 accumulator blocks, and per 32-channel slice
+// 24 fragments (4 blocks x 3 terms per operand, one ds_read_b128 each) feed 96 MFMAs — one slice is one phase: group A's MFMA phase
+// runs beside group B's LOAD phase (fragment reads of ITS slice, DMA issue for the slice after), then the roles swap.  Two LDS stages
+// of 72 KiB (V terms 48 + U terms 24); a group requests slice k + 1 at the start of its LOAD(k) and confirms it (vmcnt(0)) at the end
+// of its MFMA(k), ~1.5 phases later; group A moves the shared U tile as well.  D = U * V^T orientation (A operand = U): a lane ends
+// with four consecutive output channels of one tile row -> 16-byte stores.
+#include <type_traits>
+#include "cvk_common.h"
+#include "lds_dma.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned bf16_bits(float v) {          // round to nearest even
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_val(unsigned b) { return __builtin_bit_cast(float, b << 16); }
+
+// fp32 planes [NX][R][C] -> split planes [NX][C/32][3][Rpad][32] (see the file header); one thread = one 8-channel chunk of one row
+__global__ __launch_bounds__(256) void k_split3_planes(const float* __restrict__ P, unsigned* __restrict__ S, int R, int Rpad, int C, long total) {
+    const int c8n = C >> 3, ncs = C >> 5;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % c8n);
+        const long xr = i / c8n;
+        const int r = (int)(xr % Rpad), xi = (int)(xr / Rpad);
+        unsigned t[3][4] = {};
+        if (r < R) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(P + ((size_t)xi * R + r) * C + c8 * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(P + ((size_t)xi * R + r) * C + c8 * 8 + 4);
+            const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned b1 = bf16_bits(v[e]);
+                const float r1 = v[e] - bf16_val(b1);
+                const unsigned b2 = bf16_bits(r1);
+                const unsigned b3 = bf16_bits(r1 - bf16_val(b2));
+                const int sh = (e & 1) * 16;
+                t[0][e >> 1] |= b1 << sh; t[1][e >> 1] |= b2 << sh; t[2][e >> 1] |= b3 << sh;
+            }
+        }
+        const int cs = c8 >> 2, pos = (c8 & 3) ^ (((r >> 2) & 1) << 1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 o = {t[k][0], t[k][1], t[k][2], t[k][3]};
+            *reinterpret_cast<u32x4*>(S + ((((size_t)xi * ncs + cs) * 3 + k) * Rpad + r) * 16 + pos * 4) = o;
+        }
+    }
+}
+
+template <int IMM> __device__ __forceinline__ void dma16_s(unsigned voff, const void* sbase, unsigned lds_base) {
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_base), "n"(IMM) : "memory", "scc");
+}
+__device__ __forceinline__ void pbar() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ bf16x8 rd16(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+constexpr int S3_TM = 256, S3_TN = 128;                 // tile: rows of V (tile index t) x rows of U (output channels)
+constexpr int S3_XT = 3 * S3_TM * 64;                   // 48 KiB: the three V terms of a slice
+constexpr int S3_WT = 3 * S3_TN * 64;                   // 24 KiB: the three U terms
+constexpr int S3_STAGE = S3_XT + S3_WT;                 // 72 KiB
+
+__global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__ V3, const char* __restrict__ U3, float* __restrict__ Mo,
+                                                       int T, int Tpad, int Cin, int Cout, int Cpad, int tilesM, int tilesN) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * S3_STAGE];
+    const unsigned smem_addr = cvk_lds_addr(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int grp = wave >> 2, wi = wave & 3, wc = wave & 1, wp = (wave >> 1) & 1;
+    const int ncs = Cin >> 5;
+    // tile order: the Cout tiles of one row tile are neighbours (they re-read the same V rows: same XCD, same L2), then row tiles, then xi
+    const int bid = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % tilesN;
+    const int mt = (bid / tilesN) % tilesM;
+    const int xi = bid / (tilesN * tilesM);
+
+    // ---- DMA: this wave moves pieces wi and wi + 4 (1 KiB each) of every term of its group's 128 V rows; group A also of the U tile
+    const size_t xterm = (size_t)Tpad * 64, wterm = (size_t)Cpad * 64;          // bytes between two terms of one slice
+    const char* xsrc = V3 + ((size_t)xi * ncs * 3 * Tpad + (size_t)mt * S3_TM + grp * 128) * 64;     // slice 0, term 0, this group's rows
+    const char* wsrc = U3 + ((size_t)xi * ncs * 3 * Cpad + (size_t)nt * S3_TN) * 64;
+    const unsigned voff = wi * 1024 + lane * 16;
+    const unsigned xdst = smem_addr + grp * 8192 + wi * 1024;                   // + stage * S3_STAGE + term * 16384 (+ 4096)
+    const unsigned wdst = smem_addr + S3_XT + wi * 1024;                        // + stage * S3_STAGE + term * 8192 (+ 4096)
+    auto issue_slice = [&](unsigned stage_off) {                               // requests the slice xsrc / wsrc point at, then advances them
+        dma16_s<0>(voff, xsrc, xdst + stage_off);
+        dma16_s<4096>(voff, xsrc + 4096, xdst + stage_off);
+        dma16_s<16384>(voff, xsrc + xterm, xdst + stage_off);
+        dma16_s<16384 + 4096>(voff, xsrc + xterm + 4096, xdst + stage_off);
+        dma16_s<32768>(voff, xsrc + 2 * xterm, xdst + stage_off);
+        dma16_s<32768 + 4096>(voff, xsrc + 2 * xterm + 4096, xdst + stage_off);
+        xsrc += 3 * xterm;
+        if (grp == 0) {
+            dma16_s<0>(voff, wsrc, wdst + stage_off);
+            dma16_s<4096>(voff, wsrc + 4096, wdst + stage_off);
+            dma16_s<8192>(voff, wsrc + wterm, wdst + stage_off);
+            dma16_s<8192 + 4096>(voff, wsrc + wterm + 4096, wdst + stage_off);
+            dma16_s<16384>(voff, wsrc + 2 * wterm, wdst + stage_off);
+            dma16_s<16384 + 4096>(voff, wsrc + 2 * wterm + 4096, wdst + stage_off);
+            wsrc += 3 * wterm;
+        }
+    };
+
+    // ---- fragment addresses: U rows (A operand) wc*64 + rb*16 + l15, V rows (B operand) grp*128 + wp*64 + cb*16 + l15; chunk q4 swizzled
+    const int sw = (q4 ^ (((l15 >> 2) & 1) << 1)) << 4;
+    int wa = S3_XT + (wc * 64 + l15) * 64 + sw;             // + term * 8192 + rb * 1024
+    int xa = (grp * 128 + wp * 64 + l15) * 64 + sw;         // + term * 16384 + cb * 1024
+    int flip = S3_STAGE;
+
+    f32x4v acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    issue_slice(0);
+    cvk_wait_vm<0>();
+    pbar();
+    if (grp == 1) pbar();                       // group B runs one interval behind group A
+
+    for (int cs = 0; cs < ncs; ++cs) {
+        // ======== LOAD phase: request the next slice into the other stage (everybody read it out two phases ago), read this slice's
+        // 24 fragments
+        if (cs + 1 < ncs) issue_slice(((cs + 1) & 1) ? S3_STAGE : 0);
+        bf16x8 w[3][4], x[3][4];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) w[k][rb] = rd16(smem + (wa + k * 8192 + rb * 1024));
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) x[k][cb] = rd16(smem + (xa + k * 16384 + cb * 1024));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pbar();
+        // ======== MFMA phase: 6 cross-products x 16 blocks, the smallest terms first
+        __builtin_amdgcn_s_setprio(1);
+        auto prod = [&](int kw, int kx) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[kw][rb], x[kx][cb], acc[rb][cb], 0, 0, 0);
+        };
+        prod(2, 0); prod(0, 2); prod(1, 1); prod(1, 0); prod(0, 1); prod(0, 0);
+        wa += flip; xa += flip; flip = -flip;
+        __builtin_amdgcn_s_setprio(0);
+        cvk_wait_vm<0>();                       // this wave's pieces of the next slice have landed (requested ~1.5 phases ago)
+        pbar();
+    }
+    if (grp == 0) pbar();
+
+    // ---- epilogue: acc[rb][cb][j] = M[t = mt*256 + grp*128 + wp*64 + cb*16 + l15][co = nt*128 + wc*64 + rb*16 + 4*q4 + j]
+    float* const mo = Mo + (size_t)xi * T * Cout;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int t = mt * S3_TM + grp * 128 + wp * 64 + cb * 16 + l15;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const int co = nt * S3_TN + wc * 64 + rb * 16 + 4 * q4;
+            if (t < T && co < Cout) *reinterpret_cast<f32x4v*>(mo + (size_t)t * Cout + co) = acc[rb][cb];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cvk_split3_rows_pad(int R, int mult) { return (R > 0 && mult > 0) ? cvk_cdiv(R, mult) * mult : 0; }
+
+// P fp32 [NX][R][C] -> S bf16 [NX][C/32][3][Rpad][32] (Rpad = cvk_split3_rows_pad(R, 256) for V, (R, 128) for U; rows >= R zero)
+extern "C" int cvk_split3_planes(const float* P, void* S, int NX, int R, int Rpad, int C, void* stream) {
+    CVK_CHECK_ARG(P && S && NX > 0 && R > 0 && Rpad >= R && C > 0 && C % 32 == 0, "cvk_split3_planes: bad arguments (C must be a multiple of 32)");
+    CVK_CHECK_ARG(cvk_aligned16(P) && cvk_aligned16(S), "cvk_split3_planes: pointers must be 16-byte aligned");
+    const long total = (long)NX * Rpad * (C / 8);
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(k_split3_planes, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, (unsigned*)S, R, Rpad, C, total);
+    CVK_LAUNCH_RETURN("cvk_split3_planes");
+}
+
+// Mo fp32 [NX][T][Cout] = V * U^T per xi, operands as split planes (V3 rows padded to Tpad % 256 == 0, U3 rows to Cpad % 128 == 0)
+extern "C" int cvk_w2d_gemm_split3(const void* V3, const void* U3, float* Mo, int NX, int T, int Tpad, int Cin, int Cout, int Cpad,
+                                   void* stream) {
+    CVK_CHECK_ARG(V3 && U3 && Mo && NX > 0 && T > 0 && Cin > 0 && Cout > 0, "cvk_w2d_gemm_split3: bad arguments");
+    CVK_CHECK_ARG(Cin % 32 == 0 && Cout % 4 == 0 && Tpad % S3_TM == 0 && Tpad >= T && Cpad % S3_TN == 0 && Cpad >= Cout,
+                  "cvk_w2d_gemm_split3: Cin %% 32, Cout %% 4, Tpad %% 256, Cpad %% 128");
+    CVK_CHECK_ARG(cvk_aligned16(V3) && cvk_aligned16(U3) && cvk_aligned16(Mo), "cvk_w2d_gemm_split3: pointers must be 16-byte aligned");
+    const int tilesM = Tpad / S3_TM, tilesN = Cpad / S3_TN;
+    CVK_CHECK_ARG((long)NX * tilesM * tilesN < (1L << 31), "cvk_w2d_gemm_split3: grid too large");
+    hipLaunchKernelGGL(k_gemm_split3, dim3((unsigned)(NX * tilesM * tilesN)), dim3(512), 0, (hipStream_t)stream, (const char*)V3, (const char*)U3,
+                       Mo, T, Tpad, Cin, Cout, Cpad, tilesM, tilesN);
+    CVK_LAUNCH_RETURN("cvk_w2d_gemm_split3");
+}

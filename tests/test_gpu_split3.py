@@ -1,0 +1,110 @@
+"""STUDY kernels (csrc/split3.hip — not used by the executor): the GEMM stage of the 2-D Winograd path with 3-term split
+fp32 operands on the bf16 matrix pipe.  Checked through the C ABI against fp64: (1) the split planes hold x = x1 + x2 + x3 to the last
+bit or two of fp32; (2) the batched GEMM is at least as accurate as the exact-fp32 GEMM of the product (cvk_w6_gemm); (3) a whole
+conv layer — the product's own F(6x6,3x3) input transform, weight transform and output pass around the split GEMM — against an fp64
+convolution of the reference operator (nn.Conv2d(3x3, padding=1), models/unet.py:11)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from pytorch_camvid_amd import _lib
+    return _lib.load(), _lib.check
+
+
+def _split(lib, check, P, NX, R, mult, C, s):
+    Rp = lib.cvk_split3_rows_pad(R, mult)
+    S = torch.empty(NX * (C // 32) * 3 * Rp * 32, device=P.device, dtype=torch.bfloat16)
+    check(lib.cvk_split3_planes(P.data_ptr(), S.data_ptr(), NX, R, Rp, C, s), "cvk_split3_planes")
+    return S, Rp
+
+
+def test_split_planes_hold_the_fp32_value():
+    lib, check = _lib()
+    dev = torch.device("cuda:0"); s = torch.cuda.current_stream().cuda_stream
+    NX, R, C = 3, 37, 64
+    g = torch.Generator().manual_seed(1)
+    P = (torch.randn(NX, R, C, generator=g) * torch.exp(3 * torch.randn(NX, R, C, generator=g))).to(dev)
+    S, Rp = _split(lib, check, P, NX, R, 256, C, s)
+    assert Rp == 256
+    S = S.view(NX, C // 32, 3, Rp, 4, 8).double().cpu()                     # [xi][cs][term][row][chunk position][8]
+    r = torch.arange(Rp)
+    pos = (torch.arange(4)[None, :] ^ (((r >> 2) & 1) << 1)[:, None])       # chunk c of row r sits at position pos[r, c]
+    un = torch.gather(S, 4, pos[None, None, None, :, :, None].expand(NX, C // 32, 3, Rp, 4, 8))
+    tot = un.sum(dim=2).reshape(NX, C // 32, Rp, 32).permute(0, 2, 1, 3).reshape(NX, Rp, C)
+    ref = P.double().cpu()
+    assert torch.all(tot[:, R:] == 0)
+    err = ((tot[:, :R] - ref).abs() / ref.abs().clamp_min(1e-30)).max().item()
+    assert err < 2.0 ** -22, err                                            # 8 + 8 + 8 mantissa bits
+
+
+@pytest.mark.parametrize("T,Cin,Cout", [(300, 64, 128), (2400, 256, 256), (530, 512, 128)])
+def test_split_gemm_is_at_least_as_accurate_as_the_fp32_gemm(T, Cin, Cout):
+    lib, check = _lib()
+    dev = torch.device("cuda:0"); s = torch.cuda.current_stream().cuda_stream
+    NX = 64
+    g = torch.Generator().manual_seed(T)
+    Tp32 = lib.cvk_w2d_tpad(T)
+    V = torch.zeros(NX, Tp32, Cin)
+    V[:, :T] = torch.randn(NX, T, Cin, generator=g).clamp_min(-0.5)
+    U = torch.randn(NX, Cout, Cin, generator=g) / (Cin ** 0.5)
+    Vd, Ud = V.to(dev), U.to(dev)
+    ref = torch.einsum("xtc,xoc->xto", Vd[:, :T].double(), Ud.double())
+    # the product's exact-fp32 GEMM (k_w2d_gemm; planes padded as its contract wants)
+    f = lib.cvk_w6_ksplit(T, Cin, Cout)
+    Mo = torch.zeros(f, NX, T, Cout, device=dev)
+    Vp = torch.cat([Vd.reshape(-1), torch.zeros(128, device=dev)])
+    check(lib.cvk_w6_gemm(Vp.data_ptr(), Ud.data_ptr(), Mo.data_ptr(), T, Cin, Cout, s), "cvk_w6_gemm")
+    e32 = ((Mo.sum(0).double() - ref).norm() / ref.norm()).item()
+    # split operands
+    V3, Tp = _split(lib, check, Vd[:, :T].contiguous(), NX, T, 256, Cin, s)
+    U3, Cp = _split(lib, check, Ud, NX, Cout, 128, Cin, s)
+    M3 = torch.full((NX, T, Cout), float("nan"), device=dev)
+    check(lib.cvk_w2d_gemm_split3(V3.data_ptr(), U3.data_ptr(), M3.data_ptr(), NX, T, Tp, Cin, Cout, Cp, s), "cvk_w2d_gemm_split3")
+    assert torch.isfinite(M3).all()
+    e3 = ((M3.double() - ref).norm() / ref.norm()).item()
+    print(f"T={T} {Cin}->{Cout}: relative L2 vs fp64: exact-fp32 GEMM {e32:.2e}, 3-term split GEMM {e3:.2e}")
+    assert e3 < 5e-7 and e3 <= e32 + 2e-8, (e3, e32)          # fp32 accumulation over Cin terms: ~sqrt(Cin) x 2^-24
+    # bitwise reproducible
+    M3b = torch.empty_like(M3)
+    check(lib.cvk_w2d_gemm_split3(V3.data_ptr(), U3.data_ptr(), M3b.data_ptr(), NX, T, Tp, Cin, Cout, Cp, s), "cvk_w2d_gemm_split3")
+    assert torch.equal(M3, M3b)
+
+
+def test_whole_layer_through_the_split_gemm_vs_fp64_conv():
+    """256 -> 256 channels at 2 x 45 x 60: x -> cvk_w6_input_transform -> split -> split GEMM -> cvk_w6_output, against the fp64
+    convolution; the same layer through the product's fp32 GEMM for comparison (tools/study/split_bf16_model.py predicts 1.8e-6
+    against 3.0e-6)."""
+    lib, check = _lib()
+    dev = torch.device("cuda:0"); s = torch.cuda.current_stream().cuda_stream
+    N, H, W, Cin, Cout, NX = 2, 45, 60, 256, 256, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, H, W, Cin, generator=g).clamp_min(0).to(dev)
+    w = ((torch.rand(Cout, 3, 3, Cin, generator=g) * 2 - 1) / (9 * Cin) ** 0.5).to(dev)         # [Cout][3][3][Cin], the engine's storage
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), padding=1).permute(0, 2, 3, 1)
+    T = lib.cvk_w6_tiles(N, H, W); Tp32 = lib.cvk_w2d_tpad(T)
+    V = torch.zeros(NX * Tp32 * Cin + 128, device=dev)
+    U = torch.empty(NX * Cout * Cin, device=dev)
+    check(lib.cvk_w6_input_transform(x.data_ptr(), V.data_ptr(), N, H, W, Cin, s), "input")
+    check(lib.cvk_w6_weight_transform(w.data_ptr(), U.data_ptr(), Cout, Cin, s), "weight")
+    bias = torch.zeros(Cout, device=dev)
+
+    def finish(Mo_ptr):
+        y = torch.empty(N, H, W, Cout, device=dev)
+        check(lib.cvk_w6_output(Mo_ptr, bias.data_ptr(), y.data_ptr(), None, None, N, H, W, Cin, Cout, Cout, s), "output")
+        return ((y.double() - ref).norm() / ref.norm()).item()
+    f = lib.cvk_w6_ksplit(T, Cin, Cout)
+    Mo = torch.zeros(f * NX * T * Cout, device=dev)
+    check(lib.cvk_w6_gemm(V.data_ptr(), U.data_ptr(), Mo.data_ptr(), T, Cin, Cout, s), "gemm")
+    e32 = finish(Mo.data_ptr())
+    Vv = V[:NX * Tp32 * Cin].view(NX, Tp32, Cin)[:, :T].contiguous()
+    V3, Tp = _split(lib, check, Vv, NX, T, 256, Cin, s)
+    U3, Cp = _split(lib, check, U.view(NX, Cout, Cin), NX, Cout, 128, Cin, s)
+    M3 = torch.zeros(f * NX * T * Cout, device=dev)            # cvk_w6_output adds the f K-range planes: the rest stay zero
+    check(lib.cvk_w2d_gemm_split3(V3.data_ptr(), U3.data_ptr(), M3.data_ptr(), NX, T, Tp, Cin, Cout, Cp, s), "split gemm")
+    e3 = finish(M3.data_ptr())
+    print(f"layer 256->256 @2x45x60 F(6x6,3x3): relative L2 vs fp64: fp32 GEMM {e32:.2e}, split GEMM {e3:.2e}")
+    assert e3 <= e32 and e3 < 3e-6, (e3, e32)

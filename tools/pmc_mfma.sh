@@ -9,7 +9,7 @@ cd "$GRAFT_REPO_ROOT"
 BENCH_ARGS=${BENCH_ARGS:-}
 rm -rf gpurun_out/pmc_mfma gpurun_out/pmc_lds
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE \
-  --kernel-trace --output-format csv -d gpurun_out/pmc_mfma -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile $BENCH_ARGS > /dev/null 2> gpurun_out/pmc_mfma.err
+  --kernel-trace --output-format csv -d gpurun_out/pmc_mfma -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-dp-overhead $BENCH_ARGS > /dev/null 2> gpurun_out/pmc_mfma.err
 python3 - <<'PY'
 import csv, glob, collections, json
 f = glob.glob("gpurun_out/pmc_mfma/*/*counter_collection.csv")[0]
@@ -38,7 +38,7 @@ for n, v in out.items(): print(n[:46].ljust(46), v)
 PY
 
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 \
-  --kernel-trace --output-format csv -d gpurun_out/pmc_lds -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile $BENCH_ARGS > /dev/null 2> gpurun_out/pmc_lds.err
+  --kernel-trace --output-format csv -d gpurun_out/pmc_lds -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-dp-overhead $BENCH_ARGS > /dev/null 2> gpurun_out/pmc_lds.err
 python3 - <<'PY'
 import csv, glob, collections, json
 fs = glob.glob("gpurun_out/pmc_lds/*/*counter_collection.csv")

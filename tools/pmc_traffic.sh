@@ -7,7 +7,7 @@ cd "$GRAFT_REPO_ROOT"
 BENCH_ARGS=${BENCH_ARGS:-}
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile $BENCH_ARGS > /dev/null 2> gpurun_out/pmc_$c.err
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-dp-overhead $BENCH_ARGS > /dev/null 2> gpurun_out/pmc_$c.err
   ls gpurun_out/pmc_$c/*/*counter_collection.csv > /dev/null
 done
 python3 - <<'PY'

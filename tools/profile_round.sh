@@ -17,7 +17,7 @@ stats_pass() {   # $1 suffix, $2... bench args
     local sfx=$1; shift
     local dir="$O/${TAG}_stats_${sfx}"
     rm -rf "$dir"
-    rocprofv3 --kernel-trace --stats --output-format csv -d "$dir" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-configs "$@" \
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$dir" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-configs --no-dp-overhead "$@" \
         > "$O/${TAG}_bench_${sfx}_under_rocprof.json" 2> "$O/${TAG}_stats_${sfx}.err"
     local csv
     csv=$(ls "$dir"/*/*kernel_stats.csv | head -1)

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""time ONE layer's GEMM stage with a real micro-kernel — cvk_w2d_gemm_split3 (csrc/split3.hip: 3-term split fp32 operands
+on the bf16 matrix pipe) against the exact-fp32 GEMM the product runs (cvk_w6_gemm), same shapes, F(6x6,3x3) planes (64 GEMMs), plus the
+cost of the stand-alone conversion pass (cvk_split3_planes; a production version would emit the terms from the transform kernels).
+    python tools/study/split3_gemm_timing.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from pytorch_camvid_amd import _lib          # noqa: E402
+from pytorch_camvid_amd._lib import check    # noqa: E402
+
+lib = _lib.load()
+dev = torch.device("cuda:0")
+s = torch.cuda.current_stream().cuda_stream
+N, NX = 8, 64
+LAYERS = [("down3.1", 256, 256, 90, 120), ("up2.0", 512, 256, 90, 120), ("down4.1", 512, 512, 45, 60), ("up1.0", 1024, 512, 45, 60),
+          ("up3.0", 256, 128, 180, 240)]
+
+
+def timeit(fn, reps=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+print("layer (batch 8, F(6x6,3x3))      fp32 GEMM    split-3 GEMM   speed-up   (V conversion pass)   executed bf16 TFLOP/s")
+t32s = t3s = 0.0
+for name, ci, co, h, w in LAYERS:
+    T = lib.cvk_w6_tiles(N, h, w)
+    Tp32 = lib.cvk_w2d_tpad(T)
+    V = torch.randn(NX * Tp32 * ci + 128, device=dev)
+    U = torch.randn(NX * co * ci, device=dev) * 0.05
+    f = lib.cvk_w6_ksplit(T, ci, co)
+    Mo = torch.empty(f * NX * T * co + 1024, device=dev)
+    t32 = timeit(lambda: check(lib.cvk_w6_gemm(V.data_ptr(), U.data_ptr(), Mo.data_ptr(), T, ci, co, s)))
+    Tp, Cp = lib.cvk_split3_rows_pad(T, 256), lib.cvk_split3_rows_pad(co, 128)
+    Vv = V[:NX * Tp32 * ci].view(NX, Tp32, ci)[:, :T].contiguous()
+    V3 = torch.empty(NX * (ci // 32) * 3 * Tp * 32, device=dev, dtype=torch.bfloat16)
+    U3 = torch.empty(NX * (ci // 32) * 3 * Cp * 32, device=dev, dtype=torch.bfloat16)
+    tc = timeit(lambda: check(lib.cvk_split3_planes(Vv.data_ptr(), V3.data_ptr(), NX, T, Tp, ci, s)))
+    check(lib.cvk_split3_planes(U.data_ptr(), U3.data_ptr(), NX, co, Cp, ci, s))
+    t3 = timeit(lambda: check(lib.cvk_w2d_gemm_split3(V3.data_ptr(), U3.data_ptr(), Mo.data_ptr(), NX, T, Tp, ci, co, Cp, s)))
+    t32s += t32; t3s += t3
+    print(f"{name:8s} {ci:5d}->{co:4d} @{h:3d}x{w:3d}   {t32*1e6:8.1f} us   {t3*1e6:8.1f} us     {t32/t3:5.2f}x      {tc*1e6:8.1f} us          {12.0*NX*Tp*ci*Cp/t3/1e12:8.0f}")
+    del V, U, Mo, V3, U3, Vv
+print(f"sum                            {t32s*1e6:8.1f} us   {t3s*1e6:8.1f} us     {t32s/t3s:5.2f}x")
