@@ -134,7 +134,7 @@ def executed_share(name):
 
 
 def peak_of(name):
-    return PEAK_BF16_MFMA_TFLOPS if "bf16" in name else PEAK_F32_MFMA_TFLOPS
+    return PEAK_BF16_MFMA_TFLOPS if ("bf16" in name or "thinb" in name) else PEAK_F32_MFMA_TFLOPS
 
 
 def kernel_profile(step, dev, nprof=3):

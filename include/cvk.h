@@ -389,6 +389,18 @@ int cvk_conv3x3_bf16s(const void* x, const void* w, const float* bias, void* y, 
  * bitwise independent of the cap. */
 int cvk_conv3x3_bf16s_wg(const void* x, const void* w, const float* bias, void* y, float* stats, float* counts,
                       int N, int H, int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream);
+/* The THIN layers of the bf16-storage mode on their own kernels (csrc/thin_bf16.hip: register-only, no LDS; round 5): the stem 3 -> 64
+ * and the classifier head 64 -> class_num forward (models/unet.py:103,127) and the head's data-grad.  cvk_thin_bf16_mode(Cin, Cout of the
+ * FORWARD layer, pitch of the kernel's input / output tensor, dgrad): 0 not thin, 1 head forward, 2 stem forward, 3 head data-grad.
+ * cvk_pack_weight_thin_bf16: the forward layer's fp32 weights [Cout][3][3][Cin] -> the mode's filter pack (cvk_thin_bf16_pack_elems bf16).
+ * cvk_conv3x3_thin_bf16: y bf16 [N,H,W,ld_out] = conv3x3(x bf16 [N,H,W,ld_in], pack) + bias; with stats != NULL statistics partials
+ * stats[2][P][C] + counts[P], P = cvk_thin_bf16_stat_partials(N,H,W), C = Cout (mode 1) or 64 -> cvk_bn_finalize_counts. */
+int cvk_thin_bf16_mode(int Cin, int Cout, int ld_in, int ld_out, int dgrad);
+int cvk_thin_bf16_stat_partials(int N, int H, int W);
+size_t cvk_thin_bf16_pack_elems(int mode);
+int cvk_pack_weight_thin_bf16(const float* w, void* out, int Cout, int Cin, int mode, void* stream);
+int cvk_conv3x3_thin_bf16(const void* x, const void* wpack, const float* bias, void* y, float* stats, float* counts, int N, int H, int W,
+                          int ld_in, int Cout, int ld_out, int mode, void* stream);
 /* which kernel the two calls above run for a layer geometry (a query of their dispatch, no launch; measurement tools label their
  * timings with the name a kernel trace shows): 0 k_conv_bf16s (tile kernel), 1 k_conv_bf16q, 2 k_conv_bf16h, 3 k_conv_bf16h on the
  * 128-row weight pack, 4 k_conv_bf16s_strip, 5 two k_conv_bf16s_strip passes (64 -> 128 channels without statistics); < 0: bad shape */

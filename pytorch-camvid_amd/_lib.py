@@ -149,6 +149,11 @@ SIGNATURES = {
     "cvk_conv3x3_bf16s": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_bf16s_wg": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_bf16s_kernel": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "cvk_thin_bf16_mode": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "cvk_thin_bf16_stat_partials": (c_int, [c_int, c_int, c_int]),
+    "cvk_thin_bf16_pack_elems": (c_size, [c_int]),
+    "cvk_pack_weight_thin_bf16": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "cvk_conv3x3_thin_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_bn_finalize_counts": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                        c_float, c_float, c_vp, c_size, c_vp]),
     "cvk_conv3x3_wgrad_bf16s_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),

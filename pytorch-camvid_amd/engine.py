@@ -745,6 +745,14 @@ class ConvBnRelu(Op):
         R.grads_ready(st, self.pslot)
 
     # ---- bf16-storage mode (BASELINE.json configs[3]; csrc/conv_bf16s.hip, csrc/elem_bf16.hip) ------------------------
+    def _thin_bf16_mode(self, R, lib, dgrad, ld_dy=0):
+        """csrc/thin_bf16.hip mode of this layer's forward (dgrad=False) / data-grad launch, 0 = the general kernels (also with CVK_THIN=0)."""
+        if not R.thin or self.src.H * self.src.W * max(self.src.ld, self.cout, ld_dy, 64) * 2 >= 2 ** 31:
+            return 0
+        if dgrad:
+            return lib.cvk_thin_bf16_mode(self.cin, self.cout, ld_dy, self.src.ld, 1) if self.src.ld == 64 and self.cin == 64 else 0
+        return lib.cvk_thin_bf16_mode(self.cin, self.cout, self.src.ld, self.cout, 0)
+
     def _fwd_bf16(self, R, st):
         """bf16 NHWC activations in HBM: conv (bf16 MFMA, fp32 accumulate, fp32 statistics from the accumulators) writes
         the pre-BN tensor y as bf16; ONE elementwise pass applies BN + ReLU, writes the bf16 activation through the
@@ -762,21 +770,34 @@ class ConvBnRelu(Op):
             t = torch.empty(lib.cvk_bf16s_rows_pad(C) * 9 * src.ld, device=dev, dtype=_BF16)
             check(lib.cvk_pack_weight_fwd_bf16(wc.data_ptr(), t.data_ptr(), C, self.cin, src.ld, s), "cvk_pack_weight_fwd_bf16")
             return t
-        wb = R.derived(((self.pslot, "f"), "bf16"), w, build_wb)
+        # the stem (3 -> 64) and the head (64 -> 12) run the register-only thin kernels (csrc/thin_bf16.hip, round 5)
+        tmode = self._thin_bf16_mode(R, lib, False)
+
+        def build_thin():
+            t = torch.empty(lib.cvk_thin_bf16_pack_elems(tmode), device=dev, dtype=_BF16)
+            check(lib.cvk_pack_weight_thin_bf16(wc.data_ptr(), t.data_ptr(), C, self.cin, tmode, s), "cvk_pack_weight_thin_bf16")
+            return t
+        wb = R.derived(((self.pslot, "f"), "thinb"), w, build_thin) if tmode else R.derived(((self.pslot, "f"), "bf16"), w, build_wb)
         y = torch.empty(M * C, device=dev, dtype=_BF16)
         bnp = _empty(4 * C, dev)
         pm, pr, psc, psh = (bnp.data_ptr() + 4 * C * i for i in range(4))
         conv, bn = self.holder.conv_bn()
         flops = 18.0 * M * C * self.cin
+        tname = {1: "k_thinb_head_fwd", 2: "k_thinb_wide<1>"}.get(tmode)
         if st.training:
             if M <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {[N, C, H, W]}")
-            P = lib.cvk_bf16s_stat_partials_c(N, H, W, src.ld, C)
+            P = lib.cvk_thin_bf16_stat_partials(N, H, W) if tmode else lib.cvk_bf16s_stat_partials_c(N, H, W, src.ld, C)
             stats = _empty(2 * P * C + P, dev)
             cnt = stats.data_ptr() + 4 * 2 * P * C
-            _timed(R, bf16_kernel_name(lib, N, H, W, src.ld, C, True), flops, lambda: check(
-                lib.cvk_conv3x3_bf16s_wg(X.data_ptr(), wb.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), cnt, N, H, W, src.ld, C, C,
-                                         R.launch_wgs(), s), "cvk_conv3x3_bf16s"))
+            if tmode:
+                _timed(R, tname, flops, lambda: check(
+                    lib.cvk_conv3x3_thin_bf16(X.data_ptr(), wb.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), cnt, N, H, W, src.ld, C, C,
+                                              tmode, s), "cvk_conv3x3_thin_bf16"), nbytes=2.0 * M * (src.ld + C))
+            else:
+                _timed(R, bf16_kernel_name(lib, N, H, W, src.ld, C, True), flops, lambda: check(
+                    lib.cvk_conv3x3_bf16s_wg(X.data_ptr(), wb.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), cnt, N, H, W, src.ld, C, C,
+                                             R.launch_wgs(), s), "cvk_conv3x3_bf16s"))
             wsb = lib.cvk_bn_finalize_workspace_bytes(P, C)
             ws = R.workspace(wsb, dev)
             track = bn.track_running_stats and bn.running_mean is not None
@@ -787,9 +808,14 @@ class ConvBnRelu(Op):
                                              bn.num_batches_tracked.data_ptr() if track else None,
                                              mom, float(bn.eps), ws.data_ptr(), wsb, s), "cvk_bn_finalize_counts")
         else:
-            _timed(R, bf16_kernel_name(lib, N, H, W, src.ld, C, False), flops, lambda: check(
-                lib.cvk_conv3x3_bf16s(X.data_ptr(), wb.data_ptr(), b.data_ptr(), y.data_ptr(), None, None, N, H, W, src.ld, C, C, s),
-                "cvk_conv3x3_bf16s"))
+            if tmode:
+                _timed(R, tname, flops, lambda: check(
+                    lib.cvk_conv3x3_thin_bf16(X.data_ptr(), wb.data_ptr(), b.data_ptr(), y.data_ptr(), None, None, N, H, W, src.ld, C, C, tmode, s),
+                    "cvk_conv3x3_thin_bf16"), nbytes=2.0 * M * (src.ld + C))
+            else:
+                _timed(R, bf16_kernel_name(lib, N, H, W, src.ld, C, False), flops, lambda: check(
+                    lib.cvk_conv3x3_bf16s(X.data_ptr(), wb.data_ptr(), b.data_ptr(), y.data_ptr(), None, None, N, H, W, src.ld, C, C, s),
+                    "cvk_conv3x3_bf16s"))
             check(lib.cvk_bn_eval_params(gamma.data_ptr(), beta.data_ptr(), bn.running_mean.data_ptr(),
                                          bn.running_var.data_ptr(), pm, pr, psc, psh, C, float(bn.eps), s), "cvk_bn_eval_params")
         out = R.alloc_act(st, dst.buf, dev)
@@ -840,11 +866,23 @@ class ConvBnRelu(Op):
                 t = torch.empty(lib.cvk_bf16s_rows_pad(self.cin) * 9 * ld_dy, device=dev, dtype=_BF16)
                 check(lib.cvk_pack_weight_dgrad_bf16(wc.data_ptr(), t.data_ptr(), C, self.cin, ld_dy, s), "cvk_pack_weight_dgrad_bf16")
                 return t
-            wd = R.derived(((self.pslot, "d"), "bf16"), w, build_wd)
+            dmode = self._thin_bf16_mode(R, lib, True, ld_dy)
+
+            def build_thin_d():
+                t = torch.empty(lib.cvk_thin_bf16_pack_elems(dmode), device=dev, dtype=_BF16)
+                check(lib.cvk_pack_weight_thin_bf16(wc.data_ptr(), t.data_ptr(), C, self.cin, dmode, s), "cvk_pack_weight_thin_bf16")
+                return t
             dX = torch.empty((N, H, W, src.ld), device=dev, dtype=_BF16)
-            _timed(R, bf16_kernel_name(lib, N, H, W, ld_dy, self.cin, False), flops, lambda: check(
-                lib.cvk_conv3x3_bf16s_wg(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, None, N, H, W, ld_dy, self.cin, src.ld,
-                                         R.launch_wgs(), s), "cvk_conv3x3_bf16s(dgrad)"))
+            if dmode:
+                wd = R.derived(((self.pslot, "d"), "thinb"), w, build_thin_d)
+                _timed(R, "k_thinb_wide<3>(dgrad)", flops, lambda: check(
+                    lib.cvk_conv3x3_thin_bf16(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, None, N, H, W, ld_dy, C, src.ld, dmode, s),
+                    "cvk_conv3x3_thin_bf16(dgrad)"), nbytes=2.0 * M * (ld_dy + src.ld))
+            else:
+                wd = R.derived(((self.pslot, "d"), "bf16"), w, build_wd)
+                _timed(R, bf16_kernel_name(lib, N, H, W, ld_dy, self.cin, False), flops, lambda: check(
+                    lib.cvk_conv3x3_bf16s_wg(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, None, N, H, W, ld_dy, self.cin, src.ld,
+                                             R.launch_wgs(), s), "cvk_conv3x3_bf16s(dgrad)"))
             st.grad[src.id] = dX
         # partial slabs now, the sum over the slabs with every other layer's in ONE launch (Runner.flush_wreduces): nobody reads a weight
         # gradient before the end of backward (or the all-reduce of its bucket); 23 reductions of ~11 us were 0.26 ms of a 21 ms step
@@ -1089,15 +1127,23 @@ class Plan:
     def zero_frame(self, view):
         self.add(ZeroFrame(view))
 
-    def seal(self):
+    def seal(self, thin=True):
         """Called once after recording.  bf16-storage plans hand their result (the logits) to the caller and to the loss
-        in fp32: the buffer of the output view becomes an fp32 buffer (written by the last block's BN-apply pass)."""
+        in fp32: the buffer of the output view becomes an fp32 buffer (written by the last block's BN-apply pass).
+        Their imported input keeps a pixel pitch of 8 instead of 32 channels when every reader is a stem the thin kernel serves
+        (csrc/thin_bf16.hip mode 2: <= 4 real channels -> 64; the weight-grad kernel reads any pitch % 8 == 0): a 3-channel image
+        was 64 bytes per pixel — 177 MB written by the import pass and read twice per step at 4 x 720 x 960, 133 MB of it padding."""
         if self.bf16:
             b = self.output.buf
             if not self.output.is_full:
                 raise NotImplementedError("bf16 mode: the network output must be a whole buffer")
             b.dtype = _F32
             b.ld = pad4(b.C)
+            readers = [op for op in self.ops if getattr(op, "src", None) is self.input]
+            if (thin and not self.input_needs_grad and self.input.C <= 4 and readers and self.input is not self.output.buf
+                    and all(isinstance(op, ConvBnRelu) and op.cout == 64 for op in readers)
+                    and self.input.H * self.input.W * 64 * 2 < 2 ** 31):
+                self.input.ld = 8
 
 
 class Runner:
@@ -1210,8 +1256,10 @@ class Runner:
                 continue
             w = st.params[4 * op.pslot]
             sig = (WEIGHT_EPOCH[0], self.wepoch, w.data_ptr(), w._version, self._pass_token)
-            want = [(((op.pslot, "f"), "bf16"), 0, op.cout, op.src.ld)]
-            if need_grad and op.src_needs_grad:
+            want = []
+            if not op._thin_bf16_mode(self, lib, False):        # thin layers pack their own (tiny) filter formats where they run
+                want.append((((op.pslot, "f"), "bf16"), 0, op.cout, op.src.ld))
+            if need_grad and op.src_needs_grad and not op._thin_bf16_mode(self, lib, True, max(32, op.cout)):
                 want.append((((op.pslot, "d"), "bf16"), 1, op.cin, max(32, op.cout)))
             for key, dgrad, rows, kpad in want:
                 ent = self._wc.get(key)

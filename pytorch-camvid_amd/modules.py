@@ -237,13 +237,13 @@ def _run(root, x):
     state = _state_of(root)
     N, C, H, W = x.shape
     bf16 = bool(state["runner"].bf16)
-    key = (N, C, H, W, bool(x.requires_grad and torch.is_grad_enabled()), bf16)
+    key = (N, C, H, W, bool(x.requires_grad and torch.is_grad_enabled()), bf16, bool(state["runner"].thin) if bf16 else None)
     plan = state["plans"].get(key)
     if plan is None:
         plan = engine.Plan(N, C, H, W, bf16=bf16)
         plan.input_needs_grad = key[4]
         plan.output = root._emit(plan, plan.input)
-        plan.seal()
+        plan.seal(thin=bool(state["runner"].thin))
         state["plans"][key] = plan
     params = []
     for h in plan.holders:

@@ -486,3 +486,78 @@ def test_wgrad_slabs_plus_batched_reduction_equals_the_one_call_form(case):
             check(lib.cvk_conv3x3_wgrad_bf16s_slabs(x.data_ptr(), dy.data_ptr(), slabs.data_ptr(), N, H, W, Ci, ldx, Co, ld_dy, 4 * S * n - 4, stream()))
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+
+
+THIN_CASES = [  # (N, H, W, Cin, Cout): stem-like (Cin <= 4 -> 64) and head-like (64 -> Cout <= 16): ragged widths, row chunks with halos, one row
+    (2, 9, 70, 3, 64), (1, 40, 33, 3, 64), (1, 1, 16, 4, 64), (3, 5, 7, 1, 64),
+    (2, 9, 70, 64, 12), (1, 40, 33, 64, 12), (1, 1, 5, 64, 16), (2, 23, 17, 64, 4),
+]
+
+
+@pytest.mark.parametrize("case", THIN_CASES)
+def test_thin_bf16_kernels_raw_abi(case):
+    """csrc/thin_bf16.hip (round 5): the stem / head forward kernels (+ statistics -> cvk_bn_finalize_counts) and the head's data-grad
+    against torch on identical bf16 operands (reference operator: nn.Conv2d(3x3, padding=1), models/unet.py:11)."""
+    from pytorch_camvid_amd import _lib
+    from pytorch_camvid_amd._lib import check
+    lib = _lib.load()
+    N, H, W, Ci, Co = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = rb(torch.randn(N, Ci, H, W, generator=g))
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * (2.0 / (9 * Ci)) ** 0.5
+    b = torch.randn(Co, generator=g) * 0.1
+    want = F.conv2d(x, rb(w), b, padding=1)
+    ldx = 32 if Ci <= 4 else 64                                                # the engine's pitches: the padded input, the dense activation
+    xd = torch.zeros((N, H, W, ldx), device=dev(), dtype=BF)
+    xd[..., :Ci] = x.permute(0, 2, 3, 1).to(BF).to(dev())
+    if Ci <= 4:
+        xd[..., Ci:] = 7.0                                                       # pad channels >= 4 must never be read; 3 is read and must be... real zeros
+        xd[..., Ci:4] = 0.0
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev())
+    bd = b.to(dev())
+    mode = lib.cvk_thin_bf16_mode(Ci, Co, ldx, Co, 0)
+    assert mode == (2 if Ci <= 4 else 1)
+    wp = torch.full((lib.cvk_thin_bf16_pack_elems(mode),), float("nan"), device=dev(), dtype=BF)
+    check(lib.cvk_pack_weight_thin_bf16(wd.data_ptr(), wp.data_ptr(), Co, Ci, mode, stream()))
+    y = torch.full((N, H, W, Co), float("nan"), device=dev(), dtype=BF)
+    P = lib.cvk_thin_bf16_stat_partials(N, H, W)
+    stats = torch.full((2 * P * Co + P,), float("nan"), device=dev())
+    cnt_ptr = stats.data_ptr() + 4 * 2 * P * Co
+    check(lib.cvk_conv3x3_thin_bf16(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), y.data_ptr(), stats.data_ptr(), cnt_ptr, N, H, W, ldx, Co, Co, mode, stream()))
+    got = y.float().permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(got).all()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2.0 ** -8, atol=2e-3 * float(want.abs().max()) * 2.0 ** -8 + 1e-6)
+    # without statistics: the same bits
+    y2 = torch.full_like(y, float("nan"))
+    check(lib.cvk_conv3x3_thin_bf16(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), y2.data_ptr(), None, None, N, H, W, ldx, Co, Co, mode, stream()))
+    assert torch.equal(y, y2)
+    assert stats[2 * P * Co:].sum().item() == N * H * W
+    M = N * H * W
+    if M > 1:
+        mean = torch.empty(Co, device=dev()); rstd = torch.empty_like(mean); sc = torch.empty_like(mean); sh = torch.empty_like(mean)
+        gamma = torch.ones(Co, device=dev()); beta = torch.zeros(Co, device=dev())
+        wsb = lib.cvk_bn_finalize_workspace_bytes(P, Co)
+        ws = torch.empty(max(wsb, 8), device=dev(), dtype=torch.uint8)
+        check(lib.cvk_bn_finalize_counts(stats.data_ptr(), cnt_ptr, P, M, Co, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                         sc.data_ptr(), sh.data_ptr(), None, None, None, 0.1, 1e-5, ws.data_ptr(), wsb, stream()))
+        wm = want.double().mean(dim=(0, 2, 3)); wv = want.double().var(dim=(0, 2, 3), unbiased=False)
+        np.testing.assert_allclose(mean.cpu().numpy(), wm.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(rstd.cpu().numpy(), (1.0 / torch.sqrt(wv + 1e-5)).numpy(), rtol=2e-4)
+    if Ci != 64:
+        return
+    # the head's data-grad: dy with <= 16 real channels in a 32-channel pitch -> dX with 64 channels
+    ld_dy = 32
+    dy = rb(torch.randn(N, Co, H, W, generator=g))
+    dyd = torch.full((N, H, W, ld_dy), 5.0, device=dev(), dtype=BF)          # channels >= 16 are never read
+    dyd[..., :16] = 0.0
+    dyd[..., :Co] = dy.permute(0, 2, 3, 1).to(BF).to(dev())
+    dmode = lib.cvk_thin_bf16_mode(Ci, Co, ld_dy, 64, 1)
+    assert dmode == 3
+    wdp = torch.full((lib.cvk_thin_bf16_pack_elems(3),), float("nan"), device=dev(), dtype=BF)
+    check(lib.cvk_pack_weight_thin_bf16(wd.data_ptr(), wdp.data_ptr(), Co, Ci, 3, stream()))
+    dx = torch.full((N, H, W, 64), float("nan"), device=dev(), dtype=BF)
+    check(lib.cvk_conv3x3_thin_bf16(dyd.data_ptr(), wdp.data_ptr(), None, dx.data_ptr(), None, None, N, H, W, ld_dy, Co, 64, 3, stream()))
+    want_dx = F.conv_transpose2d(dy, rb(w), padding=1)
+    gdx = dx.float().permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(gdx).all()
+    np.testing.assert_allclose(gdx.numpy(), want_dx.numpy(), rtol=2.0 ** -8, atol=float(want_dx.abs().max()) * 2.0 ** -8 * 2e-3 + 1e-6)
