@@ -793,7 +793,7 @@ constexpr int HROW = 3 * HBN * 64;               // 12 KiB: the weight tiles of 
 // P128: the weights come in the 128-row tile-major pack of k_conv_bf16q (layers with > 64 output channels whose tile count fills the chip
 // badly with 128-channel tiles, e.g. 512 channels at 90x120: 384 tiles = 1.5 rounds of 256 CUs, 768 half-width tiles = 3): this workgroup's
 // 64 rows are one half of every 8 KiB tap tile — three 4 KiB pieces 8 KiB apart instead of 12 contiguous KiB, still scalar-addressed.
-template <bool STATS, int DBG = 0, bool P128 = false, bool PCOL = false>     // DBG 1 (instantiated in the experiments build only): s_memrealtime stamps of workgroup 0's first 16 tiles -> `stats`
+template <bool STATS, int DBG = 0, bool P128 = false, bool PCOL = false, bool MST = true>      // MST: statistics on the matrix pipe (round 5)     // DBG 1 (instantiated in the experiments build only): s_memrealtime stamps of workgroup 0's first 16 tiles -> `stats`
 __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict__ X, const char* __restrict__ Wp,
                                                       const float* __restrict__ bias, __bf16* __restrict__ Y,
                                                       float* __restrict__ stats, float* __restrict__ cnt, int H, int W, int Cin,
@@ -1026,6 +1026,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
         const int l15 = elane & 15, q4 = elane >> 4, lane = elane;
         const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(Y + ((size_t)(cur.img * H + cur.y0) * W + cur.x0) * ldy + n0), 0, 0x7FFFFFFF, 0x00020000);
+        // Statistics (round 5, MST): NOT from the accumulators with vector instructions (16 values x (mask, add, multiply-add) + 32 row sums of four
+        // DPP steps each: ~640 of the 1440 vector instructions of this epilogue, 1.5 us of a 9-16 us tile with both waves of a SIMD in it) but on
+        // the matrix pipe, which is idle here, from the STAGED tile — the bf16 values BatchNorm will normalise (oracle/bf16_emul.py takes its
+        // statistics from the rounded tensor as well).  A wave reads its 64 pixels x 64 channels back transposed (ds_read_b64_tr_b16: lane =
+        // channel, 8 consecutive pixels = the k of v_mfma_f32_16x16x32_bf16) and issues per 16-channel block  S = A x ones  and  Q = A x A^T
+        // (the operand registers serve as B too): every column of S holds the channel sums, the diagonal of Q the sums of squares — 16 MFMAs
+        // and 16 reads per wave.  Out-of-frame pixels of a ragged tile are staged as zeros.
+        const bool ragged = (cur.y0 + TH > H) | (cur.x0 + TW > W);
         {
             float s[4][4], q[4][4];
 #pragma unroll
@@ -1039,7 +1047,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
                     float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = acc[rb][cb][j] + bv[j];
-                    if (STATS) {
+                    if (STATS && !MST) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float vm = ok ? v[j] : 0.f;
@@ -1047,14 +1055,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
                             q[rb][j] += vm * vm;
                         }
                     }
-                    const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    if (STATS && MST && ragged && !ok) o = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
                     // stage: [512 pixels][128 B], 16-byte chunk c of pixel p at position c ^ ((p >> 1) & 7)
                     const int p = (row0 + (cb >> 1)) * 32 + (cb & 1) * 16 + l15, chunk = rb * 2 + (q4 >> 1);
                     *reinterpret_cast<bf16x4*>(smem + STAGE_OFF + p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4) + 8 * (q4 & 1)) = o;
                     if (rb * 4 + cb < 7) prologue_piece(rb * 4 + cb);
                 }
             }
-            if (STATS) {
+            if (STATS && !MST) {
                 float2* const red = reinterpret_cast<float2*>(smem + RED_OFF);
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb)
@@ -1081,6 +1090,49 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
                 else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), yrsrc, ok ? off : 0x80000000u, 0, 0);
             }
         }
+        if (STATS && MST) {
+            // wave w: pixels 64 w .. 64 w + 63 (the rows it just stored).  Lane (l15, q4) of a 16-lane group addresses 4 consecutive channels
+            // (4 (l15 & 3)) of pixel row 8 q4 + (l15 >> 2) (+ 4 for the second read); the transposing read hands lane l15 channel l15 of
+            // the group's four rows.
+            typedef short s16x4t __attribute__((ext_vector_type(4)));
+            const int tq = l15 >> 2, tp = l15 & 3;
+            int ra[2];
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2) {
+                const int pl = 8 * q4 + tq + 4 * r2;                      // pixel inside a 32-pixel block: (p >> 1) & 7 only depends on it
+                ra[r2] = STAGE_OFF + (wave * 64 + pl) * 128 + (tp & 1) * 8;
+            }
+            const int swz[2] = {((8 * q4 + tq) >> 1) & 7, ((8 * q4 + tq + 4) >> 1) & 7};
+            bf16x8 ones;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.f;
+            f32x4v aS[4], aQ[4];
+#pragma unroll
+            for (int cbk = 0; cbk < 4; ++cbk) { aS[cbk] = f32x4v{0.f, 0.f, 0.f, 0.f}; aQ[cbk] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int cbk = 0; cbk < 4; ++cbk) {
+                    const int chunk = cbk * 2 + (tp >> 1);
+                    const s16x4t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4t*)(smem + ra[0] + pb * 32 * 128 + ((chunk ^ swz[0]) << 4)));
+                    const s16x4t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4t*)(smem + ra[1] + pb * 32 * 128 + ((chunk ^ swz[1]) << 4)));
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    aS[cbk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ones, aS[cbk], 0, 0, 0);
+                    aQ[cbk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, a, aQ[cbk], 0, 0, 0);
+                }
+            float2* const red = reinterpret_cast<float2*>(smem + RED_OFF);       // [channel 64][wave 8] (sum, sum of squares)
+            // aS[cbk][j]: channel 16 cbk + 4 q4 + j, identical in the 16 lanes of a group; aQ[cbk][j] in lane l15: (row 4 q4 + j, column l15):
+            // the diagonal sits in the lanes with l15 >> 2 == q4, register l15 & 3
+#pragma unroll
+            for (int cbk = 0; cbk < 4; ++cbk) {
+                const float qd = tp == 0 ? aQ[cbk][0] : (tp == 1 ? aQ[cbk][1] : (tp == 2 ? aQ[cbk][2] : aQ[cbk][3]));
+                const float sd = tp == 0 ? aS[cbk][0] : (tp == 1 ? aS[cbk][1] : (tp == 2 ? aS[cbk][2] : aS[cbk][3]));
+                if (tq == q4) red[(cbk * 16 + l15) * 8 + wave] = float2{sd, qd};
+            }
+            __syncthreads();
+        }
         if (STATS) {
             if (tid < HBN) {
                 const float2* const red = reinterpret_cast<const float2*>(smem + RED_OFF);
@@ -1090,7 +1142,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
                 const int co = n0 + tid;
                 const int nvalid = min(TH, H - cur.y0) * min(TW, W - cur.x0);
                 if (co < Cout) {
-                    const double m2 = Q - S * S / (double)nvalid;
+                    // 1 / n through the fp32 reciprocal (exact for the 512 pixels of a whole tile): an fp64 division per thread was ~40
+                    // instructions of one wave with seven waiting at the barrier below
+                    const double m2 = Q - S * S * (double)(1.0f / (float)nvalid);
                     stats[(size_t)cur.sp * Cout + co] = (float)S;
                     stats[(size_t)(P + cur.sp) * Cout + co] = (float)(m2 > 0.0 ? m2 : 0.0);
                 }
@@ -1308,6 +1362,12 @@ void launch(const void* x, const void* wpp, const float* bias, void* y, float* s
         const int hdbg = cvk_knob("CVK_BF16H_DBG", 0);      // per-tile time stamps (tools/tile_stamps_h.py)
         if (hdbg == 2 && stats) { hipLaunchKernelGGL((k_conv_bf16h<true, 1>), pgrid, block, 0, s, CVK_PP_ARGS); return; }
         if (hdbg == 1) { hipLaunchKernelGGL((k_conv_bf16h<false, 1>), pgrid, block, 0, s, CVK_PP_ARGS); return; }
+#endif
+#ifdef CVK_EXPERIMENTS
+        if (stats && !p128 && cvk_knob("CVK_BF16H_MST", 1) == 0) {      // A/B: the round-4 vector-unit statistics
+            hipLaunchKernelGGL((k_conv_bf16h<true, 0, false, false, false>), pgrid, block, 0, s, CVK_PP_ARGS);
+            return;
+        }
 #endif
         if (stats) hipLaunchKernelGGL((k_conv_bf16h<true>), pgrid, block, 0, s, CVK_PP_ARGS);
         else hipLaunchKernelGGL((k_conv_bf16h<false>), pgrid, block, 0, s, CVK_PP_ARGS);

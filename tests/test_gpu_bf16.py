@@ -76,8 +76,13 @@ def test_conv_bf16s_raw_abi(case):
     check(lib.cvk_bn_finalize_counts(stats.data_ptr(), cnt_ptr, P, M, Co, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                      sc.data_ptr(), sh.data_ptr(), None, None, None, 0.1, 1e-5, ws.data_ptr(), wsb, stream()))
     wm = want.double().mean(dim=(0, 2, 3)); wv = want.double().var(dim=(0, 2, 3), unbiased=False)
-    np.testing.assert_allclose(mean.cpu().numpy(), wm.numpy(), rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(rstd.cpu().numpy(), (1.0 / torch.sqrt(wv + 1e-5)).numpy(), rtol=2e-4)
+    # The statistics are those of the fp32 results (k_conv_bf16q, the strip / tile kernels) or of the STORED bf16 tensor (k_conv_bf16h since
+    # round 5: matrix-pipe statistics from the staged tile — what BatchNorm normalises and what oracle/bf16_emul.py defines): the two differ
+    # by the mean of M rounding errors of 2^-9 relative each.
+    rnd = 4.0 * 2.0 ** -9 / M ** 0.5
+    rms = want.double().pow(2).mean(dim=(0, 2, 3)).sqrt().numpy()
+    assert (np.abs(mean.cpu().numpy() - wm.numpy()) <= 1e-5 + 1e-4 * np.abs(wm.numpy()) + rnd * rms).all()
+    np.testing.assert_allclose(rstd.cpu().numpy(), (1.0 / torch.sqrt(wv + 1e-5)).numpy(), rtol=2e-4 + rnd)
     # data-grad: dX = conv(dy, rotated/transposed filter); dy has a padded pitch like the engine's (max(32, Cout))
     ld_dy = max(32, Co)
     dy = rb(torch.randn(N, Co, H, W, generator=g))
