@@ -1161,6 +1161,350 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
     }
 }
 
+// EXPERIMENTS BUILD ONLY (CVK_BF16H_PIPE=1): parity green (tests/test_gpu_bf16.py), but interleaved on one box the four 64-output-channel
+// forward launches and their data-grads run 3-5 % SLOWER than k_conv_bf16h (down1.1 257-264 -> 265-273 us, ups4 370-373 -> 387-393 us):
+// hiding the 4.4 us a tile spends outside its 5.4 us K loop bought nothing, like the kernel-column phases before it — on this part these
+// kernels' time follows the work done per tile (matrix + vector + LDS instructions under a power cap), not the bubbles between them; what
+// did pay is REMOVING work (the matrix-pipe statistics: -3.5 %).  DESIGN.md §5b round 5.
+#ifdef CVK_EXPERIMENTS
+// ---------------------------------------------------------------------------------------------- 64 output channels, PIPELINED EPILOGUE (round 5)
+// k_conv_bf16h with a tile's epilogue moved under the NEXT tile's K loop.  With 64 (128) input channels the K loop of a 64-channel tile is
+// 5.4 (11) us and everything outside it 4.4-5.7 us — bias, pack, transposed store, statistics, with both wave groups in it together and the
+// matrix pipe idle (tools/tile_stamps_h.py).  The microbenchmark of round 5 says vector / LDS work of one wave costs its SIMD partner's
+// MFMA stream nothing.  So:
+//   * at the end of its K loop a wave only adds the bias and packs its 64 accumulators to bf16 IN REGISTERS (32 VGPRs, kept across the
+//     tile boundary), the next tile's prologue goes out and the next K loop starts at once;
+//   * in the LOAD phase of the next tile's kernel row 1 — beside the partner group's MFMA phase — the wave writes the packed tile into its
+//     8 KiB of a 32 KiB stage, reads it back transposed (rows of 128 contiguous bytes per pixel), issues the 16-byte streaming stores and
+//     (STATS) the matrix-pipe statistics of csrc note "MST".  The stage is a per-WAVE transpose (a wave stores the two tile rows it
+//     computed), so nothing but the wave's own LDS order is needed; waves w and w + 4 share a region because their LOAD phases never
+//     coincide and each finishes all LDS work on it inside one phase;
+//   * the 8 x 2 statistics partials meet in LDS and are finalised by wave 0 in ITS next LOAD phase (kernel row 2), one barrier pair after
+//     the partner group wrote its half;
+//   * the stores are the newest entries of the in-order counter in that phase (counted vmcnt + 8) and old ones a phase later.
+// After its last tile a workgroup runs the same pieces once without a K loop around them.  And the phase sequence never stops at a tile
+// boundary: the next tile's first slab and kernel rows are requested in the current tile's last slice, in the slots k_conv_bf16h filled with
+// dead re-loads (a first version that issued the prologue at the boundary was 6-10 % SLOWER than k_conv_bf16h: with the epilogue gone
+// nothing covered the first slab's HBM latency).  Needs an even number of channel slices (Cin % 64 == 0) and Cout <= 1024 (bias in LDS).
+// LDS: ring 36 | slab A 40 | slab B 40 | stage 32 | partials 4 | bias 4 = 156 KiB.
+template <bool STATS, bool P128>
+__global__ __launch_bounds__(512, 2) void k_conv_bf16hp(const __bf16* __restrict__ X, const char* __restrict__ Wp,
+                                                       const float* __restrict__ bias, __bf16* __restrict__ Y,
+                                                       float* __restrict__ stats, float* __restrict__ cnt, int H, int W, int Cin,
+                                                       int Cout, int ldy, int tilesX, int tilesY, int tilesN, int P, int ntiles, int nts) {
+    constexpr int RING_BYTES = 3 * HROW;
+    constexpr int STAGE_OFF = RING_BYTES + 2 * SLAB_BYTES;        // four wave regions of 64 pixels x 128 B
+    constexpr int STAGE_BYTES = 4 * 64 * HBN * 2;
+    constexpr int RED_OFF = STAGE_OFF + STAGE_BYTES;              // statistics partials [channel 64][wave 8] (sum, sumsq)
+    constexpr int BIAS_OFF = RED_OFF + HBN * 8 * 8;               // the layer's bias (<= 1024 channels), copied once per workgroup
+    constexpr int LDS_BYTES = BIAS_OFF + 1024 * 4;
+    constexpr int NSTORE = 8;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS plan");
+    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+    const unsigned smem_addr = cvk_lds_addr(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int grp = wave >> 2, wp = wave & 3;
+    const int row0 = grp * 8 + wp * 2;
+    const bool lo = wave < 4;
+    const int ncs = Cin / CK, nph = ncs * 3;
+    const int G = gridDim.x;
+
+    struct Geo { int nt, sp, x0, y0, img; };
+    const TileDiv divN(tilesN), divX(tilesX), divXY(tilesX * tilesY);
+    auto geo_of = [&](int t) {
+        Geo g;
+        g.sp = divN.div(t);
+        g.nt = divN.mod(t, g.sp);
+        g.img = divXY.div(g.sp);
+        const int rem = divXY.mod(g.sp, g.img);
+        const int ty = divX.div(rem), tx = divX.mod(rem, ty);
+        g.x0 = tx * TW; g.y0 = ty * TH;
+        return g;
+    };
+    unsigned aoff[5];
+    i32x4 xrsrc;
+    xrsrc[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)(H * W * Cin) * 2u));
+    xrsrc[3] = 0x00020000;
+    constexpr int WROW = P128 ? 3 * BTAP : HROW;
+    const unsigned wvoff = (P128 ? (wave >> 2) * BTAP + (wave & 3) * 1024 : wave * 1024) + lane * 16;
+    const unsigned wave_lds = smem_addr + wave * 1024;
+    const char* wnext = Wp;
+    int slab_yx[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int row = (8 * t + wave) * 16 + (lane >> 2);
+        const int hy = row / HP;
+        slab_yx[t] = row < SLAB_ROWS ? (hy << 8) | (row - hy * HP) : 0x4000;
+    }
+    auto setup_dma = [&](const Geo& g) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int hy = slab_yx[t] >> 8, hx = slab_yx[t] & 255;
+            const int chunk = (lane & 3) ^ (((hx >> 2) & 1) << 1);
+            const int iy = g.y0 - 1 + hy, ix = g.x0 - 1 + hx;
+            const bool ok = ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+            aoff[t] = ok ? (unsigned)((iy * W + ix) * Cin + chunk * 8) * 2u : 0x80000000u;
+        }
+        const uintptr_t xbase = (uintptr_t)(X + (size_t)g.img * H * W * Cin);
+        xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xbase);
+        xrsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xbase >> 32) & 0xFFFF);
+        wnext = P128 ? Wp + (size_t)(g.nt >> 1) * nph * WROW + (g.nt & 1) * (HBN * 64) : Wp + (size_t)g.nt * nph * WROW;
+    };
+    auto dma_slab_piece = [&](auto t_tag, int cs, unsigned slab_lds) {
+        constexpr int T = decltype(t_tag)::value;
+        dma16_buf_i<T * 8192>(aoff[T], xrsrc, (unsigned)cs * (CK * 2), slab_lds);
+    };
+    auto dma_row_next = [&](auto slot_tag, bool advance) {      // the kernel row wnext points at into ring slot SLOT; then (advance) on to the next row
+        constexpr int SLOT = decltype(slot_tag)::value;
+        dma16_saddr_i<SLOT * HROW>(wvoff, wnext, wave_lds);
+        if (lo) dma16_saddr_i<SLOT * HROW + 8192>(wvoff, wnext + (P128 ? 2 * BTAP : 8192), wave_lds);
+        if (advance) wnext += WROW;
+    };
+    auto issue_prologue = [&]() {
+        dma_slab_piece(std::integral_constant<int, 0>{}, 0, wave_lds + RING_BYTES);
+        dma_slab_piece(std::integral_constant<int, 1>{}, 0, wave_lds + RING_BYTES);
+        dma_slab_piece(std::integral_constant<int, 2>{}, 0, wave_lds + RING_BYTES);
+        dma_slab_piece(std::integral_constant<int, 3>{}, 0, wave_lds + RING_BYTES);
+        dma_slab_piece(std::integral_constant<int, 4>{}, 0, wave_lds + RING_BYTES);
+        dma_row_next(std::integral_constant<int, 0>{}, true);
+        dma_row_next(std::integral_constant<int, 1>{}, true);
+    };
+    const int wa = l15 * 64 + ((q4 ^ (((l15 >> 2) & 1) << 1)) << 4);
+    int pb0[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) pb0[dx] = RING_BYTES + row0 * (HP * 64) + (l15 + dx) * 64 + ((q4 ^ ((((l15 + dx) >> 2) & 1) << 1)) << 4);
+
+    // ---- the previous tile, packed: pk[rb][cb] = channels n0 + rb*16 + 4 q4 .. + 3 of pixel (row0 + (cb >> 1), (cb & 1)*16 + l15) as 4 bf16 ------
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+    typedef short s16x4t __attribute__((ext_vector_type(4)));
+    u32x2v pk[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) pk[a][b] = u32x2v{0u, 0u};
+    Geo prev = geo_of(0);
+    bool have_prev = false;
+    const int wreg = STAGE_OFF + (wave & 3) * (64 * HBN * 2);      // this wave's stage region (shared with wave ^ 4: never in the same phase)
+
+    // stage write, statistics partials, read-back + stores of the PREVIOUS tile: everything that touches the stage, inside one phase
+    auto epi_lds_and_store = [&]() {
+        int elane = lane;
+        asm volatile("" : "+v"(elane));
+        const int l15 = elane & 15, q4 = elane >> 4, lane = elane;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const int p = (cb >> 1) * 32 + (cb & 1) * 16 + l15, chunk = rb * 2 + (q4 >> 1);
+                *reinterpret_cast<u32x2v*>(smem + wreg + p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4) + 8 * (q4 & 1)) = pk[rb][cb];
+            }
+        if (STATS) {
+            const int tq = l15 >> 2, tp = l15 & 3;
+            const int ra0 = wreg + (8 * q4 + tq) * 128 + (tp & 1) * 8, ra1 = ra0 + 4 * 128;
+            const int sw0 = ((8 * q4 + tq) >> 1) & 7, sw1 = ((8 * q4 + tq + 4) >> 1) & 7;
+            bf16x8 ones;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.f;
+            f32x4v aS[4], aQ[4];
+#pragma unroll
+            for (int cbk = 0; cbk < 4; ++cbk) { aS[cbk] = f32x4v{0.f, 0.f, 0.f, 0.f}; aQ[cbk] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int pbk = 0; pbk < 2; ++pbk)
+#pragma unroll
+                for (int cbk = 0; cbk < 4; ++cbk) {
+                    const int chunk = cbk * 2 + (tp >> 1);
+                    const s16x4t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4t*)(smem + ra0 + pbk * 32 * 128 + ((chunk ^ sw0) << 4)));
+                    const s16x4t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4t*)(smem + ra1 + pbk * 32 * 128 + ((chunk ^ sw1) << 4)));
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+                    aS[cbk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ones, aS[cbk], 0, 0, 0);
+                    aQ[cbk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, a, aQ[cbk], 0, 0, 0);
+                }
+            float2* const red = reinterpret_cast<float2*>(smem + RED_OFF);
+#pragma unroll
+            for (int cbk = 0; cbk < 4; ++cbk) {
+                const float qd = tp == 0 ? aQ[cbk][0] : (tp == 1 ? aQ[cbk][1] : (tp == 2 ? aQ[cbk][2] : aQ[cbk][3]));
+                const float sd = tp == 0 ? aS[cbk][0] : (tp == 1 ? aS[cbk][1] : (tp == 2 ? aS[cbk][2] : aS[cbk][3]));
+                if (tq == q4) red[(cbk * 16 + l15) * 8 + wave] = float2{sd, qd};
+            }
+        }
+        const int n0 = prev.nt * HBN;
+        const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(Y + ((size_t)(prev.img * H + prev.y0) * W + prev.x0) * ldy + n0), 0, 0x7FFFFFFF, 0x00020000);
+        const int chunk = lane & 7;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int p = it * 8 + (lane >> 3);
+            const int prow = row0 + (p >> 5), pcol = p & 31;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(smem + wreg + p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4));
+            const bool ok = (prev.y0 + prow < H) & (prev.x0 + pcol < W) & (n0 + chunk * 8 < ldy);
+            const unsigned off = (unsigned)((prow * W + pcol) * ldy + chunk * 8) * 2u;
+            if (nts) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), yrsrc, ok ? off : 0x80000000u, 0, 2);
+            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), yrsrc, ok ? off : 0x80000000u, 0, 0);
+        }
+    };
+    // wave 0: the eight partials of every channel in a fixed order, fp64; EXACTLY three always-issued stores (sum, M2, count: lanes
+    // that have nothing to store aim past the buffer) so that the phase's counted vmcnt stays exact
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)stats, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc((void*)cnt, 0, 0x7FFFFFFF, 0x00020000);
+    auto epi_finalize = [&]() {
+        if (wave == 0) {
+            const float2* const red = reinterpret_cast<const float2*>(smem + RED_OFF);
+            double S = 0.0, Q = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float2 v = red[lane * 8 + i]; S += (double)v.x; Q += (double)v.y; }
+            const int co = prev.nt * HBN + lane;
+            const int nvalid = min(TH, H - prev.y0) * min(TW, W - prev.x0);
+            const double m2 = Q - S * S * (double)(1.0f / (float)nvalid);
+            const bool cok = co < Cout;
+            const unsigned o1 = cok ? (unsigned)(((size_t)prev.sp * Cout + co) * 4) : 0x80000000u;
+            const unsigned o2 = cok ? (unsigned)(((size_t)(P + prev.sp) * Cout + co) * 4) : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)S), srsrc, o1, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(m2 > 0.0 ? m2 : 0.0)), srsrc, o2, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)nvalid), crsrc,
+                                                  (prev.nt == 0 && lane == 0) ? (unsigned)prev.sp * 4u : 0x80000000u, 0, 0);
+        }
+    };
+
+    // the layer's bias into LDS once (a register load later would wait for every LDS-DMA in flight: hipcc's vmcnt(0))
+    for (int i = tid; i < 1024; i += 512) reinterpret_cast<float*>(smem + BIAS_OFF)[i] = (bias != nullptr && i < Cout) ? bias[i] : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    int base = 0;
+    int tile = cvk_xcd_remap(blockIdx.x, min(G, ntiles));
+    Geo cur = geo_of(tile);
+    setup_dma(cur);
+    issue_prologue();
+    if (lo) cvk_wait_vm<2>(); else cvk_wait_vm<1>();        // slab of slice 0 and kernel row 0 have landed; row 1 (2 / 1 pieces) is behind them
+    phase_barrier();
+    if (grp == 1) phase_barrier();                          // group B runs one interval behind group A — for the whole kernel
+
+    f32x4v acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    int pb[3] = {pb0[0], pb0[1], pb0[2]};
+    int pb_flip = SLAB_BYTES;
+
+    // ONE phase sequence over all tiles of the workgroup: the weight ring (three kernel rows, nph % 3 == 0) and the two slabs (ncs even)
+    // run on across tile boundaries — the last slice of a tile requests the NEXT tile's first slab and its kernel rows 0 and 1 where
+    // k_conv_bf16h re-loaded the last step into buffers nobody reads — so there is no prologue to wait for, no drain and no barrier
+    // at a boundary; what is left there (bias, pack, 200-300 vector instructions) sits in the first LOAD phase's slack.
+    while (true) {
+        bool has_next = false;
+        Geo nxt = cur;
+        for (int cs = 0; cs < ncs; ++cs) {
+            const bool lastcs = cs == ncs - 1;
+            const unsigned slab_next = wave_lds + RING_BYTES + ((cs + 1) & 1) * SLAB_BYTES;
+            auto row_body = [&](auto dy_tag) {
+                constexpr int dy = decltype(dy_tag)::value;
+                // ======== LOAD phase: the kernel row two phases ahead (in a tile's last slice: its last row, then rows 0 and 1 of the
+                // next tile), the next slab (3 + 2 pieces; last slice: slice 0 of the next tile)
+                if (!lastcs) dma_row_next(std::integral_constant<int, (dy + 2) % 3>{}, true);
+                else if (dy == 0) {
+                    dma_row_next(std::integral_constant<int, 2>{}, false);        // this tile's last kernel row
+                    base += G;
+                    const int n_k = min(G, ntiles - base);
+                    has_next = (int)blockIdx.x < n_k;
+                    if (has_next) {
+                        nxt = geo_of(base + cvk_xcd_remap(blockIdx.x, n_k));
+                        setup_dma(nxt);                                            // slab offsets / resource / weight stream of the next tile
+                    }
+                } else dma_row_next(std::integral_constant<int, (dy + 2) % 3>{}, has_next);   // no next tile: the last row again, into a dead slot
+                const int csn = lastcs ? (has_next ? 0 : ncs - 1) : cs + 1;
+                if (dy == 0) {
+                    dma_slab_piece(std::integral_constant<int, 0>{}, csn, slab_next);
+                    dma_slab_piece(std::integral_constant<int, 1>{}, csn, slab_next);
+                    dma_slab_piece(std::integral_constant<int, 2>{}, csn, slab_next);
+                } else if (dy == 1) {
+                    dma_slab_piece(std::integral_constant<int, 3>{}, csn, slab_next);
+                    dma_slab_piece(std::integral_constant<int, 4>{}, csn, slab_next);
+                }
+                // the previous tile's epilogue, in this tile's first slice: kernel row 1 = stage / statistics / stores, kernel row 2 =
+                // the statistics' finalisation (wave 0; the partner group wrote its partials one interval ago)
+                const bool epi = have_prev && cs == 0;
+                if (dy == 1 && epi) { __builtin_amdgcn_sched_barrier(0); epi_lds_and_store(); __builtin_amdgcn_sched_barrier(0); }
+                if (STATS && dy == 2 && epi) { __builtin_amdgcn_sched_barrier(0); epi_finalize(); __builtin_amdgcn_sched_barrier(0); }
+                bf16x8 a[3][4], b[3][4];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) a[dx][rb] = lds_read16(smem + (wa + dy * HROW + dx * (HBN * 64) + rb * 16 * 64));
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) b[dx][cb] = lds_read16(smem + (pb[dx] + ((cb >> 1) + dy) * (HP * 64) + (cb & 1) * 16 * 64));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                {
+                    // everything requested before this phase's DMAs has landed (kernel row ph + 1, the slab pieces of earlier phases); this
+                    // phase's own requests — and the stores the epilogue pieces put behind them — may be in flight
+                    constexpr int NS = dy == 0 ? 3 : (dy == 1 ? 2 : 0);
+                    const bool st = (dy == 1) && epi;
+                    const bool fz = STATS && (dy == 2) && epi && wave == 0;
+                    if (lo) { if (st) cvk_wait_vm<2 + NS + NSTORE>(); else if (fz) cvk_wait_vm<2 + NS + 3>(); else cvk_wait_vm<2 + NS>(); }
+                    else    { if (st) cvk_wait_vm<1 + NS + NSTORE>(); else cvk_wait_vm<1 + NS>(); }
+                }
+                phase_barrier();
+                // ======== MFMA phase: 48 MFMAs
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                        for (int cb = 0; cb < 4; ++cb)
+                            acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[dx][rb], b[dx][cb], acc[rb][cb], 0, 0, 0);
+                if (dy == 2) {
+#pragma unroll
+                    for (int dx2 = 0; dx2 < 3; ++dx2) pb[dx2] += pb_flip;
+                    pb_flip = -pb_flip;
+                }
+                __builtin_amdgcn_s_setprio(0);
+                phase_barrier();
+            };
+            row_body(std::integral_constant<int, 0>{}); row_body(std::integral_constant<int, 1>{}); row_body(std::integral_constant<int, 2>{});
+        }
+        // ---- tile boundary: bias (from LDS), pack to bf16 in registers, clear the accumulators; out-of-frame pixels of a ragged tile as
+        // zeros (the statistics read the staged tile)
+        {
+            const int n0 = cur.nt * HBN;
+            const bool ragged = (cur.y0 + TH > H) | (cur.x0 + TW > W);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (n0 + rb * 16 + 4 * q4) * 4);
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    const bool ok = (cur.x0 + (cb & 1) * 16 + l15 < W) & (cur.y0 + row0 + (cb >> 1) < H);
+                    bf16x4 o = {(__bf16)(acc[rb][cb][0] + bv[0]), (__bf16)(acc[rb][cb][1] + bv[1]),
+                                (__bf16)(acc[rb][cb][2] + bv[2]), (__bf16)(acc[rb][cb][3] + bv[3])};
+                    if (STATS && ragged && !ok) o = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                    pk[rb][cb] = __builtin_bit_cast(u32x2v, o);
+                    acc[rb][cb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        prev = cur;
+        have_prev = true;
+        if (!has_next) break;
+        cur = nxt;
+    }
+    if (grp == 0) phase_barrier();      // pairs with group B's last MFMA-phase barrier
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the dead re-loads of the last tile have landed
+    // the last tile's epilogue, without a K loop around it: group A's waves, then group B's (they share the stage regions)
+    if (grp == 0) epi_lds_and_store();
+    __syncthreads();
+    if (grp == 1) epi_lds_and_store();
+    __syncthreads();
+    if (STATS) epi_finalize();
+}
+
+#endif  // CVK_EXPERIMENTS (k_conv_bf16hp)
+
 // fp32 master weights, physical [Cout][3][3][Cin] -> tile-major bf16 pack [row tile][slice][tap][128 rows][4 chunks][8], chunk
 // position p of row n holds source chunk p ^ ((n>>2)&3) (the LDS image of one DMA'd tap tile, byte for byte); zero padded.
 // dgrad: rows are the INPUT channels of the layer, k runs over its output channels, taps rotated by 180 degrees.
@@ -1353,6 +1697,13 @@ void launch(const void* x, const void* wpp, const float* bias, void* y, float* s
             return;
         }
 #endif
+#ifdef CVK_EXPERIMENTS
+        if (p128 && cvk_knob("CVK_BF16H_PIPE", 0) && Cin % 64 == 0 && Cout <= 1024) {
+            if (stats) hipLaunchKernelGGL((k_conv_bf16hp<true, true>), pgrid, block, 0, s, CVK_PP_ARGS);
+            else hipLaunchKernelGGL((k_conv_bf16hp<false, true>), pgrid, block, 0, s, CVK_PP_ARGS);
+            return;
+        }
+#endif
         if (p128) {
             if (stats) hipLaunchKernelGGL((k_conv_bf16h<true, 0, true>), pgrid, block, 0, s, CVK_PP_ARGS);
             else hipLaunchKernelGGL((k_conv_bf16h<false, 0, true>), pgrid, block, 0, s, CVK_PP_ARGS);
@@ -1366,6 +1717,13 @@ void launch(const void* x, const void* wpp, const float* bias, void* y, float* s
 #ifdef CVK_EXPERIMENTS
         if (stats && !p128 && cvk_knob("CVK_BF16H_MST", 1) == 0) {      // A/B: the round-4 vector-unit statistics
             hipLaunchKernelGGL((k_conv_bf16h<true, 0, false, false, false>), pgrid, block, 0, s, CVK_PP_ARGS);
+            return;
+        }
+#endif
+#ifdef CVK_EXPERIMENTS
+        if (cvk_knob("CVK_BF16H_PIPE", 0) && Cin % 64 == 0 && Cout <= 1024) {        // pipelined epilogue (round 5 experiment)
+            if (stats) hipLaunchKernelGGL((k_conv_bf16hp<true, false>), pgrid, block, 0, s, CVK_PP_ARGS);
+            else hipLaunchKernelGGL((k_conv_bf16hp<false, false>), pgrid, block, 0, s, CVK_PP_ARGS);
             return;
         }
 #endif
