@@ -204,7 +204,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16q(const __bf16* __restrict_
         dma_slab_piece(std::integral_constant<int, 3>{}, 0, wave_lds + RING_BYTES);
         dma_slab_piece(std::integral_constant<int, 4>{}, 0, wave_lds + RING_BYTES);
         dma_weights_next(std::integral_constant<int, 0>{}, 0);
-        dma_weights_next(std::integral_constant<int, 1>{}, 1);
     };
 
     // weights: row wc*64 + rb*16 + l15, chunk q4; pixels: halo row row0 + tp + dy, halo column half*16 + l15 + dx, chunk q4
@@ -224,8 +223,13 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16q(const __bf16* __restrict_
     bool stores_in_flight = false;
 
     while (true) {
-        // slab of slice 0 and the weights of step 0 have landed; behind them in the queue: the weights of step 1 and, after the
-        // first tile, the previous tile's NSTORE stores
+        // The weights of step 1 are requested HERE, behind the previous tile's stores, not with the prologue in front of them (round 5):
+        // the in-order counter then needs no special case in the K loop — vmcnt(2) at the end of step 0 covers the stores as well; the
+        // `step == 0 && stores_in_flight` branch inside the first step made hipcc peel the first slice (two copies of the MFMA stream; the
+        // data-grad variant spilled 12 registers around them: 3.57 -> 3.49 ms for its 14 launches of a configs[3] step).
+        dma_weights_next(std::integral_constant<int, 1>{}, 1);
+        // slab of slice 0 and the weights of step 0 have landed; behind them in the queue: (after the first tile) the previous tile's
+        // NSTORE stores, and the piece just requested
         if (stores_in_flight) cvk_wait_vm<1 + NSTORE>(); else cvk_wait_vm<1>();
         phase_barrier();
         if (grp == 1) phase_barrier();
@@ -256,9 +260,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16q(const __bf16* __restrict_
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 // this wave's piece of the weights of step + 1 has landed: everything requested before this phase's DMAs — except in
                 // the first phase of a later tile, whose step-1 weights sit in front of the previous tile's stores
-                if (sidx == 0) {
-                    if (step == 0 && stores_in_flight) cvk_wait_vm<2 + NSTORE>(); else cvk_wait_vm<2>();
-                } else if (sidx < 5) cvk_wait_vm<2>();
+                if (sidx < 5) cvk_wait_vm<2>();
                 else cvk_wait_vm<1>();
                 phase_barrier();
                 // ======== MFMA phase
@@ -324,6 +326,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16q(const __bf16* __restrict_
             (void*)(Y + ((size_t)(cur.img * H + cur.y0) * W + cur.x0) * ldy + n0), 0, 0x7FFFFFFF, 0x00020000);
         // Every wave: bias, statistics, pack to bf16 IN PLACE (the packed pair of a block replaces the first two of its four
         // accumulator registers: no second register array beside the 128 accumulators).
+        // (Round 5: the matrix-pipe statistics of k_conv_bf16h were tried here too — two stage passes, 16 partials per channel — and were 3 %
+        // SLOWER on the 12 forward launches, 2.36 -> 2.44 ms: the vector version stays.)
         // Statistics: a lane holds (sum, sum of squares) of 16 channels over its 8 pixel blocks; the 16 lanes of a DPP row hold the
         // same channels for 16 pixel columns: four DPP adds per value leave the row total in every lane; 4 partials per channel
         // (2 groups x 2 row halves) meet in LDS and are combined in fp64 in a fixed order.
