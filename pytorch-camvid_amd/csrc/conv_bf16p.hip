@@ -882,7 +882,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
         dma_slab_piece(std::integral_constant<int, 3>{}, 0, wave_lds + RING_BYTES);
         dma_slab_piece(std::integral_constant<int, 4>{}, 0, wave_lds + RING_BYTES);
         dma_row_next(std::integral_constant<int, 0>{}, 0);
-        dma_row_next(std::integral_constant<int, 1>{}, 1);
     };
 
     // weights: tap dx of the slot's kernel row at dx * 4 KiB, row rb*16 + l15, chunk q4; pixels: halo row row0 + tp + dy, halo column
@@ -910,8 +909,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
 
     while (true) {
         stamp(0);
-        // slab of slice 0 and the weights of kernel row 0 have landed; behind them: the weights of row 1 (2 / 1 pieces) and, after the
-        // first tile, the previous tile's NSTORE stores
+        // kernel row 1 is requested HERE, behind the previous tile's stores (round 5, as in k_conv_bf16q: no special case for a tile's first
+        // phase in the K loop, no peeled first slice)
+        dma_row_next(std::integral_constant<int, 1>{}, 1);
+        // slab of slice 0 and the weights of kernel row 0 have landed; behind them: (after the first tile) the previous tile's NSTORE
+        // stores and the row just requested (2 / 1 pieces)
         if (lo) { if (stores_in_flight) cvk_wait_vm<2 + NSTORE>(); else cvk_wait_vm<2>(); }
         else    { if (stores_in_flight) cvk_wait_vm<1 + NSTORE>(); else cvk_wait_vm<1>(); }
         phase_barrier();
@@ -955,9 +957,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
                 // slab pieces) — except in the first phase of a later tile, whose row-1 weights sit in front of the previous tile's stores
                 {
                     constexpr int NS = dy == 0 ? 3 : (dy == 1 ? 2 : 0);
-                    const bool first = (dy == 0) && (ph == 0) && stores_in_flight;
-                    if (lo) { if (first) cvk_wait_vm<2 + NS + NSTORE>(); else cvk_wait_vm<2 + NS>(); }
-                    else    { if (first) cvk_wait_vm<1 + NS + NSTORE>(); else cvk_wait_vm<1 + NS>(); }
+                    if (lo) cvk_wait_vm<2 + NS>(); else cvk_wait_vm<1 + NS>();
                 }
                 phase_barrier();
                 // ======== MFMA phase: 48 MFMAs
@@ -1021,7 +1021,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
             if (k == 3) dma_slab_piece(std::integral_constant<int, 3>{}, 0, wave_lds + RING_BYTES);
             if (k == 4) dma_slab_piece(std::integral_constant<int, 4>{}, 0, wave_lds + RING_BYTES);
             if (k == 5) dma_row_next(std::integral_constant<int, 0>{}, 0);
-            if (k == 6) dma_row_next(std::integral_constant<int, 1>{}, 1);
         };
 
         // ---- epilogue: acc[rb][cb][i] = channel n0 + rb*16 + 4*q4 + i, pixel (y0 + row0 + (cb >> 1), x0 + (cb & 1)*16 + l15) ---------------
@@ -1064,7 +1063,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bf16h(const __bf16* __restrict_
                     // stage: [512 pixels][128 B], 16-byte chunk c of pixel p at position c ^ ((p >> 1) & 7)
                     const int p = (row0 + (cb >> 1)) * 32 + (cb & 1) * 16 + l15, chunk = rb * 2 + (q4 >> 1);
                     *reinterpret_cast<bf16x4*>(smem + STAGE_OFF + p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4) + 8 * (q4 & 1)) = o;
-                    if (rb * 4 + cb < 7) prologue_piece(rb * 4 + cb);
+                    if (rb * 4 + cb < 6) prologue_piece(rb * 4 + cb);
                 }
             }
             if (STATS && !MST) {
