@@ -181,6 +181,20 @@ int cvk_w6_gemm_tn(const float* E, const float* V, float* P, int T, int Cin_pad,
 int cvk_split3_rows_pad(int R, int mult);
 int cvk_split3_planes(const float* P, void* S, int NX, int R, int Rpad, int C, void* stream);
 int cvk_w2d_gemm_split3(const void* V3, const void* U3, float* Mo, int NX, int T, int Tpad, int Cin, int Cout, int Cpad, void* stream);
+/* ... the rest of the study path (tile = 4 or 6 selects F(4x4,3x3) / F(6x6,3x3)): transforms that write split planes from their store loops
+ * (V3 / Vp3 / E3 rows padded to cvk_split3_rows_pad(T, 256); E stays fp32 [NX][cvk_w2d_tpad(T)][C] with e_split = 0), the filter as split
+ * planes (tmp: NX * Cout * Cin floats), the output pass for product planes without K-range partials, and the weight-grad GEMM
+ * P[f][NX][Cout][Cin] = E^T V on split planes (f = cvk_w2d_gemm_tn_split3_ksplit; Cout % 256 == 0 && Cin % 128 == 0 or the reverse) with
+ * its final pass for an explicit f. */
+int cvk_w2d_input_transform_split3(int tile, const float* x, void* V3, int N, int H, int W, int Cin, void* stream);
+int cvk_w2d_dy_transform_both_split3(int tile, const float* dy, int ld_dy, void* Vp3, void* E, int e_split, int N, int H, int W, int C,
+                                     void* stream);
+int cvk_w2d_weight_transform_split3(int tile, const float* w, void* U3, float* tmp, int Cout, int Cin, int dgrad, void* stream);
+int cvk_w2d_output_plain(int tile, const float* Mo, const float* bias, float* y, float* stats, float* counts, int N, int H, int W,
+                         int Cout, int ldy, void* stream);
+int cvk_w2d_gemm_tn_split3_ksplit(int NX, int Tpad, int Cin, int Cout);
+int cvk_w2d_gemm_tn_split3(const void* E3, const void* V3, float* P, int NX, int Tpad, int Cin, int Cout, void* stream);
+int cvk_w2d_wgrad_output_f(int tile, const float* P, float* dw, int Cin, int Cin_pad, int Cout, int f, void* stream);
 int cvk_w6_wgrad_output(const float* P, float* dw, int T, int Cin, int Cin_pad, int Cout, void* stream);
 /* FUSED 1-D Winograd F(4,3) (csrc/wino4f.hip; replaces nn.Conv2d(cin,cout,3,padding=1) fwd and its data-grad,
  * /root/reference/models/unet.py:11, models/segnet.py:8, for the 64/128-channel levels): one workgroup computes all six

@@ -99,6 +99,13 @@ SIGNATURES = {
     "cvk_split3_rows_pad": (c_int, [c_int, c_int]),
     "cvk_split3_planes": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_w2d_gemm_split3": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_w2d_input_transform_split3": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_w2d_dy_transform_both_split3": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_w2d_weight_transform_split3": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "cvk_w2d_output_plain": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_w2d_gemm_tn_split3_ksplit": (c_int, [c_int, c_int, c_int, c_int]),
+    "cvk_w2d_gemm_tn_split3": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_w2d_wgrad_output_f": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_w2d_wgrad_ksplit": (c_int, [c_int, c_int, c_int]),
     "cvk_w2d_dy_transform": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_w2d_dy_transform_both": (c_int, [c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),

@@ -186,6 +186,141 @@ __global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__
     }
 }
 
+
+// ---- the weight-grad GEMM on split planes: P_xi[co][ci] = sum_t E_xi[t][co] * V_xi[t][ci]  (k = the tile index t) ----------------------------
+// Both operands are the split planes the transforms wrote ([xi][C/32][term][Tpad][32]: rows = t) — the SAME V planes the forward GEMM read,
+// kept for the backward pass, and E = A dy A^T from the dy transform.  The MFMA wants 8 consecutive k (= t) per lane for its channel:
+// ds_read_b64_tr_b16 (lane group = 4 rows x 16 channels, a lane receives its channel's 4 rows; two reads = 8 rows), as k_wgrad_bf16r reads
+// its pixel-major tiles.  Same ping-pong machine as k_gemm_split3: 8 waves, two groups, tile 256 x 128 with the groups splitting the
+// 256 side (CO256: output channels, else input channels), a wave owns 64 (ci) x 64 (co): per 32-row slice 24 fragments = 48 transposing
+// reads and 96 MFMAs; two stages of 72 KiB; the A operand is V (m = ci) so that a lane ends with 4 consecutive input channels of one output
+// channel: 16-byte stores into P [part][xi][Cout][Cin].  The depth is cut into f ranges (k_w2d_wgrad_out adds the planes in a fixed order).
+template <bool CO256>
+__global__ __launch_bounds__(512, 2) void k_gemm_tn_split3(const char* __restrict__ E3, const char* __restrict__ V3, float* __restrict__ P,
+                                                          int Tpad, int Cin, int Cout, int tilesCi, int tilesCo, int f, int NX) {
+    constexpr int X256 = 8 * 3 * 2048, X128 = 4 * 3 * 2048;       // 48 KiB + 24 KiB per stage
+    constexpr int STAGE = X256 + X128;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+    const unsigned smem_addr = cvk_lds_addr(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q4 = lane >> 4, tq = l15 >> 2, tp = l15 & 3;
+    const int grp = wave >> 2, wi = wave & 3, wa_ = wave & 1, wb_ = (wave >> 1) & 1;
+    int bid = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int part = bid % f; bid /= f;
+    const int tci = bid % tilesCi; bid /= tilesCi;
+    const int tco = bid % tilesCo;
+    const int xi = bid / tilesCo;
+    const int nK = Tpad >> 5;
+    const int k0 = (int)((long)nK * part / f), k1 = (int)((long)nK * (part + 1) / f);
+    const int ncsE = Cout >> 5, ncsV = Cin >> 5;
+    // the 256 side ("big") and the 128 side ("small"): slices of 32 channels
+    const char* const big = CO256 ? E3 : V3;
+    const char* const sml = CO256 ? V3 : E3;
+    const int ncsB = CO256 ? ncsE : ncsV, ncsS = CO256 ? ncsV : ncsE;
+    const int sB0 = (CO256 ? tco : tci) * 8, sS0 = (CO256 ? tci : tco) * 4;
+    const size_t term = (size_t)Tpad * 64;                           // bytes between two terms of a slice
+    // this wave moves slice (4 grp + wi) of the big side and (group A) slice wi of the small side: 3 terms x 2 KiB each, per K slice
+    const char* bsrc = big + (((size_t)xi * ncsB + sB0 + 4 * grp + wi) * 3 * Tpad + (size_t)k0 * 32) * 64;
+    const char* ssrc = sml + (((size_t)xi * ncsS + sS0 + wi) * 3 * Tpad + (size_t)k0 * 32) * 64;
+    const unsigned voff = lane * 16;
+    const unsigned bdst = smem_addr + (4 * grp + wi) * 3 * 2048;
+    const unsigned sdst = smem_addr + X256 + wi * 3 * 2048;
+    auto issue_slice = [&](unsigned stage_off) {
+        dma16_s<0>(voff, bsrc, bdst + stage_off);
+        dma16_s<1024>(voff, bsrc + 1024, bdst + stage_off);
+        dma16_s<2048>(voff, bsrc + term, bdst + stage_off);
+        dma16_s<2048 + 1024>(voff, bsrc + term + 1024, bdst + stage_off);
+        dma16_s<4096>(voff, bsrc + 2 * term, bdst + stage_off);
+        dma16_s<4096 + 1024>(voff, bsrc + 2 * term + 1024, bdst + stage_off);
+        bsrc += 2048;
+        if (grp == 0) {
+            dma16_s<0>(voff, ssrc, sdst + stage_off);
+            dma16_s<1024>(voff, ssrc + 1024, sdst + stage_off);
+            dma16_s<2048>(voff, ssrc + term, sdst + stage_off);
+            dma16_s<2048 + 1024>(voff, ssrc + term + 1024, sdst + stage_off);
+            dma16_s<4096>(voff, ssrc + 2 * term, sdst + stage_off);
+            dma16_s<4096 + 1024>(voff, ssrc + 2 * term + 1024, sdst + stage_off);
+            ssrc += 2048;
+        }
+    };
+    // transposing fragment reads: block of 16 channels = half h16 of slice sl; the lane addresses rows 8 q4 + tq (first read) and + 4 (second:
+    // its chunk sits at position ^ 2, the swizzle bit of rows 4..7), channels 4 tp .. 4 tp + 3 of the block
+    typedef short s16x4t __attribute__((ext_vector_type(4)));
+    // per-lane byte offsets inside a (slice, term) block of 2 KiB for the two reads of the two 16-channel halves: [h16][read]
+    int fo[2][2];
+#pragma unroll
+    for (int h16 = 0; h16 < 2; ++h16) {
+        const int chunk = h16 * 2 + (tp >> 1);
+        fo[h16][0] = (8 * q4 + tq) * 64 + (chunk << 4) + (tp & 1) * 8;
+        fo[h16][1] = (8 * q4 + tq + 4) * 64 + ((chunk ^ 2) << 4) + (tp & 1) * 8;
+    }
+    auto rd = [&](int blk_off, int h16) {
+        const s16x4t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4t*)(smem + blk_off + fo[h16][0]));
+        const s16x4t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4t*)(smem + blk_off + fo[h16][1]));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    // wave tile: 64 ci x 64 co.  On the 256 side the group takes 128 channels (4 slices) and the wave 64 of them (2 slices); on the 128 side
+    // the wave takes 64 (2 slices).  ci is the A operand.
+    const int ciS = CO256 ? 2 * wa_ : 4 * grp + 2 * wa_;       // first ci slice of this wave inside its LDS region
+    const int coS = CO256 ? 4 * grp + 2 * wb_ : 2 * wb_;
+    const int ciReg = CO256 ? X256 : 0, coReg = CO256 ? 0 : X256;      // which region holds ci / co
+
+    f32x4v acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    int st = 0;
+    issue_slice(0);
+    cvk_wait_vm<0>();
+    pbar();
+    if (grp == 1) pbar();
+    for (int ks = k0; ks < k1; ++ks) {
+        if (ks + 1 < k1) issue_slice(st ? 0 : STAGE);
+        const int so = st ? STAGE : 0;
+        bf16x8 A[3][4], B[3][4];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                A[k][mb] = rd(so + ciReg + ((ciS + (mb >> 1)) * 3 + k) * 2048, mb & 1);
+                B[k][mb] = rd(so + coReg + ((coS + (mb >> 1)) * 3 + k) * 2048, mb & 1);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pbar();
+        __builtin_amdgcn_s_setprio(1);
+        auto prod = [&](int ka, int kb) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ka][mb], B[kb][nb], acc[mb][nb], 0, 0, 0);
+        };
+        prod(2, 0); prod(0, 2); prod(1, 1); prod(1, 0); prod(0, 1); prod(0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        st ^= 1;
+        cvk_wait_vm<0>();
+        pbar();
+    }
+    if (grp == 0) pbar();
+
+    // acc[mb][nb][j]: ci = ci0 + mb*16 + 4 q4 + j, co = co0 + nb*16 + l15
+    const int ci0 = tci * (CO256 ? 128 : 256) + (CO256 ? 64 * wa_ : 128 * grp + 64 * wa_);
+    const int co0 = tco * (CO256 ? 256 : 128) + (CO256 ? 128 * grp + 64 * wb_ : 64 * wb_);
+    float* const pp = P + ((size_t)part * NX + xi) * Cout * Cin;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int co = co0 + nb * 16 + l15;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const int ci = ci0 + mb * 16 + 4 * q4;
+            if (co < Cout && ci < Cin) *reinterpret_cast<f32x4v*>(pp + (size_t)co * Cin + ci) = acc[mb][nb];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int cvk_split3_rows_pad(int R, int mult) { return (R > 0 && mult > 0) ? cvk_cdiv(R, mult) * mult : 0; }
@@ -212,4 +347,32 @@ extern "C" int cvk_w2d_gemm_split3(const void* V3, const void* U3, float* Mo, in
     hipLaunchKernelGGL(k_gemm_split3, dim3((unsigned)(NX * tilesM * tilesN)), dim3(512), 0, (hipStream_t)stream, (const char*)V3, (const char*)U3,
                        Mo, T, Tpad, Cin, Cout, Cpad, tilesM, tilesN);
     CVK_LAUNCH_RETURN("cvk_w2d_gemm_split3");
+}
+
+// depth ranges of the split weight-grad GEMM for a layer: enough workgroups to fill the chip twice, at least 4 slices per range
+extern "C" int cvk_w2d_gemm_tn_split3_ksplit(int NX, int Tpad, int Cin, int Cout) {
+    if (NX <= 0 || Tpad <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    const bool co256 = Cout % 256 == 0;
+    const int nt = NX * (co256 ? (Cout / 256) * cvk_cdiv(Cin, 128) : cvk_cdiv(Cout, 128) * (Cin / 256));
+    const int nK = Tpad / 32;
+    int f = cvk_cdiv(512, nt > 0 ? nt : 1);
+    if (f > nK / 4) f = nK / 4;
+    if (f > 16) f = 16;
+    if (f < 1) f = 1;
+    return f;
+}
+
+// P fp32 [f][NX][Cout][Cin] = E^T V per transform index and depth range, operands as split planes with Tpad % 256 == 0 rows; needs
+// Cout % 256 == 0 and Cin % 128 == 0, or Cin % 256 == 0 and Cout % 128 == 0; f = cvk_w2d_gemm_tn_split3_ksplit(NX, Tpad, Cin, Cout)
+extern "C" int cvk_w2d_gemm_tn_split3(const void* E3, const void* V3, float* P, int NX, int Tpad, int Cin, int Cout, void* stream) {
+    CVK_CHECK_ARG(E3 && V3 && P && NX > 0 && Tpad > 0 && Tpad % 256 == 0, "cvk_w2d_gemm_tn_split3: bad arguments");
+    const bool co256 = Cout % 256 == 0 && Cin % 128 == 0;
+    CVK_CHECK_ARG(co256 || (Cin % 256 == 0 && Cout % 128 == 0), "cvk_w2d_gemm_tn_split3: needs Cout %% 256 == 0 and Cin %% 128 == 0, or the reverse");
+    CVK_CHECK_ARG(cvk_aligned16(E3) && cvk_aligned16(V3) && cvk_aligned16(P), "cvk_w2d_gemm_tn_split3: pointers must be 16-byte aligned");
+    const int f = cvk_w2d_gemm_tn_split3_ksplit(NX, Tpad, Cin, Cout);
+    const int tilesCo = co256 ? Cout / 256 : Cout / 128, tilesCi = co256 ? Cin / 128 : Cin / 256;
+    const dim3 grid((unsigned)(NX * tilesCo * tilesCi * f));
+    if (co256) hipLaunchKernelGGL((k_gemm_tn_split3<true>), grid, dim3(512), 0, (hipStream_t)stream, (const char*)E3, (const char*)V3, P, Tpad, Cin, Cout, tilesCi, tilesCo, f, NX);
+    else hipLaunchKernelGGL((k_gemm_tn_split3<false>), grid, dim3(512), 0, (hipStream_t)stream, (const char*)E3, (const char*)V3, P, Tpad, Cin, Cout, tilesCi, tilesCo, f, NX);
+    CVK_LAUNCH_RETURN("cvk_w2d_gemm_tn_split3");
 }

@@ -176,7 +176,51 @@ template <> struct W2T<6> {
 
 // ---- input transform: x [N,H,W,C] -> V [NX][T][C], T = N * ceil(H/MT) * ceil(W/MT); one thread = one tile x VW channels ------
 // Rows T <= t < Tpad (weight-grad: the tile index is the GEMM depth, padded to whole K slices) are written as zeros.
-template <int MT>
+// ---- split planes (round 5 study: csrc/split3.hip; cvk_split3_planes' format written straight from a transform's store loop) -------------
+// bf16 [xi][C/32][term 3][Rpad][32]: channel c of row t of transform index xi as x1 + x2 + x3 (three bf16 roundings of the remainder), the
+// 16-byte chunk (c % 32) / 8 of a 64-byte row at position chunk ^ (2 * ((t >> 2) & 1)).  One call stores VW consecutive channels (c % VW == 0).
+struct SplitDst {
+    unsigned short* base;       // element (xi = 0, this thread's channel slice, term 0, row t, swizzled chunk, c % 8)
+    size_t term, xstride;       // elements between two terms / two transform indices
+};
+template <int VW>
+__device__ __forceinline__ SplitDst split_dst(void* S, int C, int Rpad, int t, int c) {
+    const int ncs = C >> 5, cs = c >> 5, cl = c & 31;
+    const int pos = (cl >> 3) ^ (((t >> 2) & 1) << 1);
+    SplitDst d;
+    d.term = (size_t)Rpad * 32;
+    d.xstride = (size_t)ncs * 3 * d.term;
+    d.base = reinterpret_cast<unsigned short*>(S) + ((size_t)cs * 3 * Rpad + t) * 32 + pos * 8 + (cl & 7);
+    return d;
+}
+__device__ __forceinline__ unsigned short w2_bf16_rne(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+template <int VW, typename VT>
+__device__ __forceinline__ void split_store(const SplitDst& d, int xi, VT v) {
+    float r[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) r[j] = v[j];
+    unsigned short* p = d.base + (size_t)xi * d.xstride;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        unsigned short b[VW];
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+            b[j] = w2_bf16_rne(r[j]);
+            r[j] -= __builtin_bit_cast(float, (unsigned)b[j] << 16);
+        }
+        if (VW == 2) *reinterpret_cast<unsigned*>(p) = (unsigned)b[0] | ((unsigned)b[1] << 16);
+        else {
+            typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u32x2w*>(p) = u32x2w{(unsigned)b[0] | ((unsigned)b[1] << 16), (unsigned)b[VW > 2 ? 2 : 0] | ((unsigned)b[VW > 2 ? 3 : 0] << 16)};
+        }
+        p += d.term;
+    }
+}
+
+template <int MT, bool SPL = false>
 __global__ __launch_bounds__(256) void k_w2d_input(const float* __restrict__ X, float* __restrict__ V, int H, int W, int C,
                                                   int th, int tw, int T, int Tpad) {
     typedef W2T<MT> TR;
@@ -189,8 +233,13 @@ __global__ __launch_bounds__(256) void k_w2d_input(const float* __restrict__ X, 
     const int t = (int)(idx / cvn), c = (int)(idx % cvn) * VW;
     if (t >= Tpad) return;
     const VT zero = {};
+    SplitDst sd = {};
+    if (SPL) sd = split_dst<VW>(V, C, Tpad, t, c);
     if (t >= T) {
-        for (int xi = 0; xi < NX; ++xi) *reinterpret_cast<VT*>(V + ((size_t)xi * Tpad + t) * C + c) = zero;
+        for (int xi = 0; xi < NX; ++xi) {
+            if (SPL) split_store<VW>(sd, xi, zero);
+            else *reinterpret_cast<VT*>(V + ((size_t)xi * Tpad + t) * C + c) = zero;
+        }
         return;
     }
     const int n = t / (th * tw), r = t - n * th * tw, ty = r / tw, tx = r - ty * tw;
@@ -218,7 +267,10 @@ __global__ __launch_bounds__(256) void k_w2d_input(const float* __restrict__ X, 
         VT v[NT];
         TR::bt(w[i], v);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) *reinterpret_cast<VT*>(vb + (size_t)(i * NT + j) * plane) = v[j];
+        for (int j = 0; j < NT; ++j) {
+            if (SPL) split_store<VW>(sd, i * NT + j, v[j]);
+            else *reinterpret_cast<VT*>(vb + (size_t)(i * NT + j) * plane) = v[j];
+        }
     }
 }
 
@@ -496,9 +548,11 @@ __global__ __launch_bounds__(256) void k_w2d_dy(const float* __restrict__ DY, in
 // dy -> BOTH transforms of the backward pass in one launch: V' = B^T dy B (the data-grad's GEMM operand: the tile with its one-pixel
 // halo) and E = A dy A^T (the weight-grad's: the tile's own MT x MT pixels).  The thread that has just transformed a tile for V'
 // re-reads its inner pixels (L1 / L2 hits) for E: dy crosses the fabric once instead of twice, and one launch replaces two.
-template <int MT>
+template <int MT, int SPL = 0>      // SPL bit 0: V' as split planes, bit 1: E as split planes (both with Tpad rows)
 __global__ __launch_bounds__(256) void k_w2d_dy_both(const float* __restrict__ DY, int ld, float* __restrict__ Vp, float* __restrict__ E, int H,
-                                                    int W, int C, int th, int tw, int T, int Tpad) {
+                                                    int W, int C, int th, int tw, int T, int Tpad, int TpadE) {
+    // Tpad: rows of the V' planes (and of the launch), TpadE <= Tpad: rows of the E planes (fp32 E for the fp32 weight-grad GEMM keeps its
+    // 32-row padding beside 256-row split V' planes)
     typedef W2T<MT> TR;
     typedef typename TR::VT VT;
     constexpr int NT = TR::NT, NX = TR::NX, VW = TR::VW;
@@ -507,13 +561,16 @@ __global__ __launch_bounds__(256) void k_w2d_dy_both(const float* __restrict__ D
     const int t = (int)(idx / cvn), c = (int)(idx % cvn) * VW;
     if (t >= Tpad) return;
     const VT zero = {};
-    const size_t plane = (size_t)Tpad * C;
+    const size_t plane = (size_t)Tpad * C, planeE = (size_t)TpadE * C;
     float* const vb = Vp + (size_t)t * C + c;
     float* const eb = E + (size_t)t * C + c;
+    SplitDst sv = {}, se = {};
+    if (SPL & 1) sv = split_dst<VW>(Vp, C, Tpad, t, c);
+    if (SPL & 2) se = split_dst<VW>(E, C, TpadE, t, c);
     if (t >= T) {
         for (int xi = 0; xi < NX; ++xi) {
-            *reinterpret_cast<VT*>(vb + (size_t)xi * plane) = zero;
-            *reinterpret_cast<VT*>(eb + (size_t)xi * plane) = zero;
+            if (SPL & 1) split_store<VW>(sv, xi, zero); else *reinterpret_cast<VT*>(vb + (size_t)xi * plane) = zero;
+            if (t < TpadE) { if (SPL & 2) split_store<VW>(se, xi, zero); else *reinterpret_cast<VT*>(eb + (size_t)xi * planeE) = zero; }
         }
         return;
     }
@@ -541,7 +598,10 @@ __global__ __launch_bounds__(256) void k_w2d_dy_both(const float* __restrict__ D
             VT v[NT];
             TR::bt(w[i], v);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) *reinterpret_cast<VT*>(vb + (size_t)(i * NT + j) * plane) = v[j];
+            for (int j = 0; j < NT; ++j) {
+                if (SPL & 1) split_store<VW>(sv, i * NT + j, v[j]);
+                else *reinterpret_cast<VT*>(vb + (size_t)(i * NT + j) * plane) = v[j];
+            }
         }
     }
     {   // E (as k_w2d_dy)
@@ -564,7 +624,10 @@ __global__ __launch_bounds__(256) void k_w2d_dy_both(const float* __restrict__ D
             VT e[NT];
             TR::a(w[i], e);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) *reinterpret_cast<VT*>(eb + (size_t)(i * NT + j) * plane) = e[j];
+            for (int j = 0; j < NT; ++j) {
+                if (SPL & 2) split_store<VW>(se, i * NT + j, e[j]);
+                else *reinterpret_cast<VT*>(eb + (size_t)(i * NT + j) * planeE) = e[j];
+            }
         }
     }
 }
@@ -1001,9 +1064,87 @@ static int w2i_dy_both(int mt, const char* who, const float* dy, int ld_dy, floa
     const int th = (H + mt - 1) / mt, tw = (W + mt - 1) / mt, T = N * th * tw, Tpad = w2_tpad(T);
     const long threads = (long)Tpad * (C / (mt == 4 ? 4 : 2));
     const dim3 grid((unsigned)((threads + 255) / 256));
-    if (mt == 4) hipLaunchKernelGGL(k_w2d_dy_both<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, ld_dy, Vp, E, H, W, C, th, tw, T, Tpad);
-    else hipLaunchKernelGGL(k_w2d_dy_both<6>, grid, dim3(256), 0, (hipStream_t)stream, dy, ld_dy, Vp, E, H, W, C, th, tw, T, Tpad);
+    if (mt == 4) hipLaunchKernelGGL(k_w2d_dy_both<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, ld_dy, Vp, E, H, W, C, th, tw, T, Tpad, Tpad);
+    else hipLaunchKernelGGL(k_w2d_dy_both<6>, grid, dim3(256), 0, (hipStream_t)stream, dy, ld_dy, Vp, E, H, W, C, th, tw, T, Tpad, Tpad);
     CVK_LAUNCH_RETURN(who);
+}
+
+// ---- split-operand study path (round 5; csrc/split3.hip holds the GEMMs): transforms that write split planes, plain output pass -----------
+extern "C" int cvk_w2d_input_transform_split3(int tile, const float* x, void* V3, int N, int H, int W, int Cin, void* stream) {
+    CVK_CHECK_ARG((tile == 4 || tile == 6) && x && V3 && N > 0 && H > 0 && W > 0 && Cin >= 32 && Cin % 32 == 0, "cvk_w2d_input_transform_split3: bad arguments");
+    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(V3), "cvk_w2d_input_transform_split3: pointers must be 16-byte aligned");
+    const int mt = tile, th = (H + mt - 1) / mt, tw = (W + mt - 1) / mt, T = N * th * tw, Tpad = cvk_split3_rows_pad(T, 256);
+    const long threads = (long)Tpad * (Cin / (mt == 4 ? 4 : 2));
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (mt == 4) hipLaunchKernelGGL((k_w2d_input<4, true>), grid, dim3(256), 0, (hipStream_t)stream, x, (float*)V3, H, W, Cin, th, tw, T, Tpad);
+    else hipLaunchKernelGGL((k_w2d_input<6, true>), grid, dim3(256), 0, (hipStream_t)stream, x, (float*)V3, H, W, Cin, th, tw, T, Tpad);
+    CVK_LAUNCH_RETURN("cvk_w2d_input_transform_split3");
+}
+
+// dy -> V' as split planes (rows padded to 256) and E: fp32 planes [NX][cvk_w2d_tpad(T)][C] (e_split = 0) or split planes (rows padded to 256)
+extern "C" int cvk_w2d_dy_transform_both_split3(int tile, const float* dy, int ld_dy, void* Vp3, void* E, int e_split, int N, int H, int W, int C,
+                                                void* stream) {
+    CVK_CHECK_ARG((tile == 4 || tile == 6) && dy && Vp3 && E && N > 0 && H > 0 && W > 0 && C >= 32 && C % 32 == 0 && ld_dy >= C && ld_dy % 4 == 0,
+                  "cvk_w2d_dy_transform_both_split3: bad arguments");
+    CVK_CHECK_ARG(cvk_aligned16(dy) && cvk_aligned16(Vp3) && cvk_aligned16(E), "cvk_w2d_dy_transform_both_split3: pointers must be 16-byte aligned");
+    const int mt = tile, th = (H + mt - 1) / mt, tw = (W + mt - 1) / mt, T = N * th * tw, Tpad = cvk_split3_rows_pad(T, 256);
+    const int TpadE = e_split ? Tpad : w2_tpad(T);
+    const long threads = (long)Tpad * (C / (mt == 4 ? 4 : 2));
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    hipStream_t s = (hipStream_t)stream;
+    if (mt == 4) {
+        if (e_split) hipLaunchKernelGGL((k_w2d_dy_both<4, 3>), grid, dim3(256), 0, s, dy, ld_dy, (float*)Vp3, (float*)E, H, W, C, th, tw, T, Tpad, TpadE);
+        else hipLaunchKernelGGL((k_w2d_dy_both<4, 1>), grid, dim3(256), 0, s, dy, ld_dy, (float*)Vp3, (float*)E, H, W, C, th, tw, T, Tpad, TpadE);
+    } else {
+        if (e_split) hipLaunchKernelGGL((k_w2d_dy_both<6, 3>), grid, dim3(256), 0, s, dy, ld_dy, (float*)Vp3, (float*)E, H, W, C, th, tw, T, Tpad, TpadE);
+        else hipLaunchKernelGGL((k_w2d_dy_both<6, 1>), grid, dim3(256), 0, s, dy, ld_dy, (float*)Vp3, (float*)E, H, W, C, th, tw, T, Tpad, TpadE);
+    }
+    CVK_LAUNCH_RETURN("cvk_w2d_dy_transform_both_split3");
+}
+
+// filter -> U as split planes: the fp32 transform into `tmp` (NX * rows * cols floats), then the conversion pass; dgrad: the rotated /
+// channel-exchanged filter of the data-grad (rows = Cin, depth = Cout of the forward layer)
+extern "C" int cvk_w2d_weight_transform_split3(int tile, const float* w, void* U3, float* tmp, int Cout, int Cin, int dgrad, void* stream) {
+    CVK_CHECK_ARG((tile == 4 || tile == 6) && w && U3 && tmp && Cout > 0 && Cin > 0, "cvk_w2d_weight_transform_split3: bad arguments");
+    const int rows = dgrad ? Cin : Cout, cols = dgrad ? Cout : Cin;
+    CVK_CHECK_ARG(cols % 32 == 0, "cvk_w2d_weight_transform_split3: the GEMM depth (%d) must be a multiple of 32", cols);
+    const int rc = dgrad ? w2i_weight_transform_dgrad(tile, "cvk_w2d_weight_transform_split3", w, tmp, Cout, Cin, stream)
+                         : w2i_weight_transform(tile, "cvk_w2d_weight_transform_split3", w, tmp, Cout, Cin, stream);
+    if (rc != CVK_OK) return rc;
+    return cvk_split3_planes(tmp, U3, w2_nx(tile), rows, cvk_split3_rows_pad(rows, 128), cols, stream);
+}
+
+// the output pass for product planes WITHOUT K-range partials (Mo [NX][T][Cout], one plane per transform index)
+extern "C" int cvk_w2d_output_plain(int tile, const float* Mo, const float* bias, float* y, float* stats, float* counts, int N, int H, int W,
+                                    int Cout, int ldy, void* stream) {
+    const char* who = "cvk_w2d_output_plain";
+    CVK_CHECK_ARG((tile == 4 || tile == 6) && Mo && y && N > 0 && H > 0 && W > 0, "%s: bad arguments", who);
+    CVK_CHECK_ARG(Cout >= 64 && Cout % 4 == 0 && ldy >= Cout && ldy % 4 == 0, "%s: needs Cout %% 4 == 0, Cout >= 64 (got %d)", who, Cout);
+    CVK_CHECK_ARG((stats == nullptr) == (counts == nullptr), "%s: stats and counts go together", who);
+    CVK_CHECK_ARG(cvk_aligned16(Mo) && cvk_aligned16(y), "%s: pointers must be 16-byte aligned", who);
+    const int mt = tile, th = (H + mt - 1) / mt, tw = (W + mt - 1) / mt, T = N * th * tw;
+    const int vw = mt == 4 ? 4 : 2, nv = Cout / vw;
+    const int cvn = nv >= 64 ? 64 : (nv >= 32 ? 32 : 16);
+    const int P = cvk_cdiv(T, w2_tb(T));
+    const int tilesM = cvk_cdiv(T, 128), tilesN = cvk_cdiv(Cout, 128);
+    dim3 grid(P, cvk_cdiv(nv, cvn));
+    hipStream_t s = (hipStream_t)stream;
+#define CVK_W2_OUTP(MT_, ST_) hipLaunchKernelGGL((k_w2d_output<MT_, ST_>), grid, dim3(256), 0, s, Mo, Cout, bias, y, ldy, stats, counts, P, H, W, th, tw, T, Cout, cvn, \
+                                                 128, tilesM * tilesN, tilesN, tilesM * tilesN, 1)
+    if (mt == 4) { if (stats) CVK_W2_OUTP(4, true); else CVK_W2_OUTP(4, false); }
+    else         { if (stats) CVK_W2_OUTP(6, true); else CVK_W2_OUTP(6, false); }
+#undef CVK_W2_OUTP
+    CVK_LAUNCH_RETURN(who);
+}
+
+// dW from product planes P [f][NX][Cout][Cin_pad] with an explicit number of K-range planes (the split weight-grad GEMM plans its own)
+extern "C" int cvk_w2d_wgrad_output_f(int tile, const float* P, float* dw, int Cin, int Cin_pad, int Cout, int f, void* stream) {
+    CVK_CHECK_ARG((tile == 4 || tile == 6) && P && dw && Cin > 0 && Cin <= Cin_pad && Cout > 0 && f >= 1 && f <= 64, "cvk_w2d_wgrad_output_f: bad arguments");
+    const size_t total = (size_t)Cout * Cin;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (tile == 4) hipLaunchKernelGGL(k_w2d_wgrad_out<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, dw, Cout, Cin, Cin_pad, f);
+    else hipLaunchKernelGGL(k_w2d_wgrad_out<6>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, dw, Cout, Cin, Cin_pad, f);
+    CVK_LAUNCH_RETURN("cvk_w2d_wgrad_output_f");
 }
 
 // ---- C ABI: F(4x4,3x3) ----------------------------------------------------------------------------------------------------

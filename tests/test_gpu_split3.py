@@ -114,3 +114,74 @@ def test_whole_layer_through_the_split_gemm_vs_fp64_conv(tile):
     e3 = finish(M3.data_ptr())
     print(f"layer 256->256 @2x45x60 F({tile}x{tile},3x3): relative L2 vs fp64: fp32 GEMM {e32:.2e}, split GEMM {e3:.2e}")
     assert e3 <= 1.25 * e32 and e3 < (6e-6 if tile == 6 else 3e-6), (e3, e32)
+
+
+@pytest.mark.parametrize("tile", [6, 4])
+def test_transforms_write_the_split_planes_of_their_fp32_planes(tile):
+    """cvk_w2d_input_transform_split3 / cvk_w2d_dy_transform_both_split3 (split stores inside the transform kernels) must produce bit for bit
+    what cvk_split3_planes makes of the fp32 planes of the product's own transforms — same transform arithmetic, same rounding of the terms."""
+    lib, check = _lib()
+    dev = torch.device("cuda:0"); s = torch.cuda.current_stream().cuda_stream
+    N, H, W, C = 2, 23, 31, 64
+    NX = 64 if tile == 6 else 36
+    fam = "cvk_w6_" if tile == 6 else "cvk_w2d_"
+    g = torch.Generator().manual_seed(tile)
+    x = torch.randn(N, H, W, C, generator=g).to(dev)
+    T = getattr(lib, fam + "tiles")(N, H, W); Tp32 = lib.cvk_w2d_tpad(T); Tp = lib.cvk_split3_rows_pad(T, 256)
+    nel = NX * (C // 32) * 3 * Tp * 32
+    V = torch.zeros(NX * Tp32 * C + 128, device=dev)
+    check(getattr(lib, fam + "input_transform")(x.data_ptr(), V.data_ptr(), N, H, W, C, s), "input")
+    want, _ = _split(lib, check, V[:NX * Tp32 * C].view(NX, Tp32, C)[:, :T].contiguous(), NX, T, 256, C, s)
+    got = torch.full((nel,), float("nan"), device=dev, dtype=torch.bfloat16)
+    check(lib.cvk_w2d_input_transform_split3(tile, x.data_ptr(), got.data_ptr(), N, H, W, C, s), "input split")
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    # dy -> V' (split) + E (fp32, then split)
+    Vp = torch.zeros(NX * Tp32 * C + 128, device=dev); E = torch.zeros(NX * Tp32 * C + 128, device=dev)
+    check(getattr(lib, fam + "dy_transform_both")(x.data_ptr(), C, Vp.data_ptr(), E.data_ptr(), N, H, W, C, s), "dy both")
+    wantV, _ = _split(lib, check, Vp[:NX * Tp32 * C].view(NX, Tp32, C)[:, :T].contiguous(), NX, T, 256, C, s)
+    wantE, _ = _split(lib, check, E[:NX * Tp32 * C].view(NX, Tp32, C)[:, :T].contiguous(), NX, T, 256, C, s)
+    gV = torch.full((nel,), float("nan"), device=dev, dtype=torch.bfloat16)
+    gE = torch.full((nel,), float("nan"), device=dev, dtype=torch.bfloat16)
+    check(lib.cvk_w2d_dy_transform_both_split3(tile, x.data_ptr(), C, gV.data_ptr(), gE.data_ptr(), 1, N, H, W, C, s), "dy both split")
+    assert torch.equal(gV.view(torch.int16), wantV.view(torch.int16)) and torch.equal(gE.view(torch.int16), wantE.view(torch.int16))
+    E2 = torch.full((NX * Tp32 * C + 128,), float("nan"), device=dev)
+    check(lib.cvk_w2d_dy_transform_both_split3(tile, x.data_ptr(), C, gV.data_ptr(), E2.data_ptr(), 0, N, H, W, C, s), "dy both split, fp32 E")
+    assert torch.equal(E2[:NX * Tp32 * C], E[:NX * Tp32 * C])
+
+
+@pytest.mark.parametrize("T,Cin,Cout", [(1000, 256, 256), (640, 512, 256), (2400, 256, 128), (9600, 128, 256)])
+def test_split_weight_grad_gemm_vs_fp64_and_the_fp32_gemm(T, Cin, Cout):
+    """P[co][ci] = sum_t E[t][co] V[t][ci] on split planes (cvk_w2d_gemm_tn_split3 + cvk_w2d_wgrad_output_f) against fp64 and against the
+    product's fp32 weight-grad GEMM (cvk_w6_gemm_tn + cvk_w6_wgrad_output), through the final G^T . G pass both times."""
+    lib, check = _lib()
+    dev = torch.device("cuda:0"); s = torch.cuda.current_stream().cuda_stream
+    NX = 64
+    g = torch.Generator().manual_seed(T + Cin)
+    Tp32 = lib.cvk_w2d_tpad(T)
+    E = torch.zeros(NX, Tp32, Cout); V = torch.zeros(NX, Tp32, Cin)
+    E[:, :T] = torch.randn(NX, T, Cout, generator=g) * 0.1
+    V[:, :T] = torch.randn(NX, T, Cin, generator=g).clamp_min(-0.5)
+    Ed, Vd = E.to(dev), V.to(dev)
+    ref = torch.einsum("xto,xtc->xoc", Ed.double(), Vd.double())                  # [NX][Cout][Cin]
+    # product path
+    f32 = lib.cvk_w6_wgrad_ksplit(T, Cin, Cout)
+    P32 = torch.zeros(f32 * NX * Cout * Cin, device=dev)
+    Ep = torch.cat([Ed.reshape(-1), torch.zeros(128, device=dev)]); Vp = torch.cat([Vd.reshape(-1), torch.zeros(128, device=dev)])
+    check(lib.cvk_w6_gemm_tn(Ep.data_ptr(), Vp.data_ptr(), P32.data_ptr(), T, Cin, Cout, s), "gemm_tn")
+    e32 = ((P32.view(f32, NX, Cout, Cin).sum(0).double() - ref).norm() / ref.norm()).item()
+    # split path
+    E3, Tp = _split(lib, check, Ed[:, :T].contiguous(), NX, T, 256, Cout, s)
+    V3, _ = _split(lib, check, Vd[:, :T].contiguous(), NX, T, 256, Cin, s)
+    f = lib.cvk_w2d_gemm_tn_split3_ksplit(NX, Tp, Cin, Cout)
+    P3 = torch.full((f * NX * Cout * Cin,), float("nan"), device=dev)
+    check(lib.cvk_w2d_gemm_tn_split3(E3.data_ptr(), V3.data_ptr(), P3.data_ptr(), NX, Tp, Cin, Cout, s), "gemm_tn split")
+    assert torch.isfinite(P3).all()
+    e3 = ((P3.view(f, NX, Cout, Cin).sum(0).double() - ref).norm() / ref.norm()).item()
+    print(f"T={T} {Cin}->{Cout}: P relative L2 vs fp64: fp32 GEMM {e32:.2e} (f={f32}), split GEMM {e3:.2e} (f={f})")
+    assert e3 < 2e-6 and e3 <= 1.2 * e32 + 5e-8, (e3, e32)
+    # the final pass with an explicit f equals the product's final pass on the same planes
+    dw = torch.empty(Cout, 3, 3, Cin, device=dev); dw32 = torch.empty_like(dw)
+    check(lib.cvk_w2d_wgrad_output_f(6, P3.data_ptr(), dw.data_ptr(), Cin, Cin, Cout, f, s), "wgrad out f")
+    check(lib.cvk_w6_wgrad_output(P32.data_ptr(), dw32.data_ptr(), T, Cin, Cin, Cout, s), "wgrad out")
+    rel = ((dw - dw32).norm() / dw32.norm()).item()
+    assert rel < 1e-5, rel

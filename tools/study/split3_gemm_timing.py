@@ -53,3 +53,24 @@ for name, ci, co, h, w in LAYERS:
     print(f"{name:8s} {ci:5d}->{co:4d} @{h:3d}x{w:3d}   {t32*1e6:8.1f} us   {t3*1e6:8.1f} us     {t32/t3:5.2f}x      {tc*1e6:8.1f} us          {12.0*NX*Tp*ci*Cp/t3/1e12:8.0f}")
     del V, U, Mo, V3, U3, Vv
 print(f"sum                            {t32s*1e6:8.1f} us   {t3s*1e6:8.1f} us     {t32s/t3s:5.2f}x")
+
+print()
+print("weight-grad GEMM (k = tiles)        fp32 gemm_tn   split-3 gemm_tn   speed-up")
+t32s = t3s = 0.0
+for name, ci, co, h, w in LAYERS:
+    T = lib.cvk_w6_tiles(N, h, w)
+    Tp32 = lib.cvk_w2d_tpad(T); Tp = lib.cvk_split3_rows_pad(T, 256)
+    E = torch.randn(NX * Tp32 * co + 128, device=dev) * 0.1
+    V = torch.randn(NX * Tp32 * ci + 128, device=dev)
+    f32 = lib.cvk_w6_wgrad_ksplit(T, ci, co)
+    P = torch.empty(max(f32, 16) * NX * co * ci, device=dev)
+    t32 = timeit(lambda: check(lib.cvk_w6_gemm_tn(E.data_ptr(), V.data_ptr(), P.data_ptr(), T, ci, co, s)))
+    E3 = torch.empty(NX * (co // 32) * 3 * Tp * 32, device=dev, dtype=torch.bfloat16)
+    V3 = torch.empty(NX * (ci // 32) * 3 * Tp * 32, device=dev, dtype=torch.bfloat16)
+    check(lib.cvk_split3_planes(E[:NX * Tp32 * co].view(NX, Tp32, co)[:, :T].contiguous().data_ptr(), E3.data_ptr(), NX, T, Tp, co, s))
+    check(lib.cvk_split3_planes(V[:NX * Tp32 * ci].view(NX, Tp32, ci)[:, :T].contiguous().data_ptr(), V3.data_ptr(), NX, T, Tp, ci, s))
+    t3 = timeit(lambda: check(lib.cvk_w2d_gemm_tn_split3(E3.data_ptr(), V3.data_ptr(), P.data_ptr(), NX, Tp, ci, co, s)))
+    t32s += t32; t3s += t3
+    print(f"{name:8s} {ci:5d}->{co:4d} @{h:3d}x{w:3d}   {t32*1e6:8.1f} us   {t3*1e6:8.1f} us     {t32/t3:5.2f}x")
+    del E, V, P, E3, V3
+print(f"sum                            {t32s*1e6:8.1f} us   {t3s*1e6:8.1f} us     {t32s/t3s:5.2f}x")
