@@ -66,6 +66,9 @@ def parse():
                          "world-size-1 RCCL group (real all-reduce launches, CVK_DP_RESERVE_CUS CUs left free), eager and as one captured "
                          "graph; reported under `dp_overhead`, never `value`")
     ap.add_argument("--no-dp-overhead", action="store_true", help="skip the `dp_overhead` leg")
+    ap.add_argument("--w2d-split", action="store_true",
+                    help="OPT-IN study path (never the default, named in `dtype`): the 2-D Winograd GEMMs of the channel-heavy layers on the bf16 matrix "
+                         "pipe with 3-term split fp32 operands (csrc/split3.hip, DESIGN.md 5b round 5)")
     ap.add_argument("--with-input-pipeline", action="store_true",
                     help="also time the steps fed from HOST uint8 frames through DevicePrefetcher (pinned staging, 1-byte upload one "
                          "batch ahead, device-side normalisation): the PCIe-inclusive rate, reported separately, never `value`")
@@ -215,12 +218,15 @@ def logits_accuracy(net, x):
             "tolerance_max_abs": tol, "source": "measured in this run against tests/golden/unet_s0_8x360x480_dense.npz (reference-generated)"}
 
 
-def run_leg(A, dev, model, batch, h, w, precision, steps, warmup, profile, world=1, rank=0, rehearsal=False, want_model=False):
+def run_leg(A, dev, model, batch, h, w, precision, steps, warmup, profile, world=1, rank=0, rehearsal=False, want_model=False, split3=False):
     """Build the network, time `steps` steps after `warmup`, optionally profile the kernels.  Returns a dict."""
     from pytorch_camvid_amd import ddp
     torch.manual_seed(0)                                    # identical init on every rank (also broadcast by DataParallel)
     net = A.get_model(model, 3, 12).to(dev).train()
     A.set_conv_precision(net, precision)
+    if split3:
+        from pytorch_camvid_amd.modules import runner_of as _ro
+        _ro(net).w2d_split = True
     wrapped = ddp.DataParallel(net) if world > 1 else net
     lossf = A.CrossEntropyLoss()
     g = torch.Generator().manual_seed(1234 + rank)          # per-rank shard of the global batch
@@ -414,9 +420,9 @@ def main():
         else:
             _ddp.init_process_group("nccl", device_id=dev)     # RCCL
 
-    headline = (a.model, a.batch, a.height, a.width, a.precision) == ("unet", PER_GPU_BATCH, H, W, "fp32")
+    headline = (a.model, a.batch, a.height, a.width, a.precision) == ("unet", PER_GPU_BATCH, H, W, "fp32") and not a.w2d_split
     leg = run_leg(A, dev, a.model, a.batch, a.height, a.width, a.precision, a.steps, a.warmup, not a.no_kernel_profile,
-                  world=world, rank=rank, rehearsal=rehearsal, want_model=True)
+                  world=world, rank=rank, rehearsal=rehearsal, want_model=True, split3=a.w2d_split)
     step, params, net, wrapped, lossf = leg["step"], leg["params"], leg["net"], leg["wrapped"], leg["lossf"]
 
     # The optional extra loops run on EVERY rank: at N>1 each backward issues the bucketed all-reduces, which all ranks must post.
@@ -514,10 +520,14 @@ def main():
     if world == 1 and headline and not a.no_extra_configs:
         extra = []
         es, ew = max(3, min(a.steps, 10)), max(2, min(a.warmup, 3))
-        for (m, b, hh, ww, prec) in (("unet", 4, 720, 960, "bf16"), ("segnet", 8, 360, 480, "fp32")):
-            e = run_leg(A, dev, m, b, hh, ww, prec, es, ew, True)
+        SPLIT_DTYPE = ("f32 tensors; the 2-D Winograd GEMMs of the 13 channel-heavy layers as 3-term bf16 split operands, six exact cross-products "
+                       "per fp32 product on v_mfma_f32_16x16x32_bf16 with f32 accumulation (OPT-IN study path runner.w2d_split, never the default)")
+        for (m, b, hh, ww, prec, sp3) in (("unet", 4, 720, 960, "bf16", False), ("segnet", 8, 360, 480, "fp32", False),
+                                          ("unet", 8, 360, 480, "fp32", True)):
+            e = run_leg(A, dev, m, b, hh, ww, prec, es, ew, True, split3=sp3)
             r = e["roof"]
-            extra.append({"workload": config_label(m, b, hh, ww, prec, 1), "dtype": "bf16" if prec == "bf16" else "f32",
+            extra.append({"workload": config_label(m, b, hh, ww, prec, 1) + (" — OPT-IN split-operand GEMMs (study)" if sp3 else ""),
+                          "dtype": SPLIT_DTYPE if sp3 else ("bf16" if prec == "bf16" else "f32"),
                           "images_per_s": round(e["value"], 3), "ms_per_step": round(e["ms"], 3), "steps": es, "warmup": ew,
                           "loss": round(e["loss"], 6), "dominant_kernel": r["kernel"], "executed_frac_of_peak": r["frac"],
                           "peak_tflops": r["peak"], "dominant_kernel_ms_per_step": round(r["avg_launch_us"] * r["launches_per_step"] / 1e3, 3),
@@ -531,7 +541,9 @@ def main():
                       else f"images/sec fwd+bwd {a.model} 3x{a.height}x{a.width} bs={a.batch} ({a.precision})",
             "value": round(leg["value"], 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(leg["ms"], 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": "bf16 (bf16 activations/gradients in HBM, bf16 MFMA with f32 accumulate, f32 statistics/parameters)"}[a.precision],
+            "dtype": ("f32 tensors, 2-D Winograd GEMMs as 3-term bf16 split operands on bf16 MFMA with f32 accumulation (OPT-IN study path --w2d-split)"
+                      if a.w2d_split else
+                      {"fp32": "f32", "bf16": "bf16 (bf16 activations/gradients in HBM, bf16 MFMA with f32 accumulate, f32 statistics/parameters)"}[a.precision]),
             "data": "synthetic" + (" (REHEARSAL: ranks share a GPU over gloo — not a measurement)" if rehearsal else ""),
             "config": {"workload": config_label(a.model, a.batch, a.height, a.width, a.precision, world),
                        "global_batch": world * a.batch, "parallelism": f"dp{world}", "timed_region": "zero_grad+forward+CE+backward"

@@ -220,6 +220,20 @@ __device__ __forceinline__ void split_store(const SplitDst& d, int xi, VT v) {
     }
 }
 
+// one value: row r, channel c of transform index xi of split planes with Rpad rows and C channels
+__device__ __forceinline__ void split_store1(void* S, int C, int Rpad, int xi, int r, int c, float v) {
+    const int ncs = C >> 5, cs = c >> 5, cl = c & 31;
+    const int pos = (cl >> 3) ^ (((r >> 2) & 1) << 1);
+    unsigned short* p = reinterpret_cast<unsigned short*>(S) + ((((size_t)xi * ncs + cs) * 3) * Rpad + r) * 32 + pos * 8 + (cl & 7);
+    const size_t term = (size_t)Rpad * 32;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const unsigned short b = w2_bf16_rne(v);
+        v -= __builtin_bit_cast(float, (unsigned)b << 16);
+        p[k * term] = b;
+    }
+}
+
 template <int MT, bool SPL = false>
 __global__ __launch_bounds__(256) void k_w2d_input(const float* __restrict__ X, float* __restrict__ V, int H, int W, int C,
                                                   int th, int tw, int T, int Tpad) {
@@ -230,7 +244,20 @@ __global__ __launch_bounds__(256) void k_w2d_input(const float* __restrict__ X, 
     // workgroups are dealt to the XCDs in contiguous chunks of tiles: vertically neighbouring tiles share two input rows, and a
     // tile row is tw tiles — many workgroups — away
     const long idx = (long)cvk_xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    const int t = (int)(idx / cvn), c = (int)(idx % cvn) * VW;
+    int t, c;
+    if (SPL) {
+        // split planes are [slice of 32 channels][row t][32]: a thread group of 32 / VW lanes covers one row of ONE slice and consecutive
+        // groups take consecutive rows, so that a wave's stores of one (xi, term) are one contiguous run (4 or 8 rows x 64 B) — with the
+        // fp32 mapping (all channels of a tile side by side) they were 64-byte pieces Tpad rows apart and the pass ran at half its rate
+        constexpr int LPR = 32 / VW;                              // lanes per row of a slice
+        const long rowid = idx / LPR;
+        const int cs = (int)(rowid / Tpad);
+        t = (int)(rowid % Tpad);
+        c = cs * 32 + (int)(idx % LPR) * VW;
+        if (cs >= C / 32) return;
+    } else {
+        t = (int)(idx / cvn); c = (int)(idx % cvn) * VW;
+    }
     if (t >= Tpad) return;
     const VT zero = {};
     SplitDst sd = {};
@@ -275,7 +302,7 @@ __global__ __launch_bounds__(256) void k_w2d_input(const float* __restrict__ X, 
 }
 
 // ---- weight transform: w [Co][3][3][Ci] -> U [NX][Co][Ci]; one thread = one (co, ci) --------------------------------------------
-template <int MT>
+template <int MT, bool SPL = false>      // SPL: U as split planes [xi][Ci/32][term][Co padded to 128][32] (rows beyond Co are zeroed by the caller)
 __device__ __forceinline__ void w2d_weight_body(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci, unsigned vblock, unsigned nblocks) {
     typedef W2T<MT> TR;
     constexpr int NT = TR::NT;
@@ -299,19 +326,22 @@ __device__ __forceinline__ void w2d_weight_body(const float* __restrict__ Wt, fl
             float u[NT];
             TR::g(a[p], u);
 #pragma unroll
-            for (int q = 0; q < NT; ++q) U[(size_t)(p * NT + q) * total + i] = u[q];
+            for (int q = 0; q < NT; ++q) {
+                if (SPL) split_store1(U, Ci, (Co + 127) / 128 * 128, p * NT + q, (int)co, ci, u[q]);
+                else U[(size_t)(p * NT + q) * total + i] = u[q];
+            }
         }
     }
 }
-template <int MT>
+template <int MT, bool SPL = false>
 __global__ __launch_bounds__(256) void k_w2d_weight(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci) {
-    w2d_weight_body<MT>(Wt, U, Co, Ci, blockIdx.x, gridDim.x);
+    w2d_weight_body<MT, SPL>(Wt, U, Co, Ci, blockIdx.x, gridDim.x);
 }
 
 // ---- data-grad filter straight from the forward weights: U [NX][Ci][Co] = G w'[ci][.][.][co] G^T with w'[ci][r][s][co] =
 // w[co][2-r][2-s][ci] (rotated by 180 degrees, channels exchanged) — no packed copy in between.  A workgroup transposes a
 // 32 (co) x 32 (ci) tile of all nine taps through LDS: reads run along ci, writes along co.
-template <int MT>
+template <int MT, bool SPL = false>      // SPL: split planes [xi][Co/32][term][Ci padded to 128][32]
 __device__ __forceinline__ void w2d_weight_dgrad_body(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci, int bx, int by, float (*t)[32][33]) {
     typedef W2T<MT> TR;
     constexpr int NT = TR::NT;
@@ -348,14 +378,17 @@ __device__ __forceinline__ void w2d_weight_dgrad_body(const float* __restrict__ 
             float u[NT];
             TR::g(a[q], u);
 #pragma unroll
-            for (int r = 0; r < NT; ++r) U[(size_t)(q * NT + r) * total + o] = u[r];
+            for (int r = 0; r < NT; ++r) {
+                if (SPL) split_store1(U, Co, (Ci + 127) / 128 * 128, q * NT + r, ci0 + ci, co0 + co, u[r]);
+                else U[(size_t)(q * NT + r) * total + o] = u[r];
+            }
         }
     }
 }
-template <int MT>
+template <int MT, bool SPL = false>
 __global__ __launch_bounds__(256) void k_w2d_weight_dgrad(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci) {
     __shared__ float t[9][32][33];
-    w2d_weight_dgrad_body<MT>(Wt, U, Co, Ci, blockIdx.x, blockIdx.y, t);
+    w2d_weight_dgrad_body<MT, SPL>(Wt, U, Co, Ci, blockIdx.x, blockIdx.y, t);
 }
 
 // All 2-D Winograd filter transforms of a step (forward and data-grad filters, both tile sizes) in ONE launch: job j owns the blocks
@@ -558,7 +591,17 @@ __global__ __launch_bounds__(256) void k_w2d_dy_both(const float* __restrict__ D
     constexpr int NT = TR::NT, NX = TR::NX, VW = TR::VW;
     const int cvn = C / VW;
     const long idx = (long)cvk_xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    const int t = (int)(idx / cvn), c = (int)(idx % cvn) * VW;
+    int t, c;
+    if (SPL) {          // slice-major thread order (see k_w2d_input)
+        constexpr int LPR = 32 / VW;
+        const long rowid = idx / LPR;
+        const int cs = (int)(rowid / Tpad);
+        t = (int)(rowid % Tpad);
+        c = cs * 32 + (int)(idx % LPR) * VW;
+        if (cs >= C / 32) return;
+    } else {
+        t = (int)(idx / cvn); c = (int)(idx % cvn) * VW;
+    }
     if (t >= Tpad) return;
     const VT zero = {};
     const size_t plane = (size_t)Tpad * C, planeE = (size_t)TpadE * C;
@@ -1102,16 +1145,30 @@ extern "C" int cvk_w2d_dy_transform_both_split3(int tile, const float* dy, int l
     CVK_LAUNCH_RETURN("cvk_w2d_dy_transform_both_split3");
 }
 
-// filter -> U as split planes: the fp32 transform into `tmp` (NX * rows * cols floats), then the conversion pass; dgrad: the rotated /
-// channel-exchanged filter of the data-grad (rows = Cin, depth = Cout of the forward layer)
+// filter -> U as split planes, written by the transform kernels' own store loops (`tmp` is unused since the fused version; kept in the
+// signature); dgrad: the rotated / channel-exchanged filter of the data-grad (rows = Cin, depth = Cout of the forward layer)
 extern "C" int cvk_w2d_weight_transform_split3(int tile, const float* w, void* U3, float* tmp, int Cout, int Cin, int dgrad, void* stream) {
-    CVK_CHECK_ARG((tile == 4 || tile == 6) && w && U3 && tmp && Cout > 0 && Cin > 0, "cvk_w2d_weight_transform_split3: bad arguments");
+    (void)tmp;
+    CVK_CHECK_ARG((tile == 4 || tile == 6) && w && U3 && Cout > 0 && Cin > 0, "cvk_w2d_weight_transform_split3: bad arguments");
     const int rows = dgrad ? Cin : Cout, cols = dgrad ? Cout : Cin;
     CVK_CHECK_ARG(cols % 32 == 0, "cvk_w2d_weight_transform_split3: the GEMM depth (%d) must be a multiple of 32", cols);
-    const int rc = dgrad ? w2i_weight_transform_dgrad(tile, "cvk_w2d_weight_transform_split3", w, tmp, Cout, Cin, stream)
-                         : w2i_weight_transform(tile, "cvk_w2d_weight_transform_split3", w, tmp, Cout, Cin, stream);
-    if (rc != CVK_OK) return rc;
-    return cvk_split3_planes(tmp, U3, w2_nx(tile), rows, cvk_split3_rows_pad(rows, 128), cols, stream);
+    hipStream_t s = (hipStream_t)stream;
+    const int Rp = cvk_split3_rows_pad(rows, 128);
+    if (Rp != rows) {       // padding rows are never written by the transform: zero planes first
+        const hipError_t e = hipMemsetAsync(U3, 0, (size_t)w2_nx(tile) * (cols / 32) * 3 * Rp * 64, s);
+        if (e != hipSuccess) { cvk_set_error("cvk_w2d_weight_transform_split3: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    if (dgrad) {
+        const dim3 grid(cvk_cdiv(Cin, 32), cvk_cdiv(Cout, 32));
+        if (tile == 4) hipLaunchKernelGGL((k_w2d_weight_dgrad<4, true>), grid, dim3(256), 0, s, w, (float*)U3, Cout, Cin);
+        else hipLaunchKernelGGL((k_w2d_weight_dgrad<6, true>), grid, dim3(256), 0, s, w, (float*)U3, Cout, Cin);
+    } else {
+        const size_t total = (size_t)Cout * Cin;
+        const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+        if (tile == 4) hipLaunchKernelGGL((k_w2d_weight<4, true>), dim3(blocks), dim3(256), 0, s, w, (float*)U3, Cout, Cin);
+        else hipLaunchKernelGGL((k_w2d_weight<6, true>), dim3(blocks), dim3(256), 0, s, w, (float*)U3, Cout, Cin);
+    }
+    CVK_LAUNCH_RETURN("cvk_w2d_weight_transform_split3");
 }
 
 // the output pass for product planes WITHOUT K-range partials (Mo [NX][T][Cout], one plane per transform index)

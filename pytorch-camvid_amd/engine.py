@@ -209,7 +209,7 @@ def wgradp_pays(N, H, W, cin_ld, cout):
 
 
 def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what="", dgrad_of=None, keep_v=None, wsrc=None, ck=None,
-              bnred=None, v_pre=None):
+              bnred=None, v_pre=None, split=False):
     """y[N,H,W,ldy] = conv3x3(x[N,H,W,k_ch], w[cout][3][3][k_ch]) (+bias, +BN statistics partials at sp) through the
     Winograd kernels: weight transform -> (input transform ->) GEMMs M_xi -> output transform.  2-D F(4x4,3x3) for the
     channel-heavy layers (R.wino2d, wino2d_pays), else 1-D F(4,3) when R.wino4, else F(2,3).
@@ -233,6 +233,43 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
     if wino2d_ok(k_ch, cout, ldy) and (R.wino2d == "always" or (R.wino2d and wino2d_pays(N, H, W, k_ch, cout, R.w2tile))):
         tile = layer_tile(R, N, H, W, dgrad=dgrad_of is not None)
         NX = 64 if tile == 6 else 36
+        if split:
+            # OPT-IN study path (runner.w2d_split): the GEMM stage on the bf16 matrix pipe with 3-term split fp32
+            # operands — the transforms write split planes, cvk_w2d_gemm_split3 multiplies them, the plain output pass finishes
+            T = w2fn(lib, tile, "tiles")(N, H, W)
+            Tp = lib.cvk_split3_rows_pad(T, 256)
+            Cp = lib.cvk_split3_rows_pad(cout, 128)
+            def build_u3():
+                tmp = u3 = torch.empty(NX * (k_ch // 32) * 3 * Cp * 32, device=x.device, dtype=_BF16)
+                if dgrad_of is not None:
+                    _timed(R, "k_w2d_weight_dgrad+split3", 4.0 * 9 * cout * k_ch + 6.0 * NX * cout * k_ch, lambda: check(
+                        lib.cvk_w2d_weight_transform_split3(tile, dgrad_of[0].data_ptr(), u3.data_ptr(), tmp.data_ptr(), dgrad_of[1], dgrad_of[2], 1, s),
+                        "cvk_w2d_weight_transform_split3(dgrad)"), "byte")
+                else:
+                    wt = w() if callable(w) else w
+                    _timed(R, "k_w2d_weight+split3", 4.0 * 9 * cout * k_ch + 6.0 * NX * cout * k_ch, lambda: check(
+                        lib.cvk_w2d_weight_transform_split3(tile, wt.data_ptr(), u3.data_ptr(), tmp.data_ptr(), cout, k_ch, 0, s),
+                        "cvk_w2d_weight_transform_split3"), "byte")
+                return u3
+            U3 = cached("w2ds%d" % tile, build_u3)
+            v3fl = NX * (k_ch // 32) * 3 * Tp * 32
+            if v_pre is not None:
+                V3 = v_pre[1]
+            else:
+                V3 = torch.empty(v3fl, device=x.device, dtype=_BF16)
+                if keep_v is not None:
+                    keep_v.append(V3)
+                _timed(R, "k_w2d_input<split3>", (4.0 * M + 6.0 * NX * T) * k_ch, lambda: check(
+                    lib.cvk_w2d_input_transform_split3(tile, x.data_ptr(), V3.data_ptr(), N, H, W, k_ch, s), "cvk_w2d_input_transform_split3" + what), "byte")
+            ws = R.workspace(4 * NX * T * cout + 1024, x.device)
+            _timed(R, "k_gemm_split3", flops, lambda: check(
+                lib.cvk_w2d_gemm_split3(V3.data_ptr(), U3.data_ptr(), ws.data_ptr(), NX, T, Tp, k_ch, cout, Cp, s), "cvk_w2d_gemm_split3" + what),
+                executed=12.0 * NX * Tp * k_ch * Cp)     # six bf16 MFMA products per fp32 product
+            P2 = w2fn(lib, tile, "stat_partials")(N, H, W)
+            cnt = sp + 4 * 2 * P2 * cout if sp is not None else None
+            _timed(R, "k_w2d_output", 4.0 * (NX * T + M) * cout, lambda: check(
+                lib.cvk_w2d_output_plain(tile, ws.data_ptr(), bias, y.data_ptr(), sp, cnt, N, H, W, cout, ldy, s), "cvk_w2d_output_plain" + what), "byte")
+            return (P2, cnt) if sp is not None else None
         def build_u2():
             u = _empty(NX * cout * k_ch, x.device)
             if dgrad_of is not None and dgrad_of[1] == k_ch and dgrad_of[2] == cout:       # no channel padding: straight from the forward weights
@@ -474,6 +511,24 @@ class ConvBnRelu(Op):
         return (wino_ok(R, src.ld, pad4(C)) and wino2d_ok(src.ld, C, pad4(C)) and wino2d_pays(src.N, src.H, src.W, src.ld, C, R.w2tile)
                 and src.ld * C >= 32768)
 
+    def _split3(self, R):
+        """Does this layer run the OPT-IN split-operand GEMMs (runner.w2d_split; csrc/split3.hip)?  Only layers whose forward, data-grad
+        and weight-grad ALL take the 2-D path with one tile size and whose channel counts the split weight-grad GEMM serves — the three
+        GEMMs of such a layer share their split planes (V from the forward transform, V' and E from one pass over dy)."""
+        if not getattr(R, "w2d_split", False) or not self.src_needs_grad:
+            return False
+        src, C = self.src, self.cout
+        N, H, W, ldy = src.N, src.H, src.W, pad4(self.cout)
+        if not (self._wgrad2d(R) and R.w2both and ldy == C and src.ld == self.cin and src.ld % 32 == 0 and C % 32 == 0):
+            return False
+        if not (wino_ok(R, src.ld, ldy) and wino2d_ok(src.ld, C, ldy) and (R.wino2d == "always" or wino2d_pays(N, H, W, src.ld, C, R.w2tile))):
+            return False
+        if not (wino_ok(R, ldy, src.ld) and wino2d_ok(ldy, src.ld, src.ld) and (R.wino2d == "always" or wino2d_pays(N, H, W, ldy, src.ld, R.w2tile))):
+            return False
+        if layer_tile(R, N, H, W) != layer_tile(R, N, H, W, dgrad=True):
+            return False
+        return (C % 256 == 0 and src.ld % 128 == 0) or (src.ld % 256 == 0 and C % 128 == 0)
+
     def _conv(self, R, st, X, wk, b, y, stats, kind, keep_v=None):
         """y = conv3x3(X, wk) + b (+ BN statistics partials): Winograd kernels when eligible, else direct."""
         lib, s, src = R.lib, st.stream, self.src
@@ -491,7 +546,7 @@ class ConvBnRelu(Op):
             return (Pt, cnt) if sp is not None else None
         if wino_ok(R, src.ld, ldy):
             return wino_conv(R, lib, s, X, wk, b.data_ptr(), y, sp, N, H, W, src.ld, C, ldy, 18.0 * M * C * self.cin, keep_v=keep_v,
-                             wsrc=st.params[4 * self.pslot], ck=(self.pslot, "f"))
+                             wsrc=st.params[4 * self.pslot], ck=(self.pslot, "f"), split=st.need_grad and st.training and self._split3(R))
         else:
             _timed(R, conv_kernel_name("fwd", ldy, src.ld), 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy, s),
@@ -626,7 +681,21 @@ class ConvBnRelu(Op):
         # weight-grad AND data-grad on the 2-D path with the same tile: dy is transformed for both in ONE launch (csrc/wino2d.hip
         # k_w2d_dy_both): E for the weight-grad, V' for the data-grad; dy crosses the fabric once
         both2 = None
-        if (wgrad2d and self.src_needs_grad and R.w2both and ldy == C and wino_ok(R, ldy, src.ld) and wino2d_ok(ldy, src.ld, src.ld)
+        split3 = wgrad2d and st.training and self._split3(R) and Vkept is not None and Vkept.dtype == _BF16
+        if split3:
+            tile = layer_tile(R, N, H, W)
+            NX = 64 if tile == 6 else 36
+            T = w2fn(lib, tile, "tiles")(N, H, W)
+            Tp = lib.cvk_split3_rows_pad(T, 256)
+            Eb = torch.empty(NX * (C // 32) * 3 * Tp * 32, device=dev, dtype=_BF16)
+            Vb = torch.empty(NX * (C // 32) * 3 * Tp * 32, device=dev, dtype=_BF16)
+            _timed(R, "k_w2d_dy<both,split3>", (4.0 * M + 12.0 * NX * T) * C, lambda: check(
+                lib.cvk_w2d_dy_transform_both_split3(tile, dy.data_ptr(), ldy, Vb.data_ptr(), Eb.data_ptr(), 1, N, H, W, C, s),
+                "cvk_w2d_dy_transform_both_split3"), "byte")
+            both2 = (tile, Eb, Vb)
+        elif Vkept is not None and Vkept.dtype == _BF16:
+            Vkept = None            # the forward pass ran the split path but this backward pass does not (a knob changed in between)
+        if (not split3 and wgrad2d and self.src_needs_grad and R.w2both and ldy == C and wino_ok(R, ldy, src.ld) and wino2d_ok(ldy, src.ld, src.ld)
                 and (R.wino2d == "always" or (R.wino2d and wino2d_pays(N, H, W, ldy, src.ld, R.w2tile)))
                 and layer_tile(R, N, H, W) == layer_tile(R, N, H, W, dgrad=True)):
             tile = layer_tile(R, N, H, W)
@@ -659,7 +728,7 @@ class ConvBnRelu(Op):
                              pbnp.data_ptr() + 4 * src.ld, [])
                 wino_conv(R, lib, s, dy, packed, None, dX, None, N, H, W, ldy, src.ld, src.ld, 18.0 * M * C * self.cin, "(dgrad)",
                           dgrad_of=(wc, C, self.cin), wsrc=w, ck=(self.pslot, "d"), bnred=bnred,
-                          v_pre=(both2[0], both2[2]) if both2 is not None else None)
+                          v_pre=(both2[0], both2[2]) if both2 is not None else None, split=split3)
                 if bnred is not None and bnred[5]:
                     st.bnred[prod.idx] = bnred[5][0]
             elif R.thin and lib.cvk_thin_fwd_supported(ldy, src.ld, src.ld) and H * W * max(src.ld, ldy) * 4 < 2 ** 31:      # the head's data-grad: 12 -> 64 (csrc/thin.hip)
@@ -673,7 +742,20 @@ class ConvBnRelu(Op):
                     lib.cvk_conv3x3_fwd(dy.data_ptr(), wd.data_ptr(), None, dX.data_ptr(), None, N, H, W, ldy, src.ld, src.ld, s),
                     "cvk_conv3x3_fwd(dgrad)"))
             st.grad[src.id] = dX
-        if wgrad2d:
+        if wgrad2d and split3:
+            tile, Eb3 = both2[0], both2[1]
+            NX = 64 if tile == 6 else 36
+            T = w2fn(lib, tile, "tiles")(N, H, W)
+            Tp = lib.cvk_split3_rows_pad(T, 256)
+            f = lib.cvk_w2d_gemm_tn_split3_ksplit(NX, Tp, src.ld, C)
+            ws = R.workspace(4 * f * NX * C * src.ld, dev)
+            _timed(R, "k_gemm_tn_split3", 18.0 * M * C * self.cin, lambda: check(
+                lib.cvk_w2d_gemm_tn_split3(Eb3.data_ptr(), Vkept.data_ptr(), ws.data_ptr(), NX, Tp, src.ld, C, s), "cvk_w2d_gemm_tn_split3"),
+                executed=12.0 * NX * Tp * src.ld * C)
+            _timed(R, "k_w2d_wgrad_out", 4.0 * (NX * f + 9) * C * self.cin, lambda: check(
+                lib.cvk_w2d_wgrad_output_f(tile, ws.data_ptr(), gw, self.cin, src.ld, C, f, s), "cvk_w2d_wgrad_output_f"), "byte")
+            del Vkept
+        elif wgrad2d:
             tile = layer_tile(R, N, H, W)
             NX = 64 if tile == 6 else 36
             T = w2fn(lib, tile, "tiles")(N, H, W)
@@ -1163,6 +1245,9 @@ class Runner:
         self.w2both = os.environ.get("CVK_W2D_DY_BOTH", "1") != "0"   # one launch transforms dy for the data-grad and the weight-grad
         self.bnred_fuse = os.environ.get("CVK_BNRED_FUSE", "1") != "0"   # BN-backward sums in the fused data-grad's epilogue
         self.wino2d = WINO2D_DEFAULT
+        # OPT-IN study path: the 2-D Winograd GEMMs of the layers ConvBnRelu._split3 admits on the bf16 matrix pipe with
+        # 3-term split fp32 operands (csrc/split3.hip).  Not the product default; bench.py names it in `dtype` when it is on.
+        self.w2d_split = os.environ.get("CVK_W2D_SPLIT", "0") == "1"
         self.w2tile_cfg = W2TILE_DEFAULT    # None = auto (see W2TILE_DEFAULT), 4 or 6 = forced
         self.w2tile = 6                     # the tile of the plan being executed (set by forward / backward)
         self.w2tile_dgrad = 6               # ... of its data-grad launches
@@ -1220,7 +1305,7 @@ class Runner:
         every cached tensor it builds straight from a parameter, and this pass replays the record."""
         if not self.wcache or torch.cuda.is_current_stream_capturing():
             return
-        cfg = (id(plan), self.w2tile, self.w2tile_dgrad, self.wino, self.wino4, self.wino4f, self.wino2d, self.wgradp, self.thin)
+        cfg = (id(plan), self.w2tile, self.w2tile_dgrad, self.wino, self.wino4, self.wino4f, self.wino2d, self.wgradp, self.thin, self.w2d_split)
         if cfg != self._wjobs_cfg:          # another plan or other kernel knobs: the record starts over with this pass
             self._wjobs, self._wjobs_cfg = {}, cfg
             return

@@ -185,3 +185,76 @@ def test_split_weight_grad_gemm_vs_fp64_and_the_fp32_gemm(T, Cin, Cout):
     check(lib.cvk_w6_wgrad_output(P32.data_ptr(), dw32.data_ptr(), T, Cin, Cin, Cout, s), "wgrad out")
     rel = ((dw - dw32).norm() / dw32.norm()).item()
     assert rel < 1e-5, rel
+
+
+def test_unet_headline_step_with_the_split_gemms_in_the_network():
+    """The OPT-IN mode (runner.w2d_split): the headline workload (UNet 8 x 3x360x480, bench.py's seeds) with the forward, data-grad and
+    weight-grad GEMMs of the 13 channel-heavy layers on the bf16 matrix pipe (3-term split operands), against the REFERENCE-generated
+    fixtures of the fp32 network: loss, dense logits (the same sentinels as the default F(6x6) path + 15 %), gradient norms.  This is the
+    network-level parity evidence for the study path; the product default stays exact-fp32 MFMA."""
+    import json
+    import os
+    import numpy as np
+    import pytorch_camvid_amd as A
+    from pytorch_camvid_amd.modules import runner_of
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    d = dict(np.load(os.path.join(G, "unet_s0_8x360x480.npz")))
+    meta = json.loads(str(d["meta"]))
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(meta["data_seed"])
+    x = torch.randn(8, 3, 360, 480, generator=g).to(dev); t = torch.randint(0, 12, (8, 360, 480), generator=g).to(dev)
+
+    def run(split):
+        torch.manual_seed(meta["seed"])
+        net = A.UNet(3, 12).to(dev).train()
+        runner_of(net).w2d_split = split
+        out = net(x)
+        loss = A.CrossEntropyLoss()(out, t)
+        loss.backward()
+        return net, out.detach(), float(loss)
+    net, out, loss = run(True)
+    assert abs(loss - float(d["loss"])) < 2e-5, (loss, float(d["loss"]))
+    dd = np.load(os.path.join(G, "unet_s0_8x360x480_dense.npz"))
+    ref = dd["logits_dense"]
+    got = out[:, :, ::8, ::8].cpu().numpy()
+    dv = np.abs(got - ref)
+    mx, frac, rel = float(dv.max()), float((dv > 3e-4).mean()), float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    rel_g = []
+    for i, (k, p) in enumerate(net.named_parameters()):
+        if k.endswith("conv.0.bias"):
+            continue
+        rel_g.append(abs(float(p.grad.double().norm()) - d["grad_l2"][i]) / d["grad_l2"][i])
+    rel_g = np.array(rel_g)
+    print(f"split mode, headline workload: loss {loss:.7f} (reference {float(d['loss']):.7f}); dense logits max |dev| {mx:.3e}, share beyond 3e-4 "
+          f"{frac:.2e}, relative L2 {rel:.3e}; gradient norms: worst {rel_g.max():.2e}, median {np.median(rel_g):.2e}")
+    tol = json.load(open(os.path.join(G, "drift.json")))["logits_tolerance"]["unet_s0_8x360x480"]["slice_abs"]
+    assert mx <= tol and frac <= 5e-3 and rel <= 1.5e-4, (mx, frac, rel)          # the frozen bound of the fp32 path holds for the split path
+    assert rel_g.max() < 0.05 and np.median(rel_g) < 2e-3, (rel_g.max(), np.median(rel_g))
+    # and the mode really ran the split kernels: it differs from the default path, by rounding only
+    _, out32, loss32 = run(False)
+    dmode = float((out - out32).abs().max())
+    assert 0.0 < dmode < 2 * tol, dmode          # two paths, each within the bound of the reference
+
+
+@pytest.mark.parametrize("tile,dgrad", [(6, 0), (6, 1), (4, 0), (4, 1)])
+def test_weight_transform_writes_the_split_planes_of_its_fp32_planes(tile, dgrad):
+    lib, check = _lib()
+    dev = torch.device("cuda:0"); s = torch.cuda.current_stream().cuda_stream
+    Cout, Cin = 128, 64
+    NX = 64 if tile == 6 else 36
+    fam = "cvk_w6_" if tile == 6 else "cvk_w2d_"
+    g = torch.Generator().manual_seed(11 + tile + dgrad)
+    w = torch.randn(Cout, 3, 3, Cin, generator=g).to(dev)
+    rows, cols = (Cin, Cout) if dgrad else (Cout, Cin)
+    U = torch.empty(NX * rows * cols, device=dev)
+    check(getattr(lib, fam + ("weight_transform_dgrad" if dgrad else "weight_transform"))(w.data_ptr(), U.data_ptr(), Cout, Cin, s), "weight")
+    want, Rp = _split(lib, check, U.view(NX, rows, cols), NX, rows, 128, cols, s)
+    got = torch.full((NX * (cols // 32) * 3 * Rp * 32,), float("nan"), device=dev, dtype=torch.bfloat16)
+    check(lib.cvk_w2d_weight_transform_split3(tile, w.data_ptr(), got.data_ptr(), None, Cout, Cin, dgrad, s), "weight split")
+    # the fused kernel is another instantiation of the transform (hipcc may contract its multiply-adds differently): the three terms must
+    # add up to the fp32 planes to a few ulps, not bit for bit
+    def total(t):
+        return t.view(NX, cols // 32, 3, Rp, 32).double().sum(dim=2)
+    a, b = total(got), total(want)
+    assert torch.isfinite(a).all()
+    assert ((a - b).abs().max() / b.abs().max()).item() < 2.0 ** -20
