@@ -137,7 +137,7 @@ def executed_share(name):
 
 
 def peak_of(name):
-    return PEAK_BF16_MFMA_TFLOPS if ("bf16" in name or "thinb" in name) else PEAK_F32_MFMA_TFLOPS
+    return PEAK_BF16_MFMA_TFLOPS if ("bf16" in name or "thinb" in name or "split3" in name) else PEAK_F32_MFMA_TFLOPS
 
 
 def kernel_profile(step, dev, nprof=3):
@@ -224,9 +224,8 @@ def run_leg(A, dev, model, batch, h, w, precision, steps, warmup, profile, world
     torch.manual_seed(0)                                    # identical init on every rank (also broadcast by DataParallel)
     net = A.get_model(model, 3, 12).to(dev).train()
     A.set_conv_precision(net, precision)
-    if split3:
-        from pytorch_camvid_amd.modules import runner_of as _ro
-        _ro(net).w2d_split = True
+    from pytorch_camvid_amd.modules import runner_of as _ro
+    _ro(net).w2d_split = bool(split3)                       # the leg's label decides, not the environment
     wrapped = ddp.DataParallel(net) if world > 1 else net
     lossf = A.CrossEntropyLoss()
     g = torch.Generator().manual_seed(1234 + rank)          # per-rank shard of the global batch
