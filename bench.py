@@ -66,9 +66,10 @@ def parse():
                          "world-size-1 RCCL group (real all-reduce launches, CVK_DP_RESERVE_CUS CUs left free), eager and as one captured "
                          "graph; reported under `dp_overhead`, never `value`")
     ap.add_argument("--no-dp-overhead", action="store_true", help="skip the `dp_overhead` leg")
-    ap.add_argument("--w2d-split", action="store_true",
-                    help="OPT-IN study path (never the default, named in `dtype`): the 2-D Winograd GEMMs of the channel-heavy layers on the bf16 matrix "
-                         "pipe with 3-term split fp32 operands (csrc/split3.hip, DESIGN.md 5b round 5)")
+    ap.add_argument("--w2d-split", type=int, nargs="?", const=3, default=0, choices=[0, 2, 3],
+                    help="OPT-IN path (never the default, named in `dtype`): the 2-D Winograd GEMMs of the channel-heavy layers on the 16-bit matrix "
+                         "pipe with split fp32 operands — 3 (default of the flag): three bf16 terms, six cross-products; 2: two fp16 terms scaled by "
+                         "an exact power of two, three cross-products (csrc/split3.hip, csrc/split_fmt.h, DESIGN.md 5b round 5)")
     ap.add_argument("--with-input-pipeline", action="store_true",
                     help="also time the steps fed from HOST uint8 frames through DevicePrefetcher (pinned staging, 1-byte upload one "
                          "batch ahead, device-side normalisation): the PCIe-inclusive rate, reported separately, never `value`")
@@ -136,8 +137,17 @@ def executed_share(name):
     return 0.5 if "wino4" in name else ((2.0 / 3.0) if "wino" in name else 1.0)
 
 
+SPLIT_DTYPES = {
+    3: ("f32 tensors; the 2-D Winograd GEMMs of the 13 channel-heavy layers as 3-term bf16 split operands, six exact cross-products per fp32 product on "
+        "v_mfma_f32_16x16x32_bf16 with f32 accumulation (OPT-IN path runner.w2d_split = 3, never the default)"),
+    2: ("f32 tensors; the 2-D Winograd GEMMs of the 13 channel-heavy layers as 2-term fp16 split operands scaled by an exact power of two per transform "
+        "index, three exact cross-products per fp32 product on v_mfma_f32_16x16x32_f16 with f32 accumulation (OPT-IN path runner.w2d_split = 2, "
+        "never the default)"),
+}
+
+
 def peak_of(name):
-    return PEAK_BF16_MFMA_TFLOPS if ("bf16" in name or "thinb" in name or "split3" in name) else PEAK_F32_MFMA_TFLOPS
+    return PEAK_BF16_MFMA_TFLOPS if ("bf16" in name or "thinb" in name or "split3" in name or "split2h" in name) else PEAK_F32_MFMA_TFLOPS
 
 
 def kernel_profile(step, dev, nprof=3):
@@ -225,7 +235,7 @@ def run_leg(A, dev, model, batch, h, w, precision, steps, warmup, profile, world
     net = A.get_model(model, 3, 12).to(dev).train()
     A.set_conv_precision(net, precision)
     from pytorch_camvid_amd.modules import runner_of as _ro
-    _ro(net).w2d_split = bool(split3)                       # the leg's label decides, not the environment
+    _ro(net).w2d_split = int(split3)                        # 0 | 3 | 2: the leg's label decides, not the environment
     wrapped = ddp.DataParallel(net) if world > 1 else net
     lossf = A.CrossEntropyLoss()
     g = torch.Generator().manual_seed(1234 + rank)          # per-rank shard of the global batch
@@ -519,14 +529,12 @@ def main():
     if world == 1 and headline and not a.no_extra_configs:
         extra = []
         es, ew = max(3, min(a.steps, 10)), max(2, min(a.warmup, 3))
-        SPLIT_DTYPE = ("f32 tensors; the 2-D Winograd GEMMs of the 13 channel-heavy layers as 3-term bf16 split operands, six exact cross-products "
-                       "per fp32 product on v_mfma_f32_16x16x32_bf16 with f32 accumulation (OPT-IN study path runner.w2d_split, never the default)")
-        for (m, b, hh, ww, prec, sp3) in (("unet", 4, 720, 960, "bf16", False), ("segnet", 8, 360, 480, "fp32", False),
-                                          ("unet", 8, 360, 480, "fp32", True)):
+        for (m, b, hh, ww, prec, sp3) in (("unet", 4, 720, 960, "bf16", 0), ("segnet", 8, 360, 480, "fp32", 0),
+                                          ("unet", 8, 360, 480, "fp32", 3), ("unet", 8, 360, 480, "fp32", 2)):
             e = run_leg(A, dev, m, b, hh, ww, prec, es, ew, True, split3=sp3)
             r = e["roof"]
-            extra.append({"workload": config_label(m, b, hh, ww, prec, 1) + (" — OPT-IN split-operand GEMMs (study)" if sp3 else ""),
-                          "dtype": SPLIT_DTYPE if sp3 else ("bf16" if prec == "bf16" else "f32"),
+            extra.append({"workload": config_label(m, b, hh, ww, prec, 1) + (" — OPT-IN split-operand GEMMs (runner.w2d_split = %d)" % sp3 if sp3 else ""),
+                          "dtype": SPLIT_DTYPES[sp3] if sp3 else ("bf16" if prec == "bf16" else "f32"),
                           "images_per_s": round(e["value"], 3), "ms_per_step": round(e["ms"], 3), "steps": es, "warmup": ew,
                           "loss": round(e["loss"], 6), "dominant_kernel": r["kernel"], "executed_frac_of_peak": r["frac"],
                           "peak_tflops": r["peak"], "dominant_kernel_ms_per_step": round(r["avg_launch_us"] * r["launches_per_step"] / 1e3, 3),
@@ -540,8 +548,7 @@ def main():
                       else f"images/sec fwd+bwd {a.model} 3x{a.height}x{a.width} bs={a.batch} ({a.precision})",
             "value": round(leg["value"], 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(leg["ms"], 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 tensors, 2-D Winograd GEMMs as 3-term bf16 split operands on bf16 MFMA with f32 accumulation (OPT-IN study path --w2d-split)"
-                      if a.w2d_split else
+            "dtype": (SPLIT_DTYPES[a.w2d_split] if a.w2d_split else
                       {"fp32": "f32", "bf16": "bf16 (bf16 activations/gradients in HBM, bf16 MFMA with f32 accumulate, f32 statistics/parameters)"}[a.precision]),
             "data": "synthetic" + (" (REHEARSAL: ranks share a GPU over gloo — not a measurement)" if rehearsal else ""),
             "config": {"workload": config_label(a.model, a.batch, a.height, a.width, a.precision, world),

@@ -173,15 +173,27 @@ int cvk_w6_wgrad_ksplit(int T, int Cin_pad, int Cout);
 int cvk_w6_dy_transform(const float* dy, int ld_dy, float* E, int N, int H, int W, int Cout, void* stream);
 int cvk_w6_dy_transform_both(const float* dy, int ld_dy, float* Vp, float* E, int N, int H, int W, int Cout, void* stream);
 int cvk_w6_gemm_tn(const float* E, const float* V, float* P, int T, int Cin_pad, int Cout, void* stream);
-/* STUDY KERNELS (round 5; not used by the executor — its fp32 path is exact-fp32 MFMA): the GEMM stage above on the bf16 matrix pipe with
- * 3-term split fp32 operands (x = x1 + x2 + x3 in bf16, the six largest cross-products accumulated in fp32: at least fp32-MFMA accuracy at
- * 0.375 of its matrix time; csrc/split3.hip, tools/study/).  cvk_split3_planes: fp32 planes P[NX][R][C] -> split planes
- * bf16 [NX][C/32][3][Rpad][32] (Rpad = cvk_split3_rows_pad(R, 256) for V, (R, 128) for U; C % 32 == 0).  cvk_w2d_gemm_split3:
- * Mo fp32 [NX][T][Cout] = V * U^T per transform index, both operands as split planes. */
+/* OPT-IN SPLIT-OPERAND PATH (round 5; the executor's default fp32 path is exact-fp32 MFMA — this one runs only under runner.w2d_split): the
+ * GEMM stage above on the 16-bit matrix pipe with split fp32 operands, accumulated in fp32 (csrc/split3.hip, csrc/split_fmt.h, tools/study/).
+ *   fmt 3: x = x1 + x2 + x3 in bf16, the six largest cross-products (v_mfma_f32_16x16x32_bf16): fp32-MFMA accuracy at 0.375 of its matrix time;
+ *   fmt 2: 2^e * x = h1 + h2 in fp16, three cross-products (v_mfma_f32_16x16x32_f16): 0.19 of the matrix time.  The power-of-two scale per
+ *          transform index comes from the EXACT largest magnitude of the tensor a transform reads (cvk_absmax_f32 -> one word in device
+ *          memory, combined by atomicMax: zero it first) and the absolute row sums of the transform matrix, so no element can leave fp16's
+ *          range whatever the data; the GEMMs undo the scale exactly.  cvk_split_scale_exponent (host) returns e for (tile, kind, xi, word):
+ *          kind 0 = B (input transforms V, V'), 1 = G (filters U), 2 = A (dy -> E).
+ * Split planes: 16-bit [NX][C/32][fmt][Rpad][32] (Rpad = cvk_split3_rows_pad(R, 256) for V / V' / E, (R, 128) for U; C % 32 == 0).
+ * cvk_split_planes / cvk_split3_planes: fp32 planes P[NX][R][C] -> split planes (a stand-alone pass: tests and studies).
+ * cvk_w2d_gemm_split / _split3: Mo fp32 [NX][T][Cout] = V * U^T per transform index, both operands as split planes.  The *_split3 names are
+ * the fmt-3 forms of the generic entry points (no amax words). */
 int cvk_split3_rows_pad(int R, int mult);
 int cvk_split3_planes(const float* P, void* S, int NX, int R, int Rpad, int C, void* stream);
 int cvk_w2d_gemm_split3(const void* V3, const void* U3, float* Mo, int NX, int T, int Tpad, int Cin, int Cout, int Cpad, void* stream);
-/* ... the rest of the study path (tile = 4 or 6 selects F(4x4,3x3) / F(6x6,3x3)): transforms that write split planes from their store loops
+int cvk_absmax_f32(const float* x, long rows, int C, int ld, void* amax_word, void* stream);
+int cvk_split_scale_exponent(int tile, int kind, int xi, unsigned amax_word);
+int cvk_split_planes(int fmt, int tile, int kind, const float* P, void* S, const void* amax, int NX, int R, int Rpad, int C, void* stream);
+int cvk_w2d_gemm_split(int fmt, int tile, const void* V, const void* U, float* Mo, const void* amax_v, const void* amax_u, int NX, int T, int Tpad,
+                       int Cin, int Cout, int Cpad, void* stream);
+/* ... the rest of the split-operand path (tile = 4 or 6 selects F(4x4,3x3) / F(6x6,3x3)): transforms that write split planes from their store loops
  * (V3 / Vp3 / E3 rows padded to cvk_split3_rows_pad(T, 256); E stays fp32 [NX][cvk_w2d_tpad(T)][C] with e_split = 0), the filter as split
  * planes (tmp: NX * Cout * Cin floats), the output pass for product planes without K-range partials, and the weight-grad GEMM
  * P[f][NX][Cout][Cin] = E^T V on split planes (f = cvk_w2d_gemm_tn_split3_ksplit; Cout % 256 == 0 && Cin % 128 == 0 or the reverse) with
@@ -190,10 +202,16 @@ int cvk_w2d_input_transform_split3(int tile, const float* x, void* V3, int N, in
 int cvk_w2d_dy_transform_both_split3(int tile, const float* dy, int ld_dy, void* Vp3, void* E, int e_split, int N, int H, int W, int C,
                                      void* stream);
 int cvk_w2d_weight_transform_split3(int tile, const float* w, void* U3, float* tmp, int Cout, int Cin, int dgrad, void* stream);
+int cvk_w2d_input_transform_split(int fmt, int tile, const float* x, void* V, const void* amax_x, int N, int H, int W, int Cin, void* stream);
+int cvk_w2d_dy_transform_both_split(int fmt, int tile, const float* dy, int ld_dy, void* Vp, void* E, int e_split, const void* amax_dy, int N, int H,
+                                    int W, int C, void* stream);
+int cvk_w2d_weight_transform_split(int fmt, int tile, const float* w, void* U, const void* amax_w, int Cout, int Cin, int dgrad, void* stream);
 int cvk_w2d_output_plain(int tile, const float* Mo, const float* bias, float* y, float* stats, float* counts, int N, int H, int W,
                          int Cout, int ldy, void* stream);
 int cvk_w2d_gemm_tn_split3_ksplit(int NX, int Tpad, int Cin, int Cout);
 int cvk_w2d_gemm_tn_split3(const void* E3, const void* V3, float* P, int NX, int Tpad, int Cin, int Cout, void* stream);
+int cvk_w2d_gemm_tn_split(int fmt, int tile, const void* E, const void* V, float* P, const void* amax_e, const void* amax_v, int NX, int Tpad, int Cin,
+                          int Cout, void* stream);
 int cvk_w2d_wgrad_output_f(int tile, const float* P, float* dw, int Cin, int Cin_pad, int Cout, int f, void* stream);
 int cvk_w6_wgrad_output(const float* P, float* dw, int T, int Cin, int Cin_pad, int Cout, void* stream);
 /* FUSED 1-D Winograd F(4,3) (csrc/wino4f.hip; replaces nn.Conv2d(cin,cout,3,padding=1) fwd and its data-grad,

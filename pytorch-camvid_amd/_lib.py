@@ -105,6 +105,14 @@ SIGNATURES = {
     "cvk_w2d_output_plain": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_w2d_gemm_tn_split3_ksplit": (c_int, [c_int, c_int, c_int, c_int]),
     "cvk_w2d_gemm_tn_split3": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_absmax_f32": (c_int, [c_vp, ctypes.c_long, c_int, c_int, c_vp, c_vp]),
+    "cvk_split_scale_exponent": (c_int, [c_int, c_int, c_int, ctypes.c_uint]),
+    "cvk_split_planes": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_w2d_gemm_split": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_w2d_input_transform_split": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_w2d_dy_transform_both_split": (c_int, [c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_w2d_weight_transform_split": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "cvk_w2d_gemm_tn_split": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_w2d_wgrad_output_f": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_w2d_wgrad_ksplit": (c_int, [c_int, c_int, c_int]),
     "cvk_w2d_dy_transform": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp]),

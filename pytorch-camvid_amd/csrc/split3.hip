@@ -25,11 +25,29 @@
 #include <type_traits>
 #include "cvk_common.h"
 #include "lds_dma.h"
+#include "split_fmt.h"
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// operand fragments of the two formats (split_fmt.h): FMT 3 = three bf16 terms, six cross-products; FMT 2 = two fp16 terms, three
+template <int FMT> struct SplitOps;
+template <> struct SplitOps<3> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x4v mfma(frag a, frag b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct SplitOps<2> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x4v mfma(frag a, frag b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+// the cross-products of one K slice, the smallest terms first: f(a term, b term)
+template <int FMT, typename F> __device__ __forceinline__ void split_products(F f) {
+    if (FMT == 3) { f(2, 0); f(0, 2); f(1, 1); f(1, 0); f(0, 1); f(0, 0); }
+    else { f(1, 0); f(0, 1); f(0, 0); }
+}
 
 __device__ __forceinline__ unsigned bf16_bits(float v) {          // round to nearest even
     const unsigned u = __builtin_bit_cast(unsigned, v);
@@ -38,14 +56,30 @@ __device__ __forceinline__ unsigned bf16_bits(float v) {          // round to ne
 __device__ __forceinline__ float bf16_val(unsigned b) { return __builtin_bit_cast(float, b << 16); }
 
 // fp32 planes [NX][R][C] -> split planes [NX][C/32][3][Rpad][32] (see the file header); one thread = one 8-channel chunk of one row
-__global__ __launch_bounds__(256) void k_split3_planes(const float* __restrict__ P, unsigned* __restrict__ S, int R, int Rpad, int C, long total) {
+template <int FMT>
+__global__ __launch_bounds__(256) void k_split3_planes(const float* __restrict__ P, unsigned* __restrict__ S, int R, int Rpad, int C, long total,
+                                                      const unsigned* __restrict__ amax, CvkSplitTab tab) {
     const int c8n = C >> 3, ncs = C >> 5;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c8 = (int)(i % c8n);
         const long xr = i / c8n;
         const int r = (int)(xr % Rpad), xi = (int)(xr / Rpad);
         unsigned t[3][4] = {};
-        if (r < R) {
+        if (r < R && FMT == 2) {
+            const float sc = cvk_pow2f(cvk_split_exp_xi(amax, tab, xi));
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(P + ((size_t)xi * R + r) * C + c8 * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(P + ((size_t)xi * R + r) * C + c8 * 8 + 4);
+            const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = v[e] * sc;
+                const _Float16 h1 = (_Float16)x;
+                const _Float16 h2 = (_Float16)(x - (float)h1);
+                const int sh = (e & 1) * 16;
+                t[0][e >> 1] |= (unsigned)__builtin_bit_cast(unsigned short, h1) << sh;
+                t[1][e >> 1] |= (unsigned)__builtin_bit_cast(unsigned short, h2) << sh;
+            }
+        } else if (r < R) {
             const f32x4 lo = *reinterpret_cast<const f32x4*>(P + ((size_t)xi * R + r) * C + c8 * 8);
             const f32x4 hi = *reinterpret_cast<const f32x4*>(P + ((size_t)xi * R + r) * C + c8 * 8 + 4);
             const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -61,10 +95,10 @@ __global__ __launch_bounds__(256) void k_split3_planes(const float* __restrict__
         }
         const int cs = c8 >> 2, pos = (c8 & 3) ^ (((r >> 2) & 1) << 1);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < FMT; ++k) {
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 o = {t[k][0], t[k][1], t[k][2], t[k][3]};
-            *reinterpret_cast<u32x4*>(S + ((((size_t)xi * ncs + cs) * 3 + k) * Rpad + r) * 16 + pos * 4) = o;
+            *reinterpret_cast<u32x4*>(S + ((((size_t)xi * ncs + cs) * FMT + k) * Rpad + r) * 16 + pos * 4) = o;
         }
     }
 }
@@ -77,15 +111,20 @@ __device__ __forceinline__ void pbar() {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 }
-__device__ __forceinline__ bf16x8 rd16(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+template <typename FR> __device__ __forceinline__ FR rd16(const char* p) { return *reinterpret_cast<const FR*>(p); }
 
 constexpr int S3_TM = 256, S3_TN = 128;                 // tile: rows of V (tile index t) x rows of U (output channels)
-constexpr int S3_XT = 3 * S3_TM * 64;                   // 48 KiB: the three V terms of a slice
-constexpr int S3_WT = 3 * S3_TN * 64;                   // 24 KiB: the three U terms
-constexpr int S3_STAGE = S3_XT + S3_WT;                 // 72 KiB
 
+template <int FMT>
 __global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__ V3, const char* __restrict__ U3, float* __restrict__ Mo,
-                                                       int T, int Tpad, int Cin, int Cout, int Cpad, int tilesM, int tilesN) {
+                                                       int T, int Tpad, int Cin, int Cout, int Cpad, int tilesM, int tilesN,
+                                                       const unsigned* __restrict__ amaxV, const unsigned* __restrict__ amaxU, CvkSplitTab tabV,
+                                                       CvkSplitTab tabU) {
+    typedef SplitOps<FMT> OPS;
+    typedef typename OPS::frag FR;
+    constexpr int S3_XT = FMT * S3_TM * 64;                 // 48 (32) KiB: the V terms of a slice
+    constexpr int S3_WT = FMT * S3_TN * 64;                 // 24 (16) KiB: the U terms
+    constexpr int S3_STAGE = S3_XT + S3_WT;                 // 72 (48) KiB
     __shared__ __attribute__((aligned(1024))) char smem[2 * S3_STAGE];
     const unsigned smem_addr = cvk_lds_addr(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -101,8 +140,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__
 
     // ---- DMA: this wave moves pieces wi and wi + 4 (1 KiB each) of every term of its group's 128 V rows; group A also of the U tile
     const size_t xterm = (size_t)Tpad * 64, wterm = (size_t)Cpad * 64;          // bytes between two terms of one slice
-    const char* xsrc = V3 + ((size_t)xi * ncs * 3 * Tpad + (size_t)mt * S3_TM + grp * 128) * 64;     // slice 0, term 0, this group's rows
-    const char* wsrc = U3 + ((size_t)xi * ncs * 3 * Cpad + (size_t)nt * S3_TN) * 64;
+    const char* xsrc = V3 + ((size_t)xi * ncs * FMT * Tpad + (size_t)mt * S3_TM + grp * 128) * 64;     // slice 0, term 0, this group's rows
+    const char* wsrc = U3 + ((size_t)xi * ncs * FMT * Cpad + (size_t)nt * S3_TN) * 64;
     const unsigned voff = wi * 1024 + lane * 16;
     const unsigned xdst = smem_addr + grp * 8192 + wi * 1024;                   // + stage * S3_STAGE + term * 16384 (+ 4096)
     const unsigned wdst = smem_addr + S3_XT + wi * 1024;                        // + stage * S3_STAGE + term * 8192 (+ 4096)
@@ -111,17 +150,21 @@ __global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__
         dma16_s<4096>(voff, xsrc + 4096, xdst + stage_off);
         dma16_s<16384>(voff, xsrc + xterm, xdst + stage_off);
         dma16_s<16384 + 4096>(voff, xsrc + xterm + 4096, xdst + stage_off);
-        dma16_s<32768>(voff, xsrc + 2 * xterm, xdst + stage_off);
-        dma16_s<32768 + 4096>(voff, xsrc + 2 * xterm + 4096, xdst + stage_off);
-        xsrc += 3 * xterm;
+        if (FMT == 3) {
+            dma16_s<32768>(voff, xsrc + 2 * xterm, xdst + stage_off);
+            dma16_s<32768 + 4096>(voff, xsrc + 2 * xterm + 4096, xdst + stage_off);
+        }
+        xsrc += FMT * xterm;
         if (grp == 0) {
             dma16_s<0>(voff, wsrc, wdst + stage_off);
             dma16_s<4096>(voff, wsrc + 4096, wdst + stage_off);
             dma16_s<8192>(voff, wsrc + wterm, wdst + stage_off);
             dma16_s<8192 + 4096>(voff, wsrc + wterm + 4096, wdst + stage_off);
-            dma16_s<16384>(voff, wsrc + 2 * wterm, wdst + stage_off);
-            dma16_s<16384 + 4096>(voff, wsrc + 2 * wterm + 4096, wdst + stage_off);
-            wsrc += 3 * wterm;
+            if (FMT == 3) {
+                dma16_s<16384>(voff, wsrc + 2 * wterm, wdst + stage_off);
+                dma16_s<16384 + 4096>(voff, wsrc + 2 * wterm + 4096, wdst + stage_off);
+            }
+            wsrc += FMT * wterm;
         }
     };
 
@@ -146,26 +189,25 @@ __global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__
         // ======== LOAD phase: request the next slice into the other stage (everybody read it out two phases ago), read this slice's
         // 24 fragments
         if (cs + 1 < ncs) issue_slice(((cs + 1) & 1) ? S3_STAGE : 0);
-        bf16x8 w[3][4], x[3][4];
+        FR w[FMT][4], x[FMT][4];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < FMT; ++k) {
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) w[k][rb] = rd16(smem + (wa + k * 8192 + rb * 1024));
+            for (int rb = 0; rb < 4; ++rb) w[k][rb] = rd16<FR>(smem + (wa + k * 8192 + rb * 1024));
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) x[k][cb] = rd16(smem + (xa + k * 16384 + cb * 1024));
+            for (int cb = 0; cb < 4; ++cb) x[k][cb] = rd16<FR>(smem + (xa + k * 16384 + cb * 1024));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         pbar();
-        // ======== MFMA phase: 6 cross-products x 16 blocks, the smallest terms first
+        // ======== MFMA phase: 6 (3) cross-products x 16 blocks, the smallest terms first
         __builtin_amdgcn_s_setprio(1);
-        auto prod = [&](int kw, int kx) {
+        split_products<FMT>([&](int kw, int kx) {
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb)
-                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[kw][rb], x[kx][cb], acc[rb][cb], 0, 0, 0);
-        };
-        prod(2, 0); prod(0, 2); prod(1, 1); prod(1, 0); prod(0, 1); prod(0, 0);
+                    acc[rb][cb] = OPS::mfma(w[kw][rb], x[kx][cb], acc[rb][cb]);
+        });
         wa += flip; xa += flip; flip = -flip;
         __builtin_amdgcn_s_setprio(0);
         cvk_wait_vm<0>();                       // this wave's pieces of the next slice have landed (requested ~1.5 phases ago)
@@ -175,13 +217,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__
 
     // ---- epilogue: acc[rb][cb][j] = M[t = mt*256 + grp*128 + wp*64 + cb*16 + l15][co = nt*128 + wc*64 + rb*16 + 4*q4 + j]
     float* const mo = Mo + (size_t)xi * T * Cout;
+    // FMT 2: both operands carry a power-of-two scale per transform index (split_fmt.h); undoing it is exact
+    const CvkUnscale un = FMT == 2 ? cvk_unscale(-(cvk_split_exp_xi(amaxV, tabV, xi) + cvk_split_exp_xi(amaxU, tabU, xi))) : CvkUnscale{1.f, 1.f};
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
         const int t = mt * S3_TM + grp * 128 + wp * 64 + cb * 16 + l15;
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
             const int co = nt * S3_TN + wc * 64 + rb * 16 + 4 * q4;
-            if (t < T && co < Cout) *reinterpret_cast<f32x4v*>(mo + (size_t)t * Cout + co) = acc[rb][cb];
+            if (t < T && co < Cout) *reinterpret_cast<f32x4v*>(mo + (size_t)t * Cout + co) = FMT == 2 ? acc[rb][cb] * un.a * un.b : acc[rb][cb];
         }
     }
 }
@@ -195,10 +239,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__
 // 256 side (CO256: output channels, else input channels), a wave owns 64 (ci) x 64 (co): per 32-row slice 24 fragments = 48 transposing
 // reads and 96 MFMAs; two stages of 72 KiB; the A operand is V (m = ci) so that a lane ends with 4 consecutive input channels of one output
 // channel: 16-byte stores into P [part][xi][Cout][Cin].  The depth is cut into f ranges (k_w2d_wgrad_out adds the planes in a fixed order).
-template <bool CO256>
+template <bool CO256, int FMT>
 __global__ __launch_bounds__(512, 2) void k_gemm_tn_split3(const char* __restrict__ E3, const char* __restrict__ V3, float* __restrict__ P,
-                                                          int Tpad, int Cin, int Cout, int tilesCi, int tilesCo, int f, int NX) {
-    constexpr int X256 = 8 * 3 * 2048, X128 = 4 * 3 * 2048;       // 48 KiB + 24 KiB per stage
+                                                          int Tpad, int Cin, int Cout, int tilesCi, int tilesCo, int f, int NX,
+                                                          const unsigned* __restrict__ amaxE, const unsigned* __restrict__ amaxV, CvkSplitTab tabE,
+                                                          CvkSplitTab tabV) {
+    typedef SplitOps<FMT> OPS;
+    typedef typename OPS::frag FR;
+    constexpr int X256 = 8 * FMT * 2048, X128 = 4 * FMT * 2048;       // 48 (32) KiB + 24 (16) KiB per stage
     constexpr int STAGE = X256 + X128;
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
     const unsigned smem_addr = cvk_lds_addr(smem);
@@ -221,26 +269,30 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_split3(const char* __restric
     const int sB0 = (CO256 ? tco : tci) * 8, sS0 = (CO256 ? tci : tco) * 4;
     const size_t term = (size_t)Tpad * 64;                           // bytes between two terms of a slice
     // this wave moves slice (4 grp + wi) of the big side and (group A) slice wi of the small side: 3 terms x 2 KiB each, per K slice
-    const char* bsrc = big + (((size_t)xi * ncsB + sB0 + 4 * grp + wi) * 3 * Tpad + (size_t)k0 * 32) * 64;
-    const char* ssrc = sml + (((size_t)xi * ncsS + sS0 + wi) * 3 * Tpad + (size_t)k0 * 32) * 64;
+    const char* bsrc = big + (((size_t)xi * ncsB + sB0 + 4 * grp + wi) * FMT * Tpad + (size_t)k0 * 32) * 64;
+    const char* ssrc = sml + (((size_t)xi * ncsS + sS0 + wi) * FMT * Tpad + (size_t)k0 * 32) * 64;
     const unsigned voff = lane * 16;
-    const unsigned bdst = smem_addr + (4 * grp + wi) * 3 * 2048;
-    const unsigned sdst = smem_addr + X256 + wi * 3 * 2048;
+    const unsigned bdst = smem_addr + (4 * grp + wi) * FMT * 2048;
+    const unsigned sdst = smem_addr + X256 + wi * FMT * 2048;
     auto issue_slice = [&](unsigned stage_off) {
         dma16_s<0>(voff, bsrc, bdst + stage_off);
         dma16_s<1024>(voff, bsrc + 1024, bdst + stage_off);
         dma16_s<2048>(voff, bsrc + term, bdst + stage_off);
         dma16_s<2048 + 1024>(voff, bsrc + term + 1024, bdst + stage_off);
-        dma16_s<4096>(voff, bsrc + 2 * term, bdst + stage_off);
-        dma16_s<4096 + 1024>(voff, bsrc + 2 * term + 1024, bdst + stage_off);
+        if (FMT == 3) {
+            dma16_s<4096>(voff, bsrc + 2 * term, bdst + stage_off);
+            dma16_s<4096 + 1024>(voff, bsrc + 2 * term + 1024, bdst + stage_off);
+        }
         bsrc += 2048;
         if (grp == 0) {
             dma16_s<0>(voff, ssrc, sdst + stage_off);
             dma16_s<1024>(voff, ssrc + 1024, sdst + stage_off);
             dma16_s<2048>(voff, ssrc + term, sdst + stage_off);
             dma16_s<2048 + 1024>(voff, ssrc + term + 1024, sdst + stage_off);
-            dma16_s<4096>(voff, ssrc + 2 * term, sdst + stage_off);
-            dma16_s<4096 + 1024>(voff, ssrc + 2 * term + 1024, sdst + stage_off);
+            if (FMT == 3) {
+                dma16_s<4096>(voff, ssrc + 2 * term, sdst + stage_off);
+                dma16_s<4096 + 1024>(voff, ssrc + 2 * term + 1024, sdst + stage_off);
+            }
             ssrc += 2048;
         }
     };
@@ -258,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_split3(const char* __restric
     auto rd = [&](int blk_off, int h16) {
         const s16x4t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4t*)(smem + blk_off + fo[h16][0]));
         const s16x4t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4t*)(smem + blk_off + fo[h16][1]));
-        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        return __builtin_bit_cast(FR, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     // wave tile: 64 ci x 64 co.  On the 256 side the group takes 128 channels (4 slices) and the wave 64 of them (2 slices); on the 128 side
     // the wave takes 64 (2 slices).  ci is the A operand.
@@ -280,25 +332,24 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_split3(const char* __restric
     for (int ks = k0; ks < k1; ++ks) {
         if (ks + 1 < k1) issue_slice(st ? 0 : STAGE);
         const int so = st ? STAGE : 0;
-        bf16x8 A[3][4], B[3][4];
+        FR A[FMT][4], B[FMT][4];
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < FMT; ++k)
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
-                A[k][mb] = rd(so + ciReg + ((ciS + (mb >> 1)) * 3 + k) * 2048, mb & 1);
-                B[k][mb] = rd(so + coReg + ((coS + (mb >> 1)) * 3 + k) * 2048, mb & 1);
+                A[k][mb] = rd(so + ciReg + ((ciS + (mb >> 1)) * FMT + k) * 2048, mb & 1);
+                B[k][mb] = rd(so + coReg + ((coS + (mb >> 1)) * FMT + k) * 2048, mb & 1);
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         pbar();
         __builtin_amdgcn_s_setprio(1);
-        auto prod = [&](int ka, int kb) {
+        split_products<FMT>([&](int ka, int kb) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ka][mb], B[kb][nb], acc[mb][nb], 0, 0, 0);
-        };
-        prod(2, 0); prod(0, 2); prod(1, 1); prod(1, 0); prod(0, 1); prod(0, 0);
+                    acc[mb][nb] = OPS::mfma(A[ka][mb], B[kb][nb], acc[mb][nb]);
+        });
         __builtin_amdgcn_s_setprio(0);
         st ^= 1;
         cvk_wait_vm<0>();
@@ -310,13 +361,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_split3(const char* __restric
     const int ci0 = tci * (CO256 ? 128 : 256) + (CO256 ? 64 * wa_ : 128 * grp + 64 * wa_);
     const int co0 = tco * (CO256 ? 256 : 128) + (CO256 ? 128 * grp + 64 * wb_ : 64 * wb_);
     float* const pp = P + ((size_t)part * NX + xi) * Cout * Cin;
+    const CvkUnscale un = FMT == 2 ? cvk_unscale(-(cvk_split_exp_xi(amaxE, tabE, xi) + cvk_split_exp_xi(amaxV, tabV, xi))) : CvkUnscale{1.f, 1.f};
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         const int co = co0 + nb * 16 + l15;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             const int ci = ci0 + mb * 16 + 4 * q4;
-            if (co < Cout && ci < Cin) *reinterpret_cast<f32x4v*>(pp + (size_t)co * Cin + ci) = acc[mb][nb];
+            if (co < Cout && ci < Cin) *reinterpret_cast<f32x4v*>(pp + (size_t)co * Cin + ci) = FMT == 2 ? acc[mb][nb] * un.a * un.b : acc[mb][nb];
         }
     }
 }
@@ -325,28 +377,52 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_split3(const char* __restric
 
 extern "C" int cvk_split3_rows_pad(int R, int mult) { return (R > 0 && mult > 0) ? cvk_cdiv(R, mult) * mult : 0; }
 
-// P fp32 [NX][R][C] -> S bf16 [NX][C/32][3][Rpad][32] (Rpad = cvk_split3_rows_pad(R, 256) for V, (R, 128) for U; rows >= R zero)
-extern "C" int cvk_split3_planes(const float* P, void* S, int NX, int R, int Rpad, int C, void* stream) {
-    CVK_CHECK_ARG(P && S && NX > 0 && R > 0 && Rpad >= R && C > 0 && C % 32 == 0, "cvk_split3_planes: bad arguments (C must be a multiple of 32)");
-    CVK_CHECK_ARG(cvk_aligned16(P) && cvk_aligned16(S), "cvk_split3_planes: pointers must be 16-byte aligned");
+#define CVK_SPLIT_FMT_OK(who) \
+    CVK_CHECK_ARG((tile == 4 || tile == 6) && (fmt == 3 || fmt == 2), "%s: tile is 4 or 6, fmt 3 (bf16 x 3) or 2 (fp16 x 2)", who)
+
+// P fp32 [NX][R][C] -> S 16-bit [NX][C/32][fmt][Rpad][32] (Rpad = cvk_split3_rows_pad(R, 256) for V, (R, 128) for U; rows >= R zero); fmt 2: scaled
+// per transform index as a plane of `kind` (split_fmt.h) of a tensor whose cvk_absmax_f32 word is amax.  A stand-alone pass (tests, studies:
+// the executor's transforms write split planes themselves)
+extern "C" int cvk_split_planes(int fmt, int tile, int kind, const float* P, void* S, const void* amax, int NX, int R, int Rpad, int C, void* stream) {
+    const char* who = "cvk_split_planes";
+    CVK_SPLIT_FMT_OK(who);
+    CVK_CHECK_ARG(P && S && NX > 0 && R > 0 && Rpad >= R && C > 0 && C % 32 == 0 && kind >= 0 && kind <= 2, "%s: bad arguments (C must be a multiple of 32)", who);
+    CVK_CHECK_ARG(fmt == 3 || (amax != nullptr && NX == (tile + 2) * (tile + 2)), "%s: fmt 2 needs amax and NX = (tile + 2)^2", who);
+    CVK_CHECK_ARG(cvk_aligned16(P) && cvk_aligned16(S), "%s: pointers must be 16-byte aligned", who);
     const long total = (long)NX * Rpad * (C / 8);
     const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(k_split3_planes, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, (unsigned*)S, R, Rpad, C, total);
-    CVK_LAUNCH_RETURN("cvk_split3_planes");
+    const CvkSplitTab tab = cvk_split_tab(tile, kind);
+    if (fmt == 3) hipLaunchKernelGGL(k_split3_planes<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, (unsigned*)S, R, Rpad, C, total, (const unsigned*)amax, tab);
+    else hipLaunchKernelGGL(k_split3_planes<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, (unsigned*)S, R, Rpad, C, total, (const unsigned*)amax, tab);
+    CVK_LAUNCH_RETURN(who);
+}
+extern "C" int cvk_split3_planes(const float* P, void* S, int NX, int R, int Rpad, int C, void* stream) {
+    return cvk_split_planes(3, 4, 0, P, S, nullptr, NX, R, Rpad, C, stream);
 }
 
-// Mo fp32 [NX][T][Cout] = V * U^T per xi, operands as split planes (V3 rows padded to Tpad % 256 == 0, U3 rows to Cpad % 128 == 0)
-extern "C" int cvk_w2d_gemm_split3(const void* V3, const void* U3, float* Mo, int NX, int T, int Tpad, int Cin, int Cout, int Cpad,
-                                   void* stream) {
-    CVK_CHECK_ARG(V3 && U3 && Mo && NX > 0 && T > 0 && Cin > 0 && Cout > 0, "cvk_w2d_gemm_split3: bad arguments");
+// Mo fp32 [NX][T][Cout] = V * U^T per xi, operands as split planes of format fmt (V rows padded to Tpad % 256 == 0, U rows to Cpad % 128 == 0);
+// fmt 2: amax_v / amax_u = the cvk_absmax_f32 words the two transforms scaled with (V: B table, U: G table)
+extern "C" int cvk_w2d_gemm_split(int fmt, int tile, const void* V, const void* U, float* Mo, const void* amax_v, const void* amax_u, int NX, int T,
+                                  int Tpad, int Cin, int Cout, int Cpad, void* stream) {
+    const char* who = "cvk_w2d_gemm_split";
+    CVK_SPLIT_FMT_OK(who);
+    CVK_CHECK_ARG(V && U && Mo && NX > 0 && T > 0 && Cin > 0 && Cout > 0, "%s: bad arguments", who);
+    CVK_CHECK_ARG(fmt == 3 || (amax_v && amax_u && NX == (tile + 2) * (tile + 2)), "%s: fmt 2 needs both amax words and NX = (tile + 2)^2", who);
     CVK_CHECK_ARG(Cin % 32 == 0 && Cout % 4 == 0 && Tpad % S3_TM == 0 && Tpad >= T && Cpad % S3_TN == 0 && Cpad >= Cout,
-                  "cvk_w2d_gemm_split3: Cin %% 32, Cout %% 4, Tpad %% 256, Cpad %% 128");
-    CVK_CHECK_ARG(cvk_aligned16(V3) && cvk_aligned16(U3) && cvk_aligned16(Mo), "cvk_w2d_gemm_split3: pointers must be 16-byte aligned");
+                  "%s: Cin %% 32, Cout %% 4, Tpad %% 256, Cpad %% 128", who);
+    CVK_CHECK_ARG(cvk_aligned16(V) && cvk_aligned16(U) && cvk_aligned16(Mo), "%s: pointers must be 16-byte aligned", who);
     const int tilesM = Tpad / S3_TM, tilesN = Cpad / S3_TN;
-    CVK_CHECK_ARG((long)NX * tilesM * tilesN < (1L << 31), "cvk_w2d_gemm_split3: grid too large");
-    hipLaunchKernelGGL(k_gemm_split3, dim3((unsigned)(NX * tilesM * tilesN)), dim3(512), 0, (hipStream_t)stream, (const char*)V3, (const char*)U3,
-                       Mo, T, Tpad, Cin, Cout, Cpad, tilesM, tilesN);
-    CVK_LAUNCH_RETURN("cvk_w2d_gemm_split3");
+    CVK_CHECK_ARG((long)NX * tilesM * tilesN < (1L << 31), "%s: grid too large", who);
+    const CvkSplitTab tV = cvk_split_tab(tile, CVK_SPLIT_KIND_B), tU = cvk_split_tab(tile, CVK_SPLIT_KIND_G);
+    const dim3 grid((unsigned)(NX * tilesM * tilesN));
+    if (fmt == 3) hipLaunchKernelGGL(k_gemm_split3<3>, grid, dim3(512), 0, (hipStream_t)stream, (const char*)V, (const char*)U, Mo, T, Tpad, Cin, Cout, Cpad,
+                                     tilesM, tilesN, (const unsigned*)amax_v, (const unsigned*)amax_u, tV, tU);
+    else hipLaunchKernelGGL(k_gemm_split3<2>, grid, dim3(512), 0, (hipStream_t)stream, (const char*)V, (const char*)U, Mo, T, Tpad, Cin, Cout, Cpad,
+                            tilesM, tilesN, (const unsigned*)amax_v, (const unsigned*)amax_u, tV, tU);
+    CVK_LAUNCH_RETURN(who);
+}
+extern "C" int cvk_w2d_gemm_split3(const void* V3, const void* U3, float* Mo, int NX, int T, int Tpad, int Cin, int Cout, int Cpad, void* stream) {
+    return cvk_w2d_gemm_split(3, 4, V3, U3, Mo, nullptr, nullptr, NX, T, Tpad, Cin, Cout, Cpad, stream);
 }
 
 // depth ranges of the split weight-grad GEMM for a layer: enough workgroups to fill the chip twice, at least 4 slices per range
@@ -362,17 +438,29 @@ extern "C" int cvk_w2d_gemm_tn_split3_ksplit(int NX, int Tpad, int Cin, int Cout
     return f;
 }
 
-// P fp32 [f][NX][Cout][Cin] = E^T V per transform index and depth range, operands as split planes with Tpad % 256 == 0 rows; needs
-// Cout % 256 == 0 and Cin % 128 == 0, or Cin % 256 == 0 and Cout % 128 == 0; f = cvk_w2d_gemm_tn_split3_ksplit(NX, Tpad, Cin, Cout)
-extern "C" int cvk_w2d_gemm_tn_split3(const void* E3, const void* V3, float* P, int NX, int Tpad, int Cin, int Cout, void* stream) {
-    CVK_CHECK_ARG(E3 && V3 && P && NX > 0 && Tpad > 0 && Tpad % 256 == 0, "cvk_w2d_gemm_tn_split3: bad arguments");
+// P fp32 [f][NX][Cout][Cin] = E^T V per transform index and depth range, operands as split planes of format fmt with Tpad % 256 == 0 rows; needs
+// Cout % 256 == 0 and Cin % 128 == 0, or Cin % 256 == 0 and Cout % 128 == 0; f = cvk_w2d_gemm_tn_split3_ksplit(NX, Tpad, Cin, Cout);
+// fmt 2: amax_e / amax_v = the cvk_absmax_f32 words of dy (E: A table) and of x (V: B table)
+extern "C" int cvk_w2d_gemm_tn_split(int fmt, int tile, const void* E, const void* V, float* P, const void* amax_e, const void* amax_v, int NX,
+                                     int Tpad, int Cin, int Cout, void* stream) {
+    const char* who = "cvk_w2d_gemm_tn_split";
+    CVK_SPLIT_FMT_OK(who);
+    CVK_CHECK_ARG(E && V && P && NX > 0 && Tpad > 0 && Tpad % 256 == 0, "%s: bad arguments", who);
+    CVK_CHECK_ARG(fmt == 3 || (amax_e && amax_v && NX == (tile + 2) * (tile + 2)), "%s: fmt 2 needs both amax words and NX = (tile + 2)^2", who);
     const bool co256 = Cout % 256 == 0 && Cin % 128 == 0;
-    CVK_CHECK_ARG(co256 || (Cin % 256 == 0 && Cout % 128 == 0), "cvk_w2d_gemm_tn_split3: needs Cout %% 256 == 0 and Cin %% 128 == 0, or the reverse");
-    CVK_CHECK_ARG(cvk_aligned16(E3) && cvk_aligned16(V3) && cvk_aligned16(P), "cvk_w2d_gemm_tn_split3: pointers must be 16-byte aligned");
+    CVK_CHECK_ARG(co256 || (Cin % 256 == 0 && Cout % 128 == 0), "%s: needs Cout %% 256 == 0 and Cin %% 128 == 0, or the reverse", who);
+    CVK_CHECK_ARG(cvk_aligned16(E) && cvk_aligned16(V) && cvk_aligned16(P), "%s: pointers must be 16-byte aligned", who);
     const int f = cvk_w2d_gemm_tn_split3_ksplit(NX, Tpad, Cin, Cout);
     const int tilesCo = co256 ? Cout / 256 : Cout / 128, tilesCi = co256 ? Cin / 128 : Cin / 256;
     const dim3 grid((unsigned)(NX * tilesCo * tilesCi * f));
-    if (co256) hipLaunchKernelGGL((k_gemm_tn_split3<true>), grid, dim3(512), 0, (hipStream_t)stream, (const char*)E3, (const char*)V3, P, Tpad, Cin, Cout, tilesCi, tilesCo, f, NX);
-    else hipLaunchKernelGGL((k_gemm_tn_split3<false>), grid, dim3(512), 0, (hipStream_t)stream, (const char*)E3, (const char*)V3, P, Tpad, Cin, Cout, tilesCi, tilesCo, f, NX);
-    CVK_LAUNCH_RETURN("cvk_w2d_gemm_tn_split3");
+    const CvkSplitTab tE = cvk_split_tab(tile, CVK_SPLIT_KIND_A), tV = cvk_split_tab(tile, CVK_SPLIT_KIND_B);
+#define CVK_TN_SPLIT(CO_, F_) hipLaunchKernelGGL((k_gemm_tn_split3<CO_, F_>), grid, dim3(512), 0, (hipStream_t)stream, (const char*)E, (const char*)V, P, Tpad, Cin, Cout, \
+                                                 tilesCi, tilesCo, f, NX, (const unsigned*)amax_e, (const unsigned*)amax_v, tE, tV)
+    if (co256) { if (fmt == 3) CVK_TN_SPLIT(true, 3); else CVK_TN_SPLIT(true, 2); }
+    else       { if (fmt == 3) CVK_TN_SPLIT(false, 3); else CVK_TN_SPLIT(false, 2); }
+#undef CVK_TN_SPLIT
+    CVK_LAUNCH_RETURN(who);
+}
+extern "C" int cvk_w2d_gemm_tn_split3(const void* E3, const void* V3, float* P, int NX, int Tpad, int Cin, int Cout, void* stream) {
+    return cvk_w2d_gemm_tn_split(3, 4, E3, V3, P, nullptr, nullptr, NX, Tpad, Cin, Cout, stream);
 }

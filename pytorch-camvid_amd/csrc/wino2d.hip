@@ -14,6 +14,7 @@
 // slots with the fp32 MFMA (tools/micro/mfma_peak.hip) — only runs ds_reads.
 #include "cvk_common.h"
 #include "lds_dma.h"
+#include "split_fmt.h"
 
 namespace {
 
@@ -25,7 +26,7 @@ __host__ __device__ inline int w2_tb(int T) { return T >= 8192 ? 16 : 4; }
 // ---- 1-D transforms (applied along rows, then along columns) ---------------------------------------------------------------
 // B^T d
 template <typename T>
-__device__ __forceinline__ void w2_bt(const T* d, T* v) {
+__host__ __device__ __forceinline__ void w2_bt(const T* d, T* v) {
     const T a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
     v[0] = 4.f * d[0] - 5.f * d[2] + d[4];
     v[1] = a + b;
@@ -44,7 +45,7 @@ __device__ __forceinline__ void w2_at(const T* m, T* y) {
     y[3] = d12 + 8.f * d34 + m[5];
 }
 // G g
-__device__ __forceinline__ void w2_g(const float* g, float* u) {
+__host__ __device__ __forceinline__ void w2_g(const float* g, float* u) {
     const float t = g[0] + g[2];
     u[0] = 0.25f * g[0];
     u[1] = (-1.f / 6.f) * (t + g[1]);
@@ -57,7 +58,7 @@ __device__ __forceinline__ void w2_g(const float* g, float* u) {
 
 // A (6 x 4) = transpose of A^T above: e0 = d0, e1 = d0+d1+d2+d3, e2 = d0-d1+d2-d3, e3 = d0+2d1+4d2+8d3, e4 = d0-2d1+4d2-8d3, e5 = d3
 template <typename T>
-__device__ __forceinline__ void w2_a(const T* d, T* e) {
+__host__ __device__ __forceinline__ void w2_a(const T* d, T* e) {
     const T s02 = d[0] + d[2], s13 = d[1] + d[3], t02 = d[0] + 4.f * d[2], t13 = 2.f * d[1] + 8.f * d[3];
     e[0] = d[0];
     e[1] = s02 + s13;
@@ -72,7 +73,7 @@ __device__ __forceinline__ void w2_a(const T* d, T* e) {
 // that of F(4x4,3x3) (2.7e-6 / 5.1e-6 relative L2 at 64 / 256 input channels against 1.4e-6 / 2.7e-6, numpy restatement).
 // B^T d (8 -> 8)
 template <typename T>
-__device__ __forceinline__ void w6_bt(const T* d, T* v) {
+__host__ __device__ __forceinline__ void w6_bt(const T* d, T* v) {
     v[0] = d[0] - d[6] + 5.25f * (d[4] - d[2]);
     v[7] = d[7] - d[1] + 5.25f * (d[3] - d[5]);
     const T a1 = d[2] + d[6] - 4.25f * d[4], b1 = d[1] + d[5] - 4.25f * d[3];
@@ -97,7 +98,7 @@ __device__ __forceinline__ void w6_at(const T* m, T* y) {
     y[5] = d12 + 32.f * d34 + 0.03125f * d56 + m[7];
 }
 // G g (3 -> 8)
-__device__ __forceinline__ void w6_g(const float* g, float* u) {
+__host__ __device__ __forceinline__ void w6_g(const float* g, float* u) {
     const float t = g[0] + g[2];
     u[0] = g[0];
     u[1] = (-2.f / 9.f) * (t + g[1]);
@@ -112,7 +113,7 @@ __device__ __forceinline__ void w6_g(const float* g, float* u) {
 }
 // A d (6 -> 8): the transpose of the output transform (weight-grad: dy tiles)
 template <typename T>
-__device__ __forceinline__ void w6_a(const T* d, T* e) {
+__host__ __device__ __forceinline__ void w6_a(const T* d, T* e) {
     const T ev = d[0] + d[2] + d[4], od = d[1] + d[3] + d[5];
     e[0] = d[0];
     e[1] = ev + od;
@@ -148,9 +149,9 @@ template <int MT> struct W2T;
 template <> struct W2T<4> {
     static constexpr int NT = 6, NX = 36, VW = 4;
     typedef f32x4 VT;
-    template <typename T> static __device__ __forceinline__ void bt(const T* d, T* v) { w2_bt(d, v); }
-    template <typename T> static __device__ __forceinline__ void a(const T* d, T* e) { w2_a(d, e); }
-    static __device__ __forceinline__ void g(const float* x, float* u) { w2_g(x, u); }
+    template <typename T> static __host__ __device__ __forceinline__ void bt(const T* d, T* v) { w2_bt(d, v); }
+    template <typename T> static __host__ __device__ __forceinline__ void a(const T* d, T* e) { w2_a(d, e); }
+    static __host__ __device__ __forceinline__ void g(const float* x, float* u) { w2_g(x, u); }
     static __device__ __forceinline__ void gt(const float* x, float* w) { w2_gt(x, w); }
     // A^T[row][col]
     static __device__ __forceinline__ constexpr float at(int r, int c) {
@@ -162,9 +163,9 @@ template <> struct W2T<4> {
 template <> struct W2T<6> {
     static constexpr int NT = 8, NX = 64, VW = 2;
     typedef f32x2v VT;
-    template <typename T> static __device__ __forceinline__ void bt(const T* d, T* v) { w6_bt(d, v); }
-    template <typename T> static __device__ __forceinline__ void a(const T* d, T* e) { w6_a(d, e); }
-    static __device__ __forceinline__ void g(const float* x, float* u) { w6_g(x, u); }
+    template <typename T> static __host__ __device__ __forceinline__ void bt(const T* d, T* v) { w6_bt(d, v); }
+    template <typename T> static __host__ __device__ __forceinline__ void a(const T* d, T* e) { w6_a(d, e); }
+    static __host__ __device__ __forceinline__ void g(const float* x, float* u) { w6_g(x, u); }
     static __device__ __forceinline__ void gt(const float* x, float* w) { w6_gt(x, w); }
     static __device__ __forceinline__ constexpr float at(int r, int c) {
         return c == 0 ? (r == 0 ? 1.f : 0.f) : c == 7 ? (r == 5 ? 1.f : 0.f)
@@ -176,41 +177,57 @@ template <> struct W2T<6> {
 
 // ---- input transform: x [N,H,W,C] -> V [NX][T][C], T = N * ceil(H/MT) * ceil(W/MT); one thread = one tile x VW channels ------
 // Rows T <= t < Tpad (weight-grad: the tile index is the GEMM depth, padded to whole K slices) are written as zeros.
-// ---- split planes (round 5 study: csrc/split3.hip; cvk_split3_planes' format written straight from a transform's store loop) -------------
-// bf16 [xi][C/32][term 3][Rpad][32]: channel c of row t of transform index xi as x1 + x2 + x3 (three bf16 roundings of the remainder), the
-// 16-byte chunk (c % 32) / 8 of a 64-byte row at position chunk ^ (2 * ((t >> 2) & 1)).  One call stores VW consecutive channels (c % VW == 0).
+// ---- split planes (csrc/split_fmt.h; consumed by csrc/split3.hip) written straight from a transform's store loop ----------------------------
+// 16-bit [xi][C/32][term][Rpad][32]: FMT 3 = channel c of row t of transform index xi as x1 + x2 + x3 (three bf16 roundings of the remainder),
+// FMT 2 = 2^e(xi) * value as h1 + h2 (two fp16 roundings; e from the source tensor's absolute maximum, split_fmt.h); the 16-byte chunk
+// (c % 32) / 8 of a 64-byte row at position chunk ^ (2 * ((t >> 2) & 1)).  One call stores VW consecutive channels (c % VW == 0).
 struct SplitDst {
     unsigned short* base;       // element (xi = 0, this thread's channel slice, term 0, row t, swizzled chunk, c % 8)
     size_t term, xstride;       // elements between two terms / two transform indices
+    unsigned amax;              // FMT 2: bit pattern of the source tensor's largest magnitude
+    CvkSplitTab tab;
 };
-template <int VW>
-__device__ __forceinline__ SplitDst split_dst(void* S, int C, int Rpad, int t, int c) {
+template <int VW, int FMT>
+__device__ __forceinline__ SplitDst split_dst(void* S, int C, int Rpad, int t, int c, const unsigned* amax, const CvkSplitTab& tab) {
     const int ncs = C >> 5, cs = c >> 5, cl = c & 31;
     const int pos = (cl >> 3) ^ (((t >> 2) & 1) << 1);
     SplitDst d;
     d.term = (size_t)Rpad * 32;
-    d.xstride = (size_t)ncs * 3 * d.term;
-    d.base = reinterpret_cast<unsigned short*>(S) + ((size_t)cs * 3 * Rpad + t) * 32 + pos * 8 + (cl & 7);
+    d.xstride = (size_t)ncs * FMT * d.term;
+    d.base = reinterpret_cast<unsigned short*>(S) + ((size_t)cs * FMT * Rpad + t) * 32 + pos * 8 + (cl & 7);
+    d.amax = FMT == 2 ? *amax : 0u;
+    d.tab = tab;
     return d;
 }
 __device__ __forceinline__ unsigned short w2_bf16_rne(float v) {
     const unsigned u = __builtin_bit_cast(unsigned, v);
     return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
-template <int VW, typename VT>
-__device__ __forceinline__ void split_store(const SplitDst& d, int xi, VT v) {
+// one 16-bit term of r (and r -= its value): bf16 for FMT 3, fp16 for FMT 2 (both round to nearest even; the remainder is exact in fp32)
+template <int FMT>
+__device__ __forceinline__ unsigned short split_term(float& r) {
+    if (FMT == 2) {
+        const _Float16 h = (_Float16)r;
+        r -= (float)h;
+        return __builtin_bit_cast(unsigned short, h);
+    }
+    const unsigned short b = w2_bf16_rne(r);
+    r -= __builtin_bit_cast(float, (unsigned)b << 16);
+    return b;
+}
+// i, j: the transform index' row / column (compile-time constants in the unrolled store loops)
+template <int VW, int FMT, typename VT>
+__device__ __forceinline__ void split_store(const SplitDst& d, int xi, int i, int j, VT v) {
     float r[VW];
+    const float sc = FMT == 2 ? cvk_pow2f(cvk_split_exp(d.amax, cvk_split_tab_c(d.tab, i), cvk_split_tab_c(d.tab, j))) : 1.f;
 #pragma unroll
-    for (int j = 0; j < VW; ++j) r[j] = v[j];
+    for (int q = 0; q < VW; ++q) r[q] = FMT == 2 ? v[q] * sc : v[q];
     unsigned short* p = d.base + (size_t)xi * d.xstride;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < FMT; ++k) {
         unsigned short b[VW];
 #pragma unroll
-        for (int j = 0; j < VW; ++j) {
-            b[j] = w2_bf16_rne(r[j]);
-            r[j] -= __builtin_bit_cast(float, (unsigned)b[j] << 16);
-        }
+        for (int q = 0; q < VW; ++q) b[q] = split_term<FMT>(r[q]);
         if (VW == 2) *reinterpret_cast<unsigned*>(p) = (unsigned)b[0] | ((unsigned)b[1] << 16);
         else {
             typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
@@ -220,23 +237,21 @@ __device__ __forceinline__ void split_store(const SplitDst& d, int xi, VT v) {
     }
 }
 
-// one value: row r, channel c of transform index xi of split planes with Rpad rows and C channels
-__device__ __forceinline__ void split_store1(void* S, int C, int Rpad, int xi, int r, int c, float v) {
+// one value: row r, channel c of transform index (i, j) of split planes with Rpad rows and C channels
+template <int FMT>
+__device__ __forceinline__ void split_store1(void* S, int C, int Rpad, int i, int j, int r, int c, float v, unsigned amax, const CvkSplitTab& tab) {
     const int ncs = C >> 5, cs = c >> 5, cl = c & 31;
     const int pos = (cl >> 3) ^ (((r >> 2) & 1) << 1);
-    unsigned short* p = reinterpret_cast<unsigned short*>(S) + ((((size_t)xi * ncs + cs) * 3) * Rpad + r) * 32 + pos * 8 + (cl & 7);
+    unsigned short* p = reinterpret_cast<unsigned short*>(S) + ((((size_t)(i * tab.nt + j) * ncs + cs) * FMT) * Rpad + r) * 32 + pos * 8 + (cl & 7);
     const size_t term = (size_t)Rpad * 32;
+    if (FMT == 2) v *= cvk_pow2f(cvk_split_exp(amax, cvk_split_tab_c(tab, i), cvk_split_tab_c(tab, j)));
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const unsigned short b = w2_bf16_rne(v);
-        v -= __builtin_bit_cast(float, (unsigned)b << 16);
-        p[k * term] = b;
-    }
+    for (int k = 0; k < FMT; ++k) p[k * term] = split_term<FMT>(v);
 }
 
-template <int MT, bool SPL = false>
+template <int MT, int SPL = 0>       // SPL: 0 = fp32 planes, 3 / 2 = split planes of that format (split_fmt.h)
 __global__ __launch_bounds__(256) void k_w2d_input(const float* __restrict__ X, float* __restrict__ V, int H, int W, int C,
-                                                  int th, int tw, int T, int Tpad) {
+                                                  int th, int tw, int T, int Tpad, const unsigned* __restrict__ amax, CvkSplitTab tab) {
     typedef W2T<MT> TR;
     typedef typename TR::VT VT;
     constexpr int NT = TR::NT, NX = TR::NX, VW = TR::VW;
@@ -261,10 +276,10 @@ __global__ __launch_bounds__(256) void k_w2d_input(const float* __restrict__ X, 
     if (t >= Tpad) return;
     const VT zero = {};
     SplitDst sd = {};
-    if (SPL) sd = split_dst<VW>(V, C, Tpad, t, c);
+    if (SPL) sd = split_dst<VW, SPL ? SPL : 3>(V, C, Tpad, t, c, amax, tab);
     if (t >= T) {
         for (int xi = 0; xi < NX; ++xi) {
-            if (SPL) split_store<VW>(sd, xi, zero);
+            if (SPL) split_store<VW, SPL ? SPL : 3>(sd, xi, 0, 0, zero);
             else *reinterpret_cast<VT*>(V + ((size_t)xi * Tpad + t) * C + c) = zero;
         }
         return;
@@ -295,15 +310,16 @@ __global__ __launch_bounds__(256) void k_w2d_input(const float* __restrict__ X, 
         TR::bt(w[i], v);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            if (SPL) split_store<VW>(sd, i * NT + j, v[j]);
+            if (SPL) split_store<VW, SPL ? SPL : 3>(sd, i * NT + j, i, j, v[j]);
             else *reinterpret_cast<VT*>(vb + (size_t)(i * NT + j) * plane) = v[j];
         }
     }
 }
 
 // ---- weight transform: w [Co][3][3][Ci] -> U [NX][Co][Ci]; one thread = one (co, ci) --------------------------------------------
-template <int MT, bool SPL = false>      // SPL: U as split planes [xi][Ci/32][term][Co padded to 128][32] (rows beyond Co are zeroed by the caller)
-__device__ __forceinline__ void w2d_weight_body(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci, unsigned vblock, unsigned nblocks) {
+template <int MT, int SPL = 0>      // SPL 3 / 2: U as split planes [xi][Ci/32][term][Co padded to 128][32] (rows beyond Co are zeroed by the caller)
+__device__ __forceinline__ void w2d_weight_body(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci, unsigned vblock, unsigned nblocks,
+                                                unsigned amax = 0u, const CvkSplitTab& tab = CvkSplitTab{}) {
     typedef W2T<MT> TR;
     constexpr int NT = TR::NT;
     const size_t total = (size_t)Co * Ci;
@@ -327,22 +343,24 @@ __device__ __forceinline__ void w2d_weight_body(const float* __restrict__ Wt, fl
             TR::g(a[p], u);
 #pragma unroll
             for (int q = 0; q < NT; ++q) {
-                if (SPL) split_store1(U, Ci, (Co + 127) / 128 * 128, p * NT + q, (int)co, ci, u[q]);
+                if (SPL) split_store1<SPL ? SPL : 3>(U, Ci, (Co + 127) / 128 * 128, p, q, (int)co, ci, u[q], amax, tab);
                 else U[(size_t)(p * NT + q) * total + i] = u[q];
             }
         }
     }
 }
-template <int MT, bool SPL = false>
-__global__ __launch_bounds__(256) void k_w2d_weight(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci) {
-    w2d_weight_body<MT, SPL>(Wt, U, Co, Ci, blockIdx.x, gridDim.x);
+template <int MT, int SPL = 0>
+__global__ __launch_bounds__(256) void k_w2d_weight(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci, const unsigned* __restrict__ amax,
+                                                   CvkSplitTab tab) {
+    w2d_weight_body<MT, SPL>(Wt, U, Co, Ci, blockIdx.x, gridDim.x, SPL == 2 ? *amax : 0u, tab);
 }
 
 // ---- data-grad filter straight from the forward weights: U [NX][Ci][Co] = G w'[ci][.][.][co] G^T with w'[ci][r][s][co] =
 // w[co][2-r][2-s][ci] (rotated by 180 degrees, channels exchanged) — no packed copy in between.  A workgroup transposes a
 // 32 (co) x 32 (ci) tile of all nine taps through LDS: reads run along ci, writes along co.
-template <int MT, bool SPL = false>      // SPL: split planes [xi][Co/32][term][Ci padded to 128][32]
-__device__ __forceinline__ void w2d_weight_dgrad_body(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci, int bx, int by, float (*t)[32][33]) {
+template <int MT, int SPL = 0>      // SPL 3 / 2: split planes [xi][Co/32][term][Ci padded to 128][32]
+__device__ __forceinline__ void w2d_weight_dgrad_body(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci, int bx, int by, float (*t)[32][33],
+                                                      unsigned amax = 0u, const CvkSplitTab& tab = CvkSplitTab{}) {
     typedef W2T<MT> TR;
     constexpr int NT = TR::NT;
     const int ci0 = bx * 32, co0 = by * 32;
@@ -379,16 +397,17 @@ __device__ __forceinline__ void w2d_weight_dgrad_body(const float* __restrict__ 
             TR::g(a[q], u);
 #pragma unroll
             for (int r = 0; r < NT; ++r) {
-                if (SPL) split_store1(U, Co, (Ci + 127) / 128 * 128, q * NT + r, ci0 + ci, co0 + co, u[r]);
+                if (SPL) split_store1<SPL ? SPL : 3>(U, Co, (Ci + 127) / 128 * 128, q, r, ci0 + ci, co0 + co, u[r], amax, tab);
                 else U[(size_t)(q * NT + r) * total + o] = u[r];
             }
         }
     }
 }
-template <int MT, bool SPL = false>
-__global__ __launch_bounds__(256) void k_w2d_weight_dgrad(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci) {
+template <int MT, int SPL = 0>
+__global__ __launch_bounds__(256) void k_w2d_weight_dgrad(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci, const unsigned* __restrict__ amax,
+                                                         CvkSplitTab tab) {
     __shared__ float t[9][32][33];
-    w2d_weight_dgrad_body<MT, SPL>(Wt, U, Co, Ci, blockIdx.x, blockIdx.y, t);
+    w2d_weight_dgrad_body<MT, SPL>(Wt, U, Co, Ci, blockIdx.x, blockIdx.y, t, SPL == 2 ? *amax : 0u, tab);
 }
 
 // All 2-D Winograd filter transforms of a step (forward and data-grad filters, both tile sizes) in ONE launch: job j owns the blocks
@@ -581,9 +600,10 @@ __global__ __launch_bounds__(256) void k_w2d_dy(const float* __restrict__ DY, in
 // dy -> BOTH transforms of the backward pass in one launch: V' = B^T dy B (the data-grad's GEMM operand: the tile with its one-pixel
 // halo) and E = A dy A^T (the weight-grad's: the tile's own MT x MT pixels).  The thread that has just transformed a tile for V'
 // re-reads its inner pixels (L1 / L2 hits) for E: dy crosses the fabric once instead of twice, and one launch replaces two.
-template <int MT, int SPL = 0>      // SPL bit 0: V' as split planes, bit 1: E as split planes (both with Tpad rows)
+template <int MT, int SPL = 0, int FMT = 3>      // SPL bit 0: V' as split planes, bit 1: E as split planes (both with Tpad rows), of format FMT
 __global__ __launch_bounds__(256) void k_w2d_dy_both(const float* __restrict__ DY, int ld, float* __restrict__ Vp, float* __restrict__ E, int H,
-                                                    int W, int C, int th, int tw, int T, int Tpad, int TpadE) {
+                                                    int W, int C, int th, int tw, int T, int Tpad, int TpadE, const unsigned* __restrict__ amax,
+                                                    CvkSplitTab tabB, CvkSplitTab tabA) {
     // Tpad: rows of the V' planes (and of the launch), TpadE <= Tpad: rows of the E planes (fp32 E for the fp32 weight-grad GEMM keeps its
     // 32-row padding beside 256-row split V' planes)
     typedef W2T<MT> TR;
@@ -608,12 +628,12 @@ __global__ __launch_bounds__(256) void k_w2d_dy_both(const float* __restrict__ D
     float* const vb = Vp + (size_t)t * C + c;
     float* const eb = E + (size_t)t * C + c;
     SplitDst sv = {}, se = {};
-    if (SPL & 1) sv = split_dst<VW>(Vp, C, Tpad, t, c);
-    if (SPL & 2) se = split_dst<VW>(E, C, TpadE, t, c);
+    if (SPL & 1) sv = split_dst<VW, FMT>(Vp, C, Tpad, t, c, amax, tabB);
+    if (SPL & 2) se = split_dst<VW, FMT>(E, C, TpadE, t, c, amax, tabA);
     if (t >= T) {
         for (int xi = 0; xi < NX; ++xi) {
-            if (SPL & 1) split_store<VW>(sv, xi, zero); else *reinterpret_cast<VT*>(vb + (size_t)xi * plane) = zero;
-            if (t < TpadE) { if (SPL & 2) split_store<VW>(se, xi, zero); else *reinterpret_cast<VT*>(eb + (size_t)xi * planeE) = zero; }
+            if (SPL & 1) split_store<VW, FMT>(sv, xi, 0, 0, zero); else *reinterpret_cast<VT*>(vb + (size_t)xi * plane) = zero;
+            if (t < TpadE) { if (SPL & 2) split_store<VW, FMT>(se, xi, 0, 0, zero); else *reinterpret_cast<VT*>(eb + (size_t)xi * planeE) = zero; }
         }
         return;
     }
@@ -642,7 +662,7 @@ __global__ __launch_bounds__(256) void k_w2d_dy_both(const float* __restrict__ D
             TR::bt(w[i], v);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                if (SPL & 1) split_store<VW>(sv, i * NT + j, v[j]);
+                if (SPL & 1) split_store<VW, FMT>(sv, i * NT + j, i, j, v[j]);
                 else *reinterpret_cast<VT*>(vb + (size_t)(i * NT + j) * plane) = v[j];
             }
         }
@@ -668,7 +688,7 @@ __global__ __launch_bounds__(256) void k_w2d_dy_both(const float* __restrict__ D
             TR::a(w[i], e);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                if (SPL & 2) split_store<VW>(se, i * NT + j, e[j]);
+                if (SPL & 2) split_store<VW, FMT>(se, i * NT + j, i, j, e[j]);
                 else *reinterpret_cast<VT*>(eb + (size_t)(i * NT + j) * planeE) = e[j];
             }
         }
@@ -955,16 +975,16 @@ static int w2i_weight_transform(int mt, const char* who, const float* w, float* 
     CVK_CHECK_ARG(w && U && Cout > 0 && Cin > 0, "%s: bad arguments", who);
     const size_t total = (size_t)Cout * Cin;
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    if (mt == 4) hipLaunchKernelGGL(k_w2d_weight<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
-    else hipLaunchKernelGGL(k_w2d_weight<6>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
+    if (mt == 4) hipLaunchKernelGGL(k_w2d_weight<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin, (const unsigned*)nullptr, CvkSplitTab{});
+    else hipLaunchKernelGGL(k_w2d_weight<6>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin, (const unsigned*)nullptr, CvkSplitTab{});
     CVK_LAUNCH_RETURN(who);
 }
 
 static int w2i_weight_transform_dgrad(int mt, const char* who, const float* w, float* U, int Cout, int Cin, void* stream) {
     CVK_CHECK_ARG(w && U && Cout > 0 && Cin > 0, "%s: bad arguments", who);
     const dim3 grid(cvk_cdiv(Cin, 32), cvk_cdiv(Cout, 32));
-    if (mt == 4) hipLaunchKernelGGL(k_w2d_weight_dgrad<4>, grid, dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
-    else hipLaunchKernelGGL(k_w2d_weight_dgrad<6>, grid, dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin);
+    if (mt == 4) hipLaunchKernelGGL(k_w2d_weight_dgrad<4>, grid, dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin, (const unsigned*)nullptr, CvkSplitTab{});
+    else hipLaunchKernelGGL(k_w2d_weight_dgrad<6>, grid, dim3(256), 0, (hipStream_t)stream, w, U, Cout, Cin, (const unsigned*)nullptr, CvkSplitTab{});
     CVK_LAUNCH_RETURN(who);
 }
 
@@ -991,8 +1011,8 @@ static int w2i_input_transform(int mt, const char* who, const float* x, float* V
     const int th = (H + mt - 1) / mt, tw = (W + mt - 1) / mt, T = N * th * tw, Tpad = w2_tpad(T);
     const long threads = (long)Tpad * (Cin / (mt == 4 ? 4 : 2));
     const dim3 grid((unsigned)((threads + 255) / 256));
-    if (mt == 4) hipLaunchKernelGGL(k_w2d_input<4>, grid, dim3(256), 0, (hipStream_t)stream, x, V, H, W, Cin, th, tw, T, Tpad);
-    else hipLaunchKernelGGL(k_w2d_input<6>, grid, dim3(256), 0, (hipStream_t)stream, x, V, H, W, Cin, th, tw, T, Tpad);
+    if (mt == 4) hipLaunchKernelGGL(k_w2d_input<4>, grid, dim3(256), 0, (hipStream_t)stream, x, V, H, W, Cin, th, tw, T, Tpad, (const unsigned*)nullptr, CvkSplitTab{});
+    else hipLaunchKernelGGL(k_w2d_input<6>, grid, dim3(256), 0, (hipStream_t)stream, x, V, H, W, Cin, th, tw, T, Tpad, (const unsigned*)nullptr, CvkSplitTab{});
     CVK_LAUNCH_RETURN(who);
 }
 
@@ -1107,68 +1127,168 @@ static int w2i_dy_both(int mt, const char* who, const float* dy, int ld_dy, floa
     const int th = (H + mt - 1) / mt, tw = (W + mt - 1) / mt, T = N * th * tw, Tpad = w2_tpad(T);
     const long threads = (long)Tpad * (C / (mt == 4 ? 4 : 2));
     const dim3 grid((unsigned)((threads + 255) / 256));
-    if (mt == 4) hipLaunchKernelGGL(k_w2d_dy_both<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, ld_dy, Vp, E, H, W, C, th, tw, T, Tpad, Tpad);
-    else hipLaunchKernelGGL(k_w2d_dy_both<6>, grid, dim3(256), 0, (hipStream_t)stream, dy, ld_dy, Vp, E, H, W, C, th, tw, T, Tpad, Tpad);
+    if (mt == 4) hipLaunchKernelGGL(k_w2d_dy_both<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, ld_dy, Vp, E, H, W, C, th, tw, T, Tpad, Tpad, (const unsigned*)nullptr, CvkSplitTab{}, CvkSplitTab{});
+    else hipLaunchKernelGGL(k_w2d_dy_both<6>, grid, dim3(256), 0, (hipStream_t)stream, dy, ld_dy, Vp, E, H, W, C, th, tw, T, Tpad, Tpad, (const unsigned*)nullptr, CvkSplitTab{}, CvkSplitTab{});
     CVK_LAUNCH_RETURN(who);
 }
 
-// ---- split-operand study path (round 5; csrc/split3.hip holds the GEMMs): transforms that write split planes, plain output pass -----------
-extern "C" int cvk_w2d_input_transform_split3(int tile, const float* x, void* V3, int N, int H, int W, int Cin, void* stream) {
-    CVK_CHECK_ARG((tile == 4 || tile == 6) && x && V3 && N > 0 && H > 0 && W > 0 && Cin >= 32 && Cin % 32 == 0, "cvk_w2d_input_transform_split3: bad arguments");
-    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(V3), "cvk_w2d_input_transform_split3: pointers must be 16-byte aligned");
+// ---- split-operand path (opt-in; csrc/split3.hip holds the GEMMs, split_fmt.h the formats): transforms that write split planes ------------
+// exponent tables from the transform routines themselves: c[i] = ceil(log2(sum_k |M[i][k]|)), M applied to the unit vectors
+template <int MT>
+static CvkSplitTab w2_split_tab(int kind) {
+    typedef W2T<MT> TR;
+    constexpr int NT = TR::NT;
+    const int nin = kind == CVK_SPLIT_KIND_B ? NT : (kind == CVK_SPLIT_KIND_G ? 3 : MT);
+    double rs[8] = {};
+    for (int k = 0; k < nin; ++k) {
+        float d[8] = {}, v[8] = {};
+        d[k] = 1.f;
+        if (kind == CVK_SPLIT_KIND_B) TR::bt(d, v);
+        else if (kind == CVK_SPLIT_KIND_G) TR::g(d, v);
+        else TR::a(d, v);
+        for (int i = 0; i < NT; ++i) rs[i] += v[i] < 0.f ? -(double)v[i] : (double)v[i];
+    }
+    CvkSplitTab t;
+    t.c8 = 0ull;
+    t.nt = NT;
+    for (int i = 0; i < NT; ++i) {
+        int c = -20;
+        while (rs[i] > ldexp(1.0, c) * (1.0 + 1e-6)) ++c;        // 2^c >= the row sum (fp32 coefficient rounding allowed for)
+        t.c8 |= (unsigned long long)(unsigned)(c + 64) << (8 * i);
+    }
+    return t;
+}
+CvkSplitTab cvk_split_tab(int tile, int kind) { return tile == 4 ? w2_split_tab<4>(kind) : w2_split_tab<6>(kind); }
+
+// exponent e of the scale 2^e of transform index xi of a fmt-2 plane (kind 0 = input transforms B, 1 = filter transforms G, 2 = dy -> E A) for a
+// source tensor whose largest magnitude has the bit pattern amax_bits: what the transforms apply and the GEMM epilogues undo (tests)
+extern "C" int cvk_split_scale_exponent(int tile, int kind, int xi, unsigned amax_bits) {
+    if (!(tile == 4 || tile == 6) || kind < 0 || kind > 2 || xi < 0 || xi >= w2_nx(tile)) return 0;
+    const CvkSplitTab t = cvk_split_tab(tile, kind);
+    return cvk_split_exp(amax_bits, cvk_split_tab_c(t, xi / t.nt), cvk_split_tab_c(t, xi % t.nt));
+}
+
+// largest magnitude of x [rows][C] (row stride ld) as an fp32 bit pattern, combined into *amax_bits by atomicMax: the caller zeroes the word
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ X, long rows, int C, int ld, unsigned* __restrict__ out) {
+    const int c4n = C >> 2;
+    const long total = rows * c4n;
+    unsigned m = 0u;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / c4n;
+        const int c = (int)(i - r * c4n) << 2;
+        typedef unsigned u32x4a __attribute__((ext_vector_type(4)));
+        const u32x4a v = *reinterpret_cast<const u32x4a*>(X + r * ld + c) & 0x7FFFFFFFu;      // magnitudes order like their bit patterns
+        const unsigned m01 = v[0] > v[1] ? v[0] : v[1], m23 = v[2] > v[3] ? v[2] : v[3];
+        const unsigned mv = m01 > m23 ? m01 : m23;
+        m = mv > m ? mv : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned other = (unsigned)__shfl_xor((int)m, o);
+        m = other > m ? other : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
+}
+extern "C" int cvk_absmax_f32(const float* x, long rows, int C, int ld, void* amax_bits, void* stream) {
+    CVK_CHECK_ARG(x && amax_bits && rows > 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0, "cvk_absmax_f32: bad arguments (C, ld multiples of 4)");
+    CVK_CHECK_ARG(cvk_aligned16(x), "cvk_absmax_f32: x must be 16-byte aligned");
+    const long total = rows * (C / 4);
+    const int blocks = (int)((total + 1023) / 1024 < 2048 ? (total + 1023) / 1024 : 2048);
+    hipLaunchKernelGGL(k_absmax, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, x, rows, C, ld, (unsigned*)amax_bits);
+    CVK_LAUNCH_RETURN("cvk_absmax_f32");
+}
+
+#define CVK_SPLIT_FMT_CHECK(who) \
+    CVK_CHECK_ARG(fmt == 3 || (fmt == 2 && amax != nullptr), "%s: fmt is 3 (bf16 x 3) or 2 (fp16 x 2, needs the source tensor's cvk_absmax_f32 word)", who)
+
+// x -> V as split planes (rows padded to 256); amax: the cvk_absmax_f32 word of x (fmt 2)
+extern "C" int cvk_w2d_input_transform_split(int fmt, int tile, const float* x, void* V, const void* amax, int N, int H, int W, int Cin, void* stream) {
+    const char* who = "cvk_w2d_input_transform_split";
+    CVK_CHECK_ARG((tile == 4 || tile == 6) && x && V && N > 0 && H > 0 && W > 0 && Cin >= 32 && Cin % 32 == 0, "%s: bad arguments", who);
+    CVK_SPLIT_FMT_CHECK(who);
+    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(V), "%s: pointers must be 16-byte aligned", who);
     const int mt = tile, th = (H + mt - 1) / mt, tw = (W + mt - 1) / mt, T = N * th * tw, Tpad = cvk_split3_rows_pad(T, 256);
     const long threads = (long)Tpad * (Cin / (mt == 4 ? 4 : 2));
     const dim3 grid((unsigned)((threads + 255) / 256));
-    if (mt == 4) hipLaunchKernelGGL((k_w2d_input<4, true>), grid, dim3(256), 0, (hipStream_t)stream, x, (float*)V3, H, W, Cin, th, tw, T, Tpad);
-    else hipLaunchKernelGGL((k_w2d_input<6, true>), grid, dim3(256), 0, (hipStream_t)stream, x, (float*)V3, H, W, Cin, th, tw, T, Tpad);
-    CVK_LAUNCH_RETURN("cvk_w2d_input_transform_split3");
+    const CvkSplitTab tab = cvk_split_tab(tile, CVK_SPLIT_KIND_B);
+    const unsigned* am = (const unsigned*)amax;
+#define CVK_W2_INS(MT_, F_) hipLaunchKernelGGL((k_w2d_input<MT_, F_>), grid, dim3(256), 0, (hipStream_t)stream, x, (float*)V, H, W, Cin, th, tw, T, Tpad, am, tab)
+    if (mt == 4) { if (fmt == 3) CVK_W2_INS(4, 3); else CVK_W2_INS(4, 2); }
+    else         { if (fmt == 3) CVK_W2_INS(6, 3); else CVK_W2_INS(6, 2); }
+#undef CVK_W2_INS
+    CVK_LAUNCH_RETURN(who);
+}
+extern "C" int cvk_w2d_input_transform_split3(int tile, const float* x, void* V3, int N, int H, int W, int Cin, void* stream) {
+    return cvk_w2d_input_transform_split(3, tile, x, V3, nullptr, N, H, W, Cin, stream);
 }
 
-// dy -> V' as split planes (rows padded to 256) and E: fp32 planes [NX][cvk_w2d_tpad(T)][C] (e_split = 0) or split planes (rows padded to 256)
-extern "C" int cvk_w2d_dy_transform_both_split3(int tile, const float* dy, int ld_dy, void* Vp3, void* E, int e_split, int N, int H, int W, int C,
-                                                void* stream) {
-    CVK_CHECK_ARG((tile == 4 || tile == 6) && dy && Vp3 && E && N > 0 && H > 0 && W > 0 && C >= 32 && C % 32 == 0 && ld_dy >= C && ld_dy % 4 == 0,
-                  "cvk_w2d_dy_transform_both_split3: bad arguments");
-    CVK_CHECK_ARG(cvk_aligned16(dy) && cvk_aligned16(Vp3) && cvk_aligned16(E), "cvk_w2d_dy_transform_both_split3: pointers must be 16-byte aligned");
+// dy -> V' as split planes (rows padded to 256) and E: fp32 planes [NX][cvk_w2d_tpad(T)][C] (e_split = 0) or split planes (rows padded to 256);
+// amax: the cvk_absmax_f32 word of dy (fmt 2; V' is scaled with the B table, E with the A table)
+extern "C" int cvk_w2d_dy_transform_both_split(int fmt, int tile, const float* dy, int ld_dy, void* Vp, void* E, int e_split, const void* amax,
+                                               int N, int H, int W, int C, void* stream) {
+    const char* who = "cvk_w2d_dy_transform_both_split";
+    CVK_CHECK_ARG((tile == 4 || tile == 6) && dy && Vp && E && N > 0 && H > 0 && W > 0 && C >= 32 && C % 32 == 0 && ld_dy >= C && ld_dy % 4 == 0,
+                  "%s: bad arguments", who);
+    CVK_SPLIT_FMT_CHECK(who);
+    CVK_CHECK_ARG(cvk_aligned16(dy) && cvk_aligned16(Vp) && cvk_aligned16(E), "%s: pointers must be 16-byte aligned", who);
     const int mt = tile, th = (H + mt - 1) / mt, tw = (W + mt - 1) / mt, T = N * th * tw, Tpad = cvk_split3_rows_pad(T, 256);
     const int TpadE = e_split ? Tpad : w2_tpad(T);
     const long threads = (long)Tpad * (C / (mt == 4 ? 4 : 2));
     const dim3 grid((unsigned)((threads + 255) / 256));
     hipStream_t s = (hipStream_t)stream;
+    const CvkSplitTab tB = cvk_split_tab(tile, CVK_SPLIT_KIND_B), tA = cvk_split_tab(tile, CVK_SPLIT_KIND_A);
+    const unsigned* am = (const unsigned*)amax;
+#define CVK_W2_DYS(MT_, S_, F_) hipLaunchKernelGGL((k_w2d_dy_both<MT_, S_, F_>), grid, dim3(256), 0, s, dy, ld_dy, (float*)Vp, (float*)E, H, W, C, th, tw, T, Tpad, TpadE, am, tB, tA)
     if (mt == 4) {
-        if (e_split) hipLaunchKernelGGL((k_w2d_dy_both<4, 3>), grid, dim3(256), 0, s, dy, ld_dy, (float*)Vp3, (float*)E, H, W, C, th, tw, T, Tpad, TpadE);
-        else hipLaunchKernelGGL((k_w2d_dy_both<4, 1>), grid, dim3(256), 0, s, dy, ld_dy, (float*)Vp3, (float*)E, H, W, C, th, tw, T, Tpad, TpadE);
+        if (fmt == 3) { if (e_split) CVK_W2_DYS(4, 3, 3); else CVK_W2_DYS(4, 1, 3); }
+        else          { if (e_split) CVK_W2_DYS(4, 3, 2); else CVK_W2_DYS(4, 1, 2); }
     } else {
-        if (e_split) hipLaunchKernelGGL((k_w2d_dy_both<6, 3>), grid, dim3(256), 0, s, dy, ld_dy, (float*)Vp3, (float*)E, H, W, C, th, tw, T, Tpad, TpadE);
-        else hipLaunchKernelGGL((k_w2d_dy_both<6, 1>), grid, dim3(256), 0, s, dy, ld_dy, (float*)Vp3, (float*)E, H, W, C, th, tw, T, Tpad, TpadE);
+        if (fmt == 3) { if (e_split) CVK_W2_DYS(6, 3, 3); else CVK_W2_DYS(6, 1, 3); }
+        else          { if (e_split) CVK_W2_DYS(6, 3, 2); else CVK_W2_DYS(6, 1, 2); }
     }
-    CVK_LAUNCH_RETURN("cvk_w2d_dy_transform_both_split3");
+#undef CVK_W2_DYS
+    CVK_LAUNCH_RETURN(who);
+}
+extern "C" int cvk_w2d_dy_transform_both_split3(int tile, const float* dy, int ld_dy, void* Vp3, void* E, int e_split, int N, int H, int W, int C,
+                                                void* stream) {
+    return cvk_w2d_dy_transform_both_split(3, tile, dy, ld_dy, Vp3, E, e_split, nullptr, N, H, W, C, stream);
 }
 
-// filter -> U as split planes, written by the transform kernels' own store loops (`tmp` is unused since the fused version; kept in the
-// signature); dgrad: the rotated / channel-exchanged filter of the data-grad (rows = Cin, depth = Cout of the forward layer)
-extern "C" int cvk_w2d_weight_transform_split3(int tile, const float* w, void* U3, float* tmp, int Cout, int Cin, int dgrad, void* stream) {
-    (void)tmp;
-    CVK_CHECK_ARG((tile == 4 || tile == 6) && w && U3 && Cout > 0 && Cin > 0, "cvk_w2d_weight_transform_split3: bad arguments");
+// filter -> U as split planes, written by the transform kernels' own store loops; dgrad: the rotated / channel-exchanged filter of the
+// data-grad (rows = Cin, depth = Cout of the forward layer); amax: the cvk_absmax_f32 word of w (fmt 2)
+extern "C" int cvk_w2d_weight_transform_split(int fmt, int tile, const float* w, void* U, const void* amax, int Cout, int Cin, int dgrad, void* stream) {
+    const char* who = "cvk_w2d_weight_transform_split";
+    CVK_CHECK_ARG((tile == 4 || tile == 6) && w && U && Cout > 0 && Cin > 0, "%s: bad arguments", who);
+    CVK_SPLIT_FMT_CHECK(who);
     const int rows = dgrad ? Cin : Cout, cols = dgrad ? Cout : Cin;
-    CVK_CHECK_ARG(cols % 32 == 0, "cvk_w2d_weight_transform_split3: the GEMM depth (%d) must be a multiple of 32", cols);
+    CVK_CHECK_ARG(cols % 32 == 0, "%s: the GEMM depth (%d) must be a multiple of 32", who, cols);
     hipStream_t s = (hipStream_t)stream;
     const int Rp = cvk_split3_rows_pad(rows, 128);
     if (Rp != rows) {       // padding rows are never written by the transform: zero planes first
-        const hipError_t e = hipMemsetAsync(U3, 0, (size_t)w2_nx(tile) * (cols / 32) * 3 * Rp * 64, s);
-        if (e != hipSuccess) { cvk_set_error("cvk_w2d_weight_transform_split3: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+        const hipError_t e = hipMemsetAsync(U, 0, (size_t)w2_nx(tile) * (cols / 32) * fmt * Rp * 64, s);
+        if (e != hipSuccess) { cvk_set_error("%s: memset failed: %s", who, hipGetErrorString(e)); return (int)e; }
     }
+    const CvkSplitTab tab = cvk_split_tab(tile, CVK_SPLIT_KIND_G);
+    const unsigned* am = (const unsigned*)amax;
     if (dgrad) {
         const dim3 grid(cvk_cdiv(Cin, 32), cvk_cdiv(Cout, 32));
-        if (tile == 4) hipLaunchKernelGGL((k_w2d_weight_dgrad<4, true>), grid, dim3(256), 0, s, w, (float*)U3, Cout, Cin);
-        else hipLaunchKernelGGL((k_w2d_weight_dgrad<6, true>), grid, dim3(256), 0, s, w, (float*)U3, Cout, Cin);
+#define CVK_W2_WDS(MT_, F_) hipLaunchKernelGGL((k_w2d_weight_dgrad<MT_, F_>), grid, dim3(256), 0, s, w, (float*)U, Cout, Cin, am, tab)
+        if (tile == 4) { if (fmt == 3) CVK_W2_WDS(4, 3); else CVK_W2_WDS(4, 2); }
+        else           { if (fmt == 3) CVK_W2_WDS(6, 3); else CVK_W2_WDS(6, 2); }
+#undef CVK_W2_WDS
     } else {
         const size_t total = (size_t)Cout * Cin;
         const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-        if (tile == 4) hipLaunchKernelGGL((k_w2d_weight<4, true>), dim3(blocks), dim3(256), 0, s, w, (float*)U3, Cout, Cin);
-        else hipLaunchKernelGGL((k_w2d_weight<6, true>), dim3(blocks), dim3(256), 0, s, w, (float*)U3, Cout, Cin);
+#define CVK_W2_WS(MT_, F_) hipLaunchKernelGGL((k_w2d_weight<MT_, F_>), dim3(blocks), dim3(256), 0, s, w, (float*)U, Cout, Cin, am, tab)
+        if (tile == 4) { if (fmt == 3) CVK_W2_WS(4, 3); else CVK_W2_WS(4, 2); }
+        else           { if (fmt == 3) CVK_W2_WS(6, 3); else CVK_W2_WS(6, 2); }
+#undef CVK_W2_WS
     }
-    CVK_LAUNCH_RETURN("cvk_w2d_weight_transform_split3");
+    CVK_LAUNCH_RETURN(who);
+}
+extern "C" int cvk_w2d_weight_transform_split3(int tile, const float* w, void* U3, float* tmp, int Cout, int Cin, int dgrad, void* stream) {
+    (void)tmp;              // unused since the fused version; kept in the signature
+    return cvk_w2d_weight_transform_split(3, tile, w, U3, nullptr, Cout, Cin, dgrad, stream);
 }
 
 // the output pass for product planes WITHOUT K-range partials (Mo [NX][T][Cout], one plane per transform index)

@@ -208,6 +208,13 @@ def wgradp_pays(N, H, W, cin_ld, cout):
     return cin_ld == 64 and N * H * ((W + 3) // 4) >= 4096
 
 
+def split_fmt(R):
+    """runner.w2d_split as a split-plane format (csrc/split_fmt.h): 0 = off (exact-fp32 MFMA, the default), 3 = three bf16 terms (True means
+    this one), 2 = two scaled fp16 terms."""
+    v = getattr(R, "w2d_split", 0)
+    return 3 if v is True else (int(v) if v in (2, 3) else 0)
+
+
 def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what="", dgrad_of=None, keep_v=None, wsrc=None, ck=None,
               bnred=None, v_pre=None, split=False):
     """y[N,H,W,ldy] = conv3x3(x[N,H,W,k_ch], w[cout][3][3][k_ch]) (+bias, +BN statistics partials at sp) through the
@@ -234,37 +241,60 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
         tile = layer_tile(R, N, H, W, dgrad=dgrad_of is not None)
         NX = 64 if tile == 6 else 36
         if split:
-            # OPT-IN study path (runner.w2d_split): the GEMM stage on the bf16 matrix pipe with 3-term split fp32
-            # operands — the transforms write split planes, cvk_w2d_gemm_split3 multiplies them, the plain output pass finishes
+            # OPT-IN path (runner.w2d_split = 3 | 2): the GEMM stage on the 16-bit matrix pipe with split fp32 operands
+            # (csrc/split_fmt.h: three bf16 terms / six cross-products, or two fp16 terms / three cross-products scaled by an exact power of
+            # two from the source tensors' largest magnitudes) — the transforms write split planes, cvk_w2d_gemm_split multiplies them, the
+            # plain output pass finishes
+            fmt = int(split)
+            pdt = _BF16 if fmt == 3 else torch.float16
+            tag = "split3" if fmt == 3 else "split2h"
             T = w2fn(lib, tile, "tiles")(N, H, W)
             Tp = lib.cvk_split3_rows_pad(T, 256)
             Cp = lib.cvk_split3_rows_pad(cout, 128)
+            wraw = dgrad_of[0] if dgrad_of is not None else (w() if callable(w) else w)
+            am_w = None
+            if fmt == 2:
+                def build_amax_w():
+                    a = torch.zeros(1, device=x.device, dtype=torch.int32)
+                    _timed(R, "k_absmax", 4.0 * wraw.numel(), lambda: check(
+                        lib.cvk_absmax_f32(wraw.data_ptr(), wraw.numel() // 4, 4, 4, a.data_ptr(), s), "cvk_absmax_f32(w)"), "byte")
+                    return a
+                am_w = R.derived(((ck[0] if ck is not None else None, "a"), "amaxw"), wsrc, build_amax_w) if (ck is not None and wsrc is not None) \
+                    else build_amax_w()
             def build_u3():
-                tmp = u3 = torch.empty(NX * (k_ch // 32) * 3 * Cp * 32, device=x.device, dtype=_BF16)
+                u3 = torch.empty(NX * (k_ch // 32) * fmt * Cp * 32, device=x.device, dtype=pdt)
+                amp = am_w.data_ptr() if am_w is not None else None
                 if dgrad_of is not None:
-                    _timed(R, "k_w2d_weight_dgrad+split3", 4.0 * 9 * cout * k_ch + 6.0 * NX * cout * k_ch, lambda: check(
-                        lib.cvk_w2d_weight_transform_split3(tile, dgrad_of[0].data_ptr(), u3.data_ptr(), tmp.data_ptr(), dgrad_of[1], dgrad_of[2], 1, s),
-                        "cvk_w2d_weight_transform_split3(dgrad)"), "byte")
+                    _timed(R, "k_w2d_weight_dgrad+" + tag, 4.0 * 9 * cout * k_ch + 2.0 * fmt * NX * cout * k_ch, lambda: check(
+                        lib.cvk_w2d_weight_transform_split(fmt, tile, wraw.data_ptr(), u3.data_ptr(), amp, dgrad_of[1], dgrad_of[2], 1, s),
+                        "cvk_w2d_weight_transform_split(dgrad)"), "byte")
                 else:
-                    wt = w() if callable(w) else w
-                    _timed(R, "k_w2d_weight+split3", 4.0 * 9 * cout * k_ch + 6.0 * NX * cout * k_ch, lambda: check(
-                        lib.cvk_w2d_weight_transform_split3(tile, wt.data_ptr(), u3.data_ptr(), tmp.data_ptr(), cout, k_ch, 0, s),
-                        "cvk_w2d_weight_transform_split3"), "byte")
+                    _timed(R, "k_w2d_weight+" + tag, 4.0 * 9 * cout * k_ch + 2.0 * fmt * NX * cout * k_ch, lambda: check(
+                        lib.cvk_w2d_weight_transform_split(fmt, tile, wraw.data_ptr(), u3.data_ptr(), amp, cout, k_ch, 0, s),
+                        "cvk_w2d_weight_transform_split"), "byte")
                 return u3
-            U3 = cached("w2ds%d" % tile, build_u3)
-            v3fl = NX * (k_ch // 32) * 3 * Tp * 32
+            U3 = cached("w2ds%d_%d" % (fmt, tile), build_u3)
+            v3fl = NX * (k_ch // 32) * fmt * Tp * 32
             if v_pre is not None:
-                V3 = v_pre[1]
+                V3, am_x = v_pre[1], getattr(v_pre[1], "cvk_amax", None)
             else:
-                V3 = torch.empty(v3fl, device=x.device, dtype=_BF16)
+                V3 = torch.empty(v3fl, device=x.device, dtype=pdt)
+                am_x = None
+                if fmt == 2:
+                    am_x = torch.zeros(1, device=x.device, dtype=torch.int32)
+                    _timed(R, "k_absmax", 4.0 * M * k_ch, lambda: check(
+                        lib.cvk_absmax_f32(x.data_ptr(), M, k_ch, k_ch, am_x.data_ptr(), s), "cvk_absmax_f32(x)"), "byte")
+                V3.cvk_amax = am_x          # the planes travel with the word they were scaled by (weight-grad GEMM, data-grad GEMM)
                 if keep_v is not None:
                     keep_v.append(V3)
-                _timed(R, "k_w2d_input<split3>", (4.0 * M + 6.0 * NX * T) * k_ch, lambda: check(
-                    lib.cvk_w2d_input_transform_split3(tile, x.data_ptr(), V3.data_ptr(), N, H, W, k_ch, s), "cvk_w2d_input_transform_split3" + what), "byte")
+                _timed(R, "k_w2d_input<%s>" % tag, (4.0 * M + 2.0 * fmt * NX * T) * k_ch, lambda: check(
+                    lib.cvk_w2d_input_transform_split(fmt, tile, x.data_ptr(), V3.data_ptr(), am_x.data_ptr() if am_x is not None else None,
+                                                      N, H, W, k_ch, s), "cvk_w2d_input_transform_split" + what), "byte")
             ws = R.workspace(4 * NX * T * cout + 1024, x.device)
-            _timed(R, "k_gemm_split3", flops, lambda: check(
-                lib.cvk_w2d_gemm_split3(V3.data_ptr(), U3.data_ptr(), ws.data_ptr(), NX, T, Tp, k_ch, cout, Cp, s), "cvk_w2d_gemm_split3" + what),
-                executed=12.0 * NX * Tp * k_ch * Cp)     # six bf16 MFMA products per fp32 product
+            _timed(R, "k_gemm_" + tag, flops, lambda: check(
+                lib.cvk_w2d_gemm_split(fmt, tile, V3.data_ptr(), U3.data_ptr(), ws.data_ptr(), am_x.data_ptr() if am_x is not None else None,
+                                       am_w.data_ptr() if am_w is not None else None, NX, T, Tp, k_ch, cout, Cp, s), "cvk_w2d_gemm_split" + what),
+                executed=2.0 * (6 if fmt == 3 else 3) * NX * Tp * k_ch * Cp)     # six bf16 / three fp16 MFMA products per fp32 product
             P2 = w2fn(lib, tile, "stat_partials")(N, H, W)
             cnt = sp + 4 * 2 * P2 * cout if sp is not None else None
             _timed(R, "k_w2d_output", 4.0 * (NX * T + M) * cout, lambda: check(
@@ -515,7 +545,7 @@ class ConvBnRelu(Op):
         """Does this layer run the OPT-IN split-operand GEMMs (runner.w2d_split; csrc/split3.hip)?  Only layers whose forward, data-grad
         and weight-grad ALL take the 2-D path with one tile size and whose channel counts the split weight-grad GEMM serves — the three
         GEMMs of such a layer share their split planes (V from the forward transform, V' and E from one pass over dy)."""
-        if not getattr(R, "w2d_split", False) or not self.src_needs_grad:
+        if not split_fmt(R) or not self.src_needs_grad:
             return False
         src, C = self.src, self.cout
         N, H, W, ldy = src.N, src.H, src.W, pad4(self.cout)
@@ -546,7 +576,7 @@ class ConvBnRelu(Op):
             return (Pt, cnt) if sp is not None else None
         if wino_ok(R, src.ld, ldy):
             return wino_conv(R, lib, s, X, wk, b.data_ptr(), y, sp, N, H, W, src.ld, C, ldy, 18.0 * M * C * self.cin, keep_v=keep_v,
-                             wsrc=st.params[4 * self.pslot], ck=(self.pslot, "f"), split=st.need_grad and st.training and self._split3(R))
+                             wsrc=st.params[4 * self.pslot], ck=(self.pslot, "f"), split=split_fmt(R) if (st.need_grad and st.training and self._split3(R)) else 0)
         else:
             _timed(R, conv_kernel_name("fwd", ldy, src.ld), 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy, s),
@@ -681,20 +711,29 @@ class ConvBnRelu(Op):
         # weight-grad AND data-grad on the 2-D path with the same tile: dy is transformed for both in ONE launch (csrc/wino2d.hip
         # k_w2d_dy_both): E for the weight-grad, V' for the data-grad; dy crosses the fabric once
         both2 = None
-        split3 = wgrad2d and st.training and self._split3(R) and Vkept is not None and Vkept.dtype == _BF16
+        fmt = split_fmt(R) if (wgrad2d and st.training and self._split3(R)) else 0
+        pdt = {3: _BF16, 2: torch.float16}.get(fmt)
+        split3 = fmt if (fmt and Vkept is not None and Vkept.dtype == pdt) else 0
         if split3:
             tile = layer_tile(R, N, H, W)
             NX = 64 if tile == 6 else 36
             T = w2fn(lib, tile, "tiles")(N, H, W)
             Tp = lib.cvk_split3_rows_pad(T, 256)
-            Eb = torch.empty(NX * (C // 32) * 3 * Tp * 32, device=dev, dtype=_BF16)
-            Vb = torch.empty(NX * (C // 32) * 3 * Tp * 32, device=dev, dtype=_BF16)
-            _timed(R, "k_w2d_dy<both,split3>", (4.0 * M + 12.0 * NX * T) * C, lambda: check(
-                lib.cvk_w2d_dy_transform_both_split3(tile, dy.data_ptr(), ldy, Vb.data_ptr(), Eb.data_ptr(), 1, N, H, W, C, s),
-                "cvk_w2d_dy_transform_both_split3"), "byte")
+            tag = "split3" if fmt == 3 else "split2h"
+            Eb = torch.empty(NX * (C // 32) * fmt * Tp * 32, device=dev, dtype=pdt)
+            Vb = torch.empty(NX * (C // 32) * fmt * Tp * 32, device=dev, dtype=pdt)
+            am_dy = None
+            if fmt == 2:
+                am_dy = torch.zeros(1, device=dev, dtype=torch.int32)
+                _timed(R, "k_absmax", 4.0 * M * C, lambda: check(lib.cvk_absmax_f32(dy.data_ptr(), M, C, ldy, am_dy.data_ptr(), s), "cvk_absmax_f32(dy)"), "byte")
+            Eb.cvk_amax = Vb.cvk_amax = am_dy
+            _timed(R, "k_w2d_dy<both,%s>" % tag, (4.0 * M + 4.0 * fmt * NX * T) * C, lambda: check(
+                lib.cvk_w2d_dy_transform_both_split(fmt, tile, dy.data_ptr(), ldy, Vb.data_ptr(), Eb.data_ptr(), 1,
+                                                    am_dy.data_ptr() if am_dy is not None else None, N, H, W, C, s),
+                "cvk_w2d_dy_transform_both_split"), "byte")
             both2 = (tile, Eb, Vb)
-        elif Vkept is not None and Vkept.dtype == _BF16:
-            Vkept = None            # the forward pass ran the split path but this backward pass does not (a knob changed in between)
+        elif Vkept is not None and Vkept.dtype in (_BF16, torch.float16):
+            Vkept = None            # the forward pass ran a split path but this backward pass does not run the same (a knob changed in between)
         if (not split3 and wgrad2d and self.src_needs_grad and R.w2both and ldy == C and wino_ok(R, ldy, src.ld) and wino2d_ok(ldy, src.ld, src.ld)
                 and (R.wino2d == "always" or (R.wino2d and wino2d_pays(N, H, W, ldy, src.ld, R.w2tile)))
                 and layer_tile(R, N, H, W) == layer_tile(R, N, H, W, dgrad=True)):
@@ -749,9 +788,11 @@ class ConvBnRelu(Op):
             Tp = lib.cvk_split3_rows_pad(T, 256)
             f = lib.cvk_w2d_gemm_tn_split3_ksplit(NX, Tp, src.ld, C)
             ws = R.workspace(4 * f * NX * C * src.ld, dev)
-            _timed(R, "k_gemm_tn_split3", 18.0 * M * C * self.cin, lambda: check(
-                lib.cvk_w2d_gemm_tn_split3(Eb3.data_ptr(), Vkept.data_ptr(), ws.data_ptr(), NX, Tp, src.ld, C, s), "cvk_w2d_gemm_tn_split3"),
-                executed=12.0 * NX * Tp * src.ld * C)
+            am_e, am_v = getattr(Eb3, "cvk_amax", None), getattr(Vkept, "cvk_amax", None)
+            _timed(R, "k_gemm_tn_" + ("split3" if split3 == 3 else "split2h"), 18.0 * M * C * self.cin, lambda: check(
+                lib.cvk_w2d_gemm_tn_split(split3, tile, Eb3.data_ptr(), Vkept.data_ptr(), ws.data_ptr(), am_e.data_ptr() if am_e is not None else None,
+                                          am_v.data_ptr() if am_v is not None else None, NX, Tp, src.ld, C, s), "cvk_w2d_gemm_tn_split"),
+                executed=2.0 * (6 if split3 == 3 else 3) * NX * Tp * src.ld * C)
             _timed(R, "k_w2d_wgrad_out", 4.0 * (NX * f + 9) * C * self.cin, lambda: check(
                 lib.cvk_w2d_wgrad_output_f(tile, ws.data_ptr(), gw, self.cin, src.ld, C, f, s), "cvk_w2d_wgrad_output_f"), "byte")
             del Vkept
@@ -1247,7 +1288,7 @@ class Runner:
         self.wino2d = WINO2D_DEFAULT
         # OPT-IN study path: the 2-D Winograd GEMMs of the layers ConvBnRelu._split3 admits on the bf16 matrix pipe with
         # 3-term split fp32 operands (csrc/split3.hip).  Not the product default; bench.py names it in `dtype` when it is on.
-        self.w2d_split = os.environ.get("CVK_W2D_SPLIT", "0") == "1"
+        self.w2d_split = {"0": 0, "1": 3, "3": 3, "2": 2}[os.environ.get("CVK_W2D_SPLIT", "0")]      # 0 off | 3: bf16 x 3 | 2: fp16 x 2
         self.w2tile_cfg = W2TILE_DEFAULT    # None = auto (see W2TILE_DEFAULT), 4 or 6 = forced
         self.w2tile = 6                     # the tile of the plan being executed (set by forward / backward)
         self.w2tile_dgrad = 6               # ... of its data-grad launches

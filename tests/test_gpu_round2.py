@@ -186,11 +186,13 @@ def test_bench_json_contract_single_gpu():
     assert "configs[1]" in d["config"]["workload"]
     # the other single-GPU configurations of BASELINE.json ride on the same line
     ex = d["extra_configs"]
-    assert len(ex) == 3 and "configs[3]" in ex[0]["workload"] and "configs[4]" in ex[1]["workload"]
+    assert len(ex) == 4 and "configs[3]" in ex[0]["workload"] and "configs[4]" in ex[1]["workload"]
     assert ex[0]["dtype"] == "bf16" and ex[0]["peak_tflops"] == 2500.0 and ex[1]["dtype"] == "f32" and ex[1]["peak_tflops"] == 157.3
     # the opt-in split-operand mode rides along as a labelled extra leg of the headline workload: never the headline itself
     assert "configs[1]" in ex[2]["workload"] and "OPT-IN" in ex[2]["workload"] and "split" in ex[2]["dtype"]
-    assert "k_gemm_split3" in ex[2]["top_kernels_ms_per_step"] and "split3" not in rf["kernel"] and not any("split3" in k for k in d["conv_kernels"])
+    assert "k_gemm_split3" in ex[2]["top_kernels_ms_per_step"] and "split" not in rf["kernel"] and not any("split" in k for k in d["conv_kernels"])
+    assert "configs[1]" in ex[3]["workload"] and "OPT-IN" in ex[3]["workload"] and "fp16" in ex[3]["dtype"]
+    assert any("split2h" in k for k in ex[3]["top_kernels_ms_per_step"])
     for e in ex:
         for k in ("workload", "dtype", "images_per_s", "ms_per_step", "dominant_kernel", "executed_frac_of_peak", "loss"):
             assert k in e, k
