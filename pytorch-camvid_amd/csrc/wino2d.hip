@@ -1168,33 +1168,56 @@ extern "C" int cvk_split_scale_exponent(int tile, int kind, int xi, unsigned ama
     return cvk_split_exp(amax_bits, cvk_split_tab_c(t, xi / t.nt), cvk_split_tab_c(t, xi % t.nt));
 }
 
-// largest magnitude of x [rows][C] (row stride ld) as an fp32 bit pattern, combined into *amax_bits by atomicMax: the caller zeroes the word
+// largest magnitude of x [rows][C] (row stride ld) as an fp32 bit pattern, combined into *amax_bits by atomicMax: the caller zeroes the word.
+// Magnitudes order like their bit patterns, so the maximum is exact and independent of the order (bitwise reproducible).  Four 16-byte loads
+// per thread in flight; a dense tensor (ld == C) is walked as one flat array.
+typedef unsigned u32x4a __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned absmax4(u32x4a v, unsigned m) {
+    v &= 0x7FFFFFFFu;
+    const unsigned m01 = v[0] > v[1] ? v[0] : v[1], m23 = v[2] > v[3] ? v[2] : v[3];
+    const unsigned mv = m01 > m23 ? m01 : m23;
+    return mv > m ? mv : m;
+}
+template <bool DENSE>
 __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ X, long rows, int C, int ld, unsigned* __restrict__ out) {
     const int c4n = C >> 2;
-    const long total = rows * c4n;
+    const long total = rows * c4n;                          // 16-byte pieces
+    const long step = (long)gridDim.x * 256;
     unsigned m = 0u;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    auto piece = [&](long i) -> const u32x4a* {
+        if (DENSE) return reinterpret_cast<const u32x4a*>(X) + i;
         const long r = i / c4n;
-        const int c = (int)(i - r * c4n) << 2;
-        typedef unsigned u32x4a __attribute__((ext_vector_type(4)));
-        const u32x4a v = *reinterpret_cast<const u32x4a*>(X + r * ld + c) & 0x7FFFFFFFu;      // magnitudes order like their bit patterns
-        const unsigned m01 = v[0] > v[1] ? v[0] : v[1], m23 = v[2] > v[3] ? v[2] : v[3];
-        const unsigned mv = m01 > m23 ? m01 : m23;
-        m = mv > m ? mv : m;
+        return reinterpret_cast<const u32x4a*>(X + r * ld + ((int)(i - r * c4n) << 2));
+    };
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * step < total; i += 4 * step) {
+        const u32x4a v0 = *piece(i), v1 = *piece(i + step), v2 = *piece(i + 2 * step), v3 = *piece(i + 3 * step);
+        m = absmax4(v0, m); m = absmax4(v1, m); m = absmax4(v2, m); m = absmax4(v3, m);
     }
+    for (; i < total; i += step) m = absmax4(*piece(i), m);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned other = (unsigned)__shfl_xor((int)m, o);
         m = other > m ? other : m;
     }
-    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
+    // one atomic per workgroup, and only when it can raise the word: thousands of atomics on one address serialise in the L2
+    __shared__ unsigned wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned a01 = wm[0] > wm[1] ? wm[0] : wm[1], a23 = wm[2] > wm[3] ? wm[2] : wm[3];
+        const unsigned bm = a01 > a23 ? a01 : a23;
+        if (bm > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bm);
+    }
 }
 extern "C" int cvk_absmax_f32(const float* x, long rows, int C, int ld, void* amax_bits, void* stream) {
     CVK_CHECK_ARG(x && amax_bits && rows > 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0, "cvk_absmax_f32: bad arguments (C, ld multiples of 4)");
     CVK_CHECK_ARG(cvk_aligned16(x), "cvk_absmax_f32: x must be 16-byte aligned");
     const long total = rows * (C / 4);
-    const int blocks = (int)((total + 1023) / 1024 < 2048 ? (total + 1023) / 1024 : 2048);
-    hipLaunchKernelGGL(k_absmax, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, x, rows, C, ld, (unsigned*)amax_bits);
+    const long want = (total + 1023) / 1024;                // four pieces per thread and round
+    const int blocks = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+    if (ld == C) hipLaunchKernelGGL(k_absmax<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, rows, C, ld, (unsigned*)amax_bits);
+    else hipLaunchKernelGGL(k_absmax<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, rows, C, ld, (unsigned*)amax_bits);
     CVK_LAUNCH_RETURN("cvk_absmax_f32");
 }
 
