@@ -177,9 +177,12 @@ int cvk_w6_gemm_tn(const float* E, const float* V, float* P, int T, int Cin_pad,
  * GEMM stage above on the 16-bit matrix pipe with split fp32 operands, accumulated in fp32 (csrc/split3.hip, csrc/split_fmt.h, tools/study/).
  *   fmt 3: x = x1 + x2 + x3 in bf16, the six largest cross-products (v_mfma_f32_16x16x32_bf16): fp32-MFMA accuracy at 0.375 of its matrix time;
  *   fmt 2: 2^e * x = h1 + h2 in fp16, three cross-products (v_mfma_f32_16x16x32_f16): 0.19 of the matrix time.  The power-of-two scale per
- *          transform index comes from the EXACT largest magnitude of the tensor a transform reads (cvk_absmax_f32 -> one word in device
- *          memory, combined by atomicMax: zero it first) and the absolute row sums of the transform matrix, so no element can leave fp16's
- *          range whatever the data; the GEMMs undo the scale exactly.  cvk_split_scale_exponent (host) returns e for (tile, kind, xi, word):
+ *          transform index comes from the EXACT largest magnitude of the tensor a transform reads and the absolute row sums of the transform
+ *          matrix, so no element can leave fp16's range whatever the data; the GEMMs undo the scale exactly.  The magnitude lives in an "amax
+ *          block" of device memory: cvk_amax_block_words() 32-bit words (8 slots one cache line apart, each an atomicMax of fp32 bit patterns —
+ *          one hot word would serialise tens of thousands of waves in the L2; the value is the maximum over the slots, cvk_amax_block_value on a
+ *          host copy).  Zero the block, then cvk_absmax_f32 (a pass over the tensor) or the *_amax variants of the passes that WRITE the tensor
+ *          (below) fill it; every `amax*` argument of this section is such a block.  cvk_split_scale_exponent (host) returns e for (tile, kind, xi, word):
  *          kind 0 = B (input transforms V, V'), 1 = G (filters U), 2 = A (dy -> E).
  * Split planes: 16-bit [NX][C/32][fmt][Rpad][32] (Rpad = cvk_split3_rows_pad(R, 256) for V / V' / E, (R, 128) for U; C % 32 == 0).
  * cvk_split_planes / cvk_split3_planes: fp32 planes P[NX][R][C] -> split planes (a stand-alone pass: tests and studies).
@@ -188,8 +191,10 @@ int cvk_w6_gemm_tn(const float* E, const float* V, float* P, int T, int Cin_pad,
 int cvk_split3_rows_pad(int R, int mult);
 int cvk_split3_planes(const float* P, void* S, int NX, int R, int Rpad, int C, void* stream);
 int cvk_w2d_gemm_split3(const void* V3, const void* U3, float* Mo, int NX, int T, int Tpad, int Cin, int Cout, int Cpad, void* stream);
-int cvk_absmax_f32(const float* x, long rows, int C, int ld, void* amax_word, void* stream);
-int cvk_split_scale_exponent(int tile, int kind, int xi, unsigned amax_word);
+int cvk_amax_block_words(void);
+unsigned cvk_amax_block_value(const unsigned* host_words, int n);
+int cvk_absmax_f32(const float* x, long rows, int C, int ld, void* amax_block, void* stream);
+int cvk_split_scale_exponent(int tile, int kind, int xi, unsigned amax_block);
 int cvk_split_planes(int fmt, int tile, int kind, const float* P, void* S, const void* amax, int NX, int R, int Rpad, int C, void* stream);
 int cvk_w2d_gemm_split(int fmt, int tile, const void* V, const void* U, float* Mo, const void* amax_v, const void* amax_u, int NX, int T, int Tpad,
                        int Cin, int Cout, int Cpad, void* stream);
@@ -337,6 +342,16 @@ typedef struct cvk_colsum_job { const float* part; float* out; int PB, C; } cvk_
 int cvk_colsum_finalize_batch(const cvk_colsum_job* jobs, int n, void* stream);
 /* backward, pass 2: dy = scale*(g - dbeta/M - xhat*dgamma/M) (training) or dy = scale*g (eval: use_batch_stats=0);
  *   also emits column-sum partials of dy (conv bias gradient) into dbias_part float[PB][C] when non-NULL. */
+/* Variants that also leave the EXACT largest magnitude they write in a device word (atomicMax of fp32 bit patterns; the caller zeroes the word
+ * first) — what cvk_absmax_f32 of the written tensor would return, without the extra pass.  The opt-in fp16 split-operand path
+ * (cvk_w2d_*_split with fmt 2) scales its planes by these words.  cvk_bn_relu_apply_pool_amax: either word may be NULL. */
+int cvk_bn_relu_apply_amax(const float* y, int ldy, const float* scale, const float* shift, cvk_view out, int N, int H, int W, int C,
+                           void* amax_block, void* stream);
+int cvk_bn_relu_apply_pool_amax(const float* y, int ldy, const float* scale, const float* shift, cvk_view out, float* pool,
+                                unsigned char* code, int N, int H, int W, int C, void* amax_out, void* amax_pool, void* stream);
+int cvk_bn_bwd_dx_amax(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
+                       const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* dbias_part, int N,
+                       int H, int W, int C, int use_batch_stats, void* amax_block, void* stream);
 int cvk_bn_bwd_dx(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift,
                   const float* mean, const float* rstd, const float* dgamma, const float* dbeta,
                   float* dy, int ld_dy, float* dbias_part, int N, int H, int W, int C, int use_batch_stats, void* stream);

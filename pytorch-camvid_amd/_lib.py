@@ -105,6 +105,8 @@ SIGNATURES = {
     "cvk_w2d_output_plain": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_w2d_gemm_tn_split3_ksplit": (c_int, [c_int, c_int, c_int, c_int]),
     "cvk_w2d_gemm_tn_split3": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_amax_block_words": (c_int, []),
+    "cvk_amax_block_value": (ctypes.c_uint, [c_vp, c_int]),
     "cvk_absmax_f32": (c_int, [c_vp, ctypes.c_long, c_int, c_int, c_vp, c_vp]),
     "cvk_split_scale_exponent": (c_int, [c_int, c_int, c_int, ctypes.c_uint]),
     "cvk_split_planes": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
@@ -142,6 +144,10 @@ SIGNATURES = {
     "cvk_colsum_finalize_batch": (c_int, [c_vp, c_int, c_vp]),            # jobs: host array of ColsumJob
     "cvk_bn_bwd_dx": (c_int, [View, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp,
                               c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_bn_relu_apply_amax": (c_int, [c_vp, c_int, c_vp, c_vp, View, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "cvk_bn_relu_apply_pool_amax": (c_int, [c_vp, c_int, c_vp, c_vp, View, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "cvk_bn_bwd_dx_amax": (c_int, [View, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp,
+                                   c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "cvk_maxpool2x2_fwd": (c_int, [View, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_maxpool2x2_bwd": (c_int, [c_vp, View, c_vp, View, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_maxunpool2x2_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),

@@ -172,10 +172,12 @@ template <> __device__ __forceinline__ void vset<1>(float& v, int, float x) { v 
 template <int V>
 __global__ __launch_bounds__(256) void k_bn_relu_apply(const float* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, float* __restrict__ out, PixMap om,
-                                                      int M, int C) {
+                                                      int M, int C, unsigned* __restrict__ amax) {
     typedef typename Vec<V>::T VT;
     const int cvn = C / V;  // vectors per pixel
     const long total = (long)M * cvn;
+    float mx = 0.f;         // the largest activation this thread wrote (>= 0 behind the ReLU)
+    const unsigned snap = cvk_amax_snapshot(amax);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int m = (int)(i / cvn);
         const int c = (int)(i - (long)m * cvn) * V;
@@ -184,9 +186,14 @@ __global__ __launch_bounds__(256) void k_bn_relu_apply(const float* __restrict__
         const VT sh = *reinterpret_cast<const VT*>(shift + c);
         VT o;
 #pragma unroll
-        for (int j = 0; j < V; ++j) vset<V>(o, j, fmaxf(vget<V>(v, j) * vget<V>(sc, j) + vget<V>(sh, j), 0.f));
+        for (int j = 0; j < V; ++j) {
+            const float r = fmaxf(vget<V>(v, j) * vget<V>(sc, j) + vget<V>(sh, j), 0.f);
+            vset<V>(o, j, r);
+            mx = fmaxf(mx, r);
+        }
         *reinterpret_cast<VT*>(out + om.off(m) + c) = o;
     }
+    if (amax != nullptr) cvk_amax_publish_wg(mx, amax, snap);    // consumed by the opt-in fp16 split-operand transforms (csrc/split_fmt.h)
 }
 
 // BN-apply + ReLU with the 2x2 max pool of the result fused in (nn.MaxPool2d(2,2) directly behind a conv block:
@@ -196,9 +203,11 @@ __global__ __launch_bounds__(256) void k_bn_relu_apply(const float* __restrict__
 __global__ __launch_bounds__(256) void k_bn_relu_apply_pool(const float* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, float* __restrict__ out, PixMap om,
                                                            float* __restrict__ pool, unsigned char* __restrict__ code, int N, int H,
-                                                           int W, int C) {
+                                                           int W, int C, unsigned* __restrict__ amax_out, unsigned* __restrict__ amax_pool) {
     const int cvn = C >> 2, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Ho = H >> 1, Wo = W >> 1;
     const long total = (long)N * Hc * Wc * cvn;
+    float mxo = 0.f, mxp = 0.f;         // largest activation / largest pooled value this thread wrote
+    const unsigned snapo = cvk_amax_snapshot(amax_out), snapp = cvk_amax_snapshot(amax_pool);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int cv = (int)(i % cvn);
         long t = i / cvn;
@@ -216,7 +225,10 @@ __global__ __launch_bounds__(256) void k_bn_relu_apply_pool(const float* __restr
                 const int m = (n * H + yy) * W + xx;
                 const f32x4 a = *reinterpret_cast<const f32x4*>(y + (size_t)m * ldy + c);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[k][j] = fmaxf(a[j] * sc[j] + sh[j], 0.f);
+                for (int j = 0; j < 4; ++j) {
+                    v[k][j] = fmaxf(a[j] * sc[j] + sh[j], 0.f);
+                    mxo = fmaxf(mxo, v[k][j]);
+                }
                 *reinterpret_cast<f32x4*>(out + om.off(m) + c) = v[k];
             }
         }
@@ -232,12 +244,16 @@ __global__ __launch_bounds__(256) void k_bn_relu_apply_pool(const float* __restr
                 }
             const long o = (((long)n * Ho + yc) * Wo + xc) * C + c;
             *reinterpret_cast<f32x4*>(pool + o) = best;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mxp = fmaxf(mxp, best[j]);
             if (code != nullptr) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) code[o + j] = cd[j];
             }
         }
     }
+    if (amax_out != nullptr) cvk_amax_publish_wg(mxo, amax_out, snapo);
+    if (amax_pool != nullptr) { __syncthreads(); cvk_amax_publish_wg(mxp, amax_pool, snapp); }
 }
 
 // ---------------------------------------------------------------------------------------------- backward
@@ -249,9 +265,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dout, 
                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                float* __restrict__ dy, int ld_dy, float* __restrict__ part, int M, int C,
-                                               int rows, int PB, int cchunk, int use_batch_stats) {
+                                               int rows, int PB, int cchunk, int use_batch_stats, unsigned* __restrict__ amax) {
     typedef typename Vec<V>::T VT;
     __shared__ float red[2][256 * V];
+    float mx = 0.f;                       // MODE 1 with amax: the largest |dy| this thread wrote
+    const unsigned snap = MODE == 1 ? cvk_amax_snapshot(amax) : 0u;
     const int c0 = blockIdx.y * cchunk;
     const int cw = min(cchunk, C - c0);  // channels handled by this block column
     const int cvn = cw / V;               // vectors per pixel in this chunk (cw % V == 0 by construction)
@@ -296,11 +314,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd(const float* __restrict__ dout, 
                     const float r = vget<V>(sc, j) * (g - k1[j] - xh * k2[j]);
                     vset<V>(o, j, r);
                     s0[j] += r;
+                    mx = fmaxf(mx, fabsf(r));
                 }
             }
             if (MODE == 1) *reinterpret_cast<VT*>(dy + (size_t)m * ld_dy + c) = o;
         }
     }
+    if (MODE == 1 && amax != nullptr) cvk_amax_publish(mx, amax, snap);      // the split-operand consumer scales by the exact maximum (csrc/split_fmt.h)
     if (part == nullptr) return;
     // block combine: threads with equal cv, fixed order over pr
 #pragma unroll
@@ -549,35 +569,63 @@ extern "C" int cvk_bn_eval_params(const float* gamma, const float* beta, const f
     CVK_LAUNCH_RETURN("cvk_bn_eval_params");
 }
 
+static int bn_relu_apply_launch(const char* who, const float* y, int ldy, const float* scale, const float* shift, cvk_view out, int N, int H,
+                                int W, int C, void* amax, void* stream);
 extern "C" int cvk_bn_relu_apply(const float* y, int ldy, const float* scale, const float* shift, cvk_view out, int N, int H,
                                  int W, int C, void* stream) {
-    CVK_CHECK_ARG(y && scale && shift && out.ptr, "cvk_bn_relu_apply: null pointer");
-    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && ldy >= C && (long)N * H * W < (1L << 31), "cvk_bn_relu_apply: bad shape");
+    return bn_relu_apply_launch("cvk_bn_relu_apply", y, ldy, scale, shift, out, N, H, W, C, nullptr, stream);
+}
+// ... that also combines the largest activation it writes into *amax_block (atomicMax of fp32 bit patterns; the caller zeroes the word): what
+// cvk_absmax_f32 of the written view would return, without the extra pass (the opt-in fp16 split-operand transforms scale by it)
+extern "C" int cvk_bn_relu_apply_amax(const float* y, int ldy, const float* scale, const float* shift, cvk_view out, int N, int H,
+                                      int W, int C, void* amax_block, void* stream) {
+    CVK_CHECK_ARG(amax_block, "cvk_bn_relu_apply_amax: null amax_block");
+    return bn_relu_apply_launch("cvk_bn_relu_apply_amax", y, ldy, scale, shift, out, N, H, W, C, amax_block, stream);
+}
+static int bn_relu_apply_launch(const char* who, const float* y, int ldy, const float* scale, const float* shift, cvk_view out, int N, int H,
+                                int W, int C, void* amax, void* stream) {
+    CVK_CHECK_ARG(y && scale && shift && out.ptr, "%s: null pointer", who);
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && ldy >= C && (long)N * H * W < (1L << 31), "%s: bad shape", who);
     const int M = N * H * W;
     const PixMap om = make_map(out, H, W);
     const bool v4 = vec_ok(y, out.ptr, scale, ldy, 0, C, &om) && cvk_aligned16(shift);
     const long total = (long)M * (v4 ? C / 4 : C);
-    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    const int cap = amax ? 2048 : 16384;        // with the maximum: one full round of longer-lived workgroups (the publish is per workgroup)
+    const int blocks = (int)((total + 255) / 256 < cap ? (total + 255) / 256 : cap);
     if (v4)
-        hipLaunchKernelGGL(k_bn_relu_apply<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, ldy, scale, shift, out.ptr, om, M, C);
+        hipLaunchKernelGGL(k_bn_relu_apply<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, ldy, scale, shift, out.ptr, om, M, C, (unsigned*)amax);
     else
-        hipLaunchKernelGGL(k_bn_relu_apply<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, ldy, scale, shift, out.ptr, om, M, C);
-    CVK_LAUNCH_RETURN("cvk_bn_relu_apply");
+        hipLaunchKernelGGL(k_bn_relu_apply<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, ldy, scale, shift, out.ptr, om, M, C, (unsigned*)amax);
+    CVK_LAUNCH_RETURN(who);
 }
 
 // BN-apply + ReLU + MaxPool2d(2,2) of the result (pool [N][H/2][W/2][C] dense, code optional: as cvk_maxpool2x2_fwd).  4-channel
 // vector layout only (CVK_EINVAL otherwise: the caller then runs cvk_bn_relu_apply + cvk_maxpool2x2_fwd).
+static int bn_relu_apply_pool_launch(const char* who, const float* y, int ldy, const float* scale, const float* shift, cvk_view out, float* pool,
+                                     unsigned char* code, int N, int H, int W, int C, void* amax_out, void* amax_pool, void* stream);
 extern "C" int cvk_bn_relu_apply_pool(const float* y, int ldy, const float* scale, const float* shift, cvk_view out, float* pool,
                                       unsigned char* code, int N, int H, int W, int C, void* stream) {
-    CVK_CHECK_ARG(y && scale && shift && out.ptr && pool, "cvk_bn_relu_apply_pool: null pointer");
-    CVK_CHECK_ARG(N > 0 && H >= 2 && W >= 2 && C > 0 && ldy >= C && (long)N * H * W < (1L << 31), "cvk_bn_relu_apply_pool: bad shape");
+    return bn_relu_apply_pool_launch("cvk_bn_relu_apply_pool", y, ldy, scale, shift, out, pool, code, N, H, W, C, nullptr, nullptr, stream);
+}
+// ... with the largest activation written through `out` and the largest pooled value combined into two words (either may be NULL), as
+// cvk_bn_relu_apply_amax
+extern "C" int cvk_bn_relu_apply_pool_amax(const float* y, int ldy, const float* scale, const float* shift, cvk_view out, float* pool,
+                                           unsigned char* code, int N, int H, int W, int C, void* amax_out, void* amax_pool, void* stream) {
+    return bn_relu_apply_pool_launch("cvk_bn_relu_apply_pool_amax", y, ldy, scale, shift, out, pool, code, N, H, W, C, amax_out, amax_pool, stream);
+}
+static int bn_relu_apply_pool_launch(const char* who, const float* y, int ldy, const float* scale, const float* shift, cvk_view out, float* pool,
+                                     unsigned char* code, int N, int H, int W, int C, void* amax_out, void* amax_pool, void* stream) {
+    CVK_CHECK_ARG(y && scale && shift && out.ptr && pool, "%s: null pointer", who);
+    CVK_CHECK_ARG(N > 0 && H >= 2 && W >= 2 && C > 0 && ldy >= C && (long)N * H * W < (1L << 31), "%s: bad shape", who);
     const PixMap om = make_map(out, H, W);
     const bool v4 = vec_ok(y, out.ptr, scale, ldy, 0, C, &om) && cvk_aligned16(shift) && cvk_aligned16(pool);
-    CVK_CHECK_ARG(v4, "cvk_bn_relu_apply_pool: needs the 4-channel vector layout");
+    CVK_CHECK_ARG(v4, "%s: needs the 4-channel vector layout", who);
     const long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
-    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(k_bn_relu_apply_pool, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, ldy, scale, shift, out.ptr, om, pool, code, N, H, W, C);
-    CVK_LAUNCH_RETURN("cvk_bn_relu_apply_pool");
+    const int cap = (amax_out || amax_pool) ? 2048 : 16384;
+    const int blocks = (int)((total + 255) / 256 < cap ? (total + 255) / 256 : cap);
+    hipLaunchKernelGGL(k_bn_relu_apply_pool, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, ldy, scale, shift, out.ptr, om, pool, code, N, H, W, C,
+                       (unsigned*)amax_out, (unsigned*)amax_pool);
+    CVK_LAUNCH_RETURN(who);
 }
 
 extern "C" int cvk_bn_bwd_blocks(int M) {
@@ -590,7 +638,7 @@ extern "C" int cvk_bn_bwd_blocks(int M) {
 
 static int bn_bwd_launch(int mode, cvk_view dout, const float* y, int ldy, const float* scale, const float* shift,
                          const float* mean, const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy,
-                         float* part, int N, int H, int W, int C, int use_batch_stats, void* stream, const char* name) {
+                         float* part, int N, int H, int W, int C, int use_batch_stats, void* stream, const char* name, void* amax = nullptr) {
     CVK_CHECK_ARG(dout.ptr && y && scale && shift && mean && rstd, "%s: null pointer", name);
     CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && ldy >= C && (long)N * H * W < (1L << 31), "%s: bad shape", name);
     const int M = N * H * W;
@@ -604,7 +652,7 @@ static int bn_bwd_launch(int mode, cvk_view dout, const float* y, int ldy, const
     hipStream_t s = (hipStream_t)stream;
 #define CVK_BWD(V_, MODE_)                                                                                              \
     hipLaunchKernelGGL((k_bn_bwd<V_, MODE_>), grid, dim3(256), 0, s, dout.ptr, dm, y, ldy, scale, shift, mean, rstd, dgamma, \
-                       dbeta, dy, ld_dy, part, M, C, rows, PB, cchunk, use_batch_stats)
+                       dbeta, dy, ld_dy, part, M, C, rows, PB, cchunk, use_batch_stats, (unsigned*)amax)
     if (mode == 0) { if (v4) CVK_BWD(4, 0); else CVK_BWD(1, 0); }
     else { if (v4) CVK_BWD(4, 1); else CVK_BWD(1, 1); }
 #undef CVK_BWD
@@ -625,6 +673,17 @@ extern "C" int cvk_bn_bwd_dx(cvk_view dout, const float* y, int ldy, const float
     CVK_CHECK_ARG(!use_batch_stats || (dgamma && dbeta), "cvk_bn_bwd_dx: dgamma/dbeta required in training mode");
     return bn_bwd_launch(1, dout, y, ldy, scale, shift, mean, rstd, dgamma, dbeta, dy, ld_dy, dbias_part, N, H, W, C,
                          use_batch_stats, stream, "cvk_bn_bwd_dx");
+}
+
+// cvk_bn_bwd_dx that also combines the largest |dy| it writes into *amax_block (atomicMax of fp32 bit patterns; the caller zeroes the word):
+// what cvk_absmax_f32(dy) would return, without the extra pass (the opt-in fp16 split-operand GEMMs scale by it: csrc/split_fmt.h)
+extern "C" int cvk_bn_bwd_dx_amax(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
+                                  const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* dbias_part,
+                                  int N, int H, int W, int C, int use_batch_stats, void* amax_block, void* stream) {
+    CVK_CHECK_ARG(dy && ld_dy >= C && amax_block, "cvk_bn_bwd_dx_amax: bad dy / amax_block");
+    CVK_CHECK_ARG(!use_batch_stats || (dgamma && dbeta), "cvk_bn_bwd_dx_amax: dgamma/dbeta required in training mode");
+    return bn_bwd_launch(1, dout, y, ldy, scale, shift, mean, rstd, dgamma, dbeta, dy, ld_dy, dbias_part, N, H, W, C,
+                         use_batch_stats, stream, "cvk_bn_bwd_dx_amax", amax_block);
 }
 
 // Fused variant of cvk_bn_bwd_dx for layers whose weight-grad runs through the transposed F(4,3): also writes the planes

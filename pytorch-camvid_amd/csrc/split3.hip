@@ -125,7 +125,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__
     constexpr int S3_XT = FMT * S3_TM * 64;                 // 48 (32) KiB: the V terms of a slice
     constexpr int S3_WT = FMT * S3_TN * 64;                 // 24 (16) KiB: the U terms
     constexpr int S3_STAGE = S3_XT + S3_WT;                 // 72 (48) KiB
-    __shared__ __attribute__((aligned(1024))) char smem[2 * S3_STAGE];
+    // stages: two of 72 KiB for three terms; THREE of 48 KiB for two terms — a two-term MFMA phase lasts ~0.4 us, so a slice requested 1.5
+    // phases ahead (two stages) has not crossed the fabric when it is wanted; with three stages it is requested 3.5 phases ahead and the wait
+    // at the end of an MFMA phase leaves the youngest slice in flight (counted vmcnt)
+    constexpr int NST = FMT == 2 ? 3 : 2;
+    __shared__ __attribute__((aligned(1024))) char smem[NST * S3_STAGE];
     const unsigned smem_addr = cvk_lds_addr(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,6 +141,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__
     const int nt = bid % tilesN;
     const int mt = (bid / tilesN) % tilesM;
     const int xi = bid / (tilesN * tilesM);
+    // FMT 2: both operands carry a power-of-two scale per transform index (split_fmt.h); undoing it is exact.  The exponents come from the two
+    // amax blocks: read here, under the first slice's flight, not in the epilogue
+    const int unscale_exp = FMT == 2 ? -(cvk_split_exp_xi(amaxV, tabV, xi) + cvk_split_exp_xi(amaxU, tabU, xi)) : 0;
 
     // ---- DMA: this wave moves pieces wi and wi + 4 (1 KiB each) of every term of its group's 128 V rows; group A also of the U tile
     const size_t xterm = (size_t)Tpad * 64, wterm = (size_t)Cpad * 64;          // bytes between two terms of one slice
@@ -172,7 +179,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__
     const int sw = (q4 ^ (((l15 >> 2) & 1) << 1)) << 4;
     int wa = S3_XT + (wc * 64 + l15) * 64 + sw;             // + term * 8192 + rb * 1024
     int xa = (grp * 128 + wp * 64 + l15) * 64 + sw;         // + term * 16384 + cb * 1024
-    int flip = S3_STAGE;
+    int so = 0;                                 // byte offset of the stage being read
+    unsigned dso = 0;                           // ... of the stage the next request goes to
+    // DMA instructions of one slice for this wave (what a counted wait leaves in flight)
+    auto wait_keep_one_slice = [&]() {
+        if (FMT == 3) { if (grp == 0) cvk_wait_vm<12>(); else cvk_wait_vm<6>(); }
+        else          { if (grp == 0) cvk_wait_vm<8>(); else cvk_wait_vm<4>(); }
+    };
 
     f32x4v acc[4][4];
 #pragma unroll
@@ -181,21 +194,31 @@ __global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     issue_slice(0);
-    cvk_wait_vm<0>();
+    dso = S3_STAGE;
+    if (NST == 3 && ncs > 1) {
+        issue_slice(dso);
+        dso = 2 * S3_STAGE;
+        wait_keep_one_slice();
+    } else {
+        cvk_wait_vm<0>();
+    }
     pbar();
     if (grp == 1) pbar();                       // group B runs one interval behind group A
 
     for (int cs = 0; cs < ncs; ++cs) {
-        // ======== LOAD phase: request the next slice into the other stage (everybody read it out two phases ago), read this slice's
-        // 24 fragments
-        if (cs + 1 < ncs) issue_slice(((cs + 1) & 1) ? S3_STAGE : 0);
+        // ======== LOAD phase: request slice cs + NST - 1 into the stage everybody read out two phases ago, read this slice's fragments
+        const bool more = cs + NST - 1 < ncs;
+        if (more) {
+            issue_slice(dso);
+            dso = dso + S3_STAGE == (unsigned)(NST * S3_STAGE) ? 0u : dso + S3_STAGE;
+        }
         FR w[FMT][4], x[FMT][4];
 #pragma unroll
         for (int k = 0; k < FMT; ++k) {
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) w[k][rb] = rd16<FR>(smem + (wa + k * 8192 + rb * 1024));
+            for (int rb = 0; rb < 4; ++rb) w[k][rb] = rd16<FR>(smem + (wa + so + k * 8192 + rb * 1024));
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) x[k][cb] = rd16<FR>(smem + (xa + k * 16384 + cb * 1024));
+            for (int cb = 0; cb < 4; ++cb) x[k][cb] = rd16<FR>(smem + (xa + so + k * 16384 + cb * 1024));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         pbar();
@@ -208,17 +231,17 @@ __global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__
                 for (int cb = 0; cb < 4; ++cb)
                     acc[rb][cb] = OPS::mfma(w[kw][rb], x[kx][cb], acc[rb][cb]);
         });
-        wa += flip; xa += flip; flip = -flip;
+        so = so + S3_STAGE == NST * S3_STAGE ? 0 : so + S3_STAGE;
         __builtin_amdgcn_s_setprio(0);
-        cvk_wait_vm<0>();                       // this wave's pieces of the next slice have landed (requested ~1.5 phases ago)
+        // this wave's pieces of the next slice have landed; with three stages the slice after it (requested in this LOAD phase) stays in flight
+        if (NST == 3 && more) wait_keep_one_slice(); else cvk_wait_vm<0>();
         pbar();
     }
     if (grp == 0) pbar();
 
     // ---- epilogue: acc[rb][cb][j] = M[t = mt*256 + grp*128 + wp*64 + cb*16 + l15][co = nt*128 + wc*64 + rb*16 + 4*q4 + j]
     float* const mo = Mo + (size_t)xi * T * Cout;
-    // FMT 2: both operands carry a power-of-two scale per transform index (split_fmt.h); undoing it is exact
-    const CvkUnscale un = FMT == 2 ? cvk_unscale(-(cvk_split_exp_xi(amaxV, tabV, xi) + cvk_split_exp_xi(amaxU, tabU, xi))) : CvkUnscale{1.f, 1.f};
+    const CvkUnscale un = cvk_unscale(unscale_exp);
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
         const int t = mt * S3_TM + grp * 128 + wp * 64 + cb * 16 + l15;
@@ -248,7 +271,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_split3(const char* __restric
     typedef typename OPS::frag FR;
     constexpr int X256 = 8 * FMT * 2048, X128 = 4 * FMT * 2048;       // 48 (32) KiB + 24 (16) KiB per stage
     constexpr int STAGE = X256 + X128;
-    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+    constexpr int NST = FMT == 2 ? 3 : 2;                             // as k_gemm_split3: three stages of 48 KiB for two terms
+    __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
     const unsigned smem_addr = cvk_lds_addr(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -259,6 +283,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_split3(const char* __restric
     const int tci = bid % tilesCi; bid /= tilesCi;
     const int tco = bid % tilesCo;
     const int xi = bid / tilesCo;
+    const int unscale_exp = FMT == 2 ? -(cvk_split_exp_xi(amaxE, tabE, xi) + cvk_split_exp_xi(amaxV, tabV, xi)) : 0;
     const int nK = Tpad >> 5;
     const int k0 = (int)((long)nK * part / f), k1 = (int)((long)nK * (part + 1) / f);
     const int ncsE = Cout >> 5, ncsV = Cin >> 5;
@@ -324,14 +349,28 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_split3(const char* __restric
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-    int st = 0;
+    int so = 0;
+    unsigned dso = STAGE;
+    auto wait_keep_one_slice = [&]() {
+        if (FMT == 3) { if (grp == 0) cvk_wait_vm<12>(); else cvk_wait_vm<6>(); }
+        else          { if (grp == 0) cvk_wait_vm<8>(); else cvk_wait_vm<4>(); }
+    };
     issue_slice(0);
-    cvk_wait_vm<0>();
+    if (NST == 3 && k0 + 1 < k1) {
+        issue_slice(dso);
+        dso = 2 * STAGE;
+        wait_keep_one_slice();
+    } else {
+        cvk_wait_vm<0>();
+    }
     pbar();
     if (grp == 1) pbar();
     for (int ks = k0; ks < k1; ++ks) {
-        if (ks + 1 < k1) issue_slice(st ? 0 : STAGE);
-        const int so = st ? STAGE : 0;
+        const bool more = ks + NST - 1 < k1;
+        if (more) {
+            issue_slice(dso);
+            dso = dso + STAGE == (unsigned)(NST * STAGE) ? 0u : dso + STAGE;
+        }
         FR A[FMT][4], B[FMT][4];
 #pragma unroll
         for (int k = 0; k < FMT; ++k)
@@ -351,8 +390,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_split3(const char* __restric
                     acc[mb][nb] = OPS::mfma(A[ka][mb], B[kb][nb], acc[mb][nb]);
         });
         __builtin_amdgcn_s_setprio(0);
-        st ^= 1;
-        cvk_wait_vm<0>();
+        so = so + STAGE == NST * STAGE ? 0 : so + STAGE;
+        if (NST == 3 && more) wait_keep_one_slice(); else cvk_wait_vm<0>();
         pbar();
     }
     if (grp == 0) pbar();
@@ -361,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_split3(const char* __restric
     const int ci0 = tci * (CO256 ? 128 : 256) + (CO256 ? 64 * wa_ : 128 * grp + 64 * wa_);
     const int co0 = tco * (CO256 ? 256 : 128) + (CO256 ? 128 * grp + 64 * wb_ : 64 * wb_);
     float* const pp = P + ((size_t)part * NX + xi) * Cout * Cin;
-    const CvkUnscale un = FMT == 2 ? cvk_unscale(-(cvk_split_exp_xi(amaxE, tabE, xi) + cvk_split_exp_xi(amaxV, tabV, xi))) : CvkUnscale{1.f, 1.f};
+    const CvkUnscale un = cvk_unscale(unscale_exp);
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         const int co = co0 + nb * 16 + l15;
@@ -407,7 +446,7 @@ extern "C" int cvk_w2d_gemm_split(int fmt, int tile, const void* V, const void* 
     const char* who = "cvk_w2d_gemm_split";
     CVK_SPLIT_FMT_OK(who);
     CVK_CHECK_ARG(V && U && Mo && NX > 0 && T > 0 && Cin > 0 && Cout > 0, "%s: bad arguments", who);
-    CVK_CHECK_ARG(fmt == 3 || (amax_v && amax_u && NX == (tile + 2) * (tile + 2)), "%s: fmt 2 needs both amax words and NX = (tile + 2)^2", who);
+    CVK_CHECK_ARG(fmt == 3 || (amax_v && amax_u && NX == (tile + 2) * (tile + 2)), "%s: fmt 2 needs both amax blocks and NX = (tile + 2)^2", who);
     CVK_CHECK_ARG(Cin % 32 == 0 && Cout % 4 == 0 && Tpad % S3_TM == 0 && Tpad >= T && Cpad % S3_TN == 0 && Cpad >= Cout,
                   "%s: Cin %% 32, Cout %% 4, Tpad %% 256, Cpad %% 128", who);
     CVK_CHECK_ARG(cvk_aligned16(V) && cvk_aligned16(U) && cvk_aligned16(Mo), "%s: pointers must be 16-byte aligned", who);
@@ -446,7 +485,7 @@ extern "C" int cvk_w2d_gemm_tn_split(int fmt, int tile, const void* E, const voi
     const char* who = "cvk_w2d_gemm_tn_split";
     CVK_SPLIT_FMT_OK(who);
     CVK_CHECK_ARG(E && V && P && NX > 0 && Tpad > 0 && Tpad % 256 == 0, "%s: bad arguments", who);
-    CVK_CHECK_ARG(fmt == 3 || (amax_e && amax_v && NX == (tile + 2) * (tile + 2)), "%s: fmt 2 needs both amax words and NX = (tile + 2)^2", who);
+    CVK_CHECK_ARG(fmt == 3 || (amax_e && amax_v && NX == (tile + 2) * (tile + 2)), "%s: fmt 2 needs both amax blocks and NX = (tile + 2)^2", who);
     const bool co256 = Cout % 256 == 0 && Cin % 128 == 0;
     CVK_CHECK_ARG(co256 || (Cin % 256 == 0 && Cout % 128 == 0), "%s: needs Cout %% 256 == 0 and Cin %% 128 == 0, or the reverse", who);
     CVK_CHECK_ARG(cvk_aligned16(E) && cvk_aligned16(V) && cvk_aligned16(P), "%s: pointers must be 16-byte aligned", who);

@@ -195,7 +195,7 @@ __device__ __forceinline__ SplitDst split_dst(void* S, int C, int Rpad, int t, i
     d.term = (size_t)Rpad * 32;
     d.xstride = (size_t)ncs * FMT * d.term;
     d.base = reinterpret_cast<unsigned short*>(S) + ((size_t)cs * FMT * Rpad + t) * 32 + pos * 8 + (cl & 7);
-    d.amax = FMT == 2 ? *amax : 0u;
+    d.amax = FMT == 2 ? cvk_amax_read(amax) : 0u;
     d.tab = tab;
     return d;
 }
@@ -352,7 +352,7 @@ __device__ __forceinline__ void w2d_weight_body(const float* __restrict__ Wt, fl
 template <int MT, int SPL = 0>
 __global__ __launch_bounds__(256) void k_w2d_weight(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci, const unsigned* __restrict__ amax,
                                                    CvkSplitTab tab) {
-    w2d_weight_body<MT, SPL>(Wt, U, Co, Ci, blockIdx.x, gridDim.x, SPL == 2 ? *amax : 0u, tab);
+    w2d_weight_body<MT, SPL>(Wt, U, Co, Ci, blockIdx.x, gridDim.x, SPL == 2 ? cvk_amax_read(amax) : 0u, tab);
 }
 
 // ---- data-grad filter straight from the forward weights: U [NX][Ci][Co] = G w'[ci][.][.][co] G^T with w'[ci][r][s][co] =
@@ -407,7 +407,7 @@ template <int MT, int SPL = 0>
 __global__ __launch_bounds__(256) void k_w2d_weight_dgrad(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci, const unsigned* __restrict__ amax,
                                                          CvkSplitTab tab) {
     __shared__ float t[9][32][33];
-    w2d_weight_dgrad_body<MT, SPL>(Wt, U, Co, Ci, blockIdx.x, blockIdx.y, t, SPL == 2 ? *amax : 0u, tab);
+    w2d_weight_dgrad_body<MT, SPL>(Wt, U, Co, Ci, blockIdx.x, blockIdx.y, t, SPL == 2 ? cvk_amax_read(amax) : 0u, tab);
 }
 
 // All 2-D Winograd filter transforms of a step (forward and data-grad filters, both tile sizes) in ONE launch: job j owns the blocks
@@ -1168,7 +1168,8 @@ extern "C" int cvk_split_scale_exponent(int tile, int kind, int xi, unsigned ama
     return cvk_split_exp(amax_bits, cvk_split_tab_c(t, xi / t.nt), cvk_split_tab_c(t, xi % t.nt));
 }
 
-// largest magnitude of x [rows][C] (row stride ld) as an fp32 bit pattern, combined into *amax_bits by atomicMax: the caller zeroes the word.
+// largest magnitude of x [rows][C] (row stride ld) as an fp32 bit pattern, combined into the amax block (cvk_common.h) by atomicMax: the caller
+// zeroes the block (cvk_amax_block_words() words).
 // Magnitudes order like their bit patterns, so the maximum is exact and independent of the order (bitwise reproducible).  Four 16-byte loads
 // per thread in flight; a dense tensor (ld == C) is walked as one flat array.
 typedef unsigned u32x4a __attribute__((ext_vector_type(4)));
@@ -1200,15 +1201,23 @@ __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ X, lon
         const unsigned other = (unsigned)__shfl_xor((int)m, o);
         m = other > m ? other : m;
     }
-    // one atomic per workgroup, and only when it can raise the word: thousands of atomics on one address serialise in the L2
+    // one atomic per workgroup, into the slot of its number, and only when it can raise it (cvk_common.h, amax blocks)
     __shared__ unsigned wm[4];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned a01 = wm[0] > wm[1] ? wm[0] : wm[1], a23 = wm[2] > wm[3] ? wm[2] : wm[3];
         const unsigned bm = a01 > a23 ? a01 : a23;
-        if (bm > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bm);
+        unsigned* const slot = out + (size_t)(blockIdx.x % CVK_AMAX_SLOTS) * CVK_AMAX_STRIDE;
+        if (bm > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, bm);
     }
+}
+extern "C" int cvk_amax_block_words(void) { return CVK_AMAX_WORDS; }
+// the value of an amax block copied to the host (n = cvk_amax_block_words() words): the maximum over its slots
+extern "C" unsigned cvk_amax_block_value(const unsigned* host_words, int n) {
+    unsigned m = 0u;
+    for (int i = 0; i + 1 <= n; i += CVK_AMAX_STRIDE) m = host_words[i] > m ? host_words[i] : m;
+    return m;
 }
 extern "C" int cvk_absmax_f32(const float* x, long rows, int C, int ld, void* amax_bits, void* stream) {
     CVK_CHECK_ARG(x && amax_bits && rows > 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0, "cvk_absmax_f32: bad arguments (C, ld multiples of 4)");

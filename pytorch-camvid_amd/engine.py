@@ -94,6 +94,9 @@ class RunState:
         self.wreduces = []          # queued weight-gradient slab reductions of the bf16 path (Runner.defer_wreduce)
         self.pass_token = 0         # derived-weight cache token of this pass (Runner.forward)
         self.bnred = {}             # op index of a conv block -> (partials, count): its BN-backward sums, left by the consumer's data-grad
+        self.amax = {}              # buf.id -> amax block (device int32 words): the largest magnitude written into the buffer, left by the passes
+                                    # that write it (opt-in fp16 split-operand layers scale by it: Runner.plan_amax)
+        self.amax_spare = []        # zeroed amax blocks for the backward pass (|dy| maxima)
 
 
 def _empty(n, dev, dtype=_F32):
@@ -208,6 +211,14 @@ def wgradp_pays(N, H, W, cin_ld, cout):
     return cin_ld == 64 and N * H * ((W + 3) // 4) >= 4096
 
 
+def amax_blocks(lib, n, dev):
+    """n zeroed "amax blocks" (csrc/cvk_common.h: the largest magnitude of a tensor in device memory, a few slots one cache line apart): a list of
+    int32 views, one fill for all of them."""
+    nw = lib.cvk_amax_block_words()
+    t = torch.zeros(n * nw, device=dev, dtype=torch.int32)
+    return [t[i * nw:(i + 1) * nw] for i in range(n)]
+
+
 def split_fmt(R):
     """runner.w2d_split as a split-plane format (csrc/split_fmt.h): 0 = off (exact-fp32 MFMA, the default), 3 = three bf16 terms (True means
     this one), 2 = two scaled fp16 terms."""
@@ -216,7 +227,7 @@ def split_fmt(R):
 
 
 def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what="", dgrad_of=None, keep_v=None, wsrc=None, ck=None,
-              bnred=None, v_pre=None, split=False):
+              bnred=None, v_pre=None, split=False, x_amax=None):
     """y[N,H,W,ldy] = conv3x3(x[N,H,W,k_ch], w[cout][3][3][k_ch]) (+bias, +BN statistics partials at sp) through the
     Winograd kernels: weight transform -> (input transform ->) GEMMs M_xi -> output transform.  2-D F(4x4,3x3) for the
     channel-heavy layers (R.wino2d, wino2d_pays), else 1-D F(4,3) when R.wino4, else F(2,3).
@@ -255,7 +266,7 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
             am_w = None
             if fmt == 2:
                 def build_amax_w():
-                    a = torch.zeros(1, device=x.device, dtype=torch.int32)
+                    a = amax_blocks(lib, 1, x.device)[0]
                     _timed(R, "k_absmax", 4.0 * wraw.numel(), lambda: check(
                         lib.cvk_absmax_f32(wraw.data_ptr(), wraw.numel() // 4, 4, 4, a.data_ptr(), s), "cvk_absmax_f32(w)"), "byte")
                     return a
@@ -279,9 +290,9 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
                 V3, am_x = v_pre[1], getattr(v_pre[1], "cvk_amax", None)
             else:
                 V3 = torch.empty(v3fl, device=x.device, dtype=pdt)
-                am_x = None
-                if fmt == 2:
-                    am_x = torch.zeros(1, device=x.device, dtype=torch.int32)
+                am_x = x_amax           # left by the passes that wrote x (Runner.plan_amax), else measured here
+                if fmt == 2 and am_x is None:
+                    am_x = amax_blocks(lib, 1, x.device)[0]
                     _timed(R, "k_absmax", 4.0 * M * k_ch, lambda: check(
                         lib.cvk_absmax_f32(x.data_ptr(), M, k_ch, k_ch, am_x.data_ptr(), s), "cvk_absmax_f32(x)"), "byte")
                 V3.cvk_amax = am_x          # the planes travel with the word they were scaled by (weight-grad GEMM, data-grad GEMM)
@@ -576,7 +587,7 @@ class ConvBnRelu(Op):
             return (Pt, cnt) if sp is not None else None
         if wino_ok(R, src.ld, ldy):
             return wino_conv(R, lib, s, X, wk, b.data_ptr(), y, sp, N, H, W, src.ld, C, ldy, 18.0 * M * C * self.cin, keep_v=keep_v,
-                             wsrc=st.params[4 * self.pslot], ck=(self.pslot, "f"), split=split_fmt(R) if (st.need_grad and st.training and self._split3(R)) else 0)
+                             wsrc=st.params[4 * self.pslot], ck=(self.pslot, "f"), split=split_fmt(R) if (st.need_grad and st.training and self._split3(R)) else 0, x_amax=st.amax.get(src.id))
         else:
             _timed(R, conv_kernel_name("fwd", ldy, src.ld), 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy, s),
@@ -630,16 +641,29 @@ class ConvBnRelu(Op):
             code = None
             if self.pool_op.keep_code:
                 code = torch.empty(self.pool_dst.M * self.pool_dst.ld, device=dev, dtype=torch.uint8)
-            rc = _timed(R, "k_bn_relu_apply<pool>", (8.0 + 1.0 + (0.25 if code is not None else 0.0)) * M * C, lambda: lib.cvk_bn_relu_apply_pool(
-                y.data_ptr(), ldy, psc, psh, dst.cview(out), pool.data_ptr(), code.data_ptr() if code is not None else None,
-                N, H, W, C, s), "byte")
+            aw, ap = st.amax.get(dst.buf.id), st.amax.get(self.pool_dst.id)
+            if aw is not None or ap is not None:
+                rc = _timed(R, "k_bn_relu_apply<pool>", (8.0 + 1.0 + (0.25 if code is not None else 0.0)) * M * C, lambda: lib.cvk_bn_relu_apply_pool_amax(
+                    y.data_ptr(), ldy, psc, psh, dst.cview(out), pool.data_ptr(), code.data_ptr() if code is not None else None,
+                    N, H, W, C, aw.data_ptr() if aw is not None else None, ap.data_ptr() if ap is not None else None, s), "byte")
+            else:
+                rc = _timed(R, "k_bn_relu_apply<pool>", (8.0 + 1.0 + (0.25 if code is not None else 0.0)) * M * C, lambda: lib.cvk_bn_relu_apply_pool(
+                    y.data_ptr(), ldy, psc, psh, dst.cview(out), pool.data_ptr(), code.data_ptr() if code is not None else None,
+                    N, H, W, C, s), "byte")
             pooled = rc == 0
+            if not pooled and ap is not None:
+                st.amax.pop(self.pool_dst.id)          # the separate pool pass writes that buffer: its reader measures it itself
             if pooled and code is not None:
                 st.saved[self.pool_op.idx] = code
         st.pooled_by_block[self.idx] = pooled
         if not pooled:
-            _timed(R, "k_bn_relu_apply", 8.0 * M * C, lambda: check(
-                lib.cvk_bn_relu_apply(y.data_ptr(), ldy, psc, psh, dst.cview(out), N, H, W, C, s), "cvk_bn_relu_apply"), "byte")
+            aw = st.amax.get(dst.buf.id)
+            if aw is not None:
+                _timed(R, "k_bn_relu_apply", 8.0 * M * C, lambda: check(
+                    lib.cvk_bn_relu_apply_amax(y.data_ptr(), ldy, psc, psh, dst.cview(out), N, H, W, C, aw.data_ptr(), s), "cvk_bn_relu_apply_amax"), "byte")
+            else:
+                _timed(R, "k_bn_relu_apply", 8.0 * M * C, lambda: check(
+                    lib.cvk_bn_relu_apply(y.data_ptr(), ldy, psc, psh, dst.cview(out), N, H, W, C, s), "cvk_bn_relu_apply"), "byte")
         if st.need_grad:
             st.saved[self.idx] = (y, bnp, keep_v[0] if keep_v else None)
 
@@ -702,10 +726,18 @@ class ConvBnRelu(Op):
                 R.defer_colsum(st, part, PBe, C, gb)           # conv bias grad: finalised with the others, in one launch
             else:
                 E = None            # layout not vectorisable (strided view): plain pass below, wgrad transforms dy itself
+        am_dy_fused = None
         if E is None and E6 is None:
-            _timed(R, "k_bn_bwd<dx>", 12.0 * M * C, lambda: check(
-                lib.cvk_bn_bwd_dx(dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, part.data_ptr(),
-                                  N, H, W, C, 1 if st.training else 0, s), "cvk_bn_bwd_dx"), "byte")
+            if (split_fmt(R) == 2 and wgrad2d and st.training and Vkept is not None and Vkept.dtype == torch.float16 and st.amax_spare
+                    and self._split3(R)):
+                am_dy_fused = st.amax_spare.pop()       # a zeroed word: the pass that writes dy leaves its largest magnitude there
+                _timed(R, "k_bn_bwd<dx>", 12.0 * M * C, lambda: check(
+                    lib.cvk_bn_bwd_dx_amax(dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, part.data_ptr(),
+                                           N, H, W, C, 1 if st.training else 0, am_dy_fused.data_ptr(), s), "cvk_bn_bwd_dx_amax"), "byte")
+            else:
+                _timed(R, "k_bn_bwd<dx>", 12.0 * M * C, lambda: check(
+                    lib.cvk_bn_bwd_dx(dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, part.data_ptr(),
+                                      N, H, W, C, 1 if st.training else 0, s), "cvk_bn_bwd_dx"), "byte")
             R.defer_colsum(st, part, PB, C, gb)             # conv bias grad: finalised with the others, in one launch
         del y
         # weight-grad AND data-grad on the 2-D path with the same tile: dy is transformed for both in ONE launch (csrc/wino2d.hip
@@ -722,9 +754,9 @@ class ConvBnRelu(Op):
             tag = "split3" if fmt == 3 else "split2h"
             Eb = torch.empty(NX * (C // 32) * fmt * Tp * 32, device=dev, dtype=pdt)
             Vb = torch.empty(NX * (C // 32) * fmt * Tp * 32, device=dev, dtype=pdt)
-            am_dy = None
-            if fmt == 2:
-                am_dy = torch.zeros(1, device=dev, dtype=torch.int32)
+            am_dy = am_dy_fused
+            if fmt == 2 and am_dy is None:
+                am_dy = amax_blocks(lib, 1, dev)[0]
                 _timed(R, "k_absmax", 4.0 * M * C, lambda: check(lib.cvk_absmax_f32(dy.data_ptr(), M, C, ldy, am_dy.data_ptr(), s), "cvk_absmax_f32(dy)"), "byte")
             Eb.cvk_amax = Vb.cvk_amax = am_dy
             _timed(R, "k_w2d_dy<both,%s>" % tag, (4.0 * M + 4.0 * fmt * NX * T) * C, lambda: check(
@@ -1137,6 +1169,9 @@ class Upsample(Op):
             return
         _timed(R, "k_bilinear_fwd", 20.0 * b.M * b.ld, lambda: check(
             R.lib.cvk_bilinear_up2_fwd(X.data_ptr(), out.data_ptr(), b.N, b.H, b.W, b.ld, st.stream), "cvk_bilinear_up2_fwd"), "byte")
+        aw = st.amax.get(self.dst.id)
+        if aw is not None:          # align_corners interpolation is a convex combination: |out| <= max |in| (an upper bound serves the scale)
+            aw.copy_(st.amax[b.id])
 
     def bwd(self, R, st):
         g = st.grad.pop(self.dst.id)
@@ -1458,6 +1493,52 @@ class Runner:
             self._collectives_in_flight = st.sync.in_flight()
 
     # ---- forward / backward -------------------------------------------------------------------------------------
+    def plan_amax(self, plan, st):
+        """fp16 split-operand mode (w2d_split = 2): the transforms of a split layer scale by the EXACT largest magnitude of the tensor they
+        read (csrc/split_fmt.h).  Where every pass that writes a layer's input can leave that maximum on its way (BN-apply passes: csrc/bn.hip
+        *_amax; bilinear upsampling: bounded by its input's maximum; the zero frame), the input's buffer gets a device word here and no extra
+        pass runs; any other input is measured by cvk_absmax_f32 in wino_conv.  One zero fill per step for all words."""
+        if split_fmt(self) != 2 or plan.bf16 or not (st.training and st.need_grad):
+            return
+        layers = [op for op in plan.ops if isinstance(op, ConvBnRelu) and op._split3(self)]
+        if not layers:
+            return
+
+        def writers(buf):
+            out = []
+            for op in plan.ops:
+                if isinstance(op, ConvBnRelu) and (op.dst.buf is buf or (op.pool_dst is buf and op.cout % 4 == 0)):
+                    out.append(op)
+                elif isinstance(op, (MaxPool, Unpool, Upsample)) and op.dst is buf and not (isinstance(op, MaxPool) and op.fused):
+                    out.append(op)
+                elif isinstance(op, ZeroFrame) and op.view.buf is buf:
+                    out.append(op)
+            return out
+
+        want, ok = [], {}
+
+        def fusable(buf):
+            if buf.id in ok:
+                return ok[buf.id]
+            ok[buf.id] = False                      # (cycles cannot occur; guards the recursion anyway)
+            ws = writers(buf)
+            good = bool(ws) and buf is not plan.input
+            for op in ws:
+                if isinstance(op, Upsample):
+                    good = good and fusable(op.src)
+                elif not isinstance(op, (ConvBnRelu, ZeroFrame)):
+                    good = False
+            ok[buf.id] = good
+            if good:
+                want.append(buf)
+            return good
+        for op in layers:
+            fusable(op.src)
+        blocks = amax_blocks(self.lib, len(want) + len(layers), st.device)
+        for i, buf in enumerate(want):
+            st.amax[buf.id] = blocks[i]
+        st.amax_spare = blocks[len(want):]
+
     def tile_for(self, plan):
         """(forward / weight-grad tile, data-grad tile) of the 2-D path for a plan."""
         if self.w2tile_cfg in (4, 6):
@@ -1496,6 +1577,7 @@ class Runner:
             self.prepack_bf16(plan, st, need_grad)
         else:
             self.prebuild_fp32(plan, st, need_grad)
+            self.plan_amax(plan, st)
         for op in plan.ops:
             op.fwd(self, st)
         ov = plan.output

@@ -1,7 +1,7 @@
 """OPT-IN split-operand path, format 2 (csrc/split_fmt.h, csrc/split3.hip; runner.w2d_split = 2 — never the default): the GEMM stage of the
 2-D Winograd path with TWO fp16 terms per fp32 operand, scaled per transform index by an exact power of two derived from the largest
 magnitude of the tensor the transform reads, three cross-products per fp32 product on v_mfma_f32_16x16x32_f16 with fp32 accumulation.
-Through the C ABI against fp64: (1) the maximum pass is exact; (2) the planes hold 2^e x = h1 + h2 to 22 bits with no value outside
+Through the C ABI against fp64: (1) the maximum pass is exact ("amax blocks", csrc/cvk_common.h); (2) the planes hold 2^e x = h1 + h2 to 22 bits with no value outside
 fp16's range whatever the magnitude of the data (1e-30 .. 1e+30) and the exponent is the one cvk_split_scale_exponent reports; (3) the
 batched GEMM and (4) the weight-grad GEMM against the exact-fp32 GEMMs of the default path; (5) a whole conv layer — transform kernels that
 write the planes themselves, split GEMM, plain output pass — against an fp64 convolution of the reference operator (nn.Conv2d(3x3,
@@ -22,9 +22,19 @@ def _lib():
 def _amax(lib, check, t, s, C=None):
     """the cvk_absmax_f32 word of a dense tensor"""
     C = t.shape[-1] if C is None else C
-    a = torch.zeros(1, device=t.device, dtype=torch.int32)
+    a = _block(lib, t.device)
     check(lib.cvk_absmax_f32(t.data_ptr(), t.numel() // C, C, C, a.data_ptr(), s), "cvk_absmax_f32")
     return a
+
+
+def _block(lib, dev):
+    """a zeroed amax block (csrc/cvk_common.h)"""
+    return torch.zeros(lib.cvk_amax_block_words(), device=dev, dtype=torch.int32)
+
+
+def _val(a):
+    """the value of an amax block as a float: the maximum over its slots (bit patterns of non-negative floats order like integers)"""
+    return a[::32].max().view(torch.float32).item()
 
 
 def _unswizzle(S, NX, C, Rp):
@@ -42,18 +52,21 @@ def test_absmax_is_exact_and_combines_by_atomic_max():
     g = torch.Generator().manual_seed(3)
     x = (torch.randn(1000, 52, generator=g) * torch.exp(4 * torch.randn(1000, 52, generator=g))).to(dev)
     a = _amax(lib, check, x, s)
-    assert a.view(torch.float32).item() == x.abs().max().item()
+    assert _val(a) == x.abs().max().item()
     # a strided view: only the first 20 of 52 columns count
-    a2 = torch.zeros(1, device=dev, dtype=torch.int32)
+    a2 = _block(lib, dev)
     check(lib.cvk_absmax_f32(x.data_ptr(), 1000, 20, 52, a2.data_ptr(), s), "absmax strided")
-    assert a2.view(torch.float32).item() == x[:, :20].abs().max().item()
+    assert _val(a2) == x[:, :20].abs().max().item()
     # a second tensor into the same word: the larger value stays
     y = torch.full((8, 4), -3e30, device=dev)
     check(lib.cvk_absmax_f32(y.data_ptr(), 8, 4, 4, a2.data_ptr(), s), "absmax second")
-    assert a2.view(torch.float32).item() == torch.tensor(3e30).item()
+    assert _val(a2) == torch.tensor(3e30).item()
     z = torch.zeros(64, 4, device=dev)
     a3 = _amax(lib, check, z, s)
-    assert a3.item() == 0
+    assert _val(a3) == 0 and int(a3.abs().max()) == 0
+    host = a2.cpu().numpy().astype(np.uint32)
+    import ctypes
+    assert lib.cvk_amax_block_value(host.ctypes.data_as(ctypes.c_void_p), host.size) == int(a2[::32].max().item())
 
 
 @pytest.mark.parametrize("tile,kind", [(6, 0), (6, 1), (6, 2), (4, 0)])
@@ -67,7 +80,7 @@ def test_planes_hold_the_scaled_value_inside_fp16_range(tile, kind, mag):
     g = torch.Generator().manual_seed(tile + kind)
     src = torch.tensor([mag, -0.25 * mag, 0.0, 0.0], device=dev)            # "the tensor the transform read": its maximum is mag
     am = _amax(lib, check, src.view(1, 4), s)
-    word = int(am.item()) & 0xFFFFFFFF
+    word = int(am[::32].max().item()) & 0xFFFFFFFF
     e = torch.tensor([lib.cvk_split_scale_exponent(tile, kind, xi, word) for xi in range(NX)], dtype=torch.float64)
     bound = 2.0 ** (15 - e)                                                   # what |value| may reach in plane xi
     P = (torch.rand(NX, R, C, generator=g, dtype=torch.float64) * 2 - 1) * torch.exp(-6 * torch.rand(NX, R, C, generator=g, dtype=torch.float64))
@@ -294,3 +307,44 @@ def test_unet_headline_step_in_the_network():
     # bitwise reproducible (the maximum passes use atomicMax: order-independent)
     _, outb, lossb = run(2)
     assert torch.equal(out, outb) and loss == lossb
+
+
+def test_producer_passes_leave_the_exact_maximum():
+    """cvk_bn_relu_apply_amax / cvk_bn_relu_apply_pool_amax / cvk_bn_bwd_dx_amax: the results are bitwise those of the plain entry points and the
+    device word holds exactly the largest magnitude written (what cvk_absmax_f32 of the output returns)."""
+    from pytorch_camvid_amd._lib import View
+    lib, check = _lib()
+    dev = torch.device("cuda:0"); s = torch.cuda.current_stream().cuda_stream
+    N, H, W, C = 2, 23, 30, 64
+    g = torch.Generator().manual_seed(9)
+    y = (torch.randn(N, H, W, C, generator=g) * 3).to(dev)
+    sc = (torch.rand(C, generator=g) + 0.5).to(dev); sh = (torch.randn(C, generator=g) * 0.3).to(dev)
+
+    def view(t):
+        return View(t.data_ptr(), H * W * C, W * C, C)
+    out0 = torch.empty_like(y); out1 = torch.empty_like(y)
+    a = _block(lib, dev)
+    check(lib.cvk_bn_relu_apply(y.data_ptr(), C, sc.data_ptr(), sh.data_ptr(), view(out0), N, H, W, C, s), "apply")
+    check(lib.cvk_bn_relu_apply_amax(y.data_ptr(), C, sc.data_ptr(), sh.data_ptr(), view(out1), N, H, W, C, a.data_ptr(), s), "apply amax")
+    assert torch.equal(out0, out1) and _val(a) == out0.max().item()
+    # pool variant: both words
+    p0 = torch.empty(N, H // 2, W // 2, C, device=dev); p1 = torch.empty_like(p0)
+    ao = _block(lib, dev); ap = _block(lib, dev)
+    check(lib.cvk_bn_relu_apply_pool(y.data_ptr(), C, sc.data_ptr(), sh.data_ptr(), view(out0), p0.data_ptr(), None, N, H, W, C, s), "apply pool")
+    check(lib.cvk_bn_relu_apply_pool_amax(y.data_ptr(), C, sc.data_ptr(), sh.data_ptr(), view(out1), p1.data_ptr(), None, N, H, W, C,
+                                          ao.data_ptr(), ap.data_ptr(), s), "apply pool amax")
+    assert torch.equal(out0, out1) and torch.equal(p0, p1)
+    assert _val(ao) == out0.max().item() and _val(ap) == p0.max().item()
+    # BatchNorm/ReLU backward: dy
+    dO = torch.randn(N, H, W, C, generator=g).to(dev) * 1e-5
+    mean = y.mean(dim=(0, 1, 2)).contiguous(); rstd = (1.0 / (y.var(dim=(0, 1, 2), unbiased=False) + 1e-5).sqrt()).contiguous()
+    dgamma = torch.randn(C, generator=g).to(dev) * 1e-3; dbeta = torch.randn(C, generator=g).to(dev) * 1e-3
+    PB = lib.cvk_bn_bwd_blocks(N * H * W)
+    part0 = torch.zeros(PB * C, device=dev); part1 = torch.zeros(PB * C, device=dev)
+    dy0 = torch.empty_like(y); dy1 = torch.empty_like(y)
+    ad = _block(lib, dev)
+    args = (y.data_ptr(), C, sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr())
+    check(lib.cvk_bn_bwd_dx(view(dO), *args, dy0.data_ptr(), C, part0.data_ptr(), N, H, W, C, 1, s), "bwd dx")
+    check(lib.cvk_bn_bwd_dx_amax(view(dO), *args, dy1.data_ptr(), C, part1.data_ptr(), N, H, W, C, 1, ad.data_ptr(), s), "bwd dx amax")
+    assert torch.equal(dy0, dy1) and torch.equal(part0, part1)
+    assert _val(ad) == dy0.abs().max().item()

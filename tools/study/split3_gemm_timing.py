@@ -54,6 +54,28 @@ for name, ci, co, h, w in LAYERS:
     del V, U, Mo, V3, U3, Vv
 print(f"sum                            {t32s*1e6:8.1f} us   {t3s*1e6:8.1f} us     {t32s/t3s:5.2f}x")
 
+# the second format (two scaled fp16 terms, three cross-products): the same GEMMs; "streamed" = operand bytes the workgroups pull through
+# their LDS (V once per Cout tile, U once per row tile) + the product planes written, over the launch time
+print()
+print("layer (batch 8, F(6x6,3x3))      split-3 GEMM   split-2h GEMM   executed fp16 TFLOP/s   streamed GB/s (fmt 3 / fmt 2)")
+for name, ci, co, h, w in LAYERS:
+    T = lib.cvk_w6_tiles(N, h, w)
+    Tp, Cp = lib.cvk_split3_rows_pad(T, 256), lib.cvk_split3_rows_pad(co, 128)
+    Mo = torch.empty(NX * T * co + 1024, device=dev)
+    am = torch.full((lib.cvk_amax_block_words(),), 0x3F800000, device=dev, dtype=torch.int32)
+    res = {}
+    for fmt in (3, 2):
+        dt = torch.bfloat16 if fmt == 3 else torch.float16
+        Vs = (torch.randn(NX * (ci // 32) * fmt * Tp * 32, device=dev) * 0.5).to(dt)
+        Us = (torch.randn(NX * (ci // 32) * fmt * Cp * 32, device=dev) * 0.05).to(dt)
+        t = timeit(lambda: check(lib.cvk_w2d_gemm_split(fmt, 6, Vs.data_ptr(), Us.data_ptr(), Mo.data_ptr(), am.data_ptr(), am.data_ptr(), NX, T, Tp, ci, co, Cp, s)))
+        streamed = NX * (2.0 * fmt * ci * (Tp * (Cp // 128) + Cp * (Tp // 256)) + 4.0 * T * co)
+        res[fmt] = (t, streamed / t / 1e9)
+        del Vs, Us
+    print(f"{name:8s} {ci:5d}->{co:4d} @{h:3d}x{w:3d}   {res[3][0]*1e6:8.1f} us   {res[2][0]*1e6:8.1f} us     {6.0*NX*Tp*ci*Cp/res[2][0]/1e12:8.0f}               "
+          f"{res[3][1]:6.0f} / {res[2][1]:6.0f}")
+    del Mo
+
 print()
 print("weight-grad GEMM (k = tiles)        fp32 gemm_tn   split-3 gemm_tn   speed-up")
 t32s = t3s = 0.0
