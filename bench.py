@@ -147,7 +147,7 @@ SPLIT_DTYPES = {
 
 
 def peak_of(name):
-    return PEAK_BF16_MFMA_TFLOPS if ("bf16" in name or "thinb" in name or "split3" in name or "split2h" in name) else PEAK_F32_MFMA_TFLOPS
+    return PEAK_BF16_MFMA_TFLOPS if ("bf16" in name or "thinb" in name or "split3" in name or "split2h" in name or "wino4h" in name) else PEAK_F32_MFMA_TFLOPS
 
 
 def kernel_profile(step, dev, nprof=3):

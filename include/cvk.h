@@ -219,6 +219,16 @@ int cvk_w2d_gemm_tn_split(int fmt, int tile, const void* E, const void* V, float
                           int Cout, void* stream);
 int cvk_w2d_wgrad_output_f(int tile, const float* P, float* dw, int Cin, int Cin_pad, int Cout, int f, void* stream);
 int cvk_w6_wgrad_output(const float* P, float* dw, int T, int Cin, int Cin_pad, int Cout, void* stream);
+/* The fused F(4,3) convolution below in the opt-in fp16 split-operand form (csrc/split_fmt.h; runner.w2d_split = 2, never the default): same
+ * contracts as cvk_wino4f_weight_transform / cvk_conv3x3_wino4f / cvk_conv3x3_wino4f_bnred plus the amax blocks of x and of the filter w; Uh has the
+ * size of Uf (cvk_wino4f_weight_floats(Cn, Ck) * 4 bytes).  V = B^T d is split into two fp16 terms inside the staging pass, a K step is 18
+ * v_mfma_f32_32x32x16_f16 instead of 48 v_mfma_f32_32x32x2f32. */
+int cvk_wino4h_weight_transform(const float* w, void* Uh, const void* amax_w, int Cn, int Ck, int dgrad, void* stream);
+int cvk_conv3x3_wino4h(const float* x, const void* Uh, const float* bias, float* y, float* stats, float* counts, const void* amax_x,
+                       const void* amax_w, int N, int H, int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream);
+int cvk_conv3x3_wino4h_bnred(const float* x, const void* Uh, float* y, const void* amax_x, const void* amax_w, int N, int H, int W, int Cin,
+                             int Cout, int ldy, const float* yP, const float* scale, const float* shift, const float* mean,
+                             const float* rstd, float* part, int max_workgroups, void* stream);
 /* FUSED 1-D Winograd F(4,3) (csrc/wino4f.hip; replaces nn.Conv2d(cin,cout,3,padding=1) fwd and its data-grad,
  * /root/reference/models/unet.py:11, models/segnet.py:8, for the 64/128-channel levels): one workgroup computes all six
  * transform indices of a 128 x 64 tile, the output transform, bias and BatchNorm statistics happen in registers — no

@@ -18,6 +18,7 @@
 // epilogue's stores retire under the next tile's MFMAs.
 #include "conv_tile.h"
 #include "lds_dma.h"
+#include "split_fmt.h"
 #include <utility>
 
 namespace {
@@ -38,8 +39,19 @@ constexpr int F_STAGE = F_ABYTES + F_BBYTES;     // 73728
 // slice*16 .. +15 of (G g)_xi, K = kernel row * Ck + input channel; 16-byte chunk c of row r is stored at c ^ ((r >> 2) & 3)
 // (the LDS image: the sixteen rows of a ds_read_b128 phase then hit sixteen different bank groups).  Rows >= Cn are zero.
 // dgrad: w is the FORWARD filter [Ck][3][3][Cn] and g_s = w[k][2-r][2-s][n] (rotated by 180 degrees, channels exchanged).
+// H2 (the opt-in fp16 split-operand form, csrc/split_fmt.h): the same image with 16-bit elements — a 64-byte row holds the two fp16 terms of its 16
+// K elements, 2^e(xi) * u = h1 + h2: chunks [h1 k0-7 | h1 k8-15 | h2 k0-7 | h2 k8-15], chunk c of row r at c ^ ((r >> 2) & 3) as before; e(xi) from the
+// filter's largest magnitude (amax block) and the row sums of G (1-D: cvk_split_exp(amax, c_G[xi], 0)).
+template <bool H2 = false>
 __device__ __forceinline__ void wino4f_weight_body(const float* __restrict__ w, float* __restrict__ Uf, int Cn, int Ck, int tilesN, int dgrad,
-                                                   unsigned vblock, unsigned nblocks) {
+                                                   unsigned vblock, unsigned nblocks, const unsigned* __restrict__ amaxW = nullptr,
+                                                   const CvkSplitTab& tabG = CvkSplitTab{}) {
+    float sc[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (H2) {
+        const unsigned am = cvk_amax_read(amaxW);
+#pragma unroll
+        for (int x = 0; x < 6; ++x) sc[x] = cvk_pow2f(cvk_split_exp(am, cvk_split_tab_c(tabG, x), 0));
+    }
     const int Nn = tilesN * F_BN;
     const size_t total = (size_t)Nn * 3 * Ck;
     for (size_t i = (size_t)vblock * blockDim.x + threadIdx.x; i < total; i += (size_t)nblocks * blockDim.x) {
@@ -67,6 +79,23 @@ __device__ __forceinline__ void wino4f_weight_body(const float* __restrict__ w, 
         }
         const int kk = r * Ck + k, slice = kk >> 4, kf = kk & 15;
         const int tn = n >> 6, nl = n & 63;
+        if (H2) {
+            const float u[6] = {(float)(0.25 * g0), (float)(-(g0 + g1 + g2) / 6.0), (float)(-(g0 - g1 + g2) / 6.0),
+                                (float)(g0 / 24.0 + g1 / 12.0 + g2 / 6.0), (float)(g0 / 24.0 - g1 / 12.0 + g2 / 6.0), (float)g2};
+            _Float16* const Uh = reinterpret_cast<_Float16*>(Uf);
+            const int swz = (nl >> 2) & 3;
+            const size_t row = (((size_t)(slice * tilesN + tn) * 6) * 64 + nl) * 32;
+            const int p1 = (((kf >> 3) ^ swz) << 3) + (kf & 7), p2 = (((2 + (kf >> 3)) ^ swz) << 3) + (kf & 7);
+#pragma unroll
+            for (int x = 0; x < 6; ++x) {
+                const float v = u[x] * sc[x];
+                const _Float16 h1 = (_Float16)v;
+                const _Float16 h2 = (_Float16)(v - (float)h1);
+                Uh[row + (size_t)x * (64 * 32) + p1] = h1;
+                Uh[row + (size_t)x * (64 * 32) + p2] = h2;
+            }
+            continue;
+        }
         const size_t o = (((size_t)(slice * tilesN + tn) * 6) * 64 + nl) * 16 + (((kf >> 2) ^ ((nl >> 2) & 3)) << 2) + (kf & 3);
         const size_t ps = 64 * 16;               // plane stride between transform indices
         Uf[o] = (float)(0.25 * g0);
@@ -81,6 +110,10 @@ __device__ __forceinline__ void wino4f_weight_body(const float* __restrict__ w, 
 __global__ __launch_bounds__(256) void k_wino4f_weight(const float* __restrict__ w, float* __restrict__ Uf, int Cn, int Ck,
                                                       int tilesN, int dgrad) {
     wino4f_weight_body(w, Uf, Cn, Ck, tilesN, dgrad, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(256) void k_wino4h_weight(const float* __restrict__ w, float* __restrict__ Uh, int Cn, int Ck, int tilesN, int dgrad,
+                                                      const unsigned* __restrict__ amaxW, CvkSplitTab tabG) {
+    wino4f_weight_body<true>(w, Uh, Cn, Ck, tilesN, dgrad, blockIdx.x, gridDim.x, amaxW, tabG);
 }
 
 // All fused-F(4,3) filter transforms of a step in ONE launch (16 launches of ~5 us each in a UNet step): the jobs travel by value in the
@@ -121,11 +154,24 @@ struct FBnRed {
     const float* rstd;
 };
 
-template <bool STATS, int ABL = 0, bool BNR = false>
+// H2: the opt-in fp16 split-operand form (csrc/split_fmt.h, runner.w2d_split = 2).  Same tile walk, loader and epilogue; the staging pass splits
+// V = B^T d into two fp16 terms of 2^e(xi) * V (e from the input tensor's amax block and the row sums of B^T) and writes them into the same
+// 64-byte LDS rows ([h1 k0-7 | h1 k8-15 | h2 k0-7 | h2 k8-15], chunks swizzled as before), the filter image carries the same two terms, and
+// a K step is 6 x 3 = 18 v_mfma_f32_32x32x16_f16 (h2.H1 + h1.H2 + h1.H1: same accumulator layout as the 48 v_mfma_f32_32x32x2f32 they
+// replace, 0.375 of their matrix time, and they do not occupy the vector lanes); the epilogue undoes the two scales exactly.
+struct FSplit {
+    const unsigned* amaxX;      // amax block of the tensor X
+    const unsigned* amaxW;      // ... of the filter
+    CvkSplitTab tabB, tabG;
+};
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <bool STATS, int ABL = 0, bool BNR = false, bool H2 = false>
 __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
     const float* __restrict__ X, const float* __restrict__ Uf, const float* __restrict__ bias, float* __restrict__ Y,
     float* __restrict__ stats, float* __restrict__ counts, int Mt, int H, int W, int Wt, int Cin, int Cout, int ldy,
-    int tilesN, int ntiles, int Mpix, int P, FBnRed bn) {
+    int tilesN, int ntiles, int Mpix, int P, FBnRed bn, FSplit sp) {
     static_assert(!(STATS && BNR), "forward statistics and the BatchNorm-backward sums are different launches");
     __shared__ __attribute__((aligned(1024))) char smem[2 * F_STAGE + 2048];
     const unsigned smem_addr = cvk_lds_addr(smem);
@@ -151,6 +197,20 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
     const int ntw = (tend - tbeg + tstride - 1) / tstride;               // tiles of this workgroup
     const int nS = 3 * Cin / F_BK;                                       // K slices per tile
     const int total = ntw * nS;
+    // H2: scale of V_xi and the exact inverse of the product's scale, per transform index (wave-uniform)
+    float sA[6];
+    CvkUnscale un[6];
+#pragma unroll
+    for (int x = 0; x < 6; ++x) { sA[x] = 1.f; un[x] = CvkUnscale{1.f, 1.f}; }
+    if (H2) {
+        const unsigned ax = cvk_amax_read(sp.amaxX), aw = cvk_amax_read(sp.amaxW);
+#pragma unroll
+        for (int x = 0; x < 6; ++x) {
+            const int ea = cvk_split_exp(ax, cvk_split_tab_c(sp.tabB, x), 0), eu = cvk_split_exp(aw, cvk_split_tab_c(sp.tabG, x), 0);
+            sA[x] = cvk_pow2f(ea);
+            un[x] = cvk_unscale(-(ea + eu));
+        }
+    }
 
     const FastDiv divWt((unsigned)Wt), divH((unsigned)H);
     // input window of the tile being loaded: starts one image row + one pixel before the tile's first pixel (possibly before
@@ -241,11 +301,24 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
         if (ABL & 2) return;
         *reinterpret_cast<f32x4*>(stage + x * (F_BM * 64) + wr_off) = tv[x];
     };
+    // H2: the two fp16 terms of 2^e * V_x for this thread's four channels: 8 bytes each into the h1 / h2 chunk of its row
+    const int swr = (srow >> 2) & 3;
+    const int wr_h1 = srow * 64 + (((schunk >> 1) ^ swr) << 4) + (schunk & 1) * 8;
+    const int wr_h2 = srow * 64 + (((2 + (schunk >> 1)) ^ swr) << 4) + (schunk & 1) * 8;
+    auto split_A = [&](char* stage, int x) {
+        if (ABL & 2) return;
+        const f32x4 v = tv[x] * sA[x];
+        const f16x4 h1 = __builtin_convertvector(v, f16x4);
+        const f32x4 r = v - __builtin_convertvector(h1, f32x4);
+        const f16x4 h2 = __builtin_convertvector(r, f16x4);
+        *reinterpret_cast<f16x4*>(stage + x * (F_BM * 64) + wr_h1) = h1;
+        *reinterpret_cast<f16x4*>(stage + x * (F_BM * 64) + wr_h2) = h2;
+    };
     auto store_A = [&](char* stage, int set) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) xform(set, c);
 #pragma unroll
-        for (int x = 0; x < 6; ++x) write_A(stage, x);
+        for (int x = 0; x < 6; ++x) { if (H2) split_A(stage, x); else write_A(stage, x); }
     };
     // ---- filter slices by LDS-DMA: slice (bslice of tile btile) -> B region of a stage; 3 pieces of 1 KiB per wave ----
     int btn = tbeg % tilesN, bslice = 0, bleft = total;       // n-tile of the tile whose filter slices are being copied
@@ -285,6 +358,26 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
         if (ABL & 16) return;
         const int sidx = k >> 2, x = sidx >> 1, slot = sidx & 1, j = k & 3;
         acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][j], fb[slot][j], acc[x], 0, 0, 0);
+    };
+
+    // H2: per transform index the two terms of both operands (one ds_read_b128 each: the lane's row, k half lh) and three MFMAs
+    // Registers: the first terms double-buffered (read three slots ahead, under the previous index' MFMAs), the second terms single: A2 is dead
+    // after the index' second MFMA, B2 after its third, and each is refilled in that slot for the next index.
+    f16x8 ha1[2], hb1[2], ha2, hb2;
+    const int swl = (li >> 2) & 3;
+    const int ha_row = (wm * 32 + li) * 64, hb_row = F_ABYTES + (wn * 32 + li) * 64;
+    auto load_h1 = [&](const char* st, int x, int slot) {
+        ha1[slot] = *reinterpret_cast<const f16x8*>(st + x * (F_BM * 64) + ha_row + ((lh ^ swl) << 4));
+        hb1[slot] = *reinterpret_cast<const f16x8*>(st + x * (F_BN * 64) + hb_row + ((lh ^ swl) << 4));
+    };
+    auto load_ha2 = [&](const char* st, int x) { ha2 = *reinterpret_cast<const f16x8*>(st + x * (F_BM * 64) + ha_row + (((2 + lh) ^ swl) << 4)); };
+    auto load_hb2 = [&](const char* st, int x) { hb2 = *reinterpret_cast<const f16x8*>(st + x * (F_BN * 64) + hb_row + (((2 + lh) ^ swl) << 4)); };
+    auto mfma_h = [&](int k) {                             // MFMA k of the step: transform index k / 3; products h1.H1, h2.H1, h1.H2
+        if (ABL & 16) return;
+        const int x = k / 3, p = k - 3 * x, slot = x & 1;
+        if (p == 0) acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha1[slot], hb1[slot], acc[x], 0, 0, 0);
+        else if (p == 1) acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha2, hb1[slot], acc[x], 0, 0, 0);
+        else acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha1[slot], hb2, acc[x], 0, 0, 0);
     };
 
     // y = A^T m in registers, + bias, stores, BatchNorm statistics partial of the tile (sum, M2 about the tile mean, count).
@@ -334,7 +427,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
             const unsigned ob = (unsigned)((4 * (wm * 32 + 4 * lh)) * ldy + col) * 4u;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float m0_ = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
+                const float m0_ = H2 ? acc[0][e] * un[0].a * un[0].b : acc[0][e], m1 = H2 ? acc[1][e] * un[1].a * un[1].b : acc[1][e],
+                            m2 = H2 ? acc[2][e] * un[2].a * un[2].b : acc[2][e], m3 = H2 ? acc[3][e] * un[3].a * un[3].b : acc[3][e],
+                            m4 = H2 ? acc[4][e] * un[4].a * un[4].b : acc[4][e], m5 = H2 ? acc[5][e] * un[5].a * un[5].b : acc[5][e];
                 const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
                 const float y0 = m0_ + s12 + s34, y1 = fmaf(2.f, d34, d12), y2 = fmaf(4.f, s34, s12), y3 = fmaf(8.f, d34, d12) + m5;
 #pragma unroll
@@ -363,7 +458,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int t = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const float m0_ = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
+                const float m0_ = H2 ? acc[0][e] * un[0].a * un[0].b : acc[0][e], m1 = H2 ? acc[1][e] * un[1].a * un[1].b : acc[1][e],
+                            m2 = H2 ? acc[2][e] * un[2].a * un[2].b : acc[2][e], m3 = H2 ? acc[3][e] * un[3].a * un[3].b : acc[3][e],
+                            m4 = H2 ? acc[4][e] * un[4].a * un[4].b : acc[4][e], m5 = H2 ? acc[5][e] * un[5].a * un[5].b : acc[5][e];
                 const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
                 const float y0 = m0_ + s12 + s34, y1 = fmaf(2.f, d34, d12), y2 = fmaf(4.f, s34, s12), y3 = fmaf(8.f, d34, d12) + m5;
 #pragma unroll
@@ -495,12 +592,70 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
         cvk_wait_vm<6>();        // the step's DMA pieces (and, older, the previous step's pixel loads) have landed
         cvk_lds_retire_barrier();
     };
+    // H2: 18 MFMA slots.  Slots 3x: the four fragment reads of transform index x + 1; 1, 2, 4, 5: the transform (the first waits for its pixel
+    // loads) with the three filter-DMA pieces behind that wait; 7, 8, 10, 11, 13, 14: split + two LDS stores of one V_x and one pixel load into
+    // the register just freed
+    auto step_h = [&](auto par_, const char* cur, char* nxt, unsigned nxt_addr) {
+        constexpr int SET = 1 - decltype(par_)::value;
+        if (lcib == 0) {
+            if (lr == 0 && ltile < tend) set_tile(ltile);
+            regroup(lr);
+        }
+        dma_B_begin();
+        load_h1(cur, 0, 0);
+        load_ha2(cur, 0);
+        load_hb2(cur, 0);
+        F_SB();
+        f_static_for(std::make_integer_sequence<int, 18>{}, [&](auto kc_) {
+            constexpr int k_ = decltype(kc_)::value;
+            mfma_h(k_);
+            if constexpr (k_ < 15) {        // the next index' fragments
+                if constexpr (k_ % 3 == 0) load_h1(cur, k_ / 3 + 1, (k_ / 3 + 1) & 1);
+                else if constexpr (k_ % 3 == 1) load_ha2(cur, k_ / 3 + 1);
+                else load_hb2(cur, k_ / 3 + 1);
+            }
+            if constexpr (k_ % 3 == 0) {
+            } else if constexpr (k_ == 1) {
+                xform(SET, 0);                              /* waits for the six pixel loads of the slice */
+            } else if constexpr (k_ == 2) {
+                xform(SET, 1);
+                dma_B_piece(nxt_addr, 0);
+            } else if constexpr (k_ == 4) {
+                xform(SET, 2);
+                dma_B_piece(nxt_addr, 1);
+            } else if constexpr (k_ == 5) {
+                xform(SET, 3);
+                dma_B_piece(nxt_addr, 2);
+            } else if constexpr (k_ == 7 || k_ == 8) {
+                split_A(nxt, k_ - 7);
+                load_A(SET, k_ - 7);
+            } else if constexpr (k_ == 10 || k_ == 11) {
+                split_A(nxt, k_ - 8);
+                load_A(SET, k_ - 8);
+            } else if constexpr (k_ == 13) {
+                split_A(nxt, 4);
+                load_A(SET, 4);
+            } else if constexpr (k_ == 14) {
+                split_A(nxt, 5);
+                load_A(SET, 5);
+                advance_A();
+            }
+            F_SB();
+        });
+        cvk_wait_vm<6>();
+        cvk_lds_retire_barrier();
+    };
     // nS is even (Cin % 32 == 0, checked by the host): every tile starts in stage 0 and the step pair below is the only copy
     // of the K step in the code (per phase); the epilogue's global stores count in vmcnt and retire under the next tile's first step
     for (int tile = tbeg; tile < tend; tile += tstride) {
-        for (int sp = 0; sp < nS; sp += 2) {
-            step(std::integral_constant<int, 0>{}, buf0, buf1, smem_addr + F_STAGE);
-            step(std::integral_constant<int, 1>{}, buf1, buf0, smem_addr);
+        for (int ks = 0; ks < nS; ks += 2) {
+            if (H2) {
+                step_h(std::integral_constant<int, 0>{}, buf0, buf1, smem_addr + F_STAGE);
+                step_h(std::integral_constant<int, 1>{}, buf1, buf0, smem_addr);
+            } else {
+                step(std::integral_constant<int, 0>{}, buf0, buf1, smem_addr + F_STAGE);
+                step(std::integral_constant<int, 1>{}, buf1, buf0, smem_addr);
+            }
         }
         epilogue(tile);
     }
@@ -551,7 +706,8 @@ extern "C" int cvk_wino4f_stat_partials(int N, int H, int W) {
 }
 
 static int wino4f_launch(const char* who, const float* x, const float* Uf, const float* bias, float* y, float* stats, float* counts,
-                         const FBnRed* bn, int N, int H, int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream) {
+                         const FBnRed* bn, int N, int H, int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream,
+                         const void* amax_x = nullptr, const void* amax_w = nullptr) {
     CVK_CHECK_ARG(x && Uf && y, "%s: null pointer", who);
     CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout, "%s: bad shape", who);
     CVK_CHECK_ARG(Cin >= 32 && Cin % 32 == 0, "%s: Cin=%d must be a multiple of 32", who, Cin);
@@ -576,15 +732,16 @@ static int wino4f_launch(const char* who, const float* x, const float* Uf, const
     CVK_CHECK_ARG((F_BM * 4 + 3L * W + 8) * Cin * 4 < (1L << 31), "%s: a tile's input window exceeds the 2 GiB buffer-addressing limit", who);
     hipStream_t s = (hipStream_t)stream;
     const FBnRed none = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (bn)
-        hipLaunchKernelGGL((k_conv3x3_wino4f<false, 0, true>), dim3(grid), dim3(512), 0, s, x, Uf, bias, y, stats, counts, Mt, H, W, Wt, Cin,
-                           Cout, ldy, tilesN, ntiles, Mpix, tilesM, *bn);
-    else if (stats)
-        hipLaunchKernelGGL(k_conv3x3_wino4f<true>, dim3(grid), dim3(512), 0, s, x, Uf, bias, y, stats, counts, Mt, H, W, Wt, Cin, Cout, ldy,
-                           tilesN, ntiles, Mpix, tilesM, none);
-    else
-        hipLaunchKernelGGL(k_conv3x3_wino4f<false>, dim3(grid), dim3(512), 0, s, x, Uf, bias, y, stats, counts, Mt, H, W, Wt, Cin, Cout, ldy,
-                           tilesN, ntiles, Mpix, tilesM, none);
+    const bool h2 = amax_x != nullptr;
+    CVK_CHECK_ARG((amax_x == nullptr) == (amax_w == nullptr), "%s: the two amax blocks go together", who);
+    FSplit sp = {(const unsigned*)amax_x, (const unsigned*)amax_w, CvkSplitTab{}, CvkSplitTab{}};
+    if (h2) { sp.tabB = cvk_split_tab(4, CVK_SPLIT_KIND_B); sp.tabG = cvk_split_tab(4, CVK_SPLIT_KIND_G); }
+#define CVK_W4F_GO(ST_, BN_, H2_, BNV_) hipLaunchKernelGGL((k_conv3x3_wino4f<ST_, 0, BN_, H2_>), dim3(grid), dim3(512), 0, s, x, Uf, bias, y, stats, counts, \
+                                                           Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, BNV_, sp)
+    if (bn)         { if (h2) CVK_W4F_GO(false, true, true, *bn); else CVK_W4F_GO(false, true, false, *bn); }
+    else if (stats) { if (h2) CVK_W4F_GO(true, false, true, none); else CVK_W4F_GO(true, false, false, none); }
+    else            { if (h2) CVK_W4F_GO(false, false, true, none); else CVK_W4F_GO(false, false, false, none); }
+#undef CVK_W4F_GO
     CVK_LAUNCH_RETURN(who);
 }
 
@@ -604,6 +761,33 @@ extern "C" int cvk_conv3x3_wino4f_bnred(const float* x, const float* Uf, float* 
     return wino4f_launch("cvk_conv3x3_wino4f_bnred", x, Uf, nullptr, y, part, nullptr, &bn, N, H, W, Cin, Cout, ldy, max_workgroups, stream);
 }
 
+// ---- the opt-in fp16 split-operand form (csrc/split_fmt.h; runner.w2d_split = 2): same contracts, plus the amax blocks of x and of the filter ----
+// Uh: cvk_wino4f_weight_floats(Cn, Ck) * 4 bytes (the same image size: two fp16 terms instead of one fp32 value)
+extern "C" int cvk_wino4h_weight_transform(const float* w, void* Uh, const void* amax_w, int Cn, int Ck, int dgrad, void* stream) {
+    CVK_CHECK_ARG(w && Uh && amax_w && Cn > 0 && Ck > 0, "cvk_wino4h_weight_transform: bad arguments");
+    CVK_CHECK_ARG(Ck % F_BK == 0, "cvk_wino4h_weight_transform: the contraction channel count %d must be a multiple of 16", Ck);
+    CVK_CHECK_ARG(cvk_aligned16(Uh), "cvk_wino4h_weight_transform: Uh must be 16-byte aligned");
+    const size_t total = (size_t)f_tiles_n(Cn) * F_BN * 3 * Ck;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_wino4h_weight, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)Uh, Cn, Ck, f_tiles_n(Cn), dgrad ? 1 : 0,
+                       (const unsigned*)amax_w, cvk_split_tab(4, CVK_SPLIT_KIND_G));
+    CVK_LAUNCH_RETURN("cvk_wino4h_weight_transform");
+}
+extern "C" int cvk_conv3x3_wino4h(const float* x, const void* Uh, const float* bias, float* y, float* stats, float* counts, const void* amax_x,
+                                  const void* amax_w, int N, int H, int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream) {
+    CVK_CHECK_ARG(amax_x && amax_w, "cvk_conv3x3_wino4h: null amax block");
+    return wino4f_launch("cvk_conv3x3_wino4h", x, (const float*)Uh, bias, y, stats, counts, nullptr, N, H, W, Cin, Cout, ldy, max_workgroups, stream,
+                         amax_x, amax_w);
+}
+extern "C" int cvk_conv3x3_wino4h_bnred(const float* x, const void* Uh, float* y, const void* amax_x, const void* amax_w, int N, int H, int W, int Cin,
+                                        int Cout, int ldy, const float* yP, const float* scale, const float* shift, const float* mean,
+                                        const float* rstd, float* part, int max_workgroups, void* stream) {
+    CVK_CHECK_ARG(yP && scale && shift && mean && rstd && part && amax_x && amax_w, "cvk_conv3x3_wino4h_bnred: null pointer");
+    const FBnRed bn = {yP, scale, shift, mean, rstd};
+    return wino4f_launch("cvk_conv3x3_wino4h_bnred", x, (const float*)Uh, nullptr, y, part, nullptr, &bn, N, H, W, Cin, Cout, ldy, max_workgroups, stream,
+                         amax_x, amax_w);
+}
+
 #ifdef CVK_WINO4F_ABLATE
 extern "C" int cvk_conv3x3_wino4f_ablate(const float* x, const float* Uf, const float* bias, float* y, int N, int H, int W, int Cin,
                                          int Cout, int ldy, int abl, void* stream) {
@@ -611,7 +795,7 @@ extern "C" int cvk_conv3x3_wino4f_ablate(const float* x, const float* Uf, const 
     const int tilesN = f_tiles_n(Cout), tilesM = cvk_cdiv(Mt, F_BM), ntiles = tilesM * tilesN;
     const int grid = ntiles < 256 ? ntiles : 256;
     hipStream_t s = (hipStream_t)stream;
-#define CVK_ABL(A) case A: hipLaunchKernelGGL((k_conv3x3_wino4f<false, A>), dim3(grid), dim3(512), 0, s, x, Uf, bias, y, nullptr, nullptr, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, FBnRed{nullptr, nullptr, nullptr, nullptr, nullptr}); break;
+#define CVK_ABL(A) case A: hipLaunchKernelGGL((k_conv3x3_wino4f<false, A>), dim3(grid), dim3(512), 0, s, x, Uf, bias, y, nullptr, nullptr, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, FBnRed{nullptr, nullptr, nullptr, nullptr, nullptr}, FSplit{nullptr, nullptr, CvkSplitTab{}, CvkSplitTab{}}); break;
     switch (abl) {
         CVK_ABL(0) CVK_ABL(1) CVK_ABL(2) CVK_ABL(3) CVK_ABL(4) CVK_ABL(7) CVK_ABL(8) CVK_ABL(9) CVK_ABL(11) CVK_ABL(15) CVK_ABL(16) CVK_ABL(24) CVK_ABL(31)
         default: return -1;

@@ -227,7 +227,7 @@ def split_fmt(R):
 
 
 def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what="", dgrad_of=None, keep_v=None, wsrc=None, ck=None,
-              bnred=None, v_pre=None, split=False, x_amax=None):
+              bnred=None, v_pre=None, split=False, x_amax=None, h2=False):
     """y[N,H,W,ldy] = conv3x3(x[N,H,W,k_ch], w[cout][3][3][k_ch]) (+bias, +BN statistics partials at sp) through the
     Winograd kernels: weight transform -> (input transform ->) GEMMs M_xi -> output transform.  2-D F(4x4,3x3) for the
     channel-heavy layers (R.wino2d, wino2d_pays), else 1-D F(4,3) when R.wino4, else F(2,3).
@@ -355,6 +355,42 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
     if use4 and R.wino4f and wino4f_ok(k_ch, cout) and (dgrad_of is None or (dgrad_of[1] == k_ch and dgrad_of[2] == cout)):
         # fused F(4,3) (csrc/wino4f.hip): all six transform indices in one workgroup, output transform + bias + statistics in
         # registers — no product planes, no output pass
+        if h2:
+            # OPT-IN fp16 split-operand form (runner.w2d_split = 2): the same kernel with two scaled fp16 terms per operand, 18 fp16 MFMAs per K
+            # step instead of 48 fp32 ones; needs the largest magnitudes of x (left by the pass that wrote it, else measured here) and of w
+            wraw = dgrad_of[0] if dgrad_of is not None else (w() if callable(w) else w)
+
+            def build_amax_w():
+                a = amax_blocks(lib, 1, x.device)[0]
+                _timed(R, "k_absmax", 4.0 * wraw.numel(), lambda: check(
+                    lib.cvk_absmax_f32(wraw.data_ptr(), wraw.numel() // 4, 4, 4, a.data_ptr(), s), "cvk_absmax_f32(w)"), "byte")
+                return a
+            am_w = R.derived(((ck[0], "a"), "amaxw"), wsrc, build_amax_w) if (ck is not None and wsrc is not None) else build_amax_w()
+
+            def build_uh():
+                uh = _empty(lib.cvk_wino4f_weight_floats(cout, k_ch), x.device)
+                _timed(R, "k_wino4h_weight", 4.0 * (9 + 18) * cout * k_ch, lambda: check(
+                    lib.cvk_wino4h_weight_transform(wraw.data_ptr(), uh.data_ptr(), am_w.data_ptr(), cout, k_ch, 1 if dgrad_of is not None else 0, s),
+                    "cvk_wino4h_weight_transform"), "byte")
+                return uh
+            Uh = cached("w4h", build_uh)
+            am_x = x_amax
+            if am_x is None:
+                am_x = amax_blocks(lib, 1, x.device)[0]
+                _timed(R, "k_absmax", 4.0 * M * k_ch, lambda: check(lib.cvk_absmax_f32(x.data_ptr(), M, k_ch, k_ch, am_x.data_ptr(), s), "cvk_absmax_f32(x)"), "byte")
+            Pf = lib.cvk_wino4f_stat_partials(N, H, W)
+            cnt = sp + 4 * 2 * Pf * cout if sp is not None else None
+            if bnred is not None and sp is None and bias is None and ldy == cout and R.bnred_fuse:
+                bpart = _empty(2 * Pf * cout, x.device)
+                _timed(R, "k_conv3x3_wino4h<bnred>", flops, lambda: check(
+                    lib.cvk_conv3x3_wino4h_bnred(x.data_ptr(), Uh.data_ptr(), y.data_ptr(), am_x.data_ptr(), am_w.data_ptr(), N, H, W, k_ch, cout, ldy,
+                                                 *bnred[:5], bpart.data_ptr(), R.launch_wgs(), s), "cvk_conv3x3_wino4h_bnred"), executed=1.5 * flops)
+                bnred[5].append((bpart, Pf))
+                return None
+            _timed(R, "k_conv3x3_wino4h", flops, lambda: check(
+                lib.cvk_conv3x3_wino4h(x.data_ptr(), Uh.data_ptr(), bias, y.data_ptr(), sp, cnt, am_x.data_ptr(), am_w.data_ptr(), N, H, W, k_ch, cout,
+                                       ldy, R.launch_wgs(), s), "cvk_conv3x3_wino4h" + what), executed=1.5 * flops)      # 3 fp16 products per fp32 product
+            return (Pf, cnt) if sp is not None else None
         def build_uf():
             uf = _empty(lib.cvk_wino4f_weight_floats(cout, k_ch), x.device)
             if dgrad_of is not None:
@@ -587,7 +623,8 @@ class ConvBnRelu(Op):
             return (Pt, cnt) if sp is not None else None
         if wino_ok(R, src.ld, ldy):
             return wino_conv(R, lib, s, X, wk, b.data_ptr(), y, sp, N, H, W, src.ld, C, ldy, 18.0 * M * C * self.cin, keep_v=keep_v,
-                             wsrc=st.params[4 * self.pslot], ck=(self.pslot, "f"), split=split_fmt(R) if (st.need_grad and st.training and self._split3(R)) else 0, x_amax=st.amax.get(src.id))
+                             wsrc=st.params[4 * self.pslot], ck=(self.pslot, "f"), split=split_fmt(R) if (st.need_grad and st.training and self._split3(R)) else 0, x_amax=st.amax.get(src.id),
+                             h2=split_fmt(R) == 2 and st.need_grad and st.training)
         else:
             _timed(R, conv_kernel_name("fwd", ldy, src.ld), 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy, s),
@@ -728,8 +765,7 @@ class ConvBnRelu(Op):
                 E = None            # layout not vectorisable (strided view): plain pass below, wgrad transforms dy itself
         am_dy_fused = None
         if E is None and E6 is None:
-            if (split_fmt(R) == 2 and wgrad2d and st.training and Vkept is not None and Vkept.dtype == torch.float16 and st.amax_spare
-                    and self._split3(R)):
+            if split_fmt(R) == 2 and st.training and st.amax_spare and self.src_needs_grad:
                 am_dy_fused = st.amax_spare.pop()       # a zeroed word: the pass that writes dy leaves its largest magnitude there
                 _timed(R, "k_bn_bwd<dx>", 12.0 * M * C, lambda: check(
                     lib.cvk_bn_bwd_dx_amax(dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, part.data_ptr(),
@@ -799,7 +835,8 @@ class ConvBnRelu(Op):
                              pbnp.data_ptr() + 4 * src.ld, [])
                 wino_conv(R, lib, s, dy, packed, None, dX, None, N, H, W, ldy, src.ld, src.ld, 18.0 * M * C * self.cin, "(dgrad)",
                           dgrad_of=(wc, C, self.cin), wsrc=w, ck=(self.pslot, "d"), bnred=bnred,
-                          v_pre=(both2[0], both2[2]) if both2 is not None else None, split=split3)
+                          v_pre=(both2[0], both2[2]) if both2 is not None else None, split=split3, x_amax=am_dy_fused,
+                          h2=split_fmt(R) == 2 and st.training)
                 if bnred is not None and bnred[5]:
                     st.bnred[prod.idx] = bnred[5][0]
             elif R.thin and lib.cvk_thin_fwd_supported(ldy, src.ld, src.ld) and H * W * max(src.ld, ldy) * 4 < 2 ** 31:      # the head's data-grad: 12 -> 64 (csrc/thin.hip)
@@ -1500,7 +1537,8 @@ class Runner:
         pass runs; any other input is measured by cvk_absmax_f32 in wino_conv.  One zero fill per step for all words."""
         if split_fmt(self) != 2 or plan.bf16 or not (st.training and st.need_grad):
             return
-        layers = [op for op in plan.ops if isinstance(op, ConvBnRelu) and op._split3(self)]
+        # every conv block that can run a split form: the 2-D Winograd layers (_split3) and the fused F(4,3) of the 64/128-channel levels
+        layers = [op for op in plan.ops if isinstance(op, ConvBnRelu) and (op._split3(self) or (op.src.ld % 32 == 0 and op.cout % 4 == 0))]
         if not layers:
             return
 
