@@ -359,6 +359,9 @@ int cvk_bn_relu_apply_amax(const float* y, int ldy, const float* scale, const fl
                            void* amax_block, void* stream);
 int cvk_bn_relu_apply_pool_amax(const float* y, int ldy, const float* scale, const float* shift, cvk_view out, float* pool,
                                 unsigned char* code, int N, int H, int W, int C, void* amax_out, void* amax_pool, void* stream);
+int cvk_bn_bwd_dx_e_amax(int six, cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
+                         const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* E, float* part, int N, int H,
+                         int W, int C, int use_batch_stats, void* amax_block, void* stream);   /* six: 0 = cvk_bn_bwd_dx_e, 1 = cvk_bn_bwd_dx_e6 */
 int cvk_bn_bwd_dx_amax(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
                        const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* dbias_part, int N,
                        int H, int W, int C, int use_batch_stats, void* amax_block, void* stream);

@@ -150,6 +150,8 @@ SIGNATURES = {
                               c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_bn_relu_apply_amax": (c_int, [c_vp, c_int, c_vp, c_vp, View, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "cvk_bn_relu_apply_pool_amax": (c_int, [c_vp, c_int, c_vp, c_vp, View, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "cvk_bn_bwd_dx_e_amax": (c_int, [c_int, View, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp,
+                                     c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "cvk_bn_bwd_dx_amax": (c_int, [View, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp,
                                    c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "cvk_maxpool2x2_fwd": (c_int, [View, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),

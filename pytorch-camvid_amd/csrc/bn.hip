@@ -354,8 +354,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dx_e(const float* __restrict__ d
                                                     const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                     float* __restrict__ dy, int ld_dy, float* __restrict__ E,
                                                     float* __restrict__ part, int M, int C, int W, int Wt, int Mt, int tiles,
-                                                    int cchunk, int use_batch_stats, int six_H, int six_Wtp, long six_rows) {
+                                                    int cchunk, int use_batch_stats, int six_H, int six_Wtp, long six_rows,
+                                                    unsigned* __restrict__ amax) {
     __shared__ float red[256 * 4];
+    float mx = 0.f;                       // with amax: the largest |dy| this thread wrote
+    const unsigned snap = cvk_amax_snapshot(amax);
     const int c0 = blockIdx.y * cchunk;
     const int cw = min(cchunk, C - c0);
     const int cvn = cw / 4;
@@ -396,6 +399,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dx_e(const float* __restrict__ d
                         const float v = sc[j] * (g - k1[j] - xh * k2[j]);
                         r[i][j] = v;
                         s0[j] += v;
+                        mx = fmaxf(mx, fabsf(v));
                     }
                     *reinterpret_cast<f32x4*>(dy + (size_t)m * ld_dy + c) = r[i];
                 }
@@ -421,6 +425,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dx_e(const float* __restrict__ d
             }
         }
     }
+    if (amax != nullptr) cvk_amax_publish(mx, amax, snap);
     if (part == nullptr) return;
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[t * 4 + j] = s0[j];
@@ -698,23 +703,57 @@ extern "C" int cvk_bn_bwd_e_blocks(int N, int H, int W) {
     return cvk_cdiv(Mt, tiles);
 }
 
+static int bn_bwd_dx_e_launch(const char* who, int six, cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
+                              const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* E,
+                              float* part, int N, int H, int W, int C, int use_batch_stats, void* amax, void* stream);
 extern "C" int cvk_bn_bwd_dx_e(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
                                const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* E,
                                float* part, int N, int H, int W, int C, int use_batch_stats, void* stream) {
-    CVK_CHECK_ARG(dout.ptr && y && scale && shift && mean && rstd && dy && E && dgamma && dbeta, "cvk_bn_bwd_dx_e: null pointer");
-    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && ldy >= C && ld_dy >= C && (long)N * H * W < (1L << 31), "cvk_bn_bwd_dx_e: bad shape");
+    return bn_bwd_dx_e_launch("cvk_bn_bwd_dx_e", 0, dout, y, ldy, scale, shift, mean, rstd, dgamma, dbeta, dy, ld_dy, E, part, N, H, W, C, use_batch_stats,
+                              nullptr, stream);
+}
+// cvk_bn_bwd_dx_e / cvk_bn_bwd_dx_e6 (six != 0) that also leave the largest |dy| in an amax block (as cvk_bn_bwd_dx_amax)
+extern "C" int cvk_bn_bwd_dx_e_amax(int six, cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
+                                    const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* E,
+                                    float* part, int N, int H, int W, int C, int use_batch_stats, void* amax_block, void* stream) {
+    CVK_CHECK_ARG(amax_block, "cvk_bn_bwd_dx_e_amax: null amax block");
+    return bn_bwd_dx_e_launch("cvk_bn_bwd_dx_e_amax", six ? 1 : 0, dout, y, ldy, scale, shift, mean, rstd, dgamma, dbeta, dy, ld_dy, E, part, N, H, W, C,
+                              use_batch_stats, amax_block, stream);
+}
+static int bn_bwd_dx_e_launch(const char* who, int six, cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
+                              const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* E,
+                              float* part, int N, int H, int W, int C, int use_batch_stats, void* amax, void* stream) {
+    if (six) {
+        CVK_CHECK_ARG(dout.ptr && y && scale && shift && mean && rstd && dy && E && dgamma && dbeta, "%s: null pointer", who);
+        CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && ldy >= C && ld_dy == C && (long)N * H * W < (1L << 31), "%s: bad shape (ld_dy must equal C)", who);
+        const PixMap dm6 = make_map(dout, H, W);
+        const bool v46 = vec_ok(y, dout.ptr, scale, ldy, ld_dy, C, &dm6) && cvk_aligned16(shift) && cvk_aligned16(mean) &&
+                         cvk_aligned16(rstd) && cvk_aligned16(dy) && cvk_aligned16(E);
+        CVK_CHECK_ARG(v46, "%s: needs the 4-channel vector layout (use cvk_bn_bwd_dx)", who);
+        const int M6 = N * H * W, Wt6 = (W + 3) / 4, Mt6 = N * H * Wt6;
+        const int Wtp = (Wt6 + 7) / 8 * 8;
+        const long rows = (long)N * (H + 2) * Wtp + 2L * Wtp;
+        const int pb6 = cvk_bn_bwd_blocks(M6);
+        const int tiles6 = cvk_cdiv(Mt6, pb6), nb6 = cvk_cdiv(Mt6, tiles6);
+        dim3 grid6(nb6, cvk_cdiv(C, 1024));
+        hipLaunchKernelGGL(k_bn_bwd_dx_e, grid6, dim3(256), 0, (hipStream_t)stream, dout.ptr, dm6, y, ldy, scale, shift, mean, rstd,
+                           dgamma, dbeta, dy, ld_dy, E, part, M6, C, W, Wt6, Mt6, tiles6, 1024, use_batch_stats, H, Wtp, rows, (unsigned*)amax);
+        CVK_LAUNCH_RETURN(who);
+    }
+    CVK_CHECK_ARG(dout.ptr && y && scale && shift && mean && rstd && dy && E && dgamma && dbeta, "%s: null pointer", who);
+    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && ldy >= C && ld_dy >= C && (long)N * H * W < (1L << 31), "%s: bad shape", who);
     const PixMap dm = make_map(dout, H, W);
     const bool v4 = vec_ok(y, dout.ptr, scale, ldy, ld_dy, C, &dm) && cvk_aligned16(shift) && cvk_aligned16(mean) &&
                     cvk_aligned16(rstd) && cvk_aligned16(dy) && cvk_aligned16(E);
-    CVK_CHECK_ARG(v4, "cvk_bn_bwd_dx_e: needs the 4-channel vector layout (use cvk_bn_bwd_dx)");
+    CVK_CHECK_ARG(v4, "%s: needs the 4-channel vector layout (use cvk_bn_bwd_dx)", who);
     const int M = N * H * W, Wt = (W + 3) / 4, Mt = N * H * Wt;
     const int pb = cvk_bn_bwd_blocks(M);
     const int tiles = cvk_cdiv(Mt, pb), nb = cvk_cdiv(Mt, tiles);
     const int cchunk = 1024;
     dim3 grid(nb, cvk_cdiv(C, cchunk));
     hipLaunchKernelGGL(k_bn_bwd_dx_e, grid, dim3(256), 0, (hipStream_t)stream, dout.ptr, dm, y, ldy, scale, shift, mean, rstd,
-                       dgamma, dbeta, dy, ld_dy, E, part, M, C, W, Wt, Mt, tiles, cchunk, use_batch_stats, 0, 0, 0L);
-    CVK_LAUNCH_RETURN("cvk_bn_bwd_dx_e");
+                       dgamma, dbeta, dy, ld_dy, E, part, M, C, W, Wt, Mt, tiles, cchunk, use_batch_stats, 0, 0, 0L, (unsigned*)amax);
+    CVK_LAUNCH_RETURN(who);
 }
 
 // The same pass writing the SIX planes E0..E5 = A dy in the padded plane layout of csrc/wgradp.hip (cvk_wgradp_plane_rows rows of
@@ -722,22 +761,8 @@ extern "C" int cvk_bn_bwd_dx_e(cvk_view dout, const float* y, int ldy, const flo
 extern "C" int cvk_bn_bwd_dx_e6(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
                                 const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* E6,
                                 float* part, int N, int H, int W, int C, int use_batch_stats, void* stream) {
-    CVK_CHECK_ARG(dout.ptr && y && scale && shift && mean && rstd && dy && E6 && dgamma && dbeta, "cvk_bn_bwd_dx_e6: null pointer");
-    CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && ldy >= C && ld_dy == C && (long)N * H * W < (1L << 31), "cvk_bn_bwd_dx_e6: bad shape (ld_dy must equal C)");
-    const PixMap dm = make_map(dout, H, W);
-    const bool v4 = vec_ok(y, dout.ptr, scale, ldy, ld_dy, C, &dm) && cvk_aligned16(shift) && cvk_aligned16(mean) &&
-                    cvk_aligned16(rstd) && cvk_aligned16(dy) && cvk_aligned16(E6);
-    CVK_CHECK_ARG(v4, "cvk_bn_bwd_dx_e6: needs the 4-channel vector layout (use cvk_bn_bwd_dx)");
-    const int M = N * H * W, Wt = (W + 3) / 4, Mt = N * H * Wt;
-    const int Wtp = (Wt + 7) / 8 * 8;
-    const long rows = (long)N * (H + 2) * Wtp + 2L * Wtp;
-    const int pb = cvk_bn_bwd_blocks(M);
-    const int tiles = cvk_cdiv(Mt, pb), nb = cvk_cdiv(Mt, tiles);
-    const int cchunk = 1024;
-    dim3 grid(nb, cvk_cdiv(C, cchunk));
-    hipLaunchKernelGGL(k_bn_bwd_dx_e, grid, dim3(256), 0, (hipStream_t)stream, dout.ptr, dm, y, ldy, scale, shift, mean, rstd,
-                       dgamma, dbeta, dy, ld_dy, E6, part, M, C, W, Wt, Mt, tiles, cchunk, use_batch_stats, H, Wtp, rows);
-    CVK_LAUNCH_RETURN("cvk_bn_bwd_dx_e6");
+    return bn_bwd_dx_e_launch("cvk_bn_bwd_dx_e6", 1, dout, y, ldy, scale, shift, mean, rstd, dgamma, dbeta, dy, ld_dy, E6, part, N, H, W, C, use_batch_stats,
+                              nullptr, stream);
 }
 
 extern "C" int cvk_colsum_finalize_batch(const cvk_colsum_job* jobs, int n, void* stream) {

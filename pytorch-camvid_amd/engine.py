@@ -741,31 +741,48 @@ class ConvBnRelu(Op):
         wgradp = wgrad4 and R.wgradp and wgradp_ok(src.ld, C, ldy) and (R.wgradp == "always" or wgradp_pays(N, H, W, src.ld, C))
         E = None
         E6 = None
+        am_dy_fused = None
+        want_amax = split_fmt(R) == 2 and st.training and bool(st.amax_spare) and self.src_needs_grad
         if wgradp:
             rows6 = lib.cvk_wgradp_plane_rows(N, H, W)
             E6 = _empty(6 * rows6 * C, dev)
             check(lib.cvk_wgradp_zero_pads(E6.data_ptr(), N, H, W, C, s), "cvk_wgradp_zero_pads")
             PBe = lib.cvk_bn_bwd_e_blocks(N, H, W)
-            rc = _timed(R, "k_bn_bwd<dx+E6>", (12.0 * M + 24.0 * N * H * ((W + 3) // 4)) * C, lambda: lib.cvk_bn_bwd_dx_e6(
-                dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, E6.data_ptr(), part.data_ptr(),
-                N, H, W, C, 1 if st.training else 0, s), "byte")
+            blk = st.amax_spare[-1] if want_amax else None      # the opt-in fp16 data-grad scales by the largest |dy|: left by this pass
+            if blk is not None:
+                rc = _timed(R, "k_bn_bwd<dx+E6>", (12.0 * M + 24.0 * N * H * ((W + 3) // 4)) * C, lambda: lib.cvk_bn_bwd_dx_e_amax(
+                    1, dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, E6.data_ptr(), part.data_ptr(),
+                    N, H, W, C, 1 if st.training else 0, blk.data_ptr(), s), "byte")
+            else:
+                rc = _timed(R, "k_bn_bwd<dx+E6>", (12.0 * M + 24.0 * N * H * ((W + 3) // 4)) * C, lambda: lib.cvk_bn_bwd_dx_e6(
+                    dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, E6.data_ptr(), part.data_ptr(),
+                    N, H, W, C, 1 if st.training else 0, s), "byte")
             if rc == 0:
                 R.defer_colsum(st, part, PBe, C, gb)           # conv bias grad: finalised with the others, in one launch
+                if blk is not None:
+                    am_dy_fused = st.amax_spare.pop()
             else:
                 E6 = None           # layout not vectorisable (strided view): plain pass below, the weight-grad transforms dy itself
         if E6 is None and wgrad4 and not wgradp and ldy == C and C % 4 == 0:
             E = _empty(4 * N * H * ((W + 3) // 4) * ldy, dev)
             PBe = lib.cvk_bn_bwd_e_blocks(N, H, W)
-            rc = _timed(R, "k_bn_bwd<dx+E>", (12.0 * M + 16.0 * N * H * ((W + 3) // 4)) * C, lambda: lib.cvk_bn_bwd_dx_e(
-                dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, E.data_ptr(), part.data_ptr(),
-                N, H, W, C, 1 if st.training else 0, s), "byte")
+            blk = st.amax_spare[-1] if want_amax else None
+            if blk is not None:
+                rc = _timed(R, "k_bn_bwd<dx+E>", (12.0 * M + 16.0 * N * H * ((W + 3) // 4)) * C, lambda: lib.cvk_bn_bwd_dx_e_amax(
+                    0, dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, E.data_ptr(), part.data_ptr(),
+                    N, H, W, C, 1 if st.training else 0, blk.data_ptr(), s), "byte")
+            else:
+                rc = _timed(R, "k_bn_bwd<dx+E>", (12.0 * M + 16.0 * N * H * ((W + 3) // 4)) * C, lambda: lib.cvk_bn_bwd_dx_e(
+                    dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, E.data_ptr(), part.data_ptr(),
+                    N, H, W, C, 1 if st.training else 0, s), "byte")
             if rc == 0:
                 R.defer_colsum(st, part, PBe, C, gb)           # conv bias grad: finalised with the others, in one launch
+                if blk is not None:
+                    am_dy_fused = st.amax_spare.pop()
             else:
                 E = None            # layout not vectorisable (strided view): plain pass below, wgrad transforms dy itself
-        am_dy_fused = None
         if E is None and E6 is None:
-            if split_fmt(R) == 2 and st.training and st.amax_spare and self.src_needs_grad:
+            if want_amax:
                 am_dy_fused = st.amax_spare.pop()       # a zeroed word: the pass that writes dy leaves its largest magnitude there
                 _timed(R, "k_bn_bwd<dx>", 12.0 * M * C, lambda: check(
                     lib.cvk_bn_bwd_dx_amax(dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, part.data_ptr(),

@@ -253,6 +253,7 @@ def test_recorded_filter_builds_are_replayed_in_two_launches():
     ref = A.UNet(3, 12).to(dev()).train()
     ref.load_state_dict(net.state_dict())
     runner_of(ref).wcache = False
+    runner_of(net).w2d_split = runner_of(ref).w2d_split = 0        # the default path's filter batching (the opt-in split forms build theirs per layer)
     lossf = A.CrossEntropyLoss()
     x, t = batch(2, 96, 128, 3)
     for it in range(3):
