@@ -5,7 +5,7 @@ root aliases it).  Public surface mirrors the reference (models/unet.py, models/
 train.py's loss): UNet, SegNet, BasicConv2d, BasicConv, UpSample2d, get_model, CrossEntropyLoss.
 """
 from ._lib import CvkError, build as build_library, load as load_library          # noqa: F401
-from .modules import BasicConv, BasicConv2d, SegNet, UNet, UpSample2d, get_model, set_conv_precision   # noqa: F401
+from .modules import BasicConv, BasicConv2d, SegNet, UNet, UpSample2d, get_model, set_conv_precision, set_split_operands   # noqa: F401
 from .functional import (ConfusionMeter, CrossEntropyLoss, argmax_channels, cross_entropy, evaluate,  # noqa: F401
                          evaluate_report, predict, preprocess_uint8, DevicePrefetcher, last_ce_status)
 from .optim import FlatAdamW  # noqa: F401
@@ -15,6 +15,6 @@ from .engine import mark_weights_dirty  # noqa: F401
 from .checkpoint import (save_checkpoint, load_checkpoint, latest_checkpoint, checkpoint_epoch, resume,   # noqa: F401
                          save_policy, reference_state_dict)
 
-__all__ = ["UNet", "SegNet", "BasicConv2d", "BasicConv", "UpSample2d", "get_model", "set_conv_precision", "CrossEntropyLoss",
+__all__ = ["UNet", "SegNet", "BasicConv2d", "BasicConv", "UpSample2d", "get_model", "set_conv_precision", "set_split_operands", "CrossEntropyLoss",
            "cross_entropy", "last_ce_status", "argmax_channels", "ConfusionMeter", "evaluate", "evaluate_report", "predict", "preprocess_uint8", "DevicePrefetcher", "FlatAdamW", "ddp", "GraphedStep", "mark_weights_dirty", "save_checkpoint", "load_checkpoint", "latest_checkpoint", "checkpoint_epoch", "resume", "save_policy",
            "reference_state_dict", "build_library", "load_library", "CvkError"]

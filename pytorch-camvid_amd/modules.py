@@ -286,6 +286,22 @@ def set_conv_precision(module, precision):
     return module
 
 
+def set_split_operands(module, fmt):
+    """OPT-IN (never the default; fp32 plans, training passes): run the matrix products of the fp32 convolutions on the 16-bit matrix pipe with
+    SPLIT fp32 operands accumulated in fp32 (csrc/split_fmt.h):
+      0  off — exact-fp32 MFMA everywhere (the default);
+      3  three bf16 terms per operand, six cross-products: the 2-D Winograd GEMMs of the channel-heavy layers;
+      2  two fp16 terms per operand scaled by an exact power of two (from the tensors' largest magnitudes, left in device memory by the
+         passes that write them), three cross-products: those GEMMs AND the fused F(4,3) convolutions of the 64/128-channel levels.
+    Tensors, parameters, statistics and checkpoints stay fp32; measured against the reference fixtures both forms are at least as close as
+    the default path (tests/test_gpu_split2h.py, tests/test_gpu_split3.py, tests/test_gpu_protocol.py).  Same as CVK_W2D_SPLIT in the
+    environment before the first forward pass."""
+    if fmt not in (0, 2, 3):
+        raise ValueError("fmt must be 0 (off), 3 (bf16 x 3) or 2 (fp16 x 2)")
+    _state_of(module)["runner"].w2d_split = fmt
+    return module
+
+
 def runner_of(module):
     """The engine.Runner of a module (created on first use); ddp.DataParallel hooks gradient sync into it."""
     return _state_of(module)["runner"]
