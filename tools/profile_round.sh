@@ -4,7 +4,7 @@
 # Every pass writes into a directory that is removed first, every rocprofv3 exit status is checked, and a summary is only
 # copied when the CSV it is made from exists (stale files must not pass for this round's profile).
 set -euo pipefail
-TAG=${1:?usage: profile_round.sh TAG [fp32|bf16|all]}
+TAG=${1:?usage: profile_round.sh TAG [fp32|bf16|split2|all]}
 LEG=${2:-all}
 : "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run on the GPU box through gpurun)}"
 export TMPDIR=/tmp
@@ -50,5 +50,11 @@ if [ "$LEG" = bf16 ] || [ "$LEG" = all ]; then
     echo "bf16 bench done: $(python3 -c "import json;d=json.load(open('$O/${TAG}_bench_bf16_720.json'));print(d['value'], d['ms_per_step'])")"
     stats_pass bf16 $BF16_ARGS
     pmc_pass bf16 "$BF16_ARGS"
+fi
+if [ "$LEG" = split2 ]; then      # the opt-in fp16 split-operand mode on the headline workload (never part of "all": it is not the product default)
+    python3 bench.py --w2d-split=2 --no-cpu-baseline --no-extra-configs > "$O/${TAG}_bench_fp32_split2.json" 2> "$O/${TAG}_bench_fp32_split2.err"
+    echo "split2 bench done: $(python3 -c "import json;d=json.load(open('$O/${TAG}_bench_fp32_split2.json'));print(d['value'], d['ms_per_step'])")"
+    stats_pass fp32_split2 --w2d-split=2
+    pmc_pass fp32_split2 "--w2d-split=2"
 fi
 echo "all done"
