@@ -348,3 +348,51 @@ def test_producer_passes_leave_the_exact_maximum():
     check(lib.cvk_bn_bwd_dx_amax(view(dO), *args, dy1.data_ptr(), C, part1.data_ptr(), N, H, W, C, 1, ad.data_ptr(), s), "bwd dx amax")
     assert torch.equal(dy0, dy1) and torch.equal(part0, part1)
     assert _val(ad) == dy0.abs().max().item()
+
+
+def test_public_switch_and_graph_replay_in_the_fp16_mode():
+    """cvk.set_split_operands(net, 2) is the public switch (0 / 3 / 2, anything else is refused); in that mode the split kernels really run
+    (engine profile names), and the step captured as ONE HIP graph — amax blocks zeroed, filled and read inside the graph — replays bit for
+    bit what the eager step computes, over optimizer steps."""
+    import pytorch_camvid_amd as A
+    from pytorch_camvid_amd import engine
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = A.UNet(3, 12).to(dev).train()
+    ref = A.UNet(3, 12).to(dev).train()
+    ref.load_state_dict(net.state_dict())
+    with pytest.raises(ValueError):
+        A.set_split_operands(net, 1)
+    A.set_split_operands(net, 2); A.set_split_operands(ref, 2)
+    lossf = A.CrossEntropyLoss()
+    g = torch.Generator().manual_seed(3)
+
+    def batch():
+        return torch.randn(4, 3, 360, 480, generator=g).to(dev), torch.randint(0, 12, (4, 360, 480), generator=g).to(dev)
+
+    def step(m, x, t):
+        for p in m.parameters():
+            p.grad = None
+        loss = lossf(m(x), t)
+        loss.backward()
+        return loss.detach()
+    x0, t0 = batch()
+    engine.PROF = []
+    try:
+        step(ref, x0, t0)
+        names = {r[0] for r in engine.PROF}
+    finally:
+        engine.PROF = None
+    assert {"k_gemm_split2h", "k_gemm_tn_split2h", "k_conv3x3_wino4h", "k_conv3x3_wino4h<bnred>"} <= names, sorted(names)
+    assert not any(n.startswith("k_w2d_gemm") or n == "k_conv3x3_wino4f" for n in names), sorted(names)
+    ref.load_state_dict(net.state_dict())
+    gs = A.GraphedStep(net, lossf, x0, t0)
+    net.load_state_dict(ref.state_dict())
+    oa, ob = torch.optim.SGD(net.parameters(), lr=0.05), torch.optim.SGD(ref.parameters(), lr=0.05)
+    for it in range(2):
+        x, t = batch()
+        la, lb = gs.replay(x, t), step(ref, x, t)
+        assert la.item() == lb.item(), it
+        for (k, p), q in zip(net.named_parameters(), ref.parameters()):
+            assert torch.equal(p.grad, q.grad), (it, k)
+        oa.step(); ob.step()
