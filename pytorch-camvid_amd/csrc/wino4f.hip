@@ -166,6 +166,7 @@ struct FSplit {
 };
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 template <bool STATS, int ABL = 0, bool BNR = false, bool H2 = false>
 __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
@@ -296,6 +297,18 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
         tv[4][c] = fmaf(-2.f, f, e);
         tv[5][c] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
     };
+    // H2: the same transform on channel PAIRS (v_pk_fma_f32 / v_pk_add_f32: the vector instructions of a K step add to its matrix time one for
+    // one — ablation, tools/bench_wino4h_ablate.sh — so the pair form and the packed scale multiply below are worth a tenth of the step)
+    auto xform2 = [&](int set, int p) {
+        if (ABL & 2) return;
+        auto pr = [&](int j) { return f32x2v{d[set][j][2 * p], d[set][j][2 * p + 1]}; };
+        const f32x2v d0 = pr(0), d1 = pr(1), d2 = pr(2), d3 = pr(3), d4 = pr(4), d5 = pr(5);
+        const f32x2v a = d4 - 4.f * d2, b = d3 - 4.f * d1, e = d4 - d2, f = d3 - d1;
+        const f32x2v t0 = 4.f * d0 - 5.f * d2 + d4, t1 = a + b, t2 = a - b, t3 = e + 2.f * f, t4 = e - 2.f * f, t5 = 4.f * d1 - 5.f * d3 + d5;
+        tv[0][2 * p] = t0[0]; tv[0][2 * p + 1] = t0[1]; tv[1][2 * p] = t1[0]; tv[1][2 * p + 1] = t1[1];
+        tv[2][2 * p] = t2[0]; tv[2][2 * p + 1] = t2[1]; tv[3][2 * p] = t3[0]; tv[3][2 * p + 1] = t3[1];
+        tv[4][2 * p] = t4[0]; tv[4][2 * p + 1] = t4[1]; tv[5][2 * p] = t5[0]; tv[5][2 * p + 1] = t5[1];
+    };
     const int wr_off = srow * 64 + ((schunk ^ ((srow >> 2) & 3)) << 4);
     auto write_A = [&](char* stage, int x) {
         if (ABL & 2) return;
@@ -307,16 +320,41 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
     const int wr_h2 = srow * 64 + (((2 + (schunk >> 1)) ^ swr) << 4) + (schunk & 1) * 8;
     auto split_A = [&](char* stage, int x) {
         if (ABL & 2) return;
-        const f32x4 v = tv[x] * sA[x];
+        // the scale as a wave-uniform 64-bit pair {s, s}: v_pk_mul_f32 takes it from scalar registers (hipcc multiplies the four channels one by one)
+        const unsigned sb = __builtin_bit_cast(unsigned, sA[x]);
+        const unsigned long long sc2 = ((unsigned long long)sb << 32) | sb;
+        f32x2v vlo = {tv[x][0], tv[x][1]}, vhi = {tv[x][2], tv[x][3]};
+        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(vlo) : "v"(vlo), "s"(sc2));
+        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(vhi) : "v"(vhi), "s"(sc2));
+        const f32x4 v = {vlo[0], vlo[1], vhi[0], vhi[1]};
+        if (ABL & 32) {         // timing experiment (WRONG values): the conversions replaced by shifts — what do v_cvt_pk_f16_f32 / v_fma_mix_f32 cost?
+            typedef unsigned u32x2q __attribute__((ext_vector_type(2)));
+            const u32x2q a = {(__builtin_bit_cast(unsigned, v[0]) >> 16) | (__builtin_bit_cast(unsigned, v[1]) & 0xFFFF0000u),
+                              (__builtin_bit_cast(unsigned, v[2]) >> 16) | (__builtin_bit_cast(unsigned, v[3]) & 0xFFFF0000u)};
+            *reinterpret_cast<u32x2q*>(stage + x * (F_BM * 64) + wr_h1) = a;
+            *reinterpret_cast<u32x2q*>(stage + x * (F_BM * 64) + wr_h2) = a;
+            return;
+        }
         const f16x4 h1 = __builtin_convertvector(v, f16x4);
-        const f32x4 r = v - __builtin_convertvector(h1, f32x4);
+        // r = v - h1 (exact) as ONE v_fma_mix_f32 per element, which reads the fp16 operand in place: hipcc's v_cvt_f32_f16 + v_sub pair was
+        // the largest single item of the K step (ablation: transform + split + stores 164 of 293 us on 64 -> 64)
+        typedef unsigned u32x2h __attribute__((ext_vector_type(2)));
+        const u32x2h hp = __builtin_bit_cast(u32x2h, h1);
+        f32x4 r;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(hp[0]), "v"(v[0]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(hp[0]), "v"(v[1]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[2]) : "v"(hp[1]), "v"(v[2]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[3]) : "v"(hp[1]), "v"(v[3]));
         const f16x4 h2 = __builtin_convertvector(r, f16x4);
         *reinterpret_cast<f16x4*>(stage + x * (F_BM * 64) + wr_h1) = h1;
         *reinterpret_cast<f16x4*>(stage + x * (F_BM * 64) + wr_h2) = h2;
     };
     auto store_A = [&](char* stage, int set) {
+        if (H2) { xform2(set, 0); xform2(set, 1); }
+        else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) xform(set, c);
+            for (int c = 0; c < 4; ++c) xform(set, c);
+        }
 #pragma unroll
         for (int x = 0; x < 6; ++x) { if (H2) split_A(stage, x); else write_A(stage, x); }
     };
@@ -616,27 +654,22 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
             }
             if constexpr (k_ % 3 == 0) {
             } else if constexpr (k_ == 1) {
-                xform(SET, 0);                              /* waits for the six pixel loads of the slice */
+                xform2(SET, 0);                             /* waits for the six pixel loads of the slice */
             } else if constexpr (k_ == 2) {
-                xform(SET, 1);
+                xform2(SET, 1);
                 dma_B_piece(nxt_addr, 0);
             } else if constexpr (k_ == 4) {
-                xform(SET, 2);
                 dma_B_piece(nxt_addr, 1);
             } else if constexpr (k_ == 5) {
-                xform(SET, 3);
                 dma_B_piece(nxt_addr, 2);
-            } else if constexpr (k_ == 7 || k_ == 8) {
-                split_A(nxt, k_ - 7);
-                load_A(SET, k_ - 7);
-            } else if constexpr (k_ == 10 || k_ == 11) {
-                split_A(nxt, k_ - 8);
-                load_A(SET, k_ - 8);
-            } else if constexpr (k_ == 13) {
-                split_A(nxt, 4);
-                load_A(SET, 4);
+            } else if constexpr (k_ == 7 || k_ == 10 || k_ == 13) {       /* two transform indices per slot: four independent dependency chains */
+                split_A(nxt, 2 * ((k_ - 7) / 3));
+                split_A(nxt, 2 * ((k_ - 7) / 3) + 1);
+            } else if constexpr (k_ == 8 || k_ == 11) {
+                load_A(SET, 2 * ((k_ - 8) / 3));
+                load_A(SET, 2 * ((k_ - 8) / 3) + 1);
             } else if constexpr (k_ == 14) {
-                split_A(nxt, 5);
+                load_A(SET, 4);
                 load_A(SET, 5);
                 advance_A();
             }
@@ -802,5 +835,21 @@ extern "C" int cvk_conv3x3_wino4f_ablate(const float* x, const float* Uf, const 
     }
 #undef CVK_ABL
     CVK_LAUNCH_RETURN("cvk_conv3x3_wino4f_ablate");
+}
+// the same switches on the fp16 split-operand form (tools/bench_wino4h_ablate.sh)
+extern "C" int cvk_conv3x3_wino4h_ablate(const float* x, const void* Uh, const float* bias, float* y, const void* amax_x, const void* amax_w, int N,
+                                         int H, int W, int Cin, int Cout, int ldy, int abl, void* stream) {
+    const int Wt = (W + 3) / 4, Mt = N * H * Wt, Mpix = N * H * W;
+    const int tilesN = f_tiles_n(Cout), tilesM = cvk_cdiv(Mt, F_BM), ntiles = tilesM * tilesN;
+    const int grid = ntiles < 256 ? ntiles : 256;
+    hipStream_t s = (hipStream_t)stream;
+    const FSplit sp = {(const unsigned*)amax_x, (const unsigned*)amax_w, cvk_split_tab(4, CVK_SPLIT_KIND_B), cvk_split_tab(4, CVK_SPLIT_KIND_G)};
+#define CVK_ABLH(A) case A: hipLaunchKernelGGL((k_conv3x3_wino4f<false, A, false, true>), dim3(grid), dim3(512), 0, s, x, (const float*)Uh, bias, y, nullptr, nullptr, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, FBnRed{nullptr, nullptr, nullptr, nullptr, nullptr}, sp); break;
+    switch (abl) {
+        CVK_ABLH(0) CVK_ABLH(1) CVK_ABLH(2) CVK_ABLH(4) CVK_ABLH(8) CVK_ABLH(9) CVK_ABLH(11) CVK_ABLH(15) CVK_ABLH(16) CVK_ABLH(31) CVK_ABLH(32) CVK_ABLH(33)
+        default: return -1;
+    }
+#undef CVK_ABLH
+    CVK_LAUNCH_RETURN("cvk_conv3x3_wino4h_ablate");
 }
 #endif
