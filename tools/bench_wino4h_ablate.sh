@@ -29,7 +29,7 @@ for (ci, co, H, W) in ((64, 64, 360, 480), (128, 64, 360, 480), (128, 128, 180, 
     assert abl.cvk_absmax_f32(x.data_ptr(), x.numel() // ci, ci, ci, amx.data_ptr(), s) == 0
     assert abl.cvk_wino4h_weight_transform(w.data_ptr(), Uh.data_ptr(), amw.data_ptr(), co, ci, 0, s) == 0
     variants = ((0, "full"), (1, "-loads"), (2, "-xform/split"), (4, "-dma"), (8, "-epi"), (9, "-loads-epi"), (11, "-loads-xform-epi"), (15, "mfma+lds only"),
-                (16, "-mfma"), (31, "nothing"), (32, "conversions->shifts"), (33, "-loads, conversions->shifts"))
+                (16, "-mfma"), (31, "nothing"), (32, "conversions->shifts"), (33, "-loads, conversions->shifts"), (64, "-LDS stores"), (65, "-loads-LDS stores"))
     best = {a: 1e9 for a, _ in variants}
     for rnd in range(3):
         for a, name in variants:
