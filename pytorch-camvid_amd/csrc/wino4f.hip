@@ -315,7 +315,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
         *reinterpret_cast<f32x4*>(stage + x * (F_BM * 64) + wr_off) = tv[x];
     };
     // H2: the two fp16 terms of 2^e * V_x for this thread's four channels: 8 bytes each into the h1 / h2 chunk of its row
-    const int swr = (srow >> 2) & 3;
+    // (H2 swizzle of the A region: bit 1 from row bit 2, bit 0 from row bit 3 — the 8 rows of a half-wave's 8-byte stores then cover all 64 banks;
+    // with the fp32 image's (row >> 2) & 3 rows r and r + 4 met in the same half of their bank group: PMC 25 % of LDS cycles in conflicts)
+    const int swr = (((srow >> 2) & 1) << 1) | ((srow >> 3) & 1);
     const int wr_h1 = srow * 64 + (((schunk >> 1) ^ swr) << 4) + (schunk & 1) * 8;
     const int wr_h2 = srow * 64 + (((2 + (schunk >> 1)) ^ swr) << 4) + (schunk & 1) * 8;
     auto split_A = [&](char* stage, int x) {
@@ -406,13 +408,14 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
     // Registers: the first terms double-buffered (read three slots ahead, under the previous index' MFMAs), the second terms single: A2 is dead
     // after the index' second MFMA, B2 after its third, and each is refilled in that slot for the next index.
     f16x8 ha1[2], hb1[2], ha2, hb2;
-    const int swl = (li >> 2) & 3;
+    const int swl = (li >> 2) & 3;                                      // filter image (written by k_wino4h_weight)
+    const int swa = (((li >> 2) & 1) << 1) | ((li >> 3) & 1);           // A region (written by split_A)
     const int ha_row = (wm * 32 + li) * 64, hb_row = F_ABYTES + (wn * 32 + li) * 64;
     auto load_h1 = [&](const char* st, int x, int slot) {
-        ha1[slot] = *reinterpret_cast<const f16x8*>(st + x * (F_BM * 64) + ha_row + ((lh ^ swl) << 4));
+        ha1[slot] = *reinterpret_cast<const f16x8*>(st + x * (F_BM * 64) + ha_row + ((lh ^ swa) << 4));
         hb1[slot] = *reinterpret_cast<const f16x8*>(st + x * (F_BN * 64) + hb_row + ((lh ^ swl) << 4));
     };
-    auto load_ha2 = [&](const char* st, int x) { ha2 = *reinterpret_cast<const f16x8*>(st + x * (F_BM * 64) + ha_row + (((2 + lh) ^ swl) << 4)); };
+    auto load_ha2 = [&](const char* st, int x) { ha2 = *reinterpret_cast<const f16x8*>(st + x * (F_BM * 64) + ha_row + (((2 + lh) ^ swa) << 4)); };
     auto load_hb2 = [&](const char* st, int x) { hb2 = *reinterpret_cast<const f16x8*>(st + x * (F_BN * 64) + hb_row + (((2 + lh) ^ swl) << 4)); };
     auto mfma_h = [&](int k) {                             // MFMA k of the step: transform index k / 3; products h1.H1, h2.H1, h1.H2
         if (ABL & 16) return;
