@@ -115,11 +115,17 @@ template <typename FR> __device__ __forceinline__ FR rd16(const char* p) { retur
 
 constexpr int S3_TM = 256, S3_TN = 128;                 // tile: rows of V (tile index t) x rows of U (output channels)
 
-template <int FMT>
+// DBG (experiments build only, tools/tile_stamps_split.py): s_memtime stamps of waves 0 and 4 of workgroup `dbg_wg` -> dbg[2][64]
+template <int FMT, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__ V3, const char* __restrict__ U3, float* __restrict__ Mo,
                                                        int T, int Tpad, int Cin, int Cout, int Cpad, int tilesM, int tilesN,
                                                        const unsigned* __restrict__ amaxV, const unsigned* __restrict__ amaxU, CvkSplitTab tabV,
-                                                       CvkSplitTab tabU) {
+                                                       CvkSplitTab tabU, unsigned long long* __restrict__ dbg = nullptr, int dbg_wg = 0) {
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if (DBG && (int)blockIdx.x == dbg_wg && (threadIdx.x & 255) == 0 && nstamp < 64) dbg[(threadIdx.x >> 8) * 64 + nstamp++] = __builtin_amdgcn_s_memtime();
+    };
+    stamp();
     typedef SplitOps<FMT> OPS;
     typedef typename OPS::frag FR;
     constexpr int S3_XT = FMT * S3_TM * 64;                 // 48 (32) KiB: the V terms of a slice
@@ -203,6 +209,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__
         cvk_wait_vm<0>();
     }
     pbar();
+    stamp();
     if (grp == 1) pbar();                       // group B runs one interval behind group A
 
     for (int cs = 0; cs < ncs; ++cs) {
@@ -221,7 +228,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__
             for (int cb = 0; cb < 4; ++cb) x[k][cb] = rd16<FR>(smem + (xa + so + k * 16384 + cb * 1024));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp();
         pbar();
+        stamp();
         // ======== MFMA phase: 6 (3) cross-products x 16 blocks, the smallest terms first
         __builtin_amdgcn_s_setprio(1);
         split_products<FMT>([&](int kw, int kx) {
@@ -233,11 +242,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__
         });
         so = so + S3_STAGE == NST * S3_STAGE ? 0 : so + S3_STAGE;
         __builtin_amdgcn_s_setprio(0);
+        stamp();
         // this wave's pieces of the next slice have landed; with three stages the slice after it (requested in this LOAD phase) stays in flight
         if (NST == 3 && more) wait_keep_one_slice(); else cvk_wait_vm<0>();
+        stamp();
         pbar();
     }
     if (grp == 0) pbar();
+    stamp();
 
     // ---- epilogue: acc[rb][cb][j] = M[t = mt*256 + grp*128 + wp*64 + cb*16 + l15][co = nt*128 + wc*64 + rb*16 + 4*q4 + j]
     float* const mo = Mo + (size_t)xi * T * Cout;
@@ -251,8 +263,104 @@ __global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__
             if (t < T && co < Cout) *reinterpret_cast<f32x4v*>(mo + (size_t)t * Cout + co) = FMT == 2 ? acc[rb][cb] * un.a * un.b : acc[rb][cb];
         }
     }
+    stamp();
 }
 
+
+// ---- two-term format, 128 x 128 tiles, four waves, TWO workgroups per CU ------------------------------------------------------------------------
+// Time stamps of the 256 x 128 ping-pong workgroup (tools/tile_stamps_split.py, 256 -> 256 channels: 8 slices): 7-11 thousand cycles until the
+// first slice has landed, 2.5 thousand per slice, 4-8 thousand for the 16 stores per lane — with ONE workgroup per CU (96-144 KiB of LDS) 40 % of a
+// tile's time is its own start and end, and the channel depth of these layers is only 8-32 slices.  This is what the exact-fp32 GEMM (k_w2d_gemm,
+// wino2d.hip) learned in round 2: 128 x 128 tiles of four waves and 64 KiB so that TWO workgroups share a CU and one's prologue / stores run under
+// the other's MFMAs.  Same planes, same fragment layout (a wave owns 64 x 64), two stages of 32 KiB, one barrier per slice, no wave groups.
+// Measured (profiles/r05_g_split_gemm_timing.txt conditions): 256 -> 128 @180x240 225 -> 195 us, 256 -> 256 @90x120 112 -> 114, 1024 -> 512 @45x60 139 -> 157:
+// the two machines meet at the same 6-8 TB/s of operand streaming, so this one only takes the layers with ONE Cout tile (Cpad = 128).
+__global__ __launch_bounds__(256, 2) void k_gemm_split2q(const char* __restrict__ V3, const char* __restrict__ U3, float* __restrict__ Mo,
+                                                        int T, int Tpad, int Cin, int Cout, int Cpad, int tilesM, int tilesN,
+                                                        const unsigned* __restrict__ amaxV, const unsigned* __restrict__ amaxU, CvkSplitTab tabV,
+                                                        CvkSplitTab tabU) {
+    typedef SplitOps<2> OPS;
+    typedef OPS::frag FR;
+    constexpr int BLK = 128 * 64;                           // 8 KiB: one term of one operand of a slice
+    constexpr int STAGE = 4 * BLK;                          // V h1 | V h2 | U h1 | U h2
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+    const unsigned smem_addr = cvk_lds_addr(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int wc = wave & 1, wp = wave >> 1;
+    const int ncs = Cin >> 5;
+    const int bid = cvk_xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % tilesN;
+    const int mt = (bid / tilesN) % tilesM;
+    const int xi = bid / (tilesN * tilesM);
+    const int unscale_exp = -(cvk_split_exp_xi(amaxV, tabV, xi) + cvk_split_exp_xi(amaxU, tabU, xi));
+
+    const size_t xterm = (size_t)Tpad * 64, wterm = (size_t)Cpad * 64;
+    const char* xsrc = V3 + ((size_t)xi * ncs * 2 * Tpad + (size_t)mt * 128) * 64;
+    const char* wsrc = U3 + ((size_t)xi * ncs * 2 * Cpad + (size_t)nt * 128) * 64;
+    const unsigned voff = wave * 1024 + lane * 16;          // this wave moves pieces wave and wave + 4 of each of the four blocks
+    const unsigned dst = smem_addr + wave * 1024;
+    auto issue_slice = [&](unsigned stage_off) {
+        dma16_s<0>(voff, xsrc, dst + stage_off);
+        dma16_s<4096>(voff, xsrc + 4096, dst + stage_off);
+        dma16_s<BLK>(voff, xsrc + xterm, dst + stage_off);
+        dma16_s<BLK + 4096>(voff, xsrc + xterm + 4096, dst + stage_off);
+        dma16_s<2 * BLK>(voff, wsrc, dst + stage_off);
+        dma16_s<2 * BLK + 4096>(voff, wsrc + 4096, dst + stage_off);
+        dma16_s<3 * BLK>(voff, wsrc + wterm, dst + stage_off);
+        dma16_s<3 * BLK + 4096>(voff, wsrc + wterm + 4096, dst + stage_off);
+        xsrc += 2 * xterm;
+        wsrc += 2 * wterm;
+    };
+    const int sw = (q4 ^ (((l15 >> 2) & 1) << 1)) << 4;
+    const int xa = (wp * 64 + l15) * 64 + sw;               // + term * BLK + cb * 1024
+    const int wa = 2 * BLK + (wc * 64 + l15) * 64 + sw;     // + term * BLK + rb * 1024
+
+    f32x4v acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    issue_slice(0);
+    cvk_wait_vm<0>();
+    pbar();
+    int so = 0;
+    for (int cs = 0; cs < ncs; ++cs) {
+        if (cs + 1 < ncs) issue_slice(so ? 0 : STAGE);      // the other stage: every wave read it out before the barrier that ended slice cs - 1
+        FR w[2][4], x[2][4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) w[k][rb] = rd16<FR>(smem + (wa + so + k * BLK + rb * 1024));
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) x[k][cb] = rd16<FR>(smem + (xa + so + k * BLK + cb * 1024));
+        }
+        split_products<2>([&](int kw, int kx) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[rb][cb] = OPS::mfma(w[kw][rb], x[kx][cb], acc[rb][cb]);
+        });
+        so = so ? 0 : STAGE;
+        cvk_wait_vm<0>();               // this wave's pieces of the next slice have landed
+        cvk_lds_retire_barrier();       // ... everybody's, and everybody has read this slice out
+    }
+
+    float* const mo = Mo + (size_t)xi * T * Cout;
+    const CvkUnscale un = cvk_unscale(unscale_exp);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int t = mt * 128 + wp * 64 + cb * 16 + l15;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const int co = nt * 128 + wc * 64 + rb * 16 + 4 * q4;
+            if (t < T && co < Cout) *reinterpret_cast<f32x4v*>(mo + (size_t)t * Cout + co) = acc[rb][cb] * un.a * un.b;
+        }
+    }
+}
 
 // ---- the weight-grad GEMM on split planes: P_xi[co][ci] = sum_t E_xi[t][co] * V_xi[t][ci]  (k = the tile index t) ----------------------------
 // Both operands are the split planes the transforms wrote ([xi][C/32][term][Tpad][32]: rows = t) — the SAME V planes the forward GEMM read,
@@ -456,10 +564,29 @@ extern "C" int cvk_w2d_gemm_split(int fmt, int tile, const void* V, const void* 
     const dim3 grid((unsigned)(NX * tilesM * tilesN));
     if (fmt == 3) hipLaunchKernelGGL(k_gemm_split3<3>, grid, dim3(512), 0, (hipStream_t)stream, (const char*)V, (const char*)U, Mo, T, Tpad, Cin, Cout, Cpad,
                                      tilesM, tilesN, (const unsigned*)amax_v, (const unsigned*)amax_u, tV, tU);
-    else hipLaunchKernelGGL(k_gemm_split3<2>, grid, dim3(512), 0, (hipStream_t)stream, (const char*)V, (const char*)U, Mo, T, Tpad, Cin, Cout, Cpad,
-                            tilesM, tilesN, (const unsigned*)amax_v, (const unsigned*)amax_u, tV, tU);
+    else if (cvk_knob("CVK_SPLIT_Q", Cpad == 128 ? 1 : 0) != 0) {      // 128 x 128 tiles, two workgroups per CU: where it measured faster (one Cout tile)
+        const int tm = Tpad / 128;
+        hipLaunchKernelGGL(k_gemm_split2q, dim3((unsigned)(NX * tm * tilesN)), dim3(256), 0, (hipStream_t)stream, (const char*)V, (const char*)U, Mo, T, Tpad,
+                           Cin, Cout, Cpad, tm, tilesN, (const unsigned*)amax_v, (const unsigned*)amax_u, tV, tU);
+    } else hipLaunchKernelGGL(k_gemm_split3<2>, grid, dim3(512), 0, (hipStream_t)stream, (const char*)V, (const char*)U, Mo, T, Tpad, Cin, Cout, Cpad,
+                              tilesM, tilesN, (const unsigned*)amax_v, (const unsigned*)amax_u, tV, tU);
     CVK_LAUNCH_RETURN(who);
 }
+#ifdef CVK_EXPERIMENTS
+// time stamps of one workgroup (tools/tile_stamps_split.py): dbg = 128 uint64
+extern "C" int cvk_w2d_gemm_split_dbg(int fmt, int tile, const void* V, const void* U, float* Mo, const void* amax_v, const void* amax_u, int NX, int T,
+                                      int Tpad, int Cin, int Cout, int Cpad, void* dbg, int dbg_wg, void* stream) {
+    const int tilesM = Tpad / S3_TM, tilesN = Cpad / S3_TN;
+    const CvkSplitTab tV = cvk_split_tab(tile, CVK_SPLIT_KIND_B), tU = cvk_split_tab(tile, CVK_SPLIT_KIND_G);
+    const dim3 grid((unsigned)(NX * tilesM * tilesN));
+    if (fmt == 3) hipLaunchKernelGGL((k_gemm_split3<3, true>), grid, dim3(512), 0, (hipStream_t)stream, (const char*)V, (const char*)U, Mo, T, Tpad, Cin, Cout, Cpad,
+                                     tilesM, tilesN, (const unsigned*)amax_v, (const unsigned*)amax_u, tV, tU, (unsigned long long*)dbg, dbg_wg);
+    else hipLaunchKernelGGL((k_gemm_split3<2, true>), grid, dim3(512), 0, (hipStream_t)stream, (const char*)V, (const char*)U, Mo, T, Tpad, Cin, Cout, Cpad,
+                            tilesM, tilesN, (const unsigned*)amax_v, (const unsigned*)amax_u, tV, tU, (unsigned long long*)dbg, dbg_wg);
+    CVK_LAUNCH_RETURN("cvk_w2d_gemm_split_dbg");
+}
+#endif
+
 extern "C" int cvk_w2d_gemm_split3(const void* V3, const void* U3, float* Mo, int NX, int T, int Tpad, int Cin, int Cout, int Cpad, void* stream) {
     return cvk_w2d_gemm_split(3, 4, V3, U3, Mo, nullptr, nullptr, NX, T, Tpad, Cin, Cout, Cpad, stream);
 }
