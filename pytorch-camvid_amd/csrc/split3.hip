@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_split3(const char* __restrict__
 __global__ __launch_bounds__(256, 2) void k_gemm_split2q(const char* __restrict__ V3, const char* __restrict__ U3, float* __restrict__ Mo,
                                                         int T, int Tpad, int Cin, int Cout, int Cpad, int tilesM, int tilesN,
                                                         const unsigned* __restrict__ amaxV, const unsigned* __restrict__ amaxU, CvkSplitTab tabV,
-                                                        CvkSplitTab tabU) {
+                                                        CvkSplitTab tabU, int probe = 0) {
     typedef SplitOps<2> OPS;
     typedef OPS::frag FR;
     constexpr int BLK = 128 * 64;                           // 8 KiB: one term of one operand of a slice
@@ -297,8 +297,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split2q(const char* __restrict_
     const int unscale_exp = -(cvk_split_exp_xi(amaxV, tabV, xi) + cvk_split_exp_xi(amaxU, tabU, xi));
 
     const size_t xterm = (size_t)Tpad * 64, wterm = (size_t)Cpad * 64;
-    const char* xsrc = V3 + ((size_t)xi * ncs * 2 * Tpad + (size_t)mt * 128) * 64;
-    const char* wsrc = U3 + ((size_t)xi * ncs * 2 * Cpad + (size_t)nt * 128) * 64;
+    // probe (experiments build, timing only, WRONG values): 1 = every workgroup reads the operands of tile (xi 0, 0, 0): all loads hit the L2;
+    // 2 = additionally no stores
+    const char* xsrc = V3 + (probe ? 0 : ((size_t)xi * ncs * 2 * Tpad + (size_t)mt * 128) * 64);
+    const char* wsrc = U3 + (probe ? 0 : ((size_t)xi * ncs * 2 * Cpad + (size_t)nt * 128) * 64);
     const unsigned voff = wave * 1024 + lane * 16;          // this wave moves pieces wave and wave + 4 of each of the four blocks
     const unsigned dst = smem_addr + wave * 1024;
     auto issue_slice = [&](unsigned stage_off) {
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split2q(const char* __restrict_
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
             const int co = nt * 128 + wc * 64 + rb * 16 + 4 * q4;
-            if (t < T && co < Cout) *reinterpret_cast<f32x4v*>(mo + (size_t)t * Cout + co) = acc[rb][cb] * un.a * un.b;
+            if (t < T && co < Cout && probe < 2) *reinterpret_cast<f32x4v*>(mo + (size_t)t * Cout + co) = acc[rb][cb] * un.a * un.b;
         }
     }
 }
@@ -567,7 +569,7 @@ extern "C" int cvk_w2d_gemm_split(int fmt, int tile, const void* V, const void* 
     else if (cvk_knob("CVK_SPLIT_Q", Cpad == 128 ? 1 : 0) != 0) {      // 128 x 128 tiles, two workgroups per CU: where it measured faster (one Cout tile)
         const int tm = Tpad / 128;
         hipLaunchKernelGGL(k_gemm_split2q, dim3((unsigned)(NX * tm * tilesN)), dim3(256), 0, (hipStream_t)stream, (const char*)V, (const char*)U, Mo, T, Tpad,
-                           Cin, Cout, Cpad, tm, tilesN, (const unsigned*)amax_v, (const unsigned*)amax_u, tV, tU);
+                           Cin, Cout, Cpad, tm, tilesN, (const unsigned*)amax_v, (const unsigned*)amax_u, tV, tU, cvk_knob("CVK_SPLIT_PROBE", 0));
     } else hipLaunchKernelGGL(k_gemm_split3<2>, grid, dim3(512), 0, (hipStream_t)stream, (const char*)V, (const char*)U, Mo, T, Tpad, Cin, Cout, Cpad,
                               tilesM, tilesN, (const unsigned*)amax_v, (const unsigned*)amax_u, tV, tU);
     CVK_LAUNCH_RETURN(who);
