@@ -1,6 +1,8 @@
-// split3.hip — STUDY KERNELS (not used by the executor, whose fp32 path is exact-fp32 MFMA): the batched GEMM stage of
-// the 2-D Winograd path, M_xi[T][Cout] = V_xi[T][Cin] * U_xi[Cout][Cin]^T (csrc/wino2d.hip k_w2d_gemm; reference op: the multiply-adds of
-// nn.Conv2d(3x3) in models/unet.py:11), on the bf16 matrix pipe with SPLIT fp32 operands.
+// split3.hip — the GEMMs of the OPT-IN split-operand modes (cvk.set_split_operands / runner.w2d_split; the executor's DEFAULT fp32 path is
+// exact-fp32 MFMA and does not come here; began as the study VERDICT r4 #8 asked for): the batched GEMM stage of the 2-D Winograd path,
+// M_xi[T][Cout] = V_xi[T][Cin] * U_xi[Cout][Cin]^T (csrc/wino2d.hip k_w2d_gemm; reference op: the multiply-adds of nn.Conv2d(3x3) in
+// models/unet.py:11) and its weight-grad twin P_xi = E_xi^T V_xi, on the 16-bit matrix pipe with SPLIT fp32 operands.  Two formats
+// (csrc/split_fmt.h): three bf16 terms (described below; FMT 3) and two scaled fp16 terms with three cross-products (FMT 2).
 //
 // Every fp32 value x is written as three bf16 terms x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 8 + 8 + 8
 // mantissa bits) and a product x*w as its six largest cross-products x1w1 + x1w2 + x2w1 + x1w3 + x3w1 + x2w2 (the dropped ones are
@@ -12,8 +14,8 @@
 // Operand format ("split planes"): bf16 [xi][Cin/32][term 3][Rpad][32], rows padded with zeros to a multiple of 256 (V) / 128 (U), the
 // four 16-byte chunks of a 64-byte row stored at position c ^ (2 * ((row >> 2) & 1)) — byte for byte the LDS image of a (term, row tile,
 // channel slice) block, so a tile's K loop streams linear 8 KiB ranges by LDS-DMA (the tile-major idea of conv_bf16p.hip).
-// cvk_split3_planes converts fp32 planes [xi][R][C] into it (a stand-alone pass here; a production version would emit the terms from
-// the transform kernels' store loops instead).
+// cvk_split_planes converts fp32 planes [xi][R][C] into it (a stand-alone pass for tests and studies: the transform kernels of
+// csrc/wino2d.hip emit the terms from their own store loops).
 //
 // GEMM kernel: the ping-pong machine of conv_bf16p.hip.  One workgroup = 8 waves = two groups of four (waves w, w + 4 share a SIMD),
 // tile = 256 rows of V (128 per group) x 128 rows of U; a wave owns 64 (co) x 64 (t): 16 accumulator blocks, and per 32-channel slice

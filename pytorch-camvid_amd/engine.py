@@ -1375,8 +1375,8 @@ class Runner:
         self.w2both = os.environ.get("CVK_W2D_DY_BOTH", "1") != "0"   # one launch transforms dy for the data-grad and the weight-grad
         self.bnred_fuse = os.environ.get("CVK_BNRED_FUSE", "1") != "0"   # BN-backward sums in the fused data-grad's epilogue
         self.wino2d = WINO2D_DEFAULT
-        # OPT-IN study path: the 2-D Winograd GEMMs of the layers ConvBnRelu._split3 admits on the bf16 matrix pipe with
-        # 3-term split fp32 operands (csrc/split3.hip).  Not the product default; bench.py names it in `dtype` when it is on.
+        # OPT-IN split-operand modes (cvk.set_split_operands): the matrix products of the fp32 convolutions on the 16-bit
+        # matrix pipe with split fp32 operands (csrc/split_fmt.h).  Not the product default; bench.py names the mode in `dtype` when it is on.
         self.w2d_split = {"0": 0, "1": 3, "3": 3, "2": 2}[os.environ.get("CVK_W2D_SPLIT", "0")]      # 0 off | 3: bf16 x 3 | 2: fp16 x 2
         self.w2tile_cfg = W2TILE_DEFAULT    # None = auto (see W2TILE_DEFAULT), 4 or 6 = forced
         self.w2tile = 6                     # the tile of the plan being executed (set by forward / backward)

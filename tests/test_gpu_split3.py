@@ -1,4 +1,5 @@
-"""STUDY kernels (csrc/split3.hip — not used by the executor): the GEMM stage of the 2-D Winograd path with 3-term split
+"""OPT-IN split-operand mode, format 3 (csrc/split3.hip, csrc/split_fmt.h; runner.w2d_split = 3 — never the default; began as the study
+VERDICT r4 #8 asked for): the GEMM stage of the 2-D Winograd path with 3-term split
 fp32 operands on the bf16 matrix pipe.  Checked through the C ABI against fp64: (1) the split planes hold x = x1 + x2 + x3 to the last
 bit or two of fp32; (2) the batched GEMM is at least as accurate as the exact-fp32 GEMM of the product (cvk_w6_gemm); (3) a whole
 conv layer — the product's own F(6x6,3x3) input transform, weight transform and output pass around the split GEMM — against an fp64
@@ -77,7 +78,7 @@ def test_split_gemm_is_at_least_as_accurate_as_the_fp32_gemm(T, Cin, Cout):
 @pytest.mark.parametrize("tile", [6, 4])
 def test_whole_layer_through_the_split_gemm_vs_fp64_conv(tile):
     """256 -> 256 channels at 2 x 45 x 60: x -> input transform -> split -> split GEMM -> output pass (the product's own F(6x6,3x3) /
-    F(4x4,3x3) transforms around the study GEMM), against the fp64 convolution; the same layer through the product's fp32 GEMM beside it.
+    F(4x4,3x3) transforms around the split GEMM), against the fp64 convolution; the same layer through the product's fp32 GEMM beside it.
     On the device the layer error is dominated by the fp32 rounding of the transform-domain operands, which both paths share: the split
     GEMM must stay within 25 % of the fp32 path's error (measured: 4.0e-6 vs 3.6e-6 with 6x6 tiles), while the GEMM alone is ~20 % more
     accurate (test above)."""
@@ -191,7 +192,7 @@ def test_unet_headline_step_with_the_split_gemms_in_the_network():
     """The OPT-IN mode (runner.w2d_split): the headline workload (UNet 8 x 3x360x480, bench.py's seeds) with the forward, data-grad and
     weight-grad GEMMs of the 13 channel-heavy layers on the bf16 matrix pipe (3-term split operands), against the REFERENCE-generated
     fixtures of the fp32 network: loss, dense logits (the same sentinels as the default F(6x6) path + 15 %), gradient norms.  This is the
-    network-level parity evidence for the study path; the product default stays exact-fp32 MFMA."""
+    network-level parity evidence for the mode; the product default stays exact-fp32 MFMA."""
     import json
     import os
     import numpy as np
