@@ -42,4 +42,24 @@ for (ci, co, H, W) in ((64, 64, 360, 480), (128, 64, 360, 480), (128, 128, 180, 
             e1.record(); torch.cuda.synchronize()
             best[a] = min(best[a], e0.elapsed_time(e1) / 5 * 1e3)
     print(f"{ci}->{co} {H}x{W}: " + "  ".join(f"{name} {best[a]:.0f}" for a, name in variants), flush=True)
+    # the exact-fp32 kernel under the same switches, for comparison
+    abl.cvk_conv3x3_wino4f_ablate.restype = ctypes.c_int
+    abl.cvk_conv3x3_wino4f_ablate.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 7 + [ctypes.c_void_p]
+    abl.cvk_wino4f_weight_transform.restype = ctypes.c_int
+    abl.cvk_wino4f_weight_transform.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    Uf = torch.empty(abl.cvk_wino4f_weight_floats(co, ci), device="cuda")
+    assert abl.cvk_wino4f_weight_transform(w.data_ptr(), Uf.data_ptr(), co, ci, 0, s) == 0
+    v32 = ((0, "full"), (1, "-loads"), (2, "-xform"), (8, "-epi"), (9, "-loads-epi"), (15, "mfma+lds only"), (16, "-mfma"))
+    b32 = {a: 1e9 for a, _ in v32}
+    for rnd in range(3):
+        for a, name in v32:
+            def run32():
+                assert abl.cvk_conv3x3_wino4f_ablate(x.data_ptr(), Uf.data_ptr(), b.data_ptr(), y.data_ptr(), N, H, W, ci, co, co, a, s) == 0
+            run32(); torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5): run32()
+            e1.record(); torch.cuda.synchronize()
+            b32[a] = min(b32[a], e0.elapsed_time(e1) / 5 * 1e3)
+    print(f"   exact-fp32 kernel: " + "  ".join(f"{name} {b32[a]:.0f}" for a, name in v32), flush=True)
 PY
