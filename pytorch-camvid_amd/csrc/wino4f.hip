@@ -285,26 +285,17 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
     // pieces of the staging work, placed one per MFMA slot by F_STEP: xform(c) computes V = B^T d of channel component c for all
     // six transform indices (12 vector ops per six elements), write_A(stage, x) stores V_x, load_A(j) refills a register
     f32x4 tv[6];
-    auto xform = [&](int set, int c) {
-        if (ABL & 2) return;
-        const float d0 = d[set][0][c], d1 = d[set][1][c], d2 = d[set][2][c], d3 = d[set][3][c], d4 = d[set][4][c], d5 = d[set][5][c];
-        const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
-        const float e = d4 - d2, f = d3 - d1;
-        tv[0][c] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
-        tv[1][c] = a + b;
-        tv[2][c] = a - b;
-        tv[3][c] = fmaf(2.f, f, e);
-        tv[4][c] = fmaf(-2.f, f, e);
-        tv[5][c] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
-    };
-    // H2: the same transform on channel PAIRS (v_pk_fma_f32 / v_pk_add_f32: the vector instructions of a K step add to its matrix time one for
-    // one — ablation, tools/bench_wino4h_ablate.sh — so the pair form and the packed scale multiply below are worth a tenth of the step)
+    // V = B^T d of this thread's four channels for all six transform indices, on channel PAIRS (v_pk_fma_f32 / v_pk_add_f32: 12 vector
+    // instructions per pair — the vector instructions of a K step add to its matrix time one for one, tools/bench_wino4h_ablate.sh; until
+    // round 5 one component per slot, 12 scalar instructions each)
     auto xform2 = [&](int set, int p) {
         if (ABL & 2) return;
         auto pr = [&](int j) { return f32x2v{d[set][j][2 * p], d[set][j][2 * p + 1]}; };
         const f32x2v d0 = pr(0), d1 = pr(1), d2 = pr(2), d3 = pr(3), d4 = pr(4), d5 = pr(5);
-        const f32x2v a = d4 - 4.f * d2, b = d3 - 4.f * d1, e = d4 - d2, f = d3 - d1;
-        const f32x2v t0 = 4.f * d0 - 5.f * d2 + d4, t1 = a + b, t2 = a - b, t3 = e + 2.f * f, t4 = e - 2.f * f, t5 = 4.f * d1 - 5.f * d3 + d5;
+        auto fma2 = [](float c, f32x2v u, f32x2v v) { return __builtin_elementwise_fma(f32x2v{c, c}, u, v); };      // exactly xform()'s fmaf chain, two channels at once
+        const f32x2v a = fma2(-4.f, d2, d4), b = fma2(-4.f, d1, d3), e = d4 - d2, f = d3 - d1;
+        const f32x2v t0 = fma2(4.f, d0, fma2(-5.f, d2, d4)), t1 = a + b, t2 = a - b, t3 = fma2(2.f, f, e), t4 = fma2(-2.f, f, e),
+                     t5 = fma2(4.f, d1, fma2(-5.f, d3, d5));
         tv[0][2 * p] = t0[0]; tv[0][2 * p + 1] = t0[1]; tv[1][2 * p] = t1[0]; tv[1][2 * p + 1] = t1[1];
         tv[2][2 * p] = t2[0]; tv[2][2 * p + 1] = t2[1]; tv[3][2 * p] = t3[0]; tv[3][2 * p + 1] = t3[1];
         tv[4][2 * p] = t4[0]; tv[4][2 * p + 1] = t4[1]; tv[5][2 * p] = t5[0]; tv[5][2 * p + 1] = t5[1];
@@ -356,11 +347,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
         *reinterpret_cast<f16x4*>(stage + x * (F_BM * 64) + wr_h2) = h2;
     };
     auto store_A = [&](char* stage, int set) {
-        if (H2) { xform2(set, 0); xform2(set, 1); }
-        else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) xform(set, c);
-        }
+        xform2(set, 0);
+        xform2(set, 1);
 #pragma unroll
         for (int x = 0; x < 6; ++x) { if (H2) split_A(stage, x); else write_A(stage, x); }
     };
@@ -614,12 +602,13 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
             if constexpr ((k_ & 3) == 0) {
                 if constexpr (k_ < 44) load_frag(cur, (k_ >> 2) + 1, ((k_ >> 2) + 1) & 1);
             } else if constexpr (q_ == 1) {
-                xform(SET, 0);                              /* waits for the six pixel loads of the slice */
-            } else if constexpr (q_ == 2 || q_ == 3) {
-                xform(SET, q_ - 1);
-                dma_B_piece(nxt_addr, q_ - 2);
+                xform2(SET, 0);                             /* waits for the six pixel loads of the slice; two channels per instruction (round 5) */
+            } else if constexpr (q_ == 2) {
+                xform2(SET, 1);
+                dma_B_piece(nxt_addr, 0);
+            } else if constexpr (q_ == 3) {
+                dma_B_piece(nxt_addr, 1);
             } else if constexpr (q_ == 5) {
-                xform(SET, 3);
                 dma_B_piece(nxt_addr, 2);
             } else if constexpr (q_ == 6 || q_ == 7) {
                 write_A(nxt, q_ - 6);
