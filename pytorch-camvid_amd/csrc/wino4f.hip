@@ -292,10 +292,24 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
         if (ABL & 2) return;
         auto pr = [&](int j) { return f32x2v{d[set][j][2 * p], d[set][j][2 * p + 1]}; };
         const f32x2v d0 = pr(0), d1 = pr(1), d2 = pr(2), d3 = pr(3), d4 = pr(4), d5 = pr(5);
-        auto fma2 = [](float c, f32x2v u, f32x2v v) { return __builtin_elementwise_fma(f32x2v{c, c}, u, v); };      // exactly xform()'s fmaf chain, two channels at once
-        const f32x2v a = fma2(-4.f, d2, d4), b = fma2(-4.f, d1, d3), e = d4 - d2, f = d3 - d1;
-        const f32x2v t0 = fma2(4.f, d0, fma2(-5.f, d2, d4)), t1 = a + b, t2 = a - b, t3 = fma2(2.f, f, e), t4 = fma2(-2.f, f, e),
-                     t5 = fma2(4.f, d1, fma2(-5.f, d3, d5));
+        // the round-3 fmaf chain, two channels per instruction, bitwise the same values.  Written as inline asm: hipcc turns half of the vector
+        // expression back into scalar instructions (a packed fma survives only with an inline constant; a vector subtraction became two
+        // scalar adds): 12 packed instructions per channel pair, the constants {c, c} from scalar register pairs.
+        auto pkfma = [](unsigned long long cc, f32x2v u, f32x2v v) {
+            f32x2v r;
+            asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "s"(cc), "v"(u), "v"(v));
+            return r;
+        };
+        auto pkadd = [](f32x2v u, f32x2v v) {
+            f32x2v r;
+            asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(u), "v"(v));
+            return r;
+        };
+        constexpr unsigned long long C_M4 = 0xC0800000C0800000ull, C_M1 = 0xBF800000BF800000ull, C_P4 = 0x4080000040800000ull,
+                                     C_P2 = 0x4000000040000000ull, C_M2 = 0xC0000000C0000000ull, C_M5 = 0xC0A00000C0A00000ull;
+        const f32x2v a = pkfma(C_M4, d2, d4), b = pkfma(C_M4, d1, d3), e = pkfma(C_M1, d2, d4), f = pkfma(C_M1, d1, d3);
+        const f32x2v t0 = pkfma(C_P4, d0, pkfma(C_M5, d2, d4)), t1 = pkadd(a, b), t2 = pkfma(C_M1, b, a), t3 = pkfma(C_P2, f, e),
+                     t4 = pkfma(C_M2, f, e), t5 = pkfma(C_P4, d1, pkfma(C_M5, d3, d5));
         tv[0][2 * p] = t0[0]; tv[0][2 * p + 1] = t0[1]; tv[1][2 * p] = t1[0]; tv[1][2 * p + 1] = t1[1];
         tv[2][2 * p] = t2[0]; tv[2][2 * p + 1] = t2[1]; tv[3][2 * p] = t3[0]; tv[3][2 * p + 1] = t3[1];
         tv[4][2 * p] = t4[0]; tv[4][2 * p + 1] = t4[1]; tv[5][2 * p] = t5[0]; tv[5][2 * p + 1] = t5[1];
