@@ -27,7 +27,9 @@ def main():
     ap.add_argument("--iters", type=int, default=20, help="synthetic batches per epoch")
     ap.add_argument("-wd", type=float, default=0.0)            # train.py:25
     ap.add_argument("--flat-adamw", action="store_true", help="one fused optimizer kernel (cvk.FlatAdamW)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp32_split"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--split-operands", type=int, default=0, choices=[0, 2, 3],
+                    help="opt-in for fp32: matrix products on the 16-bit matrix pipe with split fp32 operands (cvk.set_split_operands; 2 = fp16 x 2)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
@@ -35,11 +37,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        cvk.ddp.init_process_group("nccl", device_id=dev)      # RCCL with the channel count / CU reservation this path is tuned for
 
     torch.manual_seed(0)
     net = cvk.get_model(a.net, 3, 12).to(dev)                              # utils.get_model (utils.py:147-160)
     cvk.set_conv_precision(net, a.precision)
+    cvk.set_split_operands(net, a.split_operands)
     model = cvk.ddp.DataParallel(net) if world > 1 else net
     opt = cvk.FlatAdamW(net, lr=a.lr, weight_decay=a.wd) if a.flat_adamw else \
         torch.optim.AdamW(net.parameters(), lr=a.lr, weight_decay=a.wd)     # train.py:100
