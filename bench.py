@@ -181,7 +181,9 @@ def kernel_profile(step, dev, nprof=3):
     peak = peak_of(dom[0])
     ach = exe / sec / 1e12                      # FLOPs the MFMA pipe really executes per second: a hardware fraction <= 1
     allf = sum(v[1] for v in agg.values()); alls = sum(v[2] for v in agg.values())
-    alle = sum(v[3] for v in agg.values())
+    # time-weighted mean of the per-kernel hardware fractions, each against ITS OWN pipe's peak (a leg can mix fp32-MFMA and 16-bit
+    # MFMA kernels: the split-operand legs once printed 2.73 here by pricing bf16-pipe FLOPs against the fp32 peak)
+    allfrac = sum(v[3] / 1e12 / peak_of(k) for k, v in agg.items()) / alls
     traffic = None
     pats = ["r*_pmc_hbm_traffic_bf16.json"] if "bf16" in dom[0] else ["r*_pmc_hbm_traffic.json", "r*_pmc_hbm_traffic_fp32.json"]
     tp = sorted((f for pat in pats for f in glob.glob(os.path.join(ROOT, "profiles", pat))), key=os.path.basename)[-1:]
@@ -199,7 +201,7 @@ def kernel_profile(step, dev, nprof=3):
             "executed_share_of_algorithmic_flops": round(exe / fl, 4),
             "flops_per_launch": fl / cnt, "avg_launch_us": round(sec / cnt * 1e6, 1), "launches_per_step": cnt // nprof,
             "all_conv_kernels": {"algorithmic_tflops": round(allf / alls / 1e12, 2),
-                                 "executed_frac_of_peak": round(alle / alls / 1e12 / peak, 4),
+                                 "executed_frac_of_peak": round(allfrac, 4),
                                  "ms_per_step": round(alls / nprof * 1e3, 2)},
             "hbm_bound_kernels_ms_per_step": round(sum(v[2] for v in mem.values()) / nprof * 1e3, 2)}
     return roof, kernels, hbm_kernels
@@ -215,8 +217,12 @@ def logits_accuracy(net, x):
         return None
     import numpy as np
     ref = np.load(path)["logits_dense"]
+    # the fixture is a TRAIN-mode forward pass, which updates the BatchNorm running statistics: put them back, later legs reuse the net
+    saved = {k: v.clone() for k, v in net.named_buffers()}
     with torch.no_grad():
         got = net(x)[:, :, ::8, ::8].float().cpu().numpy()
+        for k, v in net.named_buffers():
+            v.copy_(saved[k])
     dv = np.abs(got - ref)
     tol = None
     try:
@@ -503,17 +509,26 @@ def main():
         w2d_tile = {"tiles": f"channel-heavy layers: 2-D Winograd F({tf}x{tf},3x3) forward / weight-grad, F({td}x{td},3x3) data-grad "
                              "(CVK_W2D_TILE=4 selects the finer-rounding F(4x4,3x3) everywhere: about -8 % images/s)",
                     "logits_vs_reference": logits_accuracy(net, leg["x"]) if (headline and rank == 0) else None}
-    dp_over = None
+    dp_over, dp_fail = None, False
     if world == 1 and (a.dp_overhead or headline) and not a.no_dp_overhead and not rehearsal:
         try:
             dp_over = dp_overhead_leg(A, dev, net, lossf, leg, a, step)
         except Exception as e:          # the leg is extra evidence: a failure of RCCL initialisation must not cost the headline line
             dp_over = {"error": f"{type(e).__name__}: {e}"[:300]}
+            print(f"bench.py: the dp_overhead leg failed: {dp_over['error']}", file=sys.stderr)
+            if a.dp_overhead:           # asked for explicitly: the failure is the result
+                dp_fail = True
 
     dp = None
     if world > 1:
         dp = dp_identity(dev, world, rehearsal)
         dp.update(leg["dp_local"])
+        if not rehearsal and dp["allreduce_exposed_ms"] > 0.03 * leg["ms"]:
+            # ddp.DEFAULT_RCCL_CHANNELS (8) was chosen at world size 1, where no byte crosses xGMI: say so when it shows
+            dp["warning"] = (f"the compute stream waited {dp['allreduce_exposed_ms']} ms per step for the gradient all-reduce "
+                             f"({100 * dp['allreduce_exposed_ms'] / leg['ms']:.1f} % of the step): raise NCCL_MAX_NCHANNELS / CVK_DP_RESERVE_CUS "
+                             "(ddp.init_process_group(rccl_channels=16)) or lower CVK_DDP_BUCKET_MB")
+            print("bench.py: " + dp["warning"], file=sys.stderr)
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -578,6 +593,8 @@ def main():
         real_stdout.flush()
     if dist.is_initialized():
         dist.destroy_process_group()
+    if dp_fail:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -46,6 +46,10 @@ typedef struct cvk_viewh {       /* strided NHWC view of a bf16 (or, where state
 } cvk_viewh;
 
 int         cvk_version(void);
+/* first 64 bits of the SHA-256 of THIS header as the library was compiled against it (csrc/Makefile passes it as
+ * -DCVK_ABI_HASH).  A host binding hashes the header it was written against and refuses a library built from another
+ * one: entry points keep their names when argument lists change, and ctypes / cgo / JNI stubs do not check arity. */
+uint64_t    cvk_abi_hash(void);
 const char* cvk_last_error_string(void);
 
 /* ---- layout at the module boundary: logical NCHW tensors of any strides <-> dense NHWC (ld >= C) --------------

@@ -8,6 +8,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CVK_LIB_PATH") or os.path.join(_HERE, "lib", "libcvk.so")   # override: kernel experiments only
 CSRC = os.path.join(_HERE, "csrc")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "cvk.h")
 
 CVK_STAT_ROWS = 64
 
@@ -32,6 +33,7 @@ class ViewH(ctypes.Structure):
 # name -> (restype, argtypes); the list is checked against include/cvk.h by tests/test_abi.py
 SIGNATURES = {
     "cvk_version": (c_int, []),
+    "cvk_abi_hash": (ctypes.c_uint64, []),
     "cvk_last_error_string": (ctypes.c_char_p, []),
     "cvk_import_nchw": (c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_export_nchw": (c_int, [c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp]),
@@ -245,6 +247,28 @@ def build(verbose=False):
     return LIB_PATH
 
 
+def header_abi_hash(path=None):
+    """First 64 bits of the SHA-256 of include/cvk.h — what csrc/Makefile stamps into the library as CVK_ABI_HASH."""
+    import hashlib
+    with open(path or HEADER, "rb") as f:
+        return int(hashlib.sha256(f.read()).hexdigest()[:16], 16)
+
+
+def check_abi(lib, header=None):
+    """Refuse a library compiled against another include/cvk.h than the one this binding table was written for: entry points keep
+    their names when argument lists change and ctypes does not check arity, so a stale libcvk.so would corrupt calls silently."""
+    try:
+        fn = lib.cvk_abi_hash
+    except AttributeError:
+        raise CvkError(f"{LIB_PATH} exports no cvk_abi_hash: it predates the ABI stamp; rebuild it (make -C {CSRC})") from None
+    fn.restype = ctypes.c_uint64
+    fn.argtypes = []
+    got, want = fn(), header_abi_hash(header)
+    if got != want:
+        raise CvkError(f"{LIB_PATH} was built from another include/cvk.h (library stamp {got:016x}, header {want:016x}); "
+                       f"rebuild it: make -C {CSRC}")
+
+
 def load():
     """Load libcvk.so once.  Raises CvkError when it is missing — there is no fallback path."""
     global _lib
@@ -258,6 +282,7 @@ def load():
             raise CvkError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950).  pytorch_camvid_amd has no CPU/eager fallback.")
         lib = ctypes.CDLL(LIB_PATH)
+        check_abi(lib)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = ABI drift between header and library
             fn.restype = res

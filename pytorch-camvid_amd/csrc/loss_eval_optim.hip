@@ -357,4 +357,8 @@ void cvk_set_error(const char* fmt, ...) {
 }
 
 extern "C" int cvk_version(void) { return CVK_VERSION; }
+#ifndef CVK_ABI_HASH
+#error "CVK_ABI_HASH is not defined: build through csrc/Makefile (it hashes include/cvk.h)"
+#endif
+extern "C" uint64_t cvk_abi_hash(void) { return CVK_ABI_HASH; }
 extern "C" const char* cvk_last_error_string(void) { return g_err; }

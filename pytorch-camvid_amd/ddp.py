@@ -28,6 +28,10 @@ import torch.nn as nn
 # links are real and reserves half the CUs of round 4's 16).  The executor leaves CVK_DP_RESERVE_CUS CUs (default 8) to them: its persistent
 # one-workgroup-per-CU kernels launch on CUs - CVK_DP_RESERVE_CUS workgroups under data parallel (engine.Runner.persistent_wgs).
 # The two numbers belong together, so they are set together — here, not in a benchmark script.
+# UNVERIFIED BEYOND WORLD SIZE 1: no N>1 RCCL run has ever been possible on this pool (SCALE_r01-r05 skipped); at world size 1 the
+# all-reduce moves nothing over xGMI.  The arithmetic says 8 rings are ample (138 MB per 34 ms step = 4 GB/s against ~150 GB/s per link),
+# but if bench.py's `dp.allreduce_exposed_ms` at N>1 is not ~0, raise NCCL_MAX_NCHANNELS (the caller's environment wins) — bench.py prints
+# a `dp.warning` when the exposed wait exceeds 3 % of the step.
 DEFAULT_RCCL_CHANNELS = 8
 
 

@@ -1358,6 +1358,29 @@ class Plan:
                 self.input.ld = 8
 
 
+_SPLIT_ENV_LOGGED = False
+
+
+def _split_mode_from_env():
+    """CVK_W2D_SPLIT (unset | 0 | 1 = 3 | 2 | 3) selects the OPT-IN split-operand arithmetic for every network of the process.  Anything else is
+    an error that names the variable; a non-zero value is reported once on stderr, because it moves the fp32 products onto 16-bit MFMAs."""
+    global _SPLIT_ENV_LOGGED
+    raw = os.environ.get("CVK_W2D_SPLIT")
+    if raw is None:
+        return 0
+    modes = {"0": 0, "1": 3, "3": 3, "2": 2}
+    if raw.strip() not in modes:
+        raise ValueError(f"CVK_W2D_SPLIT={raw!r}: allowed values are 0 (off, the default), 2 (two fp16 terms) and 3 or 1 (three bf16 terms); "
+                         "or leave it unset and call pytorch_camvid_amd.set_split_operands(net, mode)")
+    mode = modes[raw.strip()]
+    if mode and not _SPLIT_ENV_LOGGED:
+        _SPLIT_ENV_LOGGED = True
+        import sys
+        print(f"pytorch_camvid_amd: CVK_W2D_SPLIT={raw} — fp32 convolution products run as split {'fp16 x 2' if mode == 2 else 'bf16 x 3'} operands "
+              "(opt-in, not the exact-fp32 default)", file=sys.stderr)
+    return mode
+
+
 class Runner:
     """Executes a Plan.  One Runner per module instance; plans are cached per input geometry."""
 
@@ -1377,7 +1400,7 @@ class Runner:
         self.wino2d = WINO2D_DEFAULT
         # OPT-IN split-operand modes (cvk.set_split_operands): the matrix products of the fp32 convolutions on the 16-bit
         # matrix pipe with split fp32 operands (csrc/split_fmt.h).  Not the product default; bench.py names the mode in `dtype` when it is on.
-        self.w2d_split = {"0": 0, "1": 3, "3": 3, "2": 2}[os.environ.get("CVK_W2D_SPLIT", "0")]      # 0 off | 3: bf16 x 3 | 2: fp16 x 2
+        self.w2d_split = _split_mode_from_env()      # 0 off | 3: bf16 x 3 | 2: fp16 x 2
         self.w2tile_cfg = W2TILE_DEFAULT    # None = auto (see W2TILE_DEFAULT), 4 or 6 = forced
         self.w2tile = 6                     # the tile of the plan being executed (set by forward / backward)
         self.w2tile_dgrad = 6               # ... of its data-grad launches

@@ -34,3 +34,38 @@ def run(rank, world, port, out_dir, shape, bucket_mb):
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def run_train(rank, world, port, out_dir, shape, bucket_mb, steps, flat):
+    """examples/train_synthetic.py's loop through the REAL executor: ddp.DataParallel + AdamW (torch's or the fused flat one) + OneCycleLR,
+    `steps` optimizer steps on this rank's shards; the parameters afterwards must be identical on every rank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pytorch_camvid_amd as A
+    from pytorch_camvid_amd import ddp
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    torch.manual_seed(100 + rank)
+    net = A.UNet(3, 12).to(dev).train()
+    dp = ddp.DataParallel(net, bucket_mb=bucket_mb)
+    opt = A.FlatAdamW(net, lr=5e-4, weight_decay=0.0) if flat else torch.optim.AdamW(net.parameters(), lr=5e-4, weight_decay=0.0)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=5e-4, steps_per_epoch=steps, epochs=1)
+    lossf = A.CrossEntropyLoss()
+    n, h, w = shape
+    losses = []
+    for k in range(steps):
+        g = torch.Generator().manual_seed(1234 + 17 * k + rank)
+        x = torch.randn(n, 3, h, w, generator=g).to(dev)
+        t = torch.randint(0, 12, (n, h, w), generator=g).to(dev)
+        opt.zero_grad()
+        loss = lossf(dp(x), t)
+        loss.backward()
+        opt.step()
+        sched.step()
+        losses.append(loss.item())
+    torch.cuda.synchronize()
+    torch.save({"params": [p.detach().cpu() for p in net.parameters()], "losses": losses, "bn": [b.detach().cpu() for b in net.buffers()]},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()

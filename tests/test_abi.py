@@ -33,6 +33,26 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert sorted(_lib.SIGNATURES) == header_symbols(), "Python binding table out of sync with include/cvk.h"
 
 
+def test_stale_library_is_refused(tmp_path):
+    """The library carries the hash of the header it was compiled against; load() compares it with the header it sees.  A library
+    built from any other header (same symbol names, other argument lists) must not load."""
+    import ctypes
+    from pytorch_camvid_amd import _lib
+    lib = _lib.load()
+    assert lib.cvk_abi_hash() == _lib.header_abi_hash()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    _lib.check_abi(raw)                                   # the real pair passes
+    other = tmp_path / "cvk.h"
+    other.write_bytes(open(_lib.HEADER, "rb").read() + b"\n/* one more argument somewhere */\n")
+    with pytest.raises(_lib.CvkError, match="another include/cvk.h"):
+        _lib.check_abi(raw, header=str(other))
+
+    class NoStamp:                                        # a library from before the stamp existed
+        pass
+    with pytest.raises(_lib.CvkError, match="predates the ABI stamp"):
+        _lib.check_abi(NoStamp())
+
+
 def test_integration_doc_matches_the_header():
     """INTEGRATION.md is the binding guide a maintainer reads: every cvk_* name it mentions must exist in include/cvk.h, every
     entry point of the header must be mentioned, and the stated counts (entry points, .hip files) must be the real ones."""

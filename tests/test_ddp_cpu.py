@@ -18,20 +18,29 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("bucket_mb", [0.5, 32.0])
-def test_gradsync_world2_gloo(bucket_mb):
+@pytest.mark.parametrize("world,bucket_mb", [(2, 0.5), (2, 32.0), (8, 32.0)])
+def test_gradsync_gloo(world, bucket_mb):
+    """world 2 and the TARGET width 8 (BASELINE.json configs[2]: 8 ranks, one shard each): every rank ends with the same gradients = the mean of
+    the `world` per-shard gradients, and the buckets tile the flat buffer in completion order."""
     from tests.ddp_worker import run
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(run, args=(2, free_port(), d, bucket_mb), nprocs=2, join=True)
-        r0 = torch.load(os.path.join(d, "rank0.pt")); r1 = torch.load(os.path.join(d, "rank1.pt"))
-    assert torch.equal(r0["flat"], r1["flat"])                      # every rank ends with the same gradients
+        mp.spawn(run, args=(world, free_port(), d, bucket_mb), nprocs=world, join=True)
+        rs = [torch.load(os.path.join(d, f"rank{r}.pt")) for r in range(world)]
+    r0 = rs[0]
+    for r in rs[1:]:
+        assert torch.equal(r0["flat"], r["flat"])                   # every rank ends with the same gradients
+        assert r["launched"] == r0["launched"] and r["offs"] == r0["offs"]
     offs = r0["offs"]
-    for i, (a, b) in enumerate(zip(r0["local"], r1["local"])):
-        want = (a + b) / 2
-        got = r0["flat"][offs[i]:offs[i] + a.numel()].view(a.shape)
-        assert torch.allclose(got, want, rtol=1e-6, atol=1e-9), i
+    for i in range(len(r0["local"])):
+        locs = [r["local"][i] for r in rs]
+        want = torch.stack(locs).double().sum(0).div(world).float()
+        got = r0["flat"][offs[i]:offs[i] + locs[0].numel()].view(locs[0].shape)
+        # gloo sums `world` fp32 terms in its own order; the bound is a few ulp of the LARGEST term (terms of both signs cancel)
+        bound = 4 * 1.2e-7 * torch.stack(locs).abs().sum(0) / world + 1e-12
+        assert bool(((got - want).abs() <= bound).all()), (i, float(((got - want).abs() / bound).max()))
     # the shards really differ (otherwise the test would pass without any communication)
-    assert not torch.allclose(r0["local"][0], r1["local"][0])
+    for r in rs[1:]:
+        assert not torch.allclose(r0["local"][0], r["local"][0])
     launched = r0["launched"]
     assert launched[0][0] == 0 and launched[-1][1] == r0["total"]
     for (a0, a1), (b0, b1) in zip(launched[:-1], launched[1:]):
@@ -40,6 +49,20 @@ def test_gradsync_world2_gloo(bucket_mb):
         assert len(launched) > 5                                     # many small buckets, issued while "backward" runs
     else:
         assert 2 <= len(launched) <= 8                               # 138 MB of gradients in a handful of buckets
+
+
+def test_two_optimizer_steps_leave_identical_parameters_on_every_rank():
+    """The loop of examples/train_synthetic.py under gloo, world 2, two AdamW + OneCycleLR steps: ranks start from different weights (the rank-0
+    broadcast equalises them), see different shards (different losses), and must hold bitwise identical parameters afterwards — rank drift is
+    the failure 8 GPUs would show first.  BatchNorm running statistics stay per rank (not reduced)."""
+    from tests.ddp_worker import run_train
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(run_train, args=(2, free_port(), d, 8.0, 2), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "rank0.pt")); r1 = torch.load(os.path.join(d, "rank1.pt"))
+    assert r0["losses"] != r1["losses"] and len(r0["losses"]) == 2
+    for i, (a, b) in enumerate(zip(r0["params"], r1["params"])):
+        assert torch.equal(a, b), i
+    assert any(not torch.equal(a, b) for a, b in zip(r0["bn"], r1["bn"]))      # per-rank BatchNorm buffers
 
 
 def test_bucket_cutting():

@@ -74,6 +74,21 @@ def test_two_ranks_real_engine_equal_grouped_bn_single_process():
     # bottleneck): the reference's own fp32-vs-fp64 runs differ by percents there (tests/test_oracle_golden.py); the exact check is the HIP one above
 
 
+@pytest.mark.parametrize("flat", [False, True])
+def test_two_optimizer_steps_real_engine_no_rank_drift(flat):
+    """The example's training loop through the real executor under ddp.DataParallel, two ranks on this GPU over gloo, two optimizer steps
+    (torch.optim.AdamW as train.py:100, and the fused flat AdamW): different initial weights (broadcast), different shards (different
+    losses), bitwise identical parameters afterwards."""
+    from tests.ddp_gpu_worker import run_train
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(run_train, args=(2, free_port(), d, (2, 48, 64), 8.0, 2, flat), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "rank0.pt")); r1 = torch.load(os.path.join(d, "rank1.pt"))
+    assert r0["losses"] != r1["losses"] and len(r0["losses"]) == 2
+    for i, (a, b) in enumerate(zip(r0["params"], r1["params"])):
+        assert torch.equal(a, b), i
+    assert any(not torch.equal(a, b) for a, b in zip(r0["bn"], r1["bn"]))      # BatchNorm buffers stay per rank
+
+
 def test_bench_rehearsal_self_launch(tmp_path):
     """`python bench.py --gpus 2` with no launcher starts its own ranks (child torch.distributed.run) and prints ONE JSON
     line with n_gpus 2; CVK_REHEARSAL=1 lets the two ranks share this box's single GPU over gloo (not a measurement)."""

@@ -387,7 +387,11 @@ def test_data_parallel_rccl_plumbing_single_rank():
     import pytorch_camvid_amd as A
     from pytorch_camvid_amd import ddp
     if not dist.is_initialized():
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1, device_id=dev())
+        import socket
+        with socket.socket() as sk:             # a free port, not a fixed one: two suites on one host must not collide
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev())
     try:
         torch.manual_seed(0)
         net = A.UNet(3, 12).to(dev()).train()

@@ -16,9 +16,10 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 sys.path.insert(0, G)
 
 
-def _run_protocol(precision, w2d_split=None):
+def _run_protocol(precision, w2d_split=None, steps=None):
     """The reference's loop (train.py:100-134) + validation pass (train.py:169-206) through the engine; returns (losses, report).
-    w2d_split: None = the runner's setting (exact-fp32 MFMA unless the environment opts in), 3 / 2 = the opt-in split-operand GEMMs."""
+    w2d_split: None = the runner's setting (exact-fp32 MFMA unless the environment opts in), 3 / 2 = the opt-in split-operand GEMMs.
+    steps: run only the first `steps` steps of the SAME 300-step schedule (no validation report then)."""
     import pytorch_camvid_amd as A
     from pytorch_camvid_amd.modules import runner_of
     from protocol_data import PROTO as P, proto_batch
@@ -32,13 +33,15 @@ def _run_protocol(precision, w2d_split=None):
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=P["lr"], steps_per_epoch=P["steps"], epochs=1)   # train.py:103-104
     lossf = A.CrossEntropyLoss()
     losses = []
-    for it in range(P["steps"]):
+    for it in range(steps or P["steps"]):
         x, m = proto_batch(it)
         opt.zero_grad()
         loss = lossf(net(x.to(dev)), m.to(dev))
         loss.backward()
         opt.step(); sched.step()
         losses.append(loss.detach())
+    if steps is not None and steps < P["steps"]:
+        return torch.stack(losses).cpu().numpy(), None
     val = [tuple(t.to(dev) for t in proto_batch(i, val=True)) for i in range(P["val_batches"])]
     return torch.stack(losses).cpu().numpy(), A.evaluate_report(net, val, num_classes=12, ignore_index=11)
 
@@ -81,18 +84,23 @@ def test_bf16_mode_trains_to_the_reference_curve_and_miou():
 @pytest.mark.parametrize("w2d_split", [None, 2, 3])
 def test_one_epoch_loss_curve_and_miou_match_the_reference_run(w2d_split):
     """w2d_split None: the product default.  2 / 3: the OPT-IN split-operand GEMMs (fp16 x 2 / bf16 x 3 terms, csrc/split_fmt.h) must train
-    to the same curve within the SAME tolerance — derived from the reference's own reproducibility, not widened for them."""
+    to the same curve within the SAME tolerance — derived from the reference's own reproducibility, not widened for them; they run the first
+    120 steps of the schedule (the suite's wall time: VERDICT r5 #8; the default and the bf16 mode run all 300 and the validation pass)."""
     r0 = dict(np.load(os.path.join(G, "protocol_unet_2x360x480_run0.npz")))
     r1 = dict(np.load(os.path.join(G, "protocol_unet_2x360x480_run1.npz")))
     spread = np.abs(r0["losses"] - r1["losses"])
     assert spread[0] == 0.0 and spread.max() < 5e-3                   # the fixture pair itself: identical start, close curves
     tol = np.maximum(4.0 * np.maximum.accumulate(spread), 2e-5)       # non-decreasing envelope; first step is a pure forward
     tol[1:] = np.maximum(tol[1:], 4.0 * spread.max() * 0.1)           # early steps: at least a tenth of the curve's spread
-    losses, rep = _run_protocol("fp32", w2d_split)
-    d = np.abs(losses - r0["losses"])
+    losses, rep = _run_protocol("fp32", w2d_split, steps=None if w2d_split is None else 120)
+    tol = tol[:len(losses)]
+    d = np.abs(losses - r0["losses"][:len(losses)])
     worst = int(np.argmax(d / tol))
-    print(f"protocol (w2d_split {w2d_split}): max |loss - ref| {d.max():.2e} (reference pair {spread.max():.2e}); final {losses[-1]:.5f} vs {r0['losses'][-1]:.5f}")
+    print(f"protocol (w2d_split {w2d_split}, {len(losses)} steps): max |loss - ref| {d.max():.2e} (reference pair {spread[:len(losses)].max():.2e}); "
+          f"last {losses[-1]:.5f} vs {r0['losses'][len(losses) - 1]:.5f}")
     assert (d <= tol).all(), (worst, float(d[worst]), float(tol[worst]), float(losses[worst]), float(r0["losses"][worst]))
+    if rep is None:
+        return
     ref_miou = float(r0["miou"])
     print(f"protocol: mIoU {rep['miou']:.5f} vs reference {ref_miou:.5f} (reference pair differs by {abs(ref_miou - float(r1['miou'])):.1e})")
     assert abs(rep["miou"] - ref_miou) <= 0.005                         # BASELINE.json: mIoU +-0.005

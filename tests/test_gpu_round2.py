@@ -197,3 +197,6 @@ def test_bench_json_contract_single_gpu():
         for k in ("workload", "dtype", "images_per_s", "ms_per_step", "dominant_kernel", "executed_frac_of_peak", "loss"):
             assert k in e, k
         assert e["images_per_s"] > 0 and 0 < e["executed_frac_of_peak"] <= 1.0 and 2.0 < e["loss"] < 3.0
+        # every printed fraction is a hardware fraction: each kernel against its own pipe's peak (the split legs mix two pipes)
+        assert 0 < e["all_conv_kernels"]["executed_frac_of_peak"] <= 1.0, e["all_conv_kernels"]
+    assert 0 < rf["all_conv_kernels"]["executed_frac_of_peak"] <= 1.0

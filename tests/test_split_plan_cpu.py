@@ -30,6 +30,22 @@ def test_switch_values():
         pass
 
 
+def test_environment_switch_is_validated(monkeypatch, capsys):
+    """CVK_W2D_SPLIT moves the fp32 products onto 16-bit MFMAs for every network of the process: a bad value is a ValueError naming the variable
+    (it used to be a bare KeyError on the first forward pass), a non-zero value is announced once on stderr."""
+    import pytest
+    monkeypatch.delenv("CVK_W2D_SPLIT", raising=False)
+    assert engine._split_mode_from_env() == 0
+    for raw, want in (("0", 0), ("1", 3), ("3", 3), ("2", 2), (" 2 ", 2)):
+        monkeypatch.setenv("CVK_W2D_SPLIT", raw)
+        assert engine._split_mode_from_env() == want
+    assert "CVK_W2D_SPLIT" in capsys.readouterr().err
+    for raw in ("", "true", "4"):
+        monkeypatch.setenv("CVK_W2D_SPLIT", raw)
+        with pytest.raises(ValueError, match="CVK_W2D_SPLIT"):
+            engine._split_mode_from_env()
+
+
 def test_thirteen_layers_run_the_split_gemms_and_none_by_default():
     net = A.UNet(3, 12)
     plan = _headline_plan(net)
