@@ -40,7 +40,10 @@ __host__ __device__ inline long p_rows(int N, int H, int Wtp) { return (long)N *
 // MODE 0: V = B^T d of x (six taps d_j = x[.][4 xt - 1 + j]);  MODE 1: E = A dy (four columns dy[.][4 xt + i]).
 // One thread = one plane row x 4 channels; pad rows / pad column groups are written as zeros (the planes live in a reused
 // workspace).  Reads 1x, writes 1.5x the tensor.
-template <int MODE>
+// SM (MODE 0 only): the SLICE-MAJOR plane layout  plane[xi][C / 16][rows][16]  — the layout the fused forward kernel writes from its staging
+// path (csrc/wino4f.hip, VPL: a wave's store covers 16 consecutive plane rows x 64 bytes = 1 KiB contiguous); element (xi, row, c) at
+// ((xi * (C / 16) + c / 16) * rows + row) * 16 + c % 16.  C % 16 == 0.
+template <int MODE, bool SM = false>
 __global__ __launch_bounds__(256) void k_wgradp_planes(const float* __restrict__ X, int ld, float* __restrict__ P, int N, int H, int W,
                                                       int Wt, int Wtp, int C) {
     const int cvn = C >> 2;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) void k_wgradp_planes(const float* __restrict__
             }
         }
     }
-    float* o = P + (size_t)row * C + c;
+    float* o = SM ? P + ((size_t)(c >> 4) * rows + (size_t)row) * 16 + (c & 15) : P + (size_t)row * C + c;
     const size_t ps = (size_t)rows * C;
 #pragma unroll
     for (int x = 0; x < 6; ++x) *reinterpret_cast<f32x4*>(o + x * ps) = v[x];
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(256) void k_wgradp_planes(const float* __restrict__
 
 // zero rows / column groups of the six planes that no producer writes: the Wtp rows before and after, image rows 0 and H+1 of
 // every image, column groups >= Wt of every image row (for planes written by cvk_bn_bwd_dx_e6)
+template <bool SM = false>
 __global__ __launch_bounds__(256) void k_wgradp_zero_pads(float* __restrict__ P, int N, int H, int Wt, int Wtp, int C) {
     const int cvn = C >> 2;
     const long rows = p_rows(N, H, Wtp);
@@ -122,12 +126,17 @@ __global__ __launch_bounds__(256) void k_wgradp_zero_pads(float* __restrict__ P,
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     const size_t ps = (size_t)rows * C;
 #pragma unroll
-    for (int x = 0; x < 6; ++x) *reinterpret_cast<f32x4*>(P + x * ps + (size_t)row * C + c) = z;
+    for (int x = 0; x < 6; ++x)
+        *reinterpret_cast<f32x4*>(P + x * ps + (SM ? ((size_t)(c >> 4) * rows + (size_t)row) * 16 + (c & 15) : (size_t)row * C + c)) = z;
 }
 
 // ---- the GEMM: one wave per workgroup ----------------------------------------------------------------------------------
 // task = (transform index xi, co block, ci block, run): the depth steps q = strip * H + y of its run, strip = (n, column-group
 // octet).  LDS (12 KiB): V ring of four 2 KiB blocks (image rows y-1, y, y+1 in use, y+2 arriving), E double buffer.
+// VSM: the V planes are slice-major (k_wgradp_planes<0, true> / the fused forward kernel): a 64-channel block of 8 plane rows is four
+// 512-byte runs (one per 16-channel slice); only the per-lane source offset of the two DMA pieces and the row pitch differ — the LDS
+// image ([depth row][64 channels]) and everything behind it are the same.
+template <bool VSM>
 __global__ __launch_bounds__(64, 2) void k_wgradp_gemm(const float* __restrict__ E6, const float* __restrict__ V6, float* __restrict__ slab,
                                                       int H, int Wtp, int Cin_ld, int Cout, long rows, int Q, int runs, int nci, int nco) {
     __shared__ __attribute__((aligned(1024))) char smem[12 * 1024];
@@ -145,19 +154,21 @@ __global__ __launch_bounds__(64, 2) void k_wgradp_gemm(const float* __restrict__
     const int so = Wtp >> 3;                               // strips per image
 
     const float* const Eb = E6 + (size_t)xi * rows * Cout + cot * 64;
-    const float* const Vb = V6 + (size_t)xi * rows * Cin_ld + cit * 64;
+    const float* const Vb = V6 + (size_t)xi * rows * Cin_ld + (VSM ? (size_t)cit * 4 * rows * 16 : (size_t)cit * 64);
+    const int vpitch = VSM ? 16 : Cin_ld;                  // floats between consecutive plane rows of V
     // a 2 KiB block = 8 plane rows x 256 B (64 channels): two DMA pieces of 4 rows; lane -> row lane / 16, 16-byte chunk lane % 16
     const unsigned evoff = (unsigned)(((lane >> 4) * Cout + (lane & 15) * 4) * 4);
-    const unsigned vvoff = (unsigned)(((lane >> 4) * Cin_ld + (lane & 15) * 4) * 4);
+    const unsigned vvoff = VSM ? (unsigned)((((unsigned long)((lane & 15) >> 2) * (unsigned long)rows + (lane >> 4)) * 16 + (lane & 3) * 4) * 4)
+                               : (unsigned)(((lane >> 4) * Cin_ld + (lane & 15) * 4) * 4);
     auto block_row = [&](int strip, int yp) -> long {       // first plane row of (strip, padded image row yp)
         const int n = strip / so, xg = strip - n * so;
         return (long)Wtp + ((long)n * (H + 2) + yp) * Wtp + 8 * xg;
     };
     auto dma_V = [&](int strip, int yp) {                   // -> ring slot yp & 3
-        const float* src = Vb + (size_t)block_row(strip, yp) * Cin_ld;
+        const float* src = Vb + (size_t)block_row(strip, yp) * vpitch;
         const unsigned dst = smem_addr + (yp & 3) * 2048;
         p_dma16(src, vvoff, dst);
-        p_dma16(src + 4 * (size_t)Cin_ld, vvoff, dst + 1024);
+        p_dma16(src + 4 * (size_t)vpitch, vvoff, dst + 1024);
     };
     auto dma_E = [&](int strip, int yp, int slot) {
         const float* src = Eb + (size_t)block_row(strip, yp) * Cout;

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(rank, world, port, out_dir, shape, bucket_mb):
+def run(rank, world, port, out_dir, shape, bucket_mb, train_steps=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -29,26 +29,19 @@ def run(rank, world, port, out_dir, shape, bucket_mb):
     loss = A.CrossEntropyLoss()(dp(x), t)
     loss.backward()
     torch.cuda.synchronize()
-    torch.save({"w0": w0, "grads": [p.grad.detach().cpu() for p in net.parameters()], "loss": loss.item(),
-                "launched": dp.sync.launched, "bn": [b.detach().cpu() for b in net.buffers()]},
-               os.path.join(out_dir, f"rank{rank}.pt"))
+    out = {"w0": w0, "grads": [p.grad.detach().cpu().clone() for p in net.parameters()], "loss": loss.item(),
+           "launched": dp.sync.launched, "bn": [b.detach().cpu().clone() for b in net.buffers()]}
+    if train_steps:         # the same ranks go on training (one spawn for both tests: a fresh box pays ~1 min of imports per spawn)
+        out["train_adamw"] = _train(A, ddp, net, dp, shape, train_steps, False, rank, dev)
+        out["train_flat"] = _train(A, ddp, net, dp, shape, train_steps, True, rank, dev)
+    torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def run_train(rank, world, port, out_dir, shape, bucket_mb, steps, flat):
+def _train(A, ddp, net, dp, shape, steps, flat, rank, dev):
     """examples/train_synthetic.py's loop through the REAL executor: ddp.DataParallel + AdamW (torch's or the fused flat one) + OneCycleLR,
     `steps` optimizer steps on this rank's shards; the parameters afterwards must be identical on every rank."""
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    import pytorch_camvid_amd as A
-    from pytorch_camvid_amd import ddp
-    dev = torch.device("cuda:0")
-    torch.cuda.set_device(dev)
-    torch.manual_seed(100 + rank)
-    net = A.UNet(3, 12).to(dev).train()
-    dp = ddp.DataParallel(net, bucket_mb=bucket_mb)
     opt = A.FlatAdamW(net, lr=5e-4, weight_decay=0.0) if flat else torch.optim.AdamW(net.parameters(), lr=5e-4, weight_decay=0.0)
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=5e-4, steps_per_epoch=steps, epochs=1)
     lossf = A.CrossEntropyLoss()
@@ -65,7 +58,4 @@ def run_train(rank, world, port, out_dir, shape, bucket_mb, steps, flat):
         sched.step()
         losses.append(loss.item())
     torch.cuda.synchronize()
-    torch.save({"params": [p.detach().cpu() for p in net.parameters()], "losses": losses, "bn": [b.detach().cpu() for b in net.buffers()]},
-               os.path.join(out_dir, f"rank{rank}.pt"))
-    dist.barrier()
-    dist.destroy_process_group()
+    return {"params": [p.detach().cpu().clone() for p in net.parameters()], "losses": losses, "bn": [b.detach().cpu().clone() for b in net.buffers()]}

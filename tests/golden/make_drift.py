@@ -94,6 +94,48 @@ def logits_drift(kind, seed, shape, data_seed, stride, noise_seeds=NOISE_SEEDS[:
     return out
 
 
+def grads_drift(kind, seed, shape, data_seed, noise_seeds=NOISE_SEEDS[:2]):
+    """One fwd+bwd of the reference graph at the headline workload: how far do two correct evaluations of every parameter GRADIENT differ,
+    element-wise?  fp32 vs fp64 and fp32 vs fp32-with-1e-6-relative-input-noise.  Per tensor: relative L2 of the difference and the
+    largest element difference over the tensor's largest entry (ReLU-mask and max-pool arg-max flips move single elements)."""
+    n, h, w = shape
+
+    def run(dtype, noise=0.0, ns=7):
+        torch.manual_seed(seed)
+        net = R.build(kind, 3, 12).to(dtype).train()
+        x, t = R.synthetic_batch(n, h, w, data_seed)
+        x = x.to(dtype)
+        if noise:
+            x = x * (1 + noise * torch.randn(x.shape, generator=torch.Generator().manual_seed(ns)).to(dtype))
+        F.cross_entropy(net(x), t).backward()
+        return {k: p.grad.double() for k, p in net.named_parameters() if not k.endswith("conv.0.bias")}
+
+    a = run(torch.float32)
+    out = {}
+
+    def fold(tag, b):
+        for k in a:
+            e = out.setdefault(k, {"fp64_rel_l2": 0.0, "fp64_max_rel": 0.0, "noise_rel_l2": 0.0, "noise_max_rel": 0.0})
+            dlt = a[k] - b[k]
+            e[tag + "_rel_l2"] = max(e[tag + "_rel_l2"], float(dlt.norm() / b[k].norm()))
+            e[tag + "_max_rel"] = max(e[tag + "_max_rel"], float(dlt.abs().max() / b[k].abs().max()))
+
+    fold("fp64", run(torch.float64))
+    for ns in noise_seeds:
+        fold("noise", run(torch.float32, 1e-6, ns))
+    return out
+
+
+GRAD_FLOOR = {"rel_l2": 2e-4, "max_rel": 1e-3}
+
+
+def grads_tolerance(v):
+    """Per tensor: SAFETY x the larger of the two drifts, with a floor (a tensor whose two reference evaluations happen to agree very well
+    is not held to less than the typical fp32 noise of the graph)."""
+    return {k: {"rel_l2": max(GRAD_FLOOR["rel_l2"], SAFETY * max(e["fp64_rel_l2"], e["noise_rel_l2"])),
+                "max_rel": max(GRAD_FLOOR["max_rel"], SAFETY * max(e["fp64_max_rel"], e["noise_max_rel"]))} for k, e in v.items()}
+
+
 LOGITS_FLOOR = 3e-4
 
 
@@ -276,6 +318,11 @@ def main():
     if "logits" in which:
         d["logits"]["unet_s0_2x360x480"] = logits_drift("unet", 0, (2, 360, 480), 1234, (40, 48))
         d["logits"]["unet_s0_8x360x480"] = logits_drift("unet", 0, (8, 360, 480), 1234, (40, 48))
+    d.setdefault("grads", {}); d.setdefault("grads_tolerance", {})
+    if "grads" in which:
+        d["grads"]["unet_s0_8x360x480"] = grads_drift("unet", 0, (8, 360, 480), 1234)
+    for k, v in d["grads"].items():
+        d["grads_tolerance"][k] = grads_tolerance(v)
     for k, v in d["logits"].items():
         d["logits_tolerance"][k] = logits_tolerance(v)
     for k, v in d["trajectory"].items():

@@ -379,6 +379,38 @@ def gold_batch8():
     _fullsize_case("unet", 0, (8, 3, 360, 480), 1234, "unet_s0_8x360x480", (40, 48))
 
 
+DENSE_GRAD_KEYS = ("down1.1.conv.0.weight", "down2.1.conv.0.weight", "up4.0.conv.0.weight", "up4.1.conv.0.weight",
+                   "upsample4.conv.conv.0.weight", "output.conv.0.weight")
+GRAD_STRIDE = 97        # prime: walks every (output channel, input channel, tap) residue of the OIHW order
+
+
+def gold_batch8_grads():
+    """Round 6: the gradients of the headline workload, DENSELY.  loss.backward() (train.py:130-131) of the imported
+    reference at BASELINE.json configs[1] (UNet(3,12), 8x3x360x480, seed 0 / data seed 1234 = bench.py's batch): the FULL weight gradient
+    (logical OIHW order) of six representative conv layers of the full-resolution / half-resolution double-conv blocks (models/unet.py:40-47,
+    81-89) and the head, every 97th element of every other 4-D gradient, and every BatchNorm gamma / beta gradient in full.  Conv biases
+    are left out (their true gradient is 0 under train-mode BatchNorm)."""
+    torch.manual_seed(0)
+    net = UNet(3, 12)
+    net.train()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(8, 3, 360, 480, generator=g)
+    t = torch.randint(0, 12, (8, 360, 480), generator=g)
+    loss = nn.CrossEntropyLoss()(net(x), t)
+    loss.backward()
+    d = {"meta": json.dumps({"kind": "unet", "seed": 0, "shape": [8, 3, 360, 480], "data_seed": 1234, "stride": GRAD_STRIDE,
+                              "dense": list(DENSE_GRAD_KEYS), "torch": torch.__version__}), "loss": npy(loss)}
+    for k, p in net.named_parameters():
+        if k.endswith("conv.0.bias"):
+            continue
+        gr = p.grad.contiguous().flatten()
+        if p.dim() == 4 and k not in DENSE_GRAD_KEYS:
+            gr = gr[::GRAD_STRIDE]
+        d["g." + k] = npy(gr).astype(np.float32)
+    print("b8 grads loss", float(loss), flush=True)
+    save("unet_s0_8x360x480_grads", **d)
+
+
 def gold_segnet_batch8():
     """BASELINE.json configs[4]: SegNet(3,12), 8x3x360x480 (models/segnet.py:82-119), bench.py's batch; plus the same
     run under a 1e-6 relative input perturbation (arg-max flips in the five pool/unpool pairs make single gradients
@@ -460,6 +492,8 @@ if __name__ == "__main__":
         gold_fullsize()
     if "b8" in which:
         gold_batch8()
+    if "b8grads" in which:
+        gold_batch8_grads()
     if "segb8" in which:
         gold_segnet_batch8()
     if "c3" in which:

@@ -223,3 +223,33 @@ def test_w6_point_sets_and_exact_transforms():
     print("F(6x6) standard", e6, "exact transforms", e6x, "F(4x4)", e4, "best alternative", min(others))
     assert min(others) > 0.9 * e6, (e6, others)                  # no alternative point set is meaningfully better
     assert e6x > 0.8 * e6 and e6 > 1.7 * e4, (e6, e6x, e4)      # exact transforms do not close the gap to F(4x4)
+
+
+def test_gradient_tolerances_follow_the_rule_and_cover_the_fixture():
+    """drift.json grads_tolerance is SAFETY x max(fp32-vs-fp64, fp32-vs-noise) per tensor with the stated floors, and names exactly the
+    tensors of the dense gradient fixture (tests/golden/unet_s0_8x360x480_grads.npz: six full conv weight gradients, strided samples of the
+    others, all BatchNorm gradients; no conv biases)."""
+    import json, os
+    import numpy as np
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    sys_path_mod = __import__("sys")
+    sys_path_mod.path.insert(0, G)
+    import make_drift as MD
+    dj = json.load(open(os.path.join(G, "drift.json")))
+    g, t = dj["grads"]["unet_s0_8x360x480"], dj["grads_tolerance"]["unet_s0_8x360x480"]
+    assert MD.grads_tolerance(g) == t
+    fx = np.load(os.path.join(G, "unet_s0_8x360x480_grads.npz"))
+    meta = json.loads(str(fx["meta"]))
+    keys = sorted(k[2:] for k in fx.files if k.startswith("g."))
+    assert keys == sorted(t) and len(keys) == 69 and not any(k.endswith("conv.0.bias") for k in keys)
+    from oracle import torch_ref as R
+    net = R.build("unet", 3, 12)
+    shapes = {k: p.shape for k, p in net.named_parameters()}
+    for k in keys:
+        n = int(np.prod(shapes[k]))
+        want = n if (len(shapes[k]) != 4 or k in meta["dense"]) else (n + meta["stride"] - 1) // meta["stride"]
+        assert fx["g." + k].size == want, k
+    assert len(meta["dense"]) == 6 and sum(fx["g." + k].size for k in meta["dense"]) == 36864 * 2 + 147456 + 73728 * 2 + 6912
+    # the reference's own element-wise gradient drift at this workload is percents for the deep layers (ReLU-mask / arg-max flips) and
+    # 1e-3 for the last block: the tolerances inherit that shape
+    assert 0.02 < t["down3.1.conv.0.weight"]["rel_l2"] < 0.1 and t["output.conv.0.weight"]["rel_l2"] < 0.01

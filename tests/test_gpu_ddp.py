@@ -18,14 +18,24 @@ def free_port():
     return p
 
 
-def test_two_ranks_real_engine_equal_grouped_bn_single_process():
+SHAPE = (2, 48, 64)
+
+
+@pytest.fixture(scope="module")
+def two_ranks():
+    """ONE spawn of two ranks on this GPU (gloo): a backward pass whose gradients are saved, then two optimizer steps with torch's AdamW
+    and two with the fused flat AdamW (tests/ddp_gpu_worker.py)."""
+    from tests.ddp_gpu_worker import run
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(run, args=(2, free_port(), d, SHAPE, 8.0, 2), nprocs=2, join=True)
+        return torch.load(os.path.join(d, "rank0.pt")), torch.load(os.path.join(d, "rank1.pt"))
+
+
+def test_two_ranks_real_engine_equal_grouped_bn_single_process(two_ranks):
     import pytorch_camvid_amd as A
     from oracle import torch_ref as R
-    from tests.ddp_gpu_worker import run
-    shape = (2, 48, 64)
-    with tempfile.TemporaryDirectory() as d:
-        mp.spawn(run, args=(2, free_port(), d, shape, 8.0), nprocs=2, join=True)
-        r0 = torch.load(os.path.join(d, "rank0.pt")); r1 = torch.load(os.path.join(d, "rank1.pt"))
+    shape = SHAPE
+    r0, r1 = two_ranks
     # rank 0's parameters were broadcast: both ranks started from the same weights and ended with the same gradients
     for a, b in zip(r0["w0"], r1["w0"]):
         assert torch.equal(a, b)
@@ -74,15 +84,12 @@ def test_two_ranks_real_engine_equal_grouped_bn_single_process():
     # bottleneck): the reference's own fp32-vs-fp64 runs differ by percents there (tests/test_oracle_golden.py); the exact check is the HIP one above
 
 
-@pytest.mark.parametrize("flat", [False, True])
-def test_two_optimizer_steps_real_engine_no_rank_drift(flat):
+@pytest.mark.parametrize("which", ["train_adamw", "train_flat"])
+def test_two_optimizer_steps_real_engine_no_rank_drift(two_ranks, which):
     """The example's training loop through the real executor under ddp.DataParallel, two ranks on this GPU over gloo, two optimizer steps
-    (torch.optim.AdamW as train.py:100, and the fused flat AdamW): different initial weights (broadcast), different shards (different
-    losses), bitwise identical parameters afterwards."""
-    from tests.ddp_gpu_worker import run_train
-    with tempfile.TemporaryDirectory() as d:
-        mp.spawn(run_train, args=(2, free_port(), d, (2, 48, 64), 8.0, 2, flat), nprocs=2, join=True)
-        r0 = torch.load(os.path.join(d, "rank0.pt")); r1 = torch.load(os.path.join(d, "rank1.pt"))
+    (torch.optim.AdamW as train.py:100, then the fused flat AdamW): different initial weights (broadcast), different shards (different
+    losses), bitwise identical parameters afterwards — rank drift is the failure 8 GPUs would show first."""
+    r0, r1 = (r[which] for r in two_ranks)
     assert r0["losses"] != r1["losses"] and len(r0["losses"]) == 2
     for i, (a, b) in enumerate(zip(r0["params"], r1["params"])):
         assert torch.equal(a, b), i

@@ -353,6 +353,51 @@ def test_unet_fullsize_batch8_golden():
     np.testing.assert_allclose(bv, d["bn_var_l2"], rtol=1e-4)
 
 
+@pytest.mark.parametrize("tile", [6, 4])
+def test_unet_fullsize_batch8_dense_gradients(tile):
+    """VERDICT r5 #3 — the gradients of the headline workload (BASELINE.json configs[1]; loss.backward() of train.py:130-131), ELEMENT-WISE
+    against the imported reference (tests/golden/unet_s0_8x360x480_grads.npz, make_golden.py b8grads): the full weight gradient of six conv
+    layers of the full- / half-resolution double-conv blocks and the head, every 97th element of every other conv weight gradient, every
+    BatchNorm gamma / beta gradient — for the default 2-D tile F(6x6,3x3) and for F(4x4,3x3).  Tolerances per tensor are DERIVED
+    (tests/golden/make_drift.py grads -> drift.json grads_tolerance): 4 x the larger of the reference graph's own fp32-vs-fp64 and
+    fp32-vs-1e-6-input-noise drift of that tensor (relative L2, and largest element difference over the tensor's largest entry)."""
+    import pytorch_camvid_amd as A
+    from pytorch_camvid_amd.modules import runner_of
+    d = dict(np.load(os.path.join(G, "unet_s0_8x360x480_grads.npz")))
+    meta = json.loads(str(d["meta"]))
+    dj = json.load(open(os.path.join(G, "drift.json")))
+    tol, drift = dj["grads_tolerance"]["unet_s0_8x360x480"], dj["grads"]["unet_s0_8x360x480"]
+    torch.manual_seed(meta["seed"])
+    net = A.UNet(3, 12).to(dev()).train()
+    runner_of(net).w2tile_cfg = tile
+    x, t = batch(8, 360, 480, meta["data_seed"])
+    loss = A.CrossEntropyLoss()(net(x), t)
+    loss.backward()
+    assert abs(loss.item() - float(d["loss"])) < 2e-5
+    used, rows = [], []
+    for k, p in net.named_parameters():
+        if k.endswith("conv.0.bias"):
+            continue
+        got = p.grad.detach().contiguous().flatten()                 # logical OIHW order, as the fixture
+        if p.dim() == 4 and k not in meta["dense"]:
+            got = got[::meta["stride"]]
+        got = got.double().cpu().numpy()
+        ref = d["g." + k].astype(np.float64)
+        assert got.shape == ref.shape, k
+        rl2 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+        mx = float(np.abs(got - ref).max() / np.abs(ref).max())
+        rows.append((k, rl2, mx, tol[k]["rel_l2"], tol[k]["max_rel"]))
+        used.append(max(rl2 / tol[k]["rel_l2"], mx / tol[k]["max_rel"]))
+        # also relative to the reference's own drift (1.0 = as far from the reference as the reference is from itself)
+    worst = int(np.argmax(used))
+    dense = [r for r in rows if r[0] in meta["dense"]]
+    print(f"dense gradients, tile {tile}: {len(rows)} tensors ({sum(d['g.' + r[0]].size for r in rows)} elements), share of the derived tolerance "
+          f"used: max {max(used):.2f} ({rows[worst][0]}), median {float(np.median(used)):.2f}; six full tensors: "
+          + ", ".join(f"{r[0].split('.conv.0')[0]} relL2 {r[1]:.1e}/{r[3]:.1e}" for r in dense))
+    for (k, rl2, mx, t1, t2) in rows:
+        assert rl2 <= t1 and mx <= t2, (k, rl2, t1, mx, t2, "reference drift", drift[k])
+
+
 def test_unet_batch8_properties():
     """BASELINE.json configs[1] (8x3x360x480): size-independent properties — per-sample independence of eval-mode
     forward (batch of 8 == eight batches of 1), determinism (bitwise equal reruns), finite grads for all 92 tensors."""

@@ -2,6 +2,9 @@
 nn.Conv2d(cin, cout, 3, padding=1) of /root/reference/models/unet.py:11 (forward, + the BatchNorm batch statistics the
 block's train-mode BN needs, unet.py:12) and its data-gradient (backward of train.py:131).  Tolerances: the F(4,3)
 transform constants (4, 5, 8) round 6-8e-7 relative L2 per layer (tests/test_drift_cpu.py); stated below per check."""
+import os
+
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -187,3 +190,22 @@ def test_planes_weight_grad_is_deterministic():
     dy = torch.randn(2, 40, 72, 128, generator=g).cuda()
     a, b = _planes_wgrad(x, dy), _planes_wgrad(x, dy)
     assert torch.equal(a, b)
+
+
+def test_fused_f43_bitwise_equals_the_pre_packed_kernel():
+    """commits eb2087d / 36c1d00 (input transform on channel pairs, packed FMAs, inline asm) claimed "bitwise the same
+    values" in their messages.  tests/golden/wino4f_bits.npz holds bit-pattern checksums (1024 wrapping uint32 sums per tensor) of the
+    output and statistics partials of the library built at bf80833 — the commit before them — on one ragged shape, forward (bias +
+    statistics) and data-grad form; today's kernel must reproduce every bucket (tests/golden/make_wino4f_bits.py, raw C ABI)."""
+    import ctypes
+    import sys
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    sys.path.insert(0, G)
+    import make_wino4f_bits as M
+    from pytorch_camvid_amd import _lib
+    _lib.load()                                    # ABI stamp checked; the calls below go through a raw handle
+    ref = dict(np.load(os.path.join(G, "wino4f_bits.npz")))
+    got = M.run(ctypes.CDLL(_lib.LIB_PATH))
+    for k in ("fwd_y", "fwd_stats", "dgrad_y"):
+        bad = int((got[k] != ref[k]).sum())
+        assert bad == 0, (k, bad, got[k + "_first"] if k + "_first" in got else None)
