@@ -253,6 +253,14 @@ typedef struct cvk_wt_job { const float* w; float* out; int rows, cols, tile, dg
 int cvk_wino4f_weight_transform_batch(const cvk_wt_job* jobs, int n, void* stream);
 int cvk_w2d_weight_transform_batch(const cvk_wt_job* jobs, int n, void* stream);
 int cvk_wino4f_stat_partials(int N, int H, int W);
+/* cvk_conv3x3_wino4f (forward form) that ALSO leaves the layer's weight-grad operand behind: the kernel's staging path computes exactly the
+ * rows V_xi = B^T d that the plane GEMM of the weight-grad reads (cvk_wgradp_gemm_sm), so the centre-kernel-row slices are stored as six
+ * SLICE-MAJOR planes Vsm[6][Cin / 16][cvk_wgradp_plane_rows(N,H,W)][16] (element (xi, row, c) at ((xi * Cin/16 + c/16) * rows + row) * 16 + c % 16;
+ * a wave's store is 1 KiB contiguous).  The pad rows must have been zeroed by cvk_wgradp_zero_pads_sm.  y / stats / counts are bitwise those of
+ * cvk_conv3x3_wino4f; stats and counts may both be NULL (frozen BatchNorm).  Replaces the x -> V pass of the weight-grad of
+ * nn.Conv2d(cin,cout,3,padding=1) (/root/reference/models/unet.py:11, backward of train.py:131). */
+int cvk_conv3x3_wino4f_vplanes(const float* x, const float* Uf, const float* bias, float* y, float* stats, float* counts, float* Vsm,
+                               int N, int H, int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream);
 int cvk_conv3x3_wino4f(const float* x, const float* Uf, const float* bias, float* y, float* stats, float* counts, int N, int H,
                        int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream);
 /* The data-grad launch whose result y is the COMPLETE dL/d(activation) of the block that produced this conv's input
@@ -300,6 +308,14 @@ size_t cvk_wgradp_gemm_workspace_bytes(int N, int H, int W, int Cin_pad, int Cou
 int cvk_wgradp_gemm(const float* E6, const float* V6, float* dw, int N, int H, int W, int Cin, int Cin_pad, int Cout, void* workspace,
                     size_t workspace_bytes, void* stream);
 int cvk_wgradp_zero_pads(float* planes, int N, int H, int W, int C, void* stream);
+/* the same three steps for SLICE-MAJOR V planes [6][C / 16][rows][16] (C % 16 == 0) — the layout cvk_conv3x3_wino4f_vplanes writes from the forward
+ * pass, so that the weight-grad needs no pass over x at all: zero the pad rows before the forward launch; cvk_wgradp_planes_sm builds the
+ * same planes from x in a pass of its own (forward ran another kernel; tests); cvk_wgradp_gemm_sm = cvk_wgradp_gemm reading them (E6 stays
+ * row-major [6][rows][Cout]; same workspace size). */
+int cvk_wgradp_zero_pads_sm(float* planes, int N, int H, int W, int C, void* stream);
+int cvk_wgradp_planes_sm(const float* x, int ld, float* planes, int N, int H, int W, int C, void* stream);
+int cvk_wgradp_gemm_sm(const float* E6, const float* V6sm, float* dw, int N, int H, int W, int Cin, int Cin_pad, int Cout, void* workspace,
+                       size_t workspace_bytes, void* stream);
 int cvk_bn_bwd_dx_e6(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
                      const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* E6, float* part,
                      int N, int H, int W, int C, int use_batch_stats, void* stream);

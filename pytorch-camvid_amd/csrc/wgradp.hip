@@ -330,8 +330,18 @@ extern "C" int cvk_wgradp_zero_pads(float* planes, int N, int H, int W, int C, v
     const int Wt = (W + 3) / 4, Wtp = (Wt + 7) / 8 * 8;
     const long pr = 2L * Wtp + (long)N * 2 * Wtp + (long)N * H * (Wtp - Wt);
     const long threads = pr * (C / 4);
-    hipLaunchKernelGGL(k_wgradp_zero_pads, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, planes, N, H, Wt, Wtp, C);
+    hipLaunchKernelGGL(k_wgradp_zero_pads<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, planes, N, H, Wt, Wtp, C);
     CVK_LAUNCH_RETURN("cvk_wgradp_zero_pads");
+}
+
+// ... of six SLICE-MAJOR V planes [6][C / 16][rows][16] that the fused forward kernel is about to fill (cvk_conv3x3_wino4f_vplanes)
+extern "C" int cvk_wgradp_zero_pads_sm(float* planes, int N, int H, int W, int C, void* stream) {
+    CVK_CHECK_ARG(planes && N > 0 && H > 0 && W > 0 && C > 0 && C % 16 == 0 && cvk_aligned16(planes), "cvk_wgradp_zero_pads_sm: bad arguments");
+    const int Wt = (W + 3) / 4, Wtp = (Wt + 7) / 8 * 8;
+    const long pr = 2L * Wtp + (long)N * 2 * Wtp + (long)N * H * (Wtp - Wt);
+    const long threads = pr * (C / 4);
+    hipLaunchKernelGGL(k_wgradp_zero_pads<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, planes, N, H, Wt, Wtp, C);
+    CVK_LAUNCH_RETURN("cvk_wgradp_zero_pads_sm");
 }
 
 extern "C" size_t cvk_conv3x3_wgradp_workspace_bytes(int N, int H, int W, int Cin_ld, int Cout) {
@@ -353,6 +363,17 @@ extern "C" int cvk_wgradp_planes(const float* t, int ld, float* planes, int N, i
     CVK_LAUNCH_RETURN("cvk_wgradp_planes");
 }
 
+// V = B^T d of x as six SLICE-MAJOR planes [6][C / 16][rows][16] (pad rows included) — what cvk_conv3x3_wino4f_vplanes leaves behind, as a pass
+// of its own (callers whose forward pass ran another kernel; tests)
+extern "C" int cvk_wgradp_planes_sm(const float* x, int ld, float* planes, int N, int H, int W, int C, void* stream) {
+    CVK_CHECK_ARG(x && planes && N > 0 && H > 0 && W > 0 && C > 0 && C % 16 == 0 && ld >= C && ld % 4 == 0, "cvk_wgradp_planes_sm: bad arguments");
+    CVK_CHECK_ARG(cvk_aligned16(x) && cvk_aligned16(planes), "cvk_wgradp_planes_sm: pointers must be 16-byte aligned");
+    const int Wt = (W + 3) / 4, Wtp = (Wt + 7) / 8 * 8;
+    const long th = p_rows(N, H, Wtp) * (C / 4);
+    hipLaunchKernelGGL((k_wgradp_planes<0, true>), dim3((unsigned)((th + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld, planes, N, H, W, Wt, Wtp, C);
+    CVK_LAUNCH_RETURN("cvk_wgradp_planes_sm");
+}
+
 extern "C" size_t cvk_wgradp_gemm_workspace_bytes(int N, int H, int W, int Cin_ld, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin_ld < 64 || Cout < 64 || Cin_ld % 64 || Cout % 64) return 0;
     const PPlan p = plan_wgradp(N, H, W, Cin_ld, Cout);
@@ -360,8 +381,8 @@ extern "C" size_t cvk_wgradp_gemm_workspace_bytes(int N, int H, int W, int Cin_l
 }
 
 // dw from the planes E6 [6][rows][Cout] and V6 [6][rows][Cin_ld]: GEMM into slabs (workspace) + fixed-order reduction with G^T
-extern "C" int cvk_wgradp_gemm(const float* E6, const float* V6, float* dw, int N, int H, int W, int Cin, int Cin_ld, int Cout,
-                               void* workspace, size_t workspace_bytes, void* stream) {
+static int wgradp_gemm_go(bool vsm, const float* E6, const float* V6, float* dw, int N, int H, int W, int Cin, int Cin_ld, int Cout,
+                          void* workspace, size_t workspace_bytes, void* stream) {
     CVK_CHECK_ARG(E6 && V6 && dw && workspace, "cvk_wgradp_gemm: null pointer");
     CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= Cin_ld && Cin_ld % 64 == 0 && Cout % 64 == 0 && Cout >= 64,
                   "cvk_wgradp_gemm: Cin_ld=%d and Cout=%d must be multiples of 64", Cin_ld, Cout);
@@ -374,7 +395,12 @@ extern "C" int cvk_wgradp_gemm(const float* E6, const float* V6, float* dw, int 
     hipStream_t s = (hipStream_t)stream;
     float* slab = (float*)workspace;
     const int per = 6 * p.nci * p.nco;
-    hipLaunchKernelGGL(k_wgradp_gemm, dim3(per * p.runs), dim3(64), 0, s, E6, V6, slab, H, p.Wtp, Cin_ld, Cout, p.rows, p.Q, p.runs, p.nci, p.nco);
+    if (vsm) {
+        CVK_CHECK_ARG(3L * p.rows * 64 + 4096 < (1L << 32), "cvk_wgradp_gemm_sm: %ld plane rows exceed the 32-bit lane offset of the slice-major V block", p.rows);
+        hipLaunchKernelGGL(k_wgradp_gemm<true>, dim3(per * p.runs), dim3(64), 0, s, E6, V6, slab, H, p.Wtp, Cin_ld, Cout, p.rows, p.Q, p.runs, p.nci, p.nco);
+    } else {
+        hipLaunchKernelGGL(k_wgradp_gemm<false>, dim3(per * p.runs), dim3(64), 0, s, E6, V6, slab, H, p.Wtp, Cin_ld, Cout, p.rows, p.Q, p.runs, p.nci, p.nco);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         cvk_set_error("cvk_wgradp_gemm: launch failed: %s", hipGetErrorString(e));
@@ -383,6 +409,16 @@ extern "C" int cvk_wgradp_gemm(const float* E6, const float* V6, float* dw, int 
     const size_t total = (size_t)Cout * 3 * Cin;
     hipLaunchKernelGGL(k_wgradp_reduce, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, s, slab, dw, p.runs, Cout, Cin, Cin_ld);
     CVK_LAUNCH_RETURN("cvk_wgradp_gemm");
+}
+
+extern "C" int cvk_wgradp_gemm(const float* E6, const float* V6, float* dw, int N, int H, int W, int Cin, int Cin_ld, int Cout,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    return wgradp_gemm_go(false, E6, V6, dw, N, H, W, Cin, Cin_ld, Cout, workspace, workspace_bytes, stream);
+}
+// the same with SLICE-MAJOR V planes (cvk_conv3x3_wino4f_vplanes / cvk_wgradp_planes_sm); E6 stays row-major [6][rows][Cout]
+extern "C" int cvk_wgradp_gemm_sm(const float* E6, const float* V6sm, float* dw, int N, int H, int W, int Cin, int Cin_ld, int Cout,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    return wgradp_gemm_go(true, E6, V6sm, dw, N, H, W, Cin, Cin_ld, Cout, workspace, workspace_bytes, stream);
 }
 
 // one call: E6_pre NULL (the E planes are built from dy in the workspace) or the six planes written by cvk_wgradp_zero_pads +

@@ -34,6 +34,12 @@ constexpr int F_BM = 128, F_BN = 64, F_BK = 16;
 constexpr int F_ABYTES = 6 * F_BM * 64;          // six V_xi tiles, 64-byte rows
 constexpr int F_BBYTES = 6 * F_BN * 64;          // six U_xi tiles
 constexpr int F_STAGE = F_ABYTES + F_BBYTES;     // 73728
+// per-channel constants of the epilogue (bias; BNR: scale, shift, mean, rstd of the producer's BatchNorm) live in LDS, copied once before the
+// K loop: ANY vector-memory load in the epilogue — even the single conditional `bias[col]` — made hipcc's wait-count bookkeeping give up at
+// the loop header and put an `s_waitcnt vmcnt(0)` into the first K step of every pair (round 6, read off the ISA of all variants: the pixel
+// loads then had half a step instead of almost two to arrive).  Cout <= F_CMAX (host check).
+constexpr int F_CMAX = 512;
+constexpr int F_CST = 5 * F_CMAX * 4;            // bias | scale | shift | mean | rstd
 
 // Uf[slice][n-tile][xi][64 rows][16 floats]: row = output channel (n-tile * 64 + row), the 16 floats = K elements
 // slice*16 .. +15 of (G g)_xi, K = kernel row * Ck + input channel; 16-byte chunk c of row r is stored at c ^ ((r >> 2) & 3)
@@ -164,19 +170,46 @@ struct FSplit {
     const unsigned* amaxW;      // ... of the filter
     CvkSplitTab tabB, tabG;
 };
+// VPL (forward launches of layers whose weight-grad runs the plane GEMM of csrc/wgradp.hip): the staging path computes exactly the rows
+// V_xi = B^T d that k_wgradp_gemm reads, so the slices of the CENTRE kernel row (input row = the tile row's own image row) of n-tile 0 are
+// also stored to the weight-grad's V planes — SLICE-MAJOR, plane[xi][Cin / 16][rows][16]: the 64 bytes a thread group of four holds for one
+// plane row are contiguous with its neighbours' (a wave's store = 16 plane rows x 64 B = 1 KiB contiguous, whole 128-byte lines; round 3's
+// row-major attempt wrote 64-byte half lines 256-512 B apart and lost the weight-grad's gain in the forward kernel).  Pad rows are
+// zeroed by cvk_wgradp_zero_pads_sm beforehand.
+struct FVpl {
+    float* p;            // six slice-major planes
+    long rows;           // cvk_wgradp_plane_rows(N, H, W)
+    int Wtp;             // column groups per plane image row (ceil(W/4) rounded up to 8)
+};
+typedef unsigned u32x4f __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
-template <bool STATS, int ABL = 0, bool BNR = false, bool H2 = false>
+// CL: the epilogue's per-channel constants come from LDS (Cout <= F_CMAX; see F_CMAX) instead of global memory
+template <bool STATS, int ABL = 0, bool BNR = false, bool H2 = false, bool VPL = false, bool CL = false>
 __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
     const float* __restrict__ X, const float* __restrict__ Uf, const float* __restrict__ bias, float* __restrict__ Y,
     float* __restrict__ stats, float* __restrict__ counts, int Mt, int H, int W, int Wt, int Cin, int Cout, int ldy,
-    int tilesN, int ntiles, int Mpix, int P, FBnRed bn, FSplit sp) {
+    int tilesN, int ntiles, int Mpix, int P, FBnRed bn, FSplit sp, FVpl vp) {
     static_assert(!(STATS && BNR), "forward statistics and the BatchNorm-backward sums are different launches");
-    __shared__ __attribute__((aligned(1024))) char smem[2 * F_STAGE + 2048];
+    static_assert(!(VPL && (BNR || H2)), "the weight-grad's V planes are written by exact-fp32 forward launches only");
+    static_assert(!(CL && H2) && !(VPL && !CL), "LDS constants: exact-fp32 variants; the plane-writing launch always has them");
+    __shared__ __attribute__((aligned(1024))) char smem[2 * F_STAGE + 2048 + (CL ? F_CST : 0)];
     const unsigned smem_addr = cvk_lds_addr(smem);
     float* const red = reinterpret_cast<float*>(smem + 2 * F_STAGE);     // [2 sums][4 wave rows][64 channels]
+    float* const cst = red + 512;                                         // [5][F_CMAX] per-channel constants (zero beyond Cout)
+    if constexpr (CL) {
+        const int c = threadIdx.x;                                        // 512 threads == F_CMAX
+        const bool ok = c < Cout;
+        cst[c] = (bias != nullptr && ok) ? bias[c] : 0.f;
+        if (BNR) {
+            cst[F_CMAX + c] = ok ? bn.scale[c] : 0.f;
+            cst[2 * F_CMAX + c] = ok ? bn.shift[c] : 0.f;
+            cst[3 * F_CMAX + c] = ok ? bn.mean[c] : 0.f;
+            cst[4 * F_CMAX + c] = ok ? bn.rstd[c] : 0.f;
+        }
+    }                                                                     // visible after the prologue's barrier
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -225,6 +258,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
     const int srow = tid >> 2, schunk = tid & 3;
     unsigned ibase = 0, iflag = 0;      // byte offset of (pixel d1 - first) * Cin * 4 + chunk * 16; bits 0..2 kernel rows, 3..8 columns d0..d5
     unsigned aoff[6];
+    constexpr unsigned VPO_NONE = 0xFFFFFFF0u;
+    unsigned vpo = VPO_NONE;            // VPL: byte offset of this thread's 16 bytes in a (xi, slice) sub-plane (out of range for rows beyond the tensor)
     auto set_tile = [&](int tile) {
         const int m0 = (tile / tilesN) * F_BM;
         const int q0 = (int)divWt.div((unsigned)m0);
@@ -236,13 +271,16 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
         unsigned fl = 0, base = 0;
         if (t < Mt) {
             const int q = (int)divWt.div((unsigned)t), xt = t - q * Wt;
-            const int y = q - (int)divH.div((unsigned)q) * H;
+            const int nimg = (int)divH.div((unsigned)q);
+            const int y = q - nimg * H;
+            if (VPL) vpo = ((unsigned)(vp.Wtp + (q + 2 * nimg + 1) * vp.Wtp + xt) << 6) + (unsigned)schunk * 16u;
             fl = 2u | (y > 0 ? 1u : 0u) | (y + 1 < H ? 4u : 0u);
             fl |= (xt > 0 ? 8u : 0u) | 16u;
 #pragma unroll
             for (int j = 2; j < 6; ++j) fl |= (4 * xt + j - 1 < W) ? (8u << j) : 0u;
             base = (unsigned)(q * W + 4 * xt - first) * (unsigned)Cin * 4u + (unsigned)schunk * 16u;
         }
+        else if (VPL) vpo = VPO_NONE;
         ibase = base;
         iflag = fl;
     };
@@ -318,6 +356,44 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
     auto write_A = [&](char* stage, int x) {
         if (ABL & 2) return;
         *reinterpret_cast<f32x4*>(stage + x * (F_BM * 64) + wr_off) = tv[x];
+    };
+    // VPL: the slice being staged (two behind the loader: the loader's tile is still the staged slice's tile while kernel row 1 is staged,
+    // Cin >= 32) — kernel row, channel offset, n-tile; and the store of V_x to sub-plane (x, channel slice)
+    int st_r = 0, st_cib = F_BK, st_tn = tbeg % tilesN;
+    // ONE resource over the six planes (< 4 GiB: host check); the (xi, slice) sub-plane travels in the store's scalar offset.  gfx9 range
+    // check of a raw buffer: dropped if vgpr_offset >= num_records - sgpr_offset — the scalar offset COUNTS (a first version with num_records =
+    // one sub-plane wrote sub-plane (0, 0) only), so num_records is the whole allocation and VPO_NONE lies beyond any of it.
+    const unsigned vsub = VPL ? (unsigned)(vp.rows * 64) : 0u;            // bytes per (xi, slice) sub-plane
+    const unsigned vxs = vsub * (unsigned)(Cin >> 4);                     // bytes per plane
+    const unsigned long long vpa = (unsigned long long)vp.p;
+    const u32x4f vr = {(unsigned)vpa, (unsigned)(vpa >> 32) & 0xFFFFu, 6u * vxs, 0x00020000u};     // raw buffer: base, stride 0, num_records, dword format
+    unsigned vso = 0;                                                     // sub-plane (0, staged slice)
+    auto advance_staged = [&]() {
+        st_cib += F_BK;
+        const int w1 = st_cib >= Cin;
+        st_cib = w1 ? 0 : st_cib;
+        st_r += w1;
+        const int w2 = st_r == 3;
+        st_r = w2 ? 0 : st_r;
+        st_tn = w2 ? (st_tn + tstride) % tilesN : st_tn;
+    };
+    auto store_V = [&](int x) {
+        if (!VPL) return;
+        // Inline asm on purpose: hipcc must not SEE these stores.  They sit under a uniform branch, and every such branch costs its wait-count
+        // bookkeeping one position at the merge (the pixel loads look one younger per branch): with builtin stores the transform's wait for its
+        // pixel loads became vmcnt(0) — a full drain every other step.  Unseen, the stores only make hipcc's counted waits conservative (loads,
+        // stores and LDS-DMA retire through ONE in-order counter: a wait for "all but the N youngest" then covers a few operations more).
+        // Streaming (nt): the planes are read again only by the weight-grad.  tv[x] is not written again before the next step's transform.
+#ifndef CVK_VPL_POLICY
+#define CVK_VPL_POLICY 0
+#endif
+#if CVK_VPL_POLICY == 0
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(vpo), "s"(vr), "s"(vso + (unsigned)x * vxs) : "memory");
+#elif CVK_VPL_POLICY == 1
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" : : "v"(tv[x]), "v"(vpo), "s"(vr), "s"(vso + (unsigned)x * vxs) : "memory");
+#else
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc0 sc1 nt" : : "v"(tv[x]), "v"(vpo), "s"(vr), "s"(vso + (unsigned)x * vxs) : "memory");
+#endif
     };
     // H2: the two fp16 terms of 2^e * V_x for this thread's four channels: 8 bytes each into the h1 / h2 chunk of its row
     // (H2 swizzle of the A region: bit 1 from row bit 2, bit 0 from row bit 3 — the 8 rows of a half-wave's 8-byte stores then cover all 64 banks;
@@ -446,7 +522,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
         const int m0 = mt * F_BM;
         const int col = tn * F_BN + wn * 32 + li;
         const bool cok = col < Cout;
-        const float bs = (bias != nullptr && cok) ? bias[col] : 0.f;
+        const float bs = CL ? cst[col & (F_CMAX - 1)] : ((bias != nullptr && cok) ? bias[col] : 0.f);
         const int qb = (int)divWt.div((unsigned)m0);
         const int pixb = qb * W + 4 * (m0 - qb * Wt);               // first pixel of the tile (uniform)
         const size_t ybytes = ((size_t)Mpix - pixb) * ldy * 4;
@@ -459,7 +535,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
         if (BNR) {
             pr = __builtin_amdgcn_make_buffer_rsrc((void*)(bn.y + (size_t)pixb * ldy), 0,
                                                    (int)(ybytes < 0x7FFFFFFFu ? ybytes : 0x7FFFFFFFu), 0x00020000);
-            if (cok) { bsc = bn.scale[col]; bsh = bn.shift[col]; bmu = bn.mean[col]; }
+            if (CL) { bsc = cst[F_CMAX + (col & (F_CMAX - 1))]; bsh = cst[2 * F_CMAX + (col & (F_CMAX - 1))]; bmu = cst[3 * F_CMAX + (col & (F_CMAX - 1))]; }
+            else if (cok) { bsc = bn.scale[col]; bsh = bn.shift[col]; bmu = bn.mean[col]; }
         }
         // g = dX where the producer's ReLU passed; accumulates sum g and sum g * (yP - mean)  (rstd multiplies once, at the end)
         auto bnacc = [&](float q, float v) {
@@ -548,7 +625,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
                     const float a = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
                     const float b = (red[256 + tid] + red[320 + tid]) + (red[384 + tid] + red[448 + tid]);
                     stats[(size_t)mt * Cout + c] = a;
-                    stats[(size_t)(P + mt) * Cout + c] = b * bn.rstd[c];
+                    stats[(size_t)(P + mt) * Cout + c] = b * (CL ? cst[4 * F_CMAX + c] : bn.rstd[c]);
                 }
             }
         }
@@ -569,7 +646,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
                     const float a = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
                     const float b = (red[256 + tid] + red[320 + tid]) + (red[384 + tid] + red[448 + tid]);
                     const float m2 = b - a * a / cnt;                  // sums exclude the bias (shift invariance)
-                    const float bc = bias != nullptr ? bias[c] : 0.f;
+                    const float bc = CL ? cst[c] : (bias != nullptr ? bias[c] : 0.f);
                     stats[(size_t)mt * Cout + c] = a + cnt * bc;
                     stats[(size_t)(P + mt) * Cout + c] = m2 > 0.f ? m2 : 0.f;
                     if (tid == 0 && tn == 0) counts[mt] = cnt;
@@ -602,6 +679,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
     // the matrix pipe idle.  Tried without gain: waves 4-7 doing their side work half a step later than waves 0-3.
     auto step = [&](auto par_, const char* cur, char* nxt, unsigned nxt_addr) {
         constexpr int SET = 1 - decltype(par_)::value;      // register set holding the slice this step stages (slice g + 1)
+        // VPL: does this step stage a centre-kernel-row slice of n-tile 0?  Then its six LDS stores of V are followed by six plane stores —
+        // a uniform branch around each (two copies of the whole step, selected per step, made hipcc spill 134 registers)
+        const bool VST = VPL && st_r == 1 && st_tn == 0;
+        if (VPL) vso = (unsigned)(st_cib >> 4) * vsub;
         if (lcib == 0) {       /* the slice issued in this step (g + 3) opens a new kernel row (or tile) */
             if (lr == 0 && ltile < tend) set_tile(ltile);
             regroup(lr);
@@ -624,21 +705,32 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
                 dma_B_piece(nxt_addr, 1);
             } else if constexpr (q_ == 5) {
                 dma_B_piece(nxt_addr, 2);
+#ifndef CVK_VPL_LATE
+#define CVK_VPL_LATE 0
+#endif
             } else if constexpr (q_ == 6 || q_ == 7) {
                 write_A(nxt, q_ - 6);
+                if (VST && !CVK_VPL_LATE) store_V(q_ - 6);
                 load_A(SET, q_ - 6);
             } else if constexpr (q_ >= 9 && q_ <= 11) {
                 write_A(nxt, q_ - 7);
+                if (VST && !CVK_VPL_LATE) store_V(q_ - 7);
                 load_A(SET, q_ - 7);
             } else if constexpr (q_ == 13) {
                 write_A(nxt, 5);
+                if (VST && !CVK_VPL_LATE) store_V(5);
                 load_A(SET, 5);
                 advance_A();
+            } else if constexpr (CVK_VPL_LATE && q_ >= 17 && q_ <= 37 && (q_ - 17) % 4 == 0) {
+                if (VST) store_V((q_ - 17) / 4);          // experiment: the six plane stores spread over the middle of the step
             }
             F_SB();
         });
-        cvk_wait_vm<6>();        // the step's DMA pieces (and, older, the previous step's pixel loads) have landed
+        // the step's DMA pieces (and, older, the previous step's pixel loads) have landed; a plane-store step leaves its six stores in
+        // flight beside its six pixel loads (they retire under the next step: loads, stores and DMA share one in-order counter)
+        if (VST) cvk_wait_vm<12>(); else cvk_wait_vm<6>();
         cvk_lds_retire_barrier();
+        if (VPL) advance_staged();
     };
     // H2: 18 MFMA slots.  Slots 3x: the four fragment reads of transform index x + 1; 1, 2, 4, 5: the transform (the first waits for its pixel
     // loads) with the three filter-DMA pieces behind that wait; 7, 8, 10, 11, 13, 14: split + two LDS stores of one V_x and one pixel load into
@@ -750,7 +842,7 @@ extern "C" int cvk_wino4f_stat_partials(int N, int H, int W) {
 
 static int wino4f_launch(const char* who, const float* x, const float* Uf, const float* bias, float* y, float* stats, float* counts,
                          const FBnRed* bn, int N, int H, int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream,
-                         const void* amax_x = nullptr, const void* amax_w = nullptr) {
+                         const void* amax_x = nullptr, const void* amax_w = nullptr, float* vplanes = nullptr) {
     CVK_CHECK_ARG(x && Uf && y, "%s: null pointer", who);
     CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0 && ldy >= Cout, "%s: bad shape", who);
     CVK_CHECK_ARG(Cin >= 32 && Cin % 32 == 0, "%s: Cin=%d must be a multiple of 32", who, Cin);
@@ -779,18 +871,44 @@ static int wino4f_launch(const char* who, const float* x, const float* Uf, const
     CVK_CHECK_ARG((amax_x == nullptr) == (amax_w == nullptr), "%s: the two amax blocks go together", who);
     FSplit sp = {(const unsigned*)amax_x, (const unsigned*)amax_w, CvkSplitTab{}, CvkSplitTab{}};
     if (h2) { sp.tabB = cvk_split_tab(4, CVK_SPLIT_KIND_B); sp.tabG = cvk_split_tab(4, CVK_SPLIT_KIND_G); }
-#define CVK_W4F_GO(ST_, BN_, H2_, BNV_) hipLaunchKernelGGL((k_conv3x3_wino4f<ST_, 0, BN_, H2_>), dim3(grid), dim3(512), 0, s, x, Uf, bias, y, stats, counts, \
-                                                           Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, BNV_, sp)
-    if (bn)         { if (h2) CVK_W4F_GO(false, true, true, *bn); else CVK_W4F_GO(false, true, false, *bn); }
-    else if (stats) { if (h2) CVK_W4F_GO(true, false, true, none); else CVK_W4F_GO(true, false, false, none); }
-    else            { if (h2) CVK_W4F_GO(false, false, true, none); else CVK_W4F_GO(false, false, false, none); }
+    FVpl vp = {nullptr, 0, 0};
+    if (vplanes) {
+        CVK_CHECK_ARG(!bn && !h2 && cvk_aligned16(vplanes), "%s: V planes go with plain fp32 forward launches", who);
+        vp.Wtp = (Wt + 7) / 8 * 8;
+        vp.rows = (long)N * (H + 2) * vp.Wtp + 2L * vp.Wtp;
+        vp.p = vplanes;
+        CVK_CHECK_ARG(6L * Cin * vp.rows * 4 < (1L << 32) - 4096, "%s: V planes of %ld rows x %d channels exceed the 4 GiB addressing limit", who, vp.rows, Cin);
+    }
+    const bool cl = Cout <= F_CMAX;      // the epilogue's per-channel constants fit the LDS copy (every layer of these networks outside the forced test modes)
+    CVK_CHECK_ARG(!vplanes || cl, "%s: the plane-writing launch needs Cout <= %d", who, F_CMAX);
+#define CVK_W4F_GO(ST_, BN_, H2_, CL_, BNV_) hipLaunchKernelGGL((k_conv3x3_wino4f<ST_, 0, BN_, H2_, false, CL_>), dim3(grid), dim3(512), 0, s, x, Uf, bias, y, \
+                                                                stats, counts, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, BNV_, sp, vp)
+#define CVK_W4F_GO2(ST_, BN_, BNV_) do { if (cl) CVK_W4F_GO(ST_, BN_, false, true, BNV_); else CVK_W4F_GO(ST_, BN_, false, false, BNV_); } while (0)
+#define CVK_W4F_GOV(ST_) hipLaunchKernelGGL((k_conv3x3_wino4f<ST_, 0, false, false, true, true>), dim3(grid), dim3(512), 0, s, x, Uf, bias, y, stats, counts, \
+                                            Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, none, sp, vp)
+    if (vplanes)    { if (stats) CVK_W4F_GOV(true); else CVK_W4F_GOV(false); }
+    else if (bn)    { if (h2) CVK_W4F_GO(false, true, true, false, *bn); else CVK_W4F_GO2(false, true, *bn); }
+    else if (stats) { if (h2) CVK_W4F_GO(true, false, true, false, none); else CVK_W4F_GO2(true, false, none); }
+    else            { if (h2) CVK_W4F_GO(false, false, true, false, none); else CVK_W4F_GO2(false, false, none); }
 #undef CVK_W4F_GO
+#undef CVK_W4F_GO2
+#undef CVK_W4F_GOV
     CVK_LAUNCH_RETURN(who);
 }
 
 extern "C" int cvk_conv3x3_wino4f(const float* x, const float* Uf, const float* bias, float* y, float* stats, float* counts, int N,
                                   int H, int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream) {
     return wino4f_launch("cvk_conv3x3_wino4f", x, Uf, bias, y, stats, counts, nullptr, N, H, W, Cin, Cout, ldy, max_workgroups, stream);
+}
+
+// The forward launch that also leaves the weight-grad's transformed input (see FVpl): Vsm = six SLICE-MAJOR planes
+// [6][Cin / 16][cvk_wgradp_plane_rows(N,H,W)][16] whose pad rows cvk_wgradp_zero_pads_sm has zeroed; read by cvk_wgradp_gemm_sm.
+// y, statistics and counts are bitwise those of cvk_conv3x3_wino4f.
+extern "C" int cvk_conv3x3_wino4f_vplanes(const float* x, const float* Uf, const float* bias, float* y, float* stats, float* counts, float* Vsm,
+                                          int N, int H, int W, int Cin, int Cout, int ldy, int max_workgroups, void* stream) {
+    CVK_CHECK_ARG(Vsm, "cvk_conv3x3_wino4f_vplanes: null plane pointer");
+    return wino4f_launch("cvk_conv3x3_wino4f_vplanes", x, Uf, bias, y, stats, counts, nullptr, N, H, W, Cin, Cout, ldy, max_workgroups, stream,
+                         nullptr, nullptr, Vsm);
 }
 
 // The data-grad launch that also leaves the producer layer's BatchNorm-backward column sums (see FBnRed): `part` is
@@ -838,7 +956,7 @@ extern "C" int cvk_conv3x3_wino4f_ablate(const float* x, const float* Uf, const 
     const int tilesN = f_tiles_n(Cout), tilesM = cvk_cdiv(Mt, F_BM), ntiles = tilesM * tilesN;
     const int grid = ntiles < 256 ? ntiles : 256;
     hipStream_t s = (hipStream_t)stream;
-#define CVK_ABL(A) case A: hipLaunchKernelGGL((k_conv3x3_wino4f<false, A>), dim3(grid), dim3(512), 0, s, x, Uf, bias, y, nullptr, nullptr, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, FBnRed{nullptr, nullptr, nullptr, nullptr, nullptr}, FSplit{nullptr, nullptr, CvkSplitTab{}, CvkSplitTab{}}); break;
+#define CVK_ABL(A) case A: hipLaunchKernelGGL((k_conv3x3_wino4f<false, A>), dim3(grid), dim3(512), 0, s, x, Uf, bias, y, nullptr, nullptr, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, FBnRed{nullptr, nullptr, nullptr, nullptr, nullptr}, FSplit{nullptr, nullptr, CvkSplitTab{}, CvkSplitTab{}}, FVpl{nullptr, 0, 0}); break;
     switch (abl) {
         CVK_ABL(0) CVK_ABL(1) CVK_ABL(2) CVK_ABL(3) CVK_ABL(4) CVK_ABL(7) CVK_ABL(8) CVK_ABL(9) CVK_ABL(11) CVK_ABL(15) CVK_ABL(16) CVK_ABL(24) CVK_ABL(31)
         default: return -1;
@@ -854,7 +972,7 @@ extern "C" int cvk_conv3x3_wino4h_ablate(const float* x, const void* Uh, const f
     const int grid = ntiles < 256 ? ntiles : 256;
     hipStream_t s = (hipStream_t)stream;
     const FSplit sp = {(const unsigned*)amax_x, (const unsigned*)amax_w, cvk_split_tab(4, CVK_SPLIT_KIND_B), cvk_split_tab(4, CVK_SPLIT_KIND_G)};
-#define CVK_ABLH(A) case A: hipLaunchKernelGGL((k_conv3x3_wino4f<false, A, false, true>), dim3(grid), dim3(512), 0, s, x, (const float*)Uh, bias, y, nullptr, nullptr, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, FBnRed{nullptr, nullptr, nullptr, nullptr, nullptr}, sp); break;
+#define CVK_ABLH(A) case A: hipLaunchKernelGGL((k_conv3x3_wino4f<false, A, false, true>), dim3(grid), dim3(512), 0, s, x, (const float*)Uh, bias, y, nullptr, nullptr, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, FBnRed{nullptr, nullptr, nullptr, nullptr, nullptr}, sp, FVpl{nullptr, 0, 0}); break;
     switch (abl) {
         CVK_ABLH(0) CVK_ABLH(1) CVK_ABLH(2) CVK_ABLH(4) CVK_ABLH(8) CVK_ABLH(9) CVK_ABLH(11) CVK_ABLH(15) CVK_ABLH(16) CVK_ABLH(31) CVK_ABLH(32) CVK_ABLH(33) CVK_ABLH(64) CVK_ABLH(65)
         default: return -1;

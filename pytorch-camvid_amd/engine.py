@@ -211,6 +211,18 @@ def wgradp_pays(N, H, W, cin_ld, cout):
     return cin_ld == 64 and N * H * ((W + 3) // 4) >= 4096
 
 
+# Round 6: the fused F(4,3) forward launch also writes the weight-grad's V planes (cvk_conv3x3_wino4f_vplanes, slice-major) — the plane GEMM then
+# takes every F(4,3) weight-grad, not only the 64-input-channel ones, and the x -> V pass is gone.  "0" off, "1" on.
+VPLANES_DEFAULT = os.environ.get("CVK_VPLANES", "1") != "0"
+
+
+def vplanes_pays(N, H, W, cin_ld, cout):
+    """tools/bench_vplanes.py at the headline shapes (64/128 -> 64/128/256 channels, 360x480 ... 90x120, batch 8): the forward launch costs
+    +9 ... +47 us, the weight-grad gains 34 ... 370 us on every layer; bounded by the kernel's 4 GiB plane addressing."""
+    rows = N * (H + 2) * (((W + 3) // 4 + 7) // 8 * 8)
+    return cin_ld % 64 == 0 and cout <= 512 and N * H * ((W + 3) // 4) >= 4096 and 24 * cin_ld * (rows + 64) < 2 ** 32 - 4096
+
+
 def amax_blocks(lib, n, dev):
     """n zeroed "amax blocks" (csrc/cvk_common.h: the largest magnitude of a tensor in device memory, a few slots one cache line apart): a list of
     int32 views, one fill for all of them."""
@@ -227,7 +239,7 @@ def split_fmt(R):
 
 
 def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, what="", dgrad_of=None, keep_v=None, wsrc=None, ck=None,
-              bnred=None, v_pre=None, split=False, x_amax=None, h2=False):
+              bnred=None, v_pre=None, split=False, x_amax=None, h2=False, want_planes=False):
     """y[N,H,W,ldy] = conv3x3(x[N,H,W,k_ch], w[cout][3][3][k_ch]) (+bias, +BN statistics partials at sp) through the
     Winograd kernels: weight transform -> (input transform ->) GEMMs M_xi -> output transform.  2-D F(4x4,3x3) for the
     channel-heavy layers (R.wino2d, wino2d_pays), else 1-D F(4,3) when R.wino4, else F(2,3).
@@ -416,6 +428,18 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
                                              bpart.data_ptr(), R.launch_wgs(), s), "cvk_conv3x3_wino4f_bnred"), executed=0.5 * flops)
             bnred[5].append((bpart, Pf))
             return None
+        if want_planes and keep_v is not None and dgrad_of is None:
+            # forward launch of a layer whose weight-grad runs the plane GEMM (csrc/wgradp.hip): the kernel's staging path leaves V = B^T d
+            # behind as six slice-major planes, kept for the backward pass like the 2-D path's V
+            rows6 = lib.cvk_wgradp_plane_rows(N, H, W)
+            V6 = _empty(6 * rows6 * k_ch, x.device)
+            V6.cvk_sm = True
+            check(lib.cvk_wgradp_zero_pads_sm(V6.data_ptr(), N, H, W, k_ch, s), "cvk_wgradp_zero_pads_sm")
+            _timed(R, "k_conv3x3_wino4f<vplanes>", flops, lambda: check(
+                lib.cvk_conv3x3_wino4f_vplanes(x.data_ptr(), Uf.data_ptr(), bias, y.data_ptr(), sp, cnt, V6.data_ptr(), N, H, W, k_ch, cout, ldy,
+                                               R.launch_wgs(), s), "cvk_conv3x3_wino4f_vplanes" + what), executed=0.5 * flops)
+            keep_v.append(V6)
+            return (Pf, cnt) if sp is not None else None
         _timed(R, "k_conv3x3_wino4f", flops, lambda: check(
             lib.cvk_conv3x3_wino4f(x.data_ptr(), Uf.data_ptr(), bias, y.data_ptr(), sp, cnt, N, H, W, k_ch, cout, ldy, R.launch_wgs(), s),
             "cvk_conv3x3_wino4f" + what), executed=0.5 * flops)
@@ -606,6 +630,16 @@ class ConvBnRelu(Op):
             return False
         return (C % 256 == 0 and src.ld % 128 == 0) or (src.ld % 256 == 0 and C % 128 == 0)
 
+    def _wgrad4(self, R):
+        """Does this layer's weight-grad run through the transposed F(4,3) (when the 2-D path does not take it)?"""
+        return bool(R.wino and self.src.ld >= 32 and self.cout > 32 and (R.wino4 == "always" or (R.wino4 and self.src.ld >= 64)))
+
+    def _want_planes(self, R, st):
+        """Should the fused forward launch (if that is the kernel the layer runs) leave the weight-grad's V planes behind?"""
+        src, C = self.src, self.cout
+        return bool(st.need_grad and R.vplanes and R.wgradp and split_fmt(R) == 0 and self._wgrad4(R) and not self._wgrad2d(R)
+                    and wgradp_ok(src.ld, C, pad4(C)) and vplanes_pays(src.N, src.H, src.W, src.ld, C))
+
     def _conv(self, R, st, X, wk, b, y, stats, kind, keep_v=None):
         """y = conv3x3(X, wk) + b (+ BN statistics partials): Winograd kernels when eligible, else direct."""
         lib, s, src = R.lib, st.stream, self.src
@@ -624,7 +658,7 @@ class ConvBnRelu(Op):
         if wino_ok(R, src.ld, ldy):
             return wino_conv(R, lib, s, X, wk, b.data_ptr(), y, sp, N, H, W, src.ld, C, ldy, 18.0 * M * C * self.cin, keep_v=keep_v,
                              wsrc=st.params[4 * self.pslot], ck=(self.pslot, "f"), split=split_fmt(R) if (st.need_grad and st.training and self._split3(R)) else 0, x_amax=st.amax.get(src.id),
-                             h2=split_fmt(R) == 2 and st.need_grad and st.training)
+                             h2=split_fmt(R) == 2 and st.need_grad and st.training, want_planes=keep_v is not None and self._want_planes(R, st))
         else:
             _timed(R, conv_kernel_name("fwd", ldy, src.ld), 18.0 * M * C * self.cin, lambda: check(
                 lib.cvk_conv3x3_fwd(X.data_ptr(), wk.data_ptr(), b.data_ptr(), y.data_ptr(), sp, N, H, W, src.ld, C, ldy, s),
@@ -645,7 +679,7 @@ class ConvBnRelu(Op):
         bnp = _empty(4 * ldy, dev)                      # mean | rstd | scale | shift
         pm, pr, psc, psh = (bnp.data_ptr() + 4 * ldy * i for i in range(4))
         conv, bn = self.holder.conv_bn()
-        keep_v = [] if (st.need_grad and self._wgrad2d(R)) else None      # transformed input, reused by the weight-grad
+        keep_v = [] if (st.need_grad and (self._wgrad2d(R) or self._want_planes(R, st))) else None      # transformed input, reused by the weight-grad
         if st.training:
             P = (M + _lib.CVK_STAT_ROWS - 1) // _lib.CVK_STAT_ROWS
             Pm = max(P, lib.cvk_w2d_stat_partials(N, H, W), lib.cvk_w6_stat_partials(N, H, W), lib.cvk_thin_stat_partials(N, H, W, src.ld))   # room for any partial layout (+ counts)
@@ -730,7 +764,7 @@ class ConvBnRelu(Op):
         del pre
         dy = torch.zeros(M * ldy, device=dev, dtype=_F32) if ldy != C else _empty(M * ldy, dev)
         # layers whose weight-grad runs through the transposed F(4,3) get its transformed dy planes E1..E4 from this pass
-        wgrad4 = R.wino and src.ld >= 32 and C > 32 and (R.wino4 == "always" or (R.wino4 and src.ld >= 64))
+        wgrad4 = self._wgrad4(R)
         # channel-heavy layers: transposed 2-D F(4x4,3x3), 36 GEMMs over the tile index (25-40 % faster than the transposed
         # F(4,3) from 256x256 channels up: tools/bench_conv.py ww2d); it transforms dy itself, so no E planes are needed
         wgrad2d = self._wgrad2d(R)
@@ -738,7 +772,9 @@ class ConvBnRelu(Op):
         # 64-input-channel layers: both transforms outside the GEMM (csrc/wgradp.hip) — the E planes come from this pass, the V
         # planes cost one pass over x; pays while that pass is cheap (measured: 64 -> 64 @360x480 0.74x, 64 -> 128 @180x240 0.7x
         # the time of the transposed F(4,3) kernel; 128 input channels: the V pass eats the gain)
-        wgradp = wgrad4 and R.wgradp and wgradp_ok(src.ld, C, ldy) and (R.wgradp == "always" or wgradp_pays(N, H, W, src.ld, C))
+        # round 6: when the fused forward launch left V behind (slice-major planes), every such layer takes the plane GEMM and no pass over x runs
+        have_planes = Vkept is not None and getattr(Vkept, "cvk_sm", False) and Vkept.numel() == 6 * lib.cvk_wgradp_plane_rows(N, H, W) * src.ld
+        wgradp = wgrad4 and R.wgradp and wgradp_ok(src.ld, C, ldy) and (R.wgradp == "always" or have_planes or wgradp_pays(N, H, W, src.ld, C))
         E = None
         E6 = None
         am_dy_fused = None
@@ -912,18 +948,21 @@ class ConvBnRelu(Op):
             rows6 = lib.cvk_wgradp_plane_rows(N, H, W)
             wsb = lib.cvk_wgradp_gemm_workspace_bytes(N, H, W, src.ld, C)
             nE = 0 if E6 is not None else 6 * rows6 * C
-            ws = R.workspace(4 * (6 * rows6 * src.ld + nE) + wsb, dev)
-            V6p = ws.data_ptr()
-            E6p = E6.data_ptr() if E6 is not None else V6p + 4 * 6 * rows6 * src.ld
-            slabp = V6p + 4 * (6 * rows6 * src.ld + nE)
-            _timed(R, "k_wgradp_planes", 4.0 * (M + 6.0 * rows6) * src.ld, lambda: check(
-                lib.cvk_wgradp_planes(X.data_ptr(), src.ld, V6p, N, H, W, src.ld, 0, s), "cvk_wgradp_planes(x)"), "byte")
+            nV = 0 if have_planes else 6 * rows6 * src.ld
+            ws = R.workspace(4 * (nV + nE) + wsb, dev)
+            V6p = Vkept.data_ptr() if have_planes else ws.data_ptr()
+            E6p = E6.data_ptr() if E6 is not None else ws.data_ptr() + 4 * nV
+            slabp = ws.data_ptr() + 4 * (nV + nE)
+            if not have_planes:
+                _timed(R, "k_wgradp_planes", 4.0 * (M + 6.0 * rows6) * src.ld, lambda: check(
+                    lib.cvk_wgradp_planes(X.data_ptr(), src.ld, V6p, N, H, W, src.ld, 0, s), "cvk_wgradp_planes(x)"), "byte")
             if E6 is None:
                 _timed(R, "k_wgradp_planes", 4.0 * (M + 6.0 * rows6) * C, lambda: check(
                     lib.cvk_wgradp_planes(dy.data_ptr(), ldy, E6p, N, H, W, C, 1, s), "cvk_wgradp_planes(dy)"), "byte")
+            gemm = lib.cvk_wgradp_gemm_sm if have_planes else lib.cvk_wgradp_gemm
             _timed(R, "k_wgradp_gemm", 18.0 * M * C * self.cin, lambda: check(
-                lib.cvk_wgradp_gemm(E6p, V6p, gw, N, H, W, self.cin, src.ld, C, slabp, wsb, s), "cvk_wgradp_gemm"),
-                executed=9.0 * M * C * self.cin)
+                gemm(E6p, V6p, gw, N, H, W, self.cin, src.ld, C, slabp, wsb, s), "cvk_wgradp_gemm"), executed=9.0 * M * C * self.cin)
+            del Vkept
         elif wgrad4:
             # transposed F(4,3): fastest weight-grad on every layer with >= 64 input channels (tools/bench_conv.py wgrad wwino wwino4)
             wsb = lib.cvk_conv3x3_wgrad_wino4_workspace_bytes(N, H, W, src.ld, C, ldy)
@@ -1394,6 +1433,7 @@ class Runner:
         self.wino4 = WINO4_DEFAULT
         self.wino4f = WINO4F_DEFAULT
         self.wgradp = WGRADP_DEFAULT
+        self.vplanes = VPLANES_DEFAULT      # fused forward launches leave the weight-grad's V planes behind (round 6)
         self.thin = os.environ.get("CVK_THIN", "1") != "0"    # csrc/thin.hip for the stem and the classifier head
         self.w2both = os.environ.get("CVK_W2D_DY_BOTH", "1") != "0"   # one launch transforms dy for the data-grad and the weight-grad
         self.bnred_fuse = os.environ.get("CVK_BNRED_FUSE", "1") != "0"   # BN-backward sums in the fused data-grad's epilogue
@@ -1458,7 +1498,7 @@ class Runner:
         every cached tensor it builds straight from a parameter, and this pass replays the record."""
         if not self.wcache or torch.cuda.is_current_stream_capturing():
             return
-        cfg = (id(plan), self.w2tile, self.w2tile_dgrad, self.wino, self.wino4, self.wino4f, self.wino2d, self.wgradp, self.thin, self.w2d_split)
+        cfg = (id(plan), self.w2tile, self.w2tile_dgrad, self.wino, self.wino4, self.wino4f, self.wino2d, self.wgradp, self.vplanes, self.thin, self.w2d_split)
         if cfg != self._wjobs_cfg:          # another plan or other kernel knobs: the record starts over with this pass
             self._wjobs, self._wjobs_cfg = {}, cfg
             return

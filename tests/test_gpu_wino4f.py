@@ -209,3 +209,60 @@ def test_fused_f43_bitwise_equals_the_pre_packed_kernel():
     for k in ("fwd_y", "fwd_stats", "dgrad_y"):
         bad = int((got[k] != ref[k]).sum())
         assert bad == 0, (k, bad, got[k + "_first"] if k + "_first" in got else None)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 9, 13, 64, 64), (1, 16, 36, 64, 128), (2, 33, 50, 128, 64), (3, 64, 96, 64, 64),
+                                             (1, 45, 60, 128, 136), (8, 90, 120, 64, 64), (1, 2, 3, 64, 64), (1, 5, 7, 32, 64)])
+def test_forward_emitted_v_planes_feed_the_weight_grad(N, H, W, Cin, Cout):
+    """Round 6: cvk_conv3x3_wino4f_vplanes = the fused forward launch that also leaves the weight-grad's transformed input as six
+    SLICE-MAJOR planes (csrc/wino4f.hip FVpl).  (1) y, statistics and counts are BITWISE those of cvk_conv3x3_wino4f, for any grid cap;
+    (2) the planes equal cvk_wgradp_planes_sm(x) — the stand-alone pass, same formulas with other rounding — to 1e-6 of the plane's scale, and
+    every pad row is zero; (3) cvk_wgradp_gemm_sm on slice-major planes is bitwise cvk_wgradp_gemm on row-major planes of the same values, and
+    the weight gradient from the forward-emitted planes matches fp64 (reference: backward of nn.Conv2d, models/unet.py:11, train.py:131)."""
+    lib, check = _lib()
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(N * 77 + H + Cin + Cout)
+    x = torch.randn(N, H, W, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    y0, st0, P = _fused_conv(x, w, b)
+    wcl = w.permute(0, 2, 3, 1).contiguous()
+    Uf = torch.empty(lib.cvk_wino4f_weight_floats(Cout, Cin), device="cuda")
+    check(lib.cvk_wino4f_weight_transform(wcl.data_ptr(), Uf.data_ptr(), Cout, Cin, 0, s), "weight")
+    rows = lib.cvk_wgradp_plane_rows(N, H, W)
+    ref_pl = torch.full((6 * rows * Cin,), float("nan"), device="cuda")
+    check(lib.cvk_wgradp_planes_sm(x.data_ptr(), Cin, ref_pl.data_ptr(), N, H, W, Cin, s), "planes_sm")
+    for cap in (0, 3):
+        y = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+        st = torch.zeros(2 * P * Cout + P, device="cuda")
+        pl = torch.full((6 * rows * Cin,), float("nan"), device="cuda")
+        check(lib.cvk_wgradp_zero_pads_sm(pl.data_ptr(), N, H, W, Cin, s), "zero_pads_sm")
+        check(lib.cvk_conv3x3_wino4f_vplanes(x.data_ptr(), Uf.data_ptr(), b.data_ptr(), y.data_ptr(), st.data_ptr(), st.data_ptr() + 8 * P * Cout,
+                                             pl.data_ptr(), N, H, W, Cin, Cout, Cout, cap, s), "vplanes")
+        torch.cuda.synchronize()
+        assert torch.equal(y, y0) and torch.equal(st, st0), cap
+        assert torch.isfinite(pl).all()                                   # every element written: by the kernel or by the pad pass
+        assert (pl - ref_pl).abs().max().item() <= 1e-6 * max(1.0, ref_pl.abs().max().item())
+        assert torch.equal(pl == 0, ref_pl == 0) or (pl[ref_pl == 0].abs().max().item() == 0.0)        # pad rows are exact zeros
+    if Cin % 64 or Cout % 64:
+        return
+    # the weight gradient: E planes from dy (stand-alone pass), V planes from the forward launch
+    dy = torch.randn(N, H, W, Cout, generator=g).cuda()
+    E6 = torch.empty(6 * rows * Cout, device="cuda")
+    check(lib.cvk_wgradp_planes(dy.data_ptr(), Cout, E6.data_ptr(), N, H, W, Cout, 1, s), "planes(dy)")
+    wsb = lib.cvk_wgradp_gemm_workspace_bytes(N, H, W, Cin, Cout)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    dw_sm = torch.empty(Cout, 3, 3, Cin, device="cuda")
+    check(lib.cvk_wgradp_gemm_sm(E6.data_ptr(), pl.data_ptr(), dw_sm.data_ptr(), N, H, W, Cin, Cin, Cout, ws.data_ptr(), wsb, s), "gemm_sm")
+    # same plane VALUES in the row-major layout -> the row-major GEMM must give the same bits
+    rm = pl.view(6, Cin // 16, rows, 16).permute(0, 2, 1, 3).contiguous().view(-1)
+    dw_rm = torch.empty(Cout, 3, 3, Cin, device="cuda")
+    check(lib.cvk_wgradp_gemm(E6.data_ptr(), rm.data_ptr(), dw_rm.data_ptr(), N, H, W, Cin, Cin, Cout, ws.data_ptr(), wsb, s), "gemm")
+    torch.cuda.synchronize()
+    assert torch.equal(dw_sm, dw_rm)
+    xr = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+    wr = w.double().cpu().requires_grad_(True)
+    F.conv2d(xr, wr, None, padding=1).backward(dy.permute(0, 3, 1, 2).double().cpu())
+    want = wr.grad.permute(0, 2, 3, 1)
+    rel = ((dw_sm.double().cpu() - want).norm() / want.norm()).item()
+    assert rel < 1e-5, rel

@@ -125,3 +125,36 @@ def test_winograd2d_tile_choice():
     assert engine.layer_tile(R, 8, 90, 120) == 4 and engine.layer_tile(R, 8, 90, 120, dgrad=True) == 6
     R.w2tile_dgrad = 4
     assert engine.layer_tile(R, 8, 90, 120, dgrad=True) == 4
+
+
+def test_which_layers_emit_v_planes_from_the_forward_pass():
+    """Round 6: the fused F(4,3) forward launch of exactly the eight 64/128-input-channel layers of the headline step (the double-conv blocks of
+    reference models/unet.py:40-47, 81-89 and their neighbours) leaves the weight-grad's V planes behind; the 2-D layers (V kept from their own
+    input transform), the thin stem / head and the split-operand modes do not; no gradient pass, no planes."""
+    from pytorch_camvid_amd.modules import runner_of
+
+    class St:
+        need_grad = True
+    net = A.UNet(3, 12)
+    p = build_plan(net, 8, 3, 360, 480)
+    R = runner_of(net)
+    R.w2tile, R.w2tile_dgrad = R.tile_for(p)
+    convs = [o for o in p.ops if isinstance(o, engine.ConvBnRelu)]
+    names = [k for k, m in net.named_modules() if isinstance(m, A.BasicConv2d)]
+    order = [names[[m for _, m in net.named_modules() if isinstance(m, A.BasicConv2d)].index(h)] for h in p.holders]
+    got = [n for n, c in zip(order, convs) if c._want_planes(R, St)]
+    assert got == ["down1.1", "down2.0", "down2.1", "down3.0", "up3.1", "upsample4.conv", "up4.0", "up4.1"], got
+    assert not any(c._want_planes(R, St) and c._wgrad2d(R) for c in convs)
+    St.need_grad = False
+    assert not any(c._want_planes(R, St) for c in convs)
+    St.need_grad = True
+    R.vplanes = False
+    assert not any(c._want_planes(R, St) for c in convs)
+    R.vplanes = True
+    R.w2d_split = 2
+    assert not any(c._want_planes(R, St) for c in convs)
+    R.w2d_split = 0
+    # tiny geometries keep the in-kernel transform (the plane GEMM needs >= 4096 tile rows)
+    p2 = build_plan(A.UNet(3, 12), 2, 3, 48, 64)
+    assert not any(c._want_planes(R, St) for c in p2.ops if isinstance(c, engine.ConvBnRelu))
+    assert engine.vplanes_pays(8, 360, 480, 128, 64) and not engine.vplanes_pays(8, 360, 480, 96, 64) and not engine.vplanes_pays(64, 720, 960, 128, 64)
