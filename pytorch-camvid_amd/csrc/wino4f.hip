@@ -383,17 +383,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
         // bookkeeping one position at the merge (the pixel loads look one younger per branch): with builtin stores the transform's wait for its
         // pixel loads became vmcnt(0) — a full drain every other step.  Unseen, the stores only make hipcc's counted waits conservative (loads,
         // stores and LDS-DMA retire through ONE in-order counter: a wait for "all but the N youngest" then covers a few operations more).
-        // Streaming (nt): the planes are read again only by the weight-grad.  tv[x] is not written again before the next step's transform.
-#ifndef CVK_VPL_POLICY
-#define CVK_VPL_POLICY 0
-#endif
-#if CVK_VPL_POLICY == 0
-        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(vpo), "s"(vr), "s"(vso + (unsigned)x * vxs) : "memory");
-#elif CVK_VPL_POLICY == 1
-        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" : : "v"(tv[x]), "v"(vpo), "s"(vr), "s"(vso + (unsigned)x * vxs) : "memory");
-#else
-        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc0 sc1 nt" : : "v"(tv[x]), "v"(vpo), "s"(vr), "s"(vso + (unsigned)x * vxs) : "memory");
-#endif
+        // Streaming (nt): the planes are read again only by the weight-grad (A/B on one box, whole step: nt 33.38, default policy 33.57, sc0 sc1 nt
+        // 33.43 ms; the six stores spread over slots 17-37 instead of beside the LDS stores: 33.44).  tv[x] is not written again before the
+        // next step's transform.
+asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(vpo), "s"(vr), "s"(vso + (unsigned)x * vxs) : "memory");
     };
     // H2: the two fp16 terms of 2^e * V_x for this thread's four channels: 8 bytes each into the h1 / h2 chunk of its row
     // (H2 swizzle of the A region: bit 1 from row bit 2, bit 0 from row bit 3 — the 8 rows of a half-wave's 8-byte stores then cover all 64 banks;
@@ -705,24 +698,19 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
                 dma_B_piece(nxt_addr, 1);
             } else if constexpr (q_ == 5) {
                 dma_B_piece(nxt_addr, 2);
-#ifndef CVK_VPL_LATE
-#define CVK_VPL_LATE 0
-#endif
             } else if constexpr (q_ == 6 || q_ == 7) {
                 write_A(nxt, q_ - 6);
-                if (VST && !CVK_VPL_LATE) store_V(q_ - 6);
+                if (VST) store_V(q_ - 6);
                 load_A(SET, q_ - 6);
             } else if constexpr (q_ >= 9 && q_ <= 11) {
                 write_A(nxt, q_ - 7);
-                if (VST && !CVK_VPL_LATE) store_V(q_ - 7);
+                if (VST) store_V(q_ - 7);
                 load_A(SET, q_ - 7);
             } else if constexpr (q_ == 13) {
                 write_A(nxt, 5);
-                if (VST && !CVK_VPL_LATE) store_V(5);
+                if (VST) store_V(5);
                 load_A(SET, 5);
                 advance_A();
-            } else if constexpr (CVK_VPL_LATE && q_ >= 17 && q_ <= 37 && (q_ - 17) % 4 == 0) {
-                if (VST) store_V((q_ - 17) / 4);          // experiment: the six plane stores spread over the middle of the step
             }
             F_SB();
         });
