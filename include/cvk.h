@@ -316,6 +316,18 @@ int cvk_wgradp_zero_pads_sm(float* planes, int N, int H, int W, int C, void* str
 int cvk_wgradp_planes_sm(const float* x, int ld, float* planes, int N, int H, int W, int C, void* stream);
 int cvk_wgradp_gemm_sm(const float* E6, const float* V6sm, float* dw, int N, int H, int W, int Cin, int Cin_pad, int Cout, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* ... with only FOUR E planes: E0 and E5 of E = A dy are columns 4 xt and 4 xt + 3 of dy itself, so the BatchNorm-backward pass writes E1..E4 only
+ * (cvk_wgradp_zero_pads4 for the pad rows, then cvk_bn_bwd_dx_e4p: contract of cvk_bn_bwd_dx_e6 with float E4p[4][cvk_wgradp_plane_rows][C]) and the GEMM
+ * reads the two identity planes from dy: dense [N*H*W][Cout] followed by cvk_wgradp_dy_slack(W) * Cout ZERO floats (pad column groups of the last row
+ * read past the tensor; their V rows are zero).  W % 4 == 0 (a ragged last group's E5 is 0, not a pixel of dy).  1.0x instead of 1.5x the tensor
+ * written beside dy. */
+int cvk_wgradp_zero_pads4(float* planes, int N, int H, int W, int C, void* stream);
+int cvk_bn_bwd_dx_e4p(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
+                      const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* E4p, float* part,
+                      int N, int H, int W, int C, int use_batch_stats, void* stream);
+int cvk_wgradp_dy_slack(int W);
+int cvk_wgradp_gemm_sm_dy(const float* E4p, const float* dy, const float* V6sm, float* dw, int N, int H, int W, int Cin, int Cin_pad, int Cout,
+                          void* workspace, size_t workspace_bytes, void* stream);
 int cvk_bn_bwd_dx_e6(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
                      const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* E6, float* part,
                      int N, int H, int W, int C, int use_batch_stats, void* stream);

@@ -80,6 +80,11 @@ SIGNATURES = {
     "cvk_wgradp_zero_pads_sm": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_wgradp_planes_sm": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_wgradp_gemm_sm": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
+    "cvk_wgradp_zero_pads4": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_bn_bwd_dx_e4p": (c_int, [View, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp,
+                                  c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_wgradp_dy_slack": (c_int, [c_int]),
+    "cvk_wgradp_gemm_sm_dy": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_size, c_vp]),
     "cvk_conv3x3_wino4f_vplanes": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_bn_bwd_dx_e6": (c_int, [View, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp,
                                  c_int, c_int, c_int, c_int, c_int, c_vp]),

@@ -416,12 +416,20 @@ __global__ __launch_bounds__(256) void k_bn_bwd_dx_e(const float* __restrict__ d
                 const size_t prow = (size_t)six_Wtp + ((size_t)n * (six_H + 2) + yy + 1) * six_Wtp + xt;
                 const size_t ps = (size_t)six_rows * C;
                 float* o = E + prow * C + c;
-                *reinterpret_cast<f32x4*>(o) = r[0];
-                *reinterpret_cast<f32x4*>(o + ps) = a + b;
-                *reinterpret_cast<f32x4*>(o + 2 * ps) = a - b;
-                *reinterpret_cast<f32x4*>(o + 3 * ps) = cc + dd;
-                *reinterpret_cast<f32x4*>(o + 4 * ps) = cc - dd;
-                *reinterpret_cast<f32x4*>(o + 5 * ps) = r[3];
+                if (six_rows < 0) {         // four planes E1..E4 only (round 6): E0 / E5 are columns of dy itself, the plane GEMM reads them from dy
+                    const size_t p4 = (size_t)(-six_rows) * C;
+                    *reinterpret_cast<f32x4*>(o) = a + b;
+                    *reinterpret_cast<f32x4*>(o + p4) = a - b;
+                    *reinterpret_cast<f32x4*>(o + 2 * p4) = cc + dd;
+                    *reinterpret_cast<f32x4*>(o + 3 * p4) = cc - dd;
+                } else {
+                    *reinterpret_cast<f32x4*>(o) = r[0];
+                    *reinterpret_cast<f32x4*>(o + ps) = a + b;
+                    *reinterpret_cast<f32x4*>(o + 2 * ps) = a - b;
+                    *reinterpret_cast<f32x4*>(o + 3 * ps) = cc + dd;
+                    *reinterpret_cast<f32x4*>(o + 4 * ps) = cc - dd;
+                    *reinterpret_cast<f32x4*>(o + 5 * ps) = r[3];
+                }
             }
         }
     }
@@ -717,7 +725,7 @@ extern "C" int cvk_bn_bwd_dx_e_amax(int six, cvk_view dout, const float* y, int 
                                     const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* E,
                                     float* part, int N, int H, int W, int C, int use_batch_stats, void* amax_block, void* stream) {
     CVK_CHECK_ARG(amax_block, "cvk_bn_bwd_dx_e_amax: null amax block");
-    return bn_bwd_dx_e_launch("cvk_bn_bwd_dx_e_amax", six ? 1 : 0, dout, y, ldy, scale, shift, mean, rstd, dgamma, dbeta, dy, ld_dy, E, part, N, H, W, C,
+    return bn_bwd_dx_e_launch("cvk_bn_bwd_dx_e_amax", six == 2 ? 2 : (six ? 1 : 0), dout, y, ldy, scale, shift, mean, rstd, dgamma, dbeta, dy, ld_dy, E, part, N, H, W, C,
                               use_batch_stats, amax_block, stream);
 }
 static int bn_bwd_dx_e_launch(const char* who, int six, cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
@@ -737,7 +745,7 @@ static int bn_bwd_dx_e_launch(const char* who, int six, cvk_view dout, const flo
         const int tiles6 = cvk_cdiv(Mt6, pb6), nb6 = cvk_cdiv(Mt6, tiles6);
         dim3 grid6(nb6, cvk_cdiv(C, 1024));
         hipLaunchKernelGGL(k_bn_bwd_dx_e, grid6, dim3(256), 0, (hipStream_t)stream, dout.ptr, dm6, y, ldy, scale, shift, mean, rstd,
-                           dgamma, dbeta, dy, ld_dy, E, part, M6, C, W, Wt6, Mt6, tiles6, 1024, use_batch_stats, H, Wtp, rows, (unsigned*)amax);
+                           dgamma, dbeta, dy, ld_dy, E, part, M6, C, W, Wt6, Mt6, tiles6, 1024, use_batch_stats, H, Wtp, six == 2 ? -rows : rows, (unsigned*)amax);
         CVK_LAUNCH_RETURN(who);
     }
     CVK_CHECK_ARG(dout.ptr && y && scale && shift && mean && rstd && dy && E && dgamma && dbeta, "%s: null pointer", who);
@@ -762,6 +770,15 @@ extern "C" int cvk_bn_bwd_dx_e6(cvk_view dout, const float* y, int ldy, const fl
                                 const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* E6,
                                 float* part, int N, int H, int W, int C, int use_batch_stats, void* stream) {
     return bn_bwd_dx_e_launch("cvk_bn_bwd_dx_e6", 1, dout, y, ldy, scale, shift, mean, rstd, dgamma, dbeta, dy, ld_dy, E6, part, N, H, W, C, use_batch_stats,
+                              nullptr, stream);
+}
+
+// ... writing only the FOUR planes E1..E4 (float[4][cvk_wgradp_plane_rows][C], padded layout, pad rows zeroed by cvk_wgradp_zero_pads4): E0 and E5
+// are columns 4 xt and 4 xt + 3 of dy itself and cvk_wgradp_gemm_sm_dy reads them from dy — 1.0x instead of 1.5x the tensor written beside dy
+extern "C" int cvk_bn_bwd_dx_e4p(cvk_view dout, const float* y, int ldy, const float* scale, const float* shift, const float* mean,
+                                 const float* rstd, const float* dgamma, const float* dbeta, float* dy, int ld_dy, float* E4p,
+                                 float* part, int N, int H, int W, int C, int use_batch_stats, void* stream) {
+    return bn_bwd_dx_e_launch("cvk_bn_bwd_dx_e4p", 2, dout, y, ldy, scale, shift, mean, rstd, dgamma, dbeta, dy, ld_dy, E4p, part, N, H, W, C, use_batch_stats,
                               nullptr, stream);
 }
 

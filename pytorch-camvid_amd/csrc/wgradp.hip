@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_wgradp_planes(const float* __restrict__
 // zero rows / column groups of the six planes that no producer writes: the Wtp rows before and after, image rows 0 and H+1 of
 // every image, column groups >= Wt of every image row (for planes written by cvk_bn_bwd_dx_e6)
 template <bool SM = false>
-__global__ __launch_bounds__(256) void k_wgradp_zero_pads(float* __restrict__ P, int N, int H, int Wt, int Wtp, int C) {
+__global__ __launch_bounds__(256) void k_wgradp_zero_pads(float* __restrict__ P, int N, int H, int Wt, int Wtp, int C, int nplanes) {
     const int cvn = C >> 2;
     const long rows = p_rows(N, H, Wtp);
     const int padc = Wtp - Wt;
@@ -125,8 +125,7 @@ __global__ __launch_bounds__(256) void k_wgradp_zero_pads(float* __restrict__ P,
     }
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     const size_t ps = (size_t)rows * C;
-#pragma unroll
-    for (int x = 0; x < 6; ++x)
+    for (int x = 0; x < nplanes; ++x)
         *reinterpret_cast<f32x4*>(P + x * ps + (SM ? ((size_t)(c >> 4) * rows + (size_t)row) * 16 + (c & 15) : (size_t)row * C + c)) = z;
 }
 
@@ -136,9 +135,13 @@ __global__ __launch_bounds__(256) void k_wgradp_zero_pads(float* __restrict__ P,
 // VSM: the V planes are slice-major (k_wgradp_planes<0, true> / the fused forward kernel): a 64-channel block of 8 plane rows is four
 // 512-byte runs (one per 16-channel slice); only the per-lane source offset of the two DMA pieces and the row pitch differ — the LDS
 // image ([depth row][64 channels]) and everything behind it are the same.
-template <bool VSM>
+// EDY (round 6): E6 holds only the four planes E1..E4; E0 and E5 = columns 4 xt and 4 xt + 3 of dy are read from `dy` [N*H*W (+ slack)][Cout] itself —
+// the block of (strip, image row y) is eight pixels 4 * Cout floats apart.  Column groups >= ceil(W/4) of a row then read the next row's (finite)
+// pixels, or the caller's zeroed slack behind the last row: their V rows are zero.
+template <bool VSM, bool EDY>
 __global__ __launch_bounds__(64, 2) void k_wgradp_gemm(const float* __restrict__ E6, const float* __restrict__ V6, float* __restrict__ slab,
-                                                      int H, int Wtp, int Cin_ld, int Cout, long rows, int Q, int runs, int nci, int nco) {
+                                                      int H, int Wtp, int Cin_ld, int Cout, long rows, int Q, int runs, int nci, int nco,
+                                                      const float* __restrict__ dy, int W) {
     __shared__ __attribute__((aligned(1024))) char smem[12 * 1024];
     const unsigned smem_addr = cvk_lds_addr(smem);
     const int lane = threadIdx.x;
@@ -153,11 +156,13 @@ __global__ __launch_bounds__(64, 2) void k_wgradp_gemm(const float* __restrict__
     if (qb >= qe) return;
     const int so = Wtp >> 3;                               // strips per image
 
-    const float* const Eb = E6 + (size_t)xi * rows * Cout + cot * 64;
+    const bool edy = EDY && (xi == 0 || xi == 5);
+    const float* const Eb = edy ? dy + cot * 64 + (xi == 5 ? 3 * Cout : 0) : E6 + (size_t)(EDY ? xi - 1 : xi) * rows * Cout + cot * 64;
+    const int epitch = edy ? 4 * Cout : Cout;              // floats between consecutive E rows
     const float* const Vb = V6 + (size_t)xi * rows * Cin_ld + (VSM ? (size_t)cit * 4 * rows * 16 : (size_t)cit * 64);
     const int vpitch = VSM ? 16 : Cin_ld;                  // floats between consecutive plane rows of V
     // a 2 KiB block = 8 plane rows x 256 B (64 channels): two DMA pieces of 4 rows; lane -> row lane / 16, 16-byte chunk lane % 16
-    const unsigned evoff = (unsigned)(((lane >> 4) * Cout + (lane & 15) * 4) * 4);
+    const unsigned evoff = (unsigned)(((lane >> 4) * epitch + (lane & 15) * 4) * 4);
     const unsigned vvoff = VSM ? (unsigned)((((unsigned long)((lane & 15) >> 2) * (unsigned long)rows + (lane >> 4)) * 16 + (lane & 3) * 4) * 4)
                                : (unsigned)(((lane >> 4) * Cin_ld + (lane & 15) * 4) * 4);
     auto block_row = [&](int strip, int yp) -> long {       // first plane row of (strip, padded image row yp)
@@ -171,10 +176,11 @@ __global__ __launch_bounds__(64, 2) void k_wgradp_gemm(const float* __restrict__
         p_dma16(src + 4 * (size_t)vpitch, vvoff, dst + 1024);
     };
     auto dma_E = [&](int strip, int yp, int slot) {
-        const float* src = Eb + (size_t)block_row(strip, yp) * Cout;
+        const int en = strip / so, exg = strip - en * so;
+        const float* src = edy ? Eb + (((size_t)en * H + (yp - 1)) * W + 32 * (size_t)exg) * Cout : Eb + (size_t)block_row(strip, yp) * Cout;
         const unsigned dst = smem_addr + 8192 + slot * 2048;
         p_dma16(src, evoff, dst);
-        p_dma16(src + 4 * (size_t)Cout, evoff, dst + 1024);
+        p_dma16(src + 4 * (size_t)epitch, evoff, dst + 1024);
     };
 
     f32x4 acc[3][16];
@@ -330,8 +336,18 @@ extern "C" int cvk_wgradp_zero_pads(float* planes, int N, int H, int W, int C, v
     const int Wt = (W + 3) / 4, Wtp = (Wt + 7) / 8 * 8;
     const long pr = 2L * Wtp + (long)N * 2 * Wtp + (long)N * H * (Wtp - Wt);
     const long threads = pr * (C / 4);
-    hipLaunchKernelGGL(k_wgradp_zero_pads<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, planes, N, H, Wt, Wtp, C);
+    hipLaunchKernelGGL(k_wgradp_zero_pads<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, planes, N, H, Wt, Wtp, C, 6);
     CVK_LAUNCH_RETURN("cvk_wgradp_zero_pads");
+}
+
+// ... of the FOUR planes E1..E4 that cvk_bn_bwd_dx_e4p is about to fill
+extern "C" int cvk_wgradp_zero_pads4(float* planes, int N, int H, int W, int C, void* stream) {
+    CVK_CHECK_ARG(planes && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && cvk_aligned16(planes), "cvk_wgradp_zero_pads4: bad arguments");
+    const int Wt = (W + 3) / 4, Wtp = (Wt + 7) / 8 * 8;
+    const long pr = 2L * Wtp + (long)N * 2 * Wtp + (long)N * H * (Wtp - Wt);
+    const long threads = pr * (C / 4);
+    hipLaunchKernelGGL(k_wgradp_zero_pads<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, planes, N, H, Wt, Wtp, C, 4);
+    CVK_LAUNCH_RETURN("cvk_wgradp_zero_pads4");
 }
 
 // ... of six SLICE-MAJOR V planes [6][C / 16][rows][16] that the fused forward kernel is about to fill (cvk_conv3x3_wino4f_vplanes)
@@ -340,7 +356,7 @@ extern "C" int cvk_wgradp_zero_pads_sm(float* planes, int N, int H, int W, int C
     const int Wt = (W + 3) / 4, Wtp = (Wt + 7) / 8 * 8;
     const long pr = 2L * Wtp + (long)N * 2 * Wtp + (long)N * H * (Wtp - Wt);
     const long threads = pr * (C / 4);
-    hipLaunchKernelGGL(k_wgradp_zero_pads<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, planes, N, H, Wt, Wtp, C);
+    hipLaunchKernelGGL(k_wgradp_zero_pads<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, planes, N, H, Wt, Wtp, C, 6);
     CVK_LAUNCH_RETURN("cvk_wgradp_zero_pads_sm");
 }
 
@@ -382,7 +398,7 @@ extern "C" size_t cvk_wgradp_gemm_workspace_bytes(int N, int H, int W, int Cin_l
 
 // dw from the planes E6 [6][rows][Cout] and V6 [6][rows][Cin_ld]: GEMM into slabs (workspace) + fixed-order reduction with G^T
 static int wgradp_gemm_go(bool vsm, const float* E6, const float* V6, float* dw, int N, int H, int W, int Cin, int Cin_ld, int Cout,
-                          void* workspace, size_t workspace_bytes, void* stream) {
+                          void* workspace, size_t workspace_bytes, void* stream, const float* dy = nullptr) {
     CVK_CHECK_ARG(E6 && V6 && dw && workspace, "cvk_wgradp_gemm: null pointer");
     CVK_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= Cin_ld && Cin_ld % 64 == 0 && Cout % 64 == 0 && Cout >= 64,
                   "cvk_wgradp_gemm: Cin_ld=%d and Cout=%d must be multiples of 64", Cin_ld, Cout);
@@ -397,9 +413,10 @@ static int wgradp_gemm_go(bool vsm, const float* E6, const float* V6, float* dw,
     const int per = 6 * p.nci * p.nco;
     if (vsm) {
         CVK_CHECK_ARG(3L * p.rows * 64 + 4096 < (1L << 32), "cvk_wgradp_gemm_sm: %ld plane rows exceed the 32-bit lane offset of the slice-major V block", p.rows);
-        hipLaunchKernelGGL(k_wgradp_gemm<true>, dim3(per * p.runs), dim3(64), 0, s, E6, V6, slab, H, p.Wtp, Cin_ld, Cout, p.rows, p.Q, p.runs, p.nci, p.nco);
+        if (dy) hipLaunchKernelGGL((k_wgradp_gemm<true, true>), dim3(per * p.runs), dim3(64), 0, s, E6, V6, slab, H, p.Wtp, Cin_ld, Cout, p.rows, p.Q, p.runs, p.nci, p.nco, dy, W);
+        else hipLaunchKernelGGL((k_wgradp_gemm<true, false>), dim3(per * p.runs), dim3(64), 0, s, E6, V6, slab, H, p.Wtp, Cin_ld, Cout, p.rows, p.Q, p.runs, p.nci, p.nco, dy, W);
     } else {
-        hipLaunchKernelGGL(k_wgradp_gemm<false>, dim3(per * p.runs), dim3(64), 0, s, E6, V6, slab, H, p.Wtp, Cin_ld, Cout, p.rows, p.Q, p.runs, p.nci, p.nco);
+        hipLaunchKernelGGL((k_wgradp_gemm<false, false>), dim3(per * p.runs), dim3(64), 0, s, E6, V6, slab, H, p.Wtp, Cin_ld, Cout, p.rows, p.Q, p.runs, p.nci, p.nco, dy, W);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -419,6 +436,17 @@ extern "C" int cvk_wgradp_gemm(const float* E6, const float* V6, float* dw, int 
 extern "C" int cvk_wgradp_gemm_sm(const float* E6, const float* V6sm, float* dw, int N, int H, int W, int Cin, int Cin_ld, int Cout,
                                   void* workspace, size_t workspace_bytes, void* stream) {
     return wgradp_gemm_go(true, E6, V6sm, dw, N, H, W, Cin, Cin_ld, Cout, workspace, workspace_bytes, stream);
+}
+
+// ... with E0 / E5 read straight from dy: E4p = the four planes E1..E4 [4][rows][Cout] (cvk_wgradp_zero_pads4 + cvk_bn_bwd_dx_e4p), dy = the dense
+// [N*H*W][Cout] tensor those passes wrote, followed by cvk_wgradp_dy_slack(W) * Cout ZERO floats (the last row's pad column groups read past the tensor)
+extern "C" int cvk_wgradp_dy_slack(int W) { return W > 0 ? 4 * (((W + 3) / 4 + 7) / 8 * 8) - W + 4 : 0; }
+extern "C" int cvk_wgradp_gemm_sm_dy(const float* E4p, const float* dy, const float* V6sm, float* dw, int N, int H, int W, int Cin, int Cin_ld, int Cout,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    CVK_CHECK_ARG(dy && cvk_aligned16(dy), "cvk_wgradp_gemm_sm_dy: dy must be a 16-byte aligned pointer");
+    // a ragged last column group (W % 4 != 0) has E5 = 0 where dy's next row begins: only whole groups are columns of dy
+    CVK_CHECK_ARG(W % 4 == 0, "cvk_wgradp_gemm_sm_dy: W=%d must be a multiple of 4 (use cvk_wgradp_gemm_sm with six planes)", W);
+    return wgradp_gemm_go(true, E4p, V6sm, dw, N, H, W, Cin, Cin_ld, Cout, workspace, workspace_bytes, stream, dy);
 }
 
 // one call: E6_pre NULL (the E planes are built from dy in the workspace) or the six planes written by cvk_wgradp_zero_pads +

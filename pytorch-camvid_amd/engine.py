@@ -762,7 +762,17 @@ class ConvBnRelu(Op):
                 lib.cvk_bn_bwd_reduce(dO, y.data_ptr(), ldy, psc, psh, pm, pr, part.data_ptr(), N, H, W, C, s), "cvk_bn_bwd_reduce"), "byte")
             check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, gbe, gg, s), "cvk_colsum_finalize")   # dbeta, dgamma
         del pre
-        dy = torch.zeros(M * ldy, device=dev, dtype=_F32) if ldy != C else _empty(M * ldy, dev)
+        # round 6: with V planes from the forward launch the plane GEMM reads E0 / E5 (columns of dy) from dy itself — dy then carries a zeroed slack
+        # behind its last row (cvk_wgradp_gemm_sm_dy) and the BatchNorm-backward pass writes four E planes instead of six
+        planes_kept = Vkept is not None and getattr(Vkept, "cvk_sm", False) and Vkept.numel() == 6 * lib.cvk_wgradp_plane_rows(N, H, W) * src.ld
+        e4p = bool(planes_kept and ldy == C and W % 4 == 0 and R.wgradp and R.e4p and self._wgrad4(R) and not self._wgrad2d(R) and wgradp_ok(src.ld, C, ldy))
+        if e4p:
+            slack = lib.cvk_wgradp_dy_slack(W) * ldy
+            dyb = _empty(M * ldy + slack, dev)
+            dyb[M * ldy:].zero_()
+            dy = dyb[:M * ldy]
+        else:
+            dy = torch.zeros(M * ldy, device=dev, dtype=_F32) if ldy != C else _empty(M * ldy, dev)
         # layers whose weight-grad runs through the transposed F(4,3) get its transformed dy planes E1..E4 from this pass
         wgrad4 = self._wgrad4(R)
         # channel-heavy layers: transposed 2-D F(4x4,3x3), 36 GEMMs over the tile index (25-40 % faster than the transposed
@@ -773,24 +783,26 @@ class ConvBnRelu(Op):
         # planes cost one pass over x; pays while that pass is cheap (measured: 64 -> 64 @360x480 0.74x, 64 -> 128 @180x240 0.7x
         # the time of the transposed F(4,3) kernel; 128 input channels: the V pass eats the gain)
         # round 6: when the fused forward launch left V behind (slice-major planes), every such layer takes the plane GEMM and no pass over x runs
-        have_planes = Vkept is not None and getattr(Vkept, "cvk_sm", False) and Vkept.numel() == 6 * lib.cvk_wgradp_plane_rows(N, H, W) * src.ld
+        have_planes = planes_kept
         wgradp = wgrad4 and R.wgradp and wgradp_ok(src.ld, C, ldy) and (R.wgradp == "always" or have_planes or wgradp_pays(N, H, W, src.ld, C))
         E = None
         E6 = None
         am_dy_fused = None
         want_amax = split_fmt(R) == 2 and st.training and bool(st.amax_spare) and self.src_needs_grad
         if wgradp:
+            e4p = e4p and have_planes
             rows6 = lib.cvk_wgradp_plane_rows(N, H, W)
-            E6 = _empty(6 * rows6 * C, dev)
-            check(lib.cvk_wgradp_zero_pads(E6.data_ptr(), N, H, W, C, s), "cvk_wgradp_zero_pads")
+            E6 = _empty((4 if e4p else 6) * rows6 * C, dev)
+            check((lib.cvk_wgradp_zero_pads4 if e4p else lib.cvk_wgradp_zero_pads)(E6.data_ptr(), N, H, W, C, s), "cvk_wgradp_zero_pads")
             PBe = lib.cvk_bn_bwd_e_blocks(N, H, W)
             blk = st.amax_spare[-1] if want_amax else None      # the opt-in fp16 data-grad scales by the largest |dy|: left by this pass
+            ebytes = (12.0 * M + (16.0 if e4p else 24.0) * N * H * ((W + 3) // 4)) * C
             if blk is not None:
-                rc = _timed(R, "k_bn_bwd<dx+E6>", (12.0 * M + 24.0 * N * H * ((W + 3) // 4)) * C, lambda: lib.cvk_bn_bwd_dx_e_amax(
-                    1, dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, E6.data_ptr(), part.data_ptr(),
+                rc = _timed(R, "k_bn_bwd<dx+E4p>" if e4p else "k_bn_bwd<dx+E6>", ebytes, lambda: lib.cvk_bn_bwd_dx_e_amax(
+                    2 if e4p else 1, dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, E6.data_ptr(), part.data_ptr(),
                     N, H, W, C, 1 if st.training else 0, blk.data_ptr(), s), "byte")
             else:
-                rc = _timed(R, "k_bn_bwd<dx+E6>", (12.0 * M + 24.0 * N * H * ((W + 3) // 4)) * C, lambda: lib.cvk_bn_bwd_dx_e6(
+                rc = _timed(R, "k_bn_bwd<dx+E4p>" if e4p else "k_bn_bwd<dx+E6>", ebytes, lambda: (lib.cvk_bn_bwd_dx_e4p if e4p else lib.cvk_bn_bwd_dx_e6)(
                     dO, y.data_ptr(), ldy, psc, psh, pm, pr, gg, gbe, dy.data_ptr(), ldy, E6.data_ptr(), part.data_ptr(),
                     N, H, W, C, 1 if st.training else 0, s), "byte")
             if rc == 0:
@@ -959,9 +971,14 @@ class ConvBnRelu(Op):
             if E6 is None:
                 _timed(R, "k_wgradp_planes", 4.0 * (M + 6.0 * rows6) * C, lambda: check(
                     lib.cvk_wgradp_planes(dy.data_ptr(), ldy, E6p, N, H, W, C, 1, s), "cvk_wgradp_planes(dy)"), "byte")
-            gemm = lib.cvk_wgradp_gemm_sm if have_planes else lib.cvk_wgradp_gemm
-            _timed(R, "k_wgradp_gemm", 18.0 * M * C * self.cin, lambda: check(
-                gemm(E6p, V6p, gw, N, H, W, self.cin, src.ld, C, slabp, wsb, s), "cvk_wgradp_gemm"), executed=9.0 * M * C * self.cin)
+            if e4p and E6 is not None:
+                _timed(R, "k_wgradp_gemm", 18.0 * M * C * self.cin, lambda: check(
+                    lib.cvk_wgradp_gemm_sm_dy(E6p, dy.data_ptr(), V6p, gw, N, H, W, self.cin, src.ld, C, slabp, wsb, s), "cvk_wgradp_gemm_sm_dy"),
+                    executed=9.0 * M * C * self.cin)
+            else:
+                gemm = lib.cvk_wgradp_gemm_sm if have_planes else lib.cvk_wgradp_gemm
+                _timed(R, "k_wgradp_gemm", 18.0 * M * C * self.cin, lambda: check(
+                    gemm(E6p, V6p, gw, N, H, W, self.cin, src.ld, C, slabp, wsb, s), "cvk_wgradp_gemm"), executed=9.0 * M * C * self.cin)
             del Vkept
         elif wgrad4:
             # transposed F(4,3): fastest weight-grad on every layer with >= 64 input channels (tools/bench_conv.py wgrad wwino wwino4)
@@ -1434,6 +1451,7 @@ class Runner:
         self.wino4f = WINO4F_DEFAULT
         self.wgradp = WGRADP_DEFAULT
         self.vplanes = VPLANES_DEFAULT      # fused forward launches leave the weight-grad's V planes behind (round 6)
+        self.e4p = os.environ.get("CVK_E4P", "1") != "0"    # ... and the plane GEMM reads E0 / E5 from dy: four E planes instead of six (round 6)
         self.thin = os.environ.get("CVK_THIN", "1") != "0"    # csrc/thin.hip for the stem and the classifier head
         self.w2both = os.environ.get("CVK_W2D_DY_BOTH", "1") != "0"   # one launch transforms dy for the data-grad and the weight-grad
         self.bnred_fuse = os.environ.get("CVK_BNRED_FUSE", "1") != "0"   # BN-backward sums in the fused data-grad's epilogue
@@ -1498,7 +1516,7 @@ class Runner:
         every cached tensor it builds straight from a parameter, and this pass replays the record."""
         if not self.wcache or torch.cuda.is_current_stream_capturing():
             return
-        cfg = (id(plan), self.w2tile, self.w2tile_dgrad, self.wino, self.wino4, self.wino4f, self.wino2d, self.wgradp, self.vplanes, self.thin, self.w2d_split)
+        cfg = (id(plan), self.w2tile, self.w2tile_dgrad, self.wino, self.wino4, self.wino4f, self.wino2d, self.wgradp, self.vplanes, self.e4p, self.thin, self.w2d_split)
         if cfg != self._wjobs_cfg:          # another plan or other kernel knobs: the record starts over with this pass
             self._wjobs, self._wjobs_cfg = {}, cfg
             return

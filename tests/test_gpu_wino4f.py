@@ -266,3 +266,61 @@ def test_forward_emitted_v_planes_feed_the_weight_grad(N, H, W, Cin, Cout):
     want = wr.grad.permute(0, 2, 3, 1)
     rel = ((dw_sm.double().cpu() - want).norm() / want.norm()).item()
     assert rel < 1e-5, rel
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 9, 12, 64, 64), (2, 33, 52, 128, 64), (1, 16, 36, 64, 128), (3, 64, 96, 64, 64), (1, 2, 4, 64, 64),
+                                             (2, 9, 13, 64, 64)])
+def test_plane_gemm_reads_the_identity_planes_from_dy(N, H, W, Cin, Cout):
+    """Round 6: E0 and E5 of E = A dy are columns 4 xt and 4 xt + 3 of dy.  (1) cvk_bn_bwd_dx_e4p writes dy and the four planes E1..E4 bitwise as
+    cvk_bn_bwd_dx_e6 writes dy and its planes 1..4; (2) cvk_wgradp_gemm_sm_dy (four planes + dy with a zeroed slack) gives bitwise the weight
+    gradient of cvk_wgradp_gemm_sm on all six planes — also when the slack holds the only finite values beside garbage-free zeros, i.e. the
+    pad column groups of the last row really read it (W = 12, 52, 36, 4: W/4 is not a multiple of 8).  W % 4 != 0 is refused: a ragged last column
+    group has E5 = 0 where dy's next row begins."""
+    from pytorch_camvid_amd._lib import View
+    lib, check = _lib()
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(N + 3 * H + 5 * W + Cin)
+    M = N * H * W
+    dout = torch.randn(N, H, W, Cout, generator=g).cuda()
+    y = torch.randn(M, Cout, generator=g).cuda()
+    gamma, beta = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.3).cuda()
+    mean, rstd = y.mean(0), (y.var(0, unbiased=False) + 1e-5).rsqrt()
+    scale = gamma * rstd
+    shift = beta - mean * scale
+    dgam, dbet = torch.randn(Cout, generator=g).cuda(), torch.randn(Cout, generator=g).cuda()
+    rows = lib.cvk_wgradp_plane_rows(N, H, W)
+    PB = lib.cvk_bn_bwd_e_blocks(N, H, W)
+    view = View(dout.data_ptr(), H * W * Cout, W * Cout, Cout)
+    slack = lib.cvk_wgradp_dy_slack(W) * Cout
+    res = {}
+    for four in (False, True):
+        dyb = torch.full((M * Cout + slack,), float("nan"), device="cuda")
+        dyb[M * Cout:].zero_()
+        E = torch.full(((4 if four else 6) * rows * Cout,), float("nan"), device="cuda")
+        part = torch.zeros(PB * Cout, device="cuda")
+        check((lib.cvk_wgradp_zero_pads4 if four else lib.cvk_wgradp_zero_pads)(E.data_ptr(), N, H, W, Cout, s), "zero pads")
+        check((lib.cvk_bn_bwd_dx_e4p if four else lib.cvk_bn_bwd_dx_e6)(
+            view, y.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dgam.data_ptr(), dbet.data_ptr(),
+            dyb.data_ptr(), Cout, E.data_ptr(), part.data_ptr(), N, H, W, Cout, 1, s), "bn_bwd_dx_e")
+        torch.cuda.synchronize()
+        assert torch.isfinite(dyb).all() and torch.isfinite(E).all()
+        res[four] = (dyb, E, part)
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][2], res[False][2])
+    assert torch.equal(res[True][1], res[False][1][rows * Cout:5 * rows * Cout])
+    # the weight-grad: V planes from x (stand-alone slice-major pass)
+    x = torch.randn(N, H, W, Cin, generator=g).cuda()
+    V = torch.empty(6 * rows * Cin, device="cuda")
+    check(lib.cvk_wgradp_planes_sm(x.data_ptr(), Cin, V.data_ptr(), N, H, W, Cin, s), "planes_sm")
+    wsb = lib.cvk_wgradp_gemm_workspace_bytes(N, H, W, Cin, Cout)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    dw6, dw4 = torch.empty(Cout, 9 * Cin, device="cuda"), torch.empty(Cout, 9 * Cin, device="cuda")
+    check(lib.cvk_wgradp_gemm_sm(res[False][1].data_ptr(), V.data_ptr(), dw6.data_ptr(), N, H, W, Cin, Cin, Cout, ws.data_ptr(), wsb, s), "gemm_sm")
+    if W % 4:
+        rc = lib.cvk_wgradp_gemm_sm_dy(res[True][1].data_ptr(), res[True][0].data_ptr(), V.data_ptr(), dw4.data_ptr(), N, H, W, Cin, Cin, Cout,
+                                       ws.data_ptr(), wsb, s)
+        assert rc == -1 and b"multiple of 4" in lib.cvk_last_error_string()
+        return
+    check(lib.cvk_wgradp_gemm_sm_dy(res[True][1].data_ptr(), res[True][0].data_ptr(), V.data_ptr(), dw4.data_ptr(), N, H, W, Cin, Cin, Cout,
+                                    ws.data_ptr(), wsb, s), "gemm_sm_dy")
+    torch.cuda.synchronize()
+    assert torch.isfinite(dw4).all() and torch.equal(dw4, dw6)
