@@ -409,6 +409,14 @@ int cvk_maxpool2x2_fwd(cvk_view x, float* out, uint8_t* code, int N, int H, int 
  * the odd trailing row/column), accumulate=1 adds. */
 int cvk_maxpool2x2_bwd(const float* dout, cvk_view x, const uint8_t* code, cvk_view dx, int accumulate,
                        int N, int H, int W, int C, void* stream);
+/* ... that also leaves the first pass of the PRODUCING block's BatchNorm+ReLU backward (nn.BatchNorm2d + nn.ReLU of models/unet.py:12-13 in front of the
+ * nn.MaxPool2d of :92; backward of train.py:131): the pool backward is the last writer of the block's output gradient dx and touches every element, so it
+ * sums g = dx * [ReLU passed] and g * xhat on the way — part = float[2][cvk_maxpool2x2_bwd_bnred_blocks(N,H,W,C)][C] for cvk_colsum_finalize; yP [N*H*W][ldp]
+ * is the block's conv output, scale / shift / mean / rstd as for cvk_bn_bwd_reduce, which is then not launched.  _blocks returns 0 for unsupported C. */
+int cvk_maxpool2x2_bwd_bnred_blocks(int N, int H, int W, int C);
+int cvk_maxpool2x2_bwd_bnred(const float* dout, cvk_view x, const uint8_t* code, cvk_view dx, int accumulate, int N, int H, int W, int C,
+                             const float* yP, int ldp, const float* scale, const float* shift, const float* mean, const float* rstd,
+                             float* part, void* stream);
 int cvk_maxunpool2x2_fwd(const float* v, const uint8_t* code, float* out, int N, int H, int W, int C, void* stream);
 int cvk_maxunpool2x2_bwd(const float* dout, const uint8_t* code, float* dv, int N, int H, int W, int C, void* stream);
 /* uint8 codes -> torch-style int64 flat H*W indices in NCHW order (API parity with return_indices=True) */

@@ -167,6 +167,8 @@ SIGNATURES = {
                                    c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "cvk_maxpool2x2_fwd": (c_int, [View, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_maxpool2x2_bwd": (c_int, [c_vp, View, c_vp, View, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_maxpool2x2_bwd_bnred_blocks": (c_int, [c_int, c_int, c_int, c_int]),
+    "cvk_maxpool2x2_bwd_bnred": (c_int, [c_vp, View, c_vp, View, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "cvk_maxunpool2x2_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_maxunpool2x2_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_pool_code_to_index": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),

@@ -183,6 +183,122 @@ __global__ void k_pool_scatter(const float* __restrict__ val, cvk_view x, const 
     }
 }
 
+// Round 6: k_pool_scatter<4, SRC> that ALSO leaves the first pass of the producing block's BatchNorm+ReLU backward (csrc/bn.hip k_bn_bwd<MODE 0>:
+// sum g and sum g * xhat over the block's output gradient, g = dO where the ReLU passed, xhat = (yP - mean) * rstd).  The max-pool backward is the
+// LAST writer of that gradient (the skip connection's share was written earlier), it touches every element of it, and the reduce pass would read
+// them all again: here the final values are in registers — one read of yP is added, one read of dO and a launch go.  A block owns a contiguous range of
+// cells, a thread a fixed 4-channel vector (256 % (C/4) == 0): partial sums [2][PB][C] for cvk_colsum_finalize, combined in a fixed order.
+template <int SRC>
+__global__ __launch_bounds__(256) void k_pool_scatter_bnred(const float* __restrict__ val, cvk_view x, const uint8_t* __restrict__ code, cvk_view dx,
+                                                           int accumulate, int N, int H, int W, int C, const float* __restrict__ yP, int ldp,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           float* __restrict__ part, int cpb, int PB) {
+    __shared__ float red[2][256 * 4];
+    const int Ho = H / 2, Wo = W / 2, Hc = (H + 1) / 2, Wc = (W + 1) / 2, cvn = C / 4;
+    const int ppp = 256 / cvn;
+    const int t = threadIdx.x, cv = t % cvn, pr = t / cvn, c = cv * 4;
+    const long total = (long)N * Hc * Wc;
+    const long cbeg = (long)blockIdx.x * cpb, cend = cbeg + cpb < total ? cbeg + cpb : total;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    // two cells per iteration, every load of both issued before the first use: the pass is latency-bound otherwise (one cell per
+    // iteration: 4.4 TB/s of its own bytes)
+    constexpr int U = 2;
+    for (long cell0 = cbeg + pr; cell0 < cend; cell0 += (long)U * ppp) {
+        float* d[U];
+        bool full[U], live[U];
+        int nn[U], yc_[U], xc_[U];
+        f32x4 g[U], o4[U][4], yv[U][4], xv[U][4];
+        uint8_t cd[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long cell = cell0 + (long)u * ppp;
+            live[u] = cell < cend;
+            const long cc = live[u] ? cell : cbeg;
+            const int xc = (int)(cc % Wc);
+            const long tq = cc / Wc;
+            const int yc = (int)(tq % Hc), n = (int)(tq / Hc);
+            nn[u] = n; yc_[u] = yc; xc_[u] = xc;
+            d[u] = dx.ptr + n * dx.sN + (2 * yc) * dx.sY + (2 * xc) * dx.sX + c;
+            full[u] = live[u] && yc < Ho && xc < Wo;
+            g[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cd[u][j] = 255;
+            if (full[u]) {
+                const long o = (((long)n * Ho + yc) * Wo + xc) * C + c;
+                g[u] = *reinterpret_cast<const f32x4*>(val + o);
+                if (SRC == 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cd[u][j] = code[o + j];
+                } else {
+                    const float* p = x.ptr + n * x.sN + (2 * yc) * x.sY + (2 * xc) * x.sX + c;
+                    xv[u][0] = *reinterpret_cast<const f32x4*>(p);
+                    xv[u][1] = *reinterpret_cast<const f32x4*>(p + x.sX);
+                    xv[u][2] = *reinterpret_cast<const f32x4*>(p + x.sY);
+                    xv[u][3] = *reinterpret_cast<const f32x4*>(p + x.sY + x.sX);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int yy = 2 * yc + (k >> 1), xx = 2 * xc + (k & 1);
+                o4[u][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                yv[u][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!live[u] || yy >= H || xx >= W) continue;
+                if (accumulate) o4[u][k] = *reinterpret_cast<const f32x4*>(d[u] + (k >> 1) * dx.sY + (k & 1) * dx.sX);
+                yv[u][k] = *reinterpret_cast<const f32x4*>(yP + (((size_t)n * H + yy) * W + xx) * ldp + c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!live[u]) continue;
+            if (full[u] && SRC == 0) {
+                f32x4 best = xv[u][0];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cd[u][j] = 0;
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float a = xv[u][k][j], b = best[j];
+                        if (a > b || a != a) { best[j] = a; cd[u][j] = (uint8_t)k; }
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int yy = 2 * yc_[u] + (k >> 1), xx = 2 * xc_[u] + (k & 1);
+                if (yy >= H || xx >= W) continue;                 // odd trailing row / column: the cell has fewer than four pixels
+                f32x4 o = o4[u][k];
+                if (full[u]) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] += cd[u][j] == k ? g[u][j] : 0.f;
+                }
+                if (full[u] || !accumulate) *reinterpret_cast<f32x4*>(d[u] + (k >> 1) * dx.sY + (k & 1) * dx.sX) = o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gg = (yv[u][k][j] * sc[j] + sh[j] > 0.f) ? o[j] : 0.f;
+                    const float xh = (yv[u][k][j] - mu[j]) * rs[j];
+                    s0[j] += gg;
+                    s1[j] += gg * xh;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[0][t * 4 + j] = s0[j]; red[1][t * 4 + j] = s1[j]; }
+    __syncthreads();
+    if (t < cvn) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.f, b = 0.f;
+            for (int p = 0; p < ppp; ++p) { a += red[0][(p * cvn + t) * 4 + j]; b += red[1][(p * cvn + t) * 4 + j]; }
+            part[(size_t)blockIdx.x * C + t * 4 + j] = a;
+            part[(size_t)(PB + blockIdx.x) * C + t * 4 + j] = b;
+        }
+    }
+}
+
 template <int V>
 __global__ void k_unpool_bwd(const float* __restrict__ dout, const uint8_t* __restrict__ code, float* __restrict__ dv, int N,
                              int H, int W, int C) {
@@ -409,6 +525,40 @@ extern "C" int cvk_maxpool2x2_bwd(const float* dout, cvk_view x, const uint8_t* 
         else hipLaunchKernelGGL((k_pool_scatter<1, 0>), dim3(grid_for(cells * C)), dim3(256), 0, s, dout, x, code, dx, accumulate, N, H, W, C);
     }
     CVK_LAUNCH_RETURN("cvk_maxpool2x2_bwd");
+}
+
+// blocks (= partial sums per channel) of cvk_maxpool2x2_bwd_bnred; 0: the shape is not supported (C/4 must divide 256)
+extern "C" int cvk_maxpool2x2_bwd_bnred_blocks(int N, int H, int W, int C) {
+    if (N <= 0 || H < 2 || W < 2 || C < 4 || C % 4 || C > 1024 || 256 % (C / 4)) return 0;
+    const long cells = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
+    const int ppp = 256 / (C / 4);
+#ifndef CVK_PBN_CPT
+#define CVK_PBN_CPT 4
+#endif
+#ifndef CVK_PBN_CAP
+#define CVK_PBN_CAP 4096
+#endif
+    const long want = (cells + (long)CVK_PBN_CPT * ppp - 1) / ((long)CVK_PBN_CPT * ppp);          // >= CVK_PBN_CPT cells per thread
+    return (int)(want < 1 ? 1 : (want > CVK_PBN_CAP ? CVK_PBN_CAP : want));
+}
+
+// cvk_maxpool2x2_bwd (4-channel vector layout required) that also leaves the partial sums of the producing block's BatchNorm-backward reduce pass
+// over the FINISHED gradient dx: part = float[2][cvk_maxpool2x2_bwd_bnred_blocks][C] for cvk_colsum_finalize(part, blocks, C, dbeta, dgamma).
+// yP [N*H*W][ldp] = the block's conv output, scale / shift / mean / rstd its BatchNorm constants (contract of cvk_bn_bwd_reduce).
+extern "C" int cvk_maxpool2x2_bwd_bnred(const float* dout, cvk_view x, const uint8_t* code, cvk_view dx, int accumulate, int N, int H, int W, int C,
+                                        const float* yP, int ldp, const float* scale, const float* shift, const float* mean, const float* rstd,
+                                        float* part, void* stream) {
+    CVK_CHECK_ARG(dout && dx.ptr && (code || x.ptr) && yP && scale && shift && mean && rstd && part, "cvk_maxpool2x2_bwd_bnred: null pointer");
+    const int PB = cvk_maxpool2x2_bwd_bnred_blocks(N, H, W, C);
+    CVK_CHECK_ARG(PB > 0 && ldp >= C && ldp % 4 == 0, "cvk_maxpool2x2_bwd_bnred: unsupported shape (C=%d: C/4 must divide 256)", C);
+    CVK_CHECK_ARG(view4(dx) && cvk_aligned16(dout) && (code || view4(x)) && cvk_aligned16(yP) && cvk_aligned16(scale) && cvk_aligned16(shift) &&
+                  cvk_aligned16(mean) && cvk_aligned16(rstd), "cvk_maxpool2x2_bwd_bnred: needs the 4-channel vector layout");
+    const long cells = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
+    const int cpb = (int)((cells + PB - 1) / PB);
+    hipStream_t s = (hipStream_t)stream;
+    if (code) hipLaunchKernelGGL(k_pool_scatter_bnred<1>, dim3(PB), dim3(256), 0, s, dout, x, code, dx, accumulate, N, H, W, C, yP, ldp, scale, shift, mean, rstd, part, cpb, PB);
+    else hipLaunchKernelGGL(k_pool_scatter_bnred<0>, dim3(PB), dim3(256), 0, s, dout, x, code, dx, accumulate, N, H, W, C, yP, ldp, scale, shift, mean, rstd, part, cpb, PB);
+    CVK_LAUNCH_RETURN("cvk_maxpool2x2_bwd_bnred");
 }
 
 extern "C" int cvk_maxunpool2x2_fwd(const float* v, const uint8_t* code, float* out, int N, int H, int W, int C, void* stream) {

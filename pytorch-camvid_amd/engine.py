@@ -1208,6 +1208,28 @@ class MaxPool(Op):
             st.grad.pop(d.id)
             return
         code = st.saved.get(self.idx)
+        # round 6: when the pool directly follows a conv block (its BN-apply pass pooled) this pass is the LAST writer of the block's output
+        # gradient — the consumers behind it in the plan ran earlier in backward — and touches every element of it: it then also leaves the block's
+        # BatchNorm-backward sums (csrc/pointwise.hip k_pool_scatter_bnred) and the block's reduce pass is not launched
+        prod = st.plan.ops[self.producer_idx] if (self.fused and self.producer_idx >= 0) else None
+        if (prod is not None and st.training and R.bnred_fuse and R.pool_bnred and isinstance(prod, ConvBnRelu) and prod.idx in st.saved
+                and prod.idx not in st.bnred and prod.dst.buf is v.buf and (prod.dst.c0, prod.dst.C, prod.dst.y0, prod.dst.x0, prod.dst.H, prod.dst.W) == (v.c0, v.C, v.y0, v.x0, v.H, v.W)
+                and pad4(prod.cout) == prod.cout == v.C
+                and st.plan.last_gradient_writer(v, prod.idx) == self.idx):
+            PBp = R.lib.cvk_maxpool2x2_bwd_bnred_blocks(v.buf.N, v.H, v.W, v.C)
+            if PBp > 0:
+                py, pbnp = st.saved[prod.idx][0], st.saved[prod.idx][1]
+                ldp = pad4(prod.cout)
+                part = _empty(2 * PBp * v.C, X.device)
+                rc = _timed(R, "k_pool_scatter(bwd+bnred)", (1.0 + (0.25 if code is not None else 4.0) + (8.0 if acc else 4.0) + 4.0) * v.buf.N * v.H * v.W * v.C,
+                            lambda: R.lib.cvk_maxpool2x2_bwd_bnred(
+                                st.grad[d.id].data_ptr(), v.cview(X), code.data_ptr() if code is not None else None, v.cview(st.grad[v.buf.id]),
+                                1 if acc else 0, v.buf.N, v.H, v.W, v.C, py.data_ptr(), ldp, pbnp.data_ptr() + 8 * ldp, pbnp.data_ptr() + 12 * ldp,
+                                pbnp.data_ptr(), pbnp.data_ptr() + 4 * ldp, part.data_ptr(), st.stream), "byte")
+                if rc == 0:
+                    st.bnred[prod.idx] = (part, PBp)
+                    st.grad.pop(d.id)
+                    return
         # bytes per input element: the pooled gradient (1) + the arg-max source (the activations, 4, or the 1-byte codes, 0.25) + the
         # gradient written (4) or accumulated (8)
         _timed(R, "k_pool_scatter(bwd)", (1.0 + (0.25 if code is not None else 4.0) + (8.0 if acc else 4.0)) * v.buf.N * v.H * v.W * v.C, lambda: check(
@@ -1341,6 +1363,20 @@ class Plan:
     def _reads(self, buf):
         self._readers[buf.id] = self._readers.get(buf.id, 0) + 1
 
+    def last_gradient_writer(self, view, producer_idx):
+        """Index of the op whose backward pass writes LAST into the gradient of `view` (channels [c0, c0 + C) of its buffer): backward runs the plan
+        in reverse, so it is the FIRST op behind the producer that reads any of those channels."""
+        for op in self.ops[producer_idx + 1:]:
+            s = getattr(op, "src", None)
+            if s is None:
+                continue
+            if isinstance(s, BufView):
+                if s.buf is view.buf and s.c0 < view.c0 + view.C and view.c0 < s.c0 + s.C:
+                    return op.idx
+            elif s is view.buf:
+                return op.idx
+        return -1
+
     def sole_producer(self, buf):
         """The ConvBnRelu block whose output is exactly `buf` when `buf` has ONE reader — that reader's data-grad is then
         the complete dL/d(activation) of the block, and may carry the block's BatchNorm-backward sums (csrc/wino4f.hip BNR)."""
@@ -1455,6 +1491,7 @@ class Runner:
         self.thin = os.environ.get("CVK_THIN", "1") != "0"    # csrc/thin.hip for the stem and the classifier head
         self.w2both = os.environ.get("CVK_W2D_DY_BOTH", "1") != "0"   # one launch transforms dy for the data-grad and the weight-grad
         self.bnred_fuse = os.environ.get("CVK_BNRED_FUSE", "1") != "0"   # BN-backward sums in the fused data-grad's epilogue
+        self.pool_bnred = os.environ.get("CVK_POOL_BNRED", "1") != "0"   # ... and in the max-pool backward pass behind a conv block (round 6)
         self.wino2d = WINO2D_DEFAULT
         # OPT-IN split-operand modes (cvk.set_split_operands): the matrix products of the fp32 convolutions on the 16-bit
         # matrix pipe with split fp32 operands (csrc/split_fmt.h).  Not the product default; bench.py names the mode in `dtype` when it is on.

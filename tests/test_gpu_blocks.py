@@ -462,3 +462,55 @@ def test_conv_small_cout_raw_abi(case):
         rows = flat[64 * p:min(M, 64 * p + 64)]
         np.testing.assert_allclose(st[0, p].numpy(), rows.sum(0).numpy(), rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(st[1, p].numpy(), ((rows - rows.mean(0)) ** 2).sum(0).numpy(), rtol=2e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("N,H,W,C,strided", [(2, 12, 16, 64, False), (1, 45, 60, 128, True), (2, 9, 7, 64, True), (1, 6, 10, 256, False)])
+def test_pool_backward_leaves_the_producers_batchnorm_sums(N, H, W, C, strided):
+    """Round 6: cvk_maxpool2x2_bwd_bnred = nn.MaxPool2d(2,2) backward (models/unet.py:92) that also leaves the partial sums of the producing block's
+    BatchNorm+ReLU backward (unet.py:12-13) over the FINISHED gradient.  dx is bitwise the plain pass's — overwrite and accumulate, arg-max from the
+    activations or from codes, odd sizes, a channel slice of a wider (concat) buffer — and d(beta), d(gamma) from the partials match cvk_bn_bwd_reduce on
+    that dx (other summation order: 2e-5 of the sums' scale) and fp64."""
+    from pytorch_camvid_amd import _lib
+    from pytorch_camvid_amd._lib import check, View
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(N * 100 + H + W + C)
+    ld = 2 * C if strided else C                                  # strided: the view is channels [C, 2C) of a concat buffer
+    xb = torch.relu(torch.randn(N, H, W, ld, generator=g)).to(dev())       # post-ReLU activations (ties at 0 included)
+    yP = torch.randn(N * H * W, C, generator=g).to(dev()) * 1.3 + 0.2
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev()), (torch.randn(C, generator=g) * 0.3).to(dev())
+    mean, rstd = yP.mean(0), (yP.var(0, unbiased=False) + 1e-5).rsqrt()
+    scale = gamma * rstd
+    shift = beta - mean * scale
+    r = torch.randn(N, H // 2, W // 2, C, generator=g).to(dev())
+    c0 = C if strided else 0
+
+    def view(t):
+        return View(t.data_ptr() + 4 * c0, H * W * ld, W * ld, ld)
+    out = torch.empty((N, H // 2, W // 2, C), device=dev())
+    code = torch.empty((N, H // 2, W // 2, C), device=dev(), dtype=torch.uint8)
+    check(lib.cvk_maxpool2x2_fwd(view(xb), out.data_ptr(), code.data_ptr(), N, H, W, C, s))
+    PB = lib.cvk_maxpool2x2_bwd_bnred_blocks(N, H, W, C)
+    assert PB > 0
+    for use_code in (False, True):
+        for acc in (0, 1):
+            base = torch.randn(N, H, W, ld, generator=g).to(dev())
+            dx0, dx1 = base.clone(), base.clone()
+            check(lib.cvk_maxpool2x2_bwd(r.data_ptr(), view(xb), code.data_ptr() if use_code else None, view(dx0), acc, N, H, W, C, s))
+            part = torch.full((2 * PB * C,), float("nan"), device=dev())
+            check(lib.cvk_maxpool2x2_bwd_bnred(r.data_ptr(), view(xb), code.data_ptr() if use_code else None, view(dx1), acc, N, H, W, C,
+                                               yP.data_ptr(), C, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), part.data_ptr(), s))
+            torch.cuda.synchronize()
+            assert torch.equal(dx0, dx1), (use_code, acc)
+            assert torch.isfinite(part).all()
+            db, dg = torch.empty(C, device=dev()), torch.empty(C, device=dev())
+            check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, db.data_ptr(), dg.data_ptr(), s))
+            dO = dx0[..., c0:c0 + C].reshape(-1, C).double()
+            y64 = yP.double()
+            gq = torch.where(y64 * scale.double() + shift.double() > 0, dO, torch.zeros_like(dO))
+            want_b = gq.sum(0)
+            want_g = (gq * (y64 - mean.double()) * rstd.double()).sum(0)
+            sb = gq.abs().sum(0).clamp_min(1.0)
+            assert ((db.double() - want_b).abs() / sb).max().item() < 2e-5
+            assert ((dg.double() - want_g).abs() / sb).max().item() < 6e-5
+    assert lib.cvk_maxpool2x2_bwd_bnred_blocks(1, 8, 8, 12) == 0 and lib.cvk_maxpool2x2_bwd_bnred_blocks(1, 8, 8, 96) == 0      # C/4 must divide 256
