@@ -17,3 +17,29 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# Round 6: `python bench.py` died with SIGSEGV in about one run of seven — AFTER its JSON line, while the interpreter, HIP and RCCL (a world-size-1
+# communicator, HIP graphs with captured collectives) unwound at exit.  The GPU suite creates the same objects
+# (tests/test_gpu_ddp.py::test_world1_rccl_group_eager_and_captured_step), and a crash in that teardown would turn a green run into rc 139.  So a
+# process that initialised the GPU leaves through os._exit with pytest's own exit status once the summary has been written; CPU runs are untouched.
+_exit_status = [None]
+
+
+def pytest_sessionfinish(session, exitstatus):
+    _exit_status[0] = int(exitstatus)
+
+
+@pytest.hookimpl(trylast=True)
+def pytest_unconfigure(config):
+    if _exit_status[0] is None or os.environ.get("CVK_TEST_NORMAL_EXIT") == "1":
+        return
+    try:
+        import torch
+        gpu = torch.cuda.is_available() and torch.cuda.is_initialized()
+    except Exception:
+        gpu = False
+    if gpu:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(_exit_status[0])
