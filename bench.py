@@ -603,6 +603,8 @@ def main():
             dist.destroy_process_group()
         except Exception as e:          # the measurement is printed; a failing teardown must not turn it into an error
             print(f"bench.py: destroy_process_group failed: {e}", file=sys.stderr)
+    import atexit
+    atexit._run_exitfuncs()             # exit callbacks still run; skipped: object destruction in interpreter finalisation and the native libraries' static destructors
     sys.stderr.flush()
     os._exit(3 if dp_fail else 0)
 
