@@ -603,6 +603,11 @@ def main():
             dist.destroy_process_group()
         except Exception as e:          # the measurement is printed; a failing teardown must not turn it into an error
             print(f"bench.py: destroy_process_group failed: {e}", file=sys.stderr)
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        # under rocprofv3 the tool library writes its trace files from exit handlers of the native runtime: leave the ordinary way
+        if dist.is_initialized() and world == 1:
+            dist.destroy_process_group()
+        raise SystemExit(3 if dp_fail else 0)
     import atexit
     atexit._run_exitfuncs()             # exit callbacks still run; skipped: object destruction in interpreter finalisation and the native libraries' static destructors
     sys.stderr.flush()
