@@ -153,7 +153,9 @@ __device__ __forceinline__ void f_dma16(const void* sbase, unsigned voff, unsign
 // yP (the producer's conv output, same geometry and row stride as Y) and leaves per-m-tile partial sums in `stats`
 // ([2][P][Cout], the layout cvk_colsum_finalize reads) — the producer's reduce pass over dX and yP is not launched at all.
 struct FBnRed {
-    const float* y;       // producer's conv output [N*H*W][ldy]
+    int ldp;              // row stride of y (round 6: the producer may cover only the first Cp of this launch's output channels — the upsample half of
+    int Cp;               // a concat gradient — so its conv output has its own pitch); Cp % 64 == 0: the n-tiles [0, Cp / 64) carry the sums
+    const float* y;       // producer's conv output [N*H*W][ldp]
     const float* scale;   // gamma * rstd, beta - mean * gamma * rstd  (the forward's apply constants: the ReLU mask)
     const float* shift;
     const float* mean;
@@ -204,10 +206,11 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
         const bool ok = c < Cout;
         cst[c] = (bias != nullptr && ok) ? bias[c] : 0.f;
         if (BNR) {
-            cst[F_CMAX + c] = ok ? bn.scale[c] : 0.f;
-            cst[2 * F_CMAX + c] = ok ? bn.shift[c] : 0.f;
-            cst[3 * F_CMAX + c] = ok ? bn.mean[c] : 0.f;
-            cst[4 * F_CMAX + c] = ok ? bn.rstd[c] : 0.f;
+            const bool okp = c < bn.Cp;
+            cst[F_CMAX + c] = okp ? bn.scale[c] : 0.f;
+            cst[2 * F_CMAX + c] = okp ? bn.shift[c] : 0.f;
+            cst[3 * F_CMAX + c] = okp ? bn.mean[c] : 0.f;
+            cst[4 * F_CMAX + c] = okp ? bn.rstd[c] : 0.f;
         }
     }                                                                     // visible after the prologue's barrier
 
@@ -525,11 +528,15 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
         float s1 = 0.f, s2 = 0.f;
         __amdgpu_buffer_rsrc_t pr = null_rsrc;
         float bsc = 0.f, bsh = 0.f, bmu = 0.f;
-        if (BNR) {
-            pr = __builtin_amdgcn_make_buffer_rsrc((void*)(bn.y + (size_t)pixb * ldy), 0,
-                                                   (int)(ybytes < 0x7FFFFFFFu ? ybytes : 0x7FFFFFFFu), 0x00020000);
+        // BNR: only the n-tiles of the producer's channels [0, Cp) carry the sums (uniform per tile); yP has its own row pitch
+        const bool bact = BNR && tn * F_BN < bn.Cp;
+        const unsigned lsp = BNR ? (unsigned)bn.ldp * 4u : 0u;
+        if (bact) {
+            const size_t pbytes = ((size_t)Mpix - pixb) * bn.ldp * 4;
+            pr = __builtin_amdgcn_make_buffer_rsrc((void*)(bn.y + (size_t)pixb * bn.ldp), 0,
+                                                   (int)(pbytes < 0x7FFFFFFFu ? pbytes : 0x7FFFFFFFu), 0x00020000);
             if (CL) { bsc = cst[F_CMAX + (col & (F_CMAX - 1))]; bsh = cst[2 * F_CMAX + (col & (F_CMAX - 1))]; bmu = cst[3 * F_CMAX + (col & (F_CMAX - 1))]; }
-            else if (cok) { bsc = bn.scale[col]; bsh = bn.shift[col]; bmu = bn.mean[col]; }
+            else if (col < bn.Cp) { bsc = bn.scale[col]; bsh = bn.shift[col]; bmu = bn.mean[col]; }
         }
         // g = dX where the producer's ReLU passed; accumulates sum g and sum g * (yP - mean)  (rstd multiplies once, at the end)
         auto bnacc = [&](float q, float v) {
@@ -542,6 +549,7 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
             // the bias and the statistics (its instructions take matrix time on this part); a row's byte offset is uniform and
             // travels in the scalar offset of the store.
             const unsigned ob = (unsigned)((4 * (wm * 32 + 4 * lh)) * ldy + col) * 4u;
+            const unsigned obp = BNR ? (unsigned)((4 * (wm * 32 + 4 * lh)) * bn.ldp + col) * 4u : 0u;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float m0_ = H2 ? acc[0][e] * un[0].a * un[0].b : acc[0][e], m1 = H2 ? acc[1][e] * un[1].a * un[1].b : acc[1][e],
@@ -560,14 +568,15 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
                     s1 += (y0 + y1) + (y2 + y3);
                     s2 += fmaf(y0, y0, y1 * y1) + fmaf(y2, y2, y3 * y3);
                 }
-                if (BNR) {
+                if (bact) {
                     // (hipcc keeps 16 of these loads in flight; asking for 32 up front changed nothing — every workgroup reaches
                     // its epilogue at about the same time and the burst is bandwidth-, not latency-bound: +10 % on the launch,
                     // against the whole reduce pass it replaces)
-                    const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, ob, so, 0));
-                    const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, ob, so + ls, 0));
-                    const float q2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, ob, so + 2 * ls, 0));
-                    const float q3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, ob, so + 3 * ls, 0));
+                    const unsigned sop = (unsigned)(4 * ((e & 3) + 8 * (e >> 2))) * lsp;
+                    const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, obp, sop, 0));
+                    const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, obp, sop + lsp, 0));
+                    const float q2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, obp, sop + 2 * lsp, 0));
+                    const float q3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, obp, sop + 3 * lsp, 0));
                     bnacc(q0, y0 + bs); bnacc(q1, y1 + bs); bnacc(q2, y2 + bs); bnacc(q3, y3 + bs);
                 }
             }
@@ -594,17 +603,18 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
                     s1 += (z0 + z1) + (z2 + z3);
                     s2 += fmaf(z0, z0, z1 * z1) + fmaf(z2, z2, z3 * z3);
                 }
-                if (BNR) {      // an out-of-range load returns 0; the value beside it is masked by nv as well
-                    const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 0, o), 0, 0));
-                    const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 1, o), ls, 0));
-                    const float q2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 2, o), 2 * ls, 0));
-                    const float q3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 3, o), 3 * ls, 0));
+                if (bact) {     // an out-of-range load returns 0; the value beside it is masked by nv as well
+                    const unsigned op = (unsigned)((q * W + 4 * xt - pixb) * bn.ldp + col) * 4u;
+                    const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 0, op), 0, 0));
+                    const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 1, op), lsp, 0));
+                    const float q2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 2, op), 2 * lsp, 0));
+                    const float q3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 3, op), 3 * lsp, 0));
                     bnacc(q0, nv > 0 ? y0 + bs : 0.f); bnacc(q1, nv > 1 ? y1 + bs : 0.f);
                     bnacc(q2, nv > 2 ? y2 + bs : 0.f); bnacc(q3, nv > 3 ? y3 + bs : 0.f);
                 }
             }
         }
-        if (BNR) {
+        if (bact) {
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (lh == 0) {
@@ -614,11 +624,11 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
             __syncthreads();
             if (tid < 64) {
                 const int c = tn * F_BN + tid;
-                if (c < Cout) {
+                if (c < bn.Cp) {
                     const float a = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
                     const float b = (red[256 + tid] + red[320 + tid]) + (red[384 + tid] + red[448 + tid]);
-                    stats[(size_t)mt * Cout + c] = a;
-                    stats[(size_t)(P + mt) * Cout + c] = b * (CL ? cst[4 * F_CMAX + c] : bn.rstd[c]);
+                    stats[(size_t)mt * bn.Cp + c] = a;
+                    stats[(size_t)(P + mt) * bn.Cp + c] = b * (CL ? cst[4 * F_CMAX + c] : bn.rstd[c]);
                 }
             }
         }
@@ -854,7 +864,7 @@ static int wino4f_launch(const char* who, const float* x, const float* Uf, const
     const int grid = ntiles < wgs ? ntiles : wgs;
     CVK_CHECK_ARG((F_BM * 4 + 3L * W + 8) * Cin * 4 < (1L << 31), "%s: a tile's input window exceeds the 2 GiB buffer-addressing limit", who);
     hipStream_t s = (hipStream_t)stream;
-    const FBnRed none = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const FBnRed none = {0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     const bool h2 = amax_x != nullptr;
     CVK_CHECK_ARG((amax_x == nullptr) == (amax_w == nullptr), "%s: the two amax blocks go together", who);
     FSplit sp = {(const unsigned*)amax_x, (const unsigned*)amax_w, CvkSplitTab{}, CvkSplitTab{}};
@@ -906,8 +916,20 @@ extern "C" int cvk_conv3x3_wino4f_bnred(const float* x, const float* Uf, float* 
                                         const float* yP, const float* scale, const float* shift, const float* mean,
                                         const float* rstd, float* part, int max_workgroups, void* stream) {
     CVK_CHECK_ARG(yP && scale && shift && mean && rstd && part, "cvk_conv3x3_wino4f_bnred: null pointer");
-    const FBnRed bn = {yP, scale, shift, mean, rstd};
+    const FBnRed bn = {ldy, Cout, yP, scale, shift, mean, rstd};
     return wino4f_launch("cvk_conv3x3_wino4f_bnred", x, Uf, nullptr, y, part, nullptr, &bn, N, H, W, Cin, Cout, ldy, max_workgroups, stream);
+}
+
+// ... when the producer block wrote only the FIRST Cp of this data-grad's Cout output channels (the upsample half of a concat buffer,
+// models/unet.py:124: torch.cat([xup, skip])): yP [N*H*W][ldp] is its conv output with its own row pitch, scale / shift / mean / rstd have Cp entries,
+// part = float[2][cvk_wino4f_stat_partials][Cp].  Cp % 64 == 0, Cp <= Cout.  y (all Cout channels) is bitwise cvk_conv3x3_wino4f's.
+extern "C" int cvk_conv3x3_wino4f_bnred_part(const float* x, const float* Uf, float* y, int N, int H, int W, int Cin, int Cout, int ldy,
+                                             const float* yP, int ldp, int Cp, const float* scale, const float* shift, const float* mean,
+                                             const float* rstd, float* part, int max_workgroups, void* stream) {
+    CVK_CHECK_ARG(yP && scale && shift && mean && rstd && part, "cvk_conv3x3_wino4f_bnred_part: null pointer");
+    CVK_CHECK_ARG(Cp > 0 && Cp % F_BN == 0 && Cp <= Cout && ldp >= Cp, "cvk_conv3x3_wino4f_bnred_part: Cp=%d must be a multiple of 64 within Cout=%d, ldp >= Cp", Cp, Cout);
+    const FBnRed bn = {ldp, Cp, yP, scale, shift, mean, rstd};
+    return wino4f_launch("cvk_conv3x3_wino4f_bnred_part", x, Uf, nullptr, y, part, nullptr, &bn, N, H, W, Cin, Cout, ldy, max_workgroups, stream);
 }
 
 // ---- the opt-in fp16 split-operand form (csrc/split_fmt.h; runner.w2d_split = 2): same contracts, plus the amax blocks of x and of the filter ----
@@ -932,7 +954,7 @@ extern "C" int cvk_conv3x3_wino4h_bnred(const float* x, const void* Uh, float* y
                                         int Cout, int ldy, const float* yP, const float* scale, const float* shift, const float* mean,
                                         const float* rstd, float* part, int max_workgroups, void* stream) {
     CVK_CHECK_ARG(yP && scale && shift && mean && rstd && part && amax_x && amax_w, "cvk_conv3x3_wino4h_bnred: null pointer");
-    const FBnRed bn = {yP, scale, shift, mean, rstd};
+    const FBnRed bn = {ldy, Cout, yP, scale, shift, mean, rstd};
     return wino4f_launch("cvk_conv3x3_wino4h_bnred", x, (const float*)Uh, nullptr, y, part, nullptr, &bn, N, H, W, Cin, Cout, ldy, max_workgroups, stream,
                          amax_x, amax_w);
 }
@@ -944,7 +966,7 @@ extern "C" int cvk_conv3x3_wino4f_ablate(const float* x, const float* Uf, const 
     const int tilesN = f_tiles_n(Cout), tilesM = cvk_cdiv(Mt, F_BM), ntiles = tilesM * tilesN;
     const int grid = ntiles < 256 ? ntiles : 256;
     hipStream_t s = (hipStream_t)stream;
-#define CVK_ABL(A) case A: hipLaunchKernelGGL((k_conv3x3_wino4f<false, A>), dim3(grid), dim3(512), 0, s, x, Uf, bias, y, nullptr, nullptr, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, FBnRed{nullptr, nullptr, nullptr, nullptr, nullptr}, FSplit{nullptr, nullptr, CvkSplitTab{}, CvkSplitTab{}}, FVpl{nullptr, 0, 0}); break;
+#define CVK_ABL(A) case A: hipLaunchKernelGGL((k_conv3x3_wino4f<false, A>), dim3(grid), dim3(512), 0, s, x, Uf, bias, y, nullptr, nullptr, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, FBnRed{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr}, FSplit{nullptr, nullptr, CvkSplitTab{}, CvkSplitTab{}}, FVpl{nullptr, 0, 0}); break;
     switch (abl) {
         CVK_ABL(0) CVK_ABL(1) CVK_ABL(2) CVK_ABL(3) CVK_ABL(4) CVK_ABL(7) CVK_ABL(8) CVK_ABL(9) CVK_ABL(11) CVK_ABL(15) CVK_ABL(16) CVK_ABL(24) CVK_ABL(31)
         default: return -1;
@@ -960,7 +982,7 @@ extern "C" int cvk_conv3x3_wino4h_ablate(const float* x, const void* Uh, const f
     const int grid = ntiles < 256 ? ntiles : 256;
     hipStream_t s = (hipStream_t)stream;
     const FSplit sp = {(const unsigned*)amax_x, (const unsigned*)amax_w, cvk_split_tab(4, CVK_SPLIT_KIND_B), cvk_split_tab(4, CVK_SPLIT_KIND_G)};
-#define CVK_ABLH(A) case A: hipLaunchKernelGGL((k_conv3x3_wino4f<false, A, false, true>), dim3(grid), dim3(512), 0, s, x, (const float*)Uh, bias, y, nullptr, nullptr, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, FBnRed{nullptr, nullptr, nullptr, nullptr, nullptr}, sp, FVpl{nullptr, 0, 0}); break;
+#define CVK_ABLH(A) case A: hipLaunchKernelGGL((k_conv3x3_wino4f<false, A, false, true>), dim3(grid), dim3(512), 0, s, x, (const float*)Uh, bias, y, nullptr, nullptr, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, FBnRed{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr}, sp, FVpl{nullptr, 0, 0}); break;
     switch (abl) {
         CVK_ABLH(0) CVK_ABLH(1) CVK_ABLH(2) CVK_ABLH(4) CVK_ABLH(8) CVK_ABLH(9) CVK_ABLH(11) CVK_ABLH(15) CVK_ABLH(16) CVK_ABLH(31) CVK_ABLH(32) CVK_ABLH(33) CVK_ABLH(64) CVK_ABLH(65)
         default: return -1;
