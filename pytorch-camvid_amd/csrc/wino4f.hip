@@ -229,9 +229,16 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
     const int xcd = blockIdx.x % nx, wi = blockIdx.x / nx;
     const int ng = G / nx + (xcd < G % nx ? 1 : 0);                      // workgroups on this XCD (round-robin dispatch)
     const int xbeg = (int)((long)xcd * ntiles / nx), xend = (int)((long)(xcd + 1) * ntiles / nx);
-    const int tbeg = xbeg + wi, tend = xend, tstride = ng;
-    if (tbeg >= tend) return;
-    const int ntw = (tend - tbeg + tstride - 1) / tstride;               // tiles of this workgroup
+    // Round 6: with several n-tiles per m-tile (tile = m-tile * tilesN + n-tile) and an even workgroup count per XCD the plain walk first + i + k ng
+    // gave every workgroup ONE n-tile parity for the whole launch — and work that only some n-tiles carry (the V-plane stores of n-tile 0, the
+    // BatchNorm sums of a concat half) landed on half of the workgroups.  The walk is rotated per round: the k-th tile of workgroup i is
+    // first + k ng + (i + k) mod ng — still one band of ng consecutive tiles per round and XCD (the L2 argument above), every tile exactly once.
+    const int rot = tilesN > 1 ? 1 : 0;
+    const int span = xend - xbeg, kfull = span / ng, krem = span - kfull * ng;
+    auto tile_at = [&](int k) { return xbeg + k * ng + (wi + k * rot) % ng; };
+    const int ntw = kfull + (((wi + kfull * rot) % ng) < krem ? 1 : 0);     // tiles of this workgroup
+    if (ntw <= 0) return;
+    const int tbeg = tile_at(0);
     const int nS = 3 * Cin / F_BK;                                       // K slices per tile
     const int total = ntw * nS;
     // H2: scale of V_xi and the exact inverse of the product's scale, per transform index (wave-uniform)
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
     };
 
     // ---- loader state (uniform): next slice whose pixels are issued into the register stage ----
-    int ltile = tbeg, lr = 0, lcib = 0, lleft = total;
+    int ltile = tbeg, lk = 0, lr = 0, lcib = 0, lleft = total;
     f32x4 d[2][6];        // two register stages: a slice's pixels are in flight for almost two K steps
     auto load_A = [&](int set, int j) {
         const __amdgpu_buffer_rsrc_t xs = (lleft > 0 && !(ABL & 1)) ? xr : null_rsrc;   // past the last slice: zeros, no memory access
@@ -312,11 +319,12 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
         lr += w1;
         const int w2 = lr == 3;
         lr = w2 ? 0 : lr;
-        ltile += w2 ? tstride : 0;
+        lk += w2;
+        ltile = w2 ? tile_at(lk) : ltile;
     };
     auto issue_A = [&](int set) {
         if (lcib == 0) {       // the slice opens a new kernel row (or tile)
-            if (lr == 0 && ltile < tend) set_tile(ltile);
+            if (lr == 0 && lk < ntw) set_tile(ltile);
             regroup(lr);
         }
 #pragma unroll
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
     };
     // VPL: the slice being staged (two behind the loader: the loader's tile is still the staged slice's tile while kernel row 1 is staged,
     // Cin >= 32) — kernel row, channel offset, n-tile; and the store of V_x to sub-plane (x, channel slice)
-    int st_r = 0, st_cib = F_BK, st_tn = tbeg % tilesN;
+    int st_r = 0, st_cib = F_BK, st_k = 0, st_tn = tbeg % tilesN;
     // ONE resource over the six planes (< 4 GiB: host check); the (xi, slice) sub-plane travels in the store's scalar offset.  gfx9 range
     // check of a raw buffer: dropped if vgpr_offset >= num_records - sgpr_offset — the scalar offset COUNTS (a first version with num_records =
     // one sub-plane wrote sub-plane (0, 0) only), so num_records is the whole allocation and VPO_NONE lies beyond any of it.
@@ -378,7 +386,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
         st_r += w1;
         const int w2 = st_r == 3;
         st_r = w2 ? 0 : st_r;
-        st_tn = w2 ? (st_tn + tstride) % tilesN : st_tn;
+        st_k += w2;
+        st_tn = w2 ? tile_at(st_k) % tilesN : st_tn;
     };
     auto store_V = [&](int x) {
         if (!VPL) return;
@@ -439,7 +448,7 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
         for (int x = 0; x < 6; ++x) { if (H2) split_A(stage, x); else write_A(stage, x); }
     };
     // ---- filter slices by LDS-DMA: slice (bslice of tile btile) -> B region of a stage; 3 pieces of 1 KiB per wave ----
-    int btn = tbeg % tilesN, bslice = 0, bleft = total;       // n-tile of the tile whose filter slices are being copied
+    int btn = tbeg % tilesN, bk = 0, bslice = 0, bleft = total;       // n-tile of the tile whose filter slices are being copied
     const unsigned bvoff = (unsigned)(wave * 3 * 1024 + lane * 16);
     const char* bsrc = nullptr;
     auto dma_B_begin = [&]() {
@@ -448,7 +457,8 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
         if (--bleft > 0) {
             const int w = ++bslice == nS;
             bslice = w ? 0 : bslice;
-            btn = w ? (btn + tstride) % tilesN : btn;
+            bk += w;
+            btn = w ? tile_at(bk) % tilesN : btn;
         }
     };
     auto dma_B_piece = [&](unsigned stage_addr, int q) {
@@ -687,7 +697,7 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
         const bool VST = VPL && st_r == 1 && st_tn == 0;
         if (VPL) vso = (unsigned)(st_cib >> 4) * vsub;
         if (lcib == 0) {       /* the slice issued in this step (g + 3) opens a new kernel row (or tile) */
-            if (lr == 0 && ltile < tend) set_tile(ltile);
+            if (lr == 0 && lk < ntw) set_tile(ltile);
             regroup(lr);
         }
         dma_B_begin();
@@ -736,7 +746,7 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
     auto step_h = [&](auto par_, const char* cur, char* nxt, unsigned nxt_addr) {
         constexpr int SET = 1 - decltype(par_)::value;
         if (lcib == 0) {
-            if (lr == 0 && ltile < tend) set_tile(ltile);
+            if (lr == 0 && lk < ntw) set_tile(ltile);
             regroup(lr);
         }
         dma_B_begin();
@@ -780,7 +790,8 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
     };
     // nS is even (Cin % 32 == 0, checked by the host): every tile starts in stage 0 and the step pair below is the only copy
     // of the K step in the code (per phase); the epilogue's global stores count in vmcnt and retire under the next tile's first step
-    for (int tile = tbeg; tile < tend; tile += tstride) {
+    for (int tk = 0; tk < ntw; ++tk) {
+        const int tile = tile_at(tk);
         for (int ks = 0; ks < nS; ks += 2) {
             if (H2) {
                 step_h(std::integral_constant<int, 0>{}, buf0, buf1, smem_addr + F_STAGE);
