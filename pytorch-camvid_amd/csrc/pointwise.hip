@@ -471,6 +471,82 @@ __global__ __launch_bounds__(256) void k_bilinear_bwd(const float* __restrict__ 
 }
 
 
+// Round 6: the same gather, SEPARABLE and walked down the image.  x2 bilinear upsampling is  out = Ry x Rx^T  with two taps per output row / column, so
+// dx = Ry^T (dout Rx).  A thread owns one input column xi (4 channels) of a strip of input rows and walks the output rows that feed the strip: per output
+// row it forms h = sum_kx wx[kx] dout[yo][2 xi - 2 + kx] (the <= 4 columns with a non-zero weight) and adds l0 h to input row i0(yo), l1 h to row
+// i0(yo) + 1 — two running accumulators, a row is written when the walk leaves it.  Loads per input pixel: 2 output rows x <= 4 instead of <= 4 x 4
+// (every output pixel is read by two threads instead of four: half the L1 / L2 traffic of k_bilinear_bwd, which ran at 3.9 TB/s of HBM traffic with
+// no redundant HBM bytes).  Strips overlap by the five output rows of their borders.  Same taps (make_tap = ATen's source index), another summation order.
+template <int V>
+__global__ __launch_bounds__(256) void k_bilinear_bwd_walk(const float* __restrict__ dout, float* __restrict__ dx, int H, int W, int C,
+                                                          float sy, float sx, RowDiv dcv, int gx, RowDiv dgx, int RS, int nstrips) {
+    typedef typename VT_<V>::T VT;
+    const int Ho = 2 * H, Wo = 2 * W, cvn = C / V;
+    const unsigned lid = (unsigned)cvk_xcd_remap(blockIdx.x, gridDim.x);      // (image, strip) major, column chunk minor: neighbouring strips share an L2
+    const unsigned srow = dgx.div(lid), bx = lid - srow * gx;
+    const int n = (int)(srow / (unsigned)nstrips), st = (int)(srow - (unsigned)n * nstrips);
+    const unsigned idx = bx * 256 + threadIdx.x;
+    if (idx >= (unsigned)(W * cvn)) return;
+    const int xi = (int)dcv.div(idx), cv = (int)idx - xi * cvn;
+    const int r0 = st * RS, r1 = min(H, r0 + RS);
+    float wx[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int xo = 2 * xi - 2 + k;
+        wx[k] = 0.f;
+        if ((unsigned)xo < (unsigned)Wo) {
+            const Tap t = make_tap(xo, sx, W);
+            wx[k] = (t.i0 == xi ? t.l0 : 0.f) + (t.i1 == xi ? t.l1 : 0.f);
+        }
+    }
+    const float* b = dout + ((long)n * Ho * Wo) * C + cv * V;
+    float* o = dx + ((long)n * H * W) * C + (long)idx * V;
+    const int y_beg = max(0, 2 * r0 - 2), y_end = min(Ho - 1, 2 * (r1 - 1) + 3);
+    VT a0, a1;
+#pragma unroll
+    for (int j = 0; j < V; ++j) { el<V>(a0, j) = 0.f; el<V>(a1, j) = 0.f; }
+    int cur = make_tap(y_beg, sy, H).i0;                  // input row of a0 (a1: cur + 1)
+    auto hrow = [&](int yo) {
+        VT h;
+#pragma unroll
+        for (int j = 0; j < V; ++j) el<V>(h, j) = 0.f;
+        const float* p = b + ((long)yo * Wo + (2 * xi - 2)) * C;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (wx[k] == 0.f) continue;
+            VT g = *reinterpret_cast<const VT*>(p + (long)k * C);
+#pragma unroll
+            for (int j = 0; j < V; ++j) el<V>(h, j) += wx[k] * el<V>(g, j);
+        }
+        return h;
+    };
+    // two output rows per iteration: their loads are issued together
+    for (int yo = y_beg; yo <= y_end; yo += 2) {
+        const bool two = yo + 1 <= y_end;
+        VT h0 = hrow(yo);
+        VT h1 = h0;
+        if (two) h1 = hrow(yo + 1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            const Tap t = make_tap(yo + u, sy, H);          // uniform
+            VT h = u == 0 ? h0 : h1;
+            while (cur < t.i0) {                            // the walk leaves row cur: it is complete
+                if (cur >= r0 && cur < r1) *reinterpret_cast<VT*>(o + (long)cur * W * C) = a0;
+                a0 = a1;
+#pragma unroll
+                for (int j = 0; j < V; ++j) el<V>(a1, j) = 0.f;
+                ++cur;
+            }
+            const float w1 = t.i1 > t.i0 ? t.l1 : 0.f, w0 = t.i1 > t.i0 ? t.l0 : t.l0 + t.l1;      // clamped at the last row: both taps are row i0
+#pragma unroll
+            for (int j = 0; j < V; ++j) { el<V>(a0, j) += w0 * el<V>(h, j); el<V>(a1, j) += w1 * el<V>(h, j); }
+        }
+    }
+    if (cur >= r0 && cur < r1) *reinterpret_cast<VT*>(o + (long)cur * W * C) = a0;
+    if (cur + 1 >= r0 && cur + 1 < r1) *reinterpret_cast<VT*>(o + (long)(cur + 1) * W * C) = a1;
+}
+
 inline bool v4ok(int C, const void* a, const void* b) { return C % 4 == 0 && cvk_aligned16(a) && cvk_aligned16(b); }
 inline bool view4(const cvk_view& v) { return cvk_aligned16(v.ptr) && ((v.sN | v.sY | v.sX) & 3) == 0; }
 
@@ -613,6 +689,20 @@ extern "C" int cvk_bilinear_up2_bwd(const float* dout, float* dx, int N, int H, 
     const bool v4 = v4ok(C, dout, dx);
     const int gx = cvk_cdiv((long)W * (v4 ? C / 4 : C), 256);
     CVK_CHECK_ARG((long)gx * H * N < (1L << 31) - 8, "cvk_bilinear_up2_bwd: too many workgroups");
+    if (v4 && H >= 2) {
+        // strips: enough threads to fill the chip, at least 4 input rows each (the five halo rows are re-read per strip).  Four launches of the headline
+        // step, interleaved builds on one box: one input row per workgroup row (k_bilinear_bwd) 0.433 ms; the walk with >= 200k / 400k / 800k threads
+        // 0.448 / 0.390 / 0.419 ms.  (The same walk for the bf16 tensors of configs[3] measured SLOWER, 0.545 against 0.49 ms: not taken there.)
+        const long cols = (long)N * W * (C / 4);
+        long want = (400000 + cols - 1) / cols;
+        int RS = (int)(H / (want < 1 ? 1 : want));
+        RS = RS < 4 ? 4 : RS;
+        RS = RS > H ? H : RS;
+        const int nstrips = cvk_cdiv(H, RS);
+        const dim3 gridw((unsigned)((long)gx * nstrips * N));
+        hipLaunchKernelGGL(k_bilinear_bwd_walk<4>, gridw, dim3(256), 0, s, dout, dx, H, W, C, sy, sx, RowDiv(C / 4), gx, RowDiv(gx), RS, nstrips);
+        CVK_LAUNCH_RETURN("cvk_bilinear_up2_bwd");
+    }
     const dim3 grid((unsigned)((long)gx * H * N));
     if (v4)
         hipLaunchKernelGGL(k_bilinear_bwd<4>, grid, dim3(256), 0, s, dout, dx, H, W, C, sy, sx, RowDiv(C / 4), gx, RowDiv(gx));
