@@ -66,6 +66,7 @@ def parse():
                          "world-size-1 RCCL group (real all-reduce launches, CVK_DP_RESERVE_CUS CUs left free), eager and as one captured "
                          "graph; reported under `dp_overhead`, never `value`")
     ap.add_argument("--no-dp-overhead", action="store_true", help="skip the `dp_overhead` leg")
+    ap.add_argument("--dp-overhead-child", action="store_true", help=argparse.SUPPRESS)     # internal: the leg's own process (see dp_overhead_in_child)
     ap.add_argument("--w2d-split", type=int, nargs="?", const=3, default=0, choices=[0, 2, 3],
                     help="OPT-IN path (never the default, named in `dtype`): the 2-D Winograd GEMMs of the channel-heavy layers on the 16-bit matrix "
                          "pipe with split fp32 operands — 3 (default of the flag): three bf16 terms, six cross-products; 2: two fp16 terms scaled by "
@@ -373,6 +374,50 @@ def dp_overhead_leg(A, dev, net, lossf, leg, a, plain_step):
     return out
 
 
+def dp_overhead_in_child(a):
+    """Run the dp_overhead leg in a CHILD process and return its object.  The leg creates an RCCL communicator and captures a HIP graph with collectives
+    inside: ProcessGroupNCCL's watchdog thread can then abort the process ("operation not permitted on an event last recorded in a capturing stream",
+    seen once in six GPU suite runs in round 6; an intermittent SIGSEGV at interpreter exit in the same configuration).  That is torch's thread, not this
+    path — and it must not be able to take the headline measurement with it: the parent never creates a process group at N = 1."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--dp-overhead-child", "--steps", str(a.steps), "--warmup", str(min(a.warmup, 3)),
+           "--model", a.model, "--batch", str(a.batch), "--height", str(a.height), "--width", str(a.width), "--precision", a.precision]
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    last = None
+    for attempt in (1, 2):              # one retry: the abort is a race inside torch
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        except subprocess.TimeoutExpired:
+            last = {"error": "the dp_overhead child process timed out"}
+            continue
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and lines:
+            out = json.loads(lines[-1])
+            if attempt > 1:
+                out["attempts"] = attempt
+            return out
+        last = {"error": f"dp_overhead child exited with {r.returncode}: {r.stderr.strip().splitlines()[-1][:200] if r.stderr.strip() else ''}"}
+    return last
+
+
+def dp_overhead_child_main(a):
+    """The child of dp_overhead_in_child: the headline network, the leg, ONE JSON object on stdout."""
+    real_stdout = _claim_stdout()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    import pytorch_camvid_amd as A
+    leg = run_leg(A, dev, a.model, a.batch, a.height, a.width, a.precision, 3, a.warmup, False, want_model=True)
+    out = dp_overhead_leg(A, dev, leg["net"], leg["lossf"], leg, a, leg["step"])
+    real_stdout.write(json.dumps(out) + "\n")
+    real_stdout.flush()
+    import atexit
+    atexit._run_exitfuncs()
+    sys.stderr.flush()
+    os._exit(0)
+
+
 def dp_identity(dev, world, rehearsal):
     """Which device each rank really runs on (all-gathered): proves N distinct GPUs took part."""
     pr = torch.cuda.get_device_properties(dev)
@@ -410,6 +455,8 @@ def main():
     import faulthandler
     faulthandler.enable()               # a native crash prints the Python stack on stderr (round 6: an intermittent SIGSEGV in interpreter teardown)
     a = parse()
+    if a.dp_overhead_child:
+        return dp_overhead_child_main(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -513,10 +560,9 @@ def main():
                     "logits_vs_reference": logits_accuracy(net, leg["x"]) if (headline and rank == 0) else None}
     dp_over, dp_fail = None, False
     if world == 1 and (a.dp_overhead or headline) and not a.no_dp_overhead and not rehearsal:
-        try:
-            dp_over = dp_overhead_leg(A, dev, net, lossf, leg, a, step)
-        except Exception as e:          # the leg is extra evidence: a failure of RCCL initialisation must not cost the headline line
-            dp_over = {"error": f"{type(e).__name__}: {e}"[:300]}
+        torch.cuda.synchronize(dev)
+        dp_over = dp_overhead_in_child(a)          # its own process: RCCL + graph capture cannot take the headline down
+        if "error" in dp_over:
             print(f"bench.py: the dp_overhead leg failed: {dp_over['error']}", file=sys.stderr)
             if a.dp_overhead:           # asked for explicitly: the failure is the result
                 dp_fail = True

@@ -272,13 +272,6 @@ int cvk_conv3x3_wino4f(const float* x, const float* Uf, const float* bias, float
 int cvk_conv3x3_wino4f_bnred(const float* x, const float* Uf, float* y, int N, int H, int W, int Cin, int Cout, int ldy,
                              const float* yP, const float* scale, const float* shift, const float* mean, const float* rstd,
                              float* part, int max_workgroups, void* stream);
-/* ... when the producer block wrote only the FIRST Cp of this data-grad's Cout output channels — the upsample half of the concat gradient
- * (torch.cat([xup, skip], dim=1), /root/reference/models/unet.py:124; the consumer up_k.0 reads the whole buffer): yP [N*H*W][ldp] is that block's conv
- * output with its own row pitch, scale / shift / mean / rstd have Cp entries, part = float[2][cvk_wino4f_stat_partials(N,H,W)][Cp] for
- * cvk_colsum_finalize.  Cp % 64 == 0, Cp <= Cout; only the n-tiles of those channels pay for the sums. */
-int cvk_conv3x3_wino4f_bnred_part(const float* x, const float* Uf, float* y, int N, int H, int W, int Cin, int Cout, int ldy,
-                                  const float* yP, int ldp, int Cp, const float* scale, const float* shift, const float* mean,
-                                  const float* rstd, float* part, int max_workgroups, void* stream);
 
 /* THIN layers (csrc/thin.hip): the stem nn.Conv2d(3, 64, 3, padding=1) (/root/reference/models/unet.py:103,
  * models/segnet.py first block) and the classifier head nn.Conv2d(64, class_num, 3, padding=1) (models/unet.py:127), forward,

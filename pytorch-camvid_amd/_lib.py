@@ -60,7 +60,6 @@ SIGNATURES = {
     "cvk_wino4f_stat_partials": (c_int, [c_int, c_int, c_int]),
     "cvk_conv3x3_wino4f": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_wino4f_bnred": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
-    "cvk_conv3x3_wino4f_bnred_part": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "cvk_wino4h_weight_transform": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_wino4h": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_conv3x3_wino4h_bnred": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,

@@ -153,9 +153,7 @@ __device__ __forceinline__ void f_dma16(const void* sbase, unsigned voff, unsign
 // yP (the producer's conv output, same geometry and row stride as Y) and leaves per-m-tile partial sums in `stats`
 // ([2][P][Cout], the layout cvk_colsum_finalize reads) — the producer's reduce pass over dX and yP is not launched at all.
 struct FBnRed {
-    int ldp;              // row stride of y (round 6: the producer may cover only the first Cp of this launch's output channels — the upsample half of
-    int Cp;               // a concat gradient — so its conv output has its own pitch); Cp % 64 == 0: the n-tiles [0, Cp / 64) carry the sums
-    const float* y;       // producer's conv output [N*H*W][ldp]
+    const float* y;       // producer's conv output [N*H*W][ldy]
     const float* scale;   // gamma * rstd, beta - mean * gamma * rstd  (the forward's apply constants: the ReLU mask)
     const float* shift;
     const float* mean;
@@ -206,11 +204,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
         const bool ok = c < Cout;
         cst[c] = (bias != nullptr && ok) ? bias[c] : 0.f;
         if (BNR) {
-            const bool okp = c < bn.Cp;
-            cst[F_CMAX + c] = okp ? bn.scale[c] : 0.f;
-            cst[2 * F_CMAX + c] = okp ? bn.shift[c] : 0.f;
-            cst[3 * F_CMAX + c] = okp ? bn.mean[c] : 0.f;
-            cst[4 * F_CMAX + c] = okp ? bn.rstd[c] : 0.f;
+            cst[F_CMAX + c] = ok ? bn.scale[c] : 0.f;
+            cst[2 * F_CMAX + c] = ok ? bn.shift[c] : 0.f;
+            cst[3 * F_CMAX + c] = ok ? bn.mean[c] : 0.f;
+            cst[4 * F_CMAX + c] = ok ? bn.rstd[c] : 0.f;
         }
     }                                                                     // visible after the prologue's barrier
 
@@ -229,16 +226,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
     const int xcd = blockIdx.x % nx, wi = blockIdx.x / nx;
     const int ng = G / nx + (xcd < G % nx ? 1 : 0);                      // workgroups on this XCD (round-robin dispatch)
     const int xbeg = (int)((long)xcd * ntiles / nx), xend = (int)((long)(xcd + 1) * ntiles / nx);
-    // Round 6: with several n-tiles per m-tile (tile = m-tile * tilesN + n-tile) and an even workgroup count per XCD the plain walk first + i + k ng
-    // gave every workgroup ONE n-tile parity for the whole launch — and work that only some n-tiles carry (the V-plane stores of n-tile 0, the
-    // BatchNorm sums of a concat half) landed on half of the workgroups.  The walk is rotated per round: the k-th tile of workgroup i is
-    // first + k ng + (i + k) mod ng — still one band of ng consecutive tiles per round and XCD (the L2 argument above), every tile exactly once.
-    const int rot = tilesN > 1 ? 1 : 0;
-    const int span = xend - xbeg, kfull = span / ng, krem = span - kfull * ng;
-    auto tile_at = [&](int k) { return xbeg + k * ng + (wi + k * rot) % ng; };
-    const int ntw = kfull + (((wi + kfull * rot) % ng) < krem ? 1 : 0);     // tiles of this workgroup
-    if (ntw <= 0) return;
-    const int tbeg = tile_at(0);
+    const int tbeg = xbeg + wi, tend = xend, tstride = ng;
+    if (tbeg >= tend) return;
+    const int ntw = (tend - tbeg + tstride - 1) / tstride;               // tiles of this workgroup
     const int nS = 3 * Cin / F_BK;                                       // K slices per tile
     const int total = ntw * nS;
     // H2: scale of V_xi and the exact inverse of the product's scale, per transform index (wave-uniform)
@@ -304,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
     };
 
     // ---- loader state (uniform): next slice whose pixels are issued into the register stage ----
-    int ltile = tbeg, lk = 0, lr = 0, lcib = 0, lleft = total;
+    int ltile = tbeg, lr = 0, lcib = 0, lleft = total;
     f32x4 d[2][6];        // two register stages: a slice's pixels are in flight for almost two K steps
     auto load_A = [&](int set, int j) {
         const __amdgpu_buffer_rsrc_t xs = (lleft > 0 && !(ABL & 1)) ? xr : null_rsrc;   // past the last slice: zeros, no memory access
@@ -319,12 +309,11 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
         lr += w1;
         const int w2 = lr == 3;
         lr = w2 ? 0 : lr;
-        lk += w2;
-        ltile = w2 ? tile_at(lk) : ltile;
+        ltile += w2 ? tstride : 0;
     };
     auto issue_A = [&](int set) {
         if (lcib == 0) {       // the slice opens a new kernel row (or tile)
-            if (lr == 0 && lk < ntw) set_tile(ltile);
+            if (lr == 0 && ltile < tend) set_tile(ltile);
             regroup(lr);
         }
 #pragma unroll
@@ -370,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
     };
     // VPL: the slice being staged (two behind the loader: the loader's tile is still the staged slice's tile while kernel row 1 is staged,
     // Cin >= 32) — kernel row, channel offset, n-tile; and the store of V_x to sub-plane (x, channel slice)
-    int st_r = 0, st_cib = F_BK, st_k = 0, st_tn = tbeg % tilesN;
+    int st_r = 0, st_cib = F_BK, st_tn = tbeg % tilesN;
     // ONE resource over the six planes (< 4 GiB: host check); the (xi, slice) sub-plane travels in the store's scalar offset.  gfx9 range
     // check of a raw buffer: dropped if vgpr_offset >= num_records - sgpr_offset — the scalar offset COUNTS (a first version with num_records =
     // one sub-plane wrote sub-plane (0, 0) only), so num_records is the whole allocation and VPO_NONE lies beyond any of it.
@@ -386,8 +375,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino4f(
         st_r += w1;
         const int w2 = st_r == 3;
         st_r = w2 ? 0 : st_r;
-        st_k += w2;
-        st_tn = w2 ? tile_at(st_k) % tilesN : st_tn;
+        st_tn = w2 ? (st_tn + tstride) % tilesN : st_tn;
     };
     auto store_V = [&](int x) {
         if (!VPL) return;
@@ -448,7 +436,7 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
         for (int x = 0; x < 6; ++x) { if (H2) split_A(stage, x); else write_A(stage, x); }
     };
     // ---- filter slices by LDS-DMA: slice (bslice of tile btile) -> B region of a stage; 3 pieces of 1 KiB per wave ----
-    int btn = tbeg % tilesN, bk = 0, bslice = 0, bleft = total;       // n-tile of the tile whose filter slices are being copied
+    int btn = tbeg % tilesN, bslice = 0, bleft = total;       // n-tile of the tile whose filter slices are being copied
     const unsigned bvoff = (unsigned)(wave * 3 * 1024 + lane * 16);
     const char* bsrc = nullptr;
     auto dma_B_begin = [&]() {
@@ -457,8 +445,7 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
         if (--bleft > 0) {
             const int w = ++bslice == nS;
             bslice = w ? 0 : bslice;
-            bk += w;
-            btn = w ? tile_at(bk) % tilesN : btn;
+            btn = w ? (btn + tstride) % tilesN : btn;
         }
     };
     auto dma_B_piece = [&](unsigned stage_addr, int q) {
@@ -538,15 +525,11 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
         float s1 = 0.f, s2 = 0.f;
         __amdgpu_buffer_rsrc_t pr = null_rsrc;
         float bsc = 0.f, bsh = 0.f, bmu = 0.f;
-        // BNR: only the n-tiles of the producer's channels [0, Cp) carry the sums (uniform per tile); yP has its own row pitch
-        const bool bact = BNR && tn * F_BN < bn.Cp;
-        const unsigned lsp = BNR ? (unsigned)bn.ldp * 4u : 0u;
-        if (bact) {
-            const size_t pbytes = ((size_t)Mpix - pixb) * bn.ldp * 4;
-            pr = __builtin_amdgcn_make_buffer_rsrc((void*)(bn.y + (size_t)pixb * bn.ldp), 0,
-                                                   (int)(pbytes < 0x7FFFFFFFu ? pbytes : 0x7FFFFFFFu), 0x00020000);
+        if (BNR) {
+            pr = __builtin_amdgcn_make_buffer_rsrc((void*)(bn.y + (size_t)pixb * ldy), 0,
+                                                   (int)(ybytes < 0x7FFFFFFFu ? ybytes : 0x7FFFFFFFu), 0x00020000);
             if (CL) { bsc = cst[F_CMAX + (col & (F_CMAX - 1))]; bsh = cst[2 * F_CMAX + (col & (F_CMAX - 1))]; bmu = cst[3 * F_CMAX + (col & (F_CMAX - 1))]; }
-            else if (col < bn.Cp) { bsc = bn.scale[col]; bsh = bn.shift[col]; bmu = bn.mean[col]; }
+            else if (cok) { bsc = bn.scale[col]; bsh = bn.shift[col]; bmu = bn.mean[col]; }
         }
         // g = dX where the producer's ReLU passed; accumulates sum g and sum g * (yP - mean)  (rstd multiplies once, at the end)
         auto bnacc = [&](float q, float v) {
@@ -559,7 +542,6 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
             // the bias and the statistics (its instructions take matrix time on this part); a row's byte offset is uniform and
             // travels in the scalar offset of the store.
             const unsigned ob = (unsigned)((4 * (wm * 32 + 4 * lh)) * ldy + col) * 4u;
-            const unsigned obp = BNR ? (unsigned)((4 * (wm * 32 + 4 * lh)) * bn.ldp + col) * 4u : 0u;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float m0_ = H2 ? acc[0][e] * un[0].a * un[0].b : acc[0][e], m1 = H2 ? acc[1][e] * un[1].a * un[1].b : acc[1][e],
@@ -578,15 +560,14 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
                     s1 += (y0 + y1) + (y2 + y3);
                     s2 += fmaf(y0, y0, y1 * y1) + fmaf(y2, y2, y3 * y3);
                 }
-                if (bact) {
+                if (BNR) {
                     // (hipcc keeps 16 of these loads in flight; asking for 32 up front changed nothing — every workgroup reaches
                     // its epilogue at about the same time and the burst is bandwidth-, not latency-bound: +10 % on the launch,
                     // against the whole reduce pass it replaces)
-                    const unsigned sop = (unsigned)(4 * ((e & 3) + 8 * (e >> 2))) * lsp;
-                    const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, obp, sop, 0));
-                    const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, obp, sop + lsp, 0));
-                    const float q2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, obp, sop + 2 * lsp, 0));
-                    const float q3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, obp, sop + 3 * lsp, 0));
+                    const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, ob, so, 0));
+                    const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, ob, so + ls, 0));
+                    const float q2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, ob, so + 2 * ls, 0));
+                    const float q3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, ob, so + 3 * ls, 0));
                     bnacc(q0, y0 + bs); bnacc(q1, y1 + bs); bnacc(q2, y2 + bs); bnacc(q3, y3 + bs);
                 }
             }
@@ -613,18 +594,17 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
                     s1 += (z0 + z1) + (z2 + z3);
                     s2 += fmaf(z0, z0, z1 * z1) + fmaf(z2, z2, z3 * z3);
                 }
-                if (bact) {     // an out-of-range load returns 0; the value beside it is masked by nv as well
-                    const unsigned op = (unsigned)((q * W + 4 * xt - pixb) * bn.ldp + col) * 4u;
-                    const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 0, op), 0, 0));
-                    const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 1, op), lsp, 0));
-                    const float q2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 2, op), 2 * lsp, 0));
-                    const float q3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 3, op), 3 * lsp, 0));
+                if (BNR) {      // an out-of-range load returns 0; the value beside it is masked by nv as well
+                    const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 0, o), 0, 0));
+                    const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 1, o), ls, 0));
+                    const float q2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 2, o), 2 * ls, 0));
+                    const float q3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, oob_unless(nv > 3, o), 3 * ls, 0));
                     bnacc(q0, nv > 0 ? y0 + bs : 0.f); bnacc(q1, nv > 1 ? y1 + bs : 0.f);
                     bnacc(q2, nv > 2 ? y2 + bs : 0.f); bnacc(q3, nv > 3 ? y3 + bs : 0.f);
                 }
             }
         }
-        if (bact) {
+        if (BNR) {
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (lh == 0) {
@@ -634,11 +614,11 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
             __syncthreads();
             if (tid < 64) {
                 const int c = tn * F_BN + tid;
-                if (c < bn.Cp) {
+                if (c < Cout) {
                     const float a = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
                     const float b = (red[256 + tid] + red[320 + tid]) + (red[384 + tid] + red[448 + tid]);
-                    stats[(size_t)mt * bn.Cp + c] = a;
-                    stats[(size_t)(P + mt) * bn.Cp + c] = b * (CL ? cst[4 * F_CMAX + c] : bn.rstd[c]);
+                    stats[(size_t)mt * Cout + c] = a;
+                    stats[(size_t)(P + mt) * Cout + c] = b * (CL ? cst[4 * F_CMAX + c] : bn.rstd[c]);
                 }
             }
         }
@@ -697,7 +677,7 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
         const bool VST = VPL && st_r == 1 && st_tn == 0;
         if (VPL) vso = (unsigned)(st_cib >> 4) * vsub;
         if (lcib == 0) {       /* the slice issued in this step (g + 3) opens a new kernel row (or tile) */
-            if (lr == 0 && lk < ntw) set_tile(ltile);
+            if (lr == 0 && ltile < tend) set_tile(ltile);
             regroup(lr);
         }
         dma_B_begin();
@@ -746,7 +726,7 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
     auto step_h = [&](auto par_, const char* cur, char* nxt, unsigned nxt_addr) {
         constexpr int SET = 1 - decltype(par_)::value;
         if (lcib == 0) {
-            if (lr == 0 && lk < ntw) set_tile(ltile);
+            if (lr == 0 && ltile < tend) set_tile(ltile);
             regroup(lr);
         }
         dma_B_begin();
@@ -790,8 +770,7 @@ asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(tv[x]), "v"(
     };
     // nS is even (Cin % 32 == 0, checked by the host): every tile starts in stage 0 and the step pair below is the only copy
     // of the K step in the code (per phase); the epilogue's global stores count in vmcnt and retire under the next tile's first step
-    for (int tk = 0; tk < ntw; ++tk) {
-        const int tile = tile_at(tk);
+    for (int tile = tbeg; tile < tend; tile += tstride) {
         for (int ks = 0; ks < nS; ks += 2) {
             if (H2) {
                 step_h(std::integral_constant<int, 0>{}, buf0, buf1, smem_addr + F_STAGE);
@@ -875,7 +854,7 @@ static int wino4f_launch(const char* who, const float* x, const float* Uf, const
     const int grid = ntiles < wgs ? ntiles : wgs;
     CVK_CHECK_ARG((F_BM * 4 + 3L * W + 8) * Cin * 4 < (1L << 31), "%s: a tile's input window exceeds the 2 GiB buffer-addressing limit", who);
     hipStream_t s = (hipStream_t)stream;
-    const FBnRed none = {0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const FBnRed none = {nullptr, nullptr, nullptr, nullptr, nullptr};
     const bool h2 = amax_x != nullptr;
     CVK_CHECK_ARG((amax_x == nullptr) == (amax_w == nullptr), "%s: the two amax blocks go together", who);
     FSplit sp = {(const unsigned*)amax_x, (const unsigned*)amax_w, CvkSplitTab{}, CvkSplitTab{}};
@@ -927,20 +906,8 @@ extern "C" int cvk_conv3x3_wino4f_bnred(const float* x, const float* Uf, float* 
                                         const float* yP, const float* scale, const float* shift, const float* mean,
                                         const float* rstd, float* part, int max_workgroups, void* stream) {
     CVK_CHECK_ARG(yP && scale && shift && mean && rstd && part, "cvk_conv3x3_wino4f_bnred: null pointer");
-    const FBnRed bn = {ldy, Cout, yP, scale, shift, mean, rstd};
+    const FBnRed bn = {yP, scale, shift, mean, rstd};
     return wino4f_launch("cvk_conv3x3_wino4f_bnred", x, Uf, nullptr, y, part, nullptr, &bn, N, H, W, Cin, Cout, ldy, max_workgroups, stream);
-}
-
-// ... when the producer block wrote only the FIRST Cp of this data-grad's Cout output channels (the upsample half of a concat buffer,
-// models/unet.py:124: torch.cat([xup, skip])): yP [N*H*W][ldp] is its conv output with its own row pitch, scale / shift / mean / rstd have Cp entries,
-// part = float[2][cvk_wino4f_stat_partials][Cp].  Cp % 64 == 0, Cp <= Cout.  y (all Cout channels) is bitwise cvk_conv3x3_wino4f's.
-extern "C" int cvk_conv3x3_wino4f_bnred_part(const float* x, const float* Uf, float* y, int N, int H, int W, int Cin, int Cout, int ldy,
-                                             const float* yP, int ldp, int Cp, const float* scale, const float* shift, const float* mean,
-                                             const float* rstd, float* part, int max_workgroups, void* stream) {
-    CVK_CHECK_ARG(yP && scale && shift && mean && rstd && part, "cvk_conv3x3_wino4f_bnred_part: null pointer");
-    CVK_CHECK_ARG(Cp > 0 && Cp % F_BN == 0 && Cp <= Cout && ldp >= Cp, "cvk_conv3x3_wino4f_bnred_part: Cp=%d must be a multiple of 64 within Cout=%d, ldp >= Cp", Cp, Cout);
-    const FBnRed bn = {ldp, Cp, yP, scale, shift, mean, rstd};
-    return wino4f_launch("cvk_conv3x3_wino4f_bnred_part", x, Uf, nullptr, y, part, nullptr, &bn, N, H, W, Cin, Cout, ldy, max_workgroups, stream);
 }
 
 // ---- the opt-in fp16 split-operand form (csrc/split_fmt.h; runner.w2d_split = 2): same contracts, plus the amax blocks of x and of the filter ----
@@ -965,7 +932,7 @@ extern "C" int cvk_conv3x3_wino4h_bnred(const float* x, const void* Uh, float* y
                                         int Cout, int ldy, const float* yP, const float* scale, const float* shift, const float* mean,
                                         const float* rstd, float* part, int max_workgroups, void* stream) {
     CVK_CHECK_ARG(yP && scale && shift && mean && rstd && part && amax_x && amax_w, "cvk_conv3x3_wino4h_bnred: null pointer");
-    const FBnRed bn = {ldy, Cout, yP, scale, shift, mean, rstd};
+    const FBnRed bn = {yP, scale, shift, mean, rstd};
     return wino4f_launch("cvk_conv3x3_wino4h_bnred", x, (const float*)Uh, nullptr, y, part, nullptr, &bn, N, H, W, Cin, Cout, ldy, max_workgroups, stream,
                          amax_x, amax_w);
 }
@@ -977,7 +944,7 @@ extern "C" int cvk_conv3x3_wino4f_ablate(const float* x, const float* Uf, const 
     const int tilesN = f_tiles_n(Cout), tilesM = cvk_cdiv(Mt, F_BM), ntiles = tilesM * tilesN;
     const int grid = ntiles < 256 ? ntiles : 256;
     hipStream_t s = (hipStream_t)stream;
-#define CVK_ABL(A) case A: hipLaunchKernelGGL((k_conv3x3_wino4f<false, A>), dim3(grid), dim3(512), 0, s, x, Uf, bias, y, nullptr, nullptr, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, FBnRed{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr}, FSplit{nullptr, nullptr, CvkSplitTab{}, CvkSplitTab{}}, FVpl{nullptr, 0, 0}); break;
+#define CVK_ABL(A) case A: hipLaunchKernelGGL((k_conv3x3_wino4f<false, A>), dim3(grid), dim3(512), 0, s, x, Uf, bias, y, nullptr, nullptr, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, FBnRed{nullptr, nullptr, nullptr, nullptr, nullptr}, FSplit{nullptr, nullptr, CvkSplitTab{}, CvkSplitTab{}}, FVpl{nullptr, 0, 0}); break;
     switch (abl) {
         CVK_ABL(0) CVK_ABL(1) CVK_ABL(2) CVK_ABL(3) CVK_ABL(4) CVK_ABL(7) CVK_ABL(8) CVK_ABL(9) CVK_ABL(11) CVK_ABL(15) CVK_ABL(16) CVK_ABL(24) CVK_ABL(31)
         default: return -1;
@@ -993,7 +960,7 @@ extern "C" int cvk_conv3x3_wino4h_ablate(const float* x, const void* Uh, const f
     const int grid = ntiles < 256 ? ntiles : 256;
     hipStream_t s = (hipStream_t)stream;
     const FSplit sp = {(const unsigned*)amax_x, (const unsigned*)amax_w, cvk_split_tab(4, CVK_SPLIT_KIND_B), cvk_split_tab(4, CVK_SPLIT_KIND_G)};
-#define CVK_ABLH(A) case A: hipLaunchKernelGGL((k_conv3x3_wino4f<false, A, false, true>), dim3(grid), dim3(512), 0, s, x, (const float*)Uh, bias, y, nullptr, nullptr, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, FBnRed{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr}, sp, FVpl{nullptr, 0, 0}); break;
+#define CVK_ABLH(A) case A: hipLaunchKernelGGL((k_conv3x3_wino4f<false, A, false, true>), dim3(grid), dim3(512), 0, s, x, (const float*)Uh, bias, y, nullptr, nullptr, Mt, H, W, Wt, Cin, Cout, ldy, tilesN, ntiles, Mpix, tilesM, FBnRed{nullptr, nullptr, nullptr, nullptr, nullptr}, sp, FVpl{nullptr, 0, 0}); break;
     switch (abl) {
         CVK_ABLH(0) CVK_ABLH(1) CVK_ABLH(2) CVK_ABLH(4) CVK_ABLH(8) CVK_ABLH(9) CVK_ABLH(11) CVK_ABLH(15) CVK_ABLH(16) CVK_ABLH(31) CVK_ABLH(32) CVK_ABLH(33) CVK_ABLH(64) CVK_ABLH(65)
         default: return -1;

@@ -422,14 +422,6 @@ def wino_conv(R, lib, s, x, w, bias, y, sp, N, H, W, k_ch, cout, ldy, flops, wha
         Pf = lib.cvk_wino4f_stat_partials(N, H, W)
         cnt = sp + 4 * 2 * Pf * cout if sp is not None else None
         if bnred is not None and sp is None and bias is None and ldy == cout and R.bnred_fuse:
-            if len(bnred) > 6:          # (.., ldp, Cp): the producer wrote only channels [0, Cp) of this data-grad's output (concat buffer)
-                ldp, Cp = bnred[6], bnred[7]
-                bpart = _empty(2 * Pf * Cp, x.device)
-                _timed(R, "k_conv3x3_wino4f<bnred>", flops, lambda: check(
-                    lib.cvk_conv3x3_wino4f_bnred_part(x.data_ptr(), Uf.data_ptr(), y.data_ptr(), N, H, W, k_ch, cout, ldy, bnred[0], ldp, Cp, *bnred[1:5],
-                                                      bpart.data_ptr(), R.launch_wgs(), s), "cvk_conv3x3_wino4f_bnred_part"), executed=0.5 * flops)
-                bnred[5].append((bpart, Pf))
-                return None
             bpart = _empty(2 * Pf * cout, x.device)
             _timed(R, "k_conv3x3_wino4f<bnred>", flops, lambda: check(
                 lib.cvk_conv3x3_wino4f_bnred(x.data_ptr(), Uf.data_ptr(), y.data_ptr(), N, H, W, k_ch, cout, ldy, *bnred[:5],
@@ -906,16 +898,6 @@ class ConvBnRelu(Op):
                     py, pbnp = st.saved[prod.idx][0], st.saved[prod.idx][1]
                     bnred = (py.data_ptr(), pbnp.data_ptr() + 8 * src.ld, pbnp.data_ptr() + 12 * src.ld, pbnp.data_ptr(),
                              pbnp.data_ptr() + 4 * src.ld, [])
-                elif prod is None and st.training and R.concat_bnred and split_fmt(R) == 0:
-                    # round 6: the block that wrote the FIRST channels of a concat buffer (the upsample conv) when this conv is the only reader of them:
-                    # the data-grad's n-tiles of those channels carry that block's sums (cvk_conv3x3_wino4f_bnred_part)
-                    prod = st.plan.head_producer(src, self.idx)
-                    if prod is not None and prod.idx in st.saved and prod.idx not in st.bnred and pad4(prod.cout) == prod.cout and prod.cout % 64 == 0:
-                        py, pbnp = st.saved[prod.idx][0], st.saved[prod.idx][1]
-                        lp = prod.cout
-                        bnred = (py.data_ptr(), pbnp.data_ptr() + 8 * lp, pbnp.data_ptr() + 12 * lp, pbnp.data_ptr(), pbnp.data_ptr() + 4 * lp, [], lp, lp)
-                    else:
-                        prod = None
                 wino_conv(R, lib, s, dy, packed, None, dX, None, N, H, W, ldy, src.ld, src.ld, 18.0 * M * C * self.cin, "(dgrad)",
                           dgrad_of=(wc, C, self.cin), wsrc=w, ck=(self.pslot, "d"), bnred=bnred,
                           v_pre=(both2[0], both2[2]) if both2 is not None else None, split=split3, x_amax=am_dy_fused,
@@ -1395,27 +1377,6 @@ class Plan:
                 return op.idx
         return -1
 
-    def head_producer(self, buf, reader_idx):
-        """The ConvBnRelu block that wrote channels [0, C') of `buf` over the whole frame (the upsample conv of a UNet concat buffer) when the op
-        `reader_idx` is the ONLY reader of those channels; its BatchNorm-backward sums can then ride on that reader's data-grad."""
-        op = self._producer.get((buf.id, 0))
-        if op is None or not isinstance(op, ConvBnRelu) or op.dst.is_full or op.dst.buf is not buf or self.output is None or self.output.buf is buf:
-            return None
-        v = op.dst
-        if (v.c0, v.y0, v.x0, v.H, v.W) != (0, 0, 0, buf.H, buf.W):
-            return None
-        readers = []
-        for o in self.ops[op.idx + 1:]:
-            s = getattr(o, "src", None)
-            if s is None:
-                continue
-            if isinstance(s, BufView):
-                if s.buf is buf and s.c0 < v.c0 + v.C and v.c0 < s.c0 + s.C:
-                    readers.append(o.idx)
-            elif s is buf:
-                readers.append(o.idx)
-        return op if readers == [reader_idx] else None
-
     def sole_producer(self, buf):
         """The ConvBnRelu block whose output is exactly `buf` when `buf` has ONE reader — that reader's data-grad is then
         the complete dL/d(activation) of the block, and may carry the block's BatchNorm-backward sums (csrc/wino4f.hip BNR)."""
@@ -1531,9 +1492,6 @@ class Runner:
         self.w2both = os.environ.get("CVK_W2D_DY_BOTH", "1") != "0"   # one launch transforms dy for the data-grad and the weight-grad
         self.bnred_fuse = os.environ.get("CVK_BNRED_FUSE", "1") != "0"   # BN-backward sums in the fused data-grad's epilogue
         self.pool_bnred = os.environ.get("CVK_POOL_BNRED", "1") != "0"   # ... and in the max-pool backward pass behind a conv block (round 6)
-        # ... and for the upsample half of a concat gradient (round 6; OFF: measured slower on the step — the n-tiles of one parity always land on
-        # the same workgroups of the persistent walk, so half of them pay every BatchNorm-sum epilogue: passes -0.15 ms, data-grad +0.28 ms)
-        self.concat_bnred = os.environ.get("CVK_CONCAT_BNRED", "0") != "0"
         self.wino2d = WINO2D_DEFAULT
         # OPT-IN split-operand modes (cvk.set_split_operands): the matrix products of the fp32 convolutions on the 16-bit
         # matrix pipe with split fp32 operands (csrc/split_fmt.h).  Not the product default; bench.py names the mode in `dtype` when it is on.

@@ -56,6 +56,12 @@ class GraphedStep:
         # the check to the capturing thread — what torch prescribes for capturing collectives.
         import torch.distributed as dist
         mode = "thread_local" if (R.grad_sync is not None or (dist.is_available() and dist.is_initialized())) else "global"
+        if mode == "thread_local":
+            # ... and the watchdog's list should be EMPTY when the capture begins: round 6 saw it die once in six suite runs with "operation not
+            # permitted on an event last recorded in a capturing stream" (hipErrorCapturedEvent from WorkNCCL::isCompleted).  Every eager
+            # collective has finished (synchronize above); three watchdog periods let the thread retire them before the first captured one exists.
+            import time
+            time.sleep(0.35)
         with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.loss = lossf(net(self.x), self.t)
             self.loss.backward()

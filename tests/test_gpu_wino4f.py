@@ -324,46 +324,3 @@ def test_plane_gemm_reads_the_identity_planes_from_dy(N, H, W, Cin, Cout):
                                     ws.data_ptr(), wsb, s), "gemm_sm_dy")
     torch.cuda.synchronize()
     assert torch.isfinite(dw4).all() and torch.equal(dw4, dw6)
-
-
-@pytest.mark.parametrize("N,H,W,Cd,Cx,Cp", [(2, 9, 13, 64, 128, 64), (1, 16, 36, 64, 128, 64), (2, 33, 48, 128, 256, 128), (1, 5, 8, 64, 192, 64)])
-def test_fused_data_grad_leaves_the_sums_of_the_upsample_half(N, H, W, Cd, Cx, Cp):
-    """Round 6: cvk_conv3x3_wino4f_bnred_part — the data-grad of a conv that reads a concat buffer (torch.cat([xup, skip]), models/unet.py:124) writes
-    dL/d(concat) for all Cx channels; the block that produced the FIRST Cp of them (the upsample conv) gets its BatchNorm-backward sums from the
-    epilogue of exactly those n-tiles: yP has its own row pitch (Cp), the partials have Cp columns.  dx is bitwise the plain launch's, the sums match
-    fp64 over channels [0, Cp) of that dx."""
-    lib, check = _lib()
-    s = torch.cuda.current_stream().cuda_stream
-    g = torch.Generator().manual_seed(23 + Cd + Cx + W)
-    w = torch.randn(Cd, Cx, 3, 3, generator=g) * (2.0 / (9 * Cx)) ** 0.5            # forward filter of the consumer: Cx -> Cd
-    dy = torch.randn(N, H, W, Cd, generator=g).cuda()
-    yP = (torch.randn(N, H, W, Cp, generator=g) * 1.5 + 0.3).cuda()
-    gamma, beta = (torch.rand(Cp, generator=g) + 0.5).cuda(), (torch.randn(Cp, generator=g) * 0.3).cuda()
-    mean = yP.mean(dim=(0, 1, 2))
-    rstd = (yP.var(dim=(0, 1, 2), unbiased=False) + 1e-5).rsqrt()
-    scale = gamma * rstd
-    shift = beta - mean * scale
-    plain, _, _ = _fused_conv(dy, w.cuda(), None, stats=False, dgrad=True)
-    wcl = w.permute(0, 2, 3, 1).contiguous().cuda()
-    Uf = torch.empty(lib.cvk_wino4f_weight_floats(Cx, Cd), device="cuda")
-    check(lib.cvk_wino4f_weight_transform(wcl.data_ptr(), Uf.data_ptr(), Cx, Cd, 1, s), "weight")
-    P = lib.cvk_wino4f_stat_partials(N, H, W)
-    for cap in (0, 3):
-        dx = torch.full((N, H, W, Cx), float("nan"), device="cuda")
-        part = torch.full((2 * P * Cp,), float("nan"), device="cuda")
-        check(lib.cvk_conv3x3_wino4f_bnred_part(dy.data_ptr(), Uf.data_ptr(), dx.data_ptr(), N, H, W, Cd, Cx, Cx, yP.data_ptr(), Cp, Cp,
-                                                scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), part.data_ptr(), cap, s), "bnred_part")
-        dbeta, dgamma = torch.empty(Cp, device="cuda"), torch.empty(Cp, device="cuda")
-        check(lib.cvk_colsum_finalize(part.data_ptr(), P, Cp, dbeta.data_ptr(), dgamma.data_ptr(), s), "finalize")
-        torch.cuda.synchronize()
-        assert torch.equal(dx, plain) and torch.isfinite(part).all()
-        dxp = dx[..., :Cp]
-        mask = (yP * scale + shift) > 0
-        gm = torch.where(mask, dxp, torch.zeros_like(dxp)).double()
-        xh = (yP.double() - mean.double()) * rstd.double()
-        want_b, want_g = gm.sum(dim=(0, 1, 2)), (gm * xh).sum(dim=(0, 1, 2))
-        sc = gm.abs().sum(dim=(0, 1, 2)).max().item()
-        assert (dbeta.double() - want_b).abs().max().item() < 2e-5 * sc, cap
-        assert (dgamma.double() - want_g).abs().max().item() < 2e-5 * max(sc, (gm * xh).abs().sum(dim=(0, 1, 2)).max().item()), cap
-    assert lib.cvk_conv3x3_wino4f_bnred_part(dy.data_ptr(), Uf.data_ptr(), dx.data_ptr(), N, H, W, Cd, Cx, Cx, yP.data_ptr(), Cp, 48,
-                                             scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), part.data_ptr(), 0, s) == -1
