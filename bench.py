@@ -366,7 +366,7 @@ def dp_overhead_leg(A, dev, net, lossf, leg, a, plain_step):
            "persistent_workgroups": runner_of(net).persistent_wgs(), "host_enqueue_ms_per_step": round(dp_host, 3),
            "graphed_dp_ms_per_step": round(g_ms, 3), "graphed_dp_host_enqueue_ms_per_step": round(g_host, 4),
            "rccl_env": {k: v for k, v in ddp.rccl_env().items() if v is not None}, "steps": n,
-           "what": "same process, same box: plain step vs the step under ddp.DataParallel on a world-size-1 RCCL group with always_issue=True "
+           "what": "one process (a child of bench.py since round 6), same box: plain step vs the step under ddp.DataParallel on a world-size-1 RCCL group with always_issue=True "
                    "(bucketed all-reduces really issued, CU reservation active), eager and replayed from one captured HIP graph; says what "
                    "data parallel costs before any xGMI link is involved — not a scaling measurement"}
     del gs
