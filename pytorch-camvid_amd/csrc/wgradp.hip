@@ -213,6 +213,7 @@ __global__ __launch_bounds__(64, 2) void k_wgradp_gemm(const float* __restrict__
         } else {
             cvk_wait_vm<0>();
         }
+        __builtin_amdgcn_s_setprio(1);                     // the step's 96 MFMAs ahead of the SIMD's other wave's DMA issue / counted wait (round 6:
         const char* const eblk = smem + 8192 + es * 2048;
         const char* const v0 = smem + ((y + 0) & 3) * 2048;      // padded rows y, y+1, y+2 = image rows y-1, y, y+1 = kernel rows 0, 1, 2
         const char* const v1 = smem + ((y + 1) & 3) * 2048;
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(64, 2) void k_wgradp_gemm(const float* __restrict__
                     acc[2][i * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b2[j], acc[2][i * 4 + j], 0, 0, 0);
                 }
         }
+        __builtin_amdgcn_s_setprio(0);                     //  3.61 -> 3.55 ms for the eight launches, 0.808 -> 0.822 executed)
         if (more) {
             if (last_in_strip) {                           // next strip: refill the ring (one exposed DMA round trip per strip)
                 ++strip;
