@@ -77,7 +77,8 @@ class GraphedStep:
     def _signature(self):
         R = self._runner
         return (id(R.grad_sync), bool(self.net.training), bool(R.bf16), R.wino, R.wino4, R.wino4f, R.wgradp, R.wino2d, R.w2tile_cfg,
-                R.thin, R.persistent_wgs(), getattr(R, "w2d_split", False))
+                R.thin, R.persistent_wgs(), getattr(R, "w2d_split", False), getattr(R, "vplanes", None), getattr(R, "e4p", None),
+                getattr(R, "pool_bnred", None), getattr(R, "bnred_fuse", None))
 
     def replay(self, x=None, t=None):
         """Copy a new batch into the static input buffers (optional) and replay the step.  Returns the (static) loss tensor."""
