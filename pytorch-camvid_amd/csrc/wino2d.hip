@@ -441,7 +441,8 @@ __global__ __launch_bounds__(256) void k_w2d_weight_batch(const W2WJobsDev jobs)
 // 3-9 % slower on every layer, <128, 16, 3> (three per CU) and <256, 16, 2> (two per CU) within +-3 % (tools/bench_conv.py w2d).
 // Tail: the tiles of the last, partial round of workgroups (ids >= split_start) are cut into f K-ranges, one workgroup
 // each; range p writes plane p of D (plane stride part_stride) and the output transform adds the planes in a fixed order.
-template <int BM, int BK, int NSTG, int WPS>      // tile rows, K slice (floats), LDS stages, waves per SIMD the kernel is built for
+template <int BM, int BK, int NSTG, int WPS, int ABL = 0>      // tile rows, K slice (floats), LDS stages, waves per SIMD the kernel is built for;
+// ABL (experiments build only, WRONG results): 1 no barrier, 2 no DMA in the loop, 3 no stores, 4 no LDS reads, 5 MFMA only, 6 every DMA re-reads the tile's first slice (cache-hot)
 __global__ __launch_bounds__(BM * 2, WPS) void k_w2d_gemm(const float* __restrict__ A, const float* __restrict__ B,
                                                          float* __restrict__ D, int T, int Tpad, int Nn, int K, int ldd,
                                                          int tilesM, int tilesN, int split_start, int f, size_t part_stride, int stagger) {
@@ -516,9 +517,12 @@ __global__ __launch_bounds__(BM * 2, WPS) void k_w2d_gemm(const float* __restric
     for (int d = 0; d < NSTG - 1; ++d) issue(min(kb + d, ke - 1), d);
     int buf = 0;
     for (int ks = kb; ks < ke; ++ks) {
-        cvk_wait_vm<(NSTG - 2) * PPW>();                  // this wave's pieces of slice ks (later slices may be in flight)
-        cvk_lds_retire_barrier();                         // slice ks complete; stage of slice ks-1 free (its reads drained)
-        issue(min(ks + NSTG - 1, ke - 1), buf == 0 ? NSTG - 1 : buf - 1);      // (buf + NSTG - 1) % NSTG
+        if (ABL != 2 && ABL != 5) cvk_wait_vm<(NSTG - 2) * PPW>();                  // this wave's pieces of slice ks (later slices may be in flight)
+        if (ABL != 1 && ABL != 5) cvk_lds_retire_barrier();                         // slice ks complete; stage of slice ks-1 free (its reads drained)
+        // (buf + NSTG - 1) % NSTG.  Two stages: every wait above is vmcnt(0), so the last slice simply issues nothing (round 6; before, it
+        // re-read itself to keep the count uniform: one slice of redundant DMA per tile — 1/8 of the tile's traffic at K = 256 — and the
+        // stores below waited for it to land)
+        if (ABL != 2 && ABL != 5 && (NSTG > 2 || ks + 1 < ke)) issue(ABL == 6 ? kb : min(ks + NSTG - 1, ke - 1), buf == 0 ? NSTG - 1 : buf - 1);
         // round 6: the wave is in its MFMA phase until the end of the slice — raise its priority over the co-resident workgroup's waves that are
         // issuing DMA / waiting at their barrier (interleaved A/B on one box: 6.80 -> 6.75 ms for the 26 launches, 0.7186 -> 0.7235 executed)
         __builtin_amdgcn_s_setprio(1);
@@ -527,9 +531,15 @@ __global__ __launch_bounds__(BM * 2, WPS) void k_w2d_gemm(const float* __restric
         for (int s = 0; s < NS; ++s) {
             f32x4 a[2], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(st + ((a_off + i * 32 * ROWB) ^ (s << 5)));
+            for (int i = 0; i < 2; ++i) {
+                if (ABL == 4 || ABL == 5) { a[i] = f32x4{acc[i][0][0], acc[i][0][1], 1.f, 2.f}; asm volatile("" : "+v"(a[i])); }
+                else a[i] = *reinterpret_cast<const f32x4*>(st + ((a_off + i * 32 * ROWB) ^ (s << 5)));
+            }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4*>(st + ((b_off + j * 32 * ROWB) ^ (s << 5)));
+            for (int j = 0; j < 2; ++j) {
+                if (ABL == 4 || ABL == 5) { b[j] = f32x4{acc[0][j][2], acc[0][j][3], 1.f, 2.f}; asm volatile("" : "+v"(b[j])); }
+                else b[j] = *reinterpret_cast<const f32x4*>(st + ((b_off + j * 32 * ROWB) ^ (s << 5)));
+            }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -542,6 +552,23 @@ __global__ __launch_bounds__(BM * 2, WPS) void k_w2d_gemm(const float* __restric
         buf = buf == NSTG - 1 ? 0 : buf + 1;
     }
     cvk_wait_vm<0>();                                     // the redundant tail DMAs land before the workgroup's LDS is released
+    // Stores.  Full-width tiles (all of this launch's when Nn is a multiple of 128) go out as raw buffer stores: the row bound is the
+    // descriptor's range check (row >= T -> byte offset >= T * ldd * 4 -> dropped by the hardware) and the register's row offset a
+    // scalar, so a store costs no vector instruction besides itself (the checked form below: a compare, a mask and a 64-bit add each).
+    if (ABL != 3 && col0 + W2_BN <= Nn && ((size_t)T + BM) * (size_t)ldd * 4 < ((size_t)1 << 32)) {
+        const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)D, 0, (int)((size_t)T * ldd * 4), 0x00020000);
+        const unsigned voff = (unsigned)(((row0 + wm * 64 + 4 * h) * ldd + col0 + wn * 64 + r) * 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const unsigned soff = (unsigned)((i * 32 + (e & 3) + 8 * (e >> 2)) * ldd * 4);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][e]), dr, voff + j * 128, soff, 0);
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -550,7 +577,7 @@ __global__ __launch_bounds__(BM * 2, WPS) void k_w2d_gemm(const float* __restric
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = row0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row < T && col < Nn) D[(size_t)row * ldd + col] = acc[i][j][e];
+                if (ABL == 3 ? (row < T && col < Nn && acc[i][j][e] == 123.456f) : (row < T && col < Nn)) D[(size_t)row * ldd + col] = acc[i][j][e];
             }
         }
 }
@@ -1039,6 +1066,18 @@ static int w2i_gemm(int mt, const char* who, const float* V, const float* U, flo
     }
     const int no_stagger = cvk_knob("CVK_W2D_NO_STAGGER", 0);          // experiments build: A/B of the staggered start
     const int stagger = (!no_stagger && (int)grid.x >= 2 * cus && p.split_start >= 2 * cus) ? cus : 0;
+#ifdef CVK_EXPERIMENTS
+#define CVK_W2D_ABL_GO(A_) hipLaunchKernelGGL((k_w2d_gemm<128, 32, 2, 2, A_>), grid, dim3(256), 0, s, V, U, Mo, T, w2_tpad(T), Cout, Cin, Cout, p.tilesM, p.tilesN, p.split_start, p.f, part_stride, stagger)
+    switch (cvk_knob("CVK_W2D_ABL", 0)) {           // ablation variants (WRONG results): where the GEMM's time goes
+        case 1: CVK_W2D_ABL_GO(1); CVK_LAUNCH_RETURN(who);
+        case 2: CVK_W2D_ABL_GO(2); CVK_LAUNCH_RETURN(who);
+        case 3: CVK_W2D_ABL_GO(3); CVK_LAUNCH_RETURN(who);
+        case 4: CVK_W2D_ABL_GO(4); CVK_LAUNCH_RETURN(who);
+        case 5: CVK_W2D_ABL_GO(5); CVK_LAUNCH_RETURN(who);
+        case 6: CVK_W2D_ABL_GO(6); CVK_LAUNCH_RETURN(who);
+        default: break;
+    }
+#endif
     hipLaunchKernelGGL((k_w2d_gemm<128, 32, 2, 2>), grid, dim3(256), 0, s, V, U, Mo, T, w2_tpad(T), Cout, Cin, Cout, p.tilesM, p.tilesN,
                        p.split_start, p.f, part_stride, stagger);
     CVK_LAUNCH_RETURN(who);

@@ -159,3 +159,34 @@ def test_both_transforms_of_dy_in_one_launch(mt, N, H, W, C):
     check(f("dy_transform_both")(dy.data_ptr(), C, V1.data_ptr(), E1.data_ptr(), N, H, W, C, _s()), "both")
     torch.cuda.synchronize()
     assert torch.equal(V1[:n], V0[:n]) and torch.equal(E1[:n], E0[:n])
+
+
+@pytest.mark.parametrize("T,Cin,Cout", [(160, 64, 256), (2400, 128, 128), (20, 512, 384), (300, 32, 192)])
+def test_gemm_store_paths_keep_to_their_plane(T, Cin, Cout):
+    """Round 6: full-width tiles of k_w2d_gemm leave as raw buffer stores whose row bound (row < T) is the descriptor's range check.  Raw C-ABI
+    call with ragged T: every plane equals the fp64 product, rows T.. of the last 128-row tile never reach the next plane (a guard band behind
+    the product planes stays untouched), and two launches agree bitwise.  Cout = 192: the checked form for the ragged column tile."""
+    lib, check = _lib()
+    nx = 64
+    g = torch.Generator().manual_seed(T + Cin + Cout)
+    Tp = lib.cvk_w2d_tpad(T)
+    ks = lib.cvk_w6_ksplit(T, Cin, Cout)
+    V = torch.zeros(nx, Tp, Cin)
+    V[:, :T] = torch.randn(nx, T, Cin, generator=g)
+    U = torch.randn(nx, Cout, Cin, generator=g) * 0.1
+    Vd = torch.cat([V.reshape(-1), torch.zeros(128)]).cuda()
+    Ud = U.cuda()
+    guard = 4096
+    out = []
+    for _ in range(2):
+        Mo = torch.zeros(ks * nx * T * Cout + guard, device="cuda")       # (parts 1.. exist for the tail tiles only: zero elsewhere)
+        Mo[-guard:] = -7.0
+        check(lib.cvk_w6_gemm(Vd.data_ptr(), Ud.data_ptr(), Mo.data_ptr(), T, Cin, Cout, _s()), "gemm")
+        torch.cuda.synchronize()
+        assert (Mo[-guard:] == -7.0).all()
+        out.append(Mo[:-guard].reshape(ks, nx, T, Cout).cpu())
+    assert torch.equal(out[0], out[1])
+    got = out[0].double().sum(0)                         # the K-split parts of the tail tiles add up in the output transform
+    ref = torch.einsum("xtk,xck->xtc", V[:, :T].double(), U.double())
+    per_plane = (got - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)
+    assert per_plane.max().item() < 2e-6, per_plane.max().item()
