@@ -442,7 +442,8 @@ __global__ __launch_bounds__(256) void k_w2d_weight_batch(const W2WJobsDev jobs)
 // Tail: the tiles of the last, partial round of workgroups (ids >= split_start) are cut into f K-ranges, one workgroup
 // each; range p writes plane p of D (plane stride part_stride) and the output transform adds the planes in a fixed order.
 template <int BM, int BK, int NSTG, int WPS, int ABL = 0>      // tile rows, K slice (floats), LDS stages, waves per SIMD the kernel is built for;
-// ABL (experiments build only, WRONG results): 1 no barrier, 2 no DMA in the loop, 3 no stores, 4 no LDS reads, 5 MFMA only, 6 every DMA re-reads the tile's first slice (cache-hot)
+// ABL (experiments build only, WRONG results): 1 no barrier, 2 no DMA in the loop, 3 no stores, 4 no LDS reads, 5 MFMA only, 6 every DMA re-reads the tile's first slice (cache-hot);
+// 8, 10, 11, 12 (correct results): other placements of the DMA issue inside the slice
 __global__ __launch_bounds__(BM * 2, WPS) void k_w2d_gemm(const float* __restrict__ A, const float* __restrict__ B,
                                                          float* __restrict__ D, int T, int Tpad, int Nn, int K, int ldd,
                                                          int tilesM, int tilesN, int split_start, int f, size_t part_stride, int stagger) {
@@ -522,7 +523,14 @@ __global__ __launch_bounds__(BM * 2, WPS) void k_w2d_gemm(const float* __restric
         // (buf + NSTG - 1) % NSTG.  Two stages: every wait above is vmcnt(0), so the last slice simply issues nothing (round 6; before, it
         // re-read itself to keep the count uniform: one slice of redundant DMA per tile — 1/8 of the tile's traffic at K = 256 — and the
         // stores below waited for it to land)
-        if (ABL != 2 && ABL != 5 && (NSTG > 2 || ks + 1 < ke)) issue(ABL == 6 ? kb : min(ks + NSTG - 1, ke - 1), buf == 0 ? NSTG - 1 : buf - 1);
+        const bool more = NSTG > 2 || ks + 1 < ke;
+        const int ksn = ABL == 6 ? kb : min(ks + NSTG - 1, ke - 1), bufn = buf == 0 ? NSTG - 1 : buf - 1;
+        // Round 6: the slice's DMA pieces are NOT issued here in one burst (ABL 12 keeps that form): a wave issues in order, and eight DMA instructions
+        // ahead of the first fragment reads kept its MFMAs waiting for their issue plus the LDS latency.  Now the reads of group 0 go first, half
+        // of the pieces follow (their issue covers the reads' latency), the other half after the reads of group 1: -1.2 ... -2.4 % on the 26
+        // launches of the headline step (tools/bench_w2d_gemm.py, two boxes; two pieces per group and all eight after group 0's reads were tried too).
+        constexpr bool SPLIT_ISSUE = PPW % 2 == 0 && NS >= 2 && !(ABL == 2 || ABL == 5 || ABL == 8 || ABL == 10 || ABL == 11 || ABL == 12);
+        if ((ABL == 12 || (!SPLIT_ISSUE && ABL != 2 && ABL != 5 && ABL < 8)) && more) issue(ksn, bufn);
         // round 6: the wave is in its MFMA phase until the end of the slice — raise its priority over the co-resident workgroup's waves that are
         // issuing DMA / waiting at their barrier (interleaved A/B on one box: 6.80 -> 6.75 ms for the 26 launches, 0.7186 -> 0.7235 executed)
         __builtin_amdgcn_s_setprio(1);
@@ -539,6 +547,23 @@ __global__ __launch_bounds__(BM * 2, WPS) void k_w2d_gemm(const float* __restric
             for (int j = 0; j < 2; ++j) {
                 if (ABL == 4 || ABL == 5) { b[j] = f32x4{acc[0][j][2], acc[0][j][3], 1.f, 2.f}; asm volatile("" : "+v"(b[j])); }
                 else b[j] = *reinterpret_cast<const f32x4*>(st + ((b_off + j * 32 * ROWB) ^ (s << 5)));
+            }
+            // ABL 8 / 10 / 11 / 12 (correct results): other placements of the slice's DMA pieces (two per group / all after group 0's reads / 2+3+3 / burst at the top)
+            if (ABL == 8 && more) {
+#pragma unroll
+                for (int q = 2 * s; q < 2 * s + 2; ++q) cvk_dma16(src[q] + ksn * BK, smem_addr + bufn * STAGE + (wave * PPW + q) * 1024);
+            }
+            if (ABL == 10 && more && s == 0) {
+#pragma unroll
+                for (int q = 0; q < PPW; ++q) cvk_dma16(src[q] + ksn * BK, smem_addr + bufn * STAGE + (wave * PPW + q) * 1024);
+            }
+            if (ABL == 11 && more && s < 3) {
+#pragma unroll
+                for (int q = (s == 0 ? 0 : 3 * s - 1); q < 3 * s + 2; ++q) cvk_dma16(src[q] + ksn * BK, smem_addr + bufn * STAGE + (wave * PPW + q) * 1024);
+            }
+            if (SPLIT_ISSUE && more && s < 2) {
+#pragma unroll
+                for (int q = s * (PPW / 2); q < (s + 1) * (PPW / 2); ++q) cvk_dma16(src[q] + ksn * BK, smem_addr + bufn * STAGE + (wave * PPW + q) * 1024);
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
@@ -733,6 +758,9 @@ __global__ __launch_bounds__(256) void k_w2d_dy_both(const float* __restrict__ D
 // ds_read_b64 at depth row 2q + h delivers a lane's A values of both row blocks, another its B values: 32 reads per 64
 // MFMAs, and the results of a lane are column pairs (8-byte stores).  The depth is cut into f ranges (grid.y) when the
 // 36 * tiles workgroups alone would not fill the chip; the planes are added by k_w2d_wgrad_out in a fixed order.
+#ifndef CVK_TN_SPLIT_ISSUE
+#define CVK_TN_SPLIT_ISSUE 1
+#endif
 __global__ __launch_bounds__(256, 2) void k_w2d_gemm_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                        float* __restrict__ D, int Kp, int Mm, int Nn, int tilesM, int tilesN,
                                                        int f, int NX) {
@@ -782,13 +810,19 @@ __global__ __launch_bounds__(256, 2) void k_w2d_gemm_tn(const float* __restrict_
     for (int ks = kb; ks < ke; ++ks) {
         cvk_wait_vm<0>();
         cvk_lds_retire_barrier();
-        issue(min(ks + 1, ke - 1), buf ^ 1);
+        const int ksn = min(ks + 1, ke - 1);
+        if (!CVK_TN_SPLIT_ISSUE) issue(ksn, buf ^ 1);
         __builtin_amdgcn_s_setprio(1);                   // MFMA phase of the slice (as k_w2d_gemm, round 6: 3.21 -> 3.14 ms for the 13 launches, 0.761 -> 0.778)
         const char* const st = smem + buf * STAGE;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const f32x2 a = *reinterpret_cast<const f32x2*>(st + a_off + q * 1024);
             const f32x2 b = *reinterpret_cast<const f32x2*>(st + b_off + q * 1024);
+            if (CVK_TN_SPLIT_ISSUE && (q == 0 || q == 4)) {          // the next slice's DMA pieces behind the first fragment reads, in two halves (as k_w2d_gemm)
+#pragma unroll
+                for (int p = (q ? PPW / 2 : 0); p < (q ? PPW : PPW / 2); ++p)
+                    cvk_dma16(src[p] + (size_t)ksn * sstep[p], smem_addr + (buf ^ 1) * STAGE + (wave * PPW + p) * 1024);
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1075,6 +1109,10 @@ static int w2i_gemm(int mt, const char* who, const float* V, const float* U, flo
         case 4: CVK_W2D_ABL_GO(4); CVK_LAUNCH_RETURN(who);
         case 5: CVK_W2D_ABL_GO(5); CVK_LAUNCH_RETURN(who);
         case 6: CVK_W2D_ABL_GO(6); CVK_LAUNCH_RETURN(who);
+        case 8: CVK_W2D_ABL_GO(8); CVK_LAUNCH_RETURN(who);
+        case 10: CVK_W2D_ABL_GO(10); CVK_LAUNCH_RETURN(who);
+        case 11: CVK_W2D_ABL_GO(11); CVK_LAUNCH_RETURN(who);
+        case 12: CVK_W2D_ABL_GO(12); CVK_LAUNCH_RETURN(who);
         default: break;
     }
 #endif
