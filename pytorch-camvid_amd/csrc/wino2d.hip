@@ -582,12 +582,12 @@ __global__ __launch_bounds__(BM * 2, WPS) void k_w2d_gemm(const float* __restric
     // scalar, so a store costs no vector instruction besides itself (the checked form below: a compare, a mask and a 64-bit add each).
     if (ABL != 3 && col0 + W2_BN <= Nn && ((size_t)T + BM) * (size_t)ldd * 4 < ((size_t)1 << 32)) {
         const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)D, 0, (int)((size_t)T * ldd * 4), 0x00020000);
-        const unsigned voff = (unsigned)(((row0 + wm * 64 + 4 * h) * ldd + col0 + wn * 64 + r) * 4);
+        const unsigned voff = ((unsigned)(row0 + wm * 64 + 4 * h) * (unsigned)ldd + (unsigned)(col0 + wn * 64 + r)) * 4u;     // < 2^32 by the test above
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const unsigned soff = (unsigned)((i * 32 + (e & 3) + 8 * (e >> 2)) * ldd * 4);
+                const unsigned soff = (unsigned)(i * 32 + (e & 3) + 8 * (e >> 2)) * (unsigned)ldd * 4u;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][e]), dr, voff + j * 128, soff, 0);
