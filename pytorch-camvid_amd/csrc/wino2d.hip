@@ -761,6 +761,7 @@ __global__ __launch_bounds__(256) void k_w2d_dy_both(const float* __restrict__ D
 #ifndef CVK_TN_SPLIT_ISSUE
 #define CVK_TN_SPLIT_ISSUE 1
 #endif
+template <int ABL = 0>       // ABL (experiments build, WRONG results): 1 no barrier, 2 no DMA in the loop, 3 no stores, 4 no LDS reads
 __global__ __launch_bounds__(256, 2) void k_w2d_gemm_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                        float* __restrict__ D, int Kp, int Mm, int Nn, int tilesM, int tilesN,
                                                        int f, int NX) {
@@ -808,17 +809,21 @@ __global__ __launch_bounds__(256, 2) void k_w2d_gemm_tn(const float* __restrict_
     if (kb < ke) issue(kb, 0);
     int buf = 0;
     for (int ks = kb; ks < ke; ++ks) {
-        cvk_wait_vm<0>();
-        cvk_lds_retire_barrier();
-        const int ksn = min(ks + 1, ke - 1);
-        if (!CVK_TN_SPLIT_ISSUE) issue(ksn, buf ^ 1);
+        if (ABL != 2) cvk_wait_vm<0>();
+        if (ABL != 1) cvk_lds_retire_barrier();
+        const int ksn = ABL == 5 ? kb : min(ks + 1, ke - 1);          // ABL 5: every DMA re-reads the first slice (cache-hot)
+        if (!CVK_TN_SPLIT_ISSUE && ABL != 2) issue(ksn, buf ^ 1);
         __builtin_amdgcn_s_setprio(1);                   // MFMA phase of the slice (as k_w2d_gemm, round 6: 3.21 -> 3.14 ms for the 13 launches, 0.761 -> 0.778)
         const char* const st = smem + buf * STAGE;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const f32x2 a = *reinterpret_cast<const f32x2*>(st + a_off + q * 1024);
-            const f32x2 b = *reinterpret_cast<const f32x2*>(st + b_off + q * 1024);
-            if (CVK_TN_SPLIT_ISSUE && (q == 0 || q == 4)) {          // the next slice's DMA pieces behind the first fragment reads, in two halves (as k_w2d_gemm)
+            f32x2 a, b;
+            if (ABL == 4) { a = f32x2{acc[0][0][0], 1.f}; b = f32x2{acc[0][0][1], 2.f}; asm volatile("" : "+v"(a), "+v"(b)); }
+            else {
+                a = *reinterpret_cast<const f32x2*>(st + a_off + q * 1024);
+                b = *reinterpret_cast<const f32x2*>(st + b_off + q * 1024);
+            }
+            if (CVK_TN_SPLIT_ISSUE && ABL != 2 && (q == 0 || q == 4)) {          // the next slice's DMA pieces behind the first fragment reads, in two halves (as k_w2d_gemm)
 #pragma unroll
                 for (int p = (q ? PPW / 2 : 0); p < (q ? PPW : PPW / 2); ++p)
                     cvk_dma16(src[p] + (size_t)ksn * sstep[p], smem_addr + (buf ^ 1) * STAGE + (wave * PPW + p) * 1024);
@@ -838,7 +843,7 @@ __global__ __launch_bounds__(256, 2) void k_w2d_gemm_tn(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int row = tm * 128 + wm * 64 + 2 * ((e & 3) + 8 * (e >> 2) + 4 * h) + i;
-            if (row < Mm) {
+            if (ABL == 3 ? (row < Mm && acc[i][0][e] == 123.456f) : row < Mm) {
                 float* const dp = D + (size_t)row * Nn + col;
                 if (col + 1 < Nn) { const f32x2 v = {acc[i][0][e], acc[i][1][e]}; *reinterpret_cast<f32x2*>(dp) = v; }
                 else if (col < Nn) dp[0] = acc[i][0][e];
@@ -1181,7 +1186,18 @@ static int w2i_gemm_tn(int mt, const char* who, const float* E, const float* V, 
     CVK_CHECK_ARG(cvk_aligned16(E) && cvk_aligned16(V) && cvk_aligned16(P), "%s: pointers must be 16-byte aligned", who);
     const int nx = w2_nx(mt);
     const W2WPlan p = plan_w2d_wgrad(nx, T, Cin_pad, Cout);
-    hipLaunchKernelGGL(k_w2d_gemm_tn, dim3(nx * p.tilesM * p.tilesN * p.f), dim3(256), 0, (hipStream_t)stream, E, Cout, V, Cin_pad, P, p.Tpad,
+#ifdef CVK_EXPERIMENTS
+#define CVK_TN_ABL_GO(A_) hipLaunchKernelGGL(k_w2d_gemm_tn<A_>, dim3(nx * p.tilesM * p.tilesN * p.f), dim3(256), 0, (hipStream_t)stream, E, Cout, V, Cin_pad, P, p.Tpad, Cout, Cin_pad, p.tilesM, p.tilesN, p.f, nx)
+    switch (cvk_knob("CVK_W2D_TN_ABL", 0)) {
+        case 1: CVK_TN_ABL_GO(1); CVK_LAUNCH_RETURN(who);
+        case 2: CVK_TN_ABL_GO(2); CVK_LAUNCH_RETURN(who);
+        case 3: CVK_TN_ABL_GO(3); CVK_LAUNCH_RETURN(who);
+        case 4: CVK_TN_ABL_GO(4); CVK_LAUNCH_RETURN(who);
+        case 5: CVK_TN_ABL_GO(5); CVK_LAUNCH_RETURN(who);
+        default: break;
+    }
+#endif
+    hipLaunchKernelGGL(k_w2d_gemm_tn<0>, dim3(nx * p.tilesM * p.tilesN * p.f), dim3(256), 0, (hipStream_t)stream, E, Cout, V, Cin_pad, P, p.Tpad,
                        Cout, Cin_pad, p.tilesM, p.tilesN, p.f, nx);
     CVK_LAUNCH_RETURN(who);
 }
