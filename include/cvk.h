@@ -544,6 +544,14 @@ int cvk_bn_bwd_dx_bf16(cvk_viewh dout, int dout_f32, const void* y, int ldy, con
 /* MaxPool2d(2,2) backward: dout dense bf16 [N,H/2,W/2,C]; x = the pooled layer's stored input (view); dx (view) is
  * written, or added to when accumulate != 0 */
 int cvk_maxpool2x2_bwd_bf16(const void* dout, cvk_viewh x, cvk_viewh dx, int accumulate, int N, int H, int W, int C, void* stream);
+/* cvk_maxpool2x2_bwd_bf16 that also leaves the partial sums of the producing block's BatchNorm+ReLU backward (reference models/unet.py:12-13 under
+ * nn.MaxPool2d(2,2), unet.py:92; the bf16 twin of cvk_maxpool2x2_bwd_bnred): when the pool directly follows a conv block this pass is the last writer of
+ * the block's output gradient, and it sums g = dx * [ReLU passed] and g * xhat over the STORED (bf16) values on the way — part = float[2]
+ * [cvk_maxpool2x2_bwd_bnred_blocks_bf16(N,H,W,C)][C] for cvk_colsum_finalize; yP [N*H*W][ldp] bf16 = the block's conv output, scale / shift / mean /
+ * rstd its BatchNorm constants (contract of cvk_bn_bwd_reduce_bf16).  C % 8 == 0 and C/8 must divide 256 (blocks() returns 0 otherwise). */
+int cvk_maxpool2x2_bwd_bnred_blocks_bf16(int N, int H, int W, int C);
+int cvk_maxpool2x2_bwd_bnred_bf16(const void* dout, cvk_viewh x, cvk_viewh dx, int accumulate, int N, int H, int W, int C, const void* yP, int ldp,
+                                  const float* scale, const float* shift, const float* mean, const float* rstd, float* part, void* stream);
 /* MaxUnpool2d(2) of bf16 plans (reference models/segnet.py:80,104-116: self.unpool(x, idx, output_size)).  No index tensor is kept:
  * the arg-max of every 2x2 cell is recomputed from x, the stored input of the pooling layer ([N,H,W,C] view; first maximum in scan
  * order, NaN wins — ATen's rule, as cvk_maxpool2x2_bwd_bf16).  FORWARD is cvk_maxpool2x2_bwd_bf16(v, x, out, 0, ...): the pooled

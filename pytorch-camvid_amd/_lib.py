@@ -208,6 +208,8 @@ SIGNATURES = {
     "cvk_bn_bwd_dx_bf16": (c_int, [ViewH, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp,
                                    c_int, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_maxpool2x2_bwd_bf16": (c_int, [c_vp, ViewH, ViewH, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "cvk_maxpool2x2_bwd_bnred_blocks_bf16": (c_int, [c_int, c_int, c_int, c_int]),
+    "cvk_maxpool2x2_bwd_bnred_bf16": (c_int, [c_vp, ViewH, ViewH, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "cvk_maxunpool2x2_bwd_bf16": (c_int, [c_vp, ViewH, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_bilinear_up2_fwd_bf16": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "cvk_bilinear_up2_bwd_bf16": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),

@@ -333,6 +333,125 @@ __global__ void k_pool_bwd_bf16(const __bf16* __restrict__ dout, const __bf16* _
 }
 
 
+// Round 6 (bf16 twin of csrc/pointwise.hip k_pool_scatter_bnred): when the pool directly follows a conv block, this pass is the LAST writer of the
+// block's output gradient and touches every element of it — it then also leaves the partial sums of the block's BatchNorm+ReLU backward reduce pass
+// (k_bnbwd_bf16 MODE 0: g = dx masked by the ReLU, g * xhat) over the STORED (bf16-rounded) gradient: one read of yP is added, the reduce pass's reads of
+// dO and yP and its launch go.  A block owns a contiguous range of cells, a thread a fixed 8-channel vector (256 % (C/8) == 0): partial sums
+// [2][PB][C] for cvk_colsum_finalize, combined in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void k_pool_bwd_bnred_bf16(const __bf16* __restrict__ dout, const __bf16* __restrict__ x, PixMapH xm,
+                                                            __bf16* __restrict__ dx, PixMapH dm, int accumulate, int N, int H, int W, int C,
+                                                            const __bf16* __restrict__ yP, int ldp, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ part, int cpb, int PB) {
+    constexpr int V = 8, U = 2;
+    __shared__ float red[2][256 * V];
+    const int Ho = H / 2, Wo = W / 2, Hc = (H + 1) / 2, Wc = (W + 1) / 2, cvn = C / V;
+    const int ppp = 256 / cvn;
+    const int t = threadIdx.x, cv = t % cvn, pr = t / cvn, c = cv * V;
+    const long total = (long)N * Hc * Wc;
+    const long cbeg = (long)blockIdx.x * cpb, cend = cbeg + cpb < total ? cbeg + cpb : total;
+    const FV<V> sc = load_f32<V>(scale + c), sh = load_f32<V>(shift + c), mu = load_f32<V>(mean + c), rs = load_f32<V>(rstd + c);
+    float s0[V], s1[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    // two cells per iteration, every load of both issued before the first use, the values kept PACKED (four registers per 8-channel vector) until
+    // they are used: one cell per iteration with unpacked vectors (186 registers, a store drain between a cell's stores and the next cell's loads
+    // on the one in-order counter) ran at 2.5 TB/s of its bytes and cost more than the reduce pass it replaces
+    for (long cell0 = cbeg + pr; cell0 < cend; cell0 += (long)U * ppp) {
+        u32x4 gw[U], xw[U][4], ow[U][4], yw[U][4];
+        int64_t doff[U][4];
+        bool live[U], full[U];
+        unsigned inmask[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long cell = cell0 + (long)u * ppp;
+            live[u] = cell < cend;
+            const long cc = live[u] ? cell : cbeg;
+            const int xc = (int)(cc % Wc);
+            const long tq = cc / Wc;
+            const int yc = (int)(tq % Hc), n = (int)(tq / Hc);
+            full[u] = live[u] && yc < Ho && xc < Wo;
+            gw[u] = zero;
+            if (full[u]) gw[u] = *reinterpret_cast<const u32x4*>(dout + (((size_t)n * Ho + yc) * Wo + xc) * C + c);
+            inmask[u] = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int yy = 2 * yc + (k >> 1), xx = 2 * xc + (k & 1);
+                const bool in = live[u] && yy < H && xx < W;
+                inmask[u] |= in ? (1u << k) : 0u;
+                const int m = (n * H + (in ? yy : 2 * yc)) * W + (in ? xx : 2 * xc);
+                doff[u][k] = dm.off(m) + c;
+                xw[u][k] = zero; ow[u][k] = zero; yw[u][k] = zero;
+                if (!in) continue;
+                if (full[u]) xw[u][k] = *reinterpret_cast<const u32x4*>(x + xm.off(m) + c);
+                if (accumulate) ow[u][k] = *reinterpret_cast<const u32x4*>(dx + doff[u][k]);
+                yw[u][k] = *reinterpret_cast<const u32x4*>(yP + (size_t)m * ldp + c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!live[u]) continue;
+            // arg-max per channel: first maximum in scan order, NaN wins (ATen's rule, as k_pool_bwd_bf16); -1: no window (odd edge)
+            int cd[V];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float b0 = bf_lo(xw[u][0][i]), b1 = bf_hi(xw[u][0][i]);
+                int c0 = full[u] ? 0 : -1, c1 = c0;
+#pragma unroll
+                for (int k = 1; k < 4; ++k) {
+                    const float a0 = bf_lo(xw[u][k][i]), a1 = bf_hi(xw[u][k][i]);
+                    if (full[u] && (a0 > b0 || a0 != a0)) { b0 = a0; c0 = k; }
+                    if (full[u] && (a1 > b1 || a1 != a1)) { b1 = a1; c1 = k; }
+                }
+                cd[2 * i] = c0; cd[2 * i + 1] = c1;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!(inmask[u] & (1u << k))) continue;
+                u32x4 w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float r0 = cd[2 * i] == k ? bf_lo(gw[u][i]) : 0.f, r1 = cd[2 * i + 1] == k ? bf_hi(gw[u][i]) : 0.f;
+                    const float o0 = accumulate ? bf_lo(ow[u][k][i]) + r0 : r0, o1 = accumulate ? bf_hi(ow[u][k][i]) + r1 : r1;
+                    w[i] = bf_pack(o0, o1);
+                }
+                *reinterpret_cast<u32x4*>(dx + doff[u][k]) = w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {               // the sums see what was stored: the bf16-rounded gradient
+                    const float st[2] = {bf_lo(w[i]), bf_hi(w[i])};
+                    const float yy2[2] = {bf_lo(yw[u][k][i]), bf_hi(yw[u][k][i])};
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = 2 * i + e;
+                        const float gq = (yy2[e] * sc.v[j] + sh.v[j] > 0.f) ? st[e] : 0.f;
+                        s0[j] += gq;
+                        s1[j] += gq * ((yy2[e] - mu.v[j]) * rs.v[j]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        red[0][t * V + j] = s0[j];
+        red[1][t * V + j] = s1[j];
+    }
+    __syncthreads();
+    if (t < cvn) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float a = 0.f, b = 0.f;
+            for (int p = 0; p < ppp; ++p) {
+                a += red[0][(p * cvn + t) * V + j];
+                b += red[1][(p * cvn + t) * V + j];
+            }
+            part[(size_t)blockIdx.x * C + t * V + j] = a;
+            part[(size_t)(PB + blockIdx.x) * C + t * V + j] = b;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ max unpool backward
 // MaxUnpool2d(2) backward = a gather at the pool's arg-max: dv[cell] = dout[arg-max pixel of the cell].  The arg-max is recomputed from
 // the pooled layer's stored input x exactly as in k_pool_bwd_bf16 (bf16 plans keep no index tensor: the forward unpool is that kernel
@@ -607,6 +726,31 @@ extern "C" int cvk_maxpool2x2_bwd_bf16(const void* dout, cvk_viewh x, cvk_viewh 
     hipLaunchKernelGGL(k_pool_bwd_bf16<8>, dim3(grid_for(cells * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dout,
                        (const __bf16*)x.ptr, make_map(x, H, W), (__bf16*)dx.ptr, make_map(dx, H, W), accumulate, N, H, W, C);
     CVK_LAUNCH_RETURN("cvk_maxpool2x2_bwd_bf16");
+}
+
+// blocks (= partial sums per channel) of cvk_maxpool2x2_bwd_bnred_bf16; 0: the shape is not supported (C/8 must divide 256)
+extern "C" int cvk_maxpool2x2_bwd_bnred_blocks_bf16(int N, int H, int W, int C) {
+    if (N <= 0 || H < 2 || W < 2 || C < 8 || C % 8 || C > 2048 || 256 % (C / 8)) return 0;
+    const long cells = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
+    const int ppp = 256 / (C / 8);
+    const long want = (cells + 4L * ppp - 1) / (4L * ppp);          // >= 4 cells per thread
+    return (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+}
+
+extern "C" int cvk_maxpool2x2_bwd_bnred_bf16(const void* dout, cvk_viewh x, cvk_viewh dx, int accumulate, int N, int H, int W, int C, const void* yP,
+                                             int ldp, const float* scale, const float* shift, const float* mean, const float* rstd, float* part,
+                                             void* stream) {
+    CVK_CHECK_ARG(dout && x.ptr && dx.ptr && yP && scale && shift && mean && rstd && part, "cvk_maxpool2x2_bwd_bnred_bf16: null pointer");
+    const int PB = cvk_maxpool2x2_bwd_bnred_blocks_bf16(N, H, W, C);
+    CVK_CHECK_ARG(PB > 0 && ldp >= C && ldp % 8 == 0, "cvk_maxpool2x2_bwd_bnred_bf16: unsupported shape (C=%d: C/8 must divide 256)", C);
+    CVK_CHECK_ARG(cvk_aligned16(dout) && viewok(x, 8, false) && viewok(dx, 8, false) && cvk_aligned16(yP) && cvk_aligned16(scale) && cvk_aligned16(shift) &&
+                  cvk_aligned16(mean) && cvk_aligned16(rstd), "cvk_maxpool2x2_bwd_bnred_bf16: misaligned pointer or view");
+    CVK_CHECK_ARG((long)N * H * W < (1L << 31), "cvk_maxpool2x2_bwd_bnred_bf16: more than 2^31 pixels");
+    const long cells = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
+    const int cpb = (int)((cells + PB - 1) / PB);
+    hipLaunchKernelGGL(k_pool_bwd_bnred_bf16, dim3(PB), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dout, (const __bf16*)x.ptr, make_map(x, H, W),
+                       (__bf16*)dx.ptr, make_map(dx, H, W), accumulate, N, H, W, C, (const __bf16*)yP, ldp, scale, shift, mean, rstd, part, cpb, PB);
+    CVK_LAUNCH_RETURN("cvk_maxpool2x2_bwd_bnred_bf16");
 }
 
 extern "C" int cvk_maxunpool2x2_bwd_bf16(const void* dout, cvk_viewh x, void* dv, int N, int H, int W, int C, void* stream) {

@@ -1111,10 +1111,15 @@ class ConvBnRelu(Op):
         esz = 4.0 if do_f32 else 2.0
         PB = lib.cvk_bn_bwd_blocks_bf16(M)
         part = _empty(2 * PB * C, dev)
-        _timed(R, "k_bnbwd_bf16<reduce>", (esz + 2.0) * M * C, lambda: check(
-            lib.cvk_bn_bwd_reduce_bf16(dO, do_f32, y.data_ptr(), C, psc, psh, pm, pr, part.data_ptr(), N, H, W, C, s),
-            "cvk_bn_bwd_reduce_bf16"), "byte")
-        check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, gbe, gg, s), "cvk_colsum_finalize")   # dbeta, dgamma
+        pre = st.bnred.pop(self.idx, None)
+        if pre is not None:     # the pass that wrote dO last summed it already (csrc/elem_bf16.hip k_pool_bwd_bnred_bf16)
+            check(lib.cvk_colsum_finalize(pre[0].data_ptr(), pre[1], C, gbe, gg, s), "cvk_colsum_finalize")
+        else:
+            _timed(R, "k_bnbwd_bf16<reduce>", (esz + 2.0) * M * C, lambda: check(
+                lib.cvk_bn_bwd_reduce_bf16(dO, do_f32, y.data_ptr(), C, psc, psh, pm, pr, part.data_ptr(), N, H, W, C, s),
+                "cvk_bn_bwd_reduce_bf16"), "byte")
+            check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, gbe, gg, s), "cvk_colsum_finalize")   # dbeta, dgamma
+        del pre
         ld_dy = max(32, C)                              # the data-grad GEMM reads dy in 32-channel K slices
         dy = torch.empty(M * ld_dy, device=dev, dtype=_BF16)
         _timed(R, "k_bnbwd_bf16<dx>", (esz + 4.0) * M * C, lambda: check(
@@ -1201,21 +1206,36 @@ class MaxPool(Op):
                 st.grad[v.buf.id] = torch.zeros_like(X)
             else:
                 st.grad[v.buf.id] = torch.empty_like(X)
+        # round 6: when the pool directly follows a conv block (its BN-apply pass pooled) this pass is the LAST writer of the block's output
+        # gradient — the consumers behind it in the plan ran earlier in backward — and touches every element of it: it then also leaves the block's
+        # BatchNorm-backward sums (csrc/pointwise.hip k_pool_scatter_bnred, csrc/elem_bf16.hip k_pool_bwd_bnred_bf16) and the block's reduce pass is
+        # not launched
+        prod = st.plan.ops[self.producer_idx] if (self.fused and self.producer_idx >= 0) else None
+        fuse_sums = (prod is not None and st.training and R.bnred_fuse and R.pool_bnred and isinstance(prod, ConvBnRelu) and prod.idx in st.saved
+                     and prod.idx not in st.bnred and prod.dst.buf is v.buf
+                     and (prod.dst.c0, prod.dst.C, prod.dst.y0, prod.dst.x0, prod.dst.H, prod.dst.W) == (v.c0, v.C, v.y0, v.x0, v.H, v.W)
+                     and prod.cout == v.C and st.plan.last_gradient_writer(v, prod.idx) == self.idx)
         if st.plan.bf16:
+            PBp = R.lib.cvk_maxpool2x2_bwd_bnred_blocks_bf16(v.buf.N, v.H, v.W, v.C) if fuse_sums else 0
+            if PBp > 0:
+                py, pbnp = st.saved[prod.idx][0], st.saved[prod.idx][1]
+                part = _empty(2 * PBp * v.C, X.device)
+                rc = _timed(R, "k_pool_bwd_bf16(+bnred)", (2.0 * 0.25 + 2.0 + (4.0 if acc else 2.0) + 2.0) * v.buf.N * v.H * v.W * v.C,
+                            lambda: R.lib.cvk_maxpool2x2_bwd_bnred_bf16(
+                                st.grad[d.id].data_ptr(), v.hview(X), v.hview(st.grad[v.buf.id]), 1 if acc else 0, v.buf.N, v.H, v.W, v.C,
+                                py.data_ptr(), v.C, pbnp.data_ptr() + 8 * v.C, pbnp.data_ptr() + 12 * v.C, pbnp.data_ptr(), pbnp.data_ptr() + 4 * v.C,
+                                part.data_ptr(), st.stream), "byte")
+                if rc == 0:
+                    st.bnred[prod.idx] = (part, PBp)
+                    st.grad.pop(d.id)
+                    return
             _timed(R, "k_pool_bwd_bf16", (2.0 * 0.25 + 2.0 + (4.0 if acc else 2.0)) * v.buf.N * v.H * v.W * v.C, lambda: check(
                 R.lib.cvk_maxpool2x2_bwd_bf16(st.grad[d.id].data_ptr(), v.hview(X), v.hview(st.grad[v.buf.id]), 1 if acc else 0,
                                               v.buf.N, v.H, v.W, v.C, st.stream), "cvk_maxpool2x2_bwd_bf16"), "byte")
             st.grad.pop(d.id)
             return
         code = st.saved.get(self.idx)
-        # round 6: when the pool directly follows a conv block (its BN-apply pass pooled) this pass is the LAST writer of the block's output
-        # gradient — the consumers behind it in the plan ran earlier in backward — and touches every element of it: it then also leaves the block's
-        # BatchNorm-backward sums (csrc/pointwise.hip k_pool_scatter_bnred) and the block's reduce pass is not launched
-        prod = st.plan.ops[self.producer_idx] if (self.fused and self.producer_idx >= 0) else None
-        if (prod is not None and st.training and R.bnred_fuse and R.pool_bnred and isinstance(prod, ConvBnRelu) and prod.idx in st.saved
-                and prod.idx not in st.bnred and prod.dst.buf is v.buf and (prod.dst.c0, prod.dst.C, prod.dst.y0, prod.dst.x0, prod.dst.H, prod.dst.W) == (v.c0, v.C, v.y0, v.x0, v.H, v.W)
-                and pad4(prod.cout) == prod.cout == v.C
-                and st.plan.last_gradient_writer(v, prod.idx) == self.idx):
+        if fuse_sums and pad4(prod.cout) == prod.cout:
             PBp = R.lib.cvk_maxpool2x2_bwd_bnred_blocks(v.buf.N, v.H, v.W, v.C)
             if PBp > 0:
                 py, pbnp = st.saved[prod.idx][0], st.saved[prod.idx][1]

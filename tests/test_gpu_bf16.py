@@ -272,6 +272,97 @@ def test_unpool_bf16_is_exact(shape):
     assert torch.equal(dv.float().cpu(), vv.grad.permute(0, 2, 3, 1))
 
 
+@pytest.mark.parametrize("N,H,W,C,strided", [(2, 8, 12, 64, False), (1, 9, 7, 64, True), (2, 10, 6, 128, True), (1, 6, 8, 256, False), (1, 22, 30, 512, False)])
+def test_pool_backward_bf16_leaves_the_producers_batchnorm_sums(N, H, W, C, strided):
+    """Round 6: cvk_maxpool2x2_bwd_bnred_bf16 = nn.MaxPool2d(2,2) backward of bf16 plans (models/unet.py:92) that also leaves the partial sums of the
+    producing block's BatchNorm+ReLU backward (unet.py:12-13) over the STORED gradient.  dx is bitwise the plain pass's (overwrite and accumulate, odd
+    sizes, a channel slice of a wider concat buffer), and d(beta), d(gamma) from the partials match cvk_bn_bwd_reduce_bf16 on that dx (other summation
+    order: 2e-5 / 6e-5 of the sums' scale) and fp64."""
+    from pytorch_camvid_amd import _lib
+    from pytorch_camvid_amd._lib import check, ViewH
+    lib = _lib.load()
+    s = stream()
+    g = torch.Generator().manual_seed(N * 100 + H + W + C)
+    ld = 2 * C if strided else C
+    c0 = C if strided else 0
+    xb = torch.relu(torch.randn(N, H, W, ld, generator=g)).to(BF).to(dev())          # post-ReLU activations (ties at 0 included)
+    yP = (torch.randn(N * H * W, C, generator=g) * 1.3 + 0.2).to(BF).to(dev())
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev()), (torch.randn(C, generator=g) * 0.3).to(dev())
+    yf = yP.float()
+    mean, rstd = yf.mean(0), (yf.var(0, unbiased=False) + 1e-5).rsqrt()
+    scale = gamma * rstd
+    shift = beta - mean * scale
+    r = torch.randn(N, H // 2, W // 2, C, generator=g).to(BF).to(dev())
+
+    def view(t):
+        return ViewH(t.data_ptr() + 2 * c0, H * W * ld, W * ld, ld)
+    PB = lib.cvk_maxpool2x2_bwd_bnred_blocks_bf16(N, H, W, C)
+    assert PB > 0
+    for acc in (0, 1):
+        base = torch.randn(N, H, W, ld, generator=g).to(BF).to(dev())
+        dx0, dx1 = base.clone(), base.clone()
+        check(lib.cvk_maxpool2x2_bwd_bf16(r.data_ptr(), view(xb), view(dx0), acc, N, H, W, C, s))
+        part = torch.full((2 * PB * C,), float("nan"), device=dev())
+        check(lib.cvk_maxpool2x2_bwd_bnred_bf16(r.data_ptr(), view(xb), view(dx1), acc, N, H, W, C, yP.data_ptr(), C, scale.data_ptr(), shift.data_ptr(),
+                                                mean.data_ptr(), rstd.data_ptr(), part.data_ptr(), s))
+        torch.cuda.synchronize()
+        assert torch.equal(dx0.view(torch.int16), dx1.view(torch.int16)), acc
+        assert torch.isfinite(part).all()
+        db, dg = torch.empty(C, device=dev()), torch.empty(C, device=dev())
+        check(lib.cvk_colsum_finalize(part.data_ptr(), PB, C, db.data_ptr(), dg.data_ptr(), s))
+        dO = dx0[..., c0:c0 + C].reshape(-1, C).double()
+        y64 = yP.double()
+        gq = torch.where(yf * scale + shift > 0, dO, torch.zeros_like(dO))      # the ReLU mask as the device evaluates it (fp32)
+        want_b = gq.sum(0)
+        want_g = (gq * (y64 - mean.double()) * rstd.double()).sum(0)
+        sb = gq.abs().sum(0).clamp_min(1.0)
+        assert ((db.double() - want_b).abs() / sb).max().item() < 2e-5
+        assert ((dg.double() - want_g).abs() / sb).max().item() < 6e-5
+        # and against the standalone reduce pass on the same stored gradient
+        PBr = lib.cvk_bn_bwd_blocks_bf16(N * H * W)
+        part2 = torch.empty(2 * PBr * C, device=dev())
+        dOc = dx0[..., c0:c0 + C].contiguous()
+        check(lib.cvk_bn_bwd_reduce_bf16(ViewH(dOc.data_ptr(), H * W * C, W * C, C), 0, yP.data_ptr(), C, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                         rstd.data_ptr(), part2.data_ptr(), N, H, W, C, s))
+        db2, dg2 = torch.empty(C, device=dev()), torch.empty(C, device=dev())
+        check(lib.cvk_colsum_finalize(part2.data_ptr(), PBr, C, db2.data_ptr(), dg2.data_ptr(), s))
+        torch.cuda.synchronize()
+        assert ((db - db2).abs().double() / sb).max().item() < 2e-5 and ((dg - dg2).abs().double() / sb).max().item() < 6e-5
+    assert lib.cvk_maxpool2x2_bwd_bnred_blocks_bf16(1, 8, 8, 24) == 0 and lib.cvk_maxpool2x2_bwd_bnred_blocks_bf16(1, 8, 8, 96) == 0    # C/8 must divide 256
+
+
+def test_unet_bf16_pool_sums_fusion_runs_and_changes_nothing_else(monkeypatch):
+    """Engine level: in bf16 plans the four pooled blocks of the UNet (models/unet.py:95-101) get their BatchNorm-backward sums from the pool's backward
+    pass (4 fused launches, 19 instead of 23 reduce passes); with CVK_POOL_BNRED=0 the plain passes run.  Forward identical; the sums differ by their
+    summation order only — a bf16 ulp of dy flips here and there, and this small bf16 network amplifies that like any other rounding-level change: the
+    gradients agree within what the emulation (oracle/bf16_emul.py) itself moves under a 1e-6 input perturbation (drift.json bf16_emul_noise: the norms'
+    relative change; the relative L2 difference measured here is held to the same numbers)."""
+    from pytorch_camvid_amd import engine
+
+    def run():
+        engine.PROF = []
+        try:
+            net, out, loss = _run_unet_bf16((2, 96, 128))
+            torch.cuda.synchronize()
+            names = [p[0] for p in engine.PROF]
+        finally:
+            engine.PROF = None
+        return net, out, loss, names
+    net1, out1, loss1, n1 = run()
+    monkeypatch.setenv("CVK_POOL_BNRED", "0")
+    net0, out0, loss0, n0 = run()
+    assert n1.count("k_pool_bwd_bf16(+bnred)") == 4 and n1.count("k_pool_bwd_bf16") == 0 and n1.count("k_bnbwd_bf16<reduce>") == 19
+    assert n0.count("k_pool_bwd_bf16(+bnred)") == 0 and n0.count("k_pool_bwd_bf16") == 4 and n0.count("k_bnbwd_bf16<reduce>") == 23
+    assert loss1 == loss0 and torch.equal(out1, out0)
+    rels = {k: float((a.grad.double() - b.grad.double()).norm() / b.grad.double().norm().clamp_min(1e-30))
+            for (k, a), (_, b) in zip(net1.named_parameters(), net0.named_parameters())
+            if not (k.endswith("conv.0.bias") or k.endswith("conv.bias"))}        # a conv bias under BatchNorm has gradient 0: what is stored is rounding noise
+    worst = max(rels, key=rels.get)
+    print("pool-sum fusion on/off, per-tensor relative L2 of the gradients: median %.2e, max %.2e (%s)" % (float(np.median(list(rels.values()))), rels[worst], worst))
+    noise = json.load(open(os.path.join(G, "drift.json")))["bf16_emul_noise"]["unet_2x96x128"]
+    assert float(np.median(list(rels.values()))) <= noise["grad_norm_rel_median"] and rels[worst] <= noise["grad_norm_rel_max"], (worst, rels[worst])
+
+
 def test_unet_bf16_input_gradient():
     """x.requires_grad in bf16 mode (round 4): the stem's data-grad is kept like every other dX (bf16) and returned as fp32.  Against
     the emulation fixture: the norm of x.grad within bf16_emul_tolerance (element-wise the graph is chaotic under bf16 rounding, see
