@@ -591,7 +591,7 @@ def main():
     extra = None
     if world == 1 and headline and not a.no_extra_configs:
         extra = []
-        es, ew = max(3, min(a.steps, 10)), max(2, min(a.warmup, 3))
+        es, ew = max(3, min(a.steps, 30)), max(2, min(a.warmup, 5))       # (round 6: 30 / 5 instead of 10 / 3 — the short legs read 0.5-0.9 % below a run of their own)
         for (m, b, hh, ww, prec, sp3) in (("unet", 4, 720, 960, "bf16", 0), ("segnet", 8, 360, 480, "fp32", 0),
                                           ("unet", 8, 360, 480, "fp32", 3), ("unet", 8, 360, 480, "fp32", 2)):
             e = run_leg(A, dev, m, b, hh, ww, prec, es, ew, True, split3=sp3)
